@@ -1,0 +1,182 @@
+/* ===========================================================================
+ * interpol_hip.h -- C-ABI of libinterpol_hip.so, the MI355X (gfx950) kernels
+ * behind the torch-interpol hot path.
+ *
+ * The reference (balbasty/torch-interpol @2024_10_08) has no FFI: its operator
+ * seam is the Python module interpol/pushpull.py.  Each entry point below is
+ * what a binding for that seam would call; the reference interface it
+ * replaces is cited on every declaration.  INTEGRATION.md shows the ctypes
+ * stub a maintainer of the reference would add.
+ *
+ * Conventions
+ *   - plain C types only: device pointers, sizes, element strides, int codes;
+ *   - the caller owns every buffer (inputs, outputs, scratch); the library
+ *     never allocates, frees or retains a pointer, and keeps no global state;
+ *   - kernels are enqueued asynchronously on `stream` (a hipStream_t passed as
+ *     void*; NULL = the default stream); no internal synchronisation;
+ *   - return value: 0 = ok, < 0 = INTERPOL_E_* (invalid argument, nothing
+ *     launched), > 0 = a hipError_t raised by the launch;
+ *   - boundary codes 0..6 = zero, replicate, dct1, dct2, dst1, dst2, dft
+ *     (reference interpol/bounds.py:8-15); spline orders 0..7
+ *     (interpol/splines.py:7-15); extrapolate 0 = no, 1 = yes, 2 = hist
+ *     (interpol/bounds.py:18-21).
+ * =========================================================================== */
+#ifndef INTERPOL_HIP_H
+#define INTERPOL_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define INTERPOL_ABI_VERSION 1
+
+/* storage types of image tensors / coordinate tensors */
+enum {
+    INTERPOL_F32  = 0,   /* float  storage, float math                        */
+    INTERPOL_F64  = 1,   /* double storage, double math (coords must be F64)  */
+    INTERPOL_BF16 = 2,   /* bf16 storage, float math   (coords must be F32)   */
+    INTERPOL_F16  = 3    /* half storage, float math   (coords must be F32)   */
+};
+
+/* error codes (negative) */
+enum {
+    INTERPOL_OK          =  0,
+    INTERPOL_E_DIM       = -1,   /* dim not in 1..3                            */
+    INTERPOL_E_ORDER     = -2,   /* spline order not in 0..7 (splines.py:80)   */
+    INTERPOL_E_BOUND     = -3,   /* bound code not in 0..6                     */
+    INTERPOL_E_DTYPE     = -4,   /* unsupported dtype combination              */
+    INTERPOL_E_SHAPE     = -5,   /* non-positive / too large extent            */
+    INTERPOL_E_NULL      = -6,   /* required pointer is NULL                   */
+    INTERPOL_E_EXTRAP    = -7,   /* extrapolate not in 0..2                    */
+    INTERPOL_E_PREFILTER = -8,   /* prefilter bound dst1/dst2 (coeff.py:243)   */
+    INTERPOL_E_SCRATCH   = -9,   /* scratch buffer too small                   */
+    INTERPOL_E_STRIDE    = -10   /* stride pattern not supported (see below)   */
+};
+
+/* ---------------------------------------------------------------------------
+ * Problem descriptor shared by all sampling operators.
+ *
+ *   "vol"  = the lattice that is INDEXED by the coordinates: the input image of
+ *            pull/grad/hess, the target image of push/count/pushgrad.
+ *            Layout (batch, channel, *vol_shape); any element strides.
+ *   "grid" = the coordinates, layout (batch, *grid_shape, dim); component d
+ *            addresses vol spatial dim d, in voxels (nd.py:44).
+ *   "val"  = the per-sample values: the output of pull/grad/hess, the input of
+ *            push/pushgrad.  Layout (batch, channel, *grid_shape[, dim[, dim]]).
+ *
+ * A batch stride of 0 broadcasts that tensor over the batch (api.py:122-126).
+ * Strides are in ELEMENTS.  Unused trailing entries (dim < 3) are ignored.
+ * Supported patterns (else INTERPOL_E_STRIDE): gather sources (vol of pull/grad/
+ * hess) may have ANY non-negative strides; grid and val must be row-major
+ * contiguous over their spatial (+component) dims with free batch/channel
+ * strides; scatter targets (vol of push/count/pushgrad) must be dense.
+ * One (batch, channel) image of vol must span < 4 GiB (32-bit byte offsets).
+ * --------------------------------------------------------------------------- */
+typedef struct interpol_problem {
+    int32_t abi_version;        /* INTERPOL_ABI_VERSION                        */
+    int32_t dim;                /* D in 1..3                                   */
+    int32_t dtype;              /* INTERPOL_* of vol and val                   */
+    int32_t grid_dtype;         /* INTERPOL_F32 or INTERPOL_F64                */
+    int32_t extrapolate;        /* 0, 1, 2                                     */
+    int32_t bound[3];           /* per spatial dim                             */
+    int32_t order[3];           /* per spatial dim                             */
+    int32_t flags;              /* INTERPOL_FLAG_*                             */
+    int64_t batch;              /* B = max over tensors                        */
+    int64_t channels;           /* C                                           */
+    int64_t vol_shape[3];
+    int64_t grid_shape[3];
+    int64_t vol_stride[5];      /* batch, channel, s0, s1, s2                  */
+    int64_t grid_stride[5];     /* batch, s0, s1, s2, component                */
+    int64_t val_stride[7];      /* batch, channel, s0, s1, s2, d, e            */
+} interpol_problem;
+
+/* flags */
+#define INTERPOL_FLAG_NO_FASTPATH   1   /* force the generic kernels (testing)           */
+#define INTERPOL_FLAG_ACCUMULATE    2   /* push/count/pushgrad: do not zero the target    */
+
+/* --- forward operators -------------------------------------------------------
+ * interpol_pull      replaces pushpull.grid_pull      (interpol/pushpull.py:35-66;
+ *                    nd.pull nd.py:80-143, iso1.pull*d, iso0.pull*d)
+ *                    vol (B,C,*in) , grid (B,*out,D) -> val (B,C,*out)
+ * interpol_push      replaces pushpull.grid_push      (pushpull.py:70-102; nd.push nd.py:146-213)
+ *                    val (B,C,*in) , grid (B,*in,D)  -> vol (B,C,*shape), zero-filled here
+ *                    unless INTERPOL_FLAG_ACCUMULATE
+ * interpol_count     replaces pushpull.grid_count     (pushpull.py:106-142)
+ *                    grid (B,*in,D) -> vol (B,1,*shape)     (p->channels must be 1)
+ * interpol_grad      replaces pushpull.grid_grad      (pushpull.py:146-172; nd.grad nd.py:216-288)
+ *                    vol , grid -> val (B,C,*out,D)
+ * interpol_pushgrad  replaces pushpull.grid_pushgrad  (pushpull.py:176-203; nd.pushgrad nd.py:291-364)
+ *                    val (B,C,*in,D) , grid -> vol (B,C,*shape)
+ * interpol_hess      replaces pushpull.grid_hess      (pushpull.py:207-233; nd.hess nd.py:367-464)
+ *                    vol , grid -> val (B,C,*out,D,D)
+ *
+ * Low-precision scatter: for dtype BF16/F16 the push-type operators need a
+ * float accumulation buffer `scratch` of batch*channels*prod(vol_shape) floats
+ * (scratch_bytes = that * 4); pass NULL/0 for F32/F64.
+ * --------------------------------------------------------------------------- */
+int interpol_pull(const interpol_problem *p, const void *vol, const void *grid, void *val, void *stream);
+int interpol_push(const interpol_problem *p, const void *val, const void *grid, void *vol,
+                  void *scratch, int64_t scratch_bytes, void *stream);
+int interpol_count(const interpol_problem *p, const void *grid, void *vol,
+                   void *scratch, int64_t scratch_bytes, void *stream);
+int interpol_grad(const interpol_problem *p, const void *vol, const void *grid, void *val, void *stream);
+int interpol_pushgrad(const interpol_problem *p, const void *val, const void *grid, void *vol,
+                      void *scratch, int64_t scratch_bytes, void *stream);
+int interpol_hess(const interpol_problem *p, const void *vol, const void *grid, void *val, void *stream);
+
+/* --- fused backward operators -------------------------------------------------
+ * interpol_pull_backward  replaces pushpull.grid_pull_backward (pushpull.py:237-258):
+ *      grad_vol  (B,C,*in)    += push(grad_out)                 if grad_vol  != NULL
+ *      grad_grid (B,*out,D)    = sum_c grad(vol)[c] * grad_out[c] if grad_grid != NULL
+ *   one pass over the grid instead of push + grad + a (B,C,N,D) temporary.
+ *   p->val_stride describes grad_out; grad_vol uses p->vol_stride's layout and is
+ *   zero-filled here unless INTERPOL_FLAG_ACCUMULATE; grad_grid is contiguous (B,*out,D).
+ * interpol_push_backward  replaces pushpull.grid_push_backward (pushpull.py:262-282):
+ *      grad_val  (B,C,*in)     = pull(grad_vol_out)              if grad_val  != NULL
+ *      grad_grid (B,*in,D)     = sum_c grad(grad_vol_out)[c] * val[c] if grad_grid != NULL
+ *   p->vol_stride describes grad_vol_out (the incoming gradient, indexed), p->val_stride
+ *   describes val; grad_val / grad_grid are contiguous.
+ * interpol_count_backward replaces pushpull.grid_count_backward (pushpull.py:286-299):
+ *      grad_grid (B,*in,D)     = sum_c grad(grad_vol_out)[c]
+ * --------------------------------------------------------------------------- */
+int interpol_pull_backward(const interpol_problem *p, const void *grad_out, const void *vol, const void *grid,
+                           void *grad_vol, void *grad_grid, void *scratch, int64_t scratch_bytes, void *stream);
+int interpol_push_backward(const interpol_problem *p, const void *grad_vol_out, const void *val, const void *grid,
+                           void *grad_val, void *grad_grid, void *stream);
+int interpol_count_backward(const interpol_problem *p, const void *grad_vol_out, const void *grid,
+                            void *grad_grid, void *stream);
+
+/* --- prefilter -----------------------------------------------------------------
+ * interpol_spline_filter replaces coeff.spline_coeff (interpol/coeff.py:288-313,
+ * filter coeff.py:258-284): in-place interpolating-coefficient IIR along the
+ * middle axis of a contiguous (outer, n, inner) array.  order 0/1 = no-op.
+ * bound codes as above; dst1/dst2 return INTERPOL_E_PREFILTER (coeff.py:243-244).
+ * --------------------------------------------------------------------------- */
+int interpol_spline_filter(void *data, int32_t dtype, int64_t outer, int64_t n, int64_t inner,
+                           int32_t bound, int32_t order, void *stream);
+
+/* --- host-side helpers (no GPU needed) ------------------------------------------
+ * The exact scalar primitives the kernels use, compiled for the host so they
+ * can be checked without a device:
+ *   interpol_host_bound_index / _sign  = Bound.index / Bound.transform (bounds.py:30-89);
+ *                                        sign returns 2 where the reference returns None
+ *   interpol_host_weight(order, x, which) which = 0 fastweight, 1 fastgrad, 2 fasthess
+ *                                        (splines.py:30-195)
+ * --------------------------------------------------------------------------- */
+int32_t interpol_host_bound_index(int32_t bound, int32_t i, int32_t n);
+int32_t interpol_host_bound_sign(int32_t bound, int32_t i, int32_t n);
+double  interpol_host_weight(int32_t order, double x, int32_t which);
+float   interpol_host_weight_f32(int32_t order, float x, int32_t which);
+
+int32_t     interpol_abi_version(void);
+const char *interpol_error_string(int code);
+/* name of the kernel family the dispatcher would pick for `p` and op
+ * ("pull","push","count","grad","pushgrad","hess"); for tests and profiling. */
+const char *interpol_kernel_name(const interpol_problem *p, const char *op);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* INTERPOL_HIP_H */

@@ -1,0 +1,56 @@
+"""TEST-ONLY kernel table: routes the product's operator seam (interpol.ops) to
+the CPU oracle so that the host logic (shape conventions, alias handling,
+autograd wiring, sharding) can be exercised without a GPU.  Never used by the
+product path."""
+import torch
+
+from oracle import oracle
+
+
+def _t(x, like):
+    return torch.as_tensor(x).to(like.dtype)
+
+
+class OracleKernels:
+    @staticmethod
+    def pull(inp, grid, bound, order, extrapolate):
+        return oracle.grid_pull(inp.detach(), grid.detach(), bound, order, extrapolate)
+
+    @staticmethod
+    def grad(inp, grid, bound, order, extrapolate):
+        return oracle.grid_grad(inp.detach(), grid.detach(), bound, order, extrapolate)
+
+    @staticmethod
+    def hess(inp, grid, bound, order, extrapolate):
+        return oracle.grid_hess(inp.detach(), grid.detach(), bound, order, extrapolate)
+
+    @staticmethod
+    def push(inp, grid, shape, bound, order, extrapolate):
+        return oracle.grid_push(inp.detach(), grid.detach(), shape, bound, order, extrapolate)
+
+    @staticmethod
+    def count(grid, shape, bound, order, extrapolate):
+        return oracle.grid_count(grid.detach(), shape, bound, order, extrapolate)
+
+    @staticmethod
+    def pushgrad(inp, grid, shape, bound, order, extrapolate):
+        return oracle.grid_pushgrad(inp.detach(), grid.detach(), shape, bound, order, extrapolate)
+
+    @staticmethod
+    def pull_backward(grad, inp, grid, bound, order, extrapolate, need_inp, need_grid):
+        gi, gg = oracle.grid_pull_backward(grad.detach(), inp.detach(), grid.detach(), bound, order, extrapolate)
+        return (gi if need_inp else None), (gg if need_grid else None)
+
+    @staticmethod
+    def push_backward(grad, inp, grid, bound, order, extrapolate, need_inp, need_grid):
+        gi, gg = oracle.grid_push_backward(grad.detach(), inp.detach(), grid.detach(), bound, order, extrapolate)
+        return (gi if need_inp else None), (gg if need_grid else None)
+
+    @staticmethod
+    def count_backward(grad, grid, bound, order, extrapolate):
+        return oracle.grid_count_backward(grad.detach(), grid.detach(), bound, order, extrapolate)
+
+    @staticmethod
+    def spline_filter_(data, bound, order, dim):
+        data.copy_(oracle.spline_coeff(data.detach(), bound, order, dim=dim))
+        return data

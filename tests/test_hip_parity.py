@@ -1,0 +1,297 @@
+"""GPU parity tests (MI355X): the HIP kernels, called through the C-ABI via the
+product's operator seam, against (1) the golden vectors generated from the
+reference, (2) the CPU oracle on seeded inputs, and (3) oracle-free properties
+at larger sizes (adjointness, partition of unity, linearity, count == push(1),
+bit-exact nearest neighbour).
+
+Stated tolerances: fp64 1e-11*max|ref|; fp32 rtol 1e-5 + atol 1e-5*max|ref|
+(5e-5 for spline orders 6-7, see golden_util.fp32_tol); bf16/f16 1e-2; order-0
+pull bit-exact."""
+import numpy as np
+import pytest
+import torch
+
+import golden_util as G
+import interpol
+from interpol import ops
+from oracle import oracle
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+class HipOps:
+    """numpy in/out adaptor over the product operators (device tensors, HIP kernels)."""
+
+    def __init__(self, dtype):
+        self.dtype = dtype
+
+    def _t(self, a):
+        return torch.from_numpy(np.ascontiguousarray(a)).to(DEV, self.dtype)
+
+    def grid_pull(self, inp, grid, b, o, e):
+        return ops.grid_pull(self._t(inp), self._t(grid), b, o, e).cpu().numpy()
+
+    def grid_grad(self, inp, grid, b, o, e):
+        return ops.grid_grad(self._t(inp), self._t(grid), b, o, e).cpu().numpy()
+
+    def grid_hess(self, inp, grid, b, o, e):
+        return ops.grid_hess(self._t(inp), self._t(grid), b, o, e).cpu().numpy()
+
+    def grid_push(self, inp, grid, shape, b, o, e):
+        return ops.grid_push(self._t(inp), self._t(grid), shape, b, o, e).cpu().numpy()
+
+    def grid_count(self, grid, shape, b, o, e):
+        return ops.grid_count(self._t(grid), shape, b, o, e).cpu().numpy()
+
+    def grid_pushgrad(self, inp, grid, shape, b, o, e):
+        return ops.grid_pushgrad(self._t(inp), self._t(grid), shape, b, o, e).cpu().numpy()
+
+
+def _cases(op):
+    return [c for c in G.manifest()["cases"] if c["op"] == op]
+
+
+def test_extension_is_loaded_and_refuses_fallbacks():
+    from interpol import _hip
+    assert _hip.lib().interpol_abi_version() == 1
+    assert ops.kernels().__name__ == "_HipKernels"
+    assert torch.cuda.is_available()
+
+
+@pytest.mark.parametrize("op", ["pull", "push", "count", "grad", "pushgrad", "hess"])
+def test_golden_fp64(op):
+    hip = HipOps(torch.float64)
+    for c in _cases(op):
+        got = G.run_case(hip, c, np.float64)
+        assert G.rel_err(got, G.arr(c["output"])) < 1e-11, c
+
+
+@pytest.mark.parametrize("op", ["pull", "push", "count", "grad", "pushgrad", "hess"])
+def test_golden_fp32(op):
+    hip = HipOps(torch.float32)
+    for c in _cases(op):
+        got = G.run_case(hip, c, np.float32)
+        assert got.dtype == np.float32
+        rtol, atol_rel = G.fp32_tol(c)
+        G.assert_close(got, G.arr(c["output"]), rtol=rtol, atol_rel=atol_rel, what=str(c))
+
+
+def test_nearest_pull_bit_exact():
+    hip = HipOps(torch.float32)
+    n = 0
+    for c in _cases("pull"):
+        if all(o == 0 for o in c["order"][:c["dim"]]):
+            got = G.run_case(hip, c, np.float32)
+            want = G.arr(c["output"]).astype(np.float32)
+            assert np.array_equal(got, want), c
+            n += 1
+    assert n >= 20
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.bfloat16, 1e-2), (torch.float16, 2e-3)])
+def test_low_precision_storage(dtype, tol):
+    """bf16/f16 storage, fp32 coordinates, fp32 math."""
+    for op in ("pull", "push", "count", "grad"):
+        for c in _cases(op)[::7]:
+            ins = {k: G.arr(v, np.float32) for k, v in c["inputs"].items()}
+            grid = torch.from_numpy(ins["grid"]).to(DEV)
+            b, o, e = c["bound"], c["order"], c["extrapolate"]
+            if op == "count":
+                got = ops.grid_count(grid, c["shape"], b, o, e)
+                ref = oracle.grid_count(ins["grid"], c["shape"], b, o, e)
+            else:
+                inp_lp = torch.from_numpy(ins["inp"]).to(DEV, dtype)
+                inp_up = inp_lp.float().cpu().numpy()
+                if op == "pull":
+                    got = ops.grid_pull(inp_lp, grid, b, o, e)
+                    ref = oracle.grid_pull(inp_up, ins["grid"], b, o, e)
+                elif op == "grad":
+                    got = ops.grid_grad(inp_lp, grid, b, o, e)
+                    ref = oracle.grid_grad(inp_up, ins["grid"], b, o, e)
+                else:
+                    got = ops.grid_push(inp_lp, grid, c["shape"], b, o, e)
+                    ref = oracle.grid_push(inp_up, ins["grid"], c["shape"], b, o, e)
+                assert got.dtype == dtype
+            G.assert_close(got.float().cpu().numpy(), ref, rtol=tol, atol_rel=tol, what=str(c))
+
+
+def test_prefilter_golden():
+    for c in G.manifest()["prefilter"]:
+        for dtype, tol in ((torch.float64, 1e-10), (torch.float32, 2e-5)):
+            x = torch.from_numpy(G.arr(c["inp"])).to(DEV, dtype)
+            if c["fn"] == "spline_coeff":
+                got = interpol.spline_coeff(x, interpolation=c["order"], bound=c["bound"], dim=c["dim"])
+            else:
+                got = interpol.spline_coeff_nd(x, interpolation=c["order"], bound=c["bound"], dim=c["dim"])
+            assert G.rel_err(got.cpu().numpy(), G.arr(c["out"])) < tol, (c, dtype)
+
+
+def test_backward_golden():
+    """API-level autograd (fused backward kernels) vs the reference's autograd."""
+    for c in G.manifest()["backward"]:
+        for dtype, tol in ((torch.float64, 1e-11), (torch.float32, 3e-5)):
+            kw = dict(interpolation=c["interpolation"], bound=c["bound"], extrapolate=c["extrapolate"])
+            grid = torch.from_numpy(G.arr(c["grid"])).to(DEV, dtype).requires_grad_(True)
+            gout = torch.from_numpy(G.arr(c["gout"])).to(DEV, dtype)
+            inp = None
+            if c["fn"] == "grid_count":
+                out = interpol.grid_count(grid, c["shape"], **kw)
+            else:
+                inp = torch.from_numpy(G.arr(c["inp"])).to(DEV, dtype).requires_grad_(True)
+                if c["fn"] == "grid_push":
+                    out = interpol.grid_push(inp, grid, c["shape"], **kw)
+                else:
+                    out = getattr(interpol, c["fn"])(inp, grid, **kw)
+            out.backward(gout)
+            assert G.rel_err(out.detach().cpu().numpy(), G.arr(c["out"])) < tol, (c["fn"], dtype)
+            if inp is not None:
+                assert G.rel_err(inp.grad.cpu().numpy(), G.arr(c["grad_inp"])) < tol, (c, dtype)
+            assert G.rel_err(grid.grad.cpu().numpy(), G.arr(c["grad_grid"])) < tol, (c, dtype)
+
+
+def _rand_problem(B, C, ishape, oshape, sigma, seed, dtype=torch.float32):
+    g = torch.Generator().manual_seed(seed)
+    dim = len(ishape)
+    inp = torch.randn([B, C, *ishape], generator=g)
+    lin = [torch.linspace(0, n - 1, m) for n, m in zip(ishape, oshape)]
+    grid = torch.stack(torch.meshgrid(*lin, indexing="ij"), -1)[None] + sigma * torch.randn([B, *oshape, dim], generator=g)
+    return inp.to(dtype), grid.to(dtype)
+
+
+@pytest.mark.parametrize("dim,order,bound", [(3, 3, 3), (3, 5, 6), (3, 1, 0), (2, 2, 2), (2, 7, 1), (1, 4, 5),
+                                             (3, 0, 3), (3, 2, 4), (2, 3, 5), (3, 6, 1)])
+def test_against_oracle_medium(dim, order, bound):
+    """Seeded medium-size problems (oracle runs in seconds), all four forward ops, ex in {0,1}."""
+    ishape = (37, 41, 29)[:dim]
+    oshape = (33, 38, 45)[:dim]
+    inp, grid = _rand_problem(2, 3, ishape, oshape, 2.0, seed=dim * 100 + order)
+    src = torch.randn([2, 3, *oshape], generator=torch.Generator().manual_seed(5))
+    b, o = [bound], [order]
+    rtol, atol_rel = G.fp32_tol(o)
+    oracle.set_threads(8)
+    try:
+        for ex in (1, 0):
+            got = ops.grid_pull(inp.to(DEV), grid.to(DEV), b, o, ex).cpu().numpy()
+            G.assert_close(got, oracle.grid_pull(inp.double(), grid.double(), b, o, ex), rtol, atol_rel, "pull")
+            got = ops.grid_grad(inp.to(DEV), grid.to(DEV), b, o, ex).cpu().numpy()
+            G.assert_close(got, oracle.grid_grad(inp.double(), grid.double(), b, o, ex), rtol, 2 * atol_rel, "grad")
+            got = ops.grid_push(src.to(DEV), grid.to(DEV), list(ishape), b, o, ex).cpu().numpy()
+            G.assert_close(got, oracle.grid_push(src.double(), grid.double(), list(ishape), b, o, ex), rtol, atol_rel, "push")
+            got = ops.grid_count(grid.to(DEV), list(ishape), b, o, ex).cpu().numpy()
+            G.assert_close(got, oracle.grid_count(grid.double(), list(ishape), b, o, ex), rtol, atol_rel, "count")
+    finally:
+        oracle.set_threads(1)
+
+
+def test_strided_and_broadcast_inputs():
+    inp, grid = _rand_problem(2, 4, (20, 22, 24), (9, 10, 11), 1.5, seed=77)
+    b, o = [3, 6, 1], [3, 2, 1]
+    full = ops.grid_pull(inp.to(DEV), grid.to(DEV), b, o, 1)
+    # channel-strided / transposed views of the volume are gathered without a copy
+    view = inp.to(DEV).permute(0, 1, 4, 3, 2).contiguous().permute(0, 1, 4, 3, 2)
+    assert not view.is_contiguous()
+    assert torch.equal(ops.grid_pull(view, grid.to(DEV), b, o, 1), full)
+    sub = inp.to(DEV)[:, 1::2]
+    assert torch.equal(ops.grid_pull(sub, grid.to(DEV), b, o, 1), full[:, 1::2])
+    # batch broadcast of either tensor
+    one = ops.grid_pull(inp[:1].to(DEV), grid.to(DEV), b, o, 1)
+    assert torch.equal(one[1], ops.grid_pull(inp[:1].to(DEV), grid[1:].to(DEV), b, o, 1)[0])
+    one = ops.grid_pull(inp.to(DEV), grid[:1].to(DEV), b, o, 1)
+    assert torch.equal(one[1], ops.grid_pull(inp[1:].to(DEV), grid[:1].to(DEV), b, o, 1)[0])
+
+
+# ---- oracle-free properties at larger sizes -----------------------------------
+
+BOUNDS_ALL = [0, 1, 2, 3, 4, 5, 6]
+
+
+@pytest.mark.parametrize("bound", BOUNDS_ALL)
+@pytest.mark.parametrize("order", [0, 1, 3])
+def test_adjointness_fp64(bound, order):
+    """<pull(x), y> == <x, push(y)> (exact in exact arithmetic), 3-D, ex in {0,1}."""
+    inp, grid = _rand_problem(2, 2, (40, 36, 44), (38, 42, 40), 3.0, seed=bound * 10 + order, dtype=torch.float64)
+    y = torch.randn([2, 2, 38, 42, 40], dtype=torch.float64, generator=torch.Generator().manual_seed(9))
+    for ex in (1, 0):
+        px = ops.grid_pull(inp.to(DEV), grid.to(DEV), [bound], [order], ex)
+        py = ops.grid_push(y.to(DEV), grid.to(DEV), [40, 36, 44], [bound], [order], ex)
+        lhs = float((px * y.to(DEV)).sum())
+        rhs = float((inp.to(DEV) * py).sum())
+        assert abs(lhs - rhs) <= 1e-10 * max(abs(lhs), abs(rhs), 1.0), (bound, order, ex, lhs, rhs)
+
+
+@pytest.mark.parametrize("order", range(8))
+def test_partition_of_unity_and_count(order):
+    """pull(ones) == 1 for sign-free bounds with extrapolate=1; count == push(ones)."""
+    _, grid = _rand_problem(1, 1, (64, 64, 64), (64, 64, 64), 2.0, seed=order)
+    ones = torch.ones(1, 2, 64, 64, 64)
+    for bound in (1, 2, 3, 6):
+        out = ops.grid_pull(ones.to(DEV), grid.to(DEV), [bound], [order], 1)
+        assert float((out - 1).abs().max()) < 2e-5
+    cnt = ops.grid_count(grid.to(DEV), [64, 64, 64], [3], [order], 1)
+    psh = ops.grid_push(ones[:, :1].to(DEV), grid.to(DEV), [64, 64, 64], [3], [order], 1)
+    G.assert_close(cnt.cpu().numpy(), psh.cpu().numpy(), 1e-5, 1e-5, "count vs push(ones)")
+    assert abs(float(cnt.sum()) - 64 ** 3) < 1e-2 * 64 ** 3 * 1e-3
+
+
+def test_identity_grid_is_exact_for_linear_and_nearest():
+    """BASELINE config 1: 1x1x128x128 linear / zero / identity grid -> output == input bit for bit."""
+    x = torch.randn(1, 1, 128, 128, device=DEV)
+    g = interpol.identity_grid([128, 128], device=DEV)[None]
+    for order in (0, 1):
+        for bound in ("zero", "dct2", "dft"):
+            y = interpol.grid_pull(x, g, interpolation=order, bound=bound, extrapolate=False)
+            assert torch.equal(y, x), (order, bound)
+
+
+def test_linearity_and_batch_independence_full_size():
+    """At a BASELINE-like size (2x2x128^3 cubic/dct2): linear in the image, and each
+    batch item is computed independently (what batch sharding relies on)."""
+    inp, grid = _rand_problem(2, 2, (128, 128, 128), (128, 128, 128), 2.0, seed=1234)
+    inp, grid = inp.to(DEV), grid.to(DEV)
+    a = ops.grid_pull(inp, grid, [3], [3], 1)
+    b2 = ops.grid_pull(2.5 * inp, grid, [3], [3], 1)
+    assert float((b2 - 2.5 * a).abs().max()) <= 1e-5 * float(a.abs().max())
+    a0 = ops.grid_pull(inp[:1], grid[:1], [3], [3], 1)
+    assert torch.equal(a0, a[:1])
+    p = ops.grid_push(inp, grid, None, [3], [3], 1)
+    p1 = ops.grid_push(inp[1:], grid[1:], None, [3], [3], 1)
+    assert float((p1 - p[1:]).abs().max()) <= 1e-5 * float(p.abs().max())
+    # adjointness in fp32 at this size
+    y = torch.randn_like(a)
+    lhs, rhs = float((a.double() * y.double()).sum()), float((inp.double() * ops.grid_push(y, grid, None, [3], [3], 1).double()).sum())
+    assert abs(lhs - rhs) <= 1e-4 * max(abs(lhs), abs(rhs))
+
+
+def test_errors_mirror_the_reference():
+    x = torch.randn(1, 1, 5, 6, device=DEV)
+    g = torch.rand(1, 5, 6, 2, device=DEV)
+    with pytest.raises(ValueError, match="Unknown boundary condition"):
+        interpol.grid_pull(x, g, bound="bogus")
+    with pytest.raises(ValueError, match="Unknown interpolation order"):
+        interpol.grid_pull(x, g, interpolation=9)
+    with pytest.raises(NotImplementedError):
+        ops.grid_pull(x, g, [0], [8], 1)
+    with pytest.raises(ValueError, match="same spatial shape"):
+        ops.grid_push(x, torch.rand(1, 4, 6, 2, device=DEV), None, [0], [1], 1)
+    with pytest.raises(NotImplementedError):
+        interpol.spline_coeff_nd(x, 3, "dst2", 2)
+    assert interpol.grid_pull(x, g[:, :0], interpolation=3).shape == (1, 1, 0, 6)
+
+
+def test_resize_identity_property_gpu():
+    for length in (1, 2, 3, 7, 9, 11):
+        torch.manual_seed(length)
+        x = torch.randn([1, 1, length], dtype=torch.float64, device=DEV)
+        for bound in ("dct1", "dct2", "dft"):
+            for order in range(8):
+                y = interpol.resize(x, shape=[length], bound=bound, interpolation=order)
+                assert torch.allclose(x, y, rtol=1e-4, atol=1e-7), (order, bound, length)
+
+
+def test_autocast_casts_to_fp32():
+    x = torch.randn(1, 2, 8, 8, 8, device=DEV, dtype=torch.bfloat16)
+    g = (interpol.identity_grid([8, 8, 8], device=DEV)[None] + 0.3).to(torch.bfloat16)
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        y = interpol.grid_pull(x, g, interpolation=3, bound="dct2", extrapolate=True)
+    assert y.dtype == torch.float32        # reference autograd.py:160 custom_fwd(cast_inputs=float32)

@@ -1,0 +1,230 @@
+"""CPU-side tests (no GPU): the C-ABI library loads and exports every declared
+symbol, its host-side scalar primitives match the reference tables, and the
+Python host logic (shape conventions, aliases, errors, autograd wiring) behaves
+like the reference's api.py / autograd.py.  Compute on CPU goes through the
+TEST-ONLY oracle kernel table; the product path itself refuses CPU tensors."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+import golden_util as G
+import interpol
+from interpol import _hip, ops
+from interpol.codes import bound_to_nitorch, inter_to_nitorch
+from oracle import oracle
+from oracle_kernels import OracleKernels
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    header = open(os.path.join(ROOT, "include", "interpol_hip.h")).read()
+    declared = set(re.findall(r"\b(interpol_[a-z0-9_]+)\s*\(", header))
+    declared -= {"interpol_problem"}
+    assert declared == set(_hip.SYMBOLS), declared ^ set(_hip.SYMBOLS)
+    lib = ctypes.CDLL(_hip.LIB_PATH)
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert _hip.lib().interpol_abi_version() == 1
+    assert ctypes.sizeof(_hip.Problem) == 4 * 12 + 8 * 2 + 8 * 6 + 8 * 17
+
+
+def test_host_index_and_sign_tables():
+    L = _hip.lib()
+    for key, t in G.api()["tables"].items():
+        n, b = int(key[1:key.index("_")]), int(key[-1])
+        for k, want in enumerate(t["idx"]):
+            i = t["i0"] + k
+            assert L.interpol_host_bound_index(b, i, n) == want, (b, n, i)
+            s = L.interpol_host_bound_sign(b, i, n)
+            assert s == (2 if t["sign"] is None else t["sign"][k]), (b, n, i)
+    # far outside (modulo path) against the oracle
+    for b in range(7):
+        for n in (1, 2, 5, 13):
+            for i in list(range(-70, 70)) + [-100003, 99991]:
+                assert L.interpol_host_bound_index(b, i, n) == oracle.bound_index(b, i, n), (b, n, i)
+                s = oracle.bound_sign(b, i, n)
+                assert L.interpol_host_bound_sign(b, i, n) == (2 if s is None else s), (b, n, i)
+
+
+def test_host_weights_match_oracle():
+    L = _hip.lib()
+    for k in range(8):
+        half = (k + 1) / 2
+        for x in np.linspace(-half, half, 401):
+            for which, fn in enumerate((oracle.weight, oracle.wgrad, oracle.whess)):
+                got = L.interpol_host_weight(k, float(x), which)
+                assert abs(got - fn(k, float(x))) < 1e-13, (k, x, which)
+            got32 = L.interpol_host_weight_f32(k, float(x), 0)
+            # fp32 Horner forms cancel near the knots (the reference's fp32 path does too)
+            assert abs(got32 - oracle.weight(k, float(np.float32(x)), 'f32')) < 2e-6
+            assert abs(got32 - oracle.weight(k, float(x))) < 1e-5
+    # partition of unity
+    for k in range(8):
+        for f in np.linspace(0, 0.999, 37):
+            t = f + (k - 1) / 2 if k % 2 else f + (k - 1) / 2
+            s = sum(L.interpol_host_weight(k, t - j, 0) for j in range(k + 1))
+            assert abs(s - 1) < 1e-14
+
+
+def test_alias_tables():
+    api = G.api()
+    for k, v in api["bounds"].items():
+        assert bound_to_nitorch(int(k) if k.isdigit() else k, "int") == v
+    for k, v in api["interpolations"].items():
+        assert inter_to_nitorch(int(k) if k.isdigit() else k, "int") == v
+    assert bound_to_nitorch(["reflect", 6], "str") == ["dct2", "dft"]
+    assert inter_to_nitorch(("cubic", 1), "int") == (3, 1)
+    with pytest.raises(ValueError, match="Unknown boundary condition"):
+        bound_to_nitorch("bogus")
+    with pytest.raises(ValueError, match="Unknown interpolation order"):
+        inter_to_nitorch(8)
+    with pytest.raises(ValueError):
+        bound_to_nitorch(7)
+
+
+def test_cpu_tensors_are_refused_loudly():
+    x, g = torch.randn(1, 1, 4, 4), torch.rand(1, 4, 4, 2)
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        interpol.grid_pull(x, g)
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        interpol.grid_push(x, g)
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        interpol.grid_count(g)
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        interpol.spline_coeff_nd(x, 3)
+
+
+def test_api_shape_conventions():
+    torch.manual_seed(0)
+    with ops.use_kernels(OracleKernels):
+        for c in G.api()["shapes"]:
+            args = []
+            if c["input"] is not None:
+                args.append(torch.randn(c["input"], dtype=torch.float64))
+            args.append(torch.rand(c["grid"], dtype=torch.float64) * 4)
+            kw = dict(c["kwargs"])
+            out = getattr(interpol, c["fn"])(*args, **kw)
+            assert list(out.shape) == c["out"], c
+        with pytest.raises(ValueError, match="Incompatible shapes for broadcasting"):
+            interpol.grid_pull(torch.randn(3, 1, 5, 6), torch.rand(2, 5, 6, 2))
+        with pytest.raises(ValueError, match="same spatial shape"):
+            ops.grid_push(torch.randn(1, 1, 5, 6), torch.rand(1, 4, 6, 2), None, [0], [1], 1)
+
+
+def test_list_padding_and_truncation():
+    """3-element lists on a 2-D problem keep their first two entries (jit_utils.py:9-15)."""
+    torch.manual_seed(1)
+    x = torch.randn(2, 3, 7, 8, dtype=torch.float64)
+    g = torch.rand(2, 5, 6, 2, dtype=torch.float64) * 9 - 1
+    with ops.use_kernels(OracleKernels):
+        a = interpol.grid_pull(x, g, interpolation=[2, 3, 5], bound=['dct1', 'dst2', 'zero'], extrapolate=True)
+        b = interpol.grid_pull(x, g, interpolation=[2, 3], bound=['dct1', 'dst2'], extrapolate=True)
+        c = interpol.grid_pull(x, g, interpolation=[3], bound='dct2', extrapolate=True)
+        d = interpol.grid_pull(x, g, interpolation=[3, 3], bound=['dct2', 'dct2'], extrapolate=True)
+    assert torch.equal(a, b) and torch.equal(c, d)
+
+
+def _bwd_case(c, dtype=torch.float64):
+    kw = dict(interpolation=c["interpolation"], bound=c["bound"], extrapolate=c["extrapolate"])
+    grid = torch.from_numpy(G.arr(c["grid"])).to(dtype).requires_grad_(True)
+    gout = torch.from_numpy(G.arr(c["gout"])).to(dtype)
+    inp = None
+    if c["fn"] == "grid_count":
+        out = interpol.grid_count(grid, c["shape"], **kw)
+    else:
+        inp = torch.from_numpy(G.arr(c["inp"])).to(dtype).requires_grad_(True)
+        if c["fn"] == "grid_push":
+            out = interpol.grid_push(inp, grid, c["shape"], **kw)
+        else:
+            out = getattr(interpol, c["fn"])(inp, grid, **kw)
+    out.backward(gout)
+    return out, inp, grid
+
+
+def test_autograd_wiring_against_reference_backward():
+    with ops.use_kernels(OracleKernels):
+        for c in G.manifest()["backward"]:
+            out, inp, grid = _bwd_case(c)
+            assert G.rel_err(out.detach().numpy(), G.arr(c["out"])) < 1e-12, c["fn"]
+            if inp is not None:
+                assert G.rel_err(inp.grad.numpy(), G.arr(c["grad_inp"])) < 1e-12, c
+            assert G.rel_err(grid.grad.numpy(), G.arr(c["grad_grid"])) < 1e-12, c
+
+
+def test_requires_grad_driven_skipping():
+    calls = []
+
+    class Spy(OracleKernels):
+        @staticmethod
+        def pull_backward(grad, inp, grid, bound, order, extrapolate, need_inp, need_grid):
+            calls.append((need_inp, need_grid))
+            return OracleKernels.pull_backward(grad, inp, grid, bound, order, extrapolate, need_inp, need_grid)
+
+    x = torch.randn(1, 1, 5, 6, dtype=torch.float64)
+    g = torch.rand(1, 5, 6, 2, dtype=torch.float64) * 4
+    with ops.use_kernels(Spy):
+        interpol.grid_pull(x.clone().requires_grad_(True), g, interpolation=3).sum().backward()
+        interpol.grid_pull(x, g.clone().requires_grad_(True), interpolation=3).sum().backward()
+    assert calls == [(True, False), (False, True)]
+
+
+def test_prefilter_api_and_errors():
+    torch.manual_seed(3)
+    x = torch.randn(2, 9, 10, dtype=torch.float64)
+    with ops.use_kernels(OracleKernels):
+        for c in G.manifest()["prefilter"]:
+            inp = torch.from_numpy(G.arr(c["inp"]))
+            if c["fn"] == "spline_coeff":
+                got = interpol.spline_coeff(inp, interpolation=c["order"], bound=c["bound"], dim=c["dim"])
+            else:
+                got = interpol.spline_coeff_nd(inp, interpolation=c["order"], bound=c["bound"], dim=c["dim"])
+            assert G.rel_err(got.numpy(), G.arr(c["out"])) < 1e-11, c
+        with pytest.raises(NotImplementedError):
+            interpol.spline_coeff_nd(x, interpolation=3, bound='dst2', dim=2)
+        with pytest.raises(NotImplementedError):
+            interpol.spline_coeff(x, interpolation=2, bound='dst1')
+        # orders 0/1 are no-ops that still copy (coeff.py:306-307)
+        y = interpol.spline_coeff_nd(x, interpolation=1, bound='dst2', dim=2)
+        assert torch.equal(y, x) and y.data_ptr() != x.data_ptr()
+        # in-place
+        z = x.clone()
+        r = interpol.spline_coeff_nd(z, interpolation=3, bound='dct2', dim=2, inplace=True)
+        assert r.data_ptr() == z.data_ptr() and not torch.equal(z, x)
+        # gradient of the (symmetric) filter = the filter
+        xr = x.clone().requires_grad_(True)
+        interpol.spline_coeff_nd(xr, 3, 'dct2', 2).backward(torch.ones_like(x))
+        want = interpol.spline_coeff_nd(torch.ones_like(x), 3, 'dct2', 2)
+        assert torch.allclose(xr.grad, want, atol=1e-12)
+
+
+@pytest.mark.parametrize("length", [1, 2, 3, 7, 9, 11])
+@pytest.mark.parametrize("bound", ["dct1", "dct2", "dft"])
+def test_resize_identity_property(length, bound):
+    """The reference's tests/test_coeff.py::test_identity, seeded, rtol 1e-4:
+    prefilter followed by sampling on the identity lattice returns the input."""
+    torch.manual_seed(100 + length)
+    x = torch.randn([1, 1, length], dtype=torch.float64)
+    with ops.use_kernels(OracleKernels):
+        for order in range(8):
+            y = interpol.resize(x, shape=[length], bound=bound, interpolation=order)
+            assert torch.allclose(x, y, rtol=1e-4, atol=1e-7), (order, bound, length)
+
+
+def test_grid_helpers():
+    g = interpol.identity_grid([3, 4])
+    assert g.shape == (3, 4, 2) and g[2, 3].tolist() == [2.0, 3.0]
+    d = torch.zeros(2, 3, 4, 2)
+    assert torch.equal(interpol.add_identity_grid(d)[1], g)
+    assert torch.equal(d, torch.zeros(2, 3, 4, 2))
+    interpol.add_identity_grid_(d)
+    assert torch.equal(d[0], g)
+    mat = torch.tensor([[2., 0., 1.], [0., 1., -1.], [0., 0., 1.]])
+    a = interpol.affine_grid(mat, [3, 4])
+    assert torch.allclose(a[..., 0], 2 * g[..., 0] + 1) and torch.allclose(a[..., 1], g[..., 1] - 1)
+    with pytest.raises(ValueError):
+        interpol.affine_grid(mat, [3, 4, 5])

@@ -1,0 +1,428 @@
+// ===========================================================================
+// abi.hip -- the C-ABI of libinterpol_hip.so (declared in include/interpol_hip.h).
+//
+// Validates the plain-C problem descriptor, converts it to the device-side
+// KParams, picks the kernel family and enqueues it on the caller's stream.
+// No allocation, no synchronisation, no global state.
+//
+// Reference interface replaced: the operator seam interpol/pushpull.py:35-325
+// and interpol/coeff.py:288-313 of balbasty/torch-interpol @2024_10_08.
+// ===========================================================================
+#include "../../include/interpol_hip.h"
+#include "stencil.hpp"
+#include "filter_params.hpp"
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <string.h>
+
+namespace ip {
+
+// typed launchers (ops_<dtype>.hip)
+#define IP_DECL(sfx)                                                                                                   \
+    int launch_pull_##sfx(const KParams &, const void *, const void *, void *, int, hipStream_t);                     \
+    int launch_grad_##sfx(const KParams &, const void *, const void *, void *, int, hipStream_t);                     \
+    int launch_push_##sfx(const KParams &, const void *, const void *, void *, int, hipStream_t);                     \
+    int launch_pullbwd_##sfx(const KParams &, const void *, const void *, const void *, void *, void *, int, int64_t, int64_t, hipStream_t); \
+    int launch_pushbwd_##sfx(const KParams &, const void *, const void *, const void *, void *, void *, int, hipStream_t); \
+    int launch_narrow_##sfx(const void *, void *, int64_t, hipStream_t);
+IP_DECL(f32) IP_DECL(f64) IP_DECL(bf16) IP_DECL(f16)
+#undef IP_DECL
+#define IP_DECL2(sfx)                                                                                                  \
+    int launch_hess_##sfx(const KParams &, const void *, const void *, void *, int, hipStream_t);                     \
+    int launch_pushgrad_##sfx(const KParams &, const void *, const void *, void *, int, hipStream_t);
+IP_DECL2(f32) IP_DECL2(f64)
+#undef IP_DECL2
+
+int launch_filter(int dtype, const FilterParams &fp, void *data, hipStream_t st);
+
+// fast paths (ops_tiled.hip); return 1 when they took the problem, 0 to decline, <0 / >0 on error
+int try_fast_pull(const interpol_problem *p, const KParams &k, const void *vol, const void *grid, void *val, hipStream_t st);
+int try_fast_push(const interpol_problem *p, const KParams &k, const void *val, const void *grid, void *vol, hipStream_t st);
+
+static size_t esize(int dtype) { return dtype == INTERPOL_F64 ? 8 : (dtype == INTERPOL_F32 ? 4 : 2); }
+static size_t acc_esize(int dtype) { return dtype == INTERPOL_F64 ? 8 : 4; }
+
+enum Role { GATHER, SCATTER };
+
+// Validate + convert.  `vol_elem_bytes`: element size of the indexed lattice as the
+// kernel sees it (storage type for gathers, accumulation type for scatters).
+static int make_params(const interpol_problem *p, Role role, int trailing, KParams *k, int *B)
+{
+    if (!p) return INTERPOL_E_NULL;
+    if (p->abi_version != INTERPOL_ABI_VERSION) return INTERPOL_E_SHAPE;
+    if (p->dim < 1 || p->dim > 3) return INTERPOL_E_DIM;
+    if (p->extrapolate < 0 || p->extrapolate > 2) return INTERPOL_E_EXTRAP;
+    if (p->dtype < 0 || p->dtype > 3) return INTERPOL_E_DTYPE;
+    if (p->dtype == INTERPOL_F64 ? p->grid_dtype != INTERPOL_F64 : p->grid_dtype != INTERPOL_F32) return INTERPOL_E_DTYPE;
+    if (p->batch < 1 || p->batch > 0x7fffffff || p->channels < 1 || p->channels > 0x7fffffff) return INTERPOL_E_SHAPE;
+    memset(k, 0, sizeof(*k));
+    k->dim = p->dim;
+    k->extrapolate = p->extrapolate;
+    bool all1 = true, all0 = true;
+    int64_t N = 1;
+    const size_t vb = role == GATHER ? esize(p->dtype) : acc_esize(p->dtype);
+    uint64_t max_off = 0;
+    for (int d = 0; d < 3; ++d) {
+        if (d >= p->dim) { k->bound[d] = 1; k->order[d] = 0; k->vol_n[d] = 1; k->vol_ss[d] = 0; continue; }
+        if (p->order[d] < 0 || p->order[d] > 7) return INTERPOL_E_ORDER;
+        if (p->bound[d] < 0 || p->bound[d] > 6) return INTERPOL_E_BOUND;
+        if (p->vol_shape[d] < 1 || p->vol_shape[d] > 0x3fffffff) return INTERPOL_E_SHAPE;
+        if (p->grid_shape[d] < 1) return INTERPOL_E_SHAPE;
+        if (p->vol_stride[2 + d] < 0) return INTERPOL_E_STRIDE;
+        k->bound[d] = p->bound[d];
+        k->order[d] = p->order[d];
+        k->vol_n[d] = (int)p->vol_shape[d];
+        const uint64_t sb = (uint64_t)p->vol_stride[2 + d] * vb;
+        if (sb > 0x7fffffffull) return INTERPOL_E_STRIDE;
+        k->vol_ss[d] = (int)sb;
+        max_off += (uint64_t)(p->vol_shape[d] - 1) * sb;
+        all1 = all1 && p->order[d] == 1;
+        all0 = all0 && p->order[d] == 0;
+        N *= p->grid_shape[d];
+        k->mask_hi[d] = (double)(p->vol_shape[d] - 1) + (p->extrapolate == 2 ? 0.5 + 5e-2 : 5e-2);
+    }
+    if (max_off + vb > 0xffffffffull) return INTERPOL_E_SHAPE;      // one (b, c) image must fit 32-bit byte offsets
+    k->mask_lo = -(p->extrapolate == 2 ? 0.5 + 5e-2 : 5e-2);
+    // pushpull.py:48-66 : all orders 1 -> iso1 semantics, all 0 -> iso0, else nd
+    k->mode = all1 ? MODE_ISO1 : (all0 ? MODE_ISO0 : MODE_ND);
+    k->C = (int)p->channels;
+    k->N = N;
+    k->vol_sb = p->vol_stride[0];
+    k->vol_sc = p->vol_stride[1];
+    // grid: spatial dims contiguous (row-major), component stride 1
+    {
+        int64_t expect = p->dim;
+        if (p->grid_stride[4] != 1 && p->dim > 1) return INTERPOL_E_STRIDE;
+        for (int d = p->dim - 1; d >= 0; --d) {
+            if (p->grid_shape[d] > 1 && p->grid_stride[1 + d] != expect) return INTERPOL_E_STRIDE;
+            expect *= p->grid_shape[d];
+        }
+        k->grid_sb = p->grid_stride[0];
+    }
+    // val: spatial (+ trailing) dims contiguous
+    {
+        int64_t expect = trailing;
+        for (int d = p->dim - 1; d >= 0; --d) {
+            if (p->grid_shape[d] > 1 && p->val_stride[2 + d] != expect) return INTERPOL_E_STRIDE;
+            expect *= p->grid_shape[d];
+        }
+        k->val_sb = p->val_stride[0];
+        k->val_sc = p->val_stride[1];
+    }
+    *B = (int)p->batch;
+    return 0;
+}
+
+static int64_t vol_numel(const interpol_problem *p)
+{
+    int64_t n = p->batch * p->channels;
+    for (int d = 0; d < p->dim; ++d) n *= p->vol_shape[d];
+    return n;
+}
+
+// scatter targets must be dense (B, C, *shape) so they can be zero-filled / narrowed in one go
+static bool vol_is_dense(const interpol_problem *p)
+{
+    int64_t expect = 1;
+    for (int d = p->dim - 1; d >= 0; --d) {
+        if (p->vol_shape[d] > 1 && p->vol_stride[2 + d] != expect) return false;
+        expect *= p->vol_shape[d];
+    }
+    if (p->channels > 1 && p->vol_stride[1] != expect) return false;
+    expect *= p->channels;
+    if (p->batch > 1 && p->vol_stride[0] != expect) return false;
+    return true;
+}
+
+template <typename F32, typename F64, typename BF, typename HF>
+static int by_dtype(int dtype, F32 f32, F64 f64, BF bf, HF hf)
+{
+    switch (dtype) {
+    case INTERPOL_F32: return f32();
+    case INTERPOL_F64: return f64();
+    case INTERPOL_BF16: return bf();
+    case INTERPOL_F16: return hf();
+    default: return INTERPOL_E_DTYPE;
+    }
+}
+
+// common driver of the scatter-type operators
+template <typename Launch>
+static int scatter_driver(const interpol_problem *p, int trailing, bool need_val, const void *val, const void *grid,
+                          void *vol, void *scratch, int64_t scratch_bytes, hipStream_t st, Launch launch)
+{
+    KParams k; int B;
+    int rc = make_params(p, SCATTER, trailing, &k, &B);
+    if (rc) return rc;
+    if (!grid || !vol || (need_val && !val)) return INTERPOL_E_NULL;
+    if (!vol_is_dense(p)) return INTERPOL_E_STRIDE;
+    const int64_t numel = vol_numel(p);
+    const bool lowp = (p->dtype == INTERPOL_BF16 || p->dtype == INTERPOL_F16);
+    void *acc = vol;
+    if (lowp) {
+        if (!scratch) return INTERPOL_E_NULL;
+        if (scratch_bytes < numel * 4) return INTERPOL_E_SCRATCH;
+        acc = scratch;
+    }
+    if (!(p->flags & INTERPOL_FLAG_ACCUMULATE) || lowp) {
+        hipError_t e = hipMemsetAsync(acc, 0, (size_t)numel * acc_esize(p->dtype), st);
+        if (e != hipSuccess) return (int)e;
+    }
+    rc = launch(k, B, acc);
+    if (rc) return rc;
+    if (lowp) {
+        // NB: with INTERPOL_FLAG_ACCUMULATE the low-precision target is overwritten, not accumulated
+        rc = p->dtype == INTERPOL_BF16 ? launch_narrow_bf16(acc, vol, numel, st) : launch_narrow_f16(acc, vol, numel, st);
+    }
+    return rc;
+}
+
+} // namespace ip
+
+using namespace ip;
+
+extern "C" {
+
+int32_t interpol_abi_version(void) { return INTERPOL_ABI_VERSION; }
+
+const char *interpol_error_string(int code)
+{
+    switch (code) {
+    case INTERPOL_OK: return "ok";
+    case INTERPOL_E_DIM: return "dim must be 1, 2 or 3";
+    case INTERPOL_E_ORDER: return "spline order must be in 0..7";
+    case INTERPOL_E_BOUND: return "unknown boundary code";
+    case INTERPOL_E_DTYPE: return "unsupported dtype combination";
+    case INTERPOL_E_SHAPE: return "bad or too large extent";
+    case INTERPOL_E_NULL: return "required pointer is NULL";
+    case INTERPOL_E_EXTRAP: return "extrapolate must be 0, 1 or 2";
+    case INTERPOL_E_PREFILTER: return "prefilter not implemented for dst1/dst2";
+    case INTERPOL_E_SCRATCH: return "scratch buffer too small";
+    case INTERPOL_E_STRIDE: return "unsupported stride pattern";
+    default: return code > 0 ? hipGetErrorString((hipError_t)code) : "unknown error";
+    }
+}
+
+int interpol_pull(const interpol_problem *p, const void *vol, const void *grid, void *val, void *stream)
+{
+    KParams k; int B;
+    int rc = make_params(p, GATHER, 1, &k, &B);
+    if (rc) return rc;
+    if (!vol || !grid || !val) return INTERPOL_E_NULL;
+    hipStream_t st = (hipStream_t)stream;
+    if (!(p->flags & INTERPOL_FLAG_NO_FASTPATH)) {
+        rc = try_fast_pull(p, k, vol, grid, val, st);
+        if (rc != 0) return rc == 1 ? 0 : rc;
+    }
+    return by_dtype(p->dtype,
+        [&] { return launch_pull_f32(k, vol, grid, val, B, st); },
+        [&] { return launch_pull_f64(k, vol, grid, val, B, st); },
+        [&] { return launch_pull_bf16(k, vol, grid, val, B, st); },
+        [&] { return launch_pull_f16(k, vol, grid, val, B, st); });
+}
+
+int interpol_grad(const interpol_problem *p, const void *vol, const void *grid, void *val, void *stream)
+{
+    KParams k; int B;
+    int rc = make_params(p, GATHER, p ? p->dim : 1, &k, &B);
+    if (rc) return rc;
+    if (!vol || !grid || !val) return INTERPOL_E_NULL;
+    hipStream_t st = (hipStream_t)stream;
+    return by_dtype(p->dtype,
+        [&] { return launch_grad_f32(k, vol, grid, val, B, st); },
+        [&] { return launch_grad_f64(k, vol, grid, val, B, st); },
+        [&] { return launch_grad_bf16(k, vol, grid, val, B, st); },
+        [&] { return launch_grad_f16(k, vol, grid, val, B, st); });
+}
+
+int interpol_hess(const interpol_problem *p, const void *vol, const void *grid, void *val, void *stream)
+{
+    KParams k; int B;
+    int rc = make_params(p, GATHER, p ? p->dim * p->dim : 1, &k, &B);
+    if (rc) return rc;
+    if (!vol || !grid || !val) return INTERPOL_E_NULL;
+    hipStream_t st = (hipStream_t)stream;
+    switch (p->dtype) {
+    case INTERPOL_F32: return launch_hess_f32(k, vol, grid, val, B, st);
+    case INTERPOL_F64: return launch_hess_f64(k, vol, grid, val, B, st);
+    default: return INTERPOL_E_DTYPE;          // second-order ops: f32 / f64 only (host upcasts)
+    }
+}
+
+int interpol_push(const interpol_problem *p, const void *val, const void *grid, void *vol,
+                  void *scratch, int64_t scratch_bytes, void *stream)
+{
+    hipStream_t st = (hipStream_t)stream;
+    return scatter_driver(p, 1, true, val, grid, vol, scratch, scratch_bytes, st, [&](const KParams &k, int B, void *acc) {
+        if (!(p->flags & INTERPOL_FLAG_NO_FASTPATH)) {
+            int rc = try_fast_push(p, k, val, grid, acc, st);
+            if (rc != 0) return rc == 1 ? 0 : rc;
+        }
+        return by_dtype(p->dtype,
+            [&] { return launch_push_f32(k, val, grid, acc, B, st); },
+            [&] { return launch_push_f64(k, val, grid, acc, B, st); },
+            [&] { return launch_push_bf16(k, val, grid, acc, B, st); },
+            [&] { return launch_push_f16(k, val, grid, acc, B, st); });
+    });
+}
+
+int interpol_count(const interpol_problem *p, const void *grid, void *vol,
+                   void *scratch, int64_t scratch_bytes, void *stream)
+{
+    if (p && p->channels != 1) return INTERPOL_E_SHAPE;
+    hipStream_t st = (hipStream_t)stream;
+    return scatter_driver(p, 1, false, nullptr, grid, vol, scratch, scratch_bytes, st, [&](const KParams &k, int B, void *acc) {
+        return by_dtype(p->dtype,
+            [&] { return launch_push_f32(k, nullptr, grid, acc, B, st); },
+            [&] { return launch_push_f64(k, nullptr, grid, acc, B, st); },
+            [&] { return launch_push_bf16(k, nullptr, grid, acc, B, st); },
+            [&] { return launch_push_f16(k, nullptr, grid, acc, B, st); });
+    });
+}
+
+int interpol_pushgrad(const interpol_problem *p, const void *val, const void *grid, void *vol,
+                      void *scratch, int64_t scratch_bytes, void *stream)
+{
+    if (p && p->dtype != INTERPOL_F32 && p->dtype != INTERPOL_F64) return INTERPOL_E_DTYPE;
+    hipStream_t st = (hipStream_t)stream;
+    return scatter_driver(p, p ? p->dim : 1, true, val, grid, vol, scratch, scratch_bytes, st, [&](const KParams &k, int B, void *acc) {
+        return p->dtype == INTERPOL_F32 ? launch_pushgrad_f32(k, val, grid, acc, B, st)
+                                        : launch_pushgrad_f64(k, val, grid, acc, B, st);
+    });
+}
+
+int interpol_pull_backward(const interpol_problem *p, const void *grad_out, const void *vol, const void *grid,
+                           void *grad_vol, void *grad_grid, void *scratch, int64_t scratch_bytes, void *stream)
+{
+    KParams k; int B;
+    int rc = make_params(p, GATHER, 1, &k, &B);
+    if (rc) return rc;
+    if (!grad_out || !vol || !grid) return INTERPOL_E_NULL;
+    if (!grad_vol && !grad_grid) return 0;
+    hipStream_t st = (hipStream_t)stream;
+    // grad_vol is a dense (B, C, *vol_shape) buffer; vol must be spatially contiguous so
+    // that both share tap offsets (channel / batch strides are free)
+    {
+        int64_t expect = 1;
+        for (int d = p->dim - 1; d >= 0; --d) {
+            if (p->vol_shape[d] > 1 && p->vol_stride[2 + d] != expect) return INTERPOL_E_STRIDE;
+            expect *= p->vol_shape[d];
+        }
+    }
+    int64_t img = 1;
+    for (int d = 0; d < p->dim; ++d) img *= p->vol_shape[d];
+    const int64_t numel = img * p->channels * p->batch;
+    const bool lowp = (p->dtype == INTERPOL_BF16 || p->dtype == INTERPOL_F16);
+    void *acc = grad_vol;
+    if (grad_vol) {
+        if (lowp) {
+            if (!scratch) return INTERPOL_E_NULL;
+            if (scratch_bytes < numel * 4) return INTERPOL_E_SCRATCH;
+            acc = scratch;
+        }
+        if (!(p->flags & INTERPOL_FLAG_ACCUMULATE) || lowp) {
+            hipError_t e = hipMemsetAsync(acc, 0, (size_t)numel * acc_esize(p->dtype), st);
+            if (e != hipSuccess) return (int)e;
+        }
+    }
+    const int64_t gsb = img * p->channels, gsc = img;
+    rc = by_dtype(p->dtype,
+        [&] { return launch_pullbwd_f32(k, grad_out, vol, grid, acc, grad_grid, B, gsb, gsc, st); },
+        [&] { return launch_pullbwd_f64(k, grad_out, vol, grid, acc, grad_grid, B, gsb, gsc, st); },
+        [&] { return launch_pullbwd_bf16(k, grad_out, vol, grid, acc, grad_grid, B, gsb, gsc, st); },
+        [&] { return launch_pullbwd_f16(k, grad_out, vol, grid, acc, grad_grid, B, gsb, gsc, st); });
+    if (rc) return rc;
+    if (grad_vol && lowp)
+        rc = p->dtype == INTERPOL_BF16 ? launch_narrow_bf16(acc, grad_vol, numel, st) : launch_narrow_f16(acc, grad_vol, numel, st);
+    return rc;
+}
+
+int interpol_push_backward(const interpol_problem *p, const void *grad_vol_out, const void *val, const void *grid,
+                           void *grad_val, void *grad_grid, void *stream)
+{
+    KParams k; int B;
+    int rc = make_params(p, GATHER, 1, &k, &B);
+    if (rc) return rc;
+    if (!grad_vol_out || !val || !grid) return INTERPOL_E_NULL;
+    if (!grad_val && !grad_grid) return 0;
+    hipStream_t st = (hipStream_t)stream;
+    return by_dtype(p->dtype,
+        [&] { return launch_pushbwd_f32(k, grad_vol_out, val, grid, grad_val, grad_grid, B, st); },
+        [&] { return launch_pushbwd_f64(k, grad_vol_out, val, grid, grad_val, grad_grid, B, st); },
+        [&] { return launch_pushbwd_bf16(k, grad_vol_out, val, grid, grad_val, grad_grid, B, st); },
+        [&] { return launch_pushbwd_f16(k, grad_vol_out, val, grid, grad_val, grad_grid, B, st); });
+}
+
+int interpol_count_backward(const interpol_problem *p, const void *grad_vol_out, const void *grid,
+                            void *grad_grid, void *stream)
+{
+    KParams k; int B;
+    int rc = make_params(p, GATHER, 1, &k, &B);
+    if (rc) return rc;
+    if (!grad_vol_out || !grid || !grad_grid) return INTERPOL_E_NULL;
+    hipStream_t st = (hipStream_t)stream;
+    return by_dtype(p->dtype,
+        [&] { return launch_pushbwd_f32(k, grad_vol_out, nullptr, grid, nullptr, grad_grid, B, st); },
+        [&] { return launch_pushbwd_f64(k, grad_vol_out, nullptr, grid, nullptr, grad_grid, B, st); },
+        [&] { return launch_pushbwd_bf16(k, grad_vol_out, nullptr, grid, nullptr, grad_grid, B, st); },
+        [&] { return launch_pushbwd_f16(k, grad_vol_out, nullptr, grid, nullptr, grad_grid, B, st); });
+}
+
+int interpol_spline_filter(void *data, int32_t dtype, int64_t outer, int64_t n, int64_t inner,
+                           int32_t bound, int32_t order, void *stream)
+{
+    if (!data) return INTERPOL_E_NULL;
+    if (dtype < 0 || dtype > 3) return INTERPOL_E_DTYPE;
+    if (order < 0 || order > 7) return INTERPOL_E_ORDER;
+    if (bound < 0 || bound > 6) return INTERPOL_E_BOUND;
+    if (outer < 0 || n < 0 || inner < 0) return INTERPOL_E_SHAPE;
+    if (order < 2) return 0;                                  // coeff.py:306-307
+    if (bound == 4 || bound == 5) return INTERPOL_E_PREFILTER;   // coeff.py:243-244
+    if (n <= 1 || outer == 0 || inner == 0) return 0;         // coeff.py:264-265
+    FilterParams fp;
+    fp.outer = outer; fp.n = n; fp.inner = inner;
+    fp.bound = (bound == 0 || bound == 2) ? 0 : ((bound == 1 || bound == 3) ? 1 : 2);   // coeff.py:237-242
+    // coeff.py:35-65 get_poles
+    switch (order) {
+    case 2: fp.npoles = 1; fp.pole[0] = sqrt(8.) - 3.; break;
+    case 3: fp.npoles = 1; fp.pole[0] = sqrt(3.) - 2.; break;
+    case 4: fp.npoles = 2;
+        fp.pole[0] = sqrt(664. - sqrt(438976.)) + sqrt(304.) - 19.;
+        fp.pole[1] = sqrt(664. + sqrt(438976.)) - sqrt(304.) - 19.; break;
+    case 5: fp.npoles = 2;
+        fp.pole[0] = sqrt(67.5 - sqrt(4436.25)) + sqrt(26.25) - 6.5;
+        fp.pole[1] = sqrt(67.5 + sqrt(4436.25)) - sqrt(26.25) - 6.5; break;
+    case 6: fp.npoles = 3;
+        fp.pole[0] = -0.488294589303044755130118038883789062112279161239377608394;
+        fp.pole[1] = -0.081679271076237512597937765737059080653379610398148178525368;
+        fp.pole[2] = -0.00141415180832581775108724397655859252786416905534669851652709; break;
+    default: fp.npoles = 3;
+        fp.pole[0] = -0.5352804307964381655424037816816460718339231523426924148812;
+        fp.pole[1] = -0.122554615192326690515272264359357343605486549427295558490763;
+        fp.pole[2] = -0.0091486948096082769285930216516478534156925639545994482648003; break;
+    }
+    fp.gain = 1.;
+    for (int i = 0; i < fp.npoles; ++i) fp.gain *= (1. - fp.pole[i]) * (1. - 1. / fp.pole[i]);   // coeff.py:69-73
+    return launch_filter(dtype, fp, data, (hipStream_t)stream);
+}
+
+// ---- host-side scalar primitives (no GPU) ------------------------------------
+int32_t interpol_host_bound_index(int32_t bound, int32_t i, int32_t n) { return wrap_index(bound, i, n); }
+int32_t interpol_host_bound_sign(int32_t bound, int32_t i, int32_t n) { return wrap_sign_raw(bound, i, n); }
+double interpol_host_weight(int32_t order, double x, int32_t which)
+{
+    return which == 0 ? bspline_w<double>(order, x) : (which == 1 ? bspline_g<double>(order, x) : bspline_h<double>(order, x));
+}
+float interpol_host_weight_f32(int32_t order, float x, int32_t which)
+{
+    return which == 0 ? bspline_w<float>(order, x) : (which == 1 ? bspline_g<float>(order, x) : bspline_h<float>(order, x));
+}
+
+const char *interpol_kernel_name(const interpol_problem *p, const char *op)
+{
+    (void)op;
+    if (!p) return "invalid";
+    return "generic";
+}
+
+} // extern "C"

@@ -1,0 +1,399 @@
+"""ctypes binding of libinterpol_hip.so (C-ABI: include/interpol_hip.h).
+
+PyTorch is plumbing here: it owns device memory and the current HIP stream; the
+sampling itself runs in the hand-written gfx950 kernels of `csrc/`.  There is
+NO CPU fallback: without the built library, or with CPU tensors, every
+operator raises.
+"""
+import ctypes
+import os
+
+import torch
+
+_PKG_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIB_PATH = os.path.join(_PKG_ROOT, "lib", "libinterpol_hip.so")
+
+ABI_VERSION = 1
+F32, F64, BF16, F16 = 0, 1, 2, 3
+FLAG_NO_FASTPATH = 1
+FLAG_ACCUMULATE = 2
+
+_DTYPE_CODE = {torch.float32: F32, torch.float64: F64, torch.bfloat16: BF16, torch.float16: F16}
+
+# exported symbols, as declared in include/interpol_hip.h
+SYMBOLS = (
+    "interpol_pull", "interpol_push", "interpol_count", "interpol_grad", "interpol_pushgrad",
+    "interpol_hess", "interpol_pull_backward", "interpol_push_backward", "interpol_count_backward",
+    "interpol_spline_filter", "interpol_host_bound_index", "interpol_host_bound_sign",
+    "interpol_host_weight", "interpol_host_weight_f32", "interpol_abi_version",
+    "interpol_error_string", "interpol_kernel_name",
+)
+
+
+class Problem(ctypes.Structure):
+    """`interpol_problem` of include/interpol_hip.h."""
+    _fields_ = [
+        ("abi_version", ctypes.c_int32),
+        ("dim", ctypes.c_int32),
+        ("dtype", ctypes.c_int32),
+        ("grid_dtype", ctypes.c_int32),
+        ("extrapolate", ctypes.c_int32),
+        ("bound", ctypes.c_int32 * 3),
+        ("order", ctypes.c_int32 * 3),
+        ("flags", ctypes.c_int32),
+        ("batch", ctypes.c_int64),
+        ("channels", ctypes.c_int64),
+        ("vol_shape", ctypes.c_int64 * 3),
+        ("grid_shape", ctypes.c_int64 * 3),
+        ("vol_stride", ctypes.c_int64 * 5),
+        ("grid_stride", ctypes.c_int64 * 5),
+        ("val_stride", ctypes.c_int64 * 7),
+    ]
+
+
+_lib = None
+
+
+class HipExtensionMissing(ImportError):
+    pass
+
+
+def lib():
+    """Load the HIP library (once).  Fails loudly when it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise HipExtensionMissing(
+            "libinterpol_hip.so not found at %s: build it with `make -C %s -j8` "
+            "(or `python -c 'import __graft_entry__ as g; g.build()'`). "
+            "There is no CPU fallback." % (LIB_PATH, _PKG_ROOT))
+    L = ctypes.CDLL(LIB_PATH)
+    vp, i64, i32 = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32
+    pp = ctypes.POINTER(Problem)
+    L.interpol_pull.argtypes = [pp, vp, vp, vp, vp]
+    L.interpol_grad.argtypes = [pp, vp, vp, vp, vp]
+    L.interpol_hess.argtypes = [pp, vp, vp, vp, vp]
+    L.interpol_push.argtypes = [pp, vp, vp, vp, vp, i64, vp]
+    L.interpol_pushgrad.argtypes = [pp, vp, vp, vp, vp, i64, vp]
+    L.interpol_count.argtypes = [pp, vp, vp, vp, i64, vp]
+    L.interpol_pull_backward.argtypes = [pp, vp, vp, vp, vp, vp, vp, i64, vp]
+    L.interpol_push_backward.argtypes = [pp, vp, vp, vp, vp, vp, vp]
+    L.interpol_count_backward.argtypes = [pp, vp, vp, vp, vp]
+    L.interpol_spline_filter.argtypes = [vp, i32, i64, i64, i64, i32, i32, vp]
+    for name in ("interpol_pull", "interpol_grad", "interpol_hess", "interpol_push", "interpol_pushgrad",
+                 "interpol_count", "interpol_pull_backward", "interpol_push_backward",
+                 "interpol_count_backward", "interpol_spline_filter"):
+        getattr(L, name).restype = ctypes.c_int
+    L.interpol_host_bound_index.argtypes = [i32, i32, i32]
+    L.interpol_host_bound_index.restype = i32
+    L.interpol_host_bound_sign.argtypes = [i32, i32, i32]
+    L.interpol_host_bound_sign.restype = i32
+    L.interpol_host_weight.argtypes = [i32, ctypes.c_double, i32]
+    L.interpol_host_weight.restype = ctypes.c_double
+    L.interpol_host_weight_f32.argtypes = [i32, ctypes.c_float, i32]
+    L.interpol_host_weight_f32.restype = ctypes.c_float
+    L.interpol_abi_version.restype = i32
+    L.interpol_error_string.argtypes = [ctypes.c_int]
+    L.interpol_error_string.restype = ctypes.c_char_p
+    L.interpol_kernel_name.argtypes = [pp, ctypes.c_char_p]
+    L.interpol_kernel_name.restype = ctypes.c_char_p
+    if L.interpol_abi_version() != ABI_VERSION:
+        raise HipExtensionMissing("libinterpol_hip.so has ABI version %d, expected %d: rebuild it"
+                                  % (L.interpol_abi_version(), ABI_VERSION))
+    _lib = L
+    return L
+
+
+def _check(rc, what):
+    if rc == 0:
+        return
+    msg = lib().interpol_error_string(rc).decode()
+    if rc == -2:
+        raise NotImplementedError("%s: %s" % (what, msg))          # reference interpol/splines.py:80
+    if rc == -8:
+        raise NotImplementedError("%s: %s" % (what, msg))          # reference interpol/coeff.py:243-244
+    if rc in (-1, -3, -5, -7):
+        raise ValueError("%s: %s" % (what, msg))
+    raise RuntimeError("%s failed: %s (code %d)" % (what, msg, rc))
+
+
+def _require_gpu(*tensors):
+    dev = None
+    for t in tensors:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise RuntimeError(
+                "interpol (MI355X build): tensors must live on a ROCm GPU; got a %s tensor. "
+                "This build has no CPU path." % t.device.type)
+        if dev is None:
+            dev = t.device
+        elif t.device != dev:
+            raise RuntimeError("interpol: all tensors must be on the same device (%s vs %s)" % (dev, t.device))
+    return dev
+
+
+def _stream(dev):
+    return ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+
+
+def _ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
+
+
+def common_dtypes(img, grid):
+    """Storage / coordinate dtypes the kernels run in.
+    (f32, f32), (f64, f64), (bf16|f16 image, f32 coordinates); anything else is
+    promoted the way the reference's elementwise ops would."""
+    if not grid.dtype.is_floating_point:
+        raise TypeError("grid must be a floating point tensor")
+    idt = img.dtype if img is not None else grid.dtype
+    if not idt.is_floating_point:
+        raise TypeError("image must be a floating point tensor")
+    if idt == torch.float64 or grid.dtype == torch.float64:
+        return torch.float64, torch.float64
+    if idt in (torch.bfloat16, torch.float16):
+        return idt, torch.float32
+    return torch.float32, torch.float32
+
+
+def _spatially_contiguous(t, first_spatial):
+    """True when dims [first_spatial:] are row-major contiguous."""
+    expect = 1
+    for d in range(t.dim() - 1, first_spatial - 1, -1):
+        if t.shape[d] > 1 and t.stride(d) != expect:
+            return False
+        expect *= t.shape[d]
+    return True
+
+
+def _bstride(t, B):
+    """Batch stride with broadcasting of a singleton batch."""
+    return 0 if (t.shape[0] == 1 and B > 1) else t.stride(0)
+
+
+def make_problem(dim, dtype, grid_dtype, bound, order, extrapolate, B, C, vol_shape, grid_shape,
+                 vol_stride, grid_stride, val_stride, flags=0):
+    p = Problem()
+    p.abi_version = ABI_VERSION
+    p.dim = dim
+    p.dtype = _DTYPE_CODE[dtype]
+    p.grid_dtype = _DTYPE_CODE[grid_dtype]
+    p.extrapolate = int(extrapolate)
+    for d in range(3):
+        p.bound[d] = int(bound[d]) if d < dim else 1
+        p.order[d] = int(order[d]) if d < dim else 0
+        p.vol_shape[d] = int(vol_shape[d]) if d < dim else 1
+        p.grid_shape[d] = int(grid_shape[d]) if d < dim else 1
+    p.flags = flags
+    p.batch, p.channels = int(B), int(C)
+    for i, s in enumerate(vol_stride):
+        p.vol_stride[i] = int(s)
+    for i, s in enumerate(grid_stride):
+        p.grid_stride[i] = int(s)
+    for i, s in enumerate(val_stride):
+        p.val_stride[i] = int(s)
+    return p
+
+
+def _dense_strides(shape):
+    st, acc = [], 1
+    for s in reversed(shape):
+        st.append(acc)
+        acc *= int(s)
+    return list(reversed(st))
+
+
+def _pad_to(lst, n, fill=0):
+    return list(lst) + [fill] * (n - len(lst))
+
+
+def _grid_strides(grid, B, dim):
+    return [_bstride(grid, B)] + _pad_to([grid.stride(1 + d) for d in range(dim)], 3) + [grid.stride(-1)]
+
+
+def gather(op, vol, grid, bound, order, extrapolate, flags=0):
+    """pull / grad / hess: vol (B,C,*in), grid (B,*out,D) -> val (B,C,*out[,D[,D]])."""
+    dev = _require_gpu(vol, grid)
+    dim = grid.shape[-1]
+    if dim not in (1, 2, 3):
+        raise NotImplementedError("interpol (MI355X build): only 1-D, 2-D and 3-D grids are supported")
+    dt, gdt = common_dtypes(vol, grid)
+    out_dt = dt
+    if op in ("hess",) and dt in (torch.bfloat16, torch.float16):
+        dt = torch.float32                                 # second-order operator: f32 / f64 kernels only
+    vol = vol.to(dt)
+    grid = grid.to(gdt)
+    if not _spatially_contiguous(grid, 1):
+        grid = grid.contiguous()
+    B = max(vol.shape[0], grid.shape[0])
+    C = vol.shape[1]
+    oshape = list(grid.shape[1:-1])
+    trailing = {"pull": [], "grad": [dim], "hess": [dim, dim]}[op]
+    val = torch.empty([B, C] + oshape + trailing, dtype=dt, device=dev)
+    if val.numel() == 0:
+        return val.to(out_dt)
+    vstr = [_bstride(vol, B), vol.stride(1)] + _pad_to([vol.stride(2 + d) for d in range(dim)], 3)
+    valstr = [val.stride(0), val.stride(1)] + _pad_to([val.stride(2 + d) for d in range(dim)], 3) + [0, 0]
+    p = make_problem(dim, dt, gdt, bound, order, extrapolate, B, C, vol.shape[2:], oshape,
+                     vstr, _grid_strides(grid, B, dim), valstr, flags)
+    fn = getattr(lib(), "interpol_" + op)
+    with torch.cuda.device(dev):
+        rc = fn(ctypes.byref(p), _ptr(vol), _ptr(grid), _ptr(val), _stream(dev))
+    _check(rc, "interpol_" + op)
+    return val.to(out_dt)
+
+
+def scatter(op, val, grid, shape, bound, order, extrapolate, flags=0, out=None):
+    """push / count / pushgrad: val (B,C,*in[,D]) , grid (B,*in,D) -> vol (B,C,*shape).
+    `out` (dense, same dtype) + FLAG_ACCUMULATE adds into an existing target."""
+    dev = _require_gpu(val, grid)
+    dim = grid.shape[-1]
+    if dim not in (1, 2, 3):
+        raise NotImplementedError("interpol (MI355X build): only 1-D, 2-D and 3-D grids are supported")
+    dt, gdt = common_dtypes(val, grid)
+    out_dt = dt
+    if op == "pushgrad" and dt in (torch.bfloat16, torch.float16):
+        dt = torch.float32
+    grid = grid.to(gdt)
+    if not _spatially_contiguous(grid, 1):
+        grid = grid.contiguous()
+    gshape = list(grid.shape[1:-1])
+    if shape is None:
+        shape = gshape
+    shape = [int(s) for s in shape]
+    if op == "count":
+        B, C = grid.shape[0], 1
+        valstr = [0] * 7
+    else:
+        val = val.to(dt)
+        if not _spatially_contiguous(val, 2):
+            val = val.contiguous()
+        B = max(val.shape[0], grid.shape[0])
+        C = val.shape[1]
+        valstr = [_bstride(val, B), val.stride(1)] + _pad_to([val.stride(2 + d) for d in range(dim)], 3) + [0, 0]
+    if out is None:
+        vol = torch.empty([B, C] + shape, dtype=dt, device=dev)
+    else:
+        vol = out
+        assert vol.is_contiguous() and vol.dtype == dt and list(vol.shape) == [B, C] + shape
+    if vol.numel() == 0:
+        return vol.to(out_dt)
+    if grid.numel() == 0:
+        return vol.zero_().to(out_dt) if out is None else vol
+    scratch, sbytes = None, 0
+    if dt in (torch.bfloat16, torch.float16):
+        scratch = torch.empty(vol.numel(), dtype=torch.float32, device=dev)
+        sbytes = scratch.numel() * 4
+    vstr = [vol.stride(0), vol.stride(1)] + _pad_to([vol.stride(2 + d) for d in range(dim)], 3)
+    p = make_problem(dim, dt, gdt, bound, order, extrapolate, B, C, shape, gshape,
+                     vstr, _grid_strides(grid, B, dim), valstr, flags)
+    L = lib()
+    with torch.cuda.device(dev):
+        if op == "count":
+            rc = L.interpol_count(ctypes.byref(p), _ptr(grid), _ptr(vol), _ptr(scratch), sbytes, _stream(dev))
+        else:
+            rc = getattr(L, "interpol_" + op)(ctypes.byref(p), _ptr(val), _ptr(grid), _ptr(vol),
+                                              _ptr(scratch), sbytes, _stream(dev))
+    _check(rc, "interpol_" + op)
+    return vol.to(out_dt)
+
+
+def pull_backward(gout, vol, grid, bound, order, extrapolate, need_vol, need_grid):
+    """Fused backward of pull: (grad_vol (B,C,*in) | None, grad_grid (B,*out,D) | None)."""
+    dev = _require_gpu(gout, vol, grid)
+    dim = grid.shape[-1]
+    dt, gdt = common_dtypes(vol, grid)
+    vol = vol.to(dt)
+    gout = gout.to(dt)
+    grid_c = grid.to(gdt)
+    if not _spatially_contiguous(grid_c, 1):
+        grid_c = grid_c.contiguous()
+    if not _spatially_contiguous(vol, 2):
+        vol = vol.contiguous()
+    if not _spatially_contiguous(gout, 2):
+        gout = gout.contiguous()
+    B = max(vol.shape[0], grid_c.shape[0])
+    C = vol.shape[1]
+    ishape = list(vol.shape[2:])
+    oshape = list(grid_c.shape[1:-1])
+    gvol = torch.empty([B, C] + ishape, dtype=dt, device=dev) if need_vol else None
+    ggrid = torch.empty([B] + oshape + [dim], dtype=gdt, device=dev) if need_grid else None
+    if gout.numel() == 0:
+        return (gvol.zero_() if need_vol else None), ggrid
+    scratch, sbytes = None, 0
+    if need_vol and dt in (torch.bfloat16, torch.float16):
+        scratch = torch.empty(gvol.numel(), dtype=torch.float32, device=dev)
+        sbytes = scratch.numel() * 4
+    vstr = [_bstride(vol, B), vol.stride(1)] + _pad_to([vol.stride(2 + d) for d in range(dim)], 3)
+    valstr = [_bstride(gout, B), gout.stride(1)] + _pad_to([gout.stride(2 + d) for d in range(dim)], 3) + [0, 0]
+    p = make_problem(dim, dt, gdt, bound, order, extrapolate, B, C, ishape, oshape,
+                     vstr, _grid_strides(grid_c, B, dim), valstr)
+    with torch.cuda.device(dev):
+        rc = lib().interpol_pull_backward(ctypes.byref(p), _ptr(gout), _ptr(vol), _ptr(grid_c), _ptr(gvol),
+                                          _ptr(ggrid), _ptr(scratch), sbytes, _stream(dev))
+    _check(rc, "interpol_pull_backward")
+    return gvol, ggrid
+
+
+def push_backward(gvol_out, val, grid, bound, order, extrapolate, need_val, need_grid):
+    """Fused backward of push (val given) or count (val None):
+    (grad_val (B,C,*in) | None, grad_grid (B,*in,D) | None)."""
+    dev = _require_gpu(gvol_out, val, grid)
+    dim = grid.shape[-1]
+    dt, gdt = common_dtypes(gvol_out, grid)
+    gvol_out = gvol_out.to(dt)
+    grid_c = grid.to(gdt)
+    if not _spatially_contiguous(grid_c, 1):
+        grid_c = grid_c.contiguous()
+    gshape = list(grid_c.shape[1:-1])
+    B = max(gvol_out.shape[0], grid_c.shape[0])
+    C = gvol_out.shape[1]
+    count = val is None
+    if not count:
+        val = val.to(dt)
+        if not val.is_contiguous():
+            val = val.contiguous()
+        B = max(B, val.shape[0])
+        if val.shape[0] != B:
+            val = val.expand([B] + list(val.shape[1:])).contiguous()
+    gval = torch.empty([B, C] + gshape, dtype=dt, device=dev) if (need_val and not count) else None
+    ggrid = torch.empty([B] + gshape + [dim], dtype=gdt, device=dev) if need_grid else None
+    if grid_c.numel() == 0 or (gval is None and ggrid is None):
+        return gval, ggrid
+    vstr = [_bstride(gvol_out, B), gvol_out.stride(1)] + _pad_to([gvol_out.stride(2 + d) for d in range(dim)], 3)
+    dense = _dense_strides([B, C] + gshape)
+    valstr = dense[:2] + _pad_to(dense[2:], 3) + [0, 0]
+    p = make_problem(dim, dt, gdt, bound, order, extrapolate, B, C, gvol_out.shape[2:], gshape,
+                     vstr, _grid_strides(grid_c, B, dim), valstr)
+    L = lib()
+    with torch.cuda.device(dev):
+        if count:
+            rc = L.interpol_count_backward(ctypes.byref(p), _ptr(gvol_out), _ptr(grid_c), _ptr(ggrid), _stream(dev))
+        else:
+            rc = L.interpol_push_backward(ctypes.byref(p), _ptr(gvol_out), _ptr(val), _ptr(grid_c),
+                                          _ptr(gval), _ptr(ggrid), _stream(dev))
+    _check(rc, "interpol_push_backward")
+    return gval, ggrid
+
+
+def spline_filter_(data, bound, order, dim):
+    """In-place prefilter of `data` (contiguous) along dimension `dim`."""
+    dev = _require_gpu(data)
+    if data.dtype not in _DTYPE_CODE:
+        raise TypeError("spline_coeff: unsupported dtype %s" % data.dtype)
+    assert data.is_contiguous()
+    dim = dim % data.dim()
+    n = data.shape[dim]
+    outer = 1
+    for s in data.shape[:dim]:
+        outer *= s
+    inner = 1
+    for s in data.shape[dim + 1:]:
+        inner *= s
+    with torch.cuda.device(dev):
+        rc = lib().interpol_spline_filter(_ptr(data), _DTYPE_CODE[data.dtype], outer, n, inner,
+                                          int(bound), int(order), _stream(dev))
+    _check(rc, "interpol_spline_filter")
+    return data

@@ -1,0 +1,153 @@
+"""Public API: `grid_pull / grid_push / grid_count / grid_grad / spline_coeff /
+spline_coeff_nd` with the reference's signatures, defaults and shape
+conventions (reference interpol/api.py:149-445):
+
+    input : (..., [channel], *inshape)        grid : (..., *outshape, dim)
+
+Batch dimensions broadcast; an input with exactly `dim` dimensions has no
+channel axis.  Coordinates are in voxels, component d addresses spatial dim d.
+
+`interpolation`: 0..7 or 'nearest' | 'linear' | 'quadratic' | 'cubic' | 'fourth'
+| 'fifth' | 'sixth' | 'seventh' (or a per-dimension list).
+`bound`: 'zero' | 'replicate' ('nearest') | 'dct1' ('mirror') | 'dct2' ('reflect')
+| 'dst1' ('antimirror') | 'dst2' ('antireflect') | 'dft' ('wrap'), their aliases,
+int codes 0..6, or a per-dimension list.
+`extrapolate`: False/0 (zero outside the field of view), True/1, or 2 ('hist').
+"""
+import torch
+
+from . import backend
+from .autograd import GridPull, GridPush, GridCount, GridGrad, SplineCoeff, SplineCoeffND
+from .utils import expanded_shape
+
+__all__ = ['pull', 'push', 'count', 'grid_pull', 'grid_push', 'grid_count', 'grid_grad',
+           'spline_coeff', 'spline_coeff_nd']
+
+
+def _fold(grid, input=None, mode=None):
+    """Broadcast and reshape user tensors to the operator layout
+    (B, C, *spatial) / (B, *spatial, dim).  Same cases as the reference's
+    `_preproc` (interpol/api.py:93-130)."""
+    dim = grid.shape[-1]
+    if input is None:
+        spatial = grid.shape[-dim - 1:-1]
+        batch = grid.shape[:-dim - 1]
+        info = dict(batch=list(batch), channel=[1] if batch else [], dim=dim)
+        return grid.reshape([-1, *spatial, dim]), info
+
+    grid_spatial = grid.shape[-dim - 1:-1]
+    grid_batch = grid.shape[:-dim - 1]
+    input_spatial = input.shape[-dim:]
+    channel = 0 if input.dim() == dim else input.shape[-dim - 1]
+    input_batch = input.shape[:-dim - 1]
+    if mode == 'push':
+        grid_spatial = input_spatial = expanded_shape(grid_spatial, input_spatial)
+
+    batch = expanded_shape(grid_batch, input_batch)
+    grid = grid.expand([*batch, *grid_spatial, dim]).reshape([-1, *grid_spatial, dim])
+    input = input.expand([*batch, channel or 1, *input_spatial]).reshape([-1, channel or 1, *input_spatial])
+    out_channel = [channel] if channel else ([1] if batch else [])
+    return grid, input, dict(batch=list(batch), channel=out_channel, dim=dim)
+
+
+def _unfold(out, info, mode):
+    """Inverse of `_fold` on the result (reference `_postproc`, api.py:133-146)."""
+    dim = info['dim']
+    if mode == 'grad':
+        spatial, feat = out.shape[-dim - 1:-1], [out.shape[-1]]
+    else:
+        spatial, feat = out.shape[-dim:], []
+    return out.reshape([*info['batch'], *info['channel'], *spatial, *feat])
+
+
+def grid_pull(input, grid, interpolation='linear', bound='zero', extrapolate=False, prefilter=False):
+    """Sample an image at the coordinates of a deformation field.
+
+    input (..., [channel], *inshape), grid (..., *outshape, dim) -> (..., [channel], *outshape).
+    Non floating-point inputs are treated as label maps: every label is
+    resampled as a soft label and the arg-max is returned (api.py:194-205).
+    """
+    if backend.jitfields:
+        raise RuntimeError('the jitfields backend is not part of the MI355X build')
+    grid, input, info = _fold(grid, input)
+    batch, channel = input.shape[:2]
+    dim = grid.shape[-1]
+
+    if not input.dtype.is_floating_point:
+        out = input.new_zeros([batch, channel, *grid.shape[1:-1]])
+        pmax = grid.new_zeros([batch, channel, *grid.shape[1:-1]])
+        for label in input.unique():
+            soft = (input == label).to(grid.dtype)
+            if prefilter:
+                soft = spline_coeff_nd(soft, interpolation=interpolation, bound=bound, dim=dim, inplace=True)
+            soft = GridPull.apply(soft, grid, interpolation, bound, extrapolate)
+            out[soft > pmax] = label
+            pmax = torch.max(pmax, soft)
+    else:
+        if prefilter:
+            input = spline_coeff_nd(input, interpolation=interpolation, bound=bound, dim=dim)
+        out = GridPull.apply(input, grid, interpolation, bound, extrapolate)
+    return _unfold(out, info, 'pull')
+
+
+def grid_push(input, grid, shape=None, interpolation='linear', bound='zero', extrapolate=False,
+              prefilter=False):
+    """Splat an image along a deformation field (adjoint of `grid_pull`).
+
+    input (..., [channel], *inshape), grid (..., *inshape, dim) -> (..., [channel], *shape);
+    `shape` defaults to `inshape`.
+    """
+    if backend.jitfields:
+        raise RuntimeError('the jitfields backend is not part of the MI355X build')
+    grid, input, info = _fold(grid, input, mode='push')
+    dim = grid.shape[-1]
+    if shape is None:
+        shape = tuple(input.shape[2:])
+    out = GridPush.apply(input, grid, shape, interpolation, bound, extrapolate)
+    if prefilter:
+        out = spline_coeff_nd(out, interpolation=interpolation, bound=bound, dim=dim, inplace=True)
+    return _unfold(out, info, 'push')
+
+
+def grid_count(grid, shape=None, interpolation='linear', bound='zero', extrapolate=False):
+    """Splat ones: grid (..., *inshape, dim) -> (..., [1], *shape)."""
+    if backend.jitfields:
+        raise RuntimeError('the jitfields backend is not part of the MI355X build')
+    grid, info = _fold(grid)
+    out = GridCount.apply(grid, shape, interpolation, bound, extrapolate)
+    return _unfold(out, info, 'count')
+
+
+def grid_grad(input, grid, interpolation='linear', bound='zero', extrapolate=False, prefilter=False):
+    """Sample the spatial gradient of an image (voxel units):
+    input (..., [channel], *inshape), grid (..., *outshape, dim) -> (..., [channel], *outshape, dim)."""
+    if backend.jitfields:
+        raise RuntimeError('the jitfields backend is not part of the MI355X build')
+    grid, input, info = _fold(grid, input)
+    dim = grid.shape[-1]
+    if prefilter:
+        input = spline_coeff_nd(input, interpolation, bound, dim)
+    out = GridGrad.apply(input, grid, interpolation, bound, extrapolate)
+    return _unfold(out, info, 'grad')
+
+
+def spline_coeff(input, interpolation='linear', bound='dct2', dim=-1, inplace=False):
+    """Interpolating B-spline coefficients along ONE dimension.
+    Bounds: zero (-> dct1), replicate (-> dct2), dct1, dct2, dft; dst1/dst2 raise
+    NotImplementedError (reference interpol/coeff.py:231-254)."""
+    if backend.jitfields:
+        raise RuntimeError('the jitfields backend is not part of the MI355X build')
+    return SplineCoeff.apply(input, bound, interpolation, dim, inplace)
+
+
+def spline_coeff_nd(input, interpolation='linear', bound='dct2', dim=None, inplace=False):
+    """Interpolating B-spline coefficients along the last `dim` dimensions
+    (ALL dimensions when `dim` is None)."""
+    if backend.jitfields:
+        raise RuntimeError('the jitfields backend is not part of the MI355X build')
+    return SplineCoeffND.apply(input, bound, interpolation, dim, inplace)
+
+
+pull = grid_pull
+push = grid_push
+count = grid_count

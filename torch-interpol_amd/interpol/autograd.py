@@ -1,0 +1,159 @@
+"""Differentiable operators (autograd boundary).
+
+Counterpart of the reference's `interpol/autograd.py:157-333`: six
+`torch.autograd.Function`s with the same `apply(...)` signatures, the same
+alias handling (`bound_to_nitorch` / `inter_to_nitorch`), float32 up-casting
+under CUDA autocast, and `requires_grad`-driven skipping in backward.  The
+forward and backward bodies call the fused HIP operators of `ops.py`.
+"""
+import torch
+
+from . import ops
+from .coeff import _spline_coeff, _spline_coeff_nd
+from .codes import bound_to_code, order_to_code
+
+try:                                    # torch >= 2.4
+    from torch.amp import custom_fwd, custom_bwd
+    _fwd32 = custom_fwd(device_type='cuda', cast_inputs=torch.float32)
+    _fwd = custom_fwd(device_type='cuda')
+    _bwd = custom_bwd(device_type='cuda')
+except ImportError:                     # pragma: no cover
+    from torch.cuda.amp import custom_fwd, custom_bwd
+    _fwd32 = custom_fwd(cast_inputs=torch.float32)
+    _fwd = custom_fwd
+    _bwd = custom_bwd
+
+
+def _as_list(x):
+    return list(x) if isinstance(x, (list, tuple)) else [x]
+
+
+def _options(bound, interpolation, extrapolate):
+    return ([bound_to_code(b) for b in _as_list(bound)],
+            [order_to_code(o) for o in _as_list(interpolation)],
+            int(extrapolate))
+
+
+class GridPull(torch.autograd.Function):
+    """reference interpol/autograd.py:157-184"""
+
+    @staticmethod
+    @_fwd32
+    def forward(ctx, input, grid, interpolation, bound, extrapolate):
+        opt = _options(bound, interpolation, extrapolate)
+        output = ops.grid_pull(input, grid, *opt)
+        ctx.opt = opt
+        ctx.save_for_backward(input, grid)
+        return output
+
+    @staticmethod
+    @_bwd
+    def backward(ctx, grad):
+        input, grid = ctx.saved_tensors
+        grad_input, grad_grid = ops.grid_pull_backward(
+            grad, input, grid, *ctx.opt,
+            need_inp=ctx.needs_input_grad[0], need_grid=ctx.needs_input_grad[1])
+        return grad_input, grad_grid, None, None, None
+
+
+class GridPush(torch.autograd.Function):
+    """reference interpol/autograd.py:187-214"""
+
+    @staticmethod
+    @_fwd32
+    def forward(ctx, input, grid, shape, interpolation, bound, extrapolate):
+        opt = _options(bound, interpolation, extrapolate)
+        output = ops.grid_push(input, grid, shape, *opt)
+        ctx.opt = opt
+        ctx.save_for_backward(input, grid)
+        return output
+
+    @staticmethod
+    @_bwd
+    def backward(ctx, grad):
+        input, grid = ctx.saved_tensors
+        grad_input, grad_grid = ops.grid_push_backward(
+            grad, input, grid, *ctx.opt,
+            need_inp=ctx.needs_input_grad[0], need_grid=ctx.needs_input_grad[1])
+        return grad_input, grad_grid, None, None, None, None
+
+
+class GridCount(torch.autograd.Function):
+    """reference interpol/autograd.py:217-245"""
+
+    @staticmethod
+    @_fwd32
+    def forward(ctx, grid, shape, interpolation, bound, extrapolate):
+        opt = _options(bound, interpolation, extrapolate)
+        output = ops.grid_count(grid, shape, *opt)
+        ctx.opt = opt
+        ctx.save_for_backward(grid)
+        return output
+
+    @staticmethod
+    @_bwd
+    def backward(ctx, grad):
+        grid, = ctx.saved_tensors
+        grad_grid = None
+        if ctx.needs_input_grad[0]:
+            grad_grid = ops.grid_count_backward(grad, grid, *ctx.opt, need_grid=True)
+        return grad_grid, None, None, None, None
+
+
+class GridGrad(torch.autograd.Function):
+    """reference interpol/autograd.py:248-277"""
+
+    @staticmethod
+    @_fwd32
+    def forward(ctx, input, grid, interpolation, bound, extrapolate):
+        opt = _options(bound, interpolation, extrapolate)
+        output = ops.grid_grad(input, grid, *opt)
+        ctx.opt = opt
+        ctx.save_for_backward(input, grid)
+        return output
+
+    @staticmethod
+    @_bwd
+    def backward(ctx, grad):
+        input, grid = ctx.saved_tensors
+        grad_input = grad_grid = None
+        if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
+            grad_input, grad_grid = ops.grid_grad_backward(
+                grad, input, grid, *ctx.opt,
+                need_inp=ctx.needs_input_grad[0], need_grid=ctx.needs_input_grad[1])
+        return grad_input, grad_grid, None, None, None
+
+
+class SplineCoeff(torch.autograd.Function):
+    """reference interpol/autograd.py:280-305"""
+
+    @staticmethod
+    @_fwd
+    def forward(ctx, input, bound, interpolation, dim, inplace):
+        bound = bound_to_code(_as_list(bound)[0])
+        interpolation = order_to_code(_as_list(interpolation)[0])
+        ctx.opt = (bound, interpolation, dim)
+        return _spline_coeff(input, bound, interpolation, dim, inplace)
+
+    @staticmethod
+    @_bwd
+    def backward(ctx, grad):
+        # the filter is symmetric: backward == forward (autograd.py:300-305)
+        return _spline_coeff(grad, *ctx.opt, inplace=False), None, None, None, None
+
+
+class SplineCoeffND(torch.autograd.Function):
+    """reference interpol/autograd.py:308-333"""
+
+    @staticmethod
+    @_fwd
+    def forward(ctx, input, bound, interpolation, dim, inplace):
+        bound = [bound_to_code(b) for b in _as_list(bound)]
+        interpolation = [order_to_code(o) for o in _as_list(interpolation)]
+        ctx.opt = (bound, interpolation, dim)
+        return _spline_coeff_nd(input, bound, interpolation, dim, inplace)
+
+    @staticmethod
+    @_bwd
+    def backward(ctx, grad):
+        return _spline_coeff_nd(grad, *ctx.opt, inplace=False), None, None, None, None

@@ -1,0 +1,192 @@
+"""Operator seam: non-differentiable forward / backward operators.
+
+Same functions, argument order and tensor layouts as the reference's
+`interpol/pushpull.py` (grid_pull 35-66, grid_push 70-102, grid_count 106-142,
+grid_grad 146-172, grid_pushgrad 176-203, grid_hess 207-233 and the four
+`*_backward` compositions 237-325):
+
+    inp  : (B, C, *spatial_in)      grid : (B, *spatial_out, D)
+    bound / interpolation : lists of int codes, padded/truncated to D
+    extrapolate : 0 | 1 | 2
+
+but every operator is ONE fused HIP kernel launch (see `csrc/`) instead of
+(order+1)^D passes of gather/scatter + broadcast multiplies, and the backward
+operators are fused too (no (B,C,N,D) temporary).
+
+`use_kernels(table)` swaps the kernel table; it exists for the CPU-side tests
+of the host logic (shape conventions, autograd wiring) and is never used by the
+product path, whose default table is the HIP library.
+"""
+import contextlib
+
+import torch
+
+from . import _hip
+from .codes import pad_codes
+
+
+class _HipKernels:
+    """Default kernel table: the gfx950 library behind the C-ABI."""
+
+    @staticmethod
+    def pull(inp, grid, bound, order, extrapolate):
+        return _hip.gather("pull", inp, grid, bound, order, extrapolate)
+
+    @staticmethod
+    def grad(inp, grid, bound, order, extrapolate):
+        return _hip.gather("grad", inp, grid, bound, order, extrapolate)
+
+    @staticmethod
+    def hess(inp, grid, bound, order, extrapolate):
+        return _hip.gather("hess", inp, grid, bound, order, extrapolate)
+
+    @staticmethod
+    def push(inp, grid, shape, bound, order, extrapolate):
+        return _hip.scatter("push", inp, grid, shape, bound, order, extrapolate)
+
+    @staticmethod
+    def count(grid, shape, bound, order, extrapolate):
+        return _hip.scatter("count", None, grid, shape, bound, order, extrapolate)
+
+    @staticmethod
+    def pushgrad(inp, grid, shape, bound, order, extrapolate):
+        return _hip.scatter("pushgrad", inp, grid, shape, bound, order, extrapolate)
+
+    @staticmethod
+    def pull_backward(grad, inp, grid, bound, order, extrapolate, need_inp, need_grid):
+        return _hip.pull_backward(grad, inp, grid, bound, order, extrapolate, need_inp, need_grid)
+
+    @staticmethod
+    def push_backward(grad, inp, grid, bound, order, extrapolate, need_inp, need_grid):
+        return _hip.push_backward(grad, inp, grid, bound, order, extrapolate, need_inp, need_grid)
+
+    @staticmethod
+    def count_backward(grad, grid, bound, order, extrapolate):
+        return _hip.push_backward(grad, None, grid, bound, order, extrapolate, False, True)[1]
+
+    @staticmethod
+    def spline_filter_(data, bound, order, dim):
+        return _hip.spline_filter_(data, bound, order, dim)
+
+
+_kernels = _HipKernels
+
+
+@contextlib.contextmanager
+def use_kernels(table):
+    """TEST HOOK: temporarily replace the kernel table (see module docstring)."""
+    global _kernels
+    old = _kernels
+    _kernels = table
+    try:
+        yield
+    finally:
+        _kernels = old
+
+
+def kernels():
+    return _kernels
+
+
+def _codes(grid, bound, interpolation):
+    dim = grid.shape[-1]
+    return pad_codes(bound, dim), pad_codes(interpolation, dim)
+
+
+def _check_push_shapes(inp, grid, trailing=0):
+    dim = grid.shape[-1]
+    isp = tuple(inp.shape[2:2 + dim]) if trailing else tuple(inp.shape[-dim:])
+    if isp != tuple(grid.shape[1:-1]):
+        # reference interpol/iso1.py:149-150, iso0.py:82-83
+        raise ValueError('Input and grid should have the same spatial shape')
+
+
+def grid_pull(inp, grid, bound, interpolation, extrapolate):
+    """(B,C,*in), (B,*out,D) -> (B,C,*out).   Reference pushpull.py:35-66."""
+    bound, interpolation = _codes(grid, bound, interpolation)
+    return _kernels.pull(inp, grid, bound, interpolation, int(extrapolate))
+
+
+def grid_push(inp, grid, shape, bound, interpolation, extrapolate):
+    """(B,C,*in), (B,*in,D) -> (B,C,*shape).   Reference pushpull.py:70-102."""
+    bound, interpolation = _codes(grid, bound, interpolation)
+    _check_push_shapes(inp, grid)
+    shape = None if shape is None else list(shape)
+    return _kernels.push(inp, grid, shape, bound, interpolation, int(extrapolate))
+
+
+def grid_count(grid, shape, bound, interpolation, extrapolate):
+    """(B,*in,D) -> (B,1,*shape).   Reference pushpull.py:106-142."""
+    bound, interpolation = _codes(grid, bound, interpolation)
+    shape = None if shape is None else list(shape)
+    return _kernels.count(grid, shape, bound, interpolation, int(extrapolate))
+
+
+def grid_grad(inp, grid, bound, interpolation, extrapolate):
+    """(B,C,*in), (B,*out,D) -> (B,C,*out,D).   Reference pushpull.py:146-172."""
+    bound, interpolation = _codes(grid, bound, interpolation)
+    return _kernels.grad(inp, grid, bound, interpolation, int(extrapolate))
+
+
+def grid_pushgrad(inp, grid, shape, bound, interpolation, extrapolate):
+    """(B,C,*in,D), (B,*in,D) -> (B,C,*shape).   Reference pushpull.py:176-203."""
+    bound, interpolation = _codes(grid, bound, interpolation)
+    _check_push_shapes(inp, grid, trailing=1)
+    shape = None if shape is None else list(shape)
+    return _kernels.pushgrad(inp, grid, shape, bound, interpolation, int(extrapolate))
+
+
+def grid_hess(inp, grid, bound, interpolation, extrapolate):
+    """(B,C,*in), (B,*out,D) -> (B,C,*out,D,D).   Reference pushpull.py:207-233."""
+    bound, interpolation = _codes(grid, bound, interpolation)
+    return _kernels.hess(inp, grid, bound, interpolation, int(extrapolate))
+
+
+def grid_pull_backward(grad, inp, grid, bound, interpolation, extrapolate,
+                       need_inp=None, need_grid=None):
+    """-> (grad_inp (B,C,*in) | None, grad_grid (B,*out,D) | None).
+    Reference pushpull.py:237-258; gradients are only computed for the inputs
+    that require them (pushpull.py:252-255)."""
+    bound, interpolation = _codes(grid, bound, interpolation)
+    need_inp = inp.requires_grad if need_inp is None else need_inp
+    need_grid = grid.requires_grad if need_grid is None else need_grid
+    if not (need_inp or need_grid):
+        return None, None
+    return _kernels.pull_backward(grad, inp, grid, bound, interpolation, int(extrapolate), need_inp, need_grid)
+
+
+def grid_push_backward(grad, inp, grid, bound, interpolation, extrapolate,
+                       need_inp=None, need_grid=None):
+    """-> (grad_inp (B,C,*in) | None, grad_grid (B,*in,D) | None).
+    Reference pushpull.py:262-282."""
+    bound, interpolation = _codes(grid, bound, interpolation)
+    need_inp = inp.requires_grad if need_inp is None else need_inp
+    need_grid = grid.requires_grad if need_grid is None else need_grid
+    if not (need_inp or need_grid):
+        return None, None
+    return _kernels.push_backward(grad, inp, grid, bound, interpolation, int(extrapolate), need_inp, need_grid)
+
+
+def grid_count_backward(grad, grid, bound, interpolation, extrapolate, need_grid=None):
+    """-> grad_grid (B,*in,D) | None.   Reference pushpull.py:286-299."""
+    bound, interpolation = _codes(grid, bound, interpolation)
+    need_grid = grid.requires_grad if need_grid is None else need_grid
+    if not need_grid:
+        return None
+    return _kernels.count_backward(grad, grid, bound, interpolation, int(extrapolate))
+
+
+def grid_grad_backward(grad, inp, grid, bound, interpolation, extrapolate,
+                       need_inp=None, need_grid=None):
+    """-> (grad_inp (B,C,*in) | None, grad_grid (B,*out,D) | None); only reached
+    by double backward.   Reference pushpull.py:303-325."""
+    dim = grid.shape[-1]
+    need_inp = inp.requires_grad if need_inp is None else need_inp
+    need_grid = grid.requires_grad if need_grid is None else need_grid
+    grad_inp = grad_grid = None
+    if need_inp:
+        grad_inp = grid_pushgrad(grad, grid, inp.shape[-dim:], bound, interpolation, extrapolate)
+    if need_grid:
+        hess = grid_hess(inp, grid, bound, interpolation, extrapolate)
+        grad_grid = (hess * grad.unsqueeze(-1)).sum(dim=[1, -2])
+    return grad_inp, grad_grid

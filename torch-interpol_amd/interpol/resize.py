@@ -1,0 +1,52 @@
+"""`resize`: sample an image on a regular (separable) lattice with `grid_pull`.
+Caller of the hot path; same signature and anchor conventions as the
+reference's `interpol/resize.py:13-119`."""
+import torch
+
+from .api import grid_pull
+from .utils import make_list
+
+__all__ = ['resize']
+
+
+def _lattice(anchor, factor, n_in, n_out, **bck):
+    """1-D sampling positions (voxels of the input) for one dimension."""
+    if anchor == 'c':       # centres of the corner voxels are aligned
+        return torch.linspace(0, n_in - 1, n_out, **bck)
+    if anchor == 'e':       # edges of the corner voxels are aligned
+        scale = n_in / n_out
+        return torch.arange(0., n_out, **bck) * scale + 0.5 * (scale - 1)
+    if anchor == 'f':       # first voxel aligned, exact factor
+        return torch.arange(0., n_out, **bck) / factor
+    if anchor == 'l':       # last voxel aligned, exact factor
+        return torch.arange(0., n_out, **bck) / factor + ((n_in - 1) - (n_out - 1) / factor)
+    raise ValueError('Unknown anchor {}'.format(anchor))
+
+
+def resize(image, factor=None, shape=None, anchor='c', interpolation=1, prefilter=True, **kwargs):
+    """Resize (batch, channel, *inshape) by `factor` and/or to `shape`.
+    Defaults: bound='nearest', extrapolate=True, prefilter=True (resize.py:112-115)."""
+    factor = make_list(factor) if factor else []
+    shape = make_list(shape) if shape else []
+    anchor = make_list(anchor)
+    nb_dim = max(len(factor), len(shape), len(anchor)) or (image.dim() - 2)
+    anchor = [a[0].lower() for a in make_list(anchor, nb_dim)]
+    bck = dict(dtype=image.dtype, device=image.device)
+    inshape = image.shape[-nb_dim:]
+    if factor:
+        factor = make_list(factor, nb_dim)
+    elif not shape:
+        raise ValueError('One of `factor` or `shape` must be provided')
+    if shape:
+        shape = make_list(shape, nb_dim)
+    else:
+        shape = [int(i * f) for i, f in zip(inshape, factor)]
+    if not factor:
+        factor = [o / i for o, i in zip(shape, inshape)]
+    lin = [_lattice(a, f, i, o, **bck) for a, f, i, o in zip(anchor, factor, inshape, shape)]
+    kwargs.setdefault('bound', 'nearest')
+    kwargs.setdefault('extrapolate', True)
+    kwargs.setdefault('interpolation', interpolation)
+    kwargs.setdefault('prefilter', prefilter)
+    grid = torch.stack(torch.meshgrid(*lin, indexing='ij'), dim=-1)
+    return grid_pull(image, grid, **kwargs)
