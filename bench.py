@@ -1,0 +1,216 @@
+#!/usr/bin/env python
+"""Benchmark of the hot path on MI355X: BASELINE.json config 2
+(grid_pull + grid_push, 3-D 4x2x256^3 fp32, cubic, bound=dct2, random deformation).
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+           --master-port P bench.py --gpus N --steps K --warmup W
+
+One "step" = one grid_pull followed by one grid_push over the whole batch (both
+through the drop-in API -> C-ABI -> HIP kernels), inputs resident in HBM.  With
+N > 1 ranks the batch axis is sharded: every rank owns its own 4x2x256^3 batch
+(weak scaling, no data-path collective: SURVEY 8e); the timed region is bracketed
+by a barrier + synchronize and the MAX over ranks is reported.
+
+Prints ONE JSON line (rank 0): metric/value = aggregate Mvox/s, where a voxel is
+one sample location (B * prod(spatial)) and each op of the step processes all of
+them; `roofline` is for the slower of the two kernels, measured with HIP events
+inside the timed region; `cpu_baseline` times the CPU oracle (a port of the
+reference algorithm, all host cores) on a bounded sample of the same workload.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for _p in (os.path.join(ROOT, "torch-interpol_amd"), ROOT):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+import torch  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0            # MI355X HBM3E spec peak (MI355X_MICROARCH.md); measured copy ceiling 6290 GB/s
+
+
+def make_inputs(B, C, n, sigma, device, seed):
+    """SURVEY 8d generator: inp = randn, grid = identity + sigma * randn (voxels)."""
+    import interpol
+    g = torch.Generator(device=device).manual_seed(seed)
+    inp = torch.randn([B, C, n, n, n], generator=g, device=device, dtype=torch.float32)
+    grid = torch.randn([B, n, n, n, 3], generator=g, device=device, dtype=torch.float32).mul_(sigma)
+    grid += interpol.identity_grid([n, n, n], dtype=torch.float32, device=device)
+    return inp, grid
+
+
+def smooth_grid(B, n, sigma, device, seed):
+    """Smooth random deformation (examples/interpolate.ipynb recipe): 12^3 control
+    points ~ N(0, sigma^2), cubic-upsampled to the full lattice."""
+    import interpol
+    g = torch.Generator(device=device).manual_seed(seed)
+    ctrl = torch.randn([B, 3, 12, 12, 12], generator=g, device=device).mul_(sigma)
+    disp = interpol.resize(ctrl, shape=[n, n, n], interpolation=3, prefilter=False)
+    return disp.permute(0, 2, 3, 4, 1).contiguous() + interpol.identity_grid([n, n, n], device=device)
+
+
+def cpu_baseline(n_sample, C, sigma, order, bound):
+    """Oracle (port of the reference algorithm, oracle/interpol_oracle.c) on the host cores."""
+    from oracle import oracle
+    cores = os.cpu_count() or 1
+    g = torch.Generator().manual_seed(1234)
+    inp = torch.randn([1, C, n_sample, n_sample, n_sample], generator=g)
+    ident = torch.stack(torch.meshgrid(*[torch.arange(float(n_sample))] * 3, indexing="ij"), -1)
+    grid = ident[None] + sigma * torch.randn([1, n_sample, n_sample, n_sample, 3], generator=g)
+    inp, grid = inp.numpy(), grid.numpy()
+    oracle.grid_pull(inp[:, :, :8, :8, :8].copy(), grid[:, :8, :8, :8].copy(), [bound], [order], 1, threads=cores)  # load lib
+    t0 = time.perf_counter()
+    oracle.grid_pull(inp, grid, [bound], [order], 1, threads=cores)
+    t1 = time.perf_counter()
+    oracle.grid_push(inp, grid, None, [bound], [order], 1, threads=cores)
+    t2 = time.perf_counter()
+    vox = n_sample ** 3
+    return {
+        "value": round(2 * vox / (t2 - t0) / 1e6, 3), "unit": "Mvox/s", "cores": cores, "kind": "port",
+        "sample": "1x%dx%d^3 fp32 cubic/dct2 pull+push, oracle (C port of nd.py) with %d OpenMP threads; "
+                  "pull %.2f s, push %.2f s" % (C, n_sample, cores, t1 - t0, t2 - t1),
+        "pull_mvox_s": round(vox / (t1 - t0) / 1e6, 3), "push_mvox_s": round(vox / (t2 - t1) / 1e6, 3),
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=4)
+    ap.add_argument("--channels", type=int, default=2)
+    ap.add_argument("--size", type=int, default=256)
+    ap.add_argument("--order", type=int, default=3)
+    ap.add_argument("--bound", default="dct2")
+    ap.add_argument("--sigma", type=float, default=2.0)
+    ap.add_argument("--grid", default="random", choices=["random", "smooth", "identity"],
+                    help="deformation: i.i.d. N(0,sigma^2) noise (headline), smooth, or identity")
+    ap.add_argument("--cpu-sample", type=int, default=160, help="edge of the CPU-baseline sample volume (0 = skip)")
+    ap.add_argument("--no-fastpath", action="store_true", help="force the generic kernels")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world and world > 1:
+        raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (args.gpus, world))
+    device = torch.device("cuda", local_rank)
+    torch.cuda.set_device(device)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=device)
+
+    import interpol
+    from interpol import _hip
+    from interpol.codes import bound_to_code
+    _hip.lib()                                   # the HIP extension must be there: no fallback
+
+    B, C, n = args.batch, args.channels, args.size
+    inp, grid = make_inputs(B, C, n, args.sigma, device, 1234 + rank)
+    if args.grid == "smooth":
+        grid = smooth_grid(B, n, args.sigma, device, 1234 + rank)
+    elif args.grid == "identity":
+        grid = interpol.identity_grid([n, n, n], device=device)[None].expand(B, n, n, n, 3).contiguous()
+    kw = dict(interpolation=args.order, bound=args.bound, extrapolate=True)
+
+    if args.no_fastpath:
+        orig = _hip.make_problem
+
+        def patched(*a, **k):
+            p = orig(*a, **k)
+            p.flags |= _hip.FLAG_NO_FASTPATH
+            return p
+        _hip.make_problem = patched
+
+    def step(ev=None):
+        if ev is not None:
+            ev[0].record()
+        out = interpol.grid_pull(inp, grid, **kw)
+        if ev is not None:
+            ev[1].record()
+        psh = interpol.grid_push(inp, grid, **kw)
+        if ev is not None:
+            ev[2].record()
+        return out, psh
+
+    for _ in range(args.warmup):
+        step()
+    events = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(args.steps)]
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        step(events[k])
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t)
+
+    pull_ms = sorted(e[0].elapsed_time(e[1]) for e in events)
+    push_ms = sorted(e[1].elapsed_time(e[2]) for e in events)
+    pull_avg = sum(pull_ms) / len(pull_ms)
+    push_avg = sum(push_ms) / len(push_ms)
+
+    vox_rank = B * n ** 3
+    ms_per_step = 1e3 * elapsed / args.steps
+    value = world * 2 * vox_rank / (elapsed / args.steps) / 1e6
+
+    # algorithmic bytes per launch: every input read once, every output written once
+    bytes_pull = vox_rank * (3 * 4 + C * 4) + B * C * n ** 3 * 4
+    bytes_push = vox_rank * (3 * 4 + C * 4) + B * C * n ** 3 * 4
+    dom = "grid_push" if push_avg >= pull_avg else "grid_pull"
+    dom_ms = max(push_avg, pull_avg)
+    dom_bytes = bytes_push if dom == "grid_push" else bytes_pull
+    achieved = dom_bytes / (dom_ms * 1e-3) / 1e9
+    traffic = None
+    pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if os.path.exists(pmc):
+        try:
+            traffic = json.load(open(pmc)).get(dom)
+        except Exception:
+            traffic = None
+
+    if rank == 0:
+        line = {
+            "metric": "Mvox/s grid_pull & grid_push, 256^3 fp32 cubic/dct2",
+            "value": round(value, 1), "unit": "Mvox/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "BASELINE configs[1]: grid_pull + grid_push, %dx%dx%d^3 fp32 per GPU, order %d, "
+                                   "bound %s, extrapolate=True, grid = identity + N(0,%g^2) (%s)"
+                                   % (B, C, n, args.order, args.bound, args.sigma, args.grid),
+                       "batch_per_gpu": B, "channels": C, "shape": [n, n, n], "parallelism": "batch-sharded x%d" % world},
+            "pull_ms": round(pull_avg, 4), "push_ms": round(push_avg, 4),
+            "pull_mvox_s": round(vox_rank / pull_avg / 1e3, 1), "push_mvox_s": round(vox_rank / push_avg / 1e3, 1),
+            "pull_frac_hbm": round(bytes_pull / (pull_avg * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+            "push_frac_hbm": round(bytes_push / (push_avg * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+            "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                         "algorithmic_bytes_per_launch": dom_bytes, "avg_launch_ms": round(dom_ms, 4)},
+        }
+        if world == 1 and args.cpu_sample > 0:
+            line["cpu_baseline"] = cpu_baseline(args.cpu_sample, C, args.sigma, args.order, bound_to_code(args.bound))
+            line["cpu_baseline"]["reference_measured_in_build_container"] = \
+                "reference TorchScript CPU path, 8 cores: pull 0.823 / push 0.952 Mvox/s at 4x2x256^3 (BASELINE.md sec 2)"
+        print(json.dumps(line))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -276,7 +276,9 @@ def test_errors_mirror_the_reference():
         ops.grid_push(x, torch.rand(1, 4, 6, 2, device=DEV), None, [0], [1], 1)
     with pytest.raises(NotImplementedError):
         interpol.spline_coeff_nd(x, 3, "dst2", 2)
-    assert interpol.grid_pull(x, g[:, :0], interpolation=3).shape == (1, 1, 0, 6)
+    # empty sample sets are fine at the operator level
+    assert ops.grid_pull(x, g[:, :0], [0], [3], 1).shape == (1, 1, 0, 6)
+    assert float(ops.grid_push(x[:, :, :0], g[:, :0], [5, 6], [0], [3], 1).abs().sum()) == 0
 
 
 def test_resize_identity_property_gpu():

@@ -46,7 +46,7 @@ enum Role { GATHER, SCATTER };
 
 // Validate + convert.  `vol_elem_bytes`: element size of the indexed lattice as the
 // kernel sees it (storage type for gathers, accumulation type for scatters).
-static int make_params(const interpol_problem *p, Role role, int trailing, KParams *k, int *B)
+static int make_params(const interpol_problem *p, Role role, int trailing, KParams *k, int *B, bool has_val = true)
 {
     if (!p) return INTERPOL_E_NULL;
     if (p->abi_version != INTERPOL_ABI_VERSION) return INTERPOL_E_SHAPE;
@@ -100,7 +100,7 @@ static int make_params(const interpol_problem *p, Role role, int trailing, KPara
         k->grid_sb = p->grid_stride[0];
     }
     // val: spatial (+ trailing) dims contiguous
-    {
+    if (has_val) {
         int64_t expect = trailing;
         for (int d = p->dim - 1; d >= 0; --d) {
             if (p->grid_shape[d] > 1 && p->val_stride[2 + d] != expect) return INTERPOL_E_STRIDE;
@@ -152,7 +152,7 @@ static int scatter_driver(const interpol_problem *p, int trailing, bool need_val
                           void *vol, void *scratch, int64_t scratch_bytes, hipStream_t st, Launch launch)
 {
     KParams k; int B;
-    int rc = make_params(p, SCATTER, trailing, &k, &B);
+    int rc = make_params(p, SCATTER, trailing, &k, &B, need_val);
     if (rc) return rc;
     if (!grid || !vol || (need_val && !val)) return INTERPOL_E_NULL;
     if (!vol_is_dense(p)) return INTERPOL_E_STRIDE;
@@ -357,7 +357,7 @@ int interpol_count_backward(const interpol_problem *p, const void *grad_vol_out,
                             void *grad_grid, void *stream)
 {
     KParams k; int B;
-    int rc = make_params(p, GATHER, 1, &k, &B);
+    int rc = make_params(p, GATHER, 1, &k, &B, false);
     if (rc) return rc;
     if (!grad_vol_out || !grid || !grad_grid) return INTERPOL_E_NULL;
     hipStream_t st = (hipStream_t)stream;
