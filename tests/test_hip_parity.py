@@ -297,3 +297,54 @@ def test_autocast_casts_to_fp32():
     with torch.autocast("cuda", dtype=torch.bfloat16):
         y = interpol.grid_pull(x, g, interpolation=3, bound="dct2", extrapolate=True)
     assert y.dtype == torch.float32        # reference autograd.py:160 custom_fwd(cast_inputs=float32)
+
+
+# ---- LDS-tiled fast paths vs the generic kernels -----------------------------------
+
+@pytest.mark.parametrize("order", [1, 2, 3])
+@pytest.mark.parametrize("sigma", [0.0, 0.7, 2.0, 9.0])
+def test_tiled_pull_matches_generic(order, sigma):
+    """Same C-ABI call with and without INTERPOL_FLAG_NO_FASTPATH: all bounds, all
+    extrapolation modes, ragged sizes, small / moderate / pathological deformation
+    (sigma = 9 voxels overflows the in-LDS box and the slow list)."""
+    from interpol import _hip
+    ishape, oshape = (50, 37, 41), (35, 45, 30)
+    inp, grid = _rand_problem(2, 3, ishape, oshape, sigma, seed=int(order * 10 + sigma))
+    flat = grid.reshape(2, -1, 3)
+    flat[0, 0] = -3.0 * torch.tensor(ishape)          # far outside
+    flat[0, 1] = 3.0 * torch.tensor(ishape) + 0.25
+    flat[1, 5] = 2.0
+    flat[1, 6] = 1.5
+    inp, grid = inp.to(DEV), grid.to(DEV)
+    for bound in range(7):
+        for ex in (1, 0, 2):
+            fast = _hip.gather("pull", inp, grid, [bound] * 3, [order] * 3, ex)
+            slow = _hip.gather("pull", inp, grid, [bound] * 3, [order] * 3, ex, flags=_hip.FLAG_NO_FASTPATH)
+            scale = float(slow.abs().max())
+            assert float((fast - slow).abs().max()) <= 2e-6 * scale, (bound, ex, order, sigma)
+    # mixed bounds per dim
+    fast = _hip.gather("pull", inp, grid, [4, 2, 6], [order] * 3, 1)
+    slow = _hip.gather("pull", inp, grid, [4, 2, 6], [order] * 3, 1, flags=_hip.FLAG_NO_FASTPATH)
+    assert float((fast - slow).abs().max()) <= 2e-6 * float(slow.abs().max())
+
+
+@pytest.mark.parametrize("order", [1, 2, 3])
+@pytest.mark.parametrize("sigma", [0.0, 0.7, 2.0, 9.0])
+def test_tiled_push_and_count_match_generic(order, sigma):
+    from interpol import _hip
+    ishape, tshape = (35, 45, 30), (50, 37, 41)      # source lattice, target lattice
+    _, grid = _rand_problem(2, 3, tshape, ishape, sigma, seed=int(order * 10 + sigma) + 1)
+    src = torch.randn([2, 3, *ishape], generator=torch.Generator().manual_seed(11))
+    flat = grid.reshape(2, -1, 3)
+    flat[0, 0] = -3.0 * torch.tensor(tshape)
+    flat[0, 1] = 3.0 * torch.tensor(tshape) + 0.25
+    src, grid = src.to(DEV), grid.to(DEV)
+    for bound in range(7):
+        for ex in (1, 0, 2):
+            b, o = [bound] * 3, [order] * 3
+            fast = _hip.scatter("push", src, grid, list(tshape), b, o, ex)
+            slow = _hip.scatter("push", src, grid, list(tshape), b, o, ex, flags=_hip.FLAG_NO_FASTPATH)
+            assert float((fast - slow).abs().max()) <= 1e-5 * float(slow.abs().max()), ("push", bound, ex, order, sigma)
+            fast = _hip.scatter("count", None, grid, list(tshape), b, o, ex)
+            slow = _hip.scatter("count", None, grid, list(tshape), b, o, ex, flags=_hip.FLAG_NO_FASTPATH)
+            assert float((fast - slow).abs().max()) <= 1e-5 * float(slow.abs().max()), ("count", bound, ex, order, sigma)

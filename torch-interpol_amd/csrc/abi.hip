@@ -272,6 +272,10 @@ int interpol_count(const interpol_problem *p, const void *grid, void *vol,
     if (p && p->channels != 1) return INTERPOL_E_SHAPE;
     hipStream_t st = (hipStream_t)stream;
     return scatter_driver(p, 1, false, nullptr, grid, vol, scratch, scratch_bytes, st, [&](const KParams &k, int B, void *acc) {
+        if (!(p->flags & INTERPOL_FLAG_NO_FASTPATH)) {
+            int rc = try_fast_push(p, k, nullptr, grid, acc, st);
+            if (rc != 0) return rc == 1 ? 0 : rc;
+        }
         return by_dtype(p->dtype,
             [&] { return launch_push_f32(k, nullptr, grid, acc, B, st); },
             [&] { return launch_push_f64(k, nullptr, grid, acc, B, st); },
