@@ -44,6 +44,7 @@ struct KParams {
     int vol_n[3];
     int vol_ss[3];          // spatial strides of vol in BYTES (whole image < 2^32 bytes, checked on host)
     int C;
+    int dbg;                // debug / ablation switches (interpol_problem.flags >> 8), 0 in production
     int64_t N;              // samples per batch item
     int64_t vol_sb, vol_sc;
     int64_t grid_sb;        // grid: spatial dims contiguous, component stride 1
