@@ -71,7 +71,9 @@ enum {
  * Supported patterns (else INTERPOL_E_STRIDE): gather sources (vol of pull/grad/
  * hess) may have ANY non-negative strides; grid and val must be row-major
  * contiguous over their spatial (+component) dims with free batch/channel
- * strides; scatter targets (vol of push/count/pushgrad) must be dense.
+ * strides; scatter targets (vol of push/count/pushgrad) must be dense, except
+ * that a batch stride of 0 makes ONE shared (C, *shape) target into which every
+ * batch item is accumulated (= grid_push(...).sum(0) of the reference).
  * One (batch, channel) image of vol must span < 4 GiB (32-bit byte offsets).
  * --------------------------------------------------------------------------- */
 typedef struct interpol_problem {

@@ -37,6 +37,16 @@ class OracleKernels:
         return oracle.grid_pushgrad(inp.detach(), grid.detach(), shape, bound, order, extrapolate)
 
     @staticmethod
+    def push_shared_(out, inp, grid, bound, order, extrapolate):
+        shape = list(out.shape[2:])
+        if inp is None:
+            r = oracle.grid_count(grid.detach(), shape, bound, order, extrapolate)
+        else:
+            r = oracle.grid_push(inp.detach(), grid.detach(), shape, bound, order, extrapolate)
+        out += torch.as_tensor(r).sum(0, keepdim=True).to(out.dtype)
+        return out
+
+    @staticmethod
     def pull_backward(grad, inp, grid, bound, order, extrapolate, need_inp, need_grid):
         gi, gg = oracle.grid_pull_backward(grad.detach(), inp.detach(), grid.detach(), bound, order, extrapolate)
         return (gi if need_inp else None), (gg if need_grid else None)

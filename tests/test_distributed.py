@@ -1,0 +1,80 @@
+"""N > 1 path on CPU: world_size-2 `gloo` processes exercise the batch sharding and
+the one collective of the path (sum-reduce of the shared push/count target).
+Compute goes through the TEST-ONLY oracle kernel table (no GPU here); on the GPU
+box the same code runs over RCCL with the HIP kernels (test_hip_parity.py)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _worker(rank, world, port, tmp):
+    sys.path.insert(0, HERE)
+    import conftest  # noqa: F401  (import paths)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import interpol
+    from interpol import ops
+    from interpol.distributed import push_count_shared, shard_range
+    from oracle_kernels import OracleKernels
+
+    g = torch.Generator().manual_seed(4321)          # same data on every rank, each takes its shard
+    B, C, n, m = 5, 2, 6, 12
+    inp = torch.randn([B, C, n, n, n], generator=g, dtype=torch.float64)
+    ident = torch.stack(torch.meshgrid(*[torch.arange(float(n))] * 3, indexing="ij"), -1)
+    grid = ident[None] * ((m - 1) / (n - 1)) + torch.randn([B, n, n, n, 3], generator=g, dtype=torch.float64)
+    lo, hi = shard_range(B, rank, world)
+    with ops.use_kernels(OracleKernels):
+        push, count = push_count_shared(inp[lo:hi], grid[lo:hi], [m, m, m], interpolation=3, bound="replicate",
+                                        extrapolate=True, reduce="all")
+        # sharded pull needs no communication: every rank computes its items
+        pulled = interpol.grid_pull(inp[lo:hi], grid[lo:hi], interpolation=3, bound="dct2", extrapolate=True)
+        p2, c2 = push_count_shared(inp[lo:hi], grid[lo:hi], [m, m, m], interpolation=3, bound="replicate",
+                                   extrapolate=True, reduce="dst", dst=1)
+    gathered = [None] * world
+    dist.all_gather_object(gathered, pulled.numpy())
+    if rank == 0:
+        np.savez(tmp, push=push.numpy(), count=count.numpy(), pulled=np.concatenate(gathered, 0),
+                 inp=inp.numpy(), grid=grid.numpy())
+    if rank == 1:
+        np.savez(tmp + ".dst", push=p2.numpy(), count=c2.numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_shard_range():
+    from interpol.distributed import shard_range
+    for n in (0, 1, 5, 8, 64):
+        for w in (1, 2, 3, 8):
+            cover = []
+            for r in range(w):
+                a, b = shard_range(n, r, w)
+                cover += list(range(a, b))
+                assert 0 <= b - a <= n // w + 1
+            assert cover == list(range(n))
+
+
+@pytest.mark.timeout(300)
+def test_push_count_shared_gloo_world2(tmp_path):
+    from oracle import oracle
+    port = 29500 + os.getpid() % 2000
+    tmp = str(tmp_path / "out.npz")
+    mp.spawn(_worker, args=(2, port, tmp), nprocs=2, join=True)
+    r = np.load(tmp)
+    m = 12
+    want_push = np.asarray(oracle.grid_push(r["inp"], r["grid"], [m, m, m], [1], [3], 1)).sum(0)
+    want_count = np.asarray(oracle.grid_count(r["grid"], [m, m, m], [1], [3], 1)).sum(0)
+    assert np.abs(r["push"] - want_push).max() < 1e-12 * np.abs(want_push).max()
+    assert np.abs(r["count"] - want_count).max() < 1e-12 * np.abs(want_count).max()
+    want_pull = np.asarray(oracle.grid_pull(r["inp"], r["grid"], [3], [3], 1))
+    assert np.array_equal(r["pulled"], want_pull)          # batch sharding == full-batch result
+    d = np.load(tmp + ".dst.npz")
+    assert np.abs(d["push"] - want_push).max() < 1e-12 * np.abs(want_push).max()
+    assert np.abs(d["count"] - want_count).max() < 1e-12 * np.abs(want_count).max()

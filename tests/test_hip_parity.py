@@ -348,3 +348,24 @@ def test_tiled_push_and_count_match_generic(order, sigma):
             fast = _hip.scatter("count", None, grid, list(tshape), b, o, ex)
             slow = _hip.scatter("count", None, grid, list(tshape), b, o, ex, flags=_hip.FLAG_NO_FASTPATH)
             assert float((fast - slow).abs().max()) <= 1e-5 * float(slow.abs().max()), ("count", bound, ex, order, sigma)
+
+
+def test_shared_target_push_count():
+    """BASELINE config 4 miniature: many sources splatted into ONE shared target
+    (batch-stride-0 target in the C-ABI) == reference grid_push(...).sum(0)."""
+    from interpol.distributed import push_count_shared
+    g = torch.Generator().manual_seed(99)
+    B, C, n, m = 6, 2, 24, 64
+    inp = torch.randn([B, C, n, n, n], generator=g)
+    ident = torch.stack(torch.meshgrid(*[torch.arange(float(n))] * 3, indexing="ij"), -1)
+    grid = ident[None] * ((m - 1) / (n - 1)) + 1.5 * torch.randn([B, n, n, n, 3], generator=g)
+    push, count = push_count_shared(inp.to(DEV), grid.to(DEV), [m, m, m], interpolation=3, bound="replicate",
+                                    extrapolate=True, reduce="none")
+    oracle.set_threads(8)
+    try:
+        want_push = np.asarray(oracle.grid_push(inp.double(), grid.double(), [m, m, m], [1], [3], 1)).sum(0)
+        want_count = np.asarray(oracle.grid_count(grid.double(), [m, m, m], [1], [3], 1)).sum(0)
+    finally:
+        oracle.set_threads(1)
+    G.assert_close(push.cpu().numpy(), want_push, 1e-5, 1e-5, "shared push")
+    G.assert_close(count.cpu().numpy(), want_count, 1e-5, 1e-5, "shared count")

@@ -116,7 +116,8 @@ static int make_params(const interpol_problem *p, Role role, int trailing, KPara
 
 static int64_t vol_numel(const interpol_problem *p)
 {
-    int64_t n = p->batch * p->channels;
+    // batch stride 0 = ONE shared target that every batch item accumulates into
+    int64_t n = (p->vol_stride[0] == 0 ? 1 : p->batch) * p->channels;
     for (int d = 0; d < p->dim; ++d) n *= p->vol_shape[d];
     return n;
 }
@@ -131,7 +132,7 @@ static bool vol_is_dense(const interpol_problem *p)
     }
     if (p->channels > 1 && p->vol_stride[1] != expect) return false;
     expect *= p->channels;
-    if (p->batch > 1 && p->vol_stride[0] != expect) return false;
+    if (p->batch > 1 && p->vol_stride[0] != expect && p->vol_stride[0] != 0) return false;
     return true;
 }
 

@@ -245,9 +245,11 @@ def gather(op, vol, grid, bound, order, extrapolate, flags=0):
     return val.to(out_dt)
 
 
-def scatter(op, val, grid, shape, bound, order, extrapolate, flags=0, out=None):
+def scatter(op, val, grid, shape, bound, order, extrapolate, flags=0, out=None, shared=False):
     """push / count / pushgrad: val (B,C,*in[,D]) , grid (B,*in,D) -> vol (B,C,*shape).
-    `out` (dense, same dtype) + FLAG_ACCUMULATE adds into an existing target."""
+    `out` (dense, same dtype) + FLAG_ACCUMULATE adds into an existing target.
+    `shared=True`: ONE target (1,C,*shape) that all batch items accumulate into
+    (the reference's grid_push(...).sum(0), without the B per-item volumes)."""
     dev = _require_gpu(val, grid)
     dim = grid.shape[-1]
     if dim not in (1, 2, 3):
@@ -273,11 +275,12 @@ def scatter(op, val, grid, shape, bound, order, extrapolate, flags=0, out=None):
         B = max(val.shape[0], grid.shape[0])
         C = val.shape[1]
         valstr = [_bstride(val, B), val.stride(1)] + _pad_to([val.stride(2 + d) for d in range(dim)], 3) + [0, 0]
+    Bv = 1 if shared else B
     if out is None:
-        vol = torch.empty([B, C] + shape, dtype=dt, device=dev)
+        vol = torch.empty([Bv, C] + shape, dtype=dt, device=dev)
     else:
         vol = out
-        assert vol.is_contiguous() and vol.dtype == dt and list(vol.shape) == [B, C] + shape
+        assert vol.is_contiguous() and vol.dtype == dt and list(vol.shape) == [Bv, C] + shape
     if vol.numel() == 0:
         return vol.to(out_dt)
     if grid.numel() == 0:
@@ -286,7 +289,7 @@ def scatter(op, val, grid, shape, bound, order, extrapolate, flags=0, out=None):
     if dt in (torch.bfloat16, torch.float16):
         scratch = torch.empty(vol.numel(), dtype=torch.float32, device=dev)
         sbytes = scratch.numel() * 4
-    vstr = [vol.stride(0), vol.stride(1)] + _pad_to([vol.stride(2 + d) for d in range(dim)], 3)
+    vstr = [0 if shared else vol.stride(0), vol.stride(1)] + _pad_to([vol.stride(2 + d) for d in range(dim)], 3)
     p = make_problem(dim, dt, gdt, bound, order, extrapolate, B, C, shape, gshape,
                      vstr, _grid_strides(grid, B, dim), valstr, flags)
     L = lib()

@@ -1,0 +1,73 @@
+"""Multi-GPU use of the hot path on one MI355X node: one process per GPU,
+`torch.distributed` with the "nccl" backend (= RCCL over xGMI on ROCm).
+
+Every operator is independent per batch item (reference interpol/nd.py:95-106),
+so pull / grad / count / push with per-item outputs shard over the batch axis
+with NO communication: each rank simply calls the API on its shard
+(`shard_range`).  The one exchange step of the path is splatting MANY sources
+into ONE shared target volume (BASELINE config 4): in reference terms
+
+    push  = grid_push(inp, grid, shape).sum(0)      count = grid_count(grid, shape).sum(0)
+
+Here every rank accumulates its local sources straight into a single local
+target (the kernels take a batch-stride-0 target, no per-item volumes), push
+and count are stacked into one buffer, and ONE sum-reduce of that buffer runs
+over RCCL.
+"""
+import torch
+
+from . import ops
+from .codes import bound_to_code, order_to_code, pad_codes
+
+
+def shard_range(n_items, rank, world_size):
+    """Contiguous, balanced [start, stop) of the batch items owned by `rank`."""
+    base, rem = divmod(n_items, world_size)
+    start = rank * base + min(rank, rem)
+    return start, start + base + (1 if rank < rem else 0)
+
+
+def _as_list(x):
+    return list(x) if isinstance(x, (list, tuple)) else [x]
+
+
+def push_count_shared(input, grid, shape, interpolation='linear', bound='zero', extrapolate=False,
+                      group=None, reduce='all', dst=0, with_count=True):
+    """Splat the LOCAL shard of sources into a shared target and sum over ranks.
+
+    input : (B_local, C, *inshape) or None (count only)     grid : (B_local, *inshape, D)
+    shape : target spatial shape
+    reduce: 'all' (all_reduce: every rank gets the result), 'dst' (reduce to rank `dst`),
+            'none' (local partial sums only)
+    Returns (push (C, *shape) | None, count (1, *shape) | None).  Equivalent to
+    `grid_push(all_inputs, all_grids, shape).sum(0)` / `grid_count(all_grids, shape).sum(0)`
+    of the reference evaluated over the batches of ALL ranks.
+    """
+    dim = grid.shape[-1]
+    shape = [int(s) for s in shape]
+    b = pad_codes([bound_to_code(x) for x in _as_list(bound)], dim)
+    o = pad_codes([order_to_code(x) for x in _as_list(interpolation)], dim)
+    ex = int(extrapolate)
+    C = 0 if input is None else input.shape[1]
+    nch = C + (1 if with_count else 0)
+    if nch == 0:
+        raise ValueError('nothing to do: no input and with_count=False')
+    dtype = grid.dtype if input is None else input.dtype
+    # push and count share one buffer -> one collective message
+    buf = torch.zeros([1, nch] + shape, dtype=dtype, device=grid.device)
+    k = ops.kernels()
+    if grid.shape[0] > 0:
+        if input is not None:
+            k.push_shared_(buf[:, :C], input, grid, b, o, ex)
+        if with_count:
+            k.push_shared_(buf[:, C:], None, grid, b, o, ex)
+    if reduce != 'none' and torch.distributed.is_available() and torch.distributed.is_initialized():
+        if reduce == 'all':
+            torch.distributed.all_reduce(buf, op=torch.distributed.ReduceOp.SUM, group=group)
+        elif reduce == 'dst':
+            torch.distributed.reduce(buf, dst=dst, op=torch.distributed.ReduceOp.SUM, group=group)
+        else:
+            raise ValueError("reduce must be 'all', 'dst' or 'none'")
+    push = buf[0, :C] if input is not None else None
+    count = buf[0, C:] if with_count else None
+    return push, count

@@ -53,6 +53,13 @@ class _HipKernels:
         return _hip.scatter("pushgrad", inp, grid, shape, bound, order, extrapolate)
 
     @staticmethod
+    def push_shared_(out, inp, grid, bound, order, extrapolate):
+        """out (1,C,*shape) += sum over the batch of push(inp, grid); count when inp is None."""
+        op = "count" if inp is None else "push"
+        return _hip.scatter(op, inp, grid, list(out.shape[2:]), bound, order, extrapolate,
+                            flags=_hip.FLAG_ACCUMULATE, out=out, shared=True)
+
+    @staticmethod
     def pull_backward(grad, inp, grid, bound, order, extrapolate, need_inp, need_grid):
         return _hip.pull_backward(grad, inp, grid, bound, order, extrapolate, need_inp, need_grid)
 
