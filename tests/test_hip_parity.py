@@ -301,55 +301,90 @@ def test_autocast_casts_to_fp32():
 
 # ---- LDS-tiled fast paths vs the generic kernels -----------------------------------
 
-@pytest.mark.parametrize("order", [1, 2, 3])
-@pytest.mark.parametrize("sigma", [0.0, 0.7, 2.0, 9.0])
-def test_tiled_pull_matches_generic(order, sigma):
-    """Same C-ABI call with and without INTERPOL_FLAG_NO_FASTPATH: all bounds, all
-    extrapolation modes, ragged sizes, small / moderate / pathological deformation
-    (sigma = 9 voxels overflows the in-LDS box and the slow list)."""
-    from interpol import _hip
-    ishape, oshape = (50, 37, 41), (35, 45, 30)
-    inp, grid = _rand_problem(2, 3, ishape, oshape, sigma, seed=int(order * 10 + sigma))
-    flat = grid.reshape(2, -1, 3)
+def _tiled_problem(dim, sigma, seed, B=2, C=3):
+    ishape = (50, 37, 41)[3 - dim:]
+    oshape = (35, 45, 30)[3 - dim:] if dim == 3 else (75, 90)
+    inp, grid = _rand_problem(B, C, ishape, oshape, sigma, seed=seed)
+    flat = grid.reshape(B, -1, dim)
     flat[0, 0] = -3.0 * torch.tensor(ishape)          # far outside
     flat[0, 1] = 3.0 * torch.tensor(ishape) + 0.25
     flat[1, 5] = 2.0
     flat[1, 6] = 1.5
-    inp, grid = inp.to(DEV), grid.to(DEV)
-    for bound in range(7):
-        for ex in (1, 0, 2):
-            fast = _hip.gather("pull", inp, grid, [bound] * 3, [order] * 3, ex)
-            slow = _hip.gather("pull", inp, grid, [bound] * 3, [order] * 3, ex, flags=_hip.FLAG_NO_FASTPATH)
-            scale = float(slow.abs().max())
-            assert float((fast - slow).abs().max()) <= 2e-6 * scale, (bound, ex, order, sigma)
-    # mixed bounds per dim
-    fast = _hip.gather("pull", inp, grid, [4, 2, 6], [order] * 3, 1)
-    slow = _hip.gather("pull", inp, grid, [4, 2, 6], [order] * 3, 1, flags=_hip.FLAG_NO_FASTPATH)
-    assert float((fast - slow).abs().max()) <= 2e-6 * float(slow.abs().max())
+    return inp.to(DEV), grid.to(DEV), ishape, oshape
 
 
-@pytest.mark.parametrize("order", [1, 2, 3])
+def _same(fast, slow, tol, what):
+    scale = max(float(slow.abs().max()), 1e-30)
+    assert float((fast - slow).abs().max()) <= tol * scale, what
+
+
+@pytest.mark.parametrize("dim", [3, 2])
+@pytest.mark.parametrize("order", [1, 2, 3, 4, 5, 6, 7])
 @pytest.mark.parametrize("sigma", [0.0, 0.7, 2.0, 9.0])
-def test_tiled_push_and_count_match_generic(order, sigma):
+def test_tiled_gather_matches_generic(dim, order, sigma):
+    """pull and grad: same C-ABI call with and without INTERPOL_FLAG_NO_FASTPATH: all bounds,
+    all extrapolation modes, ragged sizes, small / moderate / pathological deformation
+    (sigma = 9 voxels overflows the in-LDS box and the slow list)."""
     from interpol import _hip
-    ishape, tshape = (35, 45, 30), (50, 37, 41)      # source lattice, target lattice
-    _, grid = _rand_problem(2, 3, tshape, ishape, sigma, seed=int(order * 10 + sigma) + 1)
-    src = torch.randn([2, 3, *ishape], generator=torch.Generator().manual_seed(11))
-    flat = grid.reshape(2, -1, 3)
-    flat[0, 0] = -3.0 * torch.tensor(tshape)
-    flat[0, 1] = 3.0 * torch.tensor(tshape) + 0.25
-    src, grid = src.to(DEV), grid.to(DEV)
+    inp, grid, ishape, oshape = _tiled_problem(dim, sigma, seed=int(order * 10 + sigma) + dim)
     for bound in range(7):
-        for ex in (1, 0, 2):
-            b, o = [bound] * 3, [order] * 3
+        for ex in ((1, 0, 2) if bound in (0, 3, 4) else (1,)):
+            b, o = [bound] * dim, [order] * dim
+            for op in ("pull", "grad"):
+                fast = _hip.gather(op, inp, grid, b, o, ex)
+                slow = _hip.gather(op, inp, grid, b, o, ex, flags=_hip.FLAG_NO_FASTPATH)
+                _same(fast, slow, 4e-6 if order < 6 else 2e-5, (op, dim, bound, ex, order, sigma))
+    mixed = [4, 2, 6][:dim]
+    fast = _hip.gather("pull", inp, grid, mixed, [order] * dim, 1)
+    slow = _hip.gather("pull", inp, grid, mixed, [order] * dim, 1, flags=_hip.FLAG_NO_FASTPATH)
+    _same(fast, slow, 4e-6 if order < 6 else 2e-5, "mixed bounds")
+
+
+@pytest.mark.parametrize("dim", [3, 2])
+@pytest.mark.parametrize("order", [1, 2, 3, 5, 7])
+@pytest.mark.parametrize("sigma", [0.0, 0.7, 2.0, 9.0])
+def test_tiled_scatter_matches_generic(dim, order, sigma):
+    """push, count and the fused pull backward vs the generic kernels."""
+    from interpol import _hip
+    vol, grid, tshape, sshape = _tiled_problem(dim, sigma, seed=int(order * 10 + sigma) + dim + 1)
+    src = torch.randn([2, 3, *sshape], generator=torch.Generator().manual_seed(11)).to(DEV)
+    for bound in range(7):
+        for ex in ((1, 0, 2) if bound in (0, 3, 5) else (1,)):
+            b, o = [bound] * dim, [order] * dim
             fast = _hip.scatter("push", src, grid, list(tshape), b, o, ex)
             slow = _hip.scatter("push", src, grid, list(tshape), b, o, ex, flags=_hip.FLAG_NO_FASTPATH)
-            assert float((fast - slow).abs().max()) <= 1e-5 * float(slow.abs().max()), ("push", bound, ex, order, sigma)
+            _same(fast, slow, 1e-5, ("push", dim, bound, ex, order, sigma))
             fast = _hip.scatter("count", None, grid, list(tshape), b, o, ex)
             slow = _hip.scatter("count", None, grid, list(tshape), b, o, ex, flags=_hip.FLAG_NO_FASTPATH)
-            assert float((fast - slow).abs().max()) <= 1e-5 * float(slow.abs().max()), ("count", bound, ex, order, sigma)
+            _same(fast, slow, 1e-5, ("count", dim, bound, ex, order, sigma))
+    # fused pull backward (tiled) vs its composition from the generic forward operators
+    for bound, ex in ((3, 1), (0, 0), (6, 1), (4, 2)):
+        b, o = [bound] * dim, [order] * dim
+        gvol, ggrid = _hip.pull_backward(src, vol, grid, b, o, ex, True, True)
+        want_gvol = _hip.scatter("push", src, grid, list(tshape), b, o, ex, flags=_hip.FLAG_NO_FASTPATH)
+        gg = _hip.gather("grad", vol, grid, b, o, ex, flags=_hip.FLAG_NO_FASTPATH)
+        want_ggrid = (gg * src.unsqueeze(-1)).sum(1)
+        _same(gvol, want_gvol, 1e-5, ("bwd gvol", dim, bound, ex, order, sigma))
+        _same(ggrid, want_ggrid, 2e-5 if order < 6 else 1e-4, ("bwd ggrid", dim, bound, ex, order, sigma))
+        only_grid = _hip.pull_backward(src, vol, grid, b, o, ex, False, True)
+        assert only_grid[0] is None and torch.equal(only_grid[1], ggrid)
+        only_vol = _hip.pull_backward(src, vol, grid, b, o, ex, True, False)
+        assert only_vol[1] is None
+        _same(only_vol[0], want_gvol, 1e-5, "bwd gvol only")
 
 
+def test_tiled_scatter_nonfinite_sources_keep_ieee_semantics():
+    from interpol import _hip
+    vol, grid, tshape, sshape = _tiled_problem(3, 1.0, seed=5)
+    src = torch.randn([2, 3, *sshape], generator=torch.Generator().manual_seed(3)).to(DEV)
+    src[0, 0, 3, 4, 5] = float("inf")
+    src[1, 2, 7, 7, 7] = float("nan")
+    fast = _hip.scatter("push", src, grid, list(tshape), [3] * 3, [3] * 3, 1)
+    slow = _hip.scatter("push", src, grid, list(tshape), [3] * 3, [3] * 3, 1, flags=_hip.FLAG_NO_FASTPATH)
+    assert torch.equal(torch.isnan(fast), torch.isnan(slow))
+    assert torch.equal(torch.isinf(fast), torch.isinf(slow))
+    ok = torch.isfinite(slow)
+    assert float((fast[ok] - slow[ok]).abs().max()) <= 1e-5 * float(slow[ok].abs().max())
 def test_shared_target_push_count():
     """BASELINE config 4 miniature: many sources splatted into ONE shared target
     (batch-stride-0 target in the C-ABI) == reference grid_push(...).sum(0)."""

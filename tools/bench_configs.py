@@ -1,0 +1,88 @@
+#!/usr/bin/env python
+"""Timings of the other BASELINE.json configs (1, 3, 4, 5) on one MI355X: per-op ms, Mvox/s and
+fraction of the HBM roofline (algorithmic bytes of BASELINE.md sec. 3 / 8 TB/s).  Config 2 is bench.py."""
+import json, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "torch-interpol_amd")); sys.path.insert(0, ROOT)
+import torch, interpol
+from interpol.distributed import push_count_shared
+
+dev = torch.device("cuda", 0)
+PEAK = 8000e9
+
+
+def timeit(fn, reps=5):
+    fn(); torch.cuda.synchronize()
+    ts = []
+    for _ in range(reps):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record(); fn(); b.record(); torch.cuda.synchronize()
+        ts.append(a.elapsed_time(b))
+    ts.sort()
+    return ts[len(ts) // 2]
+
+
+def rec(out, name, ms, vox, nbytes):
+    out[name] = {"ms": round(ms, 4), "Mvox_s": round(vox / ms / 1e3, 1), "frac_hbm": round(nbytes / (ms * 1e-3) / PEAK, 4)}
+
+
+def ident(sp, B, sigma, g, dtype=torch.float32):
+    grid = torch.randn([B, *sp, len(sp)], generator=g, device=dev, dtype=torch.float32).mul_(sigma)
+    grid += interpol.identity_grid(sp, dtype=torch.float32, device=dev)
+    return grid.to(dtype)
+
+
+res = {}
+g = torch.Generator(device=dev).manual_seed(1234)
+which = sys.argv[1:] or ["1", "3", "4", "5"]
+
+if "1" in which:    # cfg1: 1x1x128x128 linear zero identity
+    x = torch.randn(1, 1, 128, 128, device=dev)
+    gr = interpol.identity_grid([128, 128], device=dev)[None]
+    ms = timeit(lambda: interpol.grid_pull(x, gr, interpolation=1, bound="zero", extrapolate=False), 20)
+    rec(res, "cfg1_pull_linear_zero_128x128", ms, 128 * 128, 128 * 128 * (8 + 4 + 4))
+    assert torch.equal(interpol.grid_pull(x, gr, interpolation=1, bound="zero", extrapolate=False), x)
+
+if "3" in which:    # cfg3: 8x1x192^3 order 5 dft: grid_grad + backward of grid_pull
+    B, C, n = 8, 1, 192
+    x = torch.randn(B, C, n, n, n, generator=g, device=dev)
+    gr = ident([n, n, n], B, 2.0, g)
+    kw = dict(interpolation=5, bound="dft", extrapolate=True)
+    vox = B * n ** 3
+    rec(res, "cfg3_grid_grad_o5_dft", timeit(lambda: interpol.grid_grad(x, gr, **kw), 3), vox, vox * (12 + C * 12) + B * C * n ** 3 * 4)
+    rec(res, "cfg3_grid_pull_o5_dft", timeit(lambda: interpol.grid_pull(x, gr, **kw), 3), vox, vox * (12 + C * 4) + B * C * n ** 3 * 4)
+    xr, grr = x.clone().requires_grad_(True), gr.clone().requires_grad_(True)
+    y = interpol.grid_pull(xr, grr, **kw)
+    gy = torch.randn_like(y)
+
+    def bwd():
+        xr.grad = None; grr.grad = None
+        y.backward(gy, retain_graph=True)
+    rec(res, "cfg3_pull_backward_fused_o5_dft", timeit(bwd, 3), vox, vox * (24 + C * 4) + 2 * B * C * n ** 3 * 4)
+    del xr, grr, y, gy
+
+if "4" in which:    # cfg4: 64 sources 1x128^3 -> shared 512^3, order 3 replicate (one GPU's share at 8 GPUs = 8 sources; here all 64)
+    for nsrc in (8, 64):
+        n, m = 128, 512
+        x = torch.randn(nsrc, 1, n, n, n, generator=g, device=dev)
+        gr = torch.randn([nsrc, n, n, n, 3], generator=g, device=dev).mul_(2.0)
+        gr += interpol.identity_grid([n, n, n], device=dev) * ((m - 1) / (n - 1))
+        vox = nsrc * n ** 3
+        ms = timeit(lambda: push_count_shared(x, gr, [m, m, m], interpolation=3, bound="replicate", extrapolate=True, reduce="none"), 3)
+        rec(res, "cfg4_push+count_shared_%dsrc_o3_replicate" % nsrc, ms, vox, vox * 16 + vox * 12 + 2 * m ** 3 * 4)
+        del x, gr
+
+if "5" in which:    # cfg5: 2-D, orders [2,3,5]->[2,3], bounds [dct1,dst2,zero]->[dct1,dst2], bf16 storage, fp32 grid; 32 of 256 images (1/8: one GPU's share)
+    B, C, n = 32, 3, 1024
+    x = torch.randn(B, C, n, n, generator=g, device=dev).to(torch.bfloat16)
+    gr = ident([n, n], B, 2.0, g)
+    kw = dict(interpolation=[2, 3, 5], bound=["dct1", "dst2", "zero"], extrapolate=True)
+    vox = B * n * n
+    rec(res, "cfg5_pull_bf16_o23", timeit(lambda: interpol.grid_pull(x, gr, **kw), 3), vox, vox * (8 + C * 2) + B * C * n * n * 2)
+    rec(res, "cfg5_push_bf16_o23", timeit(lambda: interpol.grid_push(x, gr, **kw), 3), vox, vox * (8 + C * 2) + B * C * n * n * 2)
+    xf = x.float()
+    rec(res, "cfg5_pull_f32_o23", timeit(lambda: interpol.grid_pull(xf, gr, **kw), 3), vox, vox * (8 + C * 4) + B * C * n * n * 4)
+    rec(res, "cfg5_prefilter_bf16_o23_dct1dct2", timeit(lambda: interpol.spline_coeff_nd(x, [2, 3], ["dct1", "dct2"], 2), 3), vox, 2 * 2 * B * C * n * n * 2)
+    rec(res, "cfg5_prefilter_f32_o23_dct1dct2", timeit(lambda: interpol.spline_coeff_nd(xf, [2, 3], ["dct1", "dct2"], 2), 3), vox, 2 * 2 * B * C * n * n * 4)
+
+print(json.dumps(res, indent=1))

@@ -38,6 +38,9 @@ int launch_filter(int dtype, const FilterParams &fp, void *data, hipStream_t st)
 // fast paths (ops_tiled.hip); return 1 when they took the problem, 0 to decline, <0 / >0 on error
 int try_fast_pull(const interpol_problem *p, const KParams &k, const void *vol, const void *grid, void *val, hipStream_t st);
 int try_fast_push(const interpol_problem *p, const KParams &k, const void *val, const void *grid, void *vol, hipStream_t st);
+int try_fast_grad(const interpol_problem *p, const KParams &k, const void *vol, const void *grid, void *val, hipStream_t st);
+int try_fast_pullbwd(const interpol_problem *p, const KParams &k, const void *gout, const void *vol, const void *grid,
+                     void *gvol, void *ggrid, int64_t gsb, int64_t gsc, hipStream_t st);
 
 static size_t esize(int dtype) { return dtype == INTERPOL_F64 ? 8 : (dtype == INTERPOL_F32 ? 4 : 2); }
 static size_t acc_esize(int dtype) { return dtype == INTERPOL_F64 ? 8 : 4; }
@@ -230,6 +233,10 @@ int interpol_grad(const interpol_problem *p, const void *vol, const void *grid, 
     if (rc) return rc;
     if (!vol || !grid || !val) return INTERPOL_E_NULL;
     hipStream_t st = (hipStream_t)stream;
+    if (!(p->flags & INTERPOL_FLAG_NO_FASTPATH)) {
+        rc = try_fast_grad(p, k, vol, grid, val, st);
+        if (rc != 0) return rc == 1 ? 0 : rc;
+    }
     return by_dtype(p->dtype,
         [&] { return launch_grad_f32(k, vol, grid, val, B, st); },
         [&] { return launch_grad_f64(k, vol, grid, val, B, st); },
@@ -332,6 +339,10 @@ int interpol_pull_backward(const interpol_problem *p, const void *grad_out, cons
         }
     }
     const int64_t gsb = img * p->channels, gsc = img;
+    if (!(p->flags & INTERPOL_FLAG_NO_FASTPATH)) {
+        rc = try_fast_pullbwd(p, k, grad_out, vol, grid, acc, grad_grid, gsb, gsc, st);
+        if (rc != 0) return rc == 1 ? 0 : rc;
+    }
     rc = by_dtype(p->dtype,
         [&] { return launch_pullbwd_f32(k, grad_out, vol, grid, acc, grad_grid, B, gsb, gsc, st); },
         [&] { return launch_pullbwd_f64(k, grad_out, vol, grid, acc, grad_grid, B, gsb, gsc, st); },

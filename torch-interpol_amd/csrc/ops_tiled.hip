@@ -1,54 +1,81 @@
 // ===========================================================================
-// ops_tiled.hip -- LDS-tiled fast paths for 3-D float32 pull and push.
+// ops_tiled.hip -- LDS-tiled fast paths: float32, 2-D / 3-D, isotropic spline
+// order 1..7, any boundary / extrapolation mode.
+//   pull, grad            (gather)
+//   push, count           (scatter)
+//   pull_backward         (fused: scatter of grad_out + gathered grid gradient)
 //
-// Why: the generic kernels gather/scatter every tap through the vector memory
-// path; with an arbitrary deformation each lane of a wave touches its own cache
-// line, so a 64-tap cubic stencil costs 64 x ~64 line accesses per wave
-// (measured: 12 ms pull / 400 ms push at 4x2x256^3, ~1% of the HBM roofline).
+// Why: the generic kernels move every tap through the vector memory path; with
+// an arbitrary deformation each lane of a wave touches its own cache line, and a
+// scattered device-scope float atomic costs one fabric transaction (measured:
+// ~21 G atomics/s).  At BASELINE config 2 that is 12 ms pull / 400 ms push
+// (~1 % / 0.06 % of the HBM roofline).
 //
-// Here one workgroup owns a TILE of 16x16x16 sample points:
-//   1. every thread computes (floor, fraction) of its 4 samples; a block-wide
-//      min/max gives the bounding box of all stencil supports;
-//   2. the box (clamped to what fits in LDS) is staged global -> LDS with the
-//      boundary condition ALREADY APPLIED (wrapped index and sign per box row,
-//      column, slice from three small tables), so the tap loop needs no index
-//      wrapping at all;
-//   3. pull: taps are read from LDS (ds_read), separable FMA accumulation;
-//      push: taps are accumulated into the LDS box (ds_add_f32), then the box is
-//      flushed with ONE coalesced global atomic per touched lattice point
-//      instead of (K+1)^3 scattered atomics per sample;
-//   4. samples whose support leaves the staged box (large local deformation)
-//      are collected in a list and handled tap-parallel by whole waves (lane =
-//      tap) straight from / to global memory.
-// One channel is resident at a time (box = up to 33x33x32 floats = 139 KiB).
+// Here one workgroup owns a TILE of TX x TY x TZ sample points:
+//   1. a block-wide min/max of the first-tap indices gives the bounding box of
+//      all stencil supports, clamped to what fits in LDS;
+//   2. gather: the box is staged global -> LDS with the boundary condition
+//      ALREADY APPLIED (wrapped offset and sign per box row / column / slice from
+//      three small tables): the tap loop needs no index wrapping at all and
+//      reads LDS (ds_read_b32), separable FMA accumulation;
+//   3. scatter: contributions are accumulated in the LDS box as 64-bit FIXED
+//      POINT with ds_add_u64 (ds_add_f32 retires 0.33 lanes/clk/CU on gfx950,
+//      ds_add_u64 4.6 -- tools/microbench/lds_atomics.hip), in passes over slabs
+//      of box rows, then each touched slot is flushed with ONE coalesced global
+//      atomic instead of (K+1)^D scattered ones;
+//   4. samples whose support leaves the staged box (large local deformation) go
+//      to a per-tile list handled tap-parallel by whole waves (lane = tap);
+//      pathological tiles fall back to per-thread global gathers / atomics.
+// One channel is resident at a time.  Per-sample quantities (floor index,
+// fraction) are recomputed from the coordinate grid in every phase instead of
+// being held in registers (register budget of a 1024-thread block).
 //
-// Numerical definition: reference interpol/nd.py:80-143 (pull), 146-213 (push);
-// weights splines.py:30-80; bounds bounds.py:30-89.  Parity with the generic
+// Numerical definition: reference interpol/nd.py:80-143 (pull), 146-213 (push),
+// 216-288 (grad), pushpull.py:237-258 (pull backward); iso1.py for all-linear;
+// weights splines.py:30-139; bounds bounds.py:30-89.  Parity with the generic
 // kernels / oracle is tested in tests/test_hip_parity.py.
 // ===========================================================================
 #include "../../include/interpol_hip.h"
 #include "stencil.hpp"
 
 namespace ip {
-
 namespace tiled {
 
-constexpr int TX = 16, TY = 16, TZ = 16;       // samples per tile
-constexpr int NT = 1024;                        // threads per block
-constexpr int VPT = TX * TY * TZ / NT;          // samples per thread (4)
-constexpr int PZ = 32;                          // LDS pitch along z (box extent along z <= 32)
-constexpr int CAPX = 33, CAPY = 33, CAPZ = 32;  // box extents that fit: 33*33*32 floats = 139392 B
-constexpr int BOX = CAPX * CAPY * PZ;
-constexpr int SLOWCAP = 512;                    // out-of-box samples handled tap-parallel per tile
+constexpr int SLOWCAP = 512;                   // out-of-box samples handled tap-parallel per tile
+constexpr int TABN = 72;                       // max box extent along one dim
 
-struct Smem {
-    float box[BOX];
-    int   taboff[3][40];       // wrapped lattice offset (elements) of box row / column / slice
-    float tabsgn[3][40];       // boundary sign of the same
-    int   lo[3], hi[3];        // block reduction of floor indices
-    int   nslow;
-    unsigned short slow[SLOWCAP];
+// Tile configuration.  Kernel dims are always (x, y, z); a 2-D problem (D = 2) uses
+// a degenerate x (one row, one tap, weight 1) and maps (y, z) to problem dims (0, 1).
+template <int K_, int D_, int TX_, int TY_, int TZ_, int NT_, int PZ_>
+struct Cfg {
+    static constexpr int K = K_, D = D_, TX = TX_, TY = TY_, TZ = TZ_, NT = NT_, PZ = PZ_;
+    static constexpr int NS = TX * TY * TZ;            // samples per tile
+    static constexpr int VPT = NS / NT;                 // samples per thread
+    static constexpr int XSTEP = NT / (TY * TZ);        // x distance between a thread's samples
+    static constexpr int KX = D == 3 ? K : 0;           // taps - 1 along x
+    static constexpr int CAPZ = PZ;
+    static constexpr int CAPX = D == 3 ? 33 : 1;
+    static constexpr int CAPY = D == 3 ? 33 : TABN;
+    // floats of LDS for the box: 3-D 33*33*32 (139392 B of the 160 KiB); 2-D twice the
+    // gather box so that the 64-bit scatter needs a single pass
+    static constexpr int BOXF = D == 3 ? CAPX * CAPY * PZ : 2 * CAPY * PZ;
+    static_assert(NS % NT == 0 && NT % (TY * TZ) == 0, "tile / thread mismatch");
+    static_assert(NT % PZ == 0, "staging maps z to tid % PZ");
+    // problem dim of kernel dim d (-1: degenerate)
+    __host__ __device__ static constexpr int pd(int d) { return d - (3 - D); }
 };
+
+// Fixed part of the LDS image; the box (C::BOXF floats) follows it.
+struct Smem {
+    int   taboff[3][TABN];     // wrapped lattice offset (elements) of box row / column / slice
+    float tabsgn[3][TABN];     // boundary sign of the same
+    int   lo[3], hi[3];        // block reductions
+    int   nslow;
+    int   pad_;
+    unsigned short slow[SLOWCAP];
+    float box[1];              // really C::BOXF floats (dynamic LDS)
+};
+template <typename C> constexpr size_t smem_bytes() { return sizeof(Smem) + sizeof(float) * (C::BOXF - 1); }
 
 __device__ __forceinline__ int wave_min(int v)
 {
@@ -79,56 +106,74 @@ __device__ __forceinline__ void split(float x, int &i0, float &t)
     i0 = (int)flc;
 }
 
-template <int K>
-__device__ __forceinline__ void weights(const KParams &p, float t, float *w)
-{
-#pragma unroll
-    for (int j = 0; j <= K; ++j) {
-        if (K == 1 && p.mode == MODE_ISO1) w[j] = (j == 0) ? 1.f - t : t;     // iso1.py:19-20
-        else w[j] = bspline_w<float>(K, t - (float)j);                          // splines.py:30-80
-    }
-}
-
-// The scalars of KParams the rare (out-of-box) paths need, passed by value to
-// out-of-line functions so that their register needs stay out of the hot loops.
+// The scalars of KParams the kernels need per kernel dim (x, y, z), by value, so that
+// out-of-line rare-path functions do not drag the whole KParams along.
 struct Lattice {
     int bound[3], n[3], ss[3];     // boundary codes, extents, strides in elements
-    int lin;                       // iso1 weights (1-t, t)
+    int lin;                       // iso1 weights (1-t, t) and gradients (-1, +1)
 };
-__device__ __forceinline__ Lattice make_lattice(const KParams &p, int K)
+template <typename C>
+__device__ __forceinline__ Lattice make_lattice(const KParams &p)
 {
     Lattice L;
 #pragma unroll
-    for (int d = 0; d < 3; ++d) { L.bound[d] = p.bound[d]; L.n[d] = p.vol_n[d]; L.ss[d] = p.vol_ss[d] >> 2; }
-    L.lin = (K == 1 && p.mode == MODE_ISO1);
+    for (int d = 0; d < 3; ++d) {
+        if (C::pd(d) >= 0) { L.bound[d] = p.bound[C::pd(d) < 0 ? 0 : C::pd(d)]; L.n[d] = p.vol_n[C::pd(d) < 0 ? 0 : C::pd(d)]; L.ss[d] = p.vol_ss[C::pd(d) < 0 ? 0 : C::pd(d)] >> 2; }
+        else               { L.bound[d] = 1; L.n[d] = 1; L.ss[d] = 0; }
+    }
+    L.lin = (C::K == 1 && p.mode == MODE_ISO1);
     return L;
 }
 
 template <int K>
 __device__ __forceinline__ float weight1(int lin, float t, int j)
 {
-    return lin ? (j == 0 ? 1.f - t : t) : bspline_w<float>(K, t - (float)j);
+    return lin ? (j == 0 ? 1.f - t : t) : bspline_w<float>(K, t - (float)j);      // iso1.py:19-20 / splines.py:30-80
+}
+template <int K>
+__device__ __forceinline__ float wgrad1(int lin, float t, int j)
+{
+    return lin ? (j == 0 ? -1.f : 1.f) : bspline_g<float>(K, t - (float)j);       // iso1.py:311-313 / splines.py:90-139
+}
+template <int K>
+__device__ __forceinline__ void weights(int lin, float t, float *w)
+{
+#pragma unroll
+    for (int j = 0; j <= K; ++j) w[j] = weight1<K>(lin, t, j);
+}
+template <int K>
+__device__ __forceinline__ void wgrads(int lin, float t, float *g)
+{
+#pragma unroll
+    for (int j = 0; j <= K; ++j) g[j] = wgrad1<K>(lin, t, j);
 }
 
+// ---------------------------------------------------------------------------
+// Rare paths, out of line.
+// ---------------------------------------------------------------------------
 // One sample gathered tap by tap from global memory by ONE thread (rolled loops).
-template <int K>
-__device__ __noinline__ float gather_one_thread(Lattice L, const float *vc, int ix, int iy, int iz, float tx, float ty, float tz)
+// which = -1: value, 0..2: derivative along kernel dim `which`.
+template <int K, int KX>
+__device__ __noinline__ float gather_one_thread(Lattice L, const float *vc, int ix, int iy, int iz,
+                                                float tx, float ty, float tz, int which)
 {
     float acc = 0.f;
-    for (int i = 0; i <= K; ++i) {
+    for (int i = 0; i <= KX; ++i) {
         const long long pk0 = wrap_outofline(L.bound[0], ix + i, L.n[0]);
-        const float sx = weight1<K>(L.lin, tx, i) * (float)(int)(pk0 >> 32);
+        const float fx = KX == 0 ? 1.f : (which == 0 ? wgrad1<K>(L.lin, tx, i) : weight1<K>(L.lin, tx, i));
+        const float sx = fx * (float)(int)(pk0 >> 32);
         const int offx = (int)(pk0 & 0xffffffffll) * L.ss[0];
         float pl = 0.f;
         for (int j = 0; j <= K; ++j) {
             const long long pk1 = wrap_outofline(L.bound[1], iy + j, L.n[1]);
-            const float sy = weight1<K>(L.lin, ty, j) * (float)(int)(pk1 >> 32);
+            const float fy = which == 1 ? wgrad1<K>(L.lin, ty, j) : weight1<K>(L.lin, ty, j);
+            const float sy = fy * (float)(int)(pk1 >> 32);
             const int offy = (int)(pk1 & 0xffffffffll) * L.ss[1];
             float r = 0.f;
             for (int k = 0; k <= K; ++k) {
                 const long long pk2 = wrap_outofline(L.bound[2], iz + k, L.n[2]);
-                const float sz = weight1<K>(L.lin, tz, k) * (float)(int)(pk2 >> 32);
-                r = __builtin_fmaf(sz, vc[offx + offy + (int)(pk2 & 0xffffffffll) * L.ss[2]], r);
+                const float fz = which == 2 ? wgrad1<K>(L.lin, tz, k) : weight1<K>(L.lin, tz, k);
+                r = __builtin_fmaf(fz * (float)(int)(pk2 >> 32), vc[offx + offy + (int)(pk2 & 0xffffffffll) * L.ss[2]], r);
             }
             pl = __builtin_fmaf(sy, r, pl);
         }
@@ -138,12 +183,13 @@ __device__ __noinline__ float gather_one_thread(Lattice L, const float *vc, int 
 }
 
 // One sample scattered tap by tap to global memory by ONE thread (rolled loops).
-template <int K>
-__device__ __noinline__ void scatter_one_thread(Lattice L, float *vc, float src, int ix, int iy, int iz, float tx, float ty, float tz)
+template <int K, int KX>
+__device__ __noinline__ void scatter_one_thread(Lattice L, float *vc, float src, int ix, int iy, int iz,
+                                                float tx, float ty, float tz)
 {
-    for (int i = 0; i <= K; ++i) {
+    for (int i = 0; i <= KX; ++i) {
         const long long pk0 = wrap_outofline(L.bound[0], ix + i, L.n[0]);
-        const float sx = src * weight1<K>(L.lin, tx, i) * (float)(int)(pk0 >> 32);
+        const float sx = src * (KX == 0 ? 1.f : weight1<K>(L.lin, tx, i)) * (float)(int)(pk0 >> 32);
         const int offx = (int)(pk0 & 0xffffffffll) * L.ss[0];
         for (int j = 0; j <= K; ++j) {
             const long long pk1 = wrap_outofline(L.bound[1], iy + j, L.n[1]);
@@ -159,80 +205,93 @@ __device__ __noinline__ void scatter_one_thread(Lattice L, float *vc, float src,
     }
 }
 
-// Tap-parallel: the calling WAVE handles one sample, lane = tap ((K+1)^3 <= 64).
-// Returns this lane's (weight * sign) and lattice offset; lanes >= (K+1)^3 get weight 0.
-template <int K>
-__device__ __noinline__ float tap_of_lane(Lattice L, float gx_, float gy_, float gz_, int lane, int *off_out)
+// Tap-parallel: tap number `tap` of the sample at coordinates (gx_, gy_, gz_):
+// returns weight * sign (0 beyond the last tap), lattice offset in *off_out and, when
+// grads != nullptr, the three derivative weights (value weights of the other dims).
+template <int K, int KX>
+__device__ __noinline__ float tap_weight(Lattice L, float gx_, float gy_, float gz_, int tap, int *off_out, float *grads)
 {
-    constexpr int K1 = K + 1;
-    const int tp[3] = { lane / (K1 * K1), (lane / K1) % K1, lane % K1 };
+    constexpr int K1 = K + 1, NTAP = (KX + 1) * K1 * K1;
+    const bool on = tap < NTAP;
+    const int tp[3] = { on ? tap / (K1 * K1) : 0, on ? (tap / K1) % K1 : 0, on ? tap % K1 : 0 };
     const float g[3] = { gx_, gy_, gz_ };
-    float w = lane < K1 * K1 * K1 ? 1.f : 0.f;
+    float w[3], dw[3];
     int off = 0;
 #pragma unroll
     for (int d = 0; d < 3; ++d) {
+        if (d == 0 && KX == 0) { w[d] = 1.f; dw[d] = 0.f; continue; }
         int i0; float t;
         split<K>(g[d], i0, t);
-        const int j = lane < K1 * K1 * K1 ? tp[d] : 0;
-        const long long pk = wrap_outofline(L.bound[d], i0 + j, L.n[d]);
-        w *= weight1<K>(L.lin, t, j) * (float)(int)(pk >> 32);
+        const long long pk = wrap_outofline(L.bound[d], i0 + tp[d], L.n[d]);
+        const float s = (float)(int)(pk >> 32);
+        w[d] = weight1<K>(L.lin, t, tp[d]) * s;
+        dw[d] = grads ? wgrad1<K>(L.lin, t, tp[d]) * s : 0.f;
         off += (int)(pk & 0xffffffffll) * L.ss[d];
     }
     *off_out = off;
-    return w;
+    const float m = on ? 1.f : 0.f;
+    if (grads) {
+        grads[0] = m * dw[0] * w[1] * w[2];
+        grads[1] = m * w[0] * dw[1] * w[2];
+        grads[2] = m * w[0] * w[1] * dw[2];
+    }
+    return m * w[0] * w[1] * w[2];
 }
 
 // ---------------------------------------------------------------------------
-// Per-sample quantities are recomputed from the coordinate grid whenever they
-// are needed (3 L1/L2-resident loads + a few VALU ops) instead of being held in
-// registers across phases: with 4 samples per thread the persistent state
-// (24+ VGPRs) pushed the tap loops over the 128-VGPR budget of a 1024-thread
-// block and into scratch.
+// Samples, tile geometry, bounding box.
 // ---------------------------------------------------------------------------
-template <int K>
+template <typename C>
 struct Sample {
     bool  valid, inb;          // inside the sample grid / extrapolation mask (nd.py:10-27)
-    int   i0[3];               // first tap (unwrapped lattice index)
+    int   i0[3];               // first tap (unwrapped lattice index) per kernel dim
     float t[3];                // stencil coordinate (nd.py:46)
     int64_t o;                 // linear index of the sample in its batch item
 };
 
 struct TileGeom {
-    int gx, gy, gz;            // sample grid extents
+    int gx, gy, gz;            // sample grid extents (gx = 1 for 2-D)
     int ox0, oy0, oz0;         // tile origin
 };
 
-template <int K>
-__device__ __forceinline__ Sample<K> load_sample(const KParams &p, const float *__restrict__ grid, int64_t b,
-                                                 const TileGeom &g, int v)
+template <typename C>
+__device__ __forceinline__ void sample_pos(const TileGeom &g, int tid, int v, int &ox, int &oy, int &oz)
 {
-    const int tid = threadIdx.x;
-    const int ox = g.ox0 + (tid >> 8) + 4 * v, oy = g.oy0 + ((tid >> 4) & 15), oz = g.oz0 + (tid & 15);
-    Sample<K> s;
+    ox = g.ox0 + tid / (C::TZ * C::TY) + C::XSTEP * v;
+    oy = g.oy0 + (tid / C::TZ) % C::TY;
+    oz = g.oz0 + tid % C::TZ;
+}
+
+template <typename C>
+__device__ __forceinline__ Sample<C> load_sample(const KParams &p, const float *__restrict__ grid, int64_t b,
+                                                 const TileGeom &g, int tid, int v)
+{
+    int ox, oy, oz;
+    sample_pos<C>(g, tid, v, ox, oy, oz);
+    Sample<C> s;
     s.valid = ox < g.gx && oy < g.gy && oz < g.gz;
     s.inb = true;
     s.o = ((int64_t)ox * g.gy + oy) * g.gz + oz;
 #pragma unroll
     for (int d = 0; d < 3; ++d) { s.i0[d] = 0; s.t[d] = 0.f; }
     if (s.valid) {
-        const float *gp = grid + b * p.grid_sb + s.o * 3;
+        const float *gp = grid + b * p.grid_sb + s.o * C::D;
 #pragma unroll
         for (int d = 0; d < 3; ++d) {
-            const float xd = gp[d];
-            if (p.extrapolate != 1) s.inb = s.inb && xd > (float)p.mask_lo && xd < (float)p.mask_hi[d];
-            split<K>(xd, s.i0[d], s.t[d]);
+            if (C::pd(d) < 0) continue;
+            const float xd = gp[C::pd(d) < 0 ? 0 : C::pd(d)];
+            if (p.extrapolate != 1) s.inb = s.inb && xd > (float)p.mask_lo && xd < (float)p.mask_hi[C::pd(d) < 0 ? 0 : C::pd(d)];
+            split<C::K>(xd, s.i0[d], s.t[d]);
         }
     }
     return s;
 }
 
-// Bounding box of the tile's stencil supports, clamped to what fits in LDS, and the
-// boundary tables of its rows / columns / slices.
-template <int K>
+template <typename C>
 struct Box {
     int lo[3], S[3];
 
-    __device__ __forceinline__ void build(const KParams &p, const float *__restrict__ grid, int64_t b,
+    __device__ __forceinline__ void build(const KParams &p, const Lattice &L, const float *__restrict__ grid, int64_t b,
                                           const TileGeom &g, Smem &sm)
     {
         const int tid = threadIdx.x;
@@ -241,8 +300,8 @@ struct Box {
         __syncthreads();
         int mn[3] = { 0x7fffffff, 0x7fffffff, 0x7fffffff }, mx[3] = { -0x7fffffff, -0x7fffffff, -0x7fffffff };
 #pragma unroll
-        for (int v = 0; v < VPT; ++v) {
-            const Sample<K> s = load_sample<K>(p, grid, b, g, v);
+        for (int v = 0; v < C::VPT; ++v) {
+            const Sample<C> s = load_sample<C>(p, grid, b, g, tid, v);
             if (s.valid) {
 #pragma unroll
                 for (int d = 0; d < 3; ++d) {
@@ -257,161 +316,239 @@ struct Box {
             if ((tid & 63) == 0) { atomicMin(&sm.lo[d], a); atomicMax(&sm.hi[d], c); }
         }
         __syncthreads();
-        const int cap[3] = { CAPX, CAPY, CAPZ };
+        const int cap[3] = { C::CAPX, C::CAPY, C::CAPZ };
+        const int kd[3] = { C::KX, C::K, C::K };
 #pragma unroll
         for (int d = 0; d < 3; ++d) {
-            int l = sm.lo[d], h = sm.hi[d] + K;          // supports span [l, h]
+            int l = sm.lo[d], h = sm.hi[d] + kd[d];      // supports span [l, h]
             if (h < l) { l = 0; h = 0; }                  // tile without valid samples
             int sz = h - l + 1;
             if (sz > cap[d]) { l += (sz - cap[d]) / 2; sz = cap[d]; }   // keep the centre; the rest goes to the slow list
             lo[d] = l; S[d] = sz;
         }
         // boundary tables: box slot -> wrapped lattice offset and sign (bounds.py:30-89)
-        // (static d: a dynamic index into the by-value KParams would push it to scratch)
 #pragma unroll
         for (int d = 0; d < 3; ++d) {
-            const int sidx = tid - 64 * d;          // one wave per dim
-            if (sidx >= 0 && sidx < S[d]) {
-                const long long pk = wrap_outofline(p.bound[d], lo[d] + sidx, p.vol_n[d]);
-                sm.taboff[d][sidx] = (int)(pk & 0xffffffffll) * (p.vol_ss[d] >> 2);
-                sm.tabsgn[d][sidx] = (float)(int)(pk >> 32);
+            if (tid < S[d]) {
+                const long long pk = wrap_outofline(L.bound[d], lo[d] + tid, L.n[d]);
+                sm.taboff[d][tid] = (int)(pk & 0xffffffffll) * L.ss[d];
+                sm.tabsgn[d][tid] = (float)(int)(pk >> 32);
             }
         }
         __syncthreads();
     }
 
-    // is the whole support of the sample inside the staged box?
-    __device__ __forceinline__ bool contains(const Sample<K> &s) const
+    __device__ __forceinline__ bool contains(const Sample<C> &s) const
     {
+        const int kd[3] = { C::KX, C::K, C::K };
         bool in = s.valid;
 #pragma unroll
-        for (int d = 0; d < 3; ++d) in = in && (s.i0[d] >= lo[d]) && (s.i0[d] + K < lo[d] + S[d]);
+        for (int d = 0; d < 3; ++d) in = in && (s.i0[d] >= lo[d]) && (s.i0[d] + kd[d] < lo[d] + S[d]);
         return in;
     }
 
-    // Classify this thread's samples: bit v of the result = "fast" (in box); the others
-    // that are valid go to the block's slow list.
+    // bit v of the result = sample v is "fast" (support inside the box); other valid
+    // samples are appended to the block's slow list.
     __device__ __forceinline__ unsigned classify(const KParams &p, const float *__restrict__ grid, int64_t b,
                                                  const TileGeom &g, Smem &sm) const
     {
         unsigned fastmask = 0;
 #pragma unroll
-        for (int v = 0; v < VPT; ++v) {
-            const Sample<K> s = load_sample<K>(p, grid, b, g, v);
+        for (int v = 0; v < C::VPT; ++v) {
+            const Sample<C> s = load_sample<C>(p, grid, b, g, threadIdx.x, v);
             if (contains(s)) fastmask |= 1u << v;
             else if (s.valid) {
                 const int slot = atomicAdd(&sm.nslow, 1);
-                if (slot < SLOWCAP) sm.slow[slot] = (unsigned short)(threadIdx.x * VPT + v);
+                if (slot < SLOWCAP) sm.slow[slot] = (unsigned short)(threadIdx.x * C::VPT + v);
             }
         }
         __syncthreads();
         return fastmask;
     }
+
+    __device__ __forceinline__ int base(const Sample<C> &s) const
+    {
+        return ((s.i0[0] - lo[0]) * S[1] + (s.i0[1] - lo[1])) * C::PZ + (s.i0[2] - lo[2]);
+    }
 };
 
+// Decode an entry of the slow list into the sample's linear index / coordinates.
+template <typename C>
+__device__ __forceinline__ int64_t slow_sample(const TileGeom &g, int code, const KParams &p, const float *__restrict__ grid,
+                                               int64_t b, float *x)
+{
+    const int stid = code / C::VPT, sv = code % C::VPT;
+    int ox, oy, oz;
+    sample_pos<C>(g, stid, sv, ox, oy, oz);
+    const int64_t o = ((int64_t)ox * g.gy + oy) * g.gz + oz;
+    const float *gp = grid + b * p.grid_sb + o * C::D;
+#pragma unroll
+    for (int d = 0; d < 3; ++d) x[d] = C::pd(d) >= 0 ? gp[C::pd(d) < 0 ? 0 : C::pd(d)] : 0.f;
+    return o;
+}
+
+template <typename C>
+__device__ __forceinline__ bool coords_inb(const KParams &p, const float *x)
+{
+    bool in = true;
+#pragma unroll
+    for (int d = 0; d < 3; ++d)
+        if (C::pd(d) >= 0) in = in && x[d] > (float)p.mask_lo && x[d] < (float)p.mask_hi[C::pd(d) < 0 ? 0 : C::pd(d)];
+    return in;
+}
+
 // Stage one channel of the box: LDS[x][y][z] = sign * vol[wrapped(x,y,z)]
+template <typename C>
 __device__ __forceinline__ void stage_box(const float *__restrict__ vc, const int *S, Smem &sm)
 {
     const int tid = threadIdx.x;
-    const int z = tid & 31;
+    const int z = tid % C::PZ;
     const bool zin = z < S[2];
     const int oz = zin ? sm.taboff[2][z] : 0;
     const float sz = zin ? sm.tabsgn[2][z] : 0.f;
     const int rows = S[0] * S[1];
-    int y = tid >> 5, x = 0;
+    constexpr int RSTEP = C::NT / C::PZ;
+    int y = tid / C::PZ, x = 0;
     while (y >= S[1]) { y -= S[1]; ++x; }
-    for (int r = tid >> 5; r < rows; r += NT / 32) {
+    for (int r = tid / C::PZ; r < rows; r += RSTEP) {
         if (zin) {
             const float s = sm.tabsgn[0][x] * sm.tabsgn[1][y] * sz;
-            const float v = vc[sm.taboff[0][x] + sm.taboff[1][y] + oz];
-            sm.box[r * PZ + z] = v * s;
+            sm.box[r * C::PZ + z] = vc[sm.taboff[0][x] + sm.taboff[1][y] + oz] * s;
         }
-        y += NT / 32;
+        y += RSTEP;
         while (y >= S[1]) { y -= S[1]; ++x; }
     }
 }
 
-// ---------------------------------------------------------------------------
-// pull
-// ---------------------------------------------------------------------------
-template <int K>
-__global__ __launch_bounds__(NT) void pull_tiled(KParams p, const float *__restrict__ vol, const float *__restrict__ grid,
-                                                 float *__restrict__ val, int gx, int gy, int gz, int ntx, int nty, int ntz)
+template <typename C>
+__device__ __forceinline__ TileGeom tile_geom(int gx, int gy, int gz, int nty, int ntz)
 {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    Smem &sm = *reinterpret_cast<Smem *>(smem_raw);
-    const int tid = threadIdx.x;
-    const int64_t b = blockIdx.y;
     int tile = blockIdx.x;
     const int tzi = tile % ntz; tile /= ntz;
     const int tyi = tile % nty; const int txi = tile / nty;
-    const TileGeom g = { gx, gy, gz, txi * TX, tyi * TY, tzi * TZ };
+    return TileGeom{ gx, gy, gz, txi * C::TX, tyi * C::TY, tzi * C::TZ };
+}
 
-    Box<K> box;
-    box.build(p, grid, b, g, sm);
+// ---------------------------------------------------------------------------
+// Gather from the staged box: value (GRAD = false) or the three partial
+// derivatives (GRAD = true).  out[0] = value, out[1..3] = d/dx, d/dy, d/dz.
+// ---------------------------------------------------------------------------
+template <typename C, bool GRAD>
+__device__ __forceinline__ void gather_box(const Smem &sm, const Box<C> &box, const Sample<C> &s, int lin, float *out)
+{
+    constexpr int K = C::K, KX = C::KX;
+    float wx[KX + 1], wy[K + 1], wz[K + 1], gx_[KX + 1], gy_[K + 1], gz_[K + 1];
+    if (KX > 0) weights<KX>(lin, s.t[0], wx); else wx[0] = 1.f;
+    weights<K>(lin, s.t[1], wy); weights<K>(lin, s.t[2], wz);
+    if (GRAD) {
+        if (KX > 0) wgrads<KX>(lin, s.t[0], gx_); else gx_[0] = 0.f;
+        wgrads<K>(lin, s.t[1], gy_); wgrads<K>(lin, s.t[2], gz_);
+    }
+    const float *bp = sm.box + box.base(s);
+    float a = 0.f, ax = 0.f, ay = 0.f, az = 0.f;
+#pragma unroll
+    for (int i = 0; i <= KX; ++i) {
+        float pW = 0.f, pGy = 0.f, pGz = 0.f;
+#pragma unroll
+        for (int j = 0; j <= K; ++j) {
+            const float *rp = bp + (i * box.S[1] + j) * C::PZ;
+            float rW = 0.f, rG = 0.f;
+#pragma unroll
+            for (int k = 0; k <= K; ++k) {
+                const float v = rp[k];
+                rW = __builtin_fmaf(wz[k], v, rW);
+                if (GRAD) rG = __builtin_fmaf(gz_[k], v, rG);
+            }
+            pW = __builtin_fmaf(wy[j], rW, pW);
+            if (GRAD) { pGy = __builtin_fmaf(gy_[j], rW, pGy); pGz = __builtin_fmaf(wy[j], rG, pGz); }
+        }
+        a = __builtin_fmaf(wx[i], pW, a);
+        if (GRAD) {
+            ax = __builtin_fmaf(gx_[i], pW, ax);
+            ay = __builtin_fmaf(wx[i], pGy, ay);
+            az = __builtin_fmaf(wx[i], pGz, az);
+        }
+    }
+    out[0] = a;
+    if (GRAD) { out[1] = ax; out[2] = ay; out[3] = az; }
+}
+
+// ---------------------------------------------------------------------------
+// pull (GRAD = false): val[b,c,o]     = mask * sum w vol
+// grad (GRAD = true) : val[b,c,o,d]   = mask * sum (g_d prod w) vol
+// ---------------------------------------------------------------------------
+template <typename C, bool GRAD>
+__global__ __launch_bounds__(C::NT) void gather_tiled(KParams p, const float *__restrict__ vol, const float *__restrict__ grid,
+                                                      float *__restrict__ val, int gx, int gy, int gz, int nty, int ntz)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    Smem &sm = *reinterpret_cast<Smem *>(smem_raw);
+    constexpr int K = C::K, KX = C::KX, D = C::D;
+    const int tid = threadIdx.x;
+    const int64_t b = blockIdx.y;
+    const TileGeom g = tile_geom<C>(gx, gy, gz, nty, ntz);
+    const Lattice L = make_lattice<C>(p);
+
+    Box<C> box;
+    box.build(p, L, grid, b, g, sm);
     const unsigned fastmask = box.classify(p, grid, b, g, sm);
     const int nslow = sm.nslow;
-    const float thr_lo = (float)p.mask_lo;
-    const float thr_hi[3] = { (float)p.mask_hi[0], (float)p.mask_hi[1], (float)p.mask_hi[2] };
-    const Lattice L = make_lattice(p, K);
 
     for (int c = 0; c < p.C; ++c) {
         const float *vc = vol + b * p.vol_sb + c * p.vol_sc;
         float *oc = val + b * p.val_sb + c * p.val_sc;
         __syncthreads();                               // previous channel's readers are done
-        if (!(p.dbg & 1)) stage_box(vc, box.S, sm);
+        if (!(p.dbg & 1)) stage_box<C>(vc, box.S, sm);
         __syncthreads();
 #pragma unroll
-        for (int v = 0; v < VPT; ++v) {
+        for (int v = 0; v < C::VPT; ++v) {
             if (p.dbg & 2) continue;
             const bool fast = (fastmask >> v) & 1;
             if (!fast && nslow <= SLOWCAP) continue;   // invalid, or waiting in the slow list
-            const Sample<K> s = load_sample<K>(p, grid, b, g, v);
+            const Sample<C> s = load_sample<C>(p, grid, b, g, tid, v);
             if (!s.valid) continue;
-            float acc = 0.f;
+            float r[4] = { 0.f, 0.f, 0.f, 0.f };
             if (fast) {
-                float wx[K + 1], wy[K + 1], wz[K + 1];
-                weights<K>(p, s.t[0], wx); weights<K>(p, s.t[1], wy); weights<K>(p, s.t[2], wz);
-                const float *bp = sm.box + ((s.i0[0] - box.lo[0]) * box.S[1] + (s.i0[1] - box.lo[1])) * PZ + (s.i0[2] - box.lo[2]);
-#pragma unroll
-                for (int i = 0; i <= K; ++i) {
-                    float pl = 0.f;
-#pragma unroll
-                    for (int j = 0; j <= K; ++j) {
-                        const float *rp = bp + (i * box.S[1] + j) * PZ;
-                        float r = 0.f;
-#pragma unroll
-                        for (int k = 0; k <= K; ++k) r = __builtin_fmaf(wz[k], rp[k], r);
-                        pl = __builtin_fmaf(wy[j], r, pl);
-                    }
-                    acc = __builtin_fmaf(wx[i], pl, acc);
-                }
+                gather_box<C, GRAD>(sm, box, s, L.lin, r);
             } else {
                 // slow list overflowed (pathological deformation): per-thread global gather
-                acc = gather_one_thread<K>(L, vc, s.i0[0], s.i0[1], s.i0[2], s.t[0], s.t[1], s.t[2]);
+                if (!GRAD) r[0] = gather_one_thread<K, KX>(L, vc, s.i0[0], s.i0[1], s.i0[2], s.t[0], s.t[1], s.t[2], -1);
+                else {
+                    if (D == 3) r[1] = gather_one_thread<K, KX>(L, vc, s.i0[0], s.i0[1], s.i0[2], s.t[0], s.t[1], s.t[2], 0);
+                    r[2] = gather_one_thread<K, KX>(L, vc, s.i0[0], s.i0[1], s.i0[2], s.t[0], s.t[1], s.t[2], 1);
+                    r[3] = gather_one_thread<K, KX>(L, vc, s.i0[0], s.i0[1], s.i0[2], s.t[0], s.t[1], s.t[2], 2);
+                }
             }
-            if (p.extrapolate != 1) acc *= s.inb ? 1.f : 0.f;      // nd.py:139-140
-            oc[s.o] = acc;
+            const float m = (p.extrapolate != 1 && !s.inb) ? 0.f : 1.f;      // nd.py:139-140, 284-285
+            if (!GRAD) oc[s.o] = r[0] * m;
+            else {
+#pragma unroll
+                for (int d = 0; d < D; ++d) oc[s.o * D + d] = r[1 + (3 - D) + d] * m;
+            }
         }
-        // slow list: one wave per sample, lane = tap (K <= 3: (K+1)^3 <= 64 taps)
+        // slow list: one wave per sample, lanes = taps
         if (nslow > 0 && nslow <= SLOWCAP) {
             const int wave = tid >> 6, lane = tid & 63;
-            for (int sidx = wave; sidx < nslow; sidx += NT / 64) {
-                const int code = sm.slow[sidx];
-                const int stid = code / VPT, sv = code % VPT;
-                const int sx_ = g.ox0 + (stid >> 8) + 4 * sv, sy_ = g.oy0 + ((stid >> 4) & 15), sz_ = g.oz0 + (stid & 15);
-                const int64_t o = ((int64_t)sx_ * gy + sy_) * gz + sz_;
-                const float *gp = grid + b * p.grid_sb + o * 3;
-                int off;
-                const float w = tap_of_lane<K>(L, gp[0], gp[1], gp[2], lane, &off);
-                float acc = wave_sum(w != 0.f ? w * vc[off] : 0.f);
-                if (lane == 0) {
-                    if (p.extrapolate != 1) {
-                        const bool in = gp[0] > thr_lo && gp[0] < thr_hi[0] && gp[1] > thr_lo && gp[1] < thr_hi[1] &&
-                                        gp[2] > thr_lo && gp[2] < thr_hi[2];
-                        acc *= in ? 1.f : 0.f;
+            constexpr int NTAP = (KX + 1) * (K + 1) * (K + 1);
+            for (int sidx = wave; sidx < nslow; sidx += C::NT / 64) {
+                float x[3];
+                const int64_t o = slow_sample<C>(g, sm.slow[sidx], p, grid, b, x);
+                float a[4] = { 0.f, 0.f, 0.f, 0.f };
+                for (int t0 = 0; t0 < NTAP; t0 += 64) {
+                    int off; float gr[3];
+                    const float w = tap_weight<K, KX>(L, x[0], x[1], x[2], t0 + lane, &off, GRAD ? gr : nullptr);
+                    const float v = (t0 + lane < NTAP) ? vc[off] : 0.f;
+                    if (!GRAD) a[0] += w * v;
+                    else { a[1] += gr[0] * v; a[2] += gr[1] * v; a[3] += gr[2] * v; }
+                }
+                const float m = (p.extrapolate != 1 && !coords_inb<C>(p, x)) ? 0.f : 1.f;
+                if (!GRAD) { const float r = wave_sum(a[0]); if (lane == 0) oc[o] = r * m; }
+                else {
+#pragma unroll
+                    for (int d = 0; d < D; ++d) {
+                        const float r = wave_sum(a[1 + (3 - D) + d]);
+                        if (lane == 0) oc[o * D + d] = r * m;
                     }
-                    oc[o] = acc;
                 }
             }
         }
@@ -419,262 +556,414 @@ __global__ __launch_bounds__(NT) void pull_tiled(KParams p, const float *__restr
 }
 
 // ---------------------------------------------------------------------------
-// push / count: the adjoint.
+// Scatter of one channel: src(sample) * weights -> target, through the LDS box in
+// 64-bit fixed point.  Shared by push / count and by the fused pull backward.
+// `src_of(sample)` returns the (masked) source value of a fast sample,
+// `src_slow(o)` the unmasked source of a slow-list sample.
 //
-// LDS float atomics are the wrong tool on gfx950: measured (tools/microbench/
-// lds_atomics.hip) ds_add_f32 retires 0.33 lanes/clk/CU, ds_add_u32 5.7 and
-// ds_add_u64 4.6 under the same random-address pattern.  So contributions are
-// accumulated in the LDS box as 64-bit FIXED POINT:
-//     q = rne(src * w * 2^e),  2^e * max|src| <= 2^30  (per tile and channel)
-// i.e. every contribution is rounded with an absolute error <= 2^-31 max|src|
-// (far below fp32 rounding of the sums) and a 64-bit slot cannot overflow.
-// The box holds 8 bytes per slot, so it is filled in passes over slabs of box
-// rows (x); each tap lands in exactly one pass.  After a pass every touched
-// slot is converted back to float, given the boundary sign of the slot, and
-// flushed with ONE coalesced global atomic instead of (K+1)^3 scattered ones.
-// Non-finite sources (inf/nan) take the per-thread float path so that IEEE
-// semantics survive.
+//     q = rne(src * w * 2^e),  2^e * max|src| <= 2^30   (per tile and channel)
+// every contribution is rounded with absolute error <= 2^-31 max|src| (far below
+// fp32 rounding of the sums) and a 64-bit slot cannot overflow.  The box holds 8
+// bytes per slot, so it is filled in passes over slabs of (flattened) box rows;
+// each tap lands in exactly one pass.  Non-finite sources (inf / nan) take the
+// per-thread float path so that IEEE semantics survive.
 // ---------------------------------------------------------------------------
-constexpr int BOX64 = BOX / 2;                 // 64-bit slots that fit in the box area
+template <typename C, typename SrcFn, typename SrcSlowFn>
+__device__ __forceinline__ void scatter_channel(const KParams &p, const Lattice &L, const float *__restrict__ grid, int64_t b,
+                                                const TileGeom &g, const Box<C> &box, unsigned fastmask, int nslow,
+                                                float *__restrict__ vc, Smem &sm, SrcFn src_of, SrcSlowFn src_slow)
+{
+    constexpr int K = C::K, KX = C::KX;
+    constexpr int BOX64 = C::BOXF / 2;             // 64-bit slots that fit in the box area
+    unsigned long long *box64 = reinterpret_cast<unsigned long long *>(sm.box);
+    const int tid = threadIdx.x;
+    // ---- block maximum of the sources -> fixed-point scale ---------------------------
+    float amax = 0.f;
+#pragma unroll
+    for (int v = 0; v < C::VPT; ++v) {
+        const Sample<C> s = load_sample<C>(p, grid, b, g, tid, v);
+        if (s.valid) {
+            const float a = __builtin_fabsf(src_of(s));
+            amax = (a > amax || a != a) ? a : amax;                            // NaN sticks
+        }
+    }
+    __syncthreads();                               // whoever used the box / sm.hi before is done
+    if (tid == 0) sm.hi[0] = 0;
+    __syncthreads();
+    {
+        int bits = __float_as_int(amax);           // non-negative floats (and NaN) order like ints
+        bits = wave_max(bits);
+        if ((tid & 63) == 0) atomicMax(&sm.hi[0], bits);
+    }
+    __syncthreads();
+    const int mbits = sm.hi[0];
+    if (mbits == 0) return;                        // nothing to splat in this tile / channel
+    const bool finite = (mbits & 0x7f800000) != 0x7f800000;
+    // 2^e * max <= 2^30 : e = 29 - exponent(max)
+    int ex = ((mbits >> 23) & 0xff) - 127;
+    ex = ex < -90 ? -90 : ex;                      // denormal / tiny maxima: keep 2^e finite
+    const float scale = __int_as_float((127 + 29 - ex) << 23);
+    const float inv_scale = __int_as_float((127 - 29 + ex) << 23);
 
-template <int K, bool COUNT>
-__global__ __launch_bounds__(NT) void push_tiled(KParams p, const float *__restrict__ val, const float *__restrict__ grid,
-                                                 float *__restrict__ vol, int gx, int gy, int gz, int ntx, int nty, int ntz)
+    if (!finite || nslow > SLOWCAP) {
+        // pathological tile (non-finite data, or the deformation does not fit the box):
+        // per-thread float atomics straight to global memory
+#pragma unroll 1
+        for (int v = 0; v < C::VPT; ++v) {
+            const Sample<C> s = load_sample<C>(p, grid, b, g, tid, v);
+            if (!s.valid || (p.dbg & 2)) continue;
+            scatter_one_thread<K, KX>(L, vc, src_of(s), s.i0[0], s.i0[1], s.i0[2], s.t[0], s.t[1], s.t[2]);
+        }
+        return;
+    }
+
+    // ---- slow list: one wave per sample, lanes = taps, one global atomic per lane --------
+    if (nslow > 0) {
+        const int wave = tid >> 6, lane = tid & 63;
+        constexpr int NTAP = (KX + 1) * (K + 1) * (K + 1);
+        for (int sidx = wave; sidx < nslow; sidx += C::NT / 64) {
+            float x[3];
+            const int64_t o = slow_sample<C>(g, sm.slow[sidx], p, grid, b, x);
+            float sv = src_slow(o);
+            if (p.extrapolate != 1 && !coords_inb<C>(p, x)) sv *= 0.f;
+            for (int t0 = 0; t0 < NTAP; t0 += 64) {
+                int off;
+                const float w = tap_weight<K, KX>(L, x[0], x[1], x[2], t0 + lane, &off, nullptr);
+                if (t0 + lane < NTAP)
+                    __hip_atomic_fetch_add(vc + off, w * sv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+    }
+
+    // ---- passes over slabs of flattened box rows r = x * S_y + y (8 bytes per slot) -------
+    const int rows_all = box.S[0] * box.S[1];
+    int rows_pp = BOX64 / C::PZ;                   // rows per pass
+    if (C::D == 3 && rows_pp >= box.S[1]) rows_pp -= rows_pp % box.S[1];   // whole x-rows per pass
+    const int npass = (rows_all + rows_pp - 1) / rows_pp;
+    for (int ps = 0; ps < npass; ++ps) {
+        const int r_lo = ps * rows_pp;
+        const int r_n = (rows_all - r_lo) < rows_pp ? (rows_all - r_lo) : rows_pp;
+        __syncthreads();                           // previous pass is flushed
+        for (int e = tid; e < r_n * C::PZ; e += C::NT) box64[e] = 0ull;
+        __syncthreads();
+#pragma unroll
+        for (int v = 0; v < C::VPT; ++v) {
+            if (!((fastmask >> v) & 1) || (p.dbg & 2)) continue;
+            const Sample<C> s = load_sample<C>(p, grid, b, g, tid, v);
+            const int r0 = (s.i0[0] - box.lo[0]) * box.S[1] + (s.i0[1] - box.lo[1]) - r_lo;   // row of tap (0,0) in this slab
+            if (r0 + KX * box.S[1] + K < 0 || r0 >= r_n) continue;
+            float wx[KX + 1], wy[K + 1], wz[K + 1];
+            if (KX > 0) weights<KX>(L.lin, s.t[0], wx); else wx[0] = 1.f;
+            weights<K>(L.lin, s.t[1], wy); weights<K>(L.lin, s.t[2], wz);
+            const float ss = src_of(s) * scale;
+            unsigned long long *bp = box64 + r0 * C::PZ + (s.i0[2] - box.lo[2]);
+#pragma unroll
+            for (int i = 0; i <= KX; ++i) {
+                const float si = ss * wx[i];
+#pragma unroll
+                for (int j = 0; j <= K; ++j) {
+                    const int rr = r0 + i * box.S[1] + j;
+                    if (rr < 0 || rr >= r_n) continue;
+                    unsigned long long *rp = bp + (i * box.S[1] + j) * C::PZ;
+                    const float sj = si * wy[j];
+#pragma unroll
+                    for (int k = 0; k <= K; ++k) {
+                        const int q = __float2int_rn(sj * wz[k]);
+                        atomicAdd(rp + k, (unsigned long long)(long long)q);      // ds_add_u64
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        // flush the slab: fixed point -> float, slot sign, one coalesced global atomic per touched slot
+        if (!(p.dbg & 1)) {
+            const int z = tid % C::PZ;
+            const bool zin = z < box.S[2];
+            const int oz_ = zin ? sm.taboff[2][z] : 0;
+            const float sz = zin ? sm.tabsgn[2][z] : 0.f;
+            constexpr int RSTEP = C::NT / C::PZ;
+            int y = r_lo + tid / C::PZ, x = 0;
+            while (y >= box.S[1]) { y -= box.S[1]; ++x; }
+            for (int r = tid / C::PZ; r < r_n; r += RSTEP) {
+                if (zin) {
+                    const long long a = (long long)box64[r * C::PZ + z];
+                    if (a != 0) {
+                        const float sgn = sm.tabsgn[0][x] * sm.tabsgn[1][y] * sz;
+                        const float f = (float)((double)a * (double)inv_scale);
+                        __hip_atomic_fetch_add(vc + sm.taboff[0][x] + sm.taboff[1][y] + oz_, f * sgn,
+                                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                }
+                y += RSTEP;
+                while (y >= box.S[1]) { y -= box.S[1]; ++x; }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// push / count : vol[b,c,tap] += w * mask * val[b,c,o]      (nd.py:146-213, pushpull.py:106-142)
+// ---------------------------------------------------------------------------
+template <typename C, bool COUNT>
+__global__ __launch_bounds__(C::NT) void push_tiled(KParams p, const float *__restrict__ val, const float *__restrict__ grid,
+                                                    float *__restrict__ vol, int gx, int gy, int gz, int nty, int ntz)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     Smem &sm = *reinterpret_cast<Smem *>(smem_raw);
-    unsigned long long *box64 = reinterpret_cast<unsigned long long *>(sm.box);
-    const int tid = threadIdx.x;
     const int64_t b = blockIdx.y;
-    int tile = blockIdx.x;
-    const int tzi = tile % ntz; tile /= ntz;
-    const int tyi = tile % nty; const int txi = tile / nty;
-    const TileGeom g = { gx, gy, gz, txi * TX, tyi * TY, tzi * TZ };
-
-    Box<K> box;
-    box.build(p, grid, b, g, sm);
+    const TileGeom g = tile_geom<C>(gx, gy, gz, nty, ntz);
+    const Lattice L = make_lattice<C>(p);
+    Box<C> box;
+    box.build(p, L, grid, b, g, sm);
     const unsigned fastmask = box.classify(p, grid, b, g, sm);
     const int nslow = sm.nslow;
-    const float thr_lo = (float)p.mask_lo;
-    const float thr_hi[3] = { (float)p.mask_hi[0], (float)p.mask_hi[1], (float)p.mask_hi[2] };
-    const Lattice L = make_lattice(p, K);
-    // rows of the box (x) per pass, so that rows * S_y * PZ 64-bit slots fit
-    const int xrows = BOX64 / (box.S[1] * PZ);
-    const int npass = (box.S[0] + xrows - 1) / xrows;
-
     for (int c = 0; c < p.C; ++c) {
         const float *ic = COUNT ? nullptr : val + b * p.val_sb + c * p.val_sc;
         float *vc = vol + b * p.vol_sb + c * p.vol_sc;
-        // ---- block maximum of the sources of this channel -> fixed-point scale -----------
-        float amax = 0.f;
+        scatter_channel<C>(p, L, grid, b, g, box, fastmask, nslow, vc, sm,
+            [&](const Sample<C> &s) { const float v = COUNT ? 1.f : ic[s.o]; return (p.extrapolate != 1 && !s.inb) ? 0.f * v : v; },   // nd.py:201-203
+            [&](int64_t o) { return COUNT ? 1.f : ic[o]; });
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Fused backward of pull (pushpull.py:237-258):
+//   gvol[b,c,tap] += w * mask * gout[b,c,o]                        (if gvol)
+//   ggrid[b,o,d]   = mask * sum_c gout[b,c,o] * d/dx_d pull(vol)   (if ggrid)
+// ---------------------------------------------------------------------------
+template <typename C>
+__global__ __launch_bounds__(C::NT) void pullbwd_tiled(KParams p, const float *__restrict__ gout, const float *__restrict__ vol,
+                                                       const float *__restrict__ grid, float *__restrict__ gvol,
+                                                       float *__restrict__ ggrid, int64_t gvol_sb, int64_t gvol_sc,
+                                                       int gx, int gy, int gz, int nty, int ntz)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    Smem &sm = *reinterpret_cast<Smem *>(smem_raw);
+    constexpr int K = C::K, KX = C::KX, D = C::D;
+    const int tid = threadIdx.x;
+    const int64_t b = blockIdx.y;
+    const TileGeom g = tile_geom<C>(gx, gy, gz, nty, ntz);
+    const Lattice L = make_lattice<C>(p);
+    Box<C> box;
+    box.build(p, L, grid, b, g, sm);
+    const unsigned fastmask = box.classify(p, grid, b, g, sm);
+    const int nslow = sm.nslow;
+
+    float gg[C::VPT][3];
 #pragma unroll
-        for (int v = 0; v < VPT; ++v) {
-            const Sample<K> s = load_sample<K>(p, grid, b, g, v);
-            if (s.valid) {
-                float sv = COUNT ? 1.f : ic[s.o];
-                if (p.extrapolate != 1) sv *= s.inb ? 1.f : 0.f;                   // nd.py:201-203
-                const float a = __builtin_fabsf(sv);
-                amax = (a > amax || a != a) ? a : amax;                            // NaN sticks
-            }
-        }
-        __syncthreads();                               // previous channel is completely flushed
-        if (tid == 0) sm.hi[0] = 0;                    // (lo/hi are free after Box::build)
-        __syncthreads();
-        {
-            int bits = __float_as_int(amax);           // non-negative floats (and NaN) order like ints
-            bits = wave_max(bits);
-            if ((tid & 63) == 0) atomicMax(&sm.hi[0], bits);
-        }
-        __syncthreads();
-        const int mbits = sm.hi[0];
-        if (mbits == 0) continue;                      // nothing to splat in this tile / channel
-        const bool finite = (mbits & 0x7f800000) != 0x7f800000;
-        // 2^e * max <= 2^30 : e = 29 - exponent(max)
-        int ex = ((mbits >> 23) & 0xff) - 127;
-        ex = ex < -90 ? -90 : ex;                      // denormal / tiny maxima: keep 2^e finite
-        const float scale = __int_as_float((127 + 29 - ex) << 23);
-        const float inv_scale = __int_as_float((127 - 29 + ex) << 23);
+    for (int v = 0; v < C::VPT; ++v) { gg[v][0] = 0.f; gg[v][1] = 0.f; gg[v][2] = 0.f; }
 
-        if (!finite || nslow > SLOWCAP) {
-            // pathological tile (non-finite data, or the deformation does not fit the box):
-            // per-thread float atomics straight to global memory
-#pragma unroll 1
-            for (int v = 0; v < VPT; ++v) {
-                const Sample<K> s = load_sample<K>(p, grid, b, g, v);
-                if (!s.valid || (p.dbg & 2)) continue;
-                float sv = COUNT ? 1.f : ic[s.o];
-                if (p.extrapolate != 1) sv *= s.inb ? 1.f : 0.f;
-                scatter_one_thread<K>(L, vc, sv, s.i0[0], s.i0[1], s.i0[2], s.t[0], s.t[1], s.t[2]);
-            }
-            continue;
-        }
-
-        // ---- slow list: one wave per sample, lane = tap, one global atomic per lane ----
-        if (nslow > 0) {
-            const int wave = tid >> 6, lane = tid & 63;
-            for (int sidx = wave; sidx < nslow; sidx += NT / 64) {
-                const int code = sm.slow[sidx];
-                const int stid = code / VPT, sv = code % VPT;
-                const int sx_ = g.ox0 + (stid >> 8) + 4 * sv, sy_ = g.oy0 + ((stid >> 4) & 15), sz_ = g.oz0 + (stid & 15);
-                const int64_t o = ((int64_t)sx_ * gy + sy_) * gz + sz_;
-                const float *gp = grid + b * p.grid_sb + o * 3;
-                float sv_ = COUNT ? 1.f : ic[o];
-                if (p.extrapolate != 1) {
-                    const bool in = gp[0] > thr_lo && gp[0] < thr_hi[0] && gp[1] > thr_lo && gp[1] < thr_hi[1] &&
-                                    gp[2] > thr_lo && gp[2] < thr_hi[2];
-                    sv_ *= in ? 1.f : 0.f;
-                }
-                int off;
-                const float w = tap_of_lane<K>(L, gp[0], gp[1], gp[2], lane, &off);
-                if (lane < (K + 1) * (K + 1) * (K + 1))
-                    __hip_atomic_fetch_add(vc + off, w * sv_, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-        }
-
-        // ---- passes over slabs of box rows ---------------------------------------------
-        for (int ps = 0; ps < npass; ++ps) {
-            const int x_lo = ps * xrows;
-            const int x_n = (box.S[0] - x_lo) < xrows ? (box.S[0] - x_lo) : xrows;
-            const int slab = x_n * box.S[1] * PZ;
-            __syncthreads();                           // previous pass is flushed
-            for (int e = tid; e < slab; e += NT) box64[e] = 0ull;
+    for (int c = 0; c < p.C; ++c) {
+        const float *vc = vol + b * p.vol_sb + c * p.vol_sc;
+        const float *gc = gout + b * p.val_sb + c * p.val_sc;
+        if (ggrid) {
+            __syncthreads();
+            stage_box<C>(vc, box.S, sm);
             __syncthreads();
 #pragma unroll
-            for (int v = 0; v < VPT; ++v) {
-                if (!((fastmask >> v) & 1) || (p.dbg & 2)) continue;
-                const Sample<K> s = load_sample<K>(p, grid, b, g, v);
-                const int bx = s.i0[0] - box.lo[0] - x_lo;              // row of tap i = 0 inside this slab
-                if (bx + K < 0 || bx >= x_n) continue;
-                float sv = COUNT ? 1.f : ic[s.o];
-                if (p.extrapolate != 1) sv *= s.inb ? 1.f : 0.f;
-                float wx[K + 1], wy[K + 1], wz[K + 1];
-                weights<K>(p, s.t[0], wx); weights<K>(p, s.t[1], wy); weights<K>(p, s.t[2], wz);
-                const float ss = sv * scale;
-                unsigned long long *bp = box64 + (bx * box.S[1] + (s.i0[1] - box.lo[1])) * PZ + (s.i0[2] - box.lo[2]);
+            for (int v = 0; v < C::VPT; ++v) {
+                const bool fast = (fastmask >> v) & 1;
+                if (!fast && nslow <= SLOWCAP) continue;
+                const Sample<C> s = load_sample<C>(p, grid, b, g, tid, v);
+                if (!s.valid) continue;
+                float r[4] = { 0.f, 0.f, 0.f, 0.f };
+                if (fast) gather_box<C, true>(sm, box, s, L.lin, r);
+                else {
+                    if (D == 3) r[1] = gather_one_thread<K, KX>(L, vc, s.i0[0], s.i0[1], s.i0[2], s.t[0], s.t[1], s.t[2], 0);
+                    r[2] = gather_one_thread<K, KX>(L, vc, s.i0[0], s.i0[1], s.i0[2], s.t[0], s.t[1], s.t[2], 1);
+                    r[3] = gather_one_thread<K, KX>(L, vc, s.i0[0], s.i0[1], s.i0[2], s.t[0], s.t[1], s.t[2], 2);
+                }
+                const float go = (p.extrapolate != 1 && !s.inb) ? 0.f * gc[s.o] : gc[s.o];
+                gg[v][0] = __builtin_fmaf(r[1], go, gg[v][0]);
+                gg[v][1] = __builtin_fmaf(r[2], go, gg[v][1]);
+                gg[v][2] = __builtin_fmaf(r[3], go, gg[v][2]);
+            }
+            // slow list: gradient of the slow samples, accumulated straight into ggrid
+            // (the same lane of the same wave owns a slow sample for every channel)
+            if (nslow > 0 && nslow <= SLOWCAP) {
+                const int wave = tid >> 6, lane = tid & 63;
+                constexpr int NTAP = (KX + 1) * (K + 1) * (K + 1);
+                for (int sidx = wave; sidx < nslow; sidx += C::NT / 64) {
+                    float x[3];
+                    const int64_t o = slow_sample<C>(g, sm.slow[sidx], p, grid, b, x);
+                    float a[3] = { 0.f, 0.f, 0.f };
+                    for (int t0 = 0; t0 < NTAP; t0 += 64) {
+                        int off; float gr[3];
+                        tap_weight<K, KX>(L, x[0], x[1], x[2], t0 + lane, &off, gr);
+                        const float vv = (t0 + lane < NTAP) ? vc[off] : 0.f;
+                        a[0] += gr[0] * vv; a[1] += gr[1] * vv; a[2] += gr[2] * vv;
+                    }
+                    const float go = (p.extrapolate != 1 && !coords_inb<C>(p, x)) ? 0.f : gc[o];
 #pragma unroll
-                for (int i = 0; i <= K; ++i) {
-                    if (bx + i < 0 || bx + i >= x_n) continue;
-                    const float si = ss * wx[i];
-#pragma unroll
-                    for (int j = 0; j <= K; ++j) {
-                        unsigned long long *rp = bp + (i * box.S[1] + j) * PZ;
-                        const float sj = si * wy[j];
-#pragma unroll
-                        for (int k = 0; k <= K; ++k) {
-                            const int q = __float2int_rn(sj * wz[k]);
-                            atomicAdd(rp + k, (unsigned long long)(long long)q);      // ds_add_u64
+                    for (int d = 0; d < D; ++d) {
+                        const float r = wave_sum(a[(3 - D) + d]);
+                        if (lane == 0) {
+                            float *q = ggrid + (b * p.N + o) * D + d;
+                            *q = (c == 0 ? 0.f : *q) + r * go;
                         }
                     }
                 }
             }
-            __syncthreads();
-            // flush the slab: fixed point -> float, slot sign, one coalesced global atomic per touched slot
-            if (!(p.dbg & 1)) {
-                const int z = tid & 31;
-                const bool zin = z < box.S[2];
-                const int oz_ = zin ? sm.taboff[2][z] : 0;
-                const float sz = zin ? sm.tabsgn[2][z] : 0.f;
-                const int rows = x_n * box.S[1];
-                int y = tid >> 5, x = x_lo;
-                while (y >= box.S[1]) { y -= box.S[1]; ++x; }
-                for (int r = tid >> 5; r < rows; r += NT / 32) {
-                    if (zin) {
-                        const long long a = (long long)box64[r * PZ + z];
-                        if (a != 0) {
-                            const float sgn = sm.tabsgn[0][x] * sm.tabsgn[1][y] * sz;
-                            const float f = (float)((double)a * (double)inv_scale);
-                            __hip_atomic_fetch_add(vc + sm.taboff[0][x] + sm.taboff[1][y] + oz_, f * sgn,
-                                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        }
-                    }
-                    y += NT / 32;
-                    while (y >= box.S[1]) { y -= box.S[1]; ++x; }
-                }
-            }
+        }
+        if (gvol) {
+            float *qc = gvol + b * gvol_sb + c * gvol_sc;
+            scatter_channel<C>(p, L, grid, b, g, box, fastmask, nslow, qc, sm,
+                [&](const Sample<C> &s) { return (p.extrapolate != 1 && !s.inb) ? 0.f * gc[s.o] : gc[s.o]; },
+                [&](int64_t o) { return gc[o]; });
+        }
+    }
+    if (ggrid) {
+#pragma unroll
+        for (int v = 0; v < C::VPT; ++v) {
+            const bool fast = (fastmask >> v) & 1;
+            if (!fast && nslow <= SLOWCAP) continue;   // slow-list samples were written above
+            int ox, oy, oz;
+            sample_pos<C>(g, tid, v, ox, oy, oz);
+            if (!(ox < gx && oy < gy && oz < gz)) continue;
+            const int64_t o = ((int64_t)ox * gy + oy) * gz + oz;
+            float *q = ggrid + (b * p.N + o) * D;
+#pragma unroll
+            for (int d = 0; d < D; ++d) q[d] = gg[v][(3 - D) + d];
         }
     }
 }
 
-template <int K>
-static int launch_push_tiled(const KParams &k, const void *val, const void *grid, void *vol, int B,
-                             const int64_t *gshape, hipStream_t st)
-{
-    const int gx = (int)gshape[0], gy = (int)gshape[1], gz = (int)gshape[2];
-    const int ntx = (gx + TX - 1) / TX, nty = (gy + TY - 1) / TY, ntz = (gz + TZ - 1) / TZ;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void *)push_tiled<K, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(Smem));
-        if (e == hipSuccess)
-            e = hipFuncSetAttribute((const void *)push_tiled<K, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(Smem));
-        if (e != hipSuccess) return (int)e;
-        attr_set = true;
+// ---------------------------------------------------------------------------
+// Launchers
+// ---------------------------------------------------------------------------
+template <typename C>
+struct TileCount {
+    int gx, gy, gz, ntx, nty, ntz;
+    explicit TileCount(const interpol_problem *p)
+    {
+        gx = C::D == 3 ? (int)p->grid_shape[0] : 1;
+        gy = (int)p->grid_shape[C::D == 3 ? 1 : 0];
+        gz = (int)p->grid_shape[C::D == 3 ? 2 : 1];
+        ntx = (gx + C::TX - 1) / C::TX; nty = (gy + C::TY - 1) / C::TY; ntz = (gz + C::TZ - 1) / C::TZ;
     }
-    const dim3 g((unsigned)(ntx * nty * ntz), (unsigned)B);
+    dim3 grid(int B) const { return dim3((unsigned)(ntx * nty * ntz), (unsigned)B); }
+};
+
+template <typename C, typename F>
+static int big_lds(F kernel)
+{
+    const hipError_t e = hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_bytes<C>());
+    return e == hipSuccess ? 0 : (int)e;
+}
+
+#define IP_CHECK_LAUNCH() do { const hipError_t e_ = hipGetLastError(); return e_ == hipSuccess ? 1 : (int)e_; } while (0)
+
+template <typename C, bool GRAD>
+static int launch_gather(const interpol_problem *p, const KParams &k, const void *vol, const void *grid, void *val, hipStream_t st)
+{
+    static int attr = big_lds<C>(gather_tiled<C, GRAD>);
+    if (attr) return attr;
+    const TileCount<C> t(p);
+    hipLaunchKernelGGL((gather_tiled<C, GRAD>), t.grid((int)p->batch), dim3(C::NT), smem_bytes<C>(), st,
+                       k, (const float *)vol, (const float *)grid, (float *)val, t.gx, t.gy, t.gz, t.nty, t.ntz);
+    IP_CHECK_LAUNCH();
+}
+
+template <typename C>
+static int launch_push(const interpol_problem *p, const KParams &k, const void *val, const void *grid, void *vol, hipStream_t st)
+{
+    static int attr = big_lds<C>(push_tiled<C, false>) | big_lds<C>(push_tiled<C, true>);
+    if (attr) return attr;
+    const TileCount<C> t(p);
     if (val)
-        hipLaunchKernelGGL((push_tiled<K, false>), g, dim3(NT), sizeof(Smem), st,
-                           k, (const float *)val, (const float *)grid, (float *)vol, gx, gy, gz, ntx, nty, ntz);
+        hipLaunchKernelGGL((push_tiled<C, false>), t.grid((int)p->batch), dim3(C::NT), smem_bytes<C>(), st,
+                           k, (const float *)val, (const float *)grid, (float *)vol, t.gx, t.gy, t.gz, t.nty, t.ntz);
     else
-        hipLaunchKernelGGL((push_tiled<K, true>), g, dim3(NT), sizeof(Smem), st,
-                           k, (const float *)nullptr, (const float *)grid, (float *)vol, gx, gy, gz, ntx, nty, ntz);
-    const hipError_t e = hipGetLastError();
-    return e == hipSuccess ? 1 : (int)e;
+        hipLaunchKernelGGL((push_tiled<C, true>), t.grid((int)p->batch), dim3(C::NT), smem_bytes<C>(), st,
+                           k, (const float *)nullptr, (const float *)grid, (float *)vol, t.gx, t.gy, t.gz, t.nty, t.ntz);
+    IP_CHECK_LAUNCH();
 }
 
-template <int K>
-static int launch_pull_tiled(const KParams &k, const void *vol, const void *grid, void *val, int B,
-                             const int64_t *gshape, hipStream_t st)
+template <typename C>
+static int launch_pullbwd(const interpol_problem *p, const KParams &k, const void *gout, const void *vol, const void *grid,
+                          void *gvol, void *ggrid, int64_t gsb, int64_t gsc, hipStream_t st)
 {
-    const int gx = (int)gshape[0], gy = (int)gshape[1], gz = (int)gshape[2];
-    const int ntx = (gx + TX - 1) / TX, nty = (gy + TY - 1) / TY, ntz = (gz + TZ - 1) / TZ;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void *)pull_tiled<K>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(Smem));
-        if (e != hipSuccess) return (int)e;
-        attr_set = true;
-    }
-    hipLaunchKernelGGL((pull_tiled<K>), dim3((unsigned)(ntx * nty * ntz), (unsigned)B), dim3(NT), sizeof(Smem), st,
-                       k, (const float *)vol, (const float *)grid, (float *)val, gx, gy, gz, ntx, nty, ntz);
-    const hipError_t e = hipGetLastError();
-    return e == hipSuccess ? 1 : (int)e;
+    static int attr = big_lds<C>(pullbwd_tiled<C>);
+    if (attr) return attr;
+    const TileCount<C> t(p);
+    hipLaunchKernelGGL((pullbwd_tiled<C>), t.grid((int)p->batch), dim3(C::NT), smem_bytes<C>(), st,
+                       k, (const float *)gout, (const float *)vol, (const float *)grid, (float *)gvol, (float *)ggrid,
+                       gsb, gsc, t.gx, t.gy, t.gz, t.nty, t.ntz);
+    IP_CHECK_LAUNCH();
 }
+
+// Tile shapes: the box must hold tile + K + 2 * halo lattice points per dim.
+//   3-D, K <= 3 : 16x16x16 samples, 1024 threads (4 samples each), box <= 33x33x32
+//   3-D, K = 4,5: 8x8x16,           1024 threads (1 sample each)
+//   3-D, K = 6,7: 8x8x8,             512 threads
+//   2-D         : 1x16x32,           512 threads, LDS pitch 64 (box <= 72x64, 36 KiB)
+template <int K> struct Tile3 { using type = Cfg<K, 3, 16, 16, 16, 1024, 32>; };
+template <> struct Tile3<4> { using type = Cfg<4, 3, 8, 8, 16, 1024, 32>; };
+template <> struct Tile3<5> { using type = Cfg<5, 3, 8, 8, 16, 1024, 32>; };
+template <> struct Tile3<6> { using type = Cfg<6, 3, 8, 8, 8, 512, 32>; };
+template <> struct Tile3<7> { using type = Cfg<7, 3, 8, 8, 8, 512, 32>; };
+template <int K> struct Tile2 { using type = Cfg<K, 2, 1, 16, 32, 512, 64>; };
 
 } // namespace tiled
 
-// The tiled kernels cover: 3-D, float32, isotropic order 1..3, any bound / extrapolate,
-// batch <= 65535, lattice spatially addressable with 4-byte-aligned strides.
+// The tiled kernels cover: 2-D / 3-D, float32, isotropic order 1..7, any bound / extrapolate,
+// batch <= 65535.  Everything else (and tiny problems) runs on the generic kernels.
 static bool tiled_eligible(const interpol_problem *p, const KParams &k)
 {
-    if (p->dim != 3 || p->dtype != INTERPOL_F32) return false;
-    if (k.order[0] != k.order[1] || k.order[0] != k.order[2]) return false;
-    if (k.order[0] < 1 || k.order[0] > 3) return false;
+    if ((p->dim != 3 && p->dim != 2) || p->dtype != INTERPOL_F32) return false;
+    for (int d = 1; d < p->dim; ++d) if (k.order[d] != k.order[0]) return false;
+    if (k.order[0] < 1 || k.order[0] > 7) return false;
     if (p->batch > 65535) return false;
-    for (int d = 0; d < 3; ++d) if (p->grid_shape[d] > 0x7fffffff / 4) return false;
-    // tiny problems: the generic kernel has less fixed cost
-    if (p->grid_shape[0] * p->grid_shape[1] * p->grid_shape[2] < 4096) return false;
+    int64_t n = 1;
+    for (int d = 0; d < p->dim; ++d) { if (p->grid_shape[d] > 0x7fffffff / 4) return false; n *= p->grid_shape[d]; }
+    if (n < 4096) return false;       // tiny problems: the generic kernel has less fixed cost
     return true;
 }
+
+#define IP_BY_ORDER(FN, ...)                                                             \
+    if (p->dim == 3) switch (k.order[0]) {                                               \
+        case 1: return FN<typename tiled::Tile3<1>::type __VA_ARGS__;                    \
+        case 2: return FN<typename tiled::Tile3<2>::type __VA_ARGS__;                    \
+        case 3: return FN<typename tiled::Tile3<3>::type __VA_ARGS__;                    \
+        case 4: return FN<typename tiled::Tile3<4>::type __VA_ARGS__;                    \
+        case 5: return FN<typename tiled::Tile3<5>::type __VA_ARGS__;                    \
+        case 6: return FN<typename tiled::Tile3<6>::type __VA_ARGS__;                    \
+        case 7: return FN<typename tiled::Tile3<7>::type __VA_ARGS__;                    \
+        default: return 0; }                                                             \
+    switch (k.order[0]) {                                                                \
+        case 1: return FN<typename tiled::Tile2<1>::type __VA_ARGS__;                    \
+        case 2: return FN<typename tiled::Tile2<2>::type __VA_ARGS__;                    \
+        case 3: return FN<typename tiled::Tile2<3>::type __VA_ARGS__;                    \
+        case 4: return FN<typename tiled::Tile2<4>::type __VA_ARGS__;                    \
+        case 5: return FN<typename tiled::Tile2<5>::type __VA_ARGS__;                    \
+        case 6: return FN<typename tiled::Tile2<6>::type __VA_ARGS__;                    \
+        case 7: return FN<typename tiled::Tile2<7>::type __VA_ARGS__;                    \
+        default: return 0; }
 
 int try_fast_pull(const interpol_problem *p, const KParams &k, const void *vol, const void *grid, void *val, hipStream_t st)
 {
     if (!tiled_eligible(p, k)) return 0;
-    switch (k.order[0]) {
-    case 1: return tiled::launch_pull_tiled<1>(k, vol, grid, val, (int)p->batch, p->grid_shape, st);
-    case 2: return tiled::launch_pull_tiled<2>(k, vol, grid, val, (int)p->batch, p->grid_shape, st);
-    case 3: return tiled::launch_pull_tiled<3>(k, vol, grid, val, (int)p->batch, p->grid_shape, st);
-    default: return 0;
-    }
+    IP_BY_ORDER(tiled::launch_gather, , false>(p, k, vol, grid, val, st))
+}
+
+int try_fast_grad(const interpol_problem *p, const KParams &k, const void *vol, const void *grid, void *val, hipStream_t st)
+{
+    if (!tiled_eligible(p, k)) return 0;
+    IP_BY_ORDER(tiled::launch_gather, , true>(p, k, vol, grid, val, st))
 }
 
 // `vol` is the (already zero-filled or accumulating) float target; `val` == NULL means count.
 int try_fast_push(const interpol_problem *p, const KParams &k, const void *val, const void *grid, void *vol, hipStream_t st)
 {
     if (!tiled_eligible(p, k)) return 0;
-    switch (k.order[0]) {
-    case 1: return tiled::launch_push_tiled<1>(k, val, grid, vol, (int)p->batch, p->grid_shape, st);
-    case 2: return tiled::launch_push_tiled<2>(k, val, grid, vol, (int)p->batch, p->grid_shape, st);
-    case 3: return tiled::launch_push_tiled<3>(k, val, grid, vol, (int)p->batch, p->grid_shape, st);
-    default: return 0;
-    }
+    IP_BY_ORDER(tiled::launch_push, >(p, k, val, grid, vol, st))
+}
+
+int try_fast_pullbwd(const interpol_problem *p, const KParams &k, const void *gout, const void *vol, const void *grid,
+                     void *gvol, void *ggrid, int64_t gsb, int64_t gsc, hipStream_t st)
+{
+    if (!tiled_eligible(p, k)) return 0;
+    IP_BY_ORDER(tiled::launch_pullbwd, >(p, k, gout, vol, grid, gvol, ggrid, gsb, gsc, st))
 }
 
 } // namespace ip
