@@ -291,18 +291,26 @@ template <typename C>
 struct Box {
     int lo[3], S[3];
 
-    __device__ __forceinline__ void build(const KParams &p, const Lattice &L, const float *__restrict__ grid, int64_t b,
-                                          const TileGeom &g, Smem &sm)
+    // Bounding box of the tile + classification of this thread's samples, from ONE read of
+    // the coordinates: bit v of the result = sample v is "fast" (support inside the box);
+    // the other valid samples are appended to the block's slow list.
+    __device__ __forceinline__ unsigned build(const KParams &p, const Lattice &L, const float *__restrict__ grid, int64_t b,
+                                              const TileGeom &g, Smem &sm)
     {
         const int tid = threadIdx.x;
         if (tid < 3) { sm.lo[tid] = 0x7fffffff; sm.hi[tid] = -0x7fffffff; }
         if (tid == 0) sm.nslow = 0;
         __syncthreads();
         int mn[3] = { 0x7fffffff, 0x7fffffff, 0x7fffffff }, mx[3] = { -0x7fffffff, -0x7fffffff, -0x7fffffff };
+        int i0[C::VPT][3];
+        unsigned validmask = 0;
 #pragma unroll
         for (int v = 0; v < C::VPT; ++v) {
             const Sample<C> s = load_sample<C>(p, grid, b, g, tid, v);
+#pragma unroll
+            for (int d = 0; d < 3; ++d) i0[v][d] = s.i0[d];
             if (s.valid) {
+                validmask |= 1u << v;
 #pragma unroll
                 for (int d = 0; d < 3; ++d) {
                     mn[d] = s.i0[d] < mn[d] ? s.i0[d] : mn[d];
@@ -335,31 +343,18 @@ struct Box {
                 sm.tabsgn[d][tid] = (float)(int)(pk >> 32);
             }
         }
-        __syncthreads();
-    }
-
-    __device__ __forceinline__ bool contains(const Sample<C> &s) const
-    {
-        const int kd[3] = { C::KX, C::K, C::K };
-        bool in = s.valid;
-#pragma unroll
-        for (int d = 0; d < 3; ++d) in = in && (s.i0[d] >= lo[d]) && (s.i0[d] + kd[d] < lo[d] + S[d]);
-        return in;
-    }
-
-    // bit v of the result = sample v is "fast" (support inside the box); other valid
-    // samples are appended to the block's slow list.
-    __device__ __forceinline__ unsigned classify(const KParams &p, const float *__restrict__ grid, int64_t b,
-                                                 const TileGeom &g, Smem &sm) const
-    {
+        // classification
         unsigned fastmask = 0;
 #pragma unroll
         for (int v = 0; v < C::VPT; ++v) {
-            const Sample<C> s = load_sample<C>(p, grid, b, g, threadIdx.x, v);
-            if (contains(s)) fastmask |= 1u << v;
-            else if (s.valid) {
+            if (!((validmask >> v) & 1)) continue;
+            bool in = true;
+#pragma unroll
+            for (int d = 0; d < 3; ++d) in = in && (i0[v][d] >= lo[d]) && (i0[v][d] + kd[d] < lo[d] + S[d]);
+            if (in) fastmask |= 1u << v;
+            else {
                 const int slot = atomicAdd(&sm.nslow, 1);
-                if (slot < SLOWCAP) sm.slow[slot] = (unsigned short)(threadIdx.x * C::VPT + v);
+                if (slot < SLOWCAP) sm.slow[slot] = (unsigned short)(tid * C::VPT + v);
             }
         }
         __syncthreads();
@@ -397,33 +392,45 @@ __device__ __forceinline__ bool coords_inb(const KParams &p, const float *x)
     return in;
 }
 
-// Stage one channel of the box: LDS[x][y][z] = sign * vol[wrapped(x,y,z)]
+// Stage one channel of the box: LDS[x][y][z] = sign * vol[wrapped(x,y,z)].
+// Memory-level parallelism matters here: with one block per CU a rolled loop keeps a
+// single 4-byte load in flight per thread (4 KB per CU: ~4 GB/s per CU, measured 6 us
+// for a 27 KB box); the loop is unrolled U-fold with all loads issued before the first
+// LDS write.  (x, y) of a flattened row come from an exact float reciprocal.
 template <typename C>
 __device__ __forceinline__ void stage_box(const float *__restrict__ vc, const int *S, Smem &sm)
 {
+    constexpr int U = 8;
+    constexpr int RSTEP = C::NT / C::PZ;
     const int tid = threadIdx.x;
     const int z = tid % C::PZ;
     const bool zin = z < S[2];
     const int oz = zin ? sm.taboff[2][z] : 0;
     const float sz = zin ? sm.tabsgn[2][z] : 0.f;
     const int rows = S[0] * S[1];
-    constexpr int RSTEP = C::NT / C::PZ;
-    int y = tid / C::PZ, x = 0;
-    while (y >= S[1]) { y -= S[1]; ++x; }
-    for (int r = tid / C::PZ; r < rows; r += RSTEP) {
-        if (zin) {
-            const float s = sm.tabsgn[0][x] * sm.tabsgn[1][y] * sz;
-            sm.box[r * C::PZ + z] = vc[sm.taboff[0][x] + sm.taboff[1][y] + oz] * s;
+    const float inv_sy = 1.f / (float)S[1];
+    for (int r0 = tid / C::PZ; r0 < rows; r0 += RSTEP * U) {
+        float v[U], sg[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int r = r0 + u * RSTEP;
+            const bool on = zin && r < rows;
+            const int x = (int)(((float)r + 0.5f) * inv_sy);
+            const int y = r - x * S[1];
+            sg[u] = on ? sm.tabsgn[0][on ? x : 0] * sm.tabsgn[1][on ? y : 0] * sz : 0.f;
+            v[u] = on ? vc[sm.taboff[0][x] + sm.taboff[1][y] + oz] : 0.f;
         }
-        y += RSTEP;
-        while (y >= S[1]) { y -= S[1]; ++x; }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int r = r0 + u * RSTEP;
+            if (zin && r < rows) sm.box[r * C::PZ + z] = v[u] * sg[u];
+        }
     }
 }
 
 template <typename C>
-__device__ __forceinline__ TileGeom tile_geom(int gx, int gy, int gz, int nty, int ntz)
+__device__ __forceinline__ TileGeom tile_geom(int tile, int gx, int gy, int gz, int nty, int ntz)
 {
-    int tile = blockIdx.x;
     const int tzi = tile % ntz; tile /= ntz;
     const int tyi = tile % nty; const int txi = tile / nty;
     return TileGeom{ gx, gy, gz, txi * C::TX, tyi * C::TY, tzi * C::TZ };
@@ -479,19 +486,20 @@ __device__ __forceinline__ void gather_box(const Smem &sm, const Box<C> &box, co
 // ---------------------------------------------------------------------------
 template <typename C, bool GRAD>
 __global__ __launch_bounds__(C::NT) void gather_tiled(KParams p, const float *__restrict__ vol, const float *__restrict__ grid,
-                                                      float *__restrict__ val, int gx, int gy, int gz, int nty, int ntz)
+                                                      float *__restrict__ val, int gx, int gy, int gz, int nty, int ntz, int ntiles, int nbatch)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     Smem &sm = *reinterpret_cast<Smem *>(smem_raw);
     constexpr int K = C::K, KX = C::KX, D = C::D;
     const int tid = threadIdx.x;
-    const int64_t b = blockIdx.y;
-    const TileGeom g = tile_geom<C>(gx, gy, gz, nty, ntz);
     const Lattice L = make_lattice<C>(p);
+    // persistent blocks: one per CU, striding over the (tile, batch item) work list
+    for (int work = blockIdx.x; work < ntiles * nbatch; work += gridDim.x) {
+    const int64_t b = work / ntiles;
+    const TileGeom g = tile_geom<C>(work % ntiles, gx, gy, gz, nty, ntz);
 
     Box<C> box;
-    box.build(p, L, grid, b, g, sm);
-    const unsigned fastmask = box.classify(p, grid, b, g, sm);
+    const unsigned fastmask = box.build(p, L, grid, b, g, sm);
     const int nslow = sm.nslow;
 
     for (int c = 0; c < p.C; ++c) {
@@ -552,6 +560,8 @@ __global__ __launch_bounds__(C::NT) void gather_tiled(KParams p, const float *__
                 }
             }
         }
+    }
+    __syncthreads();                                   // the next tile reuses the LDS tables / lists
     }
 }
 
@@ -682,20 +692,20 @@ __device__ __forceinline__ void scatter_channel(const KParams &p, const Lattice 
             const int oz_ = zin ? sm.taboff[2][z] : 0;
             const float sz = zin ? sm.tabsgn[2][z] : 0.f;
             constexpr int RSTEP = C::NT / C::PZ;
-            int y = r_lo + tid / C::PZ, x = 0;
-            while (y >= box.S[1]) { y -= box.S[1]; ++x; }
+            const float inv_sy = 1.f / (float)box.S[1];
             for (int r = tid / C::PZ; r < r_n; r += RSTEP) {
                 if (zin) {
                     const long long a = (long long)box64[r * C::PZ + z];
                     if (a != 0) {
+                        const int rg = r_lo + r;
+                        const int x = (int)(((float)rg + 0.5f) * inv_sy);
+                        const int y = rg - x * box.S[1];
                         const float sgn = sm.tabsgn[0][x] * sm.tabsgn[1][y] * sz;
                         const float f = (float)((double)a * (double)inv_scale);
                         __hip_atomic_fetch_add(vc + sm.taboff[0][x] + sm.taboff[1][y] + oz_, f * sgn,
                                                __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     }
                 }
-                y += RSTEP;
-                while (y >= box.S[1]) { y -= box.S[1]; ++x; }
             }
         }
     }
@@ -706,23 +716,26 @@ __device__ __forceinline__ void scatter_channel(const KParams &p, const Lattice 
 // ---------------------------------------------------------------------------
 template <typename C, bool COUNT>
 __global__ __launch_bounds__(C::NT) void push_tiled(KParams p, const float *__restrict__ val, const float *__restrict__ grid,
-                                                    float *__restrict__ vol, int gx, int gy, int gz, int nty, int ntz)
+                                                    float *__restrict__ vol, int gx, int gy, int gz, int nty, int ntz,
+                                                    int ntiles, int nbatch)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     Smem &sm = *reinterpret_cast<Smem *>(smem_raw);
-    const int64_t b = blockIdx.y;
-    const TileGeom g = tile_geom<C>(gx, gy, gz, nty, ntz);
     const Lattice L = make_lattice<C>(p);
-    Box<C> box;
-    box.build(p, L, grid, b, g, sm);
-    const unsigned fastmask = box.classify(p, grid, b, g, sm);
-    const int nslow = sm.nslow;
-    for (int c = 0; c < p.C; ++c) {
-        const float *ic = COUNT ? nullptr : val + b * p.val_sb + c * p.val_sc;
-        float *vc = vol + b * p.vol_sb + c * p.vol_sc;
-        scatter_channel<C>(p, L, grid, b, g, box, fastmask, nslow, vc, sm,
-            [&](const Sample<C> &s) { const float v = COUNT ? 1.f : ic[s.o]; return (p.extrapolate != 1 && !s.inb) ? 0.f * v : v; },   // nd.py:201-203
-            [&](int64_t o) { return COUNT ? 1.f : ic[o]; });
+    for (int work = blockIdx.x; work < ntiles * nbatch; work += gridDim.x) {
+        const int64_t b = work / ntiles;
+        const TileGeom g = tile_geom<C>(work % ntiles, gx, gy, gz, nty, ntz);
+        Box<C> box;
+        const unsigned fastmask = box.build(p, L, grid, b, g, sm);
+        const int nslow = sm.nslow;
+        for (int c = 0; c < p.C; ++c) {
+            const float *ic = COUNT ? nullptr : val + b * p.val_sb + c * p.val_sc;
+            float *vc = vol + b * p.vol_sb + c * p.vol_sc;
+            scatter_channel<C>(p, L, grid, b, g, box, fastmask, nslow, vc, sm,
+                [&](const Sample<C> &s) { const float v = COUNT ? 1.f : ic[s.o]; return (p.extrapolate != 1 && !s.inb) ? 0.f * v : v; },   // nd.py:201-203
+                [&](int64_t o) { return COUNT ? 1.f : ic[o]; });
+        }
+        __syncthreads();                               // the next tile reuses the LDS tables / lists
     }
 }
 
@@ -735,18 +748,18 @@ template <typename C>
 __global__ __launch_bounds__(C::NT) void pullbwd_tiled(KParams p, const float *__restrict__ gout, const float *__restrict__ vol,
                                                        const float *__restrict__ grid, float *__restrict__ gvol,
                                                        float *__restrict__ ggrid, int64_t gvol_sb, int64_t gvol_sc,
-                                                       int gx, int gy, int gz, int nty, int ntz)
+                                                       int gx, int gy, int gz, int nty, int ntz, int ntiles, int nbatch)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     Smem &sm = *reinterpret_cast<Smem *>(smem_raw);
     constexpr int K = C::K, KX = C::KX, D = C::D;
     const int tid = threadIdx.x;
-    const int64_t b = blockIdx.y;
-    const TileGeom g = tile_geom<C>(gx, gy, gz, nty, ntz);
     const Lattice L = make_lattice<C>(p);
+    for (int work = blockIdx.x; work < ntiles * nbatch; work += gridDim.x) {
+    const int64_t b = work / ntiles;
+    const TileGeom g = tile_geom<C>(work % ntiles, gx, gy, gz, nty, ntz);
     Box<C> box;
-    box.build(p, L, grid, b, g, sm);
-    const unsigned fastmask = box.classify(p, grid, b, g, sm);
+    const unsigned fastmask = box.build(p, L, grid, b, g, sm);
     const int nslow = sm.nslow;
 
     float gg[C::VPT][3];
@@ -826,6 +839,8 @@ __global__ __launch_bounds__(C::NT) void pullbwd_tiled(KParams p, const float *_
             for (int d = 0; d < D; ++d) q[d] = gg[v][(3 - D) + d];
         }
     }
+    __syncthreads();                                   // the next tile reuses the LDS tables / lists
+    }
 }
 
 // ---------------------------------------------------------------------------
@@ -841,7 +856,21 @@ struct TileCount {
         gz = (int)p->grid_shape[C::D == 3 ? 2 : 1];
         ntx = (gx + C::TX - 1) / C::TX; nty = (gy + C::TY - 1) / C::TY; ntz = (gz + C::TZ - 1) / C::TZ;
     }
-    dim3 grid(int B) const { return dim3((unsigned)(ntx * nty * ntz), (unsigned)B); }
+    int ntiles() const { return ntx * nty * ntz; }
+    // persistent launch: as many blocks as the chip holds (LDS-limited blocks per CU x CUs)
+    dim3 grid(int B) const
+    {
+        static int cus = 0;
+        if (!cus) {
+            int dev = 0; hipDeviceProp_t prop;
+            if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
+            if (cus <= 0) cus = 256;
+        }
+        const long long total = (long long)ntiles() * B;
+        const long long per_cu = (long long)(160 * 1024) / (long long)smem_bytes<C>();
+        const long long want = (long long)cus * (per_cu < 1 ? 1 : (per_cu > 4 ? 4 : per_cu));
+        return dim3((unsigned)(total < want ? total : want), 1u);
+    }
 };
 
 template <typename C, typename F>
@@ -860,7 +889,7 @@ static int launch_gather(const interpol_problem *p, const KParams &k, const void
     if (attr) return attr;
     const TileCount<C> t(p);
     hipLaunchKernelGGL((gather_tiled<C, GRAD>), t.grid((int)p->batch), dim3(C::NT), smem_bytes<C>(), st,
-                       k, (const float *)vol, (const float *)grid, (float *)val, t.gx, t.gy, t.gz, t.nty, t.ntz);
+                       k, (const float *)vol, (const float *)grid, (float *)val, t.gx, t.gy, t.gz, t.nty, t.ntz, t.ntiles(), (int)p->batch);
     IP_CHECK_LAUNCH();
 }
 
@@ -872,10 +901,10 @@ static int launch_push(const interpol_problem *p, const KParams &k, const void *
     const TileCount<C> t(p);
     if (val)
         hipLaunchKernelGGL((push_tiled<C, false>), t.grid((int)p->batch), dim3(C::NT), smem_bytes<C>(), st,
-                           k, (const float *)val, (const float *)grid, (float *)vol, t.gx, t.gy, t.gz, t.nty, t.ntz);
+                           k, (const float *)val, (const float *)grid, (float *)vol, t.gx, t.gy, t.gz, t.nty, t.ntz, t.ntiles(), (int)p->batch);
     else
         hipLaunchKernelGGL((push_tiled<C, true>), t.grid((int)p->batch), dim3(C::NT), smem_bytes<C>(), st,
-                           k, (const float *)nullptr, (const float *)grid, (float *)vol, t.gx, t.gy, t.gz, t.nty, t.ntz);
+                           k, (const float *)nullptr, (const float *)grid, (float *)vol, t.gx, t.gy, t.gz, t.nty, t.ntz, t.ntiles(), (int)p->batch);
     IP_CHECK_LAUNCH();
 }
 
@@ -888,7 +917,7 @@ static int launch_pullbwd(const interpol_problem *p, const KParams &k, const voi
     const TileCount<C> t(p);
     hipLaunchKernelGGL((pullbwd_tiled<C>), t.grid((int)p->batch), dim3(C::NT), smem_bytes<C>(), st,
                        k, (const float *)gout, (const float *)vol, (const float *)grid, (float *)gvol, (float *)ggrid,
-                       gsb, gsc, t.gx, t.gy, t.gz, t.nty, t.ntz);
+                       gsb, gsc, t.gx, t.gy, t.gz, t.nty, t.ntz, t.ntiles(), (int)p->batch);
     IP_CHECK_LAUNCH();
 }
 
@@ -914,6 +943,7 @@ static bool tiled_eligible(const interpol_problem *p, const KParams &k)
     for (int d = 1; d < p->dim; ++d) if (k.order[d] != k.order[0]) return false;
     if (k.order[0] < 1 || k.order[0] > 7) return false;
     if (p->batch > 65535) return false;
+    { int64_t nt = p->batch; for (int d = 0; d < p->dim; ++d) nt *= (p->grid_shape[d] + 7) / 8; if (nt > 0x7fffffff) return false; }
     int64_t n = 1;
     for (int d = 0; d < p->dim; ++d) { if (p->grid_shape[d] > 0x7fffffff / 4) return false; n *= p->grid_shape[d]; }
     if (n < 4096) return false;       // tiny problems: the generic kernel has less fixed cost
