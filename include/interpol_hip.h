@@ -97,6 +97,7 @@ typedef struct interpol_problem {
 /* flags */
 #define INTERPOL_FLAG_NO_FASTPATH   1   /* force the generic kernels (testing)           */
 #define INTERPOL_FLAG_ACCUMULATE    2   /* push/count/pushgrad: do not zero the target    */
+#define INTERPOL_FLAG_FORCE_TILED   4   /* take the LDS-tiled kernel wherever one exists (testing) */
 
 /* --- forward operators -------------------------------------------------------
  * interpol_pull      replaces pushpull.grid_pull      (interpol/pushpull.py:35-66;

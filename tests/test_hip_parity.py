@@ -331,7 +331,7 @@ def test_tiled_gather_matches_generic(dim, order, sigma):
         for ex in ((1, 0, 2) if bound in (0, 3, 4) else (1,)):
             b, o = [bound] * dim, [order] * dim
             for op in ("pull", "grad"):
-                fast = _hip.gather(op, inp, grid, b, o, ex)
+                fast = _hip.gather(op, inp, grid, b, o, ex, flags=_hip.FLAG_FORCE_TILED)
                 slow = _hip.gather(op, inp, grid, b, o, ex, flags=_hip.FLAG_NO_FASTPATH)
                 _same(fast, slow, 4e-6 if order < 6 else 2e-5, (op, dim, bound, ex, order, sigma))
     mixed = [4, 2, 6][:dim]
@@ -404,3 +404,53 @@ def test_shared_target_push_count():
         oracle.set_threads(1)
     G.assert_close(push.cpu().numpy(), want_push, 1e-5, 1e-5, "shared push")
     G.assert_close(count.cpu().numpy(), want_count, 1e-5, 1e-5, "shared count")
+
+
+@pytest.mark.parametrize("dim,orders", [(3, [1, 3, 2]), (3, [0, 3, 5]), (3, [2, 2, 3]), (2, [2, 3]), (2, [7, 1]), (2, [0, 4])])
+@pytest.mark.parametrize("sigma", [0.7, 2.0, 9.0])
+def test_tiled_mixed_orders_match_generic(dim, orders, sigma):
+    """Mixed per-dim orders take the ISO = false tiles (taps beyond a dim's order are
+    predicated off); BASELINE config 5 is orders [2, 3] / bounds [dct1, dst2] in 2-D."""
+    from interpol import _hip
+    inp, grid, ishape, oshape = _tiled_problem(dim, sigma, seed=int(sum(orders) * 10 + sigma) + dim)
+    src = torch.randn([2, 3, *oshape], generator=torch.Generator().manual_seed(12)).to(DEV)
+    tol = 2e-5 if max(orders) >= 6 else 4e-6
+    for bounds in ([2, 5, 0][:dim], [6, 1, 3][:dim], [4, 4, 4][:dim]):
+        for ex in (1, 0):
+            for op in ("pull", "grad"):
+                fast = _hip.gather(op, inp, grid, bounds, orders, ex, flags=_hip.FLAG_FORCE_TILED)
+                slow = _hip.gather(op, inp, grid, bounds, orders, ex, flags=_hip.FLAG_NO_FASTPATH)
+                _same(fast, slow, tol, (op, dim, bounds, ex, orders, sigma))
+            fast = _hip.scatter("push", src, grid, list(ishape), bounds, orders, ex)
+            slow = _hip.scatter("push", src, grid, list(ishape), bounds, orders, ex, flags=_hip.FLAG_NO_FASTPATH)
+            _same(fast, slow, 1e-5, ("push", dim, bounds, ex, orders, sigma))
+        gvol, ggrid = _hip.pull_backward(src, inp, grid, bounds, orders, 1, True, True)
+        want_gvol = _hip.scatter("push", src, grid, list(ishape), bounds, orders, 1, flags=_hip.FLAG_NO_FASTPATH)
+        gg = _hip.gather("grad", inp, grid, bounds, orders, 1, flags=_hip.FLAG_NO_FASTPATH)
+        _same(gvol, want_gvol, 1e-5, "bwd gvol")
+        _same(ggrid, (gg * src.unsqueeze(-1)).sum(1), 1e-4 if max(orders) >= 6 else 2e-5, "bwd ggrid")
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("dim,orders", [(3, [3, 3, 3]), (2, [2, 3]), (2, [1, 1])])
+def test_tiled_low_precision_storage_matches_generic(dtype, dim, orders):
+    """bf16 / f16 storage through the tiled kernels (fp32 math, fp32 coordinates) vs the
+    generic kernels on the same rounded inputs: only the final rounding may differ."""
+    from interpol import _hip
+    inp, grid, ishape, oshape = _tiled_problem(dim, 2.0, seed=77 + dim)
+    inp = inp.to(dtype)
+    src = torch.randn([2, 3, *oshape], generator=torch.Generator().manual_seed(13)).to(DEV, dtype)
+    eps = 2 ** -7 if dtype == torch.bfloat16 else 2 ** -10
+    b = [2, 5, 0][:dim]
+    for op in ("pull", "grad"):
+        fast = _hip.gather(op, inp, grid, b, orders, 1, flags=_hip.FLAG_FORCE_TILED)
+        slow = _hip.gather(op, inp, grid, b, orders, 1, flags=_hip.FLAG_NO_FASTPATH)
+        assert fast.dtype == dtype
+        _same(fast.float(), slow.float(), 2 * eps, (op, dtype, dim))
+    fast = _hip.scatter("push", src, grid, list(ishape), b, orders, 1)
+    slow = _hip.scatter("push", src, grid, list(ishape), b, orders, 1, flags=_hip.FLAG_NO_FASTPATH)
+    assert fast.dtype == dtype
+    _same(fast.float(), slow.float(), 2 * eps, ("push", dtype, dim))
+    gvol, ggrid = _hip.pull_backward(src, inp, grid, b, orders, 1, True, True)
+    assert gvol.dtype == dtype and ggrid.dtype == torch.float32
+    _same(gvol.float(), slow.float(), 2 * eps, ("bwd gvol", dtype, dim))

@@ -35,12 +35,32 @@ IP_DECL2(f32) IP_DECL2(f64)
 
 int launch_filter(int dtype, const FilterParams &fp, void *data, hipStream_t st);
 
-// fast paths (ops_tiled.hip); return 1 when they took the problem, 0 to decline, <0 / >0 on error
-int try_fast_pull(const interpol_problem *p, const KParams &k, const void *vol, const void *grid, void *val, hipStream_t st);
-int try_fast_push(const interpol_problem *p, const KParams &k, const void *val, const void *grid, void *vol, hipStream_t st);
-int try_fast_grad(const interpol_problem *p, const KParams &k, const void *vol, const void *grid, void *val, hipStream_t st);
-int try_fast_pullbwd(const interpol_problem *p, const KParams &k, const void *gout, const void *vol, const void *grid,
-                     void *gvol, void *ggrid, int64_t gsb, int64_t gsc, hipStream_t st);
+// fast paths (ops_tiled.hip, one translation unit per storage type); each returns 1 when it
+// took the problem, 0 to decline, <0 / >0 on error
+#define IP_DECL_TILED(sfx)                                                                                             \
+    int try_fast_pull_##sfx(const interpol_problem *, const KParams &, const void *, const void *, void *, hipStream_t); \
+    int try_fast_grad_##sfx(const interpol_problem *, const KParams &, const void *, const void *, void *, hipStream_t); \
+    int try_fast_push_##sfx(const interpol_problem *, const KParams &, const void *, const void *, void *, hipStream_t); \
+    int try_fast_pullbwd_##sfx(const interpol_problem *, const KParams &, const void *, const void *, const void *,     \
+                               void *, void *, int64_t, int64_t, hipStream_t);
+IP_DECL_TILED(f32) IP_DECL_TILED(bf16) IP_DECL_TILED(f16)
+#undef IP_DECL_TILED
+
+#define IP_TILED_BY_DTYPE(NAME, ...)                                                     \
+    switch (p->dtype) {                                                                  \
+    case INTERPOL_F32: return NAME##_f32(__VA_ARGS__);                                   \
+    case INTERPOL_BF16: return NAME##_bf16(__VA_ARGS__);                                 \
+    case INTERPOL_F16: return NAME##_f16(__VA_ARGS__);                                   \
+    default: return 0; }
+static int try_fast_pull(const interpol_problem *p, const KParams &k, const void *vol, const void *grid, void *val, hipStream_t st)
+{ IP_TILED_BY_DTYPE(try_fast_pull, p, k, vol, grid, val, st) }
+static int try_fast_grad(const interpol_problem *p, const KParams &k, const void *vol, const void *grid, void *val, hipStream_t st)
+{ IP_TILED_BY_DTYPE(try_fast_grad, p, k, vol, grid, val, st) }
+static int try_fast_push(const interpol_problem *p, const KParams &k, const void *val, const void *grid, void *vol, hipStream_t st)
+{ IP_TILED_BY_DTYPE(try_fast_push, p, k, val, grid, vol, st) }
+static int try_fast_pullbwd(const interpol_problem *p, const KParams &k, const void *gout, const void *vol, const void *grid,
+                            void *gvol, void *ggrid, int64_t gsb, int64_t gsc, hipStream_t st)
+{ IP_TILED_BY_DTYPE(try_fast_pullbwd, p, k, gout, vol, grid, gvol, ggrid, gsb, gsc, st) }
 
 static size_t esize(int dtype) { return dtype == INTERPOL_F64 ? 8 : (dtype == INTERPOL_F32 ? 4 : 2); }
 static size_t acc_esize(int dtype) { return dtype == INTERPOL_F64 ? 8 : 4; }
@@ -339,15 +359,16 @@ int interpol_pull_backward(const interpol_problem *p, const void *grad_out, cons
         }
     }
     const int64_t gsb = img * p->channels, gsc = img;
-    if (!(p->flags & INTERPOL_FLAG_NO_FASTPATH)) {
-        rc = try_fast_pullbwd(p, k, grad_out, vol, grid, acc, grad_grid, gsb, gsc, st);
-        if (rc != 0) return rc == 1 ? 0 : rc;
-    }
-    rc = by_dtype(p->dtype,
-        [&] { return launch_pullbwd_f32(k, grad_out, vol, grid, acc, grad_grid, B, gsb, gsc, st); },
-        [&] { return launch_pullbwd_f64(k, grad_out, vol, grid, acc, grad_grid, B, gsb, gsc, st); },
-        [&] { return launch_pullbwd_bf16(k, grad_out, vol, grid, acc, grad_grid, B, gsb, gsc, st); },
-        [&] { return launch_pullbwd_f16(k, grad_out, vol, grid, acc, grad_grid, B, gsb, gsc, st); });
+    rc = 0;
+    if (!(p->flags & INTERPOL_FLAG_NO_FASTPATH))
+        rc = try_fast_pullbwd(p, k, grad_out, vol, grid, acc, grad_grid, gsb, gsc, st);   // 1 = done, 0 = declined
+    if (rc == 1) rc = 0;
+    else if (rc == 0)
+        rc = by_dtype(p->dtype,
+            [&] { return launch_pullbwd_f32(k, grad_out, vol, grid, acc, grad_grid, B, gsb, gsc, st); },
+            [&] { return launch_pullbwd_f64(k, grad_out, vol, grid, acc, grad_grid, B, gsb, gsc, st); },
+            [&] { return launch_pullbwd_bf16(k, grad_out, vol, grid, acc, grad_grid, B, gsb, gsc, st); },
+            [&] { return launch_pullbwd_f16(k, grad_out, vol, grid, acc, grad_grid, B, gsb, gsc, st); });
     if (rc) return rc;
     if (grad_vol && lowp)
         rc = p->dtype == INTERPOL_BF16 ? launch_narrow_bf16(acc, grad_vol, numel, st) : launch_narrow_f16(acc, grad_vol, numel, st);

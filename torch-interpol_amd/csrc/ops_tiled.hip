@@ -1,6 +1,6 @@
 // ===========================================================================
-// ops_tiled.hip -- LDS-tiled fast paths: float32, 2-D / 3-D, isotropic spline
-// order 1..7, any boundary / extrapolation mode.
+// ops_tiled.hip -- LDS-tiled fast paths: 2-D / 3-D, f32 / bf16 / f16 storage (fp32
+// math), per-dim spline orders 0..7, any boundary / extrapolation mode.
 //   pull, grad            (gather)
 //   push, count           (scatter)
 //   pull_backward         (fused: scatter of grad_out + gathered grid gradient)
@@ -46,8 +46,13 @@ constexpr int TABN = 72;                       // max box extent along one dim
 
 // Tile configuration.  Kernel dims are always (x, y, z); a 2-D problem (D = 2) uses
 // a degenerate x (one row, one tap, weight 1) and maps (y, z) to problem dims (0, 1).
-template <int K_, int D_, int TX_, int TY_, int TZ_, int NT_, int PZ_>
+// T = storage type of images (float, bf16_t, f16_t; math is always fp32),
+// K = spline order (ISO: every dim has order K; !ISO: per-dim runtime orders <= K, taps
+// beyond a dim's order are predicated off with wave-uniform tests).
+template <typename T_, int K_, bool ISO_, int D_, int TX_, int TY_, int TZ_, int NT_, int PZ_>
 struct Cfg {
+    using T = T_;
+    static constexpr bool ISO = ISO_;
     static constexpr int K = K_, D = D_, TX = TX_, TY = TY_, TZ = TZ_, NT = NT_, PZ = PZ_;
     static constexpr int NS = TX * TY * TZ;            // samples per tile
     static constexpr int VPT = NS / NT;                 // samples per thread
@@ -97,10 +102,9 @@ __device__ __forceinline__ float wave_sum(float v)
 }
 
 // floor index and stencil coordinate t of one coordinate (nd.py:45-47 / iso1.py:13-20)
-template <int K>
-__device__ __forceinline__ void split(float x, int &i0, float &t)
+__device__ __forceinline__ void split(int k, float x, int &i0, float &t)
 {
-    const float fl = floorf(x - 0.5f * (float)(K - 1));
+    const float fl = floorf(x - 0.5f * (float)(k - 1));
     t = x - fl;
     const float flc = fl < -1073741824.f ? -1073741824.f : (fl > 1073741824.f ? 1073741824.f : fl);
     i0 = (int)flc;
@@ -110,42 +114,45 @@ __device__ __forceinline__ void split(float x, int &i0, float &t)
 // out-of-line rare-path functions do not drag the whole KParams along.
 struct Lattice {
     int bound[3], n[3], ss[3];     // boundary codes, extents, strides in elements
+    int k[3];                      // spline order per kernel dim (0 for the degenerate x of 2-D)
     int lin;                       // iso1 weights (1-t, t) and gradients (-1, +1)
 };
+// esz: size in bytes of one element of the indexed lattice as the kernel addresses it
 template <typename C>
-__device__ __forceinline__ Lattice make_lattice(const KParams &p)
+__device__ __forceinline__ Lattice make_lattice(const KParams &p, int esz)
 {
     Lattice L;
 #pragma unroll
     for (int d = 0; d < 3; ++d) {
-        if (C::pd(d) >= 0) { L.bound[d] = p.bound[C::pd(d) < 0 ? 0 : C::pd(d)]; L.n[d] = p.vol_n[C::pd(d) < 0 ? 0 : C::pd(d)]; L.ss[d] = p.vol_ss[C::pd(d) < 0 ? 0 : C::pd(d)] >> 2; }
-        else               { L.bound[d] = 1; L.n[d] = 1; L.ss[d] = 0; }
+        constexpr int dummy = 0;
+        const int q = C::pd(d) < 0 ? dummy : C::pd(d);
+        if (C::pd(d) >= 0) { L.bound[d] = p.bound[q]; L.n[d] = p.vol_n[q]; L.ss[d] = p.vol_ss[q] / esz; L.k[d] = C::ISO ? C::K : p.order[q]; }
+        else               { L.bound[d] = 1; L.n[d] = 1; L.ss[d] = 0; L.k[d] = 0; }
     }
-    L.lin = (C::K == 1 && p.mode == MODE_ISO1);
+    L.lin = (C::ISO && C::K == 1 && p.mode == MODE_ISO1);
     return L;
 }
 
-template <int K>
-__device__ __forceinline__ float weight1(int lin, float t, int j)
+// k: the dim's order (a compile-time constant after inlining when the tile is ISO)
+__device__ __forceinline__ float weight1(int lin, int k, float t, int j)
 {
-    return lin ? (j == 0 ? 1.f - t : t) : bspline_w<float>(K, t - (float)j);      // iso1.py:19-20 / splines.py:30-80
+    return lin ? (j == 0 ? 1.f - t : t) : bspline_w<float>(k, t - (float)j);      // iso1.py:19-20 / splines.py:30-80
 }
-template <int K>
-__device__ __forceinline__ float wgrad1(int lin, float t, int j)
+__device__ __forceinline__ float wgrad1(int lin, int k, float t, int j)
 {
-    return lin ? (j == 0 ? -1.f : 1.f) : bspline_g<float>(K, t - (float)j);       // iso1.py:311-313 / splines.py:90-139
+    return lin ? (j == 0 ? -1.f : 1.f) : bspline_g<float>(k, t - (float)j);       // iso1.py:311-313 / splines.py:90-139
 }
-template <int K>
-__device__ __forceinline__ void weights(int lin, float t, float *w)
+template <int KMAX>
+__device__ __forceinline__ void weights(int lin, int k, float t, float *w)
 {
 #pragma unroll
-    for (int j = 0; j <= K; ++j) w[j] = weight1<K>(lin, t, j);
+    for (int j = 0; j <= KMAX; ++j) w[j] = j <= k ? weight1(lin, k, t, j) : 0.f;
 }
-template <int K>
-__device__ __forceinline__ void wgrads(int lin, float t, float *g)
+template <int KMAX>
+__device__ __forceinline__ void wgrads(int lin, int k, float t, float *g)
 {
 #pragma unroll
-    for (int j = 0; j <= K; ++j) g[j] = wgrad1<K>(lin, t, j);
+    for (int j = 0; j <= KMAX; ++j) g[j] = j <= k ? wgrad1(lin, k, t, j) : 0.f;
 }
 
 // ---------------------------------------------------------------------------
@@ -153,27 +160,29 @@ __device__ __forceinline__ void wgrads(int lin, float t, float *g)
 // ---------------------------------------------------------------------------
 // One sample gathered tap by tap from global memory by ONE thread (rolled loops).
 // which = -1: value, 0..2: derivative along kernel dim `which`.
-template <int K, int KX>
-__device__ __noinline__ float gather_one_thread(Lattice L, const float *vc, int ix, int iy, int iz,
+template <typename T>
+__device__ __noinline__ float gather_one_thread(Lattice L, const T *vc, int ix, int iy, int iz,
                                                 float tx, float ty, float tz, int which)
 {
     float acc = 0.f;
-    for (int i = 0; i <= KX; ++i) {
+    for (int i = 0; i <= L.k[0]; ++i) {
         const long long pk0 = wrap_outofline(L.bound[0], ix + i, L.n[0]);
-        const float fx = KX == 0 ? 1.f : (which == 0 ? wgrad1<K>(L.lin, tx, i) : weight1<K>(L.lin, tx, i));
+        const float fx = L.n[0] == 1 && L.ss[0] == 0 && L.k[0] == 0 ? 1.f
+                       : (which == 0 ? wgrad1(L.lin, L.k[0], tx, i) : weight1(L.lin, L.k[0], tx, i));
         const float sx = fx * (float)(int)(pk0 >> 32);
         const int offx = (int)(pk0 & 0xffffffffll) * L.ss[0];
         float pl = 0.f;
-        for (int j = 0; j <= K; ++j) {
+        for (int j = 0; j <= L.k[1]; ++j) {
             const long long pk1 = wrap_outofline(L.bound[1], iy + j, L.n[1]);
-            const float fy = which == 1 ? wgrad1<K>(L.lin, ty, j) : weight1<K>(L.lin, ty, j);
+            const float fy = which == 1 ? wgrad1(L.lin, L.k[1], ty, j) : weight1(L.lin, L.k[1], ty, j);
             const float sy = fy * (float)(int)(pk1 >> 32);
             const int offy = (int)(pk1 & 0xffffffffll) * L.ss[1];
             float r = 0.f;
-            for (int k = 0; k <= K; ++k) {
+            for (int k = 0; k <= L.k[2]; ++k) {
                 const long long pk2 = wrap_outofline(L.bound[2], iz + k, L.n[2]);
-                const float fz = which == 2 ? wgrad1<K>(L.lin, tz, k) : weight1<K>(L.lin, tz, k);
-                r = __builtin_fmaf(fz * (float)(int)(pk2 >> 32), vc[offx + offy + (int)(pk2 & 0xffffffffll) * L.ss[2]], r);
+                const float fz = which == 2 ? wgrad1(L.lin, L.k[2], tz, k) : weight1(L.lin, L.k[2], tz, k);
+                r = __builtin_fmaf(fz * (float)(int)(pk2 >> 32),
+                                   Cvt<float, T>::ld(vc[offx + offy + (int)(pk2 & 0xffffffffll) * L.ss[2]]), r);
             }
             pl = __builtin_fmaf(sy, r, pl);
         }
@@ -182,22 +191,21 @@ __device__ __noinline__ float gather_one_thread(Lattice L, const float *vc, int 
     return acc;
 }
 
-// One sample scattered tap by tap to global memory by ONE thread (rolled loops).
-template <int K, int KX>
+// One sample scattered tap by tap to the (float) target by ONE thread (rolled loops).
 __device__ __noinline__ void scatter_one_thread(Lattice L, float *vc, float src, int ix, int iy, int iz,
                                                 float tx, float ty, float tz)
 {
-    for (int i = 0; i <= KX; ++i) {
+    for (int i = 0; i <= L.k[0]; ++i) {
         const long long pk0 = wrap_outofline(L.bound[0], ix + i, L.n[0]);
-        const float sx = src * (KX == 0 ? 1.f : weight1<K>(L.lin, tx, i)) * (float)(int)(pk0 >> 32);
+        const float sx = src * weight1(L.lin, L.k[0], tx, i) * (float)(int)(pk0 >> 32);
         const int offx = (int)(pk0 & 0xffffffffll) * L.ss[0];
-        for (int j = 0; j <= K; ++j) {
+        for (int j = 0; j <= L.k[1]; ++j) {
             const long long pk1 = wrap_outofline(L.bound[1], iy + j, L.n[1]);
-            const float sy = sx * weight1<K>(L.lin, ty, j) * (float)(int)(pk1 >> 32);
+            const float sy = sx * weight1(L.lin, L.k[1], ty, j) * (float)(int)(pk1 >> 32);
             const int offy = (int)(pk1 & 0xffffffffll) * L.ss[1];
-            for (int k = 0; k <= K; ++k) {
+            for (int k = 0; k <= L.k[2]; ++k) {
                 const long long pk2 = wrap_outofline(L.bound[2], iz + k, L.n[2]);
-                const float v = sy * weight1<K>(L.lin, tz, k) * (float)(int)(pk2 >> 32);
+                const float v = sy * weight1(L.lin, L.k[2], tz, k) * (float)(int)(pk2 >> 32);
                 __hip_atomic_fetch_add(vc + offx + offy + (int)(pk2 & 0xffffffffll) * L.ss[2], v,
                                        __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
@@ -205,27 +213,28 @@ __device__ __noinline__ void scatter_one_thread(Lattice L, float *vc, float src,
     }
 }
 
-// Tap-parallel: tap number `tap` of the sample at coordinates (gx_, gy_, gz_):
-// returns weight * sign (0 beyond the last tap), lattice offset in *off_out and, when
-// grads != nullptr, the three derivative weights (value weights of the other dims).
-template <int K, int KX>
+// Tap-parallel: tap number `tap` (row-major over the per-dim taps) of the sample at
+// coordinates (gx_, gy_, gz_): returns weight * sign (0 beyond the last tap), the lattice
+// offset in *off_out and, when grads != nullptr, the three derivative weights (times the
+// value weights of the other dims).  The degenerate x of a 2-D problem has order 0 and
+// weight bspline_w(0, .) = 1.
 __device__ __noinline__ float tap_weight(Lattice L, float gx_, float gy_, float gz_, int tap, int *off_out, float *grads)
 {
-    constexpr int K1 = K + 1, NTAP = (KX + 1) * K1 * K1;
-    const bool on = tap < NTAP;
-    const int tp[3] = { on ? tap / (K1 * K1) : 0, on ? (tap / K1) % K1 : 0, on ? tap % K1 : 0 };
+    const int k1[3] = { L.k[0] + 1, L.k[1] + 1, L.k[2] + 1 };
+    const bool on = tap < k1[0] * k1[1] * k1[2];
+    const int tp[3] = { on ? tap / (k1[1] * k1[2]) : 0, on ? (tap / k1[2]) % k1[1] : 0, on ? tap % k1[2] : 0 };
     const float g[3] = { gx_, gy_, gz_ };
     float w[3], dw[3];
     int off = 0;
 #pragma unroll
     for (int d = 0; d < 3; ++d) {
-        if (d == 0 && KX == 0) { w[d] = 1.f; dw[d] = 0.f; continue; }
         int i0; float t;
-        split<K>(g[d], i0, t);
+        split(L.k[d], g[d], i0, t);
+        if (L.n[d] == 1 && L.ss[d] == 0 && L.k[d] == 0) i0 = 0;       // degenerate dim: coordinate is a dummy
         const long long pk = wrap_outofline(L.bound[d], i0 + tp[d], L.n[d]);
         const float s = (float)(int)(pk >> 32);
-        w[d] = weight1<K>(L.lin, t, tp[d]) * s;
-        dw[d] = grads ? wgrad1<K>(L.lin, t, tp[d]) * s : 0.f;
+        w[d] = weight1(L.lin, L.k[d], t, tp[d]) * s;
+        dw[d] = grads ? wgrad1(L.lin, L.k[d], t, tp[d]) * s : 0.f;
         off += (int)(pk & 0xffffffffll) * L.ss[d];
     }
     *off_out = off;
@@ -266,6 +275,10 @@ template <typename C>
 __device__ __forceinline__ Sample<C> load_sample(const KParams &p, const float *__restrict__ grid, int64_t b,
                                                  const TileGeom &g, int tid, int v)
 {
+    // per-dim order (compile-time for ISO tiles)
+    const int kd[3] = { C::pd(0) < 0 ? 0 : (C::ISO ? C::K : p.order[C::pd(0) < 0 ? 0 : C::pd(0)]),
+                        C::ISO ? C::K : p.order[C::pd(1) < 0 ? 0 : C::pd(1)],
+                        C::ISO ? C::K : p.order[C::pd(2) < 0 ? 0 : C::pd(2)] };
     int ox, oy, oz;
     sample_pos<C>(g, tid, v, ox, oy, oz);
     Sample<C> s;
@@ -281,7 +294,7 @@ __device__ __forceinline__ Sample<C> load_sample(const KParams &p, const float *
             if (C::pd(d) < 0) continue;
             const float xd = gp[C::pd(d) < 0 ? 0 : C::pd(d)];
             if (p.extrapolate != 1) s.inb = s.inb && xd > (float)p.mask_lo && xd < (float)p.mask_hi[C::pd(d) < 0 ? 0 : C::pd(d)];
-            split<C::K>(xd, s.i0[d], s.t[d]);
+            split(kd[d], xd, s.i0[d], s.t[d]);
         }
     }
     return s;
@@ -325,7 +338,7 @@ struct Box {
         }
         __syncthreads();
         const int cap[3] = { C::CAPX, C::CAPY, C::CAPZ };
-        const int kd[3] = { C::KX, C::K, C::K };
+        const int kd[3] = { L.k[0], L.k[1], L.k[2] };
 #pragma unroll
         for (int d = 0; d < 3; ++d) {
             int l = sm.lo[d], h = sm.hi[d] + kd[d];      // supports span [l, h]
@@ -398,7 +411,7 @@ __device__ __forceinline__ bool coords_inb(const KParams &p, const float *x)
 // for a 27 KB box); the loop is unrolled U-fold with all loads issued before the first
 // LDS write.  (x, y) of a flattened row come from an exact float reciprocal.
 template <typename C>
-__device__ __forceinline__ void stage_box(const float *__restrict__ vc, const int *S, Smem &sm)
+__device__ __forceinline__ void stage_box(const typename C::T *__restrict__ vc, const int *S, Smem &sm)
 {
     constexpr int U = 8;
     constexpr int RSTEP = C::NT / C::PZ;
@@ -418,7 +431,7 @@ __device__ __forceinline__ void stage_box(const float *__restrict__ vc, const in
             const int x = (int)(((float)r + 0.5f) * inv_sy);
             const int y = r - x * S[1];
             sg[u] = on ? sm.tabsgn[0][on ? x : 0] * sm.tabsgn[1][on ? y : 0] * sz : 0.f;
-            v[u] = on ? vc[sm.taboff[0][x] + sm.taboff[1][y] + oz] : 0.f;
+            v[u] = on ? Cvt<float, typename C::T>::ld(vc[sm.taboff[0][x] + sm.taboff[1][y] + oz]) : 0.f;
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -441,27 +454,31 @@ __device__ __forceinline__ TileGeom tile_geom(int tile, int gx, int gy, int gz, 
 // derivatives (GRAD = true).  out[0] = value, out[1..3] = d/dx, d/dy, d/dz.
 // ---------------------------------------------------------------------------
 template <typename C, bool GRAD>
-__device__ __forceinline__ void gather_box(const Smem &sm, const Box<C> &box, const Sample<C> &s, int lin, float *out)
+__device__ __forceinline__ void gather_box(const Smem &sm, const Box<C> &box, const Sample<C> &s, const Lattice &L, float *out)
 {
     constexpr int K = C::K, KX = C::KX;
+    const int lin = L.lin;
     float wx[KX + 1], wy[K + 1], wz[K + 1], gx_[KX + 1], gy_[K + 1], gz_[K + 1];
-    if (KX > 0) weights<KX>(lin, s.t[0], wx); else wx[0] = 1.f;
-    weights<K>(lin, s.t[1], wy); weights<K>(lin, s.t[2], wz);
+    if (KX > 0) weights<KX>(lin, L.k[0], s.t[0], wx); else wx[0] = 1.f;
+    weights<K>(lin, L.k[1], s.t[1], wy); weights<K>(lin, L.k[2], s.t[2], wz);
     if (GRAD) {
-        if (KX > 0) wgrads<KX>(lin, s.t[0], gx_); else gx_[0] = 0.f;
-        wgrads<K>(lin, s.t[1], gy_); wgrads<K>(lin, s.t[2], gz_);
+        if (KX > 0) wgrads<KX>(lin, L.k[0], s.t[0], gx_); else gx_[0] = 0.f;
+        wgrads<K>(lin, L.k[1], s.t[1], gy_); wgrads<K>(lin, L.k[2], s.t[2], gz_);
     }
     const float *bp = sm.box + box.base(s);
     float a = 0.f, ax = 0.f, ay = 0.f, az = 0.f;
 #pragma unroll
     for (int i = 0; i <= KX; ++i) {
+        if (!C::ISO && i > L.k[0]) continue;          // wave-uniform
         float pW = 0.f, pGy = 0.f, pGz = 0.f;
 #pragma unroll
         for (int j = 0; j <= K; ++j) {
+            if (!C::ISO && j > L.k[1]) continue;
             const float *rp = bp + (i * box.S[1] + j) * C::PZ;
             float rW = 0.f, rG = 0.f;
 #pragma unroll
             for (int k = 0; k <= K; ++k) {
+                if (!C::ISO && k > L.k[2]) continue;
                 const float v = rp[k];
                 rW = __builtin_fmaf(wz[k], v, rW);
                 if (GRAD) rG = __builtin_fmaf(gz_[k], v, rG);
@@ -485,14 +502,15 @@ __device__ __forceinline__ void gather_box(const Smem &sm, const Box<C> &box, co
 // grad (GRAD = true) : val[b,c,o,d]   = mask * sum (g_d prod w) vol
 // ---------------------------------------------------------------------------
 template <typename C, bool GRAD>
-__global__ __launch_bounds__(C::NT) void gather_tiled(KParams p, const float *__restrict__ vol, const float *__restrict__ grid,
-                                                      float *__restrict__ val, int gx, int gy, int gz, int nty, int ntz, int ntiles, int nbatch)
+__global__ __launch_bounds__(C::NT) void gather_tiled(KParams p, const typename C::T *__restrict__ vol, const float *__restrict__ grid,
+                                                      typename C::T *__restrict__ val, int gx, int gy, int gz, int nty, int ntz, int ntiles, int nbatch)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     Smem &sm = *reinterpret_cast<Smem *>(smem_raw);
-    constexpr int K = C::K, KX = C::KX, D = C::D;
+    constexpr int D = C::D;
+    using T = typename C::T;
     const int tid = threadIdx.x;
-    const Lattice L = make_lattice<C>(p);
+    const Lattice L = make_lattice<C>(p, (int)sizeof(T));
     // persistent blocks: one per CU, striding over the (tile, batch item) work list
     for (int work = blockIdx.x; work < ntiles * nbatch; work += gridDim.x) {
     const int64_t b = work / ntiles;
@@ -503,8 +521,8 @@ __global__ __launch_bounds__(C::NT) void gather_tiled(KParams p, const float *__
     const int nslow = sm.nslow;
 
     for (int c = 0; c < p.C; ++c) {
-        const float *vc = vol + b * p.vol_sb + c * p.vol_sc;
-        float *oc = val + b * p.val_sb + c * p.val_sc;
+        const T *vc = vol + b * p.vol_sb + c * p.vol_sc;
+        T *oc = val + b * p.val_sb + c * p.val_sc;
         __syncthreads();                               // previous channel's readers are done
         if (!(p.dbg & 1)) stage_box<C>(vc, box.S, sm);
         __syncthreads();
@@ -517,45 +535,45 @@ __global__ __launch_bounds__(C::NT) void gather_tiled(KParams p, const float *__
             if (!s.valid) continue;
             float r[4] = { 0.f, 0.f, 0.f, 0.f };
             if (fast) {
-                gather_box<C, GRAD>(sm, box, s, L.lin, r);
+                gather_box<C, GRAD>(sm, box, s, L, r);
             } else {
                 // slow list overflowed (pathological deformation): per-thread global gather
-                if (!GRAD) r[0] = gather_one_thread<K, KX>(L, vc, s.i0[0], s.i0[1], s.i0[2], s.t[0], s.t[1], s.t[2], -1);
+                if (!GRAD) r[0] = gather_one_thread<T>(L, vc, s.i0[0], s.i0[1], s.i0[2], s.t[0], s.t[1], s.t[2], -1);
                 else {
-                    if (D == 3) r[1] = gather_one_thread<K, KX>(L, vc, s.i0[0], s.i0[1], s.i0[2], s.t[0], s.t[1], s.t[2], 0);
-                    r[2] = gather_one_thread<K, KX>(L, vc, s.i0[0], s.i0[1], s.i0[2], s.t[0], s.t[1], s.t[2], 1);
-                    r[3] = gather_one_thread<K, KX>(L, vc, s.i0[0], s.i0[1], s.i0[2], s.t[0], s.t[1], s.t[2], 2);
+                    if (D == 3) r[1] = gather_one_thread<T>(L, vc, s.i0[0], s.i0[1], s.i0[2], s.t[0], s.t[1], s.t[2], 0);
+                    r[2] = gather_one_thread<T>(L, vc, s.i0[0], s.i0[1], s.i0[2], s.t[0], s.t[1], s.t[2], 1);
+                    r[3] = gather_one_thread<T>(L, vc, s.i0[0], s.i0[1], s.i0[2], s.t[0], s.t[1], s.t[2], 2);
                 }
             }
             const float m = (p.extrapolate != 1 && !s.inb) ? 0.f : 1.f;      // nd.py:139-140, 284-285
-            if (!GRAD) oc[s.o] = r[0] * m;
+            if (!GRAD) oc[s.o] = Cvt<float, T>::st(r[0] * m);
             else {
 #pragma unroll
-                for (int d = 0; d < D; ++d) oc[s.o * D + d] = r[1 + (3 - D) + d] * m;
+                for (int d = 0; d < D; ++d) oc[s.o * D + d] = Cvt<float, T>::st(r[1 + (3 - D) + d] * m);
             }
         }
         // slow list: one wave per sample, lanes = taps
         if (nslow > 0 && nslow <= SLOWCAP) {
             const int wave = tid >> 6, lane = tid & 63;
-            constexpr int NTAP = (KX + 1) * (K + 1) * (K + 1);
+            const int NTAP = (L.k[0] + 1) * (L.k[1] + 1) * (L.k[2] + 1);
             for (int sidx = wave; sidx < nslow; sidx += C::NT / 64) {
                 float x[3];
                 const int64_t o = slow_sample<C>(g, sm.slow[sidx], p, grid, b, x);
                 float a[4] = { 0.f, 0.f, 0.f, 0.f };
                 for (int t0 = 0; t0 < NTAP; t0 += 64) {
                     int off; float gr[3];
-                    const float w = tap_weight<K, KX>(L, x[0], x[1], x[2], t0 + lane, &off, GRAD ? gr : nullptr);
-                    const float v = (t0 + lane < NTAP) ? vc[off] : 0.f;
+                    const float w = tap_weight(L, x[0], x[1], x[2], t0 + lane, &off, GRAD ? gr : nullptr);
+                    const float v = (t0 + lane < NTAP) ? Cvt<float, T>::ld(vc[off]) : 0.f;
                     if (!GRAD) a[0] += w * v;
                     else { a[1] += gr[0] * v; a[2] += gr[1] * v; a[3] += gr[2] * v; }
                 }
                 const float m = (p.extrapolate != 1 && !coords_inb<C>(p, x)) ? 0.f : 1.f;
-                if (!GRAD) { const float r = wave_sum(a[0]); if (lane == 0) oc[o] = r * m; }
+                if (!GRAD) { const float r = wave_sum(a[0]); if (lane == 0) oc[o] = Cvt<float, T>::st(r * m); }
                 else {
 #pragma unroll
                     for (int d = 0; d < D; ++d) {
                         const float r = wave_sum(a[1 + (3 - D) + d]);
-                        if (lane == 0) oc[o * D + d] = r * m;
+                        if (lane == 0) oc[o * D + d] = Cvt<float, T>::st(r * m);
                     }
                 }
             }
@@ -622,7 +640,7 @@ __device__ __forceinline__ void scatter_channel(const KParams &p, const Lattice 
         for (int v = 0; v < C::VPT; ++v) {
             const Sample<C> s = load_sample<C>(p, grid, b, g, tid, v);
             if (!s.valid || (p.dbg & 2)) continue;
-            scatter_one_thread<K, KX>(L, vc, src_of(s), s.i0[0], s.i0[1], s.i0[2], s.t[0], s.t[1], s.t[2]);
+            scatter_one_thread(L, vc, src_of(s), s.i0[0], s.i0[1], s.i0[2], s.t[0], s.t[1], s.t[2]);
         }
         return;
     }
@@ -630,7 +648,7 @@ __device__ __forceinline__ void scatter_channel(const KParams &p, const Lattice 
     // ---- slow list: one wave per sample, lanes = taps, one global atomic per lane --------
     if (nslow > 0) {
         const int wave = tid >> 6, lane = tid & 63;
-        constexpr int NTAP = (KX + 1) * (K + 1) * (K + 1);
+        const int NTAP = (L.k[0] + 1) * (L.k[1] + 1) * (L.k[2] + 1);
         for (int sidx = wave; sidx < nslow; sidx += C::NT / 64) {
             float x[3];
             const int64_t o = slow_sample<C>(g, sm.slow[sidx], p, grid, b, x);
@@ -638,7 +656,7 @@ __device__ __forceinline__ void scatter_channel(const KParams &p, const Lattice 
             if (p.extrapolate != 1 && !coords_inb<C>(p, x)) sv *= 0.f;
             for (int t0 = 0; t0 < NTAP; t0 += 64) {
                 int off;
-                const float w = tap_weight<K, KX>(L, x[0], x[1], x[2], t0 + lane, &off, nullptr);
+                const float w = tap_weight(L, x[0], x[1], x[2], t0 + lane, &off, nullptr);
                 if (t0 + lane < NTAP)
                     __hip_atomic_fetch_add(vc + off, w * sv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
@@ -663,21 +681,24 @@ __device__ __forceinline__ void scatter_channel(const KParams &p, const Lattice 
             const int r0 = (s.i0[0] - box.lo[0]) * box.S[1] + (s.i0[1] - box.lo[1]) - r_lo;   // row of tap (0,0) in this slab
             if (r0 + KX * box.S[1] + K < 0 || r0 >= r_n) continue;
             float wx[KX + 1], wy[K + 1], wz[K + 1];
-            if (KX > 0) weights<KX>(L.lin, s.t[0], wx); else wx[0] = 1.f;
-            weights<K>(L.lin, s.t[1], wy); weights<K>(L.lin, s.t[2], wz);
+            if (KX > 0) weights<KX>(L.lin, L.k[0], s.t[0], wx); else wx[0] = 1.f;
+            weights<K>(L.lin, L.k[1], s.t[1], wy); weights<K>(L.lin, L.k[2], s.t[2], wz);
             const float ss = src_of(s) * scale;
             unsigned long long *bp = box64 + r0 * C::PZ + (s.i0[2] - box.lo[2]);
 #pragma unroll
             for (int i = 0; i <= KX; ++i) {
+                if (!C::ISO && i > L.k[0]) continue;      // wave-uniform
                 const float si = ss * wx[i];
 #pragma unroll
                 for (int j = 0; j <= K; ++j) {
+                    if (!C::ISO && j > L.k[1]) continue;
                     const int rr = r0 + i * box.S[1] + j;
                     if (rr < 0 || rr >= r_n) continue;
                     unsigned long long *rp = bp + (i * box.S[1] + j) * C::PZ;
                     const float sj = si * wy[j];
 #pragma unroll
                     for (int k = 0; k <= K; ++k) {
+                        if (!C::ISO && k > L.k[2]) continue;
                         const int q = __float2int_rn(sj * wz[k]);
                         atomicAdd(rp + k, (unsigned long long)(long long)q);      // ds_add_u64
                     }
@@ -715,13 +736,14 @@ __device__ __forceinline__ void scatter_channel(const KParams &p, const Lattice 
 // push / count : vol[b,c,tap] += w * mask * val[b,c,o]      (nd.py:146-213, pushpull.py:106-142)
 // ---------------------------------------------------------------------------
 template <typename C, bool COUNT>
-__global__ __launch_bounds__(C::NT) void push_tiled(KParams p, const float *__restrict__ val, const float *__restrict__ grid,
+__global__ __launch_bounds__(C::NT) void push_tiled(KParams p, const typename C::T *__restrict__ val, const float *__restrict__ grid,
                                                     float *__restrict__ vol, int gx, int gy, int gz, int nty, int ntz,
                                                     int ntiles, int nbatch)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     Smem &sm = *reinterpret_cast<Smem *>(smem_raw);
-    const Lattice L = make_lattice<C>(p);
+    using T = typename C::T;
+    const Lattice L = make_lattice<C>(p, 4);         // the target (or its fp32 scratch) is float
     for (int work = blockIdx.x; work < ntiles * nbatch; work += gridDim.x) {
         const int64_t b = work / ntiles;
         const TileGeom g = tile_geom<C>(work % ntiles, gx, gy, gz, nty, ntz);
@@ -729,11 +751,11 @@ __global__ __launch_bounds__(C::NT) void push_tiled(KParams p, const float *__re
         const unsigned fastmask = box.build(p, L, grid, b, g, sm);
         const int nslow = sm.nslow;
         for (int c = 0; c < p.C; ++c) {
-            const float *ic = COUNT ? nullptr : val + b * p.val_sb + c * p.val_sc;
+            const T *ic = COUNT ? nullptr : val + b * p.val_sb + c * p.val_sc;
             float *vc = vol + b * p.vol_sb + c * p.vol_sc;
             scatter_channel<C>(p, L, grid, b, g, box, fastmask, nslow, vc, sm,
-                [&](const Sample<C> &s) { const float v = COUNT ? 1.f : ic[s.o]; return (p.extrapolate != 1 && !s.inb) ? 0.f * v : v; },   // nd.py:201-203
-                [&](int64_t o) { return COUNT ? 1.f : ic[o]; });
+                [&](const Sample<C> &s) { const float v = COUNT ? 1.f : Cvt<float, T>::ld(ic[s.o]); return (p.extrapolate != 1 && !s.inb) ? 0.f * v : v; },   // nd.py:201-203
+                [&](int64_t o) { return COUNT ? 1.f : Cvt<float, T>::ld(ic[o]); });
         }
         __syncthreads();                               // the next tile reuses the LDS tables / lists
     }
@@ -745,16 +767,17 @@ __global__ __launch_bounds__(C::NT) void push_tiled(KParams p, const float *__re
 //   ggrid[b,o,d]   = mask * sum_c gout[b,c,o] * d/dx_d pull(vol)   (if ggrid)
 // ---------------------------------------------------------------------------
 template <typename C>
-__global__ __launch_bounds__(C::NT) void pullbwd_tiled(KParams p, const float *__restrict__ gout, const float *__restrict__ vol,
+__global__ __launch_bounds__(C::NT) void pullbwd_tiled(KParams p, const typename C::T *__restrict__ gout, const typename C::T *__restrict__ vol,
                                                        const float *__restrict__ grid, float *__restrict__ gvol,
                                                        float *__restrict__ ggrid, int64_t gvol_sb, int64_t gvol_sc,
                                                        int gx, int gy, int gz, int nty, int ntz, int ntiles, int nbatch)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     Smem &sm = *reinterpret_cast<Smem *>(smem_raw);
-    constexpr int K = C::K, KX = C::KX, D = C::D;
+    constexpr int D = C::D;
+    using T = typename C::T;
     const int tid = threadIdx.x;
-    const Lattice L = make_lattice<C>(p);
+    const Lattice L = make_lattice<C>(p, (int)sizeof(T));    // vol strides; gvol (float) shares the element offsets
     for (int work = blockIdx.x; work < ntiles * nbatch; work += gridDim.x) {
     const int64_t b = work / ntiles;
     const TileGeom g = tile_geom<C>(work % ntiles, gx, gy, gz, nty, ntz);
@@ -767,8 +790,8 @@ __global__ __launch_bounds__(C::NT) void pullbwd_tiled(KParams p, const float *_
     for (int v = 0; v < C::VPT; ++v) { gg[v][0] = 0.f; gg[v][1] = 0.f; gg[v][2] = 0.f; }
 
     for (int c = 0; c < p.C; ++c) {
-        const float *vc = vol + b * p.vol_sb + c * p.vol_sc;
-        const float *gc = gout + b * p.val_sb + c * p.val_sc;
+        const T *vc = vol + b * p.vol_sb + c * p.vol_sc;
+        const T *gc = gout + b * p.val_sb + c * p.val_sc;
         if (ggrid) {
             __syncthreads();
             stage_box<C>(vc, box.S, sm);
@@ -780,13 +803,14 @@ __global__ __launch_bounds__(C::NT) void pullbwd_tiled(KParams p, const float *_
                 const Sample<C> s = load_sample<C>(p, grid, b, g, tid, v);
                 if (!s.valid) continue;
                 float r[4] = { 0.f, 0.f, 0.f, 0.f };
-                if (fast) gather_box<C, true>(sm, box, s, L.lin, r);
+                if (fast) gather_box<C, true>(sm, box, s, L, r);
                 else {
-                    if (D == 3) r[1] = gather_one_thread<K, KX>(L, vc, s.i0[0], s.i0[1], s.i0[2], s.t[0], s.t[1], s.t[2], 0);
-                    r[2] = gather_one_thread<K, KX>(L, vc, s.i0[0], s.i0[1], s.i0[2], s.t[0], s.t[1], s.t[2], 1);
-                    r[3] = gather_one_thread<K, KX>(L, vc, s.i0[0], s.i0[1], s.i0[2], s.t[0], s.t[1], s.t[2], 2);
+                    if (D == 3) r[1] = gather_one_thread<T>(L, vc, s.i0[0], s.i0[1], s.i0[2], s.t[0], s.t[1], s.t[2], 0);
+                    r[2] = gather_one_thread<T>(L, vc, s.i0[0], s.i0[1], s.i0[2], s.t[0], s.t[1], s.t[2], 1);
+                    r[3] = gather_one_thread<T>(L, vc, s.i0[0], s.i0[1], s.i0[2], s.t[0], s.t[1], s.t[2], 2);
                 }
-                const float go = (p.extrapolate != 1 && !s.inb) ? 0.f * gc[s.o] : gc[s.o];
+                const float gv = Cvt<float, T>::ld(gc[s.o]);
+                const float go = (p.extrapolate != 1 && !s.inb) ? 0.f * gv : gv;
                 gg[v][0] = __builtin_fmaf(r[1], go, gg[v][0]);
                 gg[v][1] = __builtin_fmaf(r[2], go, gg[v][1]);
                 gg[v][2] = __builtin_fmaf(r[3], go, gg[v][2]);
@@ -795,18 +819,18 @@ __global__ __launch_bounds__(C::NT) void pullbwd_tiled(KParams p, const float *_
             // (the same lane of the same wave owns a slow sample for every channel)
             if (nslow > 0 && nslow <= SLOWCAP) {
                 const int wave = tid >> 6, lane = tid & 63;
-                constexpr int NTAP = (KX + 1) * (K + 1) * (K + 1);
+                const int NTAP = (L.k[0] + 1) * (L.k[1] + 1) * (L.k[2] + 1);
                 for (int sidx = wave; sidx < nslow; sidx += C::NT / 64) {
                     float x[3];
                     const int64_t o = slow_sample<C>(g, sm.slow[sidx], p, grid, b, x);
                     float a[3] = { 0.f, 0.f, 0.f };
                     for (int t0 = 0; t0 < NTAP; t0 += 64) {
                         int off; float gr[3];
-                        tap_weight<K, KX>(L, x[0], x[1], x[2], t0 + lane, &off, gr);
-                        const float vv = (t0 + lane < NTAP) ? vc[off] : 0.f;
+                        tap_weight(L, x[0], x[1], x[2], t0 + lane, &off, gr);
+                        const float vv = (t0 + lane < NTAP) ? Cvt<float, T>::ld(vc[off]) : 0.f;
                         a[0] += gr[0] * vv; a[1] += gr[1] * vv; a[2] += gr[2] * vv;
                     }
-                    const float go = (p.extrapolate != 1 && !coords_inb<C>(p, x)) ? 0.f : gc[o];
+                    const float go = (p.extrapolate != 1 && !coords_inb<C>(p, x)) ? 0.f : Cvt<float, T>::ld(gc[o]);
 #pragma unroll
                     for (int d = 0; d < D; ++d) {
                         const float r = wave_sum(a[(3 - D) + d]);
@@ -821,8 +845,8 @@ __global__ __launch_bounds__(C::NT) void pullbwd_tiled(KParams p, const float *_
         if (gvol) {
             float *qc = gvol + b * gvol_sb + c * gvol_sc;
             scatter_channel<C>(p, L, grid, b, g, box, fastmask, nslow, qc, sm,
-                [&](const Sample<C> &s) { return (p.extrapolate != 1 && !s.inb) ? 0.f * gc[s.o] : gc[s.o]; },
-                [&](int64_t o) { return gc[o]; });
+                [&](const Sample<C> &s) { const float gv = Cvt<float, T>::ld(gc[s.o]); return (p.extrapolate != 1 && !s.inb) ? 0.f * gv : gv; },
+                [&](int64_t o) { return Cvt<float, T>::ld(gc[o]); });
         }
     }
     if (ggrid) {
@@ -885,26 +909,28 @@ static int big_lds(F kernel)
 template <typename C, bool GRAD>
 static int launch_gather(const interpol_problem *p, const KParams &k, const void *vol, const void *grid, void *val, hipStream_t st)
 {
+    using T = typename C::T;
     static int attr = big_lds<C>(gather_tiled<C, GRAD>);
     if (attr) return attr;
     const TileCount<C> t(p);
     hipLaunchKernelGGL((gather_tiled<C, GRAD>), t.grid((int)p->batch), dim3(C::NT), smem_bytes<C>(), st,
-                       k, (const float *)vol, (const float *)grid, (float *)val, t.gx, t.gy, t.gz, t.nty, t.ntz, t.ntiles(), (int)p->batch);
+                       k, (const T *)vol, (const float *)grid, (T *)val, t.gx, t.gy, t.gz, t.nty, t.ntz, t.ntiles(), (int)p->batch);
     IP_CHECK_LAUNCH();
 }
 
 template <typename C>
 static int launch_push(const interpol_problem *p, const KParams &k, const void *val, const void *grid, void *vol, hipStream_t st)
 {
+    using T = typename C::T;
     static int attr = big_lds<C>(push_tiled<C, false>) | big_lds<C>(push_tiled<C, true>);
     if (attr) return attr;
     const TileCount<C> t(p);
     if (val)
         hipLaunchKernelGGL((push_tiled<C, false>), t.grid((int)p->batch), dim3(C::NT), smem_bytes<C>(), st,
-                           k, (const float *)val, (const float *)grid, (float *)vol, t.gx, t.gy, t.gz, t.nty, t.ntz, t.ntiles(), (int)p->batch);
+                           k, (const T *)val, (const float *)grid, (float *)vol, t.gx, t.gy, t.gz, t.nty, t.ntz, t.ntiles(), (int)p->batch);
     else
         hipLaunchKernelGGL((push_tiled<C, true>), t.grid((int)p->batch), dim3(C::NT), smem_bytes<C>(), st,
-                           k, (const float *)nullptr, (const float *)grid, (float *)vol, t.gx, t.gy, t.gz, t.nty, t.ntz, t.ntiles(), (int)p->batch);
+                           k, (const T *)nullptr, (const float *)grid, (float *)vol, t.gx, t.gy, t.gz, t.nty, t.ntz, t.ntiles(), (int)p->batch);
     IP_CHECK_LAUNCH();
 }
 
@@ -912,11 +938,12 @@ template <typename C>
 static int launch_pullbwd(const interpol_problem *p, const KParams &k, const void *gout, const void *vol, const void *grid,
                           void *gvol, void *ggrid, int64_t gsb, int64_t gsc, hipStream_t st)
 {
+    using T = typename C::T;
     static int attr = big_lds<C>(pullbwd_tiled<C>);
     if (attr) return attr;
     const TileCount<C> t(p);
     hipLaunchKernelGGL((pullbwd_tiled<C>), t.grid((int)p->batch), dim3(C::NT), smem_bytes<C>(), st,
-                       k, (const float *)gout, (const float *)vol, (const float *)grid, (float *)gvol, (float *)ggrid,
+                       k, (const T *)gout, (const T *)vol, (const float *)grid, (float *)gvol, (float *)ggrid,
                        gsb, gsc, t.gx, t.gy, t.gz, t.nty, t.ntz, t.ntiles(), (int)p->batch);
     IP_CHECK_LAUNCH();
 }
@@ -926,73 +953,92 @@ static int launch_pullbwd(const interpol_problem *p, const KParams &k, const voi
 //   3-D, K = 4,5: 8x8x16,           1024 threads (1 sample each)
 //   3-D, K = 6,7: 8x8x8,             512 threads
 //   2-D         : 1x16x32,           512 threads, LDS pitch 64 (box <= 72x64, 36 KiB)
-template <int K> struct Tile3 { using type = Cfg<K, 3, 16, 16, 16, 1024, 32>; };
-template <> struct Tile3<4> { using type = Cfg<4, 3, 8, 8, 16, 1024, 32>; };
-template <> struct Tile3<5> { using type = Cfg<5, 3, 8, 8, 16, 1024, 32>; };
-template <> struct Tile3<6> { using type = Cfg<6, 3, 8, 8, 8, 512, 32>; };
-template <> struct Tile3<7> { using type = Cfg<7, 3, 8, 8, 8, 512, 32>; };
-template <int K> struct Tile2 { using type = Cfg<K, 2, 1, 16, 32, 512, 64>; };
+// Mixed per-dim orders use the K = 3 (max order <= 3) or K = 7 tile with ISO = false.
+template <typename T, int K, bool ISO> struct Tile3 { using type = Cfg<T, K, ISO, 3, 16, 16, 16, 1024, 32>; };
+template <typename T, bool ISO> struct Tile3<T, 4, ISO> { using type = Cfg<T, 4, ISO, 3, 8, 8, 16, 1024, 32>; };
+template <typename T, bool ISO> struct Tile3<T, 5, ISO> { using type = Cfg<T, 5, ISO, 3, 8, 8, 16, 1024, 32>; };
+template <typename T, bool ISO> struct Tile3<T, 6, ISO> { using type = Cfg<T, 6, ISO, 3, 8, 8, 8, 512, 32>; };
+template <typename T, bool ISO> struct Tile3<T, 7, ISO> { using type = Cfg<T, 7, ISO, 3, 8, 8, 8, 512, 32>; };
+template <typename T, int K, bool ISO> struct Tile2 { using type = Cfg<T, K, ISO, 2, 1, 16, 32, 512, 64>; };
 
 } // namespace tiled
 
-// The tiled kernels cover: 2-D / 3-D, float32, isotropic order 1..7, any bound / extrapolate,
-// batch <= 65535.  Everything else (and tiny problems) runs on the generic kernels.
-static bool tiled_eligible(const interpol_problem *p, const KParams &k)
+// Which tile serves the problem: { order of the tile, iso }, or order < 0 = not eligible.
+// Covered: 2-D / 3-D, storage IP_TT, per-dim orders 0..7 (not all 0), any bound / extrapolate.
+struct TiledPick { int K; bool iso; };
+static TiledPick tiled_pick(const interpol_problem *p, const KParams &k)
 {
-    if ((p->dim != 3 && p->dim != 2) || p->dtype != INTERPOL_F32) return false;
-    for (int d = 1; d < p->dim; ++d) if (k.order[d] != k.order[0]) return false;
-    if (k.order[0] < 1 || k.order[0] > 7) return false;
-    if (p->batch > 65535) return false;
-    { int64_t nt = p->batch; for (int d = 0; d < p->dim; ++d) nt *= (p->grid_shape[d] + 7) / 8; if (nt > 0x7fffffff) return false; }
-    int64_t n = 1;
-    for (int d = 0; d < p->dim; ++d) { if (p->grid_shape[d] > 0x7fffffff / 4) return false; n *= p->grid_shape[d]; }
-    if (n < 4096) return false;       // tiny problems: the generic kernel has less fixed cost
-    return true;
+    const TiledPick no = { -1, false };
+    if (p->dim != 3 && p->dim != 2) return no;
+    if (p->batch > 65535) return no;
+    int64_t n = 1, nt = p->batch;
+    for (int d = 0; d < p->dim; ++d) {
+        if (p->grid_shape[d] > 0x7fffffff / 4) return no;
+        n *= p->grid_shape[d];
+        nt *= (p->grid_shape[d] + 7) / 8;
+    }
+    if (n < 4096 || nt > 0x7fffffff) return no;     // tiny problems: the generic kernel has less fixed cost
+    bool same = true; int mx = 0;
+    for (int d = 0; d < p->dim; ++d) { same = same && k.order[d] == k.order[0]; mx = k.order[d] > mx ? k.order[d] : mx; }
+    if (mx < 1 || mx > 7) return no;
+    if (same) return TiledPick{ mx, true };
+    return TiledPick{ mx <= 3 ? 3 : 7, false };
 }
 
+#define IP_T3(K, ISO) typename tiled::Tile3<IP_TT, K, ISO>::type
+#define IP_T2(K, ISO) typename tiled::Tile2<IP_TT, K, ISO>::type
 #define IP_BY_ORDER(FN, ...)                                                             \
-    if (p->dim == 3) switch (k.order[0]) {                                               \
-        case 1: return FN<typename tiled::Tile3<1>::type __VA_ARGS__;                    \
-        case 2: return FN<typename tiled::Tile3<2>::type __VA_ARGS__;                    \
-        case 3: return FN<typename tiled::Tile3<3>::type __VA_ARGS__;                    \
-        case 4: return FN<typename tiled::Tile3<4>::type __VA_ARGS__;                    \
-        case 5: return FN<typename tiled::Tile3<5>::type __VA_ARGS__;                    \
-        case 6: return FN<typename tiled::Tile3<6>::type __VA_ARGS__;                    \
-        case 7: return FN<typename tiled::Tile3<7>::type __VA_ARGS__;                    \
-        default: return 0; }                                                             \
-    switch (k.order[0]) {                                                                \
-        case 1: return FN<typename tiled::Tile2<1>::type __VA_ARGS__;                    \
-        case 2: return FN<typename tiled::Tile2<2>::type __VA_ARGS__;                    \
-        case 3: return FN<typename tiled::Tile2<3>::type __VA_ARGS__;                    \
-        case 4: return FN<typename tiled::Tile2<4>::type __VA_ARGS__;                    \
-        case 5: return FN<typename tiled::Tile2<5>::type __VA_ARGS__;                    \
-        case 6: return FN<typename tiled::Tile2<6>::type __VA_ARGS__;                    \
-        case 7: return FN<typename tiled::Tile2<7>::type __VA_ARGS__;                    \
-        default: return 0; }
+    const TiledPick pick = tiled_pick(p, k);                                             \
+    if (pick.K < 0) return 0;                                                            \
+    if (!pick.iso) {                                                                     \
+        if (p->dim == 3) { if (pick.K == 3) return FN<IP_T3(3, false) __VA_ARGS__; return FN<IP_T3(7, false) __VA_ARGS__; } \
+        if (pick.K == 3) return FN<IP_T2(3, false) __VA_ARGS__; return FN<IP_T2(7, false) __VA_ARGS__; \
+    }                                                                                    \
+    if (p->dim == 3) switch (pick.K) {                                                   \
+        case 1: return FN<IP_T3(1, true) __VA_ARGS__;                                    \
+        case 2: return FN<IP_T3(2, true) __VA_ARGS__;                                    \
+        case 3: return FN<IP_T3(3, true) __VA_ARGS__;                                    \
+        case 4: return FN<IP_T3(4, true) __VA_ARGS__;                                    \
+        case 5: return FN<IP_T3(5, true) __VA_ARGS__;                                    \
+        case 6: return FN<IP_T3(6, true) __VA_ARGS__;                                    \
+        default: return FN<IP_T3(7, true) __VA_ARGS__; }                                 \
+    switch (pick.K) {                                                                    \
+        case 1: return FN<IP_T2(1, true) __VA_ARGS__;                                    \
+        case 2: return FN<IP_T2(2, true) __VA_ARGS__;                                    \
+        case 3: return FN<IP_T2(3, true) __VA_ARGS__;                                    \
+        case 4: return FN<IP_T2(4, true) __VA_ARGS__;                                    \
+        case 5: return FN<IP_T2(5, true) __VA_ARGS__;                                    \
+        case 6: return FN<IP_T2(6, true) __VA_ARGS__;                                    \
+        default: return FN<IP_T2(7, true) __VA_ARGS__; }
 
-int try_fast_pull(const interpol_problem *p, const KParams &k, const void *vol, const void *grid, void *val, hipStream_t st)
+#define IP_SYM2(a, b) a##b
+#define IP_SYM(a, b) IP_SYM2(a, b)
+
+// One translation unit per storage type (IP_TT / IP_TSFX given on the command line);
+// each returns 1 when it took the problem, 0 to decline (the generic kernels run).
+// 2-D gathers stay on the generic kernel: with (K+1)^2 taps per sample the direct gather is
+// already cheaper than staging a tile (measured at config 5: 1.36 ms generic vs 2.19 ms tiled).
+int IP_SYM(try_fast_pull_, IP_TSFX)(const interpol_problem *p, const KParams &k, const void *vol, const void *grid, void *val, hipStream_t st)
 {
-    if (!tiled_eligible(p, k)) return 0;
+    if (p->dim != 3 && !(p->flags & INTERPOL_FLAG_FORCE_TILED)) return 0;
     IP_BY_ORDER(tiled::launch_gather, , false>(p, k, vol, grid, val, st))
 }
 
-int try_fast_grad(const interpol_problem *p, const KParams &k, const void *vol, const void *grid, void *val, hipStream_t st)
+int IP_SYM(try_fast_grad_, IP_TSFX)(const interpol_problem *p, const KParams &k, const void *vol, const void *grid, void *val, hipStream_t st)
 {
-    if (!tiled_eligible(p, k)) return 0;
+    if (p->dim != 3 && !(p->flags & INTERPOL_FLAG_FORCE_TILED)) return 0;
     IP_BY_ORDER(tiled::launch_gather, , true>(p, k, vol, grid, val, st))
 }
 
-// `vol` is the (already zero-filled or accumulating) float target; `val` == NULL means count.
-int try_fast_push(const interpol_problem *p, const KParams &k, const void *val, const void *grid, void *vol, hipStream_t st)
+// `vol` is the (already zero-filled or accumulating) FLOAT target; `val` == NULL means count.
+int IP_SYM(try_fast_push_, IP_TSFX)(const interpol_problem *p, const KParams &k, const void *val, const void *grid, void *vol, hipStream_t st)
 {
-    if (!tiled_eligible(p, k)) return 0;
     IP_BY_ORDER(tiled::launch_push, >(p, k, val, grid, vol, st))
 }
 
-int try_fast_pullbwd(const interpol_problem *p, const KParams &k, const void *gout, const void *vol, const void *grid,
-                     void *gvol, void *ggrid, int64_t gsb, int64_t gsc, hipStream_t st)
+int IP_SYM(try_fast_pullbwd_, IP_TSFX)(const interpol_problem *p, const KParams &k, const void *gout, const void *vol, const void *grid,
+                                       void *gvol, void *ggrid, int64_t gsb, int64_t gsc, hipStream_t st)
 {
-    if (!tiled_eligible(p, k)) return 0;
     IP_BY_ORDER(tiled::launch_pullbwd, >(p, k, gout, vol, grid, gvol, ggrid, gsb, gsc, st))
 }
 

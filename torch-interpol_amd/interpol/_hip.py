@@ -17,6 +17,7 @@ ABI_VERSION = 1
 F32, F64, BF16, F16 = 0, 1, 2, 3
 FLAG_NO_FASTPATH = 1
 FLAG_ACCUMULATE = 2
+FLAG_FORCE_TILED = 4
 
 _DTYPE_CODE = {torch.float32: F32, torch.float64: F64, torch.bfloat16: BF16, torch.float16: F16}
 
