@@ -454,3 +454,20 @@ def test_tiled_low_precision_storage_matches_generic(dtype, dim, orders):
     gvol, ggrid = _hip.pull_backward(src, inp, grid, b, orders, 1, True, True)
     assert gvol.dtype == dtype and ggrid.dtype == torch.float32
     _same(gvol.float(), slow.float(), 2 * eps, ("bwd gvol", dtype, dim))
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float64, 1e-10), (torch.float32, 3e-5)])
+@pytest.mark.parametrize("inner", [1, 16, 33, 3])
+def test_prefilter_kernels_against_oracle(dtype, tol, inner):
+    """All three prefilter kernels (wave-per-line scan for contiguous lines, chunked
+    thread-per-line for interleaved lines, serial fallback) vs the oracle."""
+    g = torch.Generator().manual_seed(2024 + inner)
+    for n in (2, 3, 5, 17, 64, 65, 127, 128, 200, 512, 1000, 1024, 2048, 2500):
+        x = torch.randn([3, n, inner], generator=g, dtype=torch.float64).to(dtype)
+        xd = x.to(DEV)
+        for order in range(2, 8):
+            for bound in (0, 1, 2, 3, 6):
+                got = interpol.spline_coeff(xd, interpolation=order, bound=bound, dim=1).cpu()
+                want = oracle.spline_coeff(x, bound, order, dim=1)
+                err = float((got.double() - want.double()).abs().max()) / max(float(want.double().abs().max()), 1e-30)
+                assert err < tol, (n, inner, order, bound, err)
