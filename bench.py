@@ -91,8 +91,9 @@ def main():
     ap.add_argument("--sigma", type=float, default=2.0)
     ap.add_argument("--grid", default="random", choices=["random", "smooth", "identity"],
                     help="deformation: i.i.d. N(0,sigma^2) noise (headline), smooth, or identity")
-    ap.add_argument("--cpu-sample", type=int, default=160, help="edge of the CPU-baseline sample volume (0 = skip)")
+    ap.add_argument("--cpu-sample", type=int, default=256, help="edge of the CPU-baseline sample volume (0 = skip)")
     ap.add_argument("--no-fastpath", action="store_true", help="force the generic kernels")
+    ap.add_argument("--no-extras", action="store_true", help="skip the smooth / identity deformation timings")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -203,6 +204,26 @@ def main():
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "algorithmic_bytes_per_launch": dom_bytes, "avg_launch_ms": round(dom_ms, 4)},
         }
+        if world == 1 and args.grid == "random" and not args.no_extras:
+            # same workload under the other deformation models of SURVEY 8d (not the headline)
+            extras = {}
+            for name in ("smooth", "identity"):
+                g2 = smooth_grid(B, n, args.sigma, device, 1234) if name == "smooth" else \
+                    interpol.identity_grid([n, n, n], device=device)[None].expand(B, n, n, n, 3).contiguous()
+                ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+                tp, ts = [], []
+                for it in range(6):
+                    ev[0].record(); interpol.grid_pull(inp, g2, **kw)
+                    ev[1].record(); interpol.grid_push(inp, g2, **kw)
+                    ev[2].record(); torch.cuda.synchronize()
+                    if it:
+                        tp.append(ev[0].elapsed_time(ev[1])); ts.append(ev[1].elapsed_time(ev[2]))
+                tp, ts = sum(tp) / len(tp), sum(ts) / len(ts)
+                extras[name] = {"pull_ms": round(tp, 4), "push_ms": round(ts, 4),
+                                "pull_frac_hbm": round(bytes_pull / (tp * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                                "push_frac_hbm": round(bytes_push / (ts * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+                del g2
+            line["other_deformations"] = extras
         if world == 1 and args.cpu_sample > 0:
             line["cpu_baseline"] = cpu_baseline(args.cpu_sample, C, args.sigma, args.order, bound_to_code(args.bound))
             line["cpu_baseline"]["reference_measured_in_build_container"] = \

@@ -12,10 +12,10 @@ def from_db(path, out):
            group by s.kernel_name order by 6 desc"""
     rows = list(c.execute(q))
     tot = sum(r[5] for r in rows) or 1
-    out.write("%-72s %6s %10s %10s %10s %7s %5s %5s %7s %7s\n" % ("kernel", "calls", "avg_us", "min_us", "max_us", "pct", "vgpr", "sgpr", "lds_B", "scr_B"))
+    out.write("%-120s %6s %10s %10s %10s %7s %5s %5s %7s %7s\n" % ("kernel", "calls", "avg_us", "min_us", "max_us", "pct", "vgpr", "sgpr", "lds_B", "scr_B"))
     for r in rows[:25]:
-        out.write("%-72s %6d %10.1f %10.1f %10.1f %6.1f%% %5s %5s %7s %7s\n" % (
-            r[0][:72], r[1], r[2] / 1e3, r[3] / 1e3, r[4] / 1e3, 100.0 * r[5] / tot, r[6], r[7], r[8], r[9]))
+        out.write("%-120s %6d %10.1f %10.1f %10.1f %6.1f%% %5s %5s %7s %7s\n" % (
+            r[0][:120], r[1], r[2] / 1e3, r[3] / 1e3, r[4] / 1e3, 100.0 * r[5] / tot, r[6], r[7], r[8], r[9]))
     # counters, if any
     try:
         q = """select s.kernel_name, p.name, avg(e.value), count(*) from rocpd_pmc_event e
@@ -25,9 +25,9 @@ def from_db(path, out):
                group by s.kernel_name, p.name order by 1, 2"""
         rows = list(c.execute(q))
         if rows:
-            out.write("\n%-72s %-24s %16s %6s\n" % ("kernel", "counter", "avg_per_dispatch", "n"))
+            out.write("\n%-120s %-24s %16s %6s\n" % ("kernel", "counter", "avg_per_dispatch", "n"))
             for r in rows:
-                out.write("%-72s %-24s %16.1f %6d\n" % (r[0][:72], r[1], r[2], r[3]))
+                out.write("%-120s %-24s %16.1f %6d\n" % (r[0][:120], r[1], r[2], r[3]))
     except sqlite3.Error as e:
         out.write("\n(no counter tables: %s)\n" % e)
 
