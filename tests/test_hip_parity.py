@@ -471,3 +471,24 @@ def test_prefilter_kernels_against_oracle(dtype, tol, inner):
                 want = oracle.spline_coeff(x, bound, order, dim=1)
                 err = float((got.double() - want.double()).abs().max()) / max(float(want.double().abs().max()), 1e-30)
                 assert err < tol, (n, inner, order, bound, err)
+
+
+@pytest.mark.parametrize("order", [1, 2, 3, 5, 7])
+@pytest.mark.parametrize("sigma", [0.0, 2.0, 9.0])
+def test_tiled_pull_channel_pairs_match_generic(order, sigma):
+    """3-D pull with an even channel count takes the two-channels-per-LDS-slot kernel
+    (ds_read_b64, slab passes); compare with the generic kernel."""
+    from interpol import _hip
+    inp, grid, ishape, oshape = _tiled_problem(3, sigma, seed=int(order * 10 + sigma) + 31, B=2, C=4)
+    for bound in range(7):
+        for ex in ((1, 0, 2) if bound in (0, 3, 4) else (1,)):
+            b, o = [bound] * 3, [order] * 3
+            fast = _hip.gather("pull", inp, grid, b, o, ex)
+            slow = _hip.gather("pull", inp, grid, b, o, ex, flags=_hip.FLAG_NO_FASTPATH)
+            _same(fast, slow, 4e-6 if order < 6 else 2e-5, ("pull2", bound, ex, order, sigma))
+    fast = _hip.gather("pull", inp.to(torch.bfloat16), grid, [3] * 3, [order] * 3, 1)
+    slow = _hip.gather("pull", inp.to(torch.bfloat16), grid, [3] * 3, [order] * 3, 1, flags=_hip.FLAG_NO_FASTPATH)
+    _same(fast.float(), slow.float(), 2 ** -6, "pull2 bf16")
+    fast = _hip.gather("pull", inp, grid, [2, 5, 0], [1, 3, 2], 1)
+    slow = _hip.gather("pull", inp, grid, [2, 5, 0], [1, 3, 2], 1, flags=_hip.FLAG_NO_FASTPATH)
+    _same(fast, slow, 4e-6, "pull2 mixed orders")

@@ -30,3 +30,6 @@ for name, flags in (("full", 0), ("no_stage_or_flush", 1 << 8), ("no_compute", 2
 res["memset_537MB"] = timeit(lambda: torch.empty(B, C, n, n, n, device=dev).zero_())
 res["copy_537MB"] = timeit(lambda: inp.clone())
 print(json.dumps({k: round(v, 3) for k, v in res.items()}))
+res2 = {"pull_pairmode": timeit(lambda: _hip.gather("pull", inp, grid, [3] * 3, [3] * 3, 1)),
+        "pull_single_channel_mode": timeit(lambda: _hip.gather("pull", inp, grid, [3] * 3, [3] * 3, 1, flags=4 << 8))}
+print(json.dumps({k: round(v, 3) for k, v in res2.items()}))

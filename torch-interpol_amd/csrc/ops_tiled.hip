@@ -584,13 +584,160 @@ __global__ __launch_bounds__(C::NT) void gather_tiled(KParams p, const typename 
 }
 
 // ---------------------------------------------------------------------------
+// pull, two channels at a time (3-D, even channel count): the box holds channel PAIRS
+// interleaved (8 bytes per slot) so that one ds_read_b64 feeds both channels -- the tap
+// loop is LDS-issue bound, this halves its LDS instructions.  8-byte slots do not fit the
+// whole box: it is staged in passes over slabs of x-rows and the per-sample partial sums
+// stay in registers across the passes.
+// ---------------------------------------------------------------------------
+template <typename C>
+__global__ __launch_bounds__(C::NT) void pull2_tiled(KParams p, const typename C::T *__restrict__ vol, const float *__restrict__ grid,
+                                                     typename C::T *__restrict__ val, int gx, int gy, int gz, int nty, int ntz,
+                                                     int ntiles, int nbatch)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    Smem &sm = *reinterpret_cast<Smem *>(smem_raw);
+    static_assert(C::D == 3, "pair mode is 3-D only");
+    constexpr int K = C::K;
+    constexpr int BOX64 = C::BOXF / 2;
+    using T = typename C::T;
+    float2 *box2 = reinterpret_cast<float2 *>(sm.box);
+    const int tid = threadIdx.x;
+    const Lattice L = make_lattice<C>(p, (int)sizeof(T));
+    for (int work = blockIdx.x; work < ntiles * nbatch; work += gridDim.x) {
+    const int64_t b = work / ntiles;
+    const TileGeom g = tile_geom<C>(work % ntiles, gx, gy, gz, nty, ntz);
+    Box<C> box;
+    const unsigned fastmask = box.build(p, L, grid, b, g, sm);
+    const int nslow = sm.nslow;
+    const int rows_all = box.S[0] * box.S[1];
+    int rows_pp = BOX64 / C::PZ;
+    rows_pp -= rows_pp % box.S[1];                     // whole x-rows per pass
+    const int npass = (rows_all + rows_pp - 1) / rows_pp;
+    const float inv_sy = 1.f / (float)box.S[1];
+
+    for (int c = 0; c < p.C; c += 2) {
+        const T *vc0 = vol + b * p.vol_sb + c * p.vol_sc;
+        const T *vc1 = vc0 + p.vol_sc;
+        T *oc0 = val + b * p.val_sb + c * p.val_sc;
+        T *oc1 = oc0 + p.val_sc;
+        float acc[C::VPT][2];
+#pragma unroll
+        for (int v = 0; v < C::VPT; ++v) { acc[v][0] = 0.f; acc[v][1] = 0.f; }
+        for (int ps = 0; ps < npass; ++ps) {
+            const int r_lo = ps * rows_pp;
+            const int r_n = (rows_all - r_lo) < rows_pp ? (rows_all - r_lo) : rows_pp;
+            __syncthreads();                           // previous slab's readers are done
+            {   // stage the slab, both channels (unrolled for memory-level parallelism)
+                constexpr int U = 4, RSTEP = C::NT / C::PZ;
+                const int z = tid % C::PZ;
+                const bool zin = z < box.S[2];
+                const int oz = zin ? sm.taboff[2][z] : 0;
+                const float sz = zin ? sm.tabsgn[2][z] : 0.f;
+                for (int r0 = tid / C::PZ; r0 < r_n; r0 += RSTEP * U) {
+                    float v0[U], v1[U], sg[U];
+#pragma unroll
+                    for (int u = 0; u < U; ++u) {
+                        const int r = r0 + u * RSTEP;
+                        const bool on = zin && r < r_n;
+                        const int rg = r_lo + r;
+                        const int x = (int)(((float)rg + 0.5f) * inv_sy);
+                        const int y = rg - x * box.S[1];
+                        const int off = on ? sm.taboff[0][x] + sm.taboff[1][y] + oz : 0;
+                        sg[u] = on ? sm.tabsgn[0][x] * sm.tabsgn[1][y] * sz : 0.f;
+                        v0[u] = on ? Cvt<float, T>::ld(vc0[off]) : 0.f;
+                        v1[u] = on ? Cvt<float, T>::ld(vc1[off]) : 0.f;
+                    }
+#pragma unroll
+                    for (int u = 0; u < U; ++u) {
+                        const int r = r0 + u * RSTEP;
+                        if (zin && r < r_n) box2[r * C::PZ + z] = make_float2(v0[u] * sg[u], v1[u] * sg[u]);
+                    }
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int v = 0; v < C::VPT; ++v) {
+                if (!((fastmask >> v) & 1)) continue;
+                const Sample<C> s = load_sample<C>(p, grid, b, g, tid, v);
+                const int r0 = (s.i0[0] - box.lo[0]) * box.S[1] + (s.i0[1] - box.lo[1]) - r_lo;
+                if (r0 + K * box.S[1] + K < 0 || r0 >= r_n) continue;
+                float wx[K + 1], wy[K + 1], wz[K + 1];
+                weights<K>(L.lin, L.k[0], s.t[0], wx); weights<K>(L.lin, L.k[1], s.t[1], wy); weights<K>(L.lin, L.k[2], s.t[2], wz);
+                const float2 *bp = box2 + r0 * C::PZ + (s.i0[2] - box.lo[2]);
+#pragma unroll
+                for (int i = 0; i <= K; ++i) {
+                    if (!C::ISO && i > L.k[0]) continue;
+                    const int ri = r0 + i * box.S[1];
+                    if (ri < 0 || ri >= r_n) continue;     // this x-row lives in another slab
+                    float p0 = 0.f, p1 = 0.f;
+#pragma unroll
+                    for (int j = 0; j <= K; ++j) {
+                        if (!C::ISO && j > L.k[1]) continue;
+                        const float2 *rp = bp + (i * box.S[1] + j) * C::PZ;
+                        float q0 = 0.f, q1 = 0.f;
+#pragma unroll
+                        for (int k = 0; k <= K; ++k) {
+                            if (!C::ISO && k > L.k[2]) continue;
+                            const float2 t2 = rp[k];                       // ds_read_b64: both channels
+                            q0 = __builtin_fmaf(wz[k], t2.x, q0);
+                            q1 = __builtin_fmaf(wz[k], t2.y, q1);
+                        }
+                        p0 = __builtin_fmaf(wy[j], q0, p0);
+                        p1 = __builtin_fmaf(wy[j], q1, p1);
+                    }
+                    acc[v][0] = __builtin_fmaf(wx[i], p0, acc[v][0]);
+                    acc[v][1] = __builtin_fmaf(wx[i], p1, acc[v][1]);
+                }
+            }
+        }
+        // outputs of the fast samples
+#pragma unroll
+        for (int v = 0; v < C::VPT; ++v) {
+            const bool fast = (fastmask >> v) & 1;
+            if (!fast && nslow <= SLOWCAP) continue;
+            const Sample<C> s = load_sample<C>(p, grid, b, g, tid, v);
+            if (!s.valid) continue;
+            float r0v = acc[v][0], r1v = acc[v][1];
+            if (!fast) {   // slow list overflowed: per-thread global gather
+                r0v = gather_one_thread<T>(L, vc0, s.i0[0], s.i0[1], s.i0[2], s.t[0], s.t[1], s.t[2], -1);
+                r1v = gather_one_thread<T>(L, vc1, s.i0[0], s.i0[1], s.i0[2], s.t[0], s.t[1], s.t[2], -1);
+            }
+            const float m = (p.extrapolate != 1 && !s.inb) ? 0.f : 1.f;
+            oc0[s.o] = Cvt<float, T>::st(r0v * m);
+            oc1[s.o] = Cvt<float, T>::st(r1v * m);
+        }
+        // slow list: one wave per sample, lanes = taps
+        if (nslow > 0 && nslow <= SLOWCAP) {
+            const int wave = tid >> 6, lane = tid & 63;
+            const int NTAP = (L.k[0] + 1) * (L.k[1] + 1) * (L.k[2] + 1);
+            for (int sidx = wave; sidx < nslow; sidx += C::NT / 64) {
+                float x[3];
+                const int64_t o = slow_sample<C>(g, sm.slow[sidx], p, grid, b, x);
+                float a0 = 0.f, a1 = 0.f;
+                for (int t0 = 0; t0 < NTAP; t0 += 64) {
+                    int off;
+                    const float w = tap_weight(L, x[0], x[1], x[2], t0 + lane, &off, nullptr);
+                    if (t0 + lane < NTAP) { a0 += w * Cvt<float, T>::ld(vc0[off]); a1 += w * Cvt<float, T>::ld(vc1[off]); }
+                }
+                const float m = (p.extrapolate != 1 && !coords_inb<C>(p, x)) ? 0.f : 1.f;
+                a0 = wave_sum(a0); a1 = wave_sum(a1);
+                if (lane == 0) { oc0[o] = Cvt<float, T>::st(a0 * m); oc1[o] = Cvt<float, T>::st(a1 * m); }
+            }
+        }
+    }
+    __syncthreads();                                   // the next tile reuses the LDS tables / lists
+    }
+}
+
+// ---------------------------------------------------------------------------
 // Scatter of one channel: src(sample) * weights -> target, through the LDS box in
 // 64-bit fixed point.  Shared by push / count and by the fused pull backward.
 // `src_of(sample)` returns the (masked) source value of a fast sample,
 // `src_slow(o)` the unmasked source of a slow-list sample.
 //
-//     q = rne(src * w * 2^e),  2^e * max|src| <= 2^30   (per tile and channel)
-// every contribution is rounded with absolute error <= 2^-31 max|src| (far below
+//     q = trunc(src * w * 2^e),  2^e * max|src| <= 2^30   (per tile and channel)
+// every contribution is rounded with absolute error < 2^-30 max|src| (far below
 // fp32 rounding of the sums) and a 64-bit slot cannot overflow.  The box holds 8
 // bytes per slot, so it is filled in passes over slabs of (flattened) box rows;
 // each tap lands in exactly one pass.  Non-finite sources (inf / nan) take the
@@ -666,7 +813,7 @@ __device__ __forceinline__ void scatter_channel(const KParams &p, const Lattice 
     // ---- passes over slabs of flattened box rows r = x * S_y + y (8 bytes per slot) -------
     const int rows_all = box.S[0] * box.S[1];
     int rows_pp = BOX64 / C::PZ;                   // rows per pass
-    if (C::D == 3 && rows_pp >= box.S[1]) rows_pp -= rows_pp % box.S[1];   // whole x-rows per pass
+    rows_pp -= (C::D == 3) ? rows_pp % box.S[1] : 0;   // 3-D: whole x-rows per pass (BOX64 / PZ >= CAPY rows always)
     const int npass = (rows_all + rows_pp - 1) / rows_pp;
     for (int ps = 0; ps < npass; ++ps) {
         const int r_lo = ps * rows_pp;
@@ -688,18 +835,21 @@ __device__ __forceinline__ void scatter_channel(const KParams &p, const Lattice 
 #pragma unroll
             for (int i = 0; i <= KX; ++i) {
                 if (!C::ISO && i > L.k[0]) continue;      // wave-uniform
+                // 3-D slabs hold whole x-rows: one in-slab test per i instead of per (i, j)
+                const int ri = r0 + i * box.S[1];
+                if (C::D == 3 && (ri < 0 || ri >= r_n)) continue;
                 const float si = ss * wx[i];
 #pragma unroll
                 for (int j = 0; j <= K; ++j) {
                     if (!C::ISO && j > L.k[1]) continue;
-                    const int rr = r0 + i * box.S[1] + j;
-                    if (rr < 0 || rr >= r_n) continue;
+                    if (C::D != 3 && (ri + j < 0 || ri + j >= r_n)) continue;
                     unsigned long long *rp = bp + (i * box.S[1] + j) * C::PZ;
                     const float sj = si * wy[j];
 #pragma unroll
                     for (int k = 0; k <= K; ++k) {
                         if (!C::ISO && k > L.k[2]) continue;
-                        const int q = __float2int_rn(sj * wz[k]);
+                        // truncation (v_cvt_i32_f32) instead of rne: |error| < 1 unit = 2^-30 max|src|
+                        const int q = (int)(sj * wz[k]);
                         atomicAdd(rp + k, (unsigned long long)(long long)q);      // ds_add_u64
                     }
                 }
@@ -906,10 +1056,28 @@ static int big_lds(F kernel)
 
 #define IP_CHECK_LAUNCH() do { const hipError_t e_ = hipGetLastError(); return e_ == hipSuccess ? 1 : (int)e_; } while (0)
 
+template <typename C>
+static int launch_pull2(const interpol_problem *p, const KParams &k, const void *vol, const void *grid, void *val, hipStream_t st)
+{
+    using T = typename C::T;
+    if constexpr (C::D == 3) {
+        static int attr = big_lds<C>(pull2_tiled<C>);
+        if (attr) return attr;
+        const TileCount<C> t(p);
+        hipLaunchKernelGGL((pull2_tiled<C>), t.grid((int)p->batch), dim3(C::NT), smem_bytes<C>(), st,
+                           k, (const T *)vol, (const float *)grid, (T *)val, t.gx, t.gy, t.gz, t.nty, t.ntz, t.ntiles(), (int)p->batch);
+        IP_CHECK_LAUNCH();
+    } else {
+        return 0;
+    }
+}
+
 template <typename C, bool GRAD>
 static int launch_gather(const interpol_problem *p, const KParams &k, const void *vol, const void *grid, void *val, hipStream_t st)
 {
     using T = typename C::T;
+    // pull with an even channel count: two channels per LDS slot (unless disabled for A/B tests)
+    if (!GRAD && C::D == 3 && p->channels % 2 == 0 && !(k.dbg & 4)) return launch_pull2<C>(p, k, vol, grid, val, st);
     static int attr = big_lds<C>(gather_tiled<C, GRAD>);
     if (attr) return attr;
     const TileCount<C> t(p);
