@@ -492,3 +492,23 @@ def test_tiled_pull_channel_pairs_match_generic(order, sigma):
     fast = _hip.gather("pull", inp, grid, [2, 5, 0], [1, 3, 2], 1)
     slow = _hip.gather("pull", inp, grid, [2, 5, 0], [1, 3, 2], 1, flags=_hip.FLAG_NO_FASTPATH)
     _same(fast, slow, 4e-6, "pull2 mixed orders")
+
+
+@pytest.mark.parametrize("dim", [3, 2])
+@pytest.mark.parametrize("order", [1, 3, 5])
+@pytest.mark.parametrize("sigma", [0.7, 2.0, 9.0])
+def test_tiled_push_backward_matches_generic(dim, order, sigma):
+    """Fused backward of push / count: tiled vs generic kernels."""
+    from interpol import _hip
+    gvol, grid, tshape, sshape = _tiled_problem(dim, sigma, seed=int(order * 10 + sigma) + dim + 51)
+    val = torch.randn([2, 3, *sshape], generator=torch.Generator().manual_seed(14)).to(DEV)
+    for bound, ex in ((3, 1), (0, 0), (6, 1), (5, 2)):
+        b, o = [bound] * dim, [order] * dim
+        fast = _hip.push_backward(gvol, val, grid, b, o, ex, True, True, flags=_hip.FLAG_FORCE_TILED)
+        slow = _hip.push_backward(gvol, val, grid, b, o, ex, True, True, flags=_hip.FLAG_NO_FASTPATH)
+        _same(fast[0], slow[0], 4e-6, ("gval", dim, bound, ex, order, sigma))
+        _same(fast[1], slow[1], 2e-5, ("ggrid", dim, bound, ex, order, sigma))
+        fast = _hip.push_backward(gvol[:, :1], None, grid, b, o, ex, False, True, flags=_hip.FLAG_FORCE_TILED)
+        slow = _hip.push_backward(gvol[:, :1], None, grid, b, o, ex, False, True, flags=_hip.FLAG_NO_FASTPATH)
+        assert fast[0] is None
+        _same(fast[1], slow[1], 2e-5, ("count ggrid", dim, bound, ex, order, sigma))

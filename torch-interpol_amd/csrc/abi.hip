@@ -42,7 +42,9 @@ int launch_filter(int dtype, const FilterParams &fp, void *data, hipStream_t st)
     int try_fast_grad_##sfx(const interpol_problem *, const KParams &, const void *, const void *, void *, hipStream_t); \
     int try_fast_push_##sfx(const interpol_problem *, const KParams &, const void *, const void *, void *, hipStream_t); \
     int try_fast_pullbwd_##sfx(const interpol_problem *, const KParams &, const void *, const void *, const void *,     \
-                               void *, void *, int64_t, int64_t, hipStream_t);
+                               void *, void *, int64_t, int64_t, hipStream_t);                                         \
+    int try_fast_pushbwd_##sfx(const interpol_problem *, const KParams &, const void *, const void *, const void *,     \
+                               void *, void *, hipStream_t);
 IP_DECL_TILED(f32) IP_DECL_TILED(bf16) IP_DECL_TILED(f16)
 #undef IP_DECL_TILED
 
@@ -61,6 +63,9 @@ static int try_fast_push(const interpol_problem *p, const KParams &k, const void
 static int try_fast_pullbwd(const interpol_problem *p, const KParams &k, const void *gout, const void *vol, const void *grid,
                             void *gvol, void *ggrid, int64_t gsb, int64_t gsc, hipStream_t st)
 { IP_TILED_BY_DTYPE(try_fast_pullbwd, p, k, gout, vol, grid, gvol, ggrid, gsb, gsc, st) }
+static int try_fast_pushbwd(const interpol_problem *p, const KParams &k, const void *gvol_out, const void *val, const void *grid,
+                            void *gval, void *ggrid, hipStream_t st)
+{ IP_TILED_BY_DTYPE(try_fast_pushbwd, p, k, gvol_out, val, grid, gval, ggrid, st) }
 
 static size_t esize(int dtype) { return dtype == INTERPOL_F64 ? 8 : (dtype == INTERPOL_F32 ? 4 : 2); }
 static size_t acc_esize(int dtype) { return dtype == INTERPOL_F64 ? 8 : 4; }
@@ -384,6 +389,10 @@ int interpol_push_backward(const interpol_problem *p, const void *grad_vol_out, 
     if (!grad_vol_out || !val || !grid) return INTERPOL_E_NULL;
     if (!grad_val && !grad_grid) return 0;
     hipStream_t st = (hipStream_t)stream;
+    if (!(p->flags & INTERPOL_FLAG_NO_FASTPATH)) {
+        rc = try_fast_pushbwd(p, k, grad_vol_out, val, grid, grad_val, grad_grid, st);
+        if (rc != 0) return rc == 1 ? 0 : rc;
+    }
     return by_dtype(p->dtype,
         [&] { return launch_pushbwd_f32(k, grad_vol_out, val, grid, grad_val, grad_grid, B, st); },
         [&] { return launch_pushbwd_f64(k, grad_vol_out, val, grid, grad_val, grad_grid, B, st); },
@@ -399,6 +408,10 @@ int interpol_count_backward(const interpol_problem *p, const void *grad_vol_out,
     if (rc) return rc;
     if (!grad_vol_out || !grid || !grad_grid) return INTERPOL_E_NULL;
     hipStream_t st = (hipStream_t)stream;
+    if (!(p->flags & INTERPOL_FLAG_NO_FASTPATH)) {
+        rc = try_fast_pushbwd(p, k, grad_vol_out, nullptr, grid, nullptr, grad_grid, st);
+        if (rc != 0) return rc == 1 ? 0 : rc;
+    }
     return by_dtype(p->dtype,
         [&] { return launch_pushbwd_f32(k, grad_vol_out, nullptr, grid, nullptr, grad_grid, B, st); },
         [&] { return launch_pushbwd_f64(k, grad_vol_out, nullptr, grid, nullptr, grad_grid, B, st); },

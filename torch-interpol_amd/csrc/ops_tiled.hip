@@ -1018,6 +1018,108 @@ __global__ __launch_bounds__(C::NT) void pullbwd_tiled(KParams p, const typename
 }
 
 // ---------------------------------------------------------------------------
+// Fused backward of push / count (pushpull.py:262-299), one staged gather per channel:
+//   gval[b,c,o]  = mask * pull(gvol_out)[c]                              (if gval)
+//   ggrid[b,o,d] = mask * sum_c val[b,c,o] * d/dx_d pull(gvol_out)[c]    (if ggrid)
+// val == nullptr: count backward (val = 1).
+// ---------------------------------------------------------------------------
+template <typename C>
+__global__ __launch_bounds__(C::NT) void pushbwd_tiled(KParams p, const typename C::T *__restrict__ gvol_out,
+                                                       const typename C::T *__restrict__ val, const float *__restrict__ grid,
+                                                       typename C::T *__restrict__ gval, float *__restrict__ ggrid,
+                                                       int gx, int gy, int gz, int nty, int ntz, int ntiles, int nbatch)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    Smem &sm = *reinterpret_cast<Smem *>(smem_raw);
+    constexpr int D = C::D;
+    using T = typename C::T;
+    const int tid = threadIdx.x;
+    const Lattice L = make_lattice<C>(p, (int)sizeof(T));
+    for (int work = blockIdx.x; work < ntiles * nbatch; work += gridDim.x) {
+    const int64_t b = work / ntiles;
+    const TileGeom g = tile_geom<C>(work % ntiles, gx, gy, gz, nty, ntz);
+    Box<C> box;
+    const unsigned fastmask = box.build(p, L, grid, b, g, sm);
+    const int nslow = sm.nslow;
+    float gg[C::VPT][3];
+#pragma unroll
+    for (int v = 0; v < C::VPT; ++v) { gg[v][0] = 0.f; gg[v][1] = 0.f; gg[v][2] = 0.f; }
+
+    for (int c = 0; c < p.C; ++c) {
+        const T *vc = gvol_out + b * p.vol_sb + c * p.vol_sc;
+        const T *ic = val ? val + b * p.val_sb + c * p.val_sc : nullptr;
+        T *oc = gval ? gval + b * p.val_sb + c * p.val_sc : nullptr;
+        __syncthreads();
+        stage_box<C>(vc, box.S, sm);
+        __syncthreads();
+#pragma unroll
+        for (int v = 0; v < C::VPT; ++v) {
+            const bool fast = (fastmask >> v) & 1;
+            if (!fast && nslow <= SLOWCAP) continue;
+            const Sample<C> s = load_sample<C>(p, grid, b, g, tid, v);
+            if (!s.valid) continue;
+            float r[4] = { 0.f, 0.f, 0.f, 0.f };
+            if (fast) gather_box<C, true>(sm, box, s, L, r);
+            else {
+                r[0] = gather_one_thread<T>(L, vc, s.i0[0], s.i0[1], s.i0[2], s.t[0], s.t[1], s.t[2], -1);
+                if (D == 3) r[1] = gather_one_thread<T>(L, vc, s.i0[0], s.i0[1], s.i0[2], s.t[0], s.t[1], s.t[2], 0);
+                r[2] = gather_one_thread<T>(L, vc, s.i0[0], s.i0[1], s.i0[2], s.t[0], s.t[1], s.t[2], 1);
+                r[3] = gather_one_thread<T>(L, vc, s.i0[0], s.i0[1], s.i0[2], s.t[0], s.t[1], s.t[2], 2);
+            }
+            const float m = (p.extrapolate != 1 && !s.inb) ? 0.f : 1.f;
+            if (oc) oc[s.o] = Cvt<float, T>::st(r[0] * m);
+            const float sv = m * (ic ? Cvt<float, T>::ld(ic[s.o]) : 1.f);
+            gg[v][0] = __builtin_fmaf(r[1], sv, gg[v][0]);
+            gg[v][1] = __builtin_fmaf(r[2], sv, gg[v][1]);
+            gg[v][2] = __builtin_fmaf(r[3], sv, gg[v][2]);
+        }
+        if (nslow > 0 && nslow <= SLOWCAP) {
+            const int wave = tid >> 6, lane = tid & 63;
+            const int NTAP = (L.k[0] + 1) * (L.k[1] + 1) * (L.k[2] + 1);
+            for (int sidx = wave; sidx < nslow; sidx += C::NT / 64) {
+                float x[3];
+                const int64_t o = slow_sample<C>(g, sm.slow[sidx], p, grid, b, x);
+                float a[4] = { 0.f, 0.f, 0.f, 0.f };
+                for (int t0 = 0; t0 < NTAP; t0 += 64) {
+                    int off; float gr[3];
+                    const float w = tap_weight(L, x[0], x[1], x[2], t0 + lane, &off, gr);
+                    const float vv = (t0 + lane < NTAP) ? Cvt<float, T>::ld(vc[off]) : 0.f;
+                    a[0] += w * vv; a[1] += gr[0] * vv; a[2] += gr[1] * vv; a[3] += gr[2] * vv;
+                }
+                const float m = (p.extrapolate != 1 && !coords_inb<C>(p, x)) ? 0.f : 1.f;
+                const float r0 = wave_sum(a[0]);
+                if (lane == 0 && oc) oc[o] = Cvt<float, T>::st(r0 * m);
+                const float sv = m * (ic ? Cvt<float, T>::ld(ic[o]) : 1.f);
+#pragma unroll
+                for (int d = 0; d < D; ++d) {
+                    const float r = wave_sum(a[1 + (3 - D) + d]);
+                    if (lane == 0 && ggrid) {
+                        float *q = ggrid + (b * p.N + o) * D + d;
+                        *q = (c == 0 ? 0.f : *q) + r * sv;
+                    }
+                }
+            }
+        }
+    }
+    if (ggrid) {
+#pragma unroll
+        for (int v = 0; v < C::VPT; ++v) {
+            const bool fast = (fastmask >> v) & 1;
+            if (!fast && nslow <= SLOWCAP) continue;   // slow-list samples were written above
+            int ox, oy, oz;
+            sample_pos<C>(g, tid, v, ox, oy, oz);
+            if (!(ox < gx && oy < gy && oz < gz)) continue;
+            const int64_t o = ((int64_t)ox * gy + oy) * gz + oz;
+            float *q = ggrid + (b * p.N + o) * D;
+#pragma unroll
+            for (int d = 0; d < D; ++d) q[d] = gg[v][(3 - D) + d];
+        }
+    }
+    __syncthreads();                                   // the next tile reuses the LDS tables / lists
+    }
+}
+
+// ---------------------------------------------------------------------------
 // Launchers
 // ---------------------------------------------------------------------------
 template <typename C>
@@ -1047,11 +1149,18 @@ struct TileCount {
     }
 };
 
+// Kernels that need more than 64 KiB of dynamic LDS must opt in, once per device.
 template <typename C, typename F>
 static int big_lds(F kernel)
 {
+    static bool done[64] = { false };
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+    if (done[dev]) return 0;
     const hipError_t e = hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_bytes<C>());
-    return e == hipSuccess ? 0 : (int)e;
+    if (e != hipSuccess) return (int)e;
+    done[dev] = true;
+    return 0;
 }
 
 #define IP_CHECK_LAUNCH() do { const hipError_t e_ = hipGetLastError(); return e_ == hipSuccess ? 1 : (int)e_; } while (0)
@@ -1061,7 +1170,7 @@ static int launch_pull2(const interpol_problem *p, const KParams &k, const void 
 {
     using T = typename C::T;
     if constexpr (C::D == 3) {
-        static int attr = big_lds<C>(pull2_tiled<C>);
+        const int attr = big_lds<C>(pull2_tiled<C>);
         if (attr) return attr;
         const TileCount<C> t(p);
         hipLaunchKernelGGL((pull2_tiled<C>), t.grid((int)p->batch), dim3(C::NT), smem_bytes<C>(), st,
@@ -1078,7 +1187,7 @@ static int launch_gather(const interpol_problem *p, const KParams &k, const void
     using T = typename C::T;
     // pull with an even channel count: two channels per LDS slot (unless disabled for A/B tests)
     if (!GRAD && C::D == 3 && p->channels % 2 == 0 && !(k.dbg & 4)) return launch_pull2<C>(p, k, vol, grid, val, st);
-    static int attr = big_lds<C>(gather_tiled<C, GRAD>);
+    const int attr = big_lds<C>(gather_tiled<C, GRAD>);
     if (attr) return attr;
     const TileCount<C> t(p);
     hipLaunchKernelGGL((gather_tiled<C, GRAD>), t.grid((int)p->batch), dim3(C::NT), smem_bytes<C>(), st,
@@ -1090,7 +1199,7 @@ template <typename C>
 static int launch_push(const interpol_problem *p, const KParams &k, const void *val, const void *grid, void *vol, hipStream_t st)
 {
     using T = typename C::T;
-    static int attr = big_lds<C>(push_tiled<C, false>) | big_lds<C>(push_tiled<C, true>);
+    const int attr = val ? big_lds<C>(push_tiled<C, false>) : big_lds<C>(push_tiled<C, true>);
     if (attr) return attr;
     const TileCount<C> t(p);
     if (val)
@@ -1107,12 +1216,26 @@ static int launch_pullbwd(const interpol_problem *p, const KParams &k, const voi
                           void *gvol, void *ggrid, int64_t gsb, int64_t gsc, hipStream_t st)
 {
     using T = typename C::T;
-    static int attr = big_lds<C>(pullbwd_tiled<C>);
+    const int attr = big_lds<C>(pullbwd_tiled<C>);
     if (attr) return attr;
     const TileCount<C> t(p);
     hipLaunchKernelGGL((pullbwd_tiled<C>), t.grid((int)p->batch), dim3(C::NT), smem_bytes<C>(), st,
                        k, (const T *)gout, (const T *)vol, (const float *)grid, (float *)gvol, (float *)ggrid,
                        gsb, gsc, t.gx, t.gy, t.gz, t.nty, t.ntz, t.ntiles(), (int)p->batch);
+    IP_CHECK_LAUNCH();
+}
+
+template <typename C>
+static int launch_pushbwd(const interpol_problem *p, const KParams &k, const void *gvol_out, const void *val, const void *grid,
+                          void *gval, void *ggrid, hipStream_t st)
+{
+    using T = typename C::T;
+    const int attr = big_lds<C>(pushbwd_tiled<C>);
+    if (attr) return attr;
+    const TileCount<C> t(p);
+    hipLaunchKernelGGL((pushbwd_tiled<C>), t.grid((int)p->batch), dim3(C::NT), smem_bytes<C>(), st,
+                       k, (const T *)gvol_out, (const T *)val, (const float *)grid, (T *)gval, (float *)ggrid,
+                       t.gx, t.gy, t.gz, t.nty, t.ntz, t.ntiles(), (int)p->batch);
     IP_CHECK_LAUNCH();
 }
 
@@ -1208,6 +1331,13 @@ int IP_SYM(try_fast_pullbwd_, IP_TSFX)(const interpol_problem *p, const KParams 
                                        void *gvol, void *ggrid, int64_t gsb, int64_t gsc, hipStream_t st)
 {
     IP_BY_ORDER(tiled::launch_pullbwd, >(p, k, gout, vol, grid, gvol, ggrid, gsb, gsc, st))
+}
+
+int IP_SYM(try_fast_pushbwd_, IP_TSFX)(const interpol_problem *p, const KParams &k, const void *gvol_out, const void *val,
+                                       const void *grid, void *gval, void *ggrid, hipStream_t st)
+{
+    if (p->dim != 3 && !(p->flags & INTERPOL_FLAG_FORCE_TILED)) return 0;
+    IP_BY_ORDER(tiled::launch_pushbwd, >(p, k, gvol_out, val, grid, gval, ggrid, st))
 }
 
 } // namespace ip

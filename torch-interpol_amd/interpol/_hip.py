@@ -304,7 +304,7 @@ def scatter(op, val, grid, shape, bound, order, extrapolate, flags=0, out=None, 
     return vol.to(out_dt)
 
 
-def pull_backward(gout, vol, grid, bound, order, extrapolate, need_vol, need_grid):
+def pull_backward(gout, vol, grid, bound, order, extrapolate, need_vol, need_grid, flags=0):
     """Fused backward of pull: (grad_vol (B,C,*in) | None, grad_grid (B,*out,D) | None)."""
     dev = _require_gpu(gout, vol, grid)
     dim = grid.shape[-1]
@@ -333,7 +333,7 @@ def pull_backward(gout, vol, grid, bound, order, extrapolate, need_vol, need_gri
     vstr = [_bstride(vol, B), vol.stride(1)] + _pad_to([vol.stride(2 + d) for d in range(dim)], 3)
     valstr = [_bstride(gout, B), gout.stride(1)] + _pad_to([gout.stride(2 + d) for d in range(dim)], 3) + [0, 0]
     p = make_problem(dim, dt, gdt, bound, order, extrapolate, B, C, ishape, oshape,
-                     vstr, _grid_strides(grid_c, B, dim), valstr)
+                     vstr, _grid_strides(grid_c, B, dim), valstr, flags)
     with torch.cuda.device(dev):
         rc = lib().interpol_pull_backward(ctypes.byref(p), _ptr(gout), _ptr(vol), _ptr(grid_c), _ptr(gvol),
                                           _ptr(ggrid), _ptr(scratch), sbytes, _stream(dev))
@@ -341,7 +341,7 @@ def pull_backward(gout, vol, grid, bound, order, extrapolate, need_vol, need_gri
     return gvol, ggrid
 
 
-def push_backward(gvol_out, val, grid, bound, order, extrapolate, need_val, need_grid):
+def push_backward(gvol_out, val, grid, bound, order, extrapolate, need_val, need_grid, flags=0):
     """Fused backward of push (val given) or count (val None):
     (grad_val (B,C,*in) | None, grad_grid (B,*in,D) | None)."""
     dev = _require_gpu(gvol_out, val, grid)
@@ -370,7 +370,7 @@ def push_backward(gvol_out, val, grid, bound, order, extrapolate, need_val, need
     dense = _dense_strides([B, C] + gshape)
     valstr = dense[:2] + _pad_to(dense[2:], 3) + [0, 0]
     p = make_problem(dim, dt, gdt, bound, order, extrapolate, B, C, gvol_out.shape[2:], gshape,
-                     vstr, _grid_strides(grid_c, B, dim), valstr)
+                     vstr, _grid_strides(grid_c, B, dim), valstr, flags)
     L = lib()
     with torch.cuda.device(dev):
         if count:
