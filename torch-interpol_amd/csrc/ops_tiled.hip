@@ -753,12 +753,14 @@ __device__ __forceinline__ void scatter_channel(const KParams &p, const Lattice 
     unsigned long long *box64 = reinterpret_cast<unsigned long long *>(sm.box);
     const int tid = threadIdx.x;
     // ---- block maximum of the sources -> fixed-point scale ---------------------------
+    // (the unmasked sources bound the masked ones: no need to re-read the coordinates here)
     float amax = 0.f;
 #pragma unroll
     for (int v = 0; v < C::VPT; ++v) {
-        const Sample<C> s = load_sample<C>(p, grid, b, g, tid, v);
-        if (s.valid) {
-            const float a = __builtin_fabsf(src_of(s));
+        int ox, oy, oz;
+        sample_pos<C>(g, tid, v, ox, oy, oz);
+        if (ox < g.gx && oy < g.gy && oz < g.gz) {
+            const float a = __builtin_fabsf(src_slow(((int64_t)ox * g.gy + oy) * g.gz + oz));
             amax = (a > amax || a != a) ? a : amax;                            // NaN sticks
         }
     }
