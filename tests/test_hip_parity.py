@@ -512,3 +512,24 @@ def test_tiled_push_backward_matches_generic(dim, order, sigma):
         slow = _hip.push_backward(gvol[:, :1], None, grid, b, o, ex, False, True, flags=_hip.FLAG_NO_FASTPATH)
         assert fast[0] is None
         _same(fast[1], slow[1], 2e-5, ("count ggrid", dim, bound, ex, order, sigma))
+
+
+@pytest.mark.parametrize("order", [1, 3, 5])
+@pytest.mark.parametrize("sigma", [0.0, 2.0])
+def test_tiled_scatter_64bit_accumulator_path(order, sigma):
+    """The 64-bit fixed-point slab path (taken for strongly contracting deformations / high
+    orders) stays covered: force it with the debug switch and compare with the generic kernel,
+    and check a contracting deformation (all samples into a few voxels) on the default path."""
+    from interpol import _hip
+    vol, grid, tshape, sshape = _tiled_problem(3, sigma, seed=order + 90)
+    src = torch.randn([2, 3, *sshape], generator=torch.Generator().manual_seed(15)).to(DEV)
+    b, o = [3] * 3, [order] * 3
+    slow = _hip.scatter("push", src, grid, list(tshape), b, o, 1, flags=_hip.FLAG_NO_FASTPATH)
+    forced = _hip.scatter("push", src, grid, list(tshape), b, o, 1, flags=8 << 8)
+    _same(forced, slow, 1e-5, ("push64", order, sigma))
+    squeezed = (grid - 20.0) * 0.05 + 20.0            # 20x contraction: hundreds of samples per voxel
+    fast = _hip.scatter("push", src, squeezed, list(tshape), b, o, 1)
+    slow = _hip.scatter("push", src, squeezed, list(tshape), b, o, 1, flags=_hip.FLAG_NO_FASTPATH)
+    _same(fast, slow, 1e-5, ("push contracted", order, sigma))
+    cnt = _hip.scatter("count", None, squeezed, list(tshape), b, o, 1)
+    assert abs(float(cnt.sum()) - 2 * np.prod(sshape)) < 1e-3 * 2 * np.prod(sshape)

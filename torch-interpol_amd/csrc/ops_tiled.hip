@@ -76,7 +76,7 @@ struct Smem {
     float tabsgn[3][TABN];     // boundary sign of the same
     int   lo[3], hi[3];        // block reductions
     int   nslow;
-    int   pad_;
+    int   dmax;                // max number of fast samples sharing one first-tap cell (scatter kernels)
     unsigned short slow[SLOWCAP];
     float box[1];              // really C::BOXF floats (dynamic LDS)
 };
@@ -307,12 +307,13 @@ struct Box {
     // Bounding box of the tile + classification of this thread's samples, from ONE read of
     // the coordinates: bit v of the result = sample v is "fast" (support inside the box);
     // the other valid samples are appended to the block's slow list.
+    template <bool DENSITY = false>
     __device__ __forceinline__ unsigned build(const KParams &p, const Lattice &L, const float *__restrict__ grid, int64_t b,
                                               const TileGeom &g, Smem &sm)
     {
         const int tid = threadIdx.x;
         if (tid < 3) { sm.lo[tid] = 0x7fffffff; sm.hi[tid] = -0x7fffffff; }
-        if (tid == 0) sm.nslow = 0;
+        if (tid == 0) { sm.nslow = 0; sm.dmax = 0; }
         __syncthreads();
         int mn[3] = { 0x7fffffff, 0x7fffffff, 0x7fffffff }, mx[3] = { -0x7fffffff, -0x7fffffff, -0x7fffffff };
         int i0[C::VPT][3];
@@ -371,6 +372,25 @@ struct Box {
             }
         }
         __syncthreads();
+        if (DENSITY) {
+            // Sample density: how many fast samples share one first-tap cell.  It bounds how
+            // many contributions any lattice point of the box can receive, which is what lets
+            // the scatter accumulate in 32-bit fixed point (see scatter_channel).
+            unsigned *cnt = reinterpret_cast<unsigned *>(sm.box);
+            const int nslots = S[0] * S[1] * C::PZ;
+            for (int e = tid; e < nslots; e += C::NT) cnt[e] = 0u;
+            __syncthreads();
+#pragma unroll
+            for (int v = 0; v < C::VPT; ++v)
+                if ((fastmask >> v) & 1)
+                    atomicAdd(&cnt[((i0[v][0] - lo[0]) * S[1] + (i0[v][1] - lo[1])) * C::PZ + (i0[v][2] - lo[2])], 1u);
+            __syncthreads();
+            int m = 0;
+            for (int e = tid; e < nslots; e += C::NT) { const int cv = (int)cnt[e]; m = cv > m ? cv : m; }
+            m = wave_max(m);
+            if ((tid & 63) == 0 && m > 0) atomicMax(&sm.dmax, m);
+            __syncthreads();
+        }
         return fastmask;
     }
 
@@ -745,7 +765,7 @@ __global__ __launch_bounds__(C::NT) void pull2_tiled(KParams p, const typename C
 // ---------------------------------------------------------------------------
 template <typename C, typename SrcFn, typename SrcSlowFn>
 __device__ __forceinline__ void scatter_channel(const KParams &p, const Lattice &L, const float *__restrict__ grid, int64_t b,
-                                                const TileGeom &g, const Box<C> &box, unsigned fastmask, int nslow,
+                                                const TileGeom &g, const Box<C> &box, unsigned fastmask, int nslow, int dmax,
                                                 float *__restrict__ vc, Smem &sm, SrcFn src_of, SrcSlowFn src_slow)
 {
     constexpr int K = C::K, KX = C::KX;
@@ -809,6 +829,93 @@ __device__ __forceinline__ void scatter_channel(const KParams &p, const Lattice 
                 if (t0 + lane < NTAP)
                     __hip_atomic_fetch_add(vc + off, w * sv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
+        }
+    }
+
+    // ---- 32-bit mode -----------------------------------------------------------------------
+    // A lattice point x of the box receives, in units of max|src|, at most
+    //     cb = dmax * prod_d  sum_j max_t w_j(t)
+    // (group the samples by first-tap cell c: at most dmax per cell, and a sample of cell c
+    // reaches x with weight prod_d w_{x_d - c_d}(t_d) <= prod_d max_t w_j(t); the per-order sums
+    // of the tap maxima are 1, 2, 1.75, 5/3, 1.599, 1.55, 1.511, 1.479).  With hb = ceil(log2 cb)
+    // bits of headroom the sum of q = rne(src * w * 2^(e - hb)) cannot leave int32, and the
+    // whole box fits LDS at 4 bytes per slot: ONE pass with ds_add_u32 (5.7 lanes/clk/CU vs 4.6
+    // for ds_add_u64) instead of slab passes.  Each contribution is rounded to +-2^(hb-30)
+    // max|src|; with n taps the worst slot error is ~1.3 sqrt(n) 2^(hb-29) max|src|, kept below
+    // 2.5e-6 by requiring 2^hb <= 1032 / sqrt(n).  Strongly contracting deformations (large
+    // dmax) and high orders keep the 64-bit path below.
+    {
+        const float wsum[8] = { 1.f, 2.f, 1.75f, 1.6666667f, 1.5989584f, 1.55f, 1.5110244f, 1.4793651f };
+        float cb = (float)(dmax > 0 ? dmax : 1);
+        int ntap = 1;
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            float ws = 1.f;
+#pragma unroll
+            for (int o = 0; o < 8; ++o) ws = (L.k[d] == o) ? wsum[o] : ws;
+            cb *= ws;
+            ntap *= L.k[d] + 1;
+        }
+        const int hb = ((__float_as_int(cb * 1.0001f) >> 23) & 0xff) - 126;     // cb < 2^hb
+        const bool precise = (float)(1 << (hb < 0 ? 0 : (hb > 20 ? 20 : hb))) * sqrtf((float)ntap) <= 1032.f;
+        if (hb >= 0 && precise && !(p.dbg & 8)) {
+            unsigned *box32 = reinterpret_cast<unsigned *>(sm.box);
+            const float scale32 = __int_as_float((127 + 29 - ex - hb) << 23);
+            const float inv32 = __int_as_float((127 - 29 + ex + hb) << 23);
+            const int nslots = box.S[0] * box.S[1] * C::PZ;
+            __syncthreads();
+            for (int e = tid; e < nslots; e += C::NT) box32[e] = 0u;
+            __syncthreads();
+#pragma unroll
+            for (int v = 0; v < C::VPT; ++v) {
+                if (!((fastmask >> v) & 1) || (p.dbg & 2)) continue;
+                const Sample<C> s = load_sample<C>(p, grid, b, g, tid, v);
+                float wx[KX + 1], wy[K + 1], wz[K + 1];
+                if (KX > 0) weights<KX>(L.lin, L.k[0], s.t[0], wx); else wx[0] = 1.f;
+                weights<K>(L.lin, L.k[1], s.t[1], wy); weights<K>(L.lin, L.k[2], s.t[2], wz);
+                const float ss = src_of(s) * scale32;
+                unsigned *bp = box32 + box.base(s);
+#pragma unroll
+                for (int i = 0; i <= KX; ++i) {
+                    if (!C::ISO && i > L.k[0]) continue;      // wave-uniform
+                    const float si = ss * wx[i];
+#pragma unroll
+                    for (int j = 0; j <= K; ++j) {
+                        if (!C::ISO && j > L.k[1]) continue;
+                        unsigned *rp = bp + (i * box.S[1] + j) * C::PZ;
+                        const float sj = si * wy[j];
+#pragma unroll
+                        for (int k = 0; k <= K; ++k) {
+                            if (!C::ISO && k > L.k[2]) continue;
+                            // round to nearest: truncation would bias every contribution the same way
+                            atomicAdd(rp + k, (unsigned)__float2int_rn(sj * wz[k]));    // ds_add_u32
+                        }
+                    }
+                }
+            }
+            __syncthreads();
+            if (!(p.dbg & 1)) {
+                const int z = tid % C::PZ;
+                const bool zin = z < box.S[2];
+                const int oz_ = zin ? sm.taboff[2][z] : 0;
+                const float sz = zin ? sm.tabsgn[2][z] : 0.f;
+                constexpr int RSTEP = C::NT / C::PZ;
+                const float inv_sy = 1.f / (float)box.S[1];
+                const int rows = box.S[0] * box.S[1];
+                for (int r = tid / C::PZ; r < rows; r += RSTEP) {
+                    if (zin) {
+                        const int a = (int)box32[r * C::PZ + z];
+                        if (a != 0) {
+                            const int x = (int)(((float)r + 0.5f) * inv_sy);
+                            const int y = r - x * box.S[1];
+                            const float sgn = sm.tabsgn[0][x] * sm.tabsgn[1][y] * sz;
+                            __hip_atomic_fetch_add(vc + sm.taboff[0][x] + sm.taboff[1][y] + oz_, (float)a * inv32 * sgn,
+                                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        }
+                    }
+                }
+            }
+            return;
         }
     }
 
@@ -900,12 +1007,12 @@ __global__ __launch_bounds__(C::NT) void push_tiled(KParams p, const typename C:
         const int64_t b = work / ntiles;
         const TileGeom g = tile_geom<C>(work % ntiles, gx, gy, gz, nty, ntz);
         Box<C> box;
-        const unsigned fastmask = box.build(p, L, grid, b, g, sm);
-        const int nslow = sm.nslow;
+        const unsigned fastmask = box.template build<true>(p, L, grid, b, g, sm);
+        const int nslow = sm.nslow, dmax = sm.dmax;
         for (int c = 0; c < p.C; ++c) {
             const T *ic = COUNT ? nullptr : val + b * p.val_sb + c * p.val_sc;
             float *vc = vol + b * p.vol_sb + c * p.vol_sc;
-            scatter_channel<C>(p, L, grid, b, g, box, fastmask, nslow, vc, sm,
+            scatter_channel<C>(p, L, grid, b, g, box, fastmask, nslow, dmax, vc, sm,
                 [&](const Sample<C> &s) { const float v = COUNT ? 1.f : Cvt<float, T>::ld(ic[s.o]); return (p.extrapolate != 1 && !s.inb) ? 0.f * v : v; },   // nd.py:201-203
                 [&](int64_t o) { return COUNT ? 1.f : Cvt<float, T>::ld(ic[o]); });
         }
@@ -934,8 +1041,8 @@ __global__ __launch_bounds__(C::NT) void pullbwd_tiled(KParams p, const typename
     const int64_t b = work / ntiles;
     const TileGeom g = tile_geom<C>(work % ntiles, gx, gy, gz, nty, ntz);
     Box<C> box;
-    const unsigned fastmask = box.build(p, L, grid, b, g, sm);
-    const int nslow = sm.nslow;
+    const unsigned fastmask = box.template build<true>(p, L, grid, b, g, sm);
+    const int nslow = sm.nslow, dmax = sm.dmax;
 
     float gg[C::VPT][3];
 #pragma unroll
@@ -996,7 +1103,7 @@ __global__ __launch_bounds__(C::NT) void pullbwd_tiled(KParams p, const typename
         }
         if (gvol) {
             float *qc = gvol + b * gvol_sb + c * gvol_sc;
-            scatter_channel<C>(p, L, grid, b, g, box, fastmask, nslow, qc, sm,
+            scatter_channel<C>(p, L, grid, b, g, box, fastmask, nslow, dmax, qc, sm,
                 [&](const Sample<C> &s) { const float gv = Cvt<float, T>::ld(gc[s.o]); return (p.extrapolate != 1 && !s.inb) ? 0.f * gv : gv; },
                 [&](int64_t o) { return Cvt<float, T>::ld(gc[o]); });
         }
