@@ -37,6 +37,7 @@
 // ===========================================================================
 #include "../../include/interpol_hip.h"
 #include "stencil.hpp"
+#include <type_traits>
 
 namespace ip {
 namespace tiled {
@@ -77,6 +78,7 @@ struct Smem {
     int   lo[3], hi[3];        // block reductions
     int   nslow;
     int   dmax;                // max number of fast samples sharing one first-tap cell (scatter kernels)
+    int   cmax[8];             // per-channel max |source| of the tile (float bits), first 8 channels
     unsigned short slow[SLOWCAP];
     float box[1];              // really C::BOXF floats (dynamic LDS)
 };
@@ -307,13 +309,16 @@ struct Box {
     // Bounding box of the tile + classification of this thread's samples, from ONE read of
     // the coordinates: bit v of the result = sample v is "fast" (support inside the box);
     // the other valid samples are appended to the block's slow list.
-    template <bool DENSITY = false>
+    // DENSITY (scatter kernels): also leaves sm.dmax, the per-channel source maxima sm.cmax[c]
+    // (c < min(C, 8), from `src_at(c, o)`) and an all-zero box behind.
+    template <bool DENSITY = false, typename SrcAt = int>
     __device__ __forceinline__ unsigned build(const KParams &p, const Lattice &L, const float *__restrict__ grid, int64_t b,
-                                              const TileGeom &g, Smem &sm)
+                                              const TileGeom &g, Smem &sm, SrcAt src_at = 0, bool box_clean = false)
     {
         const int tid = threadIdx.x;
         if (tid < 3) { sm.lo[tid] = 0x7fffffff; sm.hi[tid] = -0x7fffffff; }
         if (tid == 0) { sm.nslow = 0; sm.dmax = 0; }
+        if (tid < 8) sm.cmax[tid] = 0;
         __syncthreads();
         int mn[3] = { 0x7fffffff, 0x7fffffff, 0x7fffffff }, mx[3] = { -0x7fffffff, -0x7fffffff, -0x7fffffff };
         int i0[C::VPT][3];
@@ -375,20 +380,49 @@ struct Box {
         if (DENSITY) {
             // Sample density: how many fast samples share one first-tap cell.  It bounds how
             // many contributions any lattice point of the box can receive, which is what lets
-            // the scatter accumulate in 32-bit fixed point (see scatter_channel).
+            // the scatter accumulate in 32-bit fixed point (see scatter_channel).  Only the
+            // cells that hold samples are touched (count, read back, re-zero): the box is
+            // all-zero on entry when the previous tile left it so (box_clean), and on exit.
             unsigned *cnt = reinterpret_cast<unsigned *>(sm.box);
-            const int nslots = S[0] * S[1] * C::PZ;
-            for (int e = tid; e < nslots; e += C::NT) cnt[e] = 0u;
+            if (!box_clean) {
+                const int nslots = C::BOXF;
+                for (int e = tid; e < nslots; e += C::NT) cnt[e] = 0u;
+                __syncthreads();
+            }
+            int cell[C::VPT];
+#pragma unroll
+            for (int v = 0; v < C::VPT; ++v) {
+                cell[v] = ((i0[v][0] - lo[0]) * S[1] + (i0[v][1] - lo[1])) * C::PZ + (i0[v][2] - lo[2]);
+                if ((fastmask >> v) & 1) atomicAdd(&cnt[cell[v]], 1u);
+            }
+            __syncthreads();
+            int m = 0;
+#pragma unroll
+            for (int v = 0; v < C::VPT; ++v)
+                if ((fastmask >> v) & 1) { const int cv = (int)cnt[cell[v]]; m = cv > m ? cv : m; }
+            m = wave_max(m);
+            if ((tid & 63) == 0 && m > 0) atomicMax(&sm.dmax, m);
             __syncthreads();
 #pragma unroll
             for (int v = 0; v < C::VPT; ++v)
-                if ((fastmask >> v) & 1)
-                    atomicAdd(&cnt[((i0[v][0] - lo[0]) * S[1] + (i0[v][1] - lo[1])) * C::PZ + (i0[v][2] - lo[2])], 1u);
-            __syncthreads();
-            int m = 0;
-            for (int e = tid; e < nslots; e += C::NT) { const int cv = (int)cnt[e]; m = cv > m ? cv : m; }
-            m = wave_max(m);
-            if ((tid & 63) == 0 && m > 0) atomicMax(&sm.dmax, m);
+                if ((fastmask >> v) & 1) cnt[cell[v]] = 0u;
+            // per-channel maxima of the (unmasked) sources -> fixed-point scales, one reduction for all channels
+            if constexpr (!std::is_same<SrcAt, int>::value) {
+                const int nc = p.C < 8 ? p.C : 8;
+                for (int c = 0; c < nc; ++c) {
+                    float amax = 0.f;
+#pragma unroll
+                    for (int v = 0; v < C::VPT; ++v) {
+                        if (!((validmask >> v) & 1)) continue;
+                        int ox, oy, oz;
+                        sample_pos<C>(g, tid, v, ox, oy, oz);
+                        const float a = __builtin_fabsf(src_at(c, ((int64_t)ox * g.gy + oy) * g.gz + oz));
+                        amax = (a > amax || a != a) ? a : amax;                    // NaN sticks
+                    }
+                    int bits = wave_max(__float_as_int(amax));   // non-negative floats (and NaN) order like ints
+                    if ((tid & 63) == 0 && bits != 0) atomicMax(&sm.cmax[c], bits);
+                }
+            }
             __syncthreads();
         }
         return fastmask;
@@ -764,8 +798,9 @@ __global__ __launch_bounds__(C::NT) void pull2_tiled(KParams p, const typename C
 // per-thread float path so that IEEE semantics survive.
 // ---------------------------------------------------------------------------
 template <typename C, typename SrcFn, typename SrcSlowFn>
-__device__ __forceinline__ void scatter_channel(const KParams &p, const Lattice &L, const float *__restrict__ grid, int64_t b,
+__device__ __forceinline__ bool scatter_channel(const KParams &p, const Lattice &L, const float *__restrict__ grid, int64_t b,
                                                 const TileGeom &g, const Box<C> &box, unsigned fastmask, int nslow, int dmax,
+                                                int cmax_bits, bool box_is_zero,
                                                 float *__restrict__ vc, Smem &sm, SrcFn src_of, SrcSlowFn src_slow)
 {
     constexpr int K = C::K, KX = C::KX;
@@ -773,28 +808,32 @@ __device__ __forceinline__ void scatter_channel(const KParams &p, const Lattice 
     unsigned long long *box64 = reinterpret_cast<unsigned long long *>(sm.box);
     const int tid = threadIdx.x;
     // ---- block maximum of the sources -> fixed-point scale ---------------------------
-    // (the unmasked sources bound the masked ones: no need to re-read the coordinates here)
-    float amax = 0.f;
+    // cmax_bits >= 0: already reduced by Box::build (first 8 channels); else reduce here.
+    // (the unmasked sources bound the masked ones: no need to re-read the coordinates)
+    int mbits = cmax_bits;
+    if (cmax_bits < 0) {
+        float amax = 0.f;
 #pragma unroll
-    for (int v = 0; v < C::VPT; ++v) {
-        int ox, oy, oz;
-        sample_pos<C>(g, tid, v, ox, oy, oz);
-        if (ox < g.gx && oy < g.gy && oz < g.gz) {
-            const float a = __builtin_fabsf(src_slow(((int64_t)ox * g.gy + oy) * g.gz + oz));
-            amax = (a > amax || a != a) ? a : amax;                            // NaN sticks
+        for (int v = 0; v < C::VPT; ++v) {
+            int ox, oy, oz;
+            sample_pos<C>(g, tid, v, ox, oy, oz);
+            if (ox < g.gx && oy < g.gy && oz < g.gz) {
+                const float a = __builtin_fabsf(src_slow(((int64_t)ox * g.gy + oy) * g.gz + oz));
+                amax = (a > amax || a != a) ? a : amax;                            // NaN sticks
+            }
         }
+        __syncthreads();                               // whoever used sm.hi before is done
+        if (tid == 0) sm.hi[0] = 0;
+        __syncthreads();
+        {
+            int bits = __float_as_int(amax);
+            bits = wave_max(bits);
+            if ((tid & 63) == 0) atomicMax(&sm.hi[0], bits);
+        }
+        __syncthreads();
+        mbits = sm.hi[0];
     }
-    __syncthreads();                               // whoever used the box / sm.hi before is done
-    if (tid == 0) sm.hi[0] = 0;
-    __syncthreads();
-    {
-        int bits = __float_as_int(amax);           // non-negative floats (and NaN) order like ints
-        bits = wave_max(bits);
-        if ((tid & 63) == 0) atomicMax(&sm.hi[0], bits);
-    }
-    __syncthreads();
-    const int mbits = sm.hi[0];
-    if (mbits == 0) return;                        // nothing to splat in this tile / channel
+    if (mbits == 0) return box_is_zero;            // nothing to splat in this tile / channel
     const bool finite = (mbits & 0x7f800000) != 0x7f800000;
     // 2^e * max <= 2^30 : e = 29 - exponent(max)
     int ex = ((mbits >> 23) & 0xff) - 127;
@@ -811,7 +850,7 @@ __device__ __forceinline__ void scatter_channel(const KParams &p, const Lattice 
             if (!s.valid || (p.dbg & 2)) continue;
             scatter_one_thread(L, vc, src_of(s), s.i0[0], s.i0[1], s.i0[2], s.t[0], s.t[1], s.t[2]);
         }
-        return;
+        return box_is_zero;
     }
 
     // ---- slow list: one wave per sample, lanes = taps, one global atomic per lane --------
@@ -863,8 +902,12 @@ __device__ __forceinline__ void scatter_channel(const KParams &p, const Lattice 
             const float scale32 = __int_as_float((127 + 29 - ex - hb) << 23);
             const float inv32 = __int_as_float((127 - 29 + ex + hb) << 23);
             const int nslots = box.S[0] * box.S[1] * C::PZ;
-            __syncthreads();
-            for (int e = tid; e < nslots; e += C::NT) box32[e] = 0u;
+            // the box is all-zero on entry when the caller says so (left so by Box::build or by
+            // the previous channel's flush): no zeroing pass, one barrier less
+            if (!box_is_zero) {
+                __syncthreads();
+                for (int e = tid; e < nslots; e += C::NT) box32[e] = 0u;
+            }
             __syncthreads();
 #pragma unroll
             for (int v = 0; v < C::VPT; ++v) {
@@ -894,7 +937,7 @@ __device__ __forceinline__ void scatter_channel(const KParams &p, const Lattice 
                 }
             }
             __syncthreads();
-            if (!(p.dbg & 1)) {
+            {
                 const int z = tid % C::PZ;
                 const bool zin = z < box.S[2];
                 const int oz_ = zin ? sm.taboff[2][z] : 0;
@@ -906,6 +949,8 @@ __device__ __forceinline__ void scatter_channel(const KParams &p, const Lattice 
                     if (zin) {
                         const int a = (int)box32[r * C::PZ + z];
                         if (a != 0) {
+                            box32[r * C::PZ + z] = 0u;                 // leave the box zeroed for the next channel
+                            if (p.dbg & 1) continue;
                             const int x = (int)(((float)r + 0.5f) * inv_sy);
                             const int y = r - x * box.S[1];
                             const float sgn = sm.tabsgn[0][x] * sm.tabsgn[1][y] * sz;
@@ -915,7 +960,7 @@ __device__ __forceinline__ void scatter_channel(const KParams &p, const Lattice 
                     }
                 }
             }
-            return;
+            return true;                                   // every touched slot was reset by the flush
         }
     }
 
@@ -989,6 +1034,7 @@ __device__ __forceinline__ void scatter_channel(const KParams &p, const Lattice 
             }
         }
     }
+    return false;                                      // the 64-bit slabs leave the box dirty
 }
 
 // ---------------------------------------------------------------------------
@@ -1003,16 +1049,20 @@ __global__ __launch_bounds__(C::NT) void push_tiled(KParams p, const typename C:
     Smem &sm = *reinterpret_cast<Smem *>(smem_raw);
     using T = typename C::T;
     const Lattice L = make_lattice<C>(p, 4);         // the target (or its fp32 scratch) is float
+    bool clean = false;                                // is the LDS box all-zero?  (block-uniform)
     for (int work = blockIdx.x; work < ntiles * nbatch; work += gridDim.x) {
         const int64_t b = work / ntiles;
         const TileGeom g = tile_geom<C>(work % ntiles, gx, gy, gz, nty, ntz);
         Box<C> box;
-        const unsigned fastmask = box.template build<true>(p, L, grid, b, g, sm);
+        const T *ib = COUNT ? nullptr : val + b * p.val_sb;
+        const unsigned fastmask = box.template build<true>(p, L, grid, b, g, sm,
+            [&](int c, int64_t o) { return COUNT ? 1.f : Cvt<float, T>::ld(ib[c * p.val_sc + o]); }, clean);
         const int nslow = sm.nslow, dmax = sm.dmax;
+        clean = true;                                  // Box::build leaves the box zeroed
         for (int c = 0; c < p.C; ++c) {
             const T *ic = COUNT ? nullptr : val + b * p.val_sb + c * p.val_sc;
             float *vc = vol + b * p.vol_sb + c * p.vol_sc;
-            scatter_channel<C>(p, L, grid, b, g, box, fastmask, nslow, dmax, vc, sm,
+            clean = scatter_channel<C>(p, L, grid, b, g, box, fastmask, nslow, dmax, c < 8 ? sm.cmax[c] : -1, clean, vc, sm,
                 [&](const Sample<C> &s) { const float v = COUNT ? 1.f : Cvt<float, T>::ld(ic[s.o]); return (p.extrapolate != 1 && !s.inb) ? 0.f * v : v; },   // nd.py:201-203
                 [&](int64_t o) { return COUNT ? 1.f : Cvt<float, T>::ld(ic[o]); });
         }
@@ -1103,7 +1153,7 @@ __global__ __launch_bounds__(C::NT) void pullbwd_tiled(KParams p, const typename
         }
         if (gvol) {
             float *qc = gvol + b * gvol_sb + c * gvol_sc;
-            scatter_channel<C>(p, L, grid, b, g, box, fastmask, nslow, dmax, qc, sm,
+            scatter_channel<C>(p, L, grid, b, g, box, fastmask, nslow, dmax, -1, false, qc, sm,
                 [&](const Sample<C> &s) { const float gv = Cvt<float, T>::ld(gc[s.o]); return (p.extrapolate != 1 && !s.inb) ? 0.f * gv : gv; },
                 [&](int64_t o) { return Cvt<float, T>::ld(gc[o]); });
         }
