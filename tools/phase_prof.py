@@ -1,0 +1,25 @@
+#!/usr/bin/env python
+"""Per-phase cycle shares of the tiled push kernel (needs ops_tiled built with -DIP_PROF:
+   rm torch-interpol_amd/build/ops_tiled_f32.o && make -C torch-interpol_amd PROF=1)."""
+import os, sys, json, ctypes
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "torch-interpol_amd")); sys.path.insert(0, ROOT)
+import torch, interpol
+from interpol import _hip
+import bench
+
+NAMES = ["build", "pair:slow", "pair:zero", "pair:taps", "pair:flush", "-", "-", "-", "single-channel path", "build:load+minmax", "build:tables+classify", "build:density"]
+dev = torch.device("cuda", 0)
+sigma = float(sys.argv[1]) if len(sys.argv) > 1 else 2.0
+inp, grid = bench.make_inputs(4, 2, 256, sigma, dev, 1234)
+L = _hip.lib()
+fn = L.interpol_debug_prof_f32
+fn.argtypes = [ctypes.c_void_p, ctypes.c_int]
+buf = (ctypes.c_ulonglong * 16)()
+_hip.scatter("push", inp, grid, None, [3] * 3, [3] * 3, 1); torch.cuda.synchronize()
+fn(None, 1)
+_hip.scatter("push", inp, grid, None, [3] * 3, [3] * 3, 1); torch.cuda.synchronize()
+fn(buf, 1)
+tot = sum(buf)
+print(json.dumps({"sigma": sigma, "total_cycles_per_block_sum": tot,
+                  "share": {NAMES[i] if i < len(NAMES) else str(i): round(buf[i] / tot, 4) for i in range(16) if buf[i]}}))

@@ -50,11 +50,35 @@ constexpr int TABN = 72;                       // max box extent along one dim
 // T = storage type of images (float, bf16_t, f16_t; math is always fp32),
 // K = spline order (ISO: every dim has order K; !ISO: per-dim runtime orders <= K, taps
 // beyond a dim's order are predicated off with wave-uniform tests).
+// Phase profiling aid (tools/phase_prof.py): build this TU with -DIP_PROF and every
+// prof_mark(i) adds the cycles since the previous mark (thread 0, after a block barrier) to
+// g_prof[i].  Compiled out otherwise.
+#ifdef IP_PROF
+__device__ unsigned long long g_prof[16];
+#endif
+__device__ __forceinline__ void prof_mark(int i)
+{
+#ifdef IP_PROF
+    __shared__ unsigned long long t0;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned long long n = clock64();
+        if (i >= 0) atomicAdd(&g_prof[i], n - t0);
+        t0 = n;
+    }
+#endif
+}
+
+#ifndef IP_LDS_PAD
+#define IP_LDS_PAD 0
+#endif
 template <typename T_, int K_, bool ISO_, int D_, int TX_, int TY_, int TZ_, int NT_, int PZ_>
 struct Cfg {
     using T = T_;
     static constexpr bool ISO = ISO_;
     static constexpr int K = K_, D = D_, TX = TX_, TY = TY_, TZ = TZ_, NT = NT_, PZ = PZ_;
+    // LDS row stride in slots: odd, so that rows (x, y) of the box start in different banks
+    static constexpr int PS = PZ_ + IP_LDS_PAD;
     static constexpr int NS = TX * TY * TZ;            // samples per tile
     static constexpr int VPT = NS / NT;                 // samples per thread
     static constexpr int XSTEP = NT / (TY * TZ);        // x distance between a thread's samples
@@ -62,9 +86,9 @@ struct Cfg {
     static constexpr int CAPZ = PZ;
     static constexpr int CAPX = D == 3 ? 33 : 1;
     static constexpr int CAPY = D == 3 ? 33 : TABN;
-    // floats of LDS for the box: 3-D 33*33*32 (139392 B of the 160 KiB); 2-D twice the
+    // floats of LDS for the box: 3-D 34*33*32 (143616 B of the 160 KiB); 2-D twice the
     // gather box so that the 64-bit scatter needs a single pass
-    static constexpr int BOXF = D == 3 ? CAPX * CAPY * PZ : 2 * CAPY * PZ;
+    static constexpr int BOXF = D == 3 ? (CAPX + 1) * CAPY * PS : 2 * CAPY * PS;   // CAPX + 1: two half boxes of 8-byte slots
     static_assert(NS % NT == 0 && NT % (TY * TZ) == 0, "tile / thread mismatch");
     static_assert(NT % PZ == 0, "staging maps z to tid % PZ");
     // problem dim of kernel dim d (-1: degenerate)
@@ -273,6 +297,26 @@ __device__ __forceinline__ void sample_pos(const TileGeom &g, int tid, int v, in
     oz = g.oz0 + tid % C::TZ;
 }
 
+// Coordinates of sample v of this thread.  The loads are UNCONDITIONAL, from a position
+// clamped into the sample grid: a branch around them would keep the compiler from batching
+// the loads of a thread's samples (one exposed HBM round trip per sample instead of one per
+// tile; measured 6.7 us -> of Box::build per 16^3 tile).  Returns whether the sample exists;
+// `o` is the linear index of the (clamped) position in its batch item.
+template <typename C>
+__device__ __forceinline__ bool load_coords(const KParams &p, const float *__restrict__ grid, int64_t b, const TileGeom &g,
+                                            int tid, int v, float *x, int64_t &o)
+{
+    int ox, oy, oz;
+    sample_pos<C>(g, tid, v, ox, oy, oz);
+    const bool valid = ox < g.gx && oy < g.gy && oz < g.gz;
+    ox = ox < g.gx ? ox : g.gx - 1; oy = oy < g.gy ? oy : g.gy - 1; oz = oz < g.gz ? oz : g.gz - 1;
+    o = ((int64_t)ox * g.gy + oy) * g.gz + oz;
+    const float *gp = grid + b * p.grid_sb + o * C::D;
+#pragma unroll
+    for (int d = 0; d < 3; ++d) x[d] = C::pd(d) >= 0 ? gp[C::pd(d) < 0 ? 0 : C::pd(d)] : 0.f;
+    return valid;
+}
+
 template <typename C>
 __device__ __forceinline__ Sample<C> load_sample(const KParams &p, const float *__restrict__ grid, int64_t b,
                                                  const TileGeom &g, int tid, int v)
@@ -281,23 +325,20 @@ __device__ __forceinline__ Sample<C> load_sample(const KParams &p, const float *
     const int kd[3] = { C::pd(0) < 0 ? 0 : (C::ISO ? C::K : p.order[C::pd(0) < 0 ? 0 : C::pd(0)]),
                         C::ISO ? C::K : p.order[C::pd(1) < 0 ? 0 : C::pd(1)],
                         C::ISO ? C::K : p.order[C::pd(2) < 0 ? 0 : C::pd(2)] };
-    int ox, oy, oz;
-    sample_pos<C>(g, tid, v, ox, oy, oz);
+    float x[3];
     Sample<C> s;
-    s.valid = ox < g.gx && oy < g.gy && oz < g.gz;
+    s.valid = load_coords<C>(p, grid, b, g, tid, v, x, s.o);
     s.inb = true;
-    s.o = ((int64_t)ox * g.gy + oy) * g.gz + oz;
 #pragma unroll
     for (int d = 0; d < 3; ++d) { s.i0[d] = 0; s.t[d] = 0.f; }
-    if (s.valid) {
-        const float *gp = grid + b * p.grid_sb + s.o * C::D;
 #pragma unroll
-        for (int d = 0; d < 3; ++d) {
-            if (C::pd(d) < 0) continue;
-            const float xd = gp[C::pd(d) < 0 ? 0 : C::pd(d)];
-            if (p.extrapolate != 1) s.inb = s.inb && xd > (float)p.mask_lo && xd < (float)p.mask_hi[C::pd(d) < 0 ? 0 : C::pd(d)];
-            split(kd[d], xd, s.i0[d], s.t[d]);
-        }
+    for (int d = 0; d < 3; ++d) {
+        if (C::pd(d) < 0) continue;
+        if (p.extrapolate != 1) s.inb = s.inb && x[d] > (float)p.mask_lo && x[d] < (float)p.mask_hi[C::pd(d) < 0 ? 0 : C::pd(d)];
+        int i0; float t;
+        split(kd[d], x[d], i0, t);
+        s.i0[d] = s.valid ? i0 : 0;
+        s.t[d] = s.valid ? t : 0.f;
     }
     return s;
 }
@@ -305,6 +346,36 @@ __device__ __forceinline__ Sample<C> load_sample(const KParams &p, const float *
 template <typename C>
 struct Box {
     int lo[3], S[3];
+
+    // max |src_at(c, .)| over the tile's samples for channels c0 and c0 + 1 (< nc) -> sm.cmax.
+    // Unconditional loads at clamped positions (see load_coords); NaN sticks.
+    template <typename SrcAt>
+    __device__ __forceinline__ static void channel_maxima(const TileGeom &g, Smem &sm, unsigned validmask, SrcAt src_at, int c0, int nc)
+    {
+        const int tid = threadIdx.x;
+        const int c1 = c0 + 1 < nc ? c0 + 1 : c0;
+        float a[2][C::VPT];
+#pragma unroll
+        for (int v = 0; v < C::VPT; ++v) {
+            int ox, oy, oz;
+            sample_pos<C>(g, tid, v, ox, oy, oz);
+            ox = ox < g.gx ? ox : g.gx - 1; oy = oy < g.gy ? oy : g.gy - 1; oz = oz < g.gz ? oz : g.gz - 1;
+            const int64_t o = ((int64_t)ox * g.gy + oy) * g.gz + oz;
+            a[0][v] = src_at(c0, o);
+            a[1][v] = src_at(c1, o);
+        }
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            float amax = 0.f;
+#pragma unroll
+            for (int v = 0; v < C::VPT; ++v) {
+                const float av = ((validmask >> v) & 1) ? __builtin_fabsf(a[h][v]) : 0.f;
+                amax = (av > amax || av != av) ? av : amax;
+            }
+            const int bits = wave_max(__float_as_int(amax));   // non-negative floats (and NaN) order like ints
+            if ((tid & 63) == 0 && bits != 0) atomicMax(&sm.cmax[h ? c1 : c0], bits);
+        }
+    }
 
     // Bounding box of the tile + classification of this thread's samples, from ONE read of
     // the coordinates: bit v of the result = sample v is "fast" (support inside the box);
@@ -323,13 +394,23 @@ struct Box {
         int mn[3] = { 0x7fffffff, 0x7fffffff, 0x7fffffff }, mx[3] = { -0x7fffffff, -0x7fffffff, -0x7fffffff };
         int i0[C::VPT][3];
         unsigned validmask = 0;
+        Sample<C> smp[C::VPT];
 #pragma unroll
         for (int v = 0; v < C::VPT; ++v) {
-            const Sample<C> s = load_sample<C>(p, grid, b, g, tid, v);
+            smp[v] = load_sample<C>(p, grid, b, g, tid, v);
+            if (smp[v].valid) validmask |= 1u << v;
+        }
+        // per-channel maxima of the (unmasked) sources -> fixed-point scales.  The loads of the
+        // first two channels are issued here, right behind the coordinate loads, so that the tile
+        // pays ONE exposed HBM round trip for both.
+        if constexpr (DENSITY && !std::is_same<SrcAt, int>::value)
+            channel_maxima(g, sm, validmask, src_at, 0, p.C < 8 ? p.C : 8);
+#pragma unroll
+        for (int v = 0; v < C::VPT; ++v) {
+            const Sample<C> &s = smp[v];
 #pragma unroll
             for (int d = 0; d < 3; ++d) i0[v][d] = s.i0[d];
             if (s.valid) {
-                validmask |= 1u << v;
 #pragma unroll
                 for (int d = 0; d < 3; ++d) {
                     mn[d] = s.i0[d] < mn[d] ? s.i0[d] : mn[d];
@@ -343,6 +424,7 @@ struct Box {
             if ((tid & 63) == 0) { atomicMin(&sm.lo[d], a); atomicMax(&sm.hi[d], c); }
         }
         __syncthreads();
+        if (DENSITY) prof_mark(9);
         const int cap[3] = { C::CAPX, C::CAPY, C::CAPZ };
         const int kd[3] = { L.k[0], L.k[1], L.k[2] };
 #pragma unroll
@@ -377,6 +459,7 @@ struct Box {
             }
         }
         __syncthreads();
+        if (DENSITY) prof_mark(10);
         if (DENSITY) {
             // Sample density: how many fast samples share one first-tap cell.  It bounds how
             // many contributions any lattice point of the box can receive, which is what lets
@@ -392,7 +475,7 @@ struct Box {
             int cell[C::VPT];
 #pragma unroll
             for (int v = 0; v < C::VPT; ++v) {
-                cell[v] = ((i0[v][0] - lo[0]) * S[1] + (i0[v][1] - lo[1])) * C::PZ + (i0[v][2] - lo[2]);
+                cell[v] = ((i0[v][0] - lo[0]) * S[1] + (i0[v][1] - lo[1])) * C::PS + (i0[v][2] - lo[2]);
                 if ((fastmask >> v) & 1) atomicAdd(&cnt[cell[v]], 1u);
             }
             __syncthreads();
@@ -406,22 +489,11 @@ struct Box {
 #pragma unroll
             for (int v = 0; v < C::VPT; ++v)
                 if ((fastmask >> v) & 1) cnt[cell[v]] = 0u;
-            // per-channel maxima of the (unmasked) sources -> fixed-point scales, one reduction for all channels
+            prof_mark(11);
+            // per-channel maxima of the channels beyond the first two (those were reduced above)
             if constexpr (!std::is_same<SrcAt, int>::value) {
                 const int nc = p.C < 8 ? p.C : 8;
-                for (int c = 0; c < nc; ++c) {
-                    float amax = 0.f;
-#pragma unroll
-                    for (int v = 0; v < C::VPT; ++v) {
-                        if (!((validmask >> v) & 1)) continue;
-                        int ox, oy, oz;
-                        sample_pos<C>(g, tid, v, ox, oy, oz);
-                        const float a = __builtin_fabsf(src_at(c, ((int64_t)ox * g.gy + oy) * g.gz + oz));
-                        amax = (a > amax || a != a) ? a : amax;                    // NaN sticks
-                    }
-                    int bits = wave_max(__float_as_int(amax));   // non-negative floats (and NaN) order like ints
-                    if ((tid & 63) == 0 && bits != 0) atomicMax(&sm.cmax[c], bits);
-                }
+                for (int c = 2; c < nc; c += 2) channel_maxima(g, sm, validmask, src_at, c, nc);
             }
             __syncthreads();
         }
@@ -430,7 +502,7 @@ struct Box {
 
     __device__ __forceinline__ int base(const Sample<C> &s) const
     {
-        return ((s.i0[0] - lo[0]) * S[1] + (s.i0[1] - lo[1])) * C::PZ + (s.i0[2] - lo[2]);
+        return ((s.i0[0] - lo[0]) * S[1] + (s.i0[1] - lo[1])) * C::PS + (s.i0[2] - lo[2]);
     }
 };
 
@@ -490,7 +562,7 @@ __device__ __forceinline__ void stage_box(const typename C::T *__restrict__ vc, 
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int r = r0 + u * RSTEP;
-            if (zin && r < rows) sm.box[r * C::PZ + z] = v[u] * sg[u];
+            if (zin && r < rows) sm.box[r * C::PS + z] = v[u] * sg[u];
         }
     }
 }
@@ -528,7 +600,7 @@ __device__ __forceinline__ void gather_box(const Smem &sm, const Box<C> &box, co
 #pragma unroll
         for (int j = 0; j <= K; ++j) {
             if (!C::ISO && j > L.k[1]) continue;
-            const float *rp = bp + (i * box.S[1] + j) * C::PZ;
+            const float *rp = bp + (i * box.S[1] + j) * C::PS;
             float rW = 0.f, rG = 0.f;
 #pragma unroll
             for (int k = 0; k <= K; ++k) {
@@ -665,7 +737,7 @@ __global__ __launch_bounds__(C::NT) void pull2_tiled(KParams p, const typename C
     const unsigned fastmask = box.build(p, L, grid, b, g, sm);
     const int nslow = sm.nslow;
     const int rows_all = box.S[0] * box.S[1];
-    int rows_pp = BOX64 / C::PZ;
+    int rows_pp = BOX64 / C::PS;
     rows_pp -= rows_pp % box.S[1];                     // whole x-rows per pass
     const int npass = (rows_all + rows_pp - 1) / rows_pp;
     const float inv_sy = 1.f / (float)box.S[1];
@@ -705,7 +777,7 @@ __global__ __launch_bounds__(C::NT) void pull2_tiled(KParams p, const typename C
 #pragma unroll
                     for (int u = 0; u < U; ++u) {
                         const int r = r0 + u * RSTEP;
-                        if (zin && r < r_n) box2[r * C::PZ + z] = make_float2(v0[u] * sg[u], v1[u] * sg[u]);
+                        if (zin && r < r_n) box2[r * C::PS + z] = make_float2(v0[u] * sg[u], v1[u] * sg[u]);
                     }
                 }
             }
@@ -718,7 +790,7 @@ __global__ __launch_bounds__(C::NT) void pull2_tiled(KParams p, const typename C
                 if (r0 + K * box.S[1] + K < 0 || r0 >= r_n) continue;
                 float wx[K + 1], wy[K + 1], wz[K + 1];
                 weights<K>(L.lin, L.k[0], s.t[0], wx); weights<K>(L.lin, L.k[1], s.t[1], wy); weights<K>(L.lin, L.k[2], s.t[2], wz);
-                const float2 *bp = box2 + r0 * C::PZ + (s.i0[2] - box.lo[2]);
+                const float2 *bp = box2 + r0 * C::PS + (s.i0[2] - box.lo[2]);
 #pragma unroll
                 for (int i = 0; i <= K; ++i) {
                     if (!C::ISO && i > L.k[0]) continue;
@@ -728,7 +800,7 @@ __global__ __launch_bounds__(C::NT) void pull2_tiled(KParams p, const typename C
 #pragma unroll
                     for (int j = 0; j <= K; ++j) {
                         if (!C::ISO && j > L.k[1]) continue;
-                        const float2 *rp = bp + (i * box.S[1] + j) * C::PZ;
+                        const float2 *rp = bp + (i * box.S[1] + j) * C::PS;
                         float q0 = 0.f, q1 = 0.f;
 #pragma unroll
                         for (int k = 0; k <= K; ++k) {
@@ -782,6 +854,34 @@ __global__ __launch_bounds__(C::NT) void pull2_tiled(KParams p, const typename C
     }
     __syncthreads();                                   // the next tile reuses the LDS tables / lists
     }
+}
+
+// floor(x + 0.5) in one instruction (v_cvt_i32_f32 truncates; rndne + cvt would be two)
+__device__ __forceinline__ int cvt_rpi(float x)
+{
+    int q;
+    asm("v_cvt_rpi_i32_f32 %0, %1" : "=v"(q) : "v"(x));
+    return q;
+}
+
+// Headroom bits of the 32-bit fixed-point scatter (see scatter_channel), or -1 when 32 bits
+// would not be precise enough for this tile (large sample density / many taps).
+__device__ __forceinline__ int headroom32(const Lattice &L, int dmax)
+{
+    const float wsum[8] = { 1.f, 2.f, 1.75f, 1.6666667f, 1.5989584f, 1.55f, 1.5110244f, 1.4793651f };
+    float cb = (float)(dmax > 0 ? dmax : 1);
+    int ntap = 1;
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        float ws = 1.f;
+#pragma unroll
+        for (int o = 0; o < 8; ++o) ws = (L.k[d] == o) ? wsum[o] : ws;
+        cb *= ws;
+        ntap *= L.k[d] + 1;
+    }
+    const int hb = ((__float_as_int(cb * 1.0001f) >> 23) & 0xff) - 126;     // cb < 2^hb
+    if (hb < 0 || hb > 20) return -1;
+    return (float)(1 << hb) * sqrtf((float)ntap) <= 1032.f ? hb : -1;
 }
 
 // ---------------------------------------------------------------------------
@@ -884,24 +984,13 @@ __device__ __forceinline__ bool scatter_channel(const KParams &p, const Lattice 
     // 2.5e-6 by requiring 2^hb <= 1032 / sqrt(n).  Strongly contracting deformations (large
     // dmax) and high orders keep the 64-bit path below.
     {
-        const float wsum[8] = { 1.f, 2.f, 1.75f, 1.6666667f, 1.5989584f, 1.55f, 1.5110244f, 1.4793651f };
-        float cb = (float)(dmax > 0 ? dmax : 1);
-        int ntap = 1;
-#pragma unroll
-        for (int d = 0; d < 3; ++d) {
-            float ws = 1.f;
-#pragma unroll
-            for (int o = 0; o < 8; ++o) ws = (L.k[d] == o) ? wsum[o] : ws;
-            cb *= ws;
-            ntap *= L.k[d] + 1;
-        }
-        const int hb = ((__float_as_int(cb * 1.0001f) >> 23) & 0xff) - 126;     // cb < 2^hb
-        const bool precise = (float)(1 << (hb < 0 ? 0 : (hb > 20 ? 20 : hb))) * sqrtf((float)ntap) <= 1032.f;
+        const int hb = headroom32(L, dmax);
+        const bool precise = hb >= 0;
         if (hb >= 0 && precise && !(p.dbg & 8)) {
             unsigned *box32 = reinterpret_cast<unsigned *>(sm.box);
             const float scale32 = __int_as_float((127 + 29 - ex - hb) << 23);
             const float inv32 = __int_as_float((127 - 29 + ex + hb) << 23);
-            const int nslots = box.S[0] * box.S[1] * C::PZ;
+            const int nslots = box.S[0] * box.S[1] * C::PS;
             // the box is all-zero on entry when the caller says so (left so by Box::build or by
             // the previous channel's flush): no zeroing pass, one barrier less
             if (!box_is_zero) {
@@ -925,13 +1014,13 @@ __device__ __forceinline__ bool scatter_channel(const KParams &p, const Lattice 
 #pragma unroll
                     for (int j = 0; j <= K; ++j) {
                         if (!C::ISO && j > L.k[1]) continue;
-                        unsigned *rp = bp + (i * box.S[1] + j) * C::PZ;
+                        unsigned *rp = bp + (i * box.S[1] + j) * C::PS;
                         const float sj = si * wy[j];
 #pragma unroll
                         for (int k = 0; k <= K; ++k) {
                             if (!C::ISO && k > L.k[2]) continue;
                             // round to nearest: truncation would bias every contribution the same way
-                            atomicAdd(rp + k, (unsigned)__float2int_rn(sj * wz[k]));    // ds_add_u32
+                            atomicAdd(rp + k, (unsigned)cvt_rpi(sj * wz[k]));           // ds_add_u32
                         }
                     }
                 }
@@ -947,9 +1036,9 @@ __device__ __forceinline__ bool scatter_channel(const KParams &p, const Lattice 
                 const int rows = box.S[0] * box.S[1];
                 for (int r = tid / C::PZ; r < rows; r += RSTEP) {
                     if (zin) {
-                        const int a = (int)box32[r * C::PZ + z];
+                        const int a = (int)box32[r * C::PS + z];
                         if (a != 0) {
-                            box32[r * C::PZ + z] = 0u;                 // leave the box zeroed for the next channel
+                            box32[r * C::PS + z] = 0u;                 // leave the box zeroed for the next channel
                             if (p.dbg & 1) continue;
                             const int x = (int)(((float)r + 0.5f) * inv_sy);
                             const int y = r - x * box.S[1];
@@ -966,14 +1055,14 @@ __device__ __forceinline__ bool scatter_channel(const KParams &p, const Lattice 
 
     // ---- passes over slabs of flattened box rows r = x * S_y + y (8 bytes per slot) -------
     const int rows_all = box.S[0] * box.S[1];
-    int rows_pp = BOX64 / C::PZ;                   // rows per pass
+    int rows_pp = BOX64 / C::PS;                   // rows per pass
     rows_pp -= (C::D == 3) ? rows_pp % box.S[1] : 0;   // 3-D: whole x-rows per pass (BOX64 / PZ >= CAPY rows always)
     const int npass = (rows_all + rows_pp - 1) / rows_pp;
     for (int ps = 0; ps < npass; ++ps) {
         const int r_lo = ps * rows_pp;
         const int r_n = (rows_all - r_lo) < rows_pp ? (rows_all - r_lo) : rows_pp;
         __syncthreads();                           // previous pass is flushed
-        for (int e = tid; e < r_n * C::PZ; e += C::NT) box64[e] = 0ull;
+        for (int e = tid; e < r_n * C::PS; e += C::NT) box64[e] = 0ull;
         __syncthreads();
 #pragma unroll
         for (int v = 0; v < C::VPT; ++v) {
@@ -985,7 +1074,7 @@ __device__ __forceinline__ bool scatter_channel(const KParams &p, const Lattice 
             if (KX > 0) weights<KX>(L.lin, L.k[0], s.t[0], wx); else wx[0] = 1.f;
             weights<K>(L.lin, L.k[1], s.t[1], wy); weights<K>(L.lin, L.k[2], s.t[2], wz);
             const float ss = src_of(s) * scale;
-            unsigned long long *bp = box64 + r0 * C::PZ + (s.i0[2] - box.lo[2]);
+            unsigned long long *bp = box64 + r0 * C::PS + (s.i0[2] - box.lo[2]);
 #pragma unroll
             for (int i = 0; i <= KX; ++i) {
                 if (!C::ISO && i > L.k[0]) continue;      // wave-uniform
@@ -997,7 +1086,7 @@ __device__ __forceinline__ bool scatter_channel(const KParams &p, const Lattice 
                 for (int j = 0; j <= K; ++j) {
                     if (!C::ISO && j > L.k[1]) continue;
                     if (C::D != 3 && (ri + j < 0 || ri + j >= r_n)) continue;
-                    unsigned long long *rp = bp + (i * box.S[1] + j) * C::PZ;
+                    unsigned long long *rp = bp + (i * box.S[1] + j) * C::PS;
                     const float sj = si * wy[j];
 #pragma unroll
                     for (int k = 0; k <= K; ++k) {
@@ -1020,7 +1109,7 @@ __device__ __forceinline__ bool scatter_channel(const KParams &p, const Lattice 
             const float inv_sy = 1.f / (float)box.S[1];
             for (int r = tid / C::PZ; r < r_n; r += RSTEP) {
                 if (zin) {
-                    const long long a = (long long)box64[r * C::PZ + z];
+                    const long long a = (long long)box64[r * C::PS + z];
                     if (a != 0) {
                         const int rg = r_lo + r;
                         const int x = (int)(((float)rg + 0.5f) * inv_sy);
@@ -1035,6 +1124,131 @@ __device__ __forceinline__ bool scatter_channel(const KParams &p, const Lattice 
         }
     }
     return false;                                      // the 64-bit slabs leave the box dirty
+}
+
+// ---------------------------------------------------------------------------
+// Scatter of a channel PAIR in the 32-bit regime: both channels' contributions to a lattice
+// point travel in ONE ds_add_u64,  W += (q1 << 32) + q0  (two's complement, exact integer
+// arithmetic: as long as each channel's true sum fits int32 -- which the headroom bound
+// guarantees -- the fields are recovered as lo = (int32) W, hi = (W - lo) >> 32).  Halves the
+// LDS atomics of the tap loop; 8-byte slots again mean slab passes.  Returns false when the
+// pair is not eligible (caller then scatters the two channels one by one).
+// ---------------------------------------------------------------------------
+template <typename C, typename SrcFn, typename SlowFn>
+__device__ __forceinline__ bool scatter_pair(const KParams &p, const Lattice &L, const float *__restrict__ grid, int64_t b,
+                                             const TileGeom &g, const Box<C> &box, unsigned fastmask, int nslow, int dmax,
+                                             int mbits0, int mbits1, float *__restrict__ vc0, float *__restrict__ vc1,
+                                             Smem &sm, SrcFn src_of, SlowFn src_slow)
+{
+    constexpr int K = C::K, KX = C::KX;
+    constexpr int BOX64 = C::BOXF / 2;
+    const int hb = headroom32(L, dmax);
+    const bool fin0 = (mbits0 & 0x7f800000) != 0x7f800000, fin1 = (mbits1 & 0x7f800000) != 0x7f800000;
+    if (hb < 0 || !fin0 || !fin1 || nslow > SLOWCAP || (p.dbg & 8) || mbits0 == 0 || mbits1 == 0) return false;
+    unsigned long long *box64 = reinterpret_cast<unsigned long long *>(sm.box);
+    const int tid = threadIdx.x;
+    // slow list: one wave per sample, lanes = taps, one global atomic per lane and channel
+    if (nslow > 0) {
+        const int wave = tid >> 6, lane = tid & 63;
+        const int NTAP = (L.k[0] + 1) * (L.k[1] + 1) * (L.k[2] + 1);
+        for (int sidx = wave; sidx < nslow; sidx += C::NT / 64) {
+            float x[3];
+            const int64_t o = slow_sample<C>(g, sm.slow[sidx], p, grid, b, x);
+            float sv0 = src_slow(0, o), sv1 = src_slow(1, o);
+            if (p.extrapolate != 1 && !coords_inb<C>(p, x)) { sv0 *= 0.f; sv1 *= 0.f; }
+            for (int t0 = 0; t0 < NTAP; t0 += 64) {
+                int off;
+                const float w = tap_weight(L, x[0], x[1], x[2], t0 + lane, &off, nullptr);
+                if (t0 + lane < NTAP) {
+                    __hip_atomic_fetch_add(vc0 + off, w * sv0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_fetch_add(vc1 + off, w * sv1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+        }
+    }
+    int ex0 = ((mbits0 >> 23) & 0xff) - 127, ex1 = ((mbits1 >> 23) & 0xff) - 127;
+    ex0 = ex0 < -90 ? -90 : ex0; ex1 = ex1 < -90 ? -90 : ex1;
+    const float sc0 = __int_as_float((127 + 29 - ex0 - hb) << 23), sc1 = __int_as_float((127 + 29 - ex1 - hb) << 23);
+    const float inv0 = __int_as_float((127 - 29 + ex0 + hb) << 23), inv1 = __int_as_float((127 - 29 + ex1 + hb) << 23);
+    prof_mark(1);
+    // 3-D: an 8-byte box does not fit LDS, so two passes -- split by the PARITY of the box row
+    // x, not into contiguous slabs: row x lives at LDS row (x >> 1) * S_y + y of pass (x & 1).
+    // Every sample then has taps in both passes (i = par, par + 2, ... with par = (x0 ^ pass) & 1),
+    // all lanes stay active and no tap needs an in-slab test.  2-D: one pass (x is degenerate).
+    constexpr int NPASS = C::D == 3 ? 2 : 1;
+    constexpr int NI = C::D == 3 ? (KX + 2) / 2 : 1;            // x taps per pass
+    constexpr bool CHECK_I = C::D == 3 && !(C::ISO && (KX & 1));  // even tap counts / runtime orders: last i may not exist
+    static_assert(C::D != 3 || ((C::CAPX + 1) / 2) * C::CAPY * C::PS <= BOX64, "half box must fit the 8-byte slots");
+    for (int ps = 0; ps < NPASS; ++ps) {
+        const int nxh = C::D == 3 ? (box.S[0] - ps + 1) >> 1 : 1;  // box rows x of this parity
+        const int r_n = nxh * box.S[1];
+        __syncthreads();
+        for (int e = tid; e < r_n * C::PS; e += C::NT) box64[e] = 0ull;
+        __syncthreads();
+        prof_mark(2);
+#pragma unroll
+        for (int v = 0; v < C::VPT; ++v) {
+            if (!((fastmask >> v) & 1) || (p.dbg & 2)) continue;
+            const Sample<C> s = load_sample<C>(p, grid, b, g, tid, v);
+            const int x0 = s.i0[0] - box.lo[0];
+            const int par = C::D == 3 ? ((x0 ^ ps) & 1) : 0;
+            float wx[KX + 2], wy[K + 1], wz[K + 1];
+            if (KX > 0) weights<KX>(L.lin, L.k[0], s.t[0], wx); else wx[0] = 1.f;
+            wx[KX + 1] = 0.f;
+            weights<K>(L.lin, L.k[1], s.t[1], wy); weights<K>(L.lin, L.k[2], s.t[2], wz);
+            const float s0 = src_of(0, s) * sc0, s1 = src_of(1, s) * sc1;
+            const int r0 = (C::D == 3 ? ((x0 + par) >> 1) * box.S[1] : 0) + (s.i0[1] - box.lo[1]);
+            unsigned long long *bp = box64 + r0 * C::PS + (s.i0[2] - box.lo[2]);
+#pragma unroll
+            for (int ii = 0; ii < NI; ++ii) {
+                if (CHECK_I && par + 2 * ii > (C::ISO ? KX : L.k[0])) continue;
+                const float wxi = C::D == 3 ? (par ? wx[2 * ii + 1 <= KX ? 2 * ii + 1 : KX + 1] : wx[2 * ii <= KX ? 2 * ii : KX + 1]) : wx[0];
+#pragma unroll
+                for (int j = 0; j <= K; ++j) {
+                    if (!C::ISO && j > L.k[1]) continue;
+                    unsigned long long *rp = bp + (ii * box.S[1] + j) * C::PS;
+                    const float wij = wxi * wy[j];
+                    const float a0 = s0 * wij, a1 = s1 * wij;
+#pragma unroll
+                    for (int k = 0; k <= K; ++k) {
+                        if (!C::ISO && k > L.k[2]) continue;
+                        const int q0 = cvt_rpi(a0 * wz[k]), q1 = cvt_rpi(a1 * wz[k]);
+                        // (q1 << 32) + sext(q0): low word q0, high word q1 + (q0 < 0 ? -1 : 0)
+                        const unsigned hi = (unsigned)(q1 + (q0 >> 31));
+                        atomicAdd(rp + k, ((unsigned long long)hi << 32) | (unsigned)q0);   // ds_add_u64, both channels
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        prof_mark(3);
+        {
+            const int z = tid % C::PZ;
+            const bool zin = z < box.S[2];
+            const int oz_ = zin ? sm.taboff[2][z] : 0;
+            const float sz = zin ? sm.tabsgn[2][z] : 0.f;
+            constexpr int RSTEP = C::NT / C::PZ;
+            const float inv_sy = 1.f / (float)box.S[1];
+            for (int r = tid / C::PZ; r < r_n; r += RSTEP) {
+                if (zin) {
+                    const long long a = (long long)box64[r * C::PS + z];
+                    if (a != 0 && !(p.dbg & 1)) {
+                        const int lo = (int)(a & 0xffffffffll);
+                        const int hi = (int)((a - (long long)lo) >> 32);
+                        const int xh = (int)(((float)r + 0.5f) * inv_sy);
+                        const int y = r - xh * box.S[1];
+                        const int x = C::D == 3 ? 2 * xh + ps : 0;
+                        const float sgn = sm.tabsgn[0][x] * sm.tabsgn[1][y] * sz;
+                        const int off = sm.taboff[0][x] + sm.taboff[1][y] + oz_;
+                        if (lo != 0) __hip_atomic_fetch_add(vc0 + off, (float)lo * inv0 * sgn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if (hi != 0) __hip_atomic_fetch_add(vc1 + off, (float)hi * inv1 * sgn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                }
+            }
+        }
+        prof_mark(4);
+    }
+    return true;
 }
 
 // ---------------------------------------------------------------------------
@@ -1055,16 +1269,30 @@ __global__ __launch_bounds__(C::NT) void push_tiled(KParams p, const typename C:
         const TileGeom g = tile_geom<C>(work % ntiles, gx, gy, gz, nty, ntz);
         Box<C> box;
         const T *ib = COUNT ? nullptr : val + b * p.val_sb;
+        prof_mark(-1);
         const unsigned fastmask = box.template build<true>(p, L, grid, b, g, sm,
             [&](int c, int64_t o) { return COUNT ? 1.f : Cvt<float, T>::ld(ib[c * p.val_sc + o]); }, clean);
         const int nslow = sm.nslow, dmax = sm.dmax;
+        prof_mark(0);
         clean = true;                                  // Box::build leaves the box zeroed
         for (int c = 0; c < p.C; ++c) {
             const T *ic = COUNT ? nullptr : val + b * p.val_sb + c * p.val_sc;
             float *vc = vol + b * p.vol_sb + c * p.vol_sc;
+            if (!COUNT && c + 1 < p.C && c < 7) {
+                // two channels per LDS atomic when the 32-bit regime applies
+                const T *ic1 = ic + p.val_sc;
+                const bool done = scatter_pair<C>(p, L, grid, b, g, box, fastmask, nslow, dmax, sm.cmax[c], sm.cmax[c + 1],
+                    vc, vc + p.vol_sc, sm,
+                    [&](int which, const Sample<C> &s) {
+                        const float v = Cvt<float, T>::ld((which ? ic1 : ic)[s.o]);
+                        return (p.extrapolate != 1 && !s.inb) ? 0.f * v : v; },
+                    [&](int which, int64_t o) { return Cvt<float, T>::ld((which ? ic1 : ic)[o]); });
+                if (done) { clean = false; ++c; continue; }
+            }
             clean = scatter_channel<C>(p, L, grid, b, g, box, fastmask, nslow, dmax, c < 8 ? sm.cmax[c] : -1, clean, vc, sm,
                 [&](const Sample<C> &s) { const float v = COUNT ? 1.f : Cvt<float, T>::ld(ic[s.o]); return (p.extrapolate != 1 && !s.inb) ? 0.f * v : v; },   // nd.py:201-203
                 [&](int64_t o) { return COUNT ? 1.f : Cvt<float, T>::ld(ic[o]); });
+            prof_mark(8);
         }
         __syncthreads();                               // the next tile reuses the LDS tables / lists
     }
@@ -1500,3 +1728,15 @@ int IP_SYM(try_fast_pushbwd_, IP_TSFX)(const interpol_problem *p, const KParams 
 }
 
 } // namespace ip
+
+#ifdef IP_PROF
+#define IP_PROF_NAME2(s) interpol_debug_prof_##s
+#define IP_PROF_NAME(s) IP_PROF_NAME2(s)
+extern "C" __attribute__((visibility("default"))) int IP_PROF_NAME(IP_TSFX)(unsigned long long *out, int reset)
+{
+    unsigned long long z[16] = { 0 };
+    if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(ip::tiled::g_prof), sizeof z) != hipSuccess) return -1;
+    if (reset && hipMemcpyToSymbol(HIP_SYMBOL(ip::tiled::g_prof), z, sizeof z) != hipSuccess) return -1;
+    return 0;
+}
+#endif
