@@ -8,7 +8,7 @@ import torch, interpol
 from interpol import _hip
 import bench
 
-NAMES = ["build", "pair:slow", "pair:zero", "pair:taps", "pair:flush", "-", "-", "-", "single-channel path", "build:load+minmax", "build:tables+classify", "build:density"]
+NAMES = ["build", "pair:slow", "pair:zero", "pair:taps", "pair:flush", "pull:stage", "pull:gather", "pull:store+slow", "single-channel path", "build:load+minmax", "build:tables+classify", "build:density", "build:issue coord loads", "build:wait coord loads", "build:channel maxima"]
 dev = torch.device("cuda", 0)
 sigma = float(sys.argv[1]) if len(sys.argv) > 1 else 2.0
 inp, grid = bench.make_inputs(4, 2, 256, sigma, dev, 1234)
@@ -16,10 +16,14 @@ L = _hip.lib()
 fn = L.interpol_debug_prof_f32
 fn.argtypes = [ctypes.c_void_p, ctypes.c_int]
 buf = (ctypes.c_ulonglong * 16)()
-_hip.scatter("push", inp, grid, None, [3] * 3, [3] * 3, 1); torch.cuda.synchronize()
-fn(None, 1)
-_hip.scatter("push", inp, grid, None, [3] * 3, [3] * 3, 1); torch.cuda.synchronize()
-fn(buf, 1)
-tot = sum(buf)
-print(json.dumps({"sigma": sigma, "total_cycles_per_block_sum": tot,
+def run(op):
+    if op == "push":
+        _hip.scatter("push", inp, grid, None, [3] * 3, [3] * 3, 1)
+    else:
+        _hip.gather("pull", inp, grid, [3] * 3, [3] * 3, 1)
+    torch.cuda.synchronize()
+for op in ("push", "pull"):
+  run(op); fn(None, 1); run(op); fn(buf, 1)
+  tot = sum(buf)
+  print(op, json.dumps({"sigma": sigma, "total_cycles_per_block_sum": tot,
                   "share": {NAMES[i] if i < len(NAMES) else str(i): round(buf[i] / tot, 4) for i in range(16) if buf[i]}}))

@@ -43,6 +43,7 @@ namespace ip {
 namespace tiled {
 
 constexpr int SLOWCAP = 512;                   // out-of-box samples handled tap-parallel per tile
+constexpr int ROWN = 17 * 33;                  // box rows (x, y) resident in one 8-byte pass
 constexpr int TABN = 72;                       // max box extent along one dim
 
 // Tile configuration.  Kernel dims are always (x, y, z); a 2-D problem (D = 2) uses
@@ -104,22 +105,41 @@ struct Smem {
     int   dmax;                // max number of fast samples sharing one first-tap cell (scatter kernels)
     int   cmax[8];             // per-channel max |source| of the tile (float bits), first 8 channels
     unsigned short slow[SLOWCAP];
+    int2  rowtab[ROWN];        // per resident box row (x, y): { taboff_x + taboff_y, bits of tabsgn_x * tabsgn_y }
     float box[1];              // really C::BOXF floats (dynamic LDS)
 };
 template <typename C> constexpr size_t smem_bytes() { return sizeof(Smem) + sizeof(float) * (C::BOXF - 1); }
 
+// Wave-wide min / max in registers: four row_shr steps inside the 16-lane rows, then
+// row_bcast:15 / row_bcast:31 across rows (GFX9 DPP), result read from lane 63.  min and max
+// are idempotent, so lanes that have no DPP source simply combine with themselves.  (The
+// __shfl_xor butterfly costs six dependent ds_bpermute round trips per value.)
+// (`old` = the identity of the operation: lanes without a DPP source keep their value, and
+// the compiler can fuse the move into v_min_i32_dpp / v_max_i32_dpp.)
+#define IP_DPP(id, v, ctrl) __builtin_amdgcn_update_dpp((int)(id), (v), (ctrl), 0xf, 0xf, false)
 __device__ __forceinline__ int wave_min(int v)
 {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { int t = __shfl_xor(v, o); v = t < v ? t : v; }
-    return v;
+    int t;
+    t = IP_DPP(0x7fffffff, v, 0x111); v = t < v ? t : v;
+    t = IP_DPP(0x7fffffff, v, 0x112); v = t < v ? t : v;
+    t = IP_DPP(0x7fffffff, v, 0x114); v = t < v ? t : v;
+    t = IP_DPP(0x7fffffff, v, 0x118); v = t < v ? t : v;
+    t = IP_DPP(0x7fffffff, v, 0x142); v = t < v ? t : v;
+    t = IP_DPP(0x7fffffff, v, 0x143); v = t < v ? t : v;
+    return __builtin_amdgcn_readlane(v, 63);
 }
 __device__ __forceinline__ int wave_max(int v)
 {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { int t = __shfl_xor(v, o); v = t > v ? t : v; }
-    return v;
+    int t;
+    t = IP_DPP(0x80000000, v, 0x111); v = t > v ? t : v;
+    t = IP_DPP(0x80000000, v, 0x112); v = t > v ? t : v;
+    t = IP_DPP(0x80000000, v, 0x114); v = t > v ? t : v;
+    t = IP_DPP(0x80000000, v, 0x118); v = t > v ? t : v;
+    t = IP_DPP(0x80000000, v, 0x142); v = t > v ? t : v;
+    t = IP_DPP(0x80000000, v, 0x143); v = t > v ? t : v;
+    return __builtin_amdgcn_readlane(v, 63);
 }
+#undef IP_DPP
 __device__ __forceinline__ float wave_sum(float v)
 {
 #pragma unroll
@@ -436,12 +456,18 @@ struct Box {
             lo[d] = l; S[d] = sz;
         }
         // boundary tables: box slot -> wrapped lattice offset and sign (bounds.py:30-89)
-#pragma unroll
-        for (int d = 0; d < 3; ++d) {
-            if (tid < S[d]) {
-                const long long pk = wrap_outofline(L.bound[d], lo[d] + tid, L.n[d]);
-                sm.taboff[d][tid] = (int)(pk & 0xffffffffll) * L.ss[d];
-                sm.tabsgn[d][tid] = (float)(int)(pk >> 32);
+        // (one pair of waves per dim, so that the three out-of-line wraps run side by side)
+        {
+            const int d = tid >> 7, slot = tid & 127;
+            const int Sd = d == 0 ? S[0] : d == 1 ? S[1] : S[2];
+            if (d < 3 && slot < Sd) {
+                const int bd = d == 0 ? L.bound[0] : d == 1 ? L.bound[1] : L.bound[2];
+                const int ld = d == 0 ? lo[0] : d == 1 ? lo[1] : lo[2];
+                const int nd = d == 0 ? L.n[0] : d == 1 ? L.n[1] : L.n[2];
+                const int sd = d == 0 ? L.ss[0] : d == 1 ? L.ss[1] : L.ss[2];
+                const long long pk = wrap_outofline(bd, ld + slot, nd);
+                sm.taboff[d][slot] = (int)(pk & 0xffffffffll) * sd;
+                sm.tabsgn[d][slot] = (float)(int)(pk >> 32);
             }
         }
         // classification
@@ -734,13 +760,16 @@ __global__ __launch_bounds__(C::NT) void pull2_tiled(KParams p, const typename C
     const int64_t b = work / ntiles;
     const TileGeom g = tile_geom<C>(work % ntiles, gx, gy, gz, nty, ntz);
     Box<C> box;
+    prof_mark(-1);
     const unsigned fastmask = box.build(p, L, grid, b, g, sm);
     const int nslow = sm.nslow;
-    const int rows_all = box.S[0] * box.S[1];
-    int rows_pp = BOX64 / C::PS;
-    rows_pp -= rows_pp % box.S[1];                     // whole x-rows per pass
-    const int npass = (rows_all + rows_pp - 1) / rows_pp;
-    const float inv_sy = 1.f / (float)box.S[1];
+    prof_mark(0);
+    // Two passes per channel pair, split by the PARITY of the box row x (see scatter_pair):
+    // LDS row r = xh * S_y + y of pass ps holds box row x = 2 xh + ps.  Every sample reads taps
+    // in both passes (i = par, par + 2, ... with par = (x0 ^ ps) & 1): no lane idles.
+    // A box small enough for one pass (smooth deformations: S ~ tile + K) is staged whole.
+    static_assert(((C::CAPX + 1) / 2) * C::CAPY * C::PS <= BOX64, "half box must fit the 8-byte slots");
+    const int xmul = box.S[0] * box.S[1] * C::PS <= BOX64 ? 1 : 2;
 
     for (int c = 0; c < p.C; c += 2) {
         const T *vc0 = vol + b * p.vol_sb + c * p.vol_sc;
@@ -750,11 +779,17 @@ __global__ __launch_bounds__(C::NT) void pull2_tiled(KParams p, const typename C
         float acc[C::VPT][2];
 #pragma unroll
         for (int v = 0; v < C::VPT; ++v) { acc[v][0] = 0.f; acc[v][1] = 0.f; }
-        for (int ps = 0; ps < npass; ++ps) {
-            const int r_lo = ps * rows_pp;
-            const int r_n = (rows_all - r_lo) < rows_pp ? (rows_all - r_lo) : rows_pp;
-            __syncthreads();                           // previous slab's readers are done
-            {   // stage the slab, both channels (unrolled for memory-level parallelism)
+        for (int ps = 0; ps < xmul; ++ps) {
+            const int nxh = xmul == 1 ? box.S[0] : (box.S[0] - ps + 1) >> 1;
+            const int r_n = nxh * box.S[1];
+            __syncthreads();                           // previous pass's readers are done
+            for (int r = tid; r < r_n; r += C::NT) {
+                const int xh = r / box.S[1], y = r - xh * box.S[1];
+                const int x = xmul * xh + ps;
+                sm.rowtab[r] = make_int2(sm.taboff[0][x] + sm.taboff[1][y], __float_as_int(sm.tabsgn[0][x] * sm.tabsgn[1][y]));
+            }
+            __syncthreads();
+            {   // stage the rows of this parity, both channels (unrolled for memory-level parallelism)
                 constexpr int U = 4, RSTEP = C::NT / C::PZ;
                 const int z = tid % C::PZ;
                 const bool zin = z < box.S[2];
@@ -766,11 +801,9 @@ __global__ __launch_bounds__(C::NT) void pull2_tiled(KParams p, const typename C
                     for (int u = 0; u < U; ++u) {
                         const int r = r0 + u * RSTEP;
                         const bool on = zin && r < r_n;
-                        const int rg = r_lo + r;
-                        const int x = (int)(((float)rg + 0.5f) * inv_sy);
-                        const int y = rg - x * box.S[1];
-                        const int off = on ? sm.taboff[0][x] + sm.taboff[1][y] + oz : 0;
-                        sg[u] = on ? sm.tabsgn[0][x] * sm.tabsgn[1][y] * sz : 0.f;
+                        const int2 rt = sm.rowtab[r < r_n ? r : 0];
+                        const int off = on ? rt.x + oz : 0;
+                        sg[u] = on ? __int_as_float(rt.y) * sz : 0.f;
                         v0[u] = on ? Cvt<float, T>::ld(vc0[off]) : 0.f;
                         v1[u] = on ? Cvt<float, T>::ld(vc1[off]) : 0.f;
                     }
@@ -782,25 +815,29 @@ __global__ __launch_bounds__(C::NT) void pull2_tiled(KParams p, const typename C
                 }
             }
             __syncthreads();
+            prof_mark(5);
 #pragma unroll
             for (int v = 0; v < C::VPT; ++v) {
                 if (!((fastmask >> v) & 1)) continue;
                 const Sample<C> s = load_sample<C>(p, grid, b, g, tid, v);
-                const int r0 = (s.i0[0] - box.lo[0]) * box.S[1] + (s.i0[1] - box.lo[1]) - r_lo;
-                if (r0 + K * box.S[1] + K < 0 || r0 >= r_n) continue;
-                float wx[K + 1], wy[K + 1], wz[K + 1];
+                const int x0 = s.i0[0] - box.lo[0];
+                const int par = xmul == 1 ? 0 : (x0 ^ ps) & 1;
+                float wx[K + 2], wy[K + 1], wz[K + 1];
                 weights<K>(L.lin, L.k[0], s.t[0], wx); weights<K>(L.lin, L.k[1], s.t[1], wy); weights<K>(L.lin, L.k[2], s.t[2], wz);
+                wx[K + 1] = 0.f;
+                const int r0 = (xmul == 1 ? x0 : (x0 + par) >> 1) * box.S[1] + (s.i0[1] - box.lo[1]);
                 const float2 *bp = box2 + r0 * C::PS + (s.i0[2] - box.lo[2]);
 #pragma unroll
-                for (int i = 0; i <= K; ++i) {
-                    if (!C::ISO && i > L.k[0]) continue;
-                    const int ri = r0 + i * box.S[1];
-                    if (ri < 0 || ri >= r_n) continue;     // this x-row lives in another slab
+                for (int ii = 0; ii <= K; ++ii) {
+                    // tap i = par + xmul * ii of this sample lives in LDS row r0 + ii * S_y
+                    if (par + xmul * ii > (C::ISO ? K : L.k[0])) continue;     // uniform but for the last i of even tap counts
+                    const float w2 = par ? wx[2 * ii + 1 <= K ? 2 * ii + 1 : K + 1] : wx[2 * ii <= K ? 2 * ii : K + 1];
+                    const float wxi = xmul == 1 ? wx[ii] : w2;
                     float p0 = 0.f, p1 = 0.f;
 #pragma unroll
                     for (int j = 0; j <= K; ++j) {
                         if (!C::ISO && j > L.k[1]) continue;
-                        const float2 *rp = bp + (i * box.S[1] + j) * C::PS;
+                        const float2 *rp = bp + (ii * box.S[1] + j) * C::PS;
                         float q0 = 0.f, q1 = 0.f;
 #pragma unroll
                         for (int k = 0; k <= K; ++k) {
@@ -812,10 +849,11 @@ __global__ __launch_bounds__(C::NT) void pull2_tiled(KParams p, const typename C
                         p0 = __builtin_fmaf(wy[j], q0, p0);
                         p1 = __builtin_fmaf(wy[j], q1, p1);
                     }
-                    acc[v][0] = __builtin_fmaf(wx[i], p0, acc[v][0]);
-                    acc[v][1] = __builtin_fmaf(wx[i], p1, acc[v][1]);
+                    acc[v][0] = __builtin_fmaf(wxi, p0, acc[v][0]);
+                    acc[v][1] = __builtin_fmaf(wxi, p1, acc[v][1]);
                 }
             }
+            prof_mark(6);
         }
         // outputs of the fast samples
 #pragma unroll
@@ -851,6 +889,7 @@ __global__ __launch_bounds__(C::NT) void pull2_tiled(KParams p, const typename C
                 if (lane == 0) { oc0[o] = Cvt<float, T>::st(a0 * m); oc1[o] = Cvt<float, T>::st(a1 * m); }
             }
         }
+        prof_mark(7);
     }
     __syncthreads();                                   // the next tile reuses the LDS tables / lists
     }
@@ -1137,7 +1176,7 @@ __device__ __forceinline__ bool scatter_channel(const KParams &p, const Lattice 
 template <typename C, typename SrcFn, typename SlowFn>
 __device__ __forceinline__ bool scatter_pair(const KParams &p, const Lattice &L, const float *__restrict__ grid, int64_t b,
                                              const TileGeom &g, const Box<C> &box, unsigned fastmask, int nslow, int dmax,
-                                             int mbits0, int mbits1, float *__restrict__ vc0, float *__restrict__ vc1,
+                                             int mbits0, int mbits1, bool box_is_zero, float *__restrict__ vc0, float *__restrict__ vc1,
                                              Smem &sm, SrcFn src_of, SlowFn src_slow)
 {
     constexpr int K = C::K, KX = C::KX;
@@ -1175,34 +1214,43 @@ __device__ __forceinline__ bool scatter_pair(const KParams &p, const Lattice &L,
     // x, not into contiguous slabs: row x lives at LDS row (x >> 1) * S_y + y of pass (x & 1).
     // Every sample then has taps in both passes (i = par, par + 2, ... with par = (x0 ^ pass) & 1),
     // all lanes stay active and no tap needs an in-slab test.  2-D: one pass (x is degenerate).
-    constexpr int NPASS = C::D == 3 ? 2 : 1;
-    constexpr int NI = C::D == 3 ? (KX + 2) / 2 : 1;            // x taps per pass
-    constexpr bool CHECK_I = C::D == 3 && !(C::ISO && (KX & 1));  // even tap counts / runtime orders: last i may not exist
+    // A box small enough for one pass (smooth deformations: S ~ tile + K) is scattered whole.
     static_assert(C::D != 3 || ((C::CAPX + 1) / 2) * C::CAPY * C::PS <= BOX64, "half box must fit the 8-byte slots");
-    for (int ps = 0; ps < NPASS; ++ps) {
-        const int nxh = C::D == 3 ? (box.S[0] - ps + 1) >> 1 : 1;  // box rows x of this parity
+    const int xmul = box.S[0] * box.S[1] * C::PS <= BOX64 ? 1 : 2;
+    for (int ps = 0; ps < xmul; ++ps) {
+        const int nxh = xmul == 1 ? box.S[0] : (box.S[0] - ps + 1) >> 1;  // box rows x of this pass
         const int r_n = nxh * box.S[1];
-        __syncthreads();
-        for (int e = tid; e < r_n * C::PS; e += C::NT) box64[e] = 0ull;
-        __syncthreads();
+        __syncthreads();                           // previous pass flushed (and its slots re-zeroed)
+        if (ps == 0 && !box_is_zero) {
+            for (int e = tid; e < BOX64; e += C::NT) box64[e] = 0ull;
+        }
+        // row table of this pass: LDS row r = xh * S_y + y  <->  box row x = 2 xh + ps
+        for (int r = tid; r < r_n; r += C::NT) {
+            const int xh = r / box.S[1], y = r - xh * box.S[1];
+            const int x = xmul * xh + ps;
+            sm.rowtab[r] = make_int2(sm.taboff[0][x] + sm.taboff[1][y], __float_as_int(sm.tabsgn[0][x] * sm.tabsgn[1][y]));
+        }
+        if (ps == 0 && !box_is_zero) __syncthreads();
         prof_mark(2);
 #pragma unroll
         for (int v = 0; v < C::VPT; ++v) {
             if (!((fastmask >> v) & 1) || (p.dbg & 2)) continue;
             const Sample<C> s = load_sample<C>(p, grid, b, g, tid, v);
             const int x0 = s.i0[0] - box.lo[0];
-            const int par = C::D == 3 ? ((x0 ^ ps) & 1) : 0;
+            const int par = xmul == 1 ? 0 : (x0 ^ ps) & 1;
             float wx[KX + 2], wy[K + 1], wz[K + 1];
             if (KX > 0) weights<KX>(L.lin, L.k[0], s.t[0], wx); else wx[0] = 1.f;
             wx[KX + 1] = 0.f;
             weights<K>(L.lin, L.k[1], s.t[1], wy); weights<K>(L.lin, L.k[2], s.t[2], wz);
             const float s0 = src_of(0, s) * sc0, s1 = src_of(1, s) * sc1;
-            const int r0 = (C::D == 3 ? ((x0 + par) >> 1) * box.S[1] : 0) + (s.i0[1] - box.lo[1]);
+            const int r0 = (xmul == 1 ? x0 : (x0 + par) >> 1) * box.S[1] + (s.i0[1] - box.lo[1]);
             unsigned long long *bp = box64 + r0 * C::PS + (s.i0[2] - box.lo[2]);
 #pragma unroll
-            for (int ii = 0; ii < NI; ++ii) {
-                if (CHECK_I && par + 2 * ii > (C::ISO ? KX : L.k[0])) continue;
-                const float wxi = C::D == 3 ? (par ? wx[2 * ii + 1 <= KX ? 2 * ii + 1 : KX + 1] : wx[2 * ii <= KX ? 2 * ii : KX + 1]) : wx[0];
+            for (int ii = 0; ii <= KX; ++ii) {
+                // tap i = par + xmul * ii of this sample lives in LDS row r0 + ii * S_y
+                if (par + xmul * ii > (C::ISO ? KX : L.k[0])) continue;     // uniform but for the last i of even tap counts
+                const float w2 = par ? wx[2 * ii + 1 <= KX ? 2 * ii + 1 : KX + 1] : wx[2 * ii <= KX ? 2 * ii : KX + 1];
+                const float wxi = xmul == 1 ? wx[ii] : w2;
 #pragma unroll
                 for (int j = 0; j <= K; ++j) {
                     if (!C::ISO && j > L.k[1]) continue;
@@ -1223,25 +1271,27 @@ __device__ __forceinline__ bool scatter_pair(const KParams &p, const Lattice &L,
         __syncthreads();
         prof_mark(3);
         {
+            // flush: fixed point -> float, slot sign, one coalesced global atomic per touched slot
+            // and channel; touched slots are re-zeroed on the way (the box stays clean)
             const int z = tid % C::PZ;
             const bool zin = z < box.S[2];
             const int oz_ = zin ? sm.taboff[2][z] : 0;
             const float sz = zin ? sm.tabsgn[2][z] : 0.f;
+            const float f0 = inv0 * sz, f1 = inv1 * sz;
             constexpr int RSTEP = C::NT / C::PZ;
-            const float inv_sy = 1.f / (float)box.S[1];
-            for (int r = tid / C::PZ; r < r_n; r += RSTEP) {
-                if (zin) {
+            if (zin) {
+                for (int r = tid / C::PZ; r < r_n; r += RSTEP) {
                     const long long a = (long long)box64[r * C::PS + z];
-                    if (a != 0 && !(p.dbg & 1)) {
+                    if (a != 0) {
+                        box64[r * C::PS + z] = 0ull;
+                        if (p.dbg & 1) continue;
+                        const int2 rt = sm.rowtab[r];
                         const int lo = (int)(a & 0xffffffffll);
                         const int hi = (int)((a - (long long)lo) >> 32);
-                        const int xh = (int)(((float)r + 0.5f) * inv_sy);
-                        const int y = r - xh * box.S[1];
-                        const int x = C::D == 3 ? 2 * xh + ps : 0;
-                        const float sgn = sm.tabsgn[0][x] * sm.tabsgn[1][y] * sz;
-                        const int off = sm.taboff[0][x] + sm.taboff[1][y] + oz_;
-                        if (lo != 0) __hip_atomic_fetch_add(vc0 + off, (float)lo * inv0 * sgn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        if (hi != 0) __hip_atomic_fetch_add(vc1 + off, (float)hi * inv1 * sgn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        const float sg = __int_as_float(rt.y);
+                        const int off = rt.x + oz_;
+                        if (lo != 0) __hip_atomic_fetch_add(vc0 + off, (float)lo * (f0 * sg), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if (hi != 0) __hip_atomic_fetch_add(vc1 + off, (float)hi * (f1 * sg), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     }
                 }
             }
@@ -1281,13 +1331,13 @@ __global__ __launch_bounds__(C::NT) void push_tiled(KParams p, const typename C:
             if (!COUNT && c + 1 < p.C && c < 7) {
                 // two channels per LDS atomic when the 32-bit regime applies
                 const T *ic1 = ic + p.val_sc;
-                const bool done = scatter_pair<C>(p, L, grid, b, g, box, fastmask, nslow, dmax, sm.cmax[c], sm.cmax[c + 1],
+                const bool done = scatter_pair<C>(p, L, grid, b, g, box, fastmask, nslow, dmax, sm.cmax[c], sm.cmax[c + 1], clean,
                     vc, vc + p.vol_sc, sm,
                     [&](int which, const Sample<C> &s) {
                         const float v = Cvt<float, T>::ld((which ? ic1 : ic)[s.o]);
                         return (p.extrapolate != 1 && !s.inb) ? 0.f * v : v; },
                     [&](int which, int64_t o) { return Cvt<float, T>::ld((which ? ic1 : ic)[o]); });
-                if (done) { clean = false; ++c; continue; }
+                if (done) { clean = true; ++c; continue; }          // the pair flush leaves the box zeroed
             }
             clean = scatter_channel<C>(p, L, grid, b, g, box, fastmask, nslow, dmax, c < 8 ? sm.cmax[c] : -1, clean, vc, sm,
                 [&](const Sample<C> &s) { const float v = COUNT ? 1.f : Cvt<float, T>::ld(ic[s.o]); return (p.extrapolate != 1 && !s.inb) ? 0.f * v : v; },   // nd.py:201-203
