@@ -529,7 +529,11 @@ def test_tiled_scatter_64bit_accumulator_path(order, sigma):
     _same(forced, slow, 1e-5, ("push64", order, sigma))
     squeezed = (grid - 20.0) * 0.05 + 20.0            # 20x contraction: hundreds of samples per voxel
     fast = _hip.scatter("push", src, squeezed, list(tshape), b, o, 1)
+    # reference in double: with ~1e5 float atomics per voxel the fp32 generic kernel itself
+    # wanders by ~1e-5 from run to run (atomic order), the fixed-point tiles do not
+    ref = _hip.scatter("push", src.double(), squeezed.double(), list(tshape), b, o, 1, flags=_hip.FLAG_NO_FASTPATH).float()
+    _same(fast, ref, 1e-5, ("push contracted", order, sigma))
     slow = _hip.scatter("push", src, squeezed, list(tshape), b, o, 1, flags=_hip.FLAG_NO_FASTPATH)
-    _same(fast, slow, 1e-5, ("push contracted", order, sigma))
+    _same(slow, ref, 5e-5, ("push contracted, generic fp32", order, sigma))
     cnt = _hip.scatter("count", None, squeezed, list(tshape), b, o, 1)
     assert abs(float(cnt.sum()) - 2 * np.prod(sshape)) < 1e-3 * 2 * np.prod(sshape)

@@ -294,6 +294,31 @@ __device__ __noinline__ float tap_weight(Lattice L, float gx_, float gy_, float 
 }
 
 // ---------------------------------------------------------------------------
+// Persistent blocks: which tiles does this block process?  Workgroups are dealt round-robin
+// to the 8 XCDs, each with its own L2.  Each XCD therefore takes one CONTIGUOUS eighth of the
+// tile sequence (z-fastest tile order) and its blocks walk it side by side: the tiles in flight
+// on one XCD are neighbours and share their halos in that XCD's L2, instead of every XCD
+// fetching every halo.  (Measured on cfg2: the gathers gain on smooth deformations, 1.57 ->
+// 1.49 ms; the scatters LOSE, 2.31 -> 2.51 ms -- neighbouring tiles then flush their halos
+// into the same L2 lines at the same time -- so the scatter kernels keep the strided order.)
+// ---------------------------------------------------------------------------
+struct WorkRange {
+    int first, end, step;
+    __device__ __forceinline__ explicit WorkRange(int total, bool by_xcd = true)
+    {
+        const int G = (int)gridDim.x, bid = (int)blockIdx.x;
+        if (by_xcd && (G & 7) == 0 && total >= 8) {
+            const int per = (total + 7) >> 3, xcd = bid & 7;
+            first = xcd * per + (bid >> 3);
+            end = (xcd + 1) * per < total ? (xcd + 1) * per : total;
+            step = G >> 3;
+        } else {
+            first = bid; end = total; step = G;
+        }
+    }
+};
+
+// ---------------------------------------------------------------------------
 // Samples, tile geometry, bounding box.
 // ---------------------------------------------------------------------------
 template <typename C>
@@ -664,7 +689,8 @@ __global__ __launch_bounds__(C::NT) void gather_tiled(KParams p, const typename 
     const int tid = threadIdx.x;
     const Lattice L = make_lattice<C>(p, (int)sizeof(T));
     // persistent blocks: one per CU, striding over the (tile, batch item) work list
-    for (int work = blockIdx.x; work < ntiles * nbatch; work += gridDim.x) {
+    const WorkRange wr(ntiles * nbatch);
+    for (int work = wr.first; work < wr.end; work += wr.step) {
     const int64_t b = work / ntiles;
     const TileGeom g = tile_geom<C>(work % ntiles, gx, gy, gz, nty, ntz);
 
@@ -756,7 +782,8 @@ __global__ __launch_bounds__(C::NT) void pull2_tiled(KParams p, const typename C
     float2 *box2 = reinterpret_cast<float2 *>(sm.box);
     const int tid = threadIdx.x;
     const Lattice L = make_lattice<C>(p, (int)sizeof(T));
-    for (int work = blockIdx.x; work < ntiles * nbatch; work += gridDim.x) {
+    const WorkRange wr(ntiles * nbatch);
+    for (int work = wr.first; work < wr.end; work += wr.step) {
     const int64_t b = work / ntiles;
     const TileGeom g = tile_geom<C>(work % ntiles, gx, gy, gz, nty, ntz);
     Box<C> box;
@@ -1314,7 +1341,8 @@ __global__ __launch_bounds__(C::NT) void push_tiled(KParams p, const typename C:
     using T = typename C::T;
     const Lattice L = make_lattice<C>(p, 4);         // the target (or its fp32 scratch) is float
     bool clean = false;                                // is the LDS box all-zero?  (block-uniform)
-    for (int work = blockIdx.x; work < ntiles * nbatch; work += gridDim.x) {
+    const WorkRange wr(ntiles * nbatch, false);
+    for (int work = wr.first; work < wr.end; work += wr.step) {
         const int64_t b = work / ntiles;
         const TileGeom g = tile_geom<C>(work % ntiles, gx, gy, gz, nty, ntz);
         Box<C> box;
@@ -1365,7 +1393,8 @@ __global__ __launch_bounds__(C::NT) void pullbwd_tiled(KParams p, const typename
     using T = typename C::T;
     const int tid = threadIdx.x;
     const Lattice L = make_lattice<C>(p, (int)sizeof(T));    // vol strides; gvol (float) shares the element offsets
-    for (int work = blockIdx.x; work < ntiles * nbatch; work += gridDim.x) {
+    const WorkRange wr(ntiles * nbatch, false);
+    for (int work = wr.first; work < wr.end; work += wr.step) {
     const int64_t b = work / ntiles;
     const TileGeom g = tile_geom<C>(work % ntiles, gx, gy, gz, nty, ntz);
     Box<C> box;
@@ -1472,7 +1501,8 @@ __global__ __launch_bounds__(C::NT) void pushbwd_tiled(KParams p, const typename
     using T = typename C::T;
     const int tid = threadIdx.x;
     const Lattice L = make_lattice<C>(p, (int)sizeof(T));
-    for (int work = blockIdx.x; work < ntiles * nbatch; work += gridDim.x) {
+    const WorkRange wr(ntiles * nbatch);
+    for (int work = wr.first; work < wr.end; work += wr.step) {
     const int64_t b = work / ntiles;
     const TileGeom g = tile_geom<C>(work % ntiles, gx, gy, gz, nty, ntz);
     Box<C> box;
