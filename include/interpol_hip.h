@@ -98,6 +98,13 @@ typedef struct interpol_problem {
 #define INTERPOL_FLAG_NO_FASTPATH   1   /* force the generic kernels (testing)           */
 #define INTERPOL_FLAG_ACCUMULATE    2   /* push/count/pushgrad: do not zero the target    */
 #define INTERPOL_FLAG_FORCE_TILED   4   /* take the LDS-tiled kernel wherever one exists (testing) */
+/* Separable (tensor-product) coordinates, the grids of resize / restrict (resize.py:96-123,
+ * restrict.py:88-117: `stack(meshgrid_ij(*lin), -1)`): `grid` points to the D coordinate vectors
+ * lin_0 (grid_shape[0] values), lin_1, lin_2 stored back to back (grid_dtype); sample
+ * (o_0, o_1, o_2) has coordinates (lin_0[o_0], lin_1[o_1], lin_2[o_2]) for every batch item.
+ * grid_stride is ignored; no (B,*out,D) grid is read (-12 B/sample in 3-D).  The backward
+ * entry points accept it only when grad_grid is not requested (else INTERPOL_E_STRIDE). */
+#define INTERPOL_FLAG_SEPARABLE_GRID 8
 
 /* --- forward operators -------------------------------------------------------
  * interpol_pull      replaces pushpull.grid_pull      (interpol/pushpull.py:35-66;

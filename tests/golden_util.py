@@ -90,3 +90,14 @@ def fp32_tol(case_or_order):
     order = order if isinstance(order, (list, tuple)) else [order]
     hi = max(order) >= 6
     return (1e-5, 5e-5) if hi else (1e-5, 1e-5)
+
+
+def resize_cases():
+    """resize / restrict golden cases (tests/golden/make_golden_resize.py): list of dicts with
+    fn, kwargs, inp (float32), out64 (reference on the float64 input), out32 (on the float32 input)."""
+    if "resize" not in _CACHE:
+        with open(os.path.join(HERE, "golden_resize.json")) as f:
+            man = json.load(f)
+        npz = np.load(os.path.join(HERE, "golden_resize.npz"))
+        _CACHE["resize"] = [dict(c, inp=npz[c["inp"]], out64=npz[c["out64"]], out32=npz[c["out32"]]) for c in man["cases"]]
+    return _CACHE["resize"]

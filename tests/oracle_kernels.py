@@ -7,6 +7,11 @@ import torch
 from oracle import oracle
 
 
+def _g(grid):
+    """dense tensor of a grid argument (a SeparableGrid lattice is expanded for the oracle)"""
+    return grid.dense() if hasattr(grid, 'dense') else grid.detach()
+
+
 def _t(x, like):
     return torch.as_tensor(x).to(like.dtype)
 
@@ -14,51 +19,51 @@ def _t(x, like):
 class OracleKernels:
     @staticmethod
     def pull(inp, grid, bound, order, extrapolate):
-        return oracle.grid_pull(inp.detach(), grid.detach(), bound, order, extrapolate)
+        return oracle.grid_pull(inp.detach(), _g(grid), bound, order, extrapolate)
 
     @staticmethod
     def grad(inp, grid, bound, order, extrapolate):
-        return oracle.grid_grad(inp.detach(), grid.detach(), bound, order, extrapolate)
+        return oracle.grid_grad(inp.detach(), _g(grid), bound, order, extrapolate)
 
     @staticmethod
     def hess(inp, grid, bound, order, extrapolate):
-        return oracle.grid_hess(inp.detach(), grid.detach(), bound, order, extrapolate)
+        return oracle.grid_hess(inp.detach(), _g(grid), bound, order, extrapolate)
 
     @staticmethod
     def push(inp, grid, shape, bound, order, extrapolate):
-        return oracle.grid_push(inp.detach(), grid.detach(), shape, bound, order, extrapolate)
+        return oracle.grid_push(inp.detach(), _g(grid), shape, bound, order, extrapolate)
 
     @staticmethod
     def count(grid, shape, bound, order, extrapolate):
-        return oracle.grid_count(grid.detach(), shape, bound, order, extrapolate)
+        return oracle.grid_count(_g(grid), shape, bound, order, extrapolate)
 
     @staticmethod
     def pushgrad(inp, grid, shape, bound, order, extrapolate):
-        return oracle.grid_pushgrad(inp.detach(), grid.detach(), shape, bound, order, extrapolate)
+        return oracle.grid_pushgrad(inp.detach(), _g(grid), shape, bound, order, extrapolate)
 
     @staticmethod
     def push_shared_(out, inp, grid, bound, order, extrapolate):
         shape = list(out.shape[2:])
         if inp is None:
-            r = oracle.grid_count(grid.detach(), shape, bound, order, extrapolate)
+            r = oracle.grid_count(_g(grid), shape, bound, order, extrapolate)
         else:
-            r = oracle.grid_push(inp.detach(), grid.detach(), shape, bound, order, extrapolate)
+            r = oracle.grid_push(inp.detach(), _g(grid), shape, bound, order, extrapolate)
         out += torch.as_tensor(r).sum(0, keepdim=True).to(out.dtype)
         return out
 
     @staticmethod
     def pull_backward(grad, inp, grid, bound, order, extrapolate, need_inp, need_grid):
-        gi, gg = oracle.grid_pull_backward(grad.detach(), inp.detach(), grid.detach(), bound, order, extrapolate)
+        gi, gg = oracle.grid_pull_backward(grad.detach(), inp.detach(), _g(grid), bound, order, extrapolate)
         return (gi if need_inp else None), (gg if need_grid else None)
 
     @staticmethod
     def push_backward(grad, inp, grid, bound, order, extrapolate, need_inp, need_grid):
-        gi, gg = oracle.grid_push_backward(grad.detach(), inp.detach(), grid.detach(), bound, order, extrapolate)
+        gi, gg = oracle.grid_push_backward(grad.detach(), inp.detach(), _g(grid), bound, order, extrapolate)
         return (gi if need_inp else None), (gg if need_grid else None)
 
     @staticmethod
     def count_backward(grad, grid, bound, order, extrapolate):
-        return oracle.grid_count_backward(grad.detach(), grid.detach(), bound, order, extrapolate)
+        return oracle.grid_count_backward(grad.detach(), _g(grid), bound, order, extrapolate)
 
     @staticmethod
     def spline_filter_(data, bound, order, dim):

@@ -215,6 +215,45 @@ def test_resize_identity_property(length, bound):
             assert torch.allclose(x, y, rtol=1e-4, atol=1e-7), (order, bound, length)
 
 
+def test_resize_restrict_golden_host_logic():
+    """`resize` / `restrict` (lattice construction, anchors, defaults, fold/unfold and the
+    SeparableGrid they hand to the operators) against the reference's outputs, with the
+    kernels served by the oracle."""
+    import golden_util as G
+    with ops.use_kernels(OracleKernels):
+        for c in G.resize_cases():
+            fn = getattr(interpol, c["fn"])
+            got64 = fn(torch.from_numpy(c["inp"]).double(), **c["kwargs"])
+            assert list(got64.shape) == c["shape"], c["kwargs"]
+            assert G.rel_err(got64.numpy(), c["out64"]) < 1e-10, (c["fn"], c["kwargs"])
+            got32 = fn(torch.from_numpy(c["inp"]), **c["kwargs"])
+            assert got32.dtype == torch.float32
+            G.assert_close(got32.numpy(), c["out32"], rtol=2e-5, atol_rel=2e-5, what=str((c["fn"], c["kwargs"])))
+
+
+def test_separable_grid_equals_dense_grid_host_logic():
+    from interpol import SeparableGrid
+    torch.manual_seed(3)
+    x = torch.randn(2, 3, 6, 7, dtype=torch.float64, requires_grad=True)
+    lin = [torch.linspace(-1, 6, 9, dtype=torch.float64), torch.linspace(0.5, 5.5, 4, dtype=torch.float64)]
+    sep = SeparableGrid(lin)
+    assert tuple(sep.shape) == (1, 9, 4, 2) and not sep.requires_grad
+    dense = sep.dense()[0]
+    with ops.use_kernels(OracleKernels):
+        a = interpol.grid_pull(x, sep, interpolation=2, bound='dct2', extrapolate=True)
+        b = interpol.grid_pull(x, dense, interpolation=2, bound='dct2', extrapolate=True)
+        assert torch.equal(a, b)
+        ga, = torch.autograd.grad(a.square().sum(), x)
+        gb, = torch.autograd.grad(b.square().sum(), x)
+        assert torch.allclose(ga, gb, atol=1e-12)
+        y = torch.randn(2, 3, 9, 4, dtype=torch.float64)
+        pa = interpol.grid_push(y, sep, shape=[6, 7], interpolation=1, bound='zero')
+        pb = interpol.grid_push(y, dense, shape=[6, 7], interpolation=1, bound='zero')
+        assert torch.allclose(pa, pb, atol=1e-12)
+    with pytest.raises(ValueError):
+        SeparableGrid([torch.zeros(2, 2)])
+
+
 def test_grid_helpers():
     g = interpol.identity_grid([3, 4])
     assert g.shape == (3, 4, 2) and g[2, 3].tolist() == [2.0, 3.0]

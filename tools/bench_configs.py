@@ -85,4 +85,24 @@ if "5" in which:    # cfg5: 2-D, orders [2,3,5]->[2,3], bounds [dct1,dst2,zero]-
     rec(res, "cfg5_prefilter_bf16_o23_dct1dct2", timeit(lambda: interpol.spline_coeff_nd(x, [2, 3], ["dct1", "dct2"], 2), 3), vox, 2 * 2 * B * C * n * n * 2)
     rec(res, "cfg5_prefilter_f32_o23_dct1dct2", timeit(lambda: interpol.spline_coeff_nd(xf, [2, 3], ["dct1", "dct2"], 2), 3), vox, 2 * 2 * B * C * n * n * 4)
 
+if "f" in which or which == "1345":    # row f2: resize / restrict on a separable lattice vs the same call with a dense grid tensor
+    B, C, n = 4, 2, 128
+    x = torch.randn(B, C, n, n, n, generator=g, device=dev)
+    kw = dict(factor=[2, 2, 2], anchor='e', interpolation=3, bound='dct2', prefilter=False)
+    m = 2 * n
+    vox = B * m ** 3
+    nbytes = B * C * (n ** 3 + m ** 3) * 4
+    rec(res, "f2_resize_2x_128to256_cubic_separable", timeit(lambda: interpol.resize(x, **kw), 3), vox, nbytes)
+    lin = torch.arange(0., m, device=dev) * 0.5 + 0.5 * (0.5 - 1)
+
+    def dense_path():
+        grid = torch.stack(torch.meshgrid(lin, lin, lin, indexing='ij'), -1)
+        return interpol.grid_pull(x, grid, interpolation=3, bound='dct2', extrapolate=True)
+    rec(res, "f2_resize_2x_128to256_cubic_dense_grid_incl_meshgrid", timeit(dense_path, 3), vox, nbytes)
+    grid = torch.stack(torch.meshgrid(lin, lin, lin, indexing='ij'), -1)
+    rec(res, "f2_resize_2x_128to256_cubic_dense_grid_kernel_only", timeit(lambda: interpol.grid_pull(x, grid, interpolation=3, bound='dct2', extrapolate=True), 3), vox, nbytes)
+    del grid
+    y = torch.randn(B, C, m, m, m, generator=g, device=dev)
+    rec(res, "f2_restrict_2x_256to128_linear_separable", timeit(lambda: interpol.restrict(y, factor=[2, 2, 2], anchor='e', interpolation=1, bound='dct2'), 3), vox, nbytes)
+
 print(json.dumps(res, indent=1))

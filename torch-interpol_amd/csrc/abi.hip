@@ -119,7 +119,12 @@ static int make_params(const interpol_problem *p, Role role, int trailing, KPara
     k->vol_sb = p->vol_stride[0];
     k->vol_sc = p->vol_stride[1];
     // grid: spatial dims contiguous (row-major), component stride 1
-    {
+    if (p->flags & INTERPOL_FLAG_SEPARABLE_GRID) {
+        if (N > 0xffffffffll) return INTERPOL_E_SHAPE;               // the sample index is split in 32 bits
+        k->sep = 1;
+        for (int d = 0; d < 3; ++d) k->gshape[d] = d < p->dim ? (int)p->grid_shape[d] : 1;
+        k->grid_sb = 0;
+    } else {
         int64_t expect = p->dim;
         if (p->grid_stride[4] != 1 && p->dim > 1) return INTERPOL_E_STRIDE;
         for (int d = p->dim - 1; d >= 0; --d) {
@@ -337,6 +342,7 @@ int interpol_pull_backward(const interpol_problem *p, const void *grad_out, cons
     if (rc) return rc;
     if (!grad_out || !vol || !grid) return INTERPOL_E_NULL;
     if (!grad_vol && !grad_grid) return 0;
+    if (grad_grid && (p->flags & INTERPOL_FLAG_SEPARABLE_GRID)) return INTERPOL_E_STRIDE;   // no per-sample grid to differentiate
     hipStream_t st = (hipStream_t)stream;
     // grad_vol is a dense (B, C, *vol_shape) buffer; vol must be spatially contiguous so
     // that both share tap offsets (channel / batch strides are free)
@@ -388,6 +394,7 @@ int interpol_push_backward(const interpol_problem *p, const void *grad_vol_out, 
     if (rc) return rc;
     if (!grad_vol_out || !val || !grid) return INTERPOL_E_NULL;
     if (!grad_val && !grad_grid) return 0;
+    if (grad_grid && (p->flags & INTERPOL_FLAG_SEPARABLE_GRID)) return INTERPOL_E_STRIDE;
     hipStream_t st = (hipStream_t)stream;
     if (!(p->flags & INTERPOL_FLAG_NO_FASTPATH)) {
         rc = try_fast_pushbwd(p, k, grad_vol_out, val, grid, grad_val, grad_grid, st);
@@ -407,6 +414,7 @@ int interpol_count_backward(const interpol_problem *p, const void *grad_vol_out,
     int rc = make_params(p, GATHER, 1, &k, &B, false);
     if (rc) return rc;
     if (!grad_vol_out || !grid || !grad_grid) return INTERPOL_E_NULL;
+    if (p->flags & INTERPOL_FLAG_SEPARABLE_GRID) return INTERPOL_E_STRIDE;
     hipStream_t st = (hipStream_t)stream;
     if (!(p->flags & INTERPOL_FLAG_NO_FASTPATH)) {
         rc = try_fast_pushbwd(p, k, grad_vol_out, nullptr, grid, nullptr, grad_grid, st);

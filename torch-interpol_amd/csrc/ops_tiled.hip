@@ -356,6 +356,13 @@ __device__ __forceinline__ bool load_coords(const KParams &p, const float *__res
     const bool valid = ox < g.gx && oy < g.gy && oz < g.gz;
     ox = ox < g.gx ? ox : g.gx - 1; oy = oy < g.gy ? oy : g.gy - 1; oz = oz < g.gz ? oz : g.gz - 1;
     o = ((int64_t)ox * g.gy + oy) * g.gz + oz;
+    if (p.sep) {
+        // tensor-product coordinates (INTERPOL_FLAG_SEPARABLE_GRID): lin_x | lin_y | lin_z back to back
+        x[0] = C::D == 3 ? grid[ox] : 0.f;
+        x[1] = grid[(C::D == 3 ? g.gx : 0) + oy];
+        x[2] = grid[(C::D == 3 ? g.gx : 0) + g.gy + oz];
+        return valid;
+    }
     const float *gp = grid + b * p.grid_sb + o * C::D;
 #pragma unroll
     for (int d = 0; d < 3; ++d) x[d] = C::pd(d) >= 0 ? gp[C::pd(d) < 0 ? 0 : C::pd(d)] : 0.f;
@@ -566,6 +573,12 @@ __device__ __forceinline__ int64_t slow_sample(const TileGeom &g, int code, cons
     int ox, oy, oz;
     sample_pos<C>(g, stid, sv, ox, oy, oz);
     const int64_t o = ((int64_t)ox * g.gy + oy) * g.gz + oz;
+    if (p.sep) {
+        x[0] = C::D == 3 ? grid[ox] : 0.f;
+        x[1] = grid[(C::D == 3 ? g.gx : 0) + oy];
+        x[2] = grid[(C::D == 3 ? g.gx : 0) + g.gy + oz];
+        return o;
+    }
     const float *gp = grid + b * p.grid_sb + o * C::D;
 #pragma unroll
     for (int d = 0; d < 3; ++d) x[d] = C::pd(d) >= 0 ? gp[C::pd(d) < 0 ? 0 : C::pd(d)] : 0.f;

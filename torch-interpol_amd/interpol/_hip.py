@@ -10,6 +10,8 @@ import os
 
 import torch
 
+from .sepgrid import SeparableGrid
+
 _PKG_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LIB_PATH = os.path.join(_PKG_ROOT, "lib", "libinterpol_hip.so")
 
@@ -18,6 +20,7 @@ F32, F64, BF16, F16 = 0, 1, 2, 3
 FLAG_NO_FASTPATH = 1
 FLAG_ACCUMULATE = 2
 FLAG_FORCE_TILED = 4
+FLAG_SEPARABLE_GRID = 8
 
 _DTYPE_CODE = {torch.float32: F32, torch.float64: F64, torch.bfloat16: BF16, torch.float16: F16}
 
@@ -211,7 +214,37 @@ def _pad_to(lst, n, fill=0):
 
 
 def _grid_strides(grid, B, dim):
+    if isinstance(grid, _PackedLattice):
+        return [0] * 5
     return [_bstride(grid, B)] + _pad_to([grid.stride(1 + d) for d in range(dim)], 3) + [grid.stride(-1)]
+
+
+class _PackedLattice:
+    """A SeparableGrid prepared for the C-ABI: the packed coordinate vectors + the shape the
+    host code sees, (1, *out, D).  Adds INTERPOL_FLAG_SEPARABLE_GRID to the call."""
+
+    def __init__(self, sep, gdt):
+        self.buf = sep.packed(gdt)
+        self.shape = sep.shape
+
+    def data_ptr(self):
+        return self.buf.data_ptr()
+
+    def numel(self):
+        n = 1
+        for s in self.shape:
+            n *= s
+        return n
+
+
+def _prep_grid(grid, gdt):
+    """-> (grid object to pass on, extra flags)."""
+    if isinstance(grid, SeparableGrid):
+        return _PackedLattice(grid, gdt), FLAG_SEPARABLE_GRID
+    grid = grid.to(gdt)
+    if not _spatially_contiguous(grid, 1):
+        grid = grid.contiguous()
+    return grid, 0
 
 
 def gather(op, vol, grid, bound, order, extrapolate, flags=0):
@@ -225,9 +258,8 @@ def gather(op, vol, grid, bound, order, extrapolate, flags=0):
     if op in ("hess",) and dt in (torch.bfloat16, torch.float16):
         dt = torch.float32                                 # second-order operator: f32 / f64 kernels only
     vol = vol.to(dt)
-    grid = grid.to(gdt)
-    if not _spatially_contiguous(grid, 1):
-        grid = grid.contiguous()
+    grid, gflag = _prep_grid(grid, gdt)
+    flags |= gflag
     B = max(vol.shape[0], grid.shape[0])
     C = vol.shape[1]
     oshape = list(grid.shape[1:-1])
@@ -259,9 +291,8 @@ def scatter(op, val, grid, shape, bound, order, extrapolate, flags=0, out=None, 
     out_dt = dt
     if op == "pushgrad" and dt in (torch.bfloat16, torch.float16):
         dt = torch.float32
-    grid = grid.to(gdt)
-    if not _spatially_contiguous(grid, 1):
-        grid = grid.contiguous()
+    grid, gflag = _prep_grid(grid, gdt)
+    flags |= gflag
     gshape = list(grid.shape[1:-1])
     if shape is None:
         shape = gshape
@@ -311,9 +342,10 @@ def pull_backward(gout, vol, grid, bound, order, extrapolate, need_vol, need_gri
     dt, gdt = common_dtypes(vol, grid)
     vol = vol.to(dt)
     gout = gout.to(dt)
-    grid_c = grid.to(gdt)
-    if not _spatially_contiguous(grid_c, 1):
-        grid_c = grid_c.contiguous()
+    grid_c, gflag = _prep_grid(grid, gdt)
+    flags |= gflag
+    if gflag and need_grid:
+        raise RuntimeError("interpol: a SeparableGrid is a constant lattice, it has no gradient")
     if not _spatially_contiguous(vol, 2):
         vol = vol.contiguous()
     if not _spatially_contiguous(gout, 2):
@@ -348,9 +380,10 @@ def push_backward(gvol_out, val, grid, bound, order, extrapolate, need_val, need
     dim = grid.shape[-1]
     dt, gdt = common_dtypes(gvol_out, grid)
     gvol_out = gvol_out.to(dt)
-    grid_c = grid.to(gdt)
-    if not _spatially_contiguous(grid_c, 1):
-        grid_c = grid_c.contiguous()
+    grid_c, gflag = _prep_grid(grid, gdt)
+    flags |= gflag
+    if gflag and need_grid:
+        raise RuntimeError("interpol: a SeparableGrid is a constant lattice, it has no gradient")
     gshape = list(grid_c.shape[1:-1])
     B = max(gvol_out.shape[0], grid_c.shape[0])
     C = gvol_out.shape[1]

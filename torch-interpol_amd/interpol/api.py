@@ -18,6 +18,7 @@ import torch
 
 from . import backend
 from .autograd import GridPull, GridPush, GridCount, GridGrad, SplineCoeff, SplineCoeffND
+from .sepgrid import SeparableGrid
 from .utils import expanded_shape
 
 __all__ = ['pull', 'push', 'count', 'grid_pull', 'grid_push', 'grid_count', 'grid_grad',
@@ -35,8 +36,9 @@ def _fold(grid, input=None, mode=None):
         info = dict(batch=list(batch), channel=[1] if batch else [], dim=dim)
         return grid.reshape([-1, *spatial, dim]), info
 
+    sep = isinstance(grid, SeparableGrid)            # constant tensor-product lattice: no batch dims
     grid_spatial = grid.shape[-dim - 1:-1]
-    grid_batch = grid.shape[:-dim - 1]
+    grid_batch = () if sep else grid.shape[:-dim - 1]
     input_spatial = input.shape[-dim:]
     channel = 0 if input.dim() == dim else input.shape[-dim - 1]
     input_batch = input.shape[:-dim - 1]
@@ -44,7 +46,8 @@ def _fold(grid, input=None, mode=None):
         grid_spatial = input_spatial = expanded_shape(grid_spatial, input_spatial)
 
     batch = expanded_shape(grid_batch, input_batch)
-    grid = grid.expand([*batch, *grid_spatial, dim]).reshape([-1, *grid_spatial, dim])
+    if not sep:
+        grid = grid.expand([*batch, *grid_spatial, dim]).reshape([-1, *grid_spatial, dim])
     input = input.expand([*batch, channel or 1, *input_spatial]).reshape([-1, channel or 1, *input_spatial])
     out_channel = [channel] if channel else ([1] if batch else [])
     return grid, input, dict(batch=list(batch), channel=out_channel, dim=dim)

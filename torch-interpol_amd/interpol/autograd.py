@@ -11,6 +11,7 @@ import torch
 from . import ops
 from .coeff import _spline_coeff, _spline_coeff_nd
 from .codes import bound_to_code, order_to_code
+from .sepgrid import SeparableGrid
 
 try:                                    # torch >= 2.4
     from torch.amp import custom_fwd, custom_bwd
@@ -28,6 +29,22 @@ def _as_list(x):
     return list(x) if isinstance(x, (list, tuple)) else [x]
 
 
+def _save(ctx, input, grid):
+    """save_for_backward with a constant SeparableGrid kept as a plain attribute."""
+    if isinstance(grid, SeparableGrid):
+        ctx.sep = grid
+        ctx.save_for_backward(input)
+    else:
+        ctx.sep = None
+        ctx.save_for_backward(input, grid)
+
+
+def _saved(ctx):
+    if ctx.sep is not None:
+        return ctx.saved_tensors[0], ctx.sep
+    return ctx.saved_tensors
+
+
 def _options(bound, interpolation, extrapolate):
     return ([bound_to_code(b) for b in _as_list(bound)],
             [order_to_code(o) for o in _as_list(interpolation)],
@@ -43,13 +60,13 @@ class GridPull(torch.autograd.Function):
         opt = _options(bound, interpolation, extrapolate)
         output = ops.grid_pull(input, grid, *opt)
         ctx.opt = opt
-        ctx.save_for_backward(input, grid)
+        _save(ctx, input, grid)
         return output
 
     @staticmethod
     @_bwd
     def backward(ctx, grad):
-        input, grid = ctx.saved_tensors
+        input, grid = _saved(ctx)
         grad_input, grad_grid = ops.grid_pull_backward(
             grad, input, grid, *ctx.opt,
             need_inp=ctx.needs_input_grad[0], need_grid=ctx.needs_input_grad[1])
@@ -65,13 +82,13 @@ class GridPush(torch.autograd.Function):
         opt = _options(bound, interpolation, extrapolate)
         output = ops.grid_push(input, grid, shape, *opt)
         ctx.opt = opt
-        ctx.save_for_backward(input, grid)
+        _save(ctx, input, grid)
         return output
 
     @staticmethod
     @_bwd
     def backward(ctx, grad):
-        input, grid = ctx.saved_tensors
+        input, grid = _saved(ctx)
         grad_input, grad_grid = ops.grid_push_backward(
             grad, input, grid, *ctx.opt,
             need_inp=ctx.needs_input_grad[0], need_grid=ctx.needs_input_grad[1])
@@ -109,13 +126,13 @@ class GridGrad(torch.autograd.Function):
         opt = _options(bound, interpolation, extrapolate)
         output = ops.grid_grad(input, grid, *opt)
         ctx.opt = opt
-        ctx.save_for_backward(input, grid)
+        _save(ctx, input, grid)
         return output
 
     @staticmethod
     @_bwd
     def backward(ctx, grad):
-        input, grid = ctx.saved_tensors
+        input, grid = _saved(ctx)
         grad_input = grad_grid = None
         if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
             grad_input, grad_grid = ops.grid_grad_backward(

@@ -4,6 +4,7 @@ reference's `interpol/resize.py:13-119`."""
 import torch
 
 from .api import grid_pull
+from .sepgrid import SeparableGrid
 from .utils import make_list
 
 __all__ = ['resize']
@@ -48,5 +49,9 @@ def resize(image, factor=None, shape=None, anchor='c', interpolation=1, prefilte
     kwargs.setdefault('extrapolate', True)
     kwargs.setdefault('interpolation', interpolation)
     kwargs.setdefault('prefilter', prefilter)
+    # the reference stacks meshgrid_ij(*lin) into a (*shape, dim) grid (resize.py:116); the
+    # kernels read the coordinate vectors themselves: same values, no grid tensor
+    if nb_dim <= 3 and image.dim() >= nb_dim:
+        return grid_pull(image, SeparableGrid(lin), **kwargs)
     grid = torch.stack(torch.meshgrid(*lin, indexing='ij'), dim=-1)
     return grid_pull(image, grid, **kwargs)

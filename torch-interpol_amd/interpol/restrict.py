@@ -3,6 +3,7 @@ path; same signature as the reference's `interpol/restrict.py:9-122`."""
 import torch
 
 from .api import grid_push
+from .sepgrid import SeparableGrid
 from .utils import make_list
 
 __all__ = ['restrict']
@@ -51,7 +52,11 @@ def restrict(image, factor=None, shape=None, anchor='c', interpolation=1, reduce
     kwargs.setdefault('extrapolate', True)
     kwargs.setdefault('interpolation', interpolation)
     kwargs.setdefault('prefilter', False)
-    grid = torch.stack(torch.meshgrid(*lin, indexing='ij'), dim=-1)
+    # reference: stack(meshgrid_ij(*lin), -1) (restrict.py:117); see resize.py
+    if nb_dim <= 3 and image.dim() >= nb_dim:
+        grid = SeparableGrid(lin)
+    else:
+        grid = torch.stack(torch.meshgrid(*lin, indexing='ij'), dim=-1)
     out = grid_push(image, grid, shape, **kwargs)
     if not reduce_sum:
         out /= fullscale
