@@ -105,6 +105,12 @@ typedef struct interpol_problem {
  * grid_stride is ignored; no (B,*out,D) grid is read (-12 B/sample in 3-D).  The backward
  * entry points accept it only when grad_grid is not requested (else INTERPOL_E_STRIDE). */
 #define INTERPOL_FLAG_SEPARABLE_GRID 8
+/* `grid` holds DISPLACEMENTS in voxels, layout as a dense grid: the coordinates are
+ * o_d + grid[b, o, d], the identity lattice being added in registers -- the fused form of
+ * add_identity_grid_ (api.py:490-513) followed by the operator; same rounding (one float add of
+ * the exactly representable index).  grad_grid of the backward entry points is then the
+ * gradient w.r.t. the displacement (identical values).  Not combinable with SEPARABLE_GRID. */
+#define INTERPOL_FLAG_DISPLACEMENT  16
 
 /* --- forward operators -------------------------------------------------------
  * interpol_pull      replaces pushpull.grid_pull      (interpol/pushpull.py:35-66;

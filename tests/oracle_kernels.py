@@ -7,9 +7,15 @@ import torch
 from oracle import oracle
 
 
-def _g(grid):
-    """dense tensor of a grid argument (a SeparableGrid lattice is expanded for the oracle)"""
-    return grid.dense() if hasattr(grid, 'dense') else grid.detach()
+def _g(grid, displacement=False):
+    """dense coordinates of a grid argument: a SeparableGrid lattice is expanded, a displacement
+    field gets the identity lattice added (interpol.add_identity_grid) -- for the oracle"""
+    if hasattr(grid, 'dense'):
+        return grid.dense()
+    if displacement:
+        import interpol
+        return interpol.add_identity_grid(grid.detach())
+    return grid.detach()
 
 
 def _t(x, like):
@@ -18,28 +24,28 @@ def _t(x, like):
 
 class OracleKernels:
     @staticmethod
-    def pull(inp, grid, bound, order, extrapolate):
-        return oracle.grid_pull(inp.detach(), _g(grid), bound, order, extrapolate)
+    def pull(inp, grid, bound, order, extrapolate, displacement=False):
+        return oracle.grid_pull(inp.detach(), _g(grid, displacement), bound, order, extrapolate)
 
     @staticmethod
-    def grad(inp, grid, bound, order, extrapolate):
-        return oracle.grid_grad(inp.detach(), _g(grid), bound, order, extrapolate)
+    def grad(inp, grid, bound, order, extrapolate, displacement=False):
+        return oracle.grid_grad(inp.detach(), _g(grid, displacement), bound, order, extrapolate)
 
     @staticmethod
-    def hess(inp, grid, bound, order, extrapolate):
-        return oracle.grid_hess(inp.detach(), _g(grid), bound, order, extrapolate)
+    def hess(inp, grid, bound, order, extrapolate, displacement=False):
+        return oracle.grid_hess(inp.detach(), _g(grid, displacement), bound, order, extrapolate)
 
     @staticmethod
-    def push(inp, grid, shape, bound, order, extrapolate):
-        return oracle.grid_push(inp.detach(), _g(grid), shape, bound, order, extrapolate)
+    def push(inp, grid, shape, bound, order, extrapolate, displacement=False):
+        return oracle.grid_push(inp.detach(), _g(grid, displacement), shape, bound, order, extrapolate)
 
     @staticmethod
-    def count(grid, shape, bound, order, extrapolate):
-        return oracle.grid_count(_g(grid), shape, bound, order, extrapolate)
+    def count(grid, shape, bound, order, extrapolate, displacement=False):
+        return oracle.grid_count(_g(grid, displacement), shape, bound, order, extrapolate)
 
     @staticmethod
-    def pushgrad(inp, grid, shape, bound, order, extrapolate):
-        return oracle.grid_pushgrad(inp.detach(), _g(grid), shape, bound, order, extrapolate)
+    def pushgrad(inp, grid, shape, bound, order, extrapolate, displacement=False):
+        return oracle.grid_pushgrad(inp.detach(), _g(grid, displacement), shape, bound, order, extrapolate)
 
     @staticmethod
     def push_shared_(out, inp, grid, bound, order, extrapolate):
@@ -52,18 +58,18 @@ class OracleKernels:
         return out
 
     @staticmethod
-    def pull_backward(grad, inp, grid, bound, order, extrapolate, need_inp, need_grid):
-        gi, gg = oracle.grid_pull_backward(grad.detach(), inp.detach(), _g(grid), bound, order, extrapolate)
+    def pull_backward(grad, inp, grid, bound, order, extrapolate, need_inp, need_grid, displacement=False):
+        gi, gg = oracle.grid_pull_backward(grad.detach(), inp.detach(), _g(grid, displacement), bound, order, extrapolate)
         return (gi if need_inp else None), (gg if need_grid else None)
 
     @staticmethod
-    def push_backward(grad, inp, grid, bound, order, extrapolate, need_inp, need_grid):
-        gi, gg = oracle.grid_push_backward(grad.detach(), inp.detach(), _g(grid), bound, order, extrapolate)
+    def push_backward(grad, inp, grid, bound, order, extrapolate, need_inp, need_grid, displacement=False):
+        gi, gg = oracle.grid_push_backward(grad.detach(), inp.detach(), _g(grid, displacement), bound, order, extrapolate)
         return (gi if need_inp else None), (gg if need_grid else None)
 
     @staticmethod
-    def count_backward(grad, grid, bound, order, extrapolate):
-        return oracle.grid_count_backward(grad.detach(), _g(grid), bound, order, extrapolate)
+    def count_backward(grad, grid, bound, order, extrapolate, displacement=False):
+        return oracle.grid_count_backward(grad.detach(), _g(grid, displacement), bound, order, extrapolate)
 
     @staticmethod
     def spline_filter_(data, bound, order, dim):

@@ -613,3 +613,42 @@ def test_resize_autograd_and_large():
     grid = torch.stack(torch.meshgrid(*lin, indexing='ij'), -1)
     (interpol.grid_pull(xs, grid, interpolation=2, bound='dct1', extrapolate=True, prefilter=True).square().sum()).backward()
     _same(g_sep, xs.grad, 1e-5, "resize gradient")
+
+
+# ---------------------------------------------------------------------------
+# displacement fields, identity lattice added in registers
+# ---------------------------------------------------------------------------
+@pytest.mark.parametrize("dim", [1, 2, 3])
+def test_displacement_flag_matches_identity_plus_displacement(dim):
+    """INTERPOL_FLAG_DISPLACEMENT == the same call on add_identity_grid(disp): bit for bit for
+    gathers and gradients w.r.t. coordinates (same float add), atomic-order rounding for scatters;
+    generic and tiled kernels, fp32 and fp64."""
+    from interpol import _hip
+    g = torch.Generator().manual_seed(70 + dim)
+    shape = (37, 29, 41)[:dim]
+    for dtype in (torch.float32, torch.float64):
+        vol = torch.randn([2, 2, *shape], generator=g).to(DEV, dtype)
+        disp = (1.7 * torch.randn([2, *shape, dim], generator=g)).to(DEV, dtype)
+        grid = interpol.add_identity_grid(disp)
+        b, o = [3] * dim, [3] * dim
+        for flags in (_hip.FLAG_NO_FASTPATH, 0, _hip.FLAG_FORCE_TILED):
+            fd = flags | _hip.FLAG_DISPLACEMENT
+            for op in ("pull", "grad"):
+                assert torch.equal(_hip.gather(op, vol, disp, b, o, 0, flags=fd), _hip.gather(op, vol, grid, b, o, 0, flags=flags)), (op, dim, flags)
+            _same(_hip.scatter("push", vol, disp, list(shape), b, o, 1, flags=fd),
+                  _hip.scatter("push", vol, grid, list(shape), b, o, 1, flags=flags), 2e-6, ("push", dim, flags))
+            ga = _hip.pull_backward(vol, vol, disp, b, o, 1, True, True, flags=fd)
+            gb = _hip.pull_backward(vol, vol, grid, b, o, 1, True, True, flags=flags)
+            _same(ga[0], gb[0], 2e-6, ("pull_backward vol", dim, flags))
+            _same(ga[1], gb[1], 1e-6, ("pull_backward grid", dim, flags))
+    # API level, with autograd through the displacement
+    x = torch.randn(1, 2, 20, 22, 24, device=DEV, requires_grad=True)
+    d = (torch.randn(1, 20, 22, 24, 3, device=DEV) * 2).requires_grad_(True)
+    kw = dict(interpolation=3, bound='dct2', extrapolate=True)
+    a = interpol.grid_pull(x, d, displacement=True, **kw)
+    bb = interpol.grid_pull(x, interpol.add_identity_grid(d), **kw)
+    assert torch.equal(a, bb)
+    ga = torch.autograd.grad(a.square().sum(), [x, d])
+    gb = torch.autograd.grad(bb.square().sum(), [x, d])
+    _same(ga[0], gb[0], 1e-5, "api grad input")
+    _same(ga[1], gb[1], 1e-5, "api grad displacement")

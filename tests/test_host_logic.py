@@ -254,6 +254,32 @@ def test_separable_grid_equals_dense_grid_host_logic():
         SeparableGrid([torch.zeros(2, 2)])
 
 
+def test_displacement_keyword_host_logic():
+    """displacement=True == the same call on add_identity_grid(disp), forward and gradients
+    (row f3: the identity lattice is added inside the operator)."""
+    torch.manual_seed(5)
+    x = torch.randn(2, 2, 7, 8, dtype=torch.float64, requires_grad=True)
+    disp = (torch.randn(2, 7, 8, 2, dtype=torch.float64) * 1.5).requires_grad_(True)
+    kw = dict(interpolation=3, bound='dct2', extrapolate=True)
+    with ops.use_kernels(OracleKernels):
+        for fn, args in ((interpol.grid_pull, (x,)), (interpol.grid_grad, (x,)), (interpol.grid_push, (x,)), (interpol.grid_count, ())):
+            a = fn(*args, disp, displacement=True, **kw)
+            b = fn(*args, interpol.add_identity_grid(disp), **kw)
+            assert torch.allclose(a, b, atol=1e-12), fn.__name__
+            ins = [t for t in (*args, disp)]
+            ga = torch.autograd.grad(a.square().sum(), ins, allow_unused=True)
+            gb = torch.autograd.grad(b.square().sum(), ins, allow_unused=True)
+            for u, v in zip(ga, gb):
+                assert (u is None) == (v is None)
+                if u is not None:
+                    assert torch.allclose(u, v, atol=1e-10), fn.__name__
+    # the reference's positional Function signature is still accepted
+    from interpol.autograd import GridPull
+    with ops.use_kernels(OracleKernels):
+        y = GridPull.apply(x, interpol.add_identity_grid(disp.detach()), 1, 'zero', False)
+        y.sum().backward()
+
+
 def test_grid_helpers():
     g = interpol.identity_grid([3, 4])
     assert g.shape == (3, 4, 2) and g[2, 3].tolist() == [2.0, 3.0]

@@ -119,10 +119,13 @@ static int make_params(const interpol_problem *p, Role role, int trailing, KPara
     k->vol_sb = p->vol_stride[0];
     k->vol_sc = p->vol_stride[1];
     // grid: spatial dims contiguous (row-major), component stride 1
-    if (p->flags & INTERPOL_FLAG_SEPARABLE_GRID) {
+    if ((p->flags & INTERPOL_FLAG_SEPARABLE_GRID) && (p->flags & INTERPOL_FLAG_DISPLACEMENT)) return INTERPOL_E_STRIDE;
+    if (p->flags & (INTERPOL_FLAG_SEPARABLE_GRID | INTERPOL_FLAG_DISPLACEMENT)) {
         if (N > 0xffffffffll) return INTERPOL_E_SHAPE;               // the sample index is split in 32 bits
-        k->sep = 1;
+        k->sep = (p->flags & INTERPOL_FLAG_SEPARABLE_GRID) ? 1 : 2;
         for (int d = 0; d < 3; ++d) k->gshape[d] = d < p->dim ? (int)p->grid_shape[d] : 1;
+    }
+    if (p->flags & INTERPOL_FLAG_SEPARABLE_GRID) {
         k->grid_sb = 0;
     } else {
         int64_t expect = p->dim;

@@ -356,7 +356,7 @@ __device__ __forceinline__ bool load_coords(const KParams &p, const float *__res
     const bool valid = ox < g.gx && oy < g.gy && oz < g.gz;
     ox = ox < g.gx ? ox : g.gx - 1; oy = oy < g.gy ? oy : g.gy - 1; oz = oz < g.gz ? oz : g.gz - 1;
     o = ((int64_t)ox * g.gy + oy) * g.gz + oz;
-    if (p.sep) {
+    if (p.sep == 1) {
         // tensor-product coordinates (INTERPOL_FLAG_SEPARABLE_GRID): lin_x | lin_y | lin_z back to back
         x[0] = C::D == 3 ? grid[ox] : 0.f;
         x[1] = grid[(C::D == 3 ? g.gx : 0) + oy];
@@ -366,6 +366,11 @@ __device__ __forceinline__ bool load_coords(const KParams &p, const float *__res
     const float *gp = grid + b * p.grid_sb + o * C::D;
 #pragma unroll
     for (int d = 0; d < 3; ++d) x[d] = C::pd(d) >= 0 ? gp[C::pd(d) < 0 ? 0 : C::pd(d)] : 0.f;
+    if (p.sep == 2) {   // displacement field (INTERPOL_FLAG_DISPLACEMENT): add the identity lattice
+        if (C::D == 3) x[0] += (float)ox;
+        x[1] += (float)oy;
+        x[2] += (float)oz;
+    }
     return valid;
 }
 
@@ -573,7 +578,7 @@ __device__ __forceinline__ int64_t slow_sample(const TileGeom &g, int code, cons
     int ox, oy, oz;
     sample_pos<C>(g, stid, sv, ox, oy, oz);
     const int64_t o = ((int64_t)ox * g.gy + oy) * g.gz + oz;
-    if (p.sep) {
+    if (p.sep == 1) {
         x[0] = C::D == 3 ? grid[ox] : 0.f;
         x[1] = grid[(C::D == 3 ? g.gx : 0) + oy];
         x[2] = grid[(C::D == 3 ? g.gx : 0) + g.gy + oz];
@@ -582,6 +587,11 @@ __device__ __forceinline__ int64_t slow_sample(const TileGeom &g, int code, cons
     const float *gp = grid + b * p.grid_sb + o * C::D;
 #pragma unroll
     for (int d = 0; d < 3; ++d) x[d] = C::pd(d) >= 0 ? gp[C::pd(d) < 0 ? 0 : C::pd(d)] : 0.f;
+    if (p.sep == 2) {
+        if (C::D == 3) x[0] += (float)ox;
+        x[1] += (float)oy;
+        x[2] += (float)oz;
+    }
     return o;
 }
 

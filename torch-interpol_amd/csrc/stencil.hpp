@@ -45,7 +45,7 @@ struct KParams {
     int vol_ss[3];          // spatial strides of vol in BYTES (whole image < 2^32 bytes, checked on host)
     int C;
     int dbg;                // debug / ablation switches (interpol_problem.flags >> 8), 0 in production
-    int sep;                // INTERPOL_FLAG_SEPARABLE_GRID: grid = D coordinate vectors back to back
+    int sep;                // 1: INTERPOL_FLAG_SEPARABLE_GRID (grid = D coordinate vectors back to back); 2: INTERPOL_FLAG_DISPLACEMENT
     int gshape[3];          // sample-grid extents (problem dims), used to split a linear sample index when sep
     int64_t N;              // samples per batch item
     int64_t vol_sb, vol_sc;
@@ -175,15 +175,22 @@ template <typename R, typename G, int D>
 __device__ __forceinline__ void load_coords(const KParams &p, const G *grid, int64_t b, int64_t o, R *x)
 {
     if (p.sep) {
-        // tensor-product coordinates (resize.py:96-123): x_d = lin_d[o_d]
         unsigned r = (unsigned)o;
         int base = 0;
         unsigned od[3] = { 0u, 0u, 0u };
 #pragma unroll
         for (int d = D - 1; d > 0; --d) { const unsigned q = r / (unsigned)p.gshape[d]; od[d] = r - q * (unsigned)p.gshape[d]; r = q; }
         od[0] = r;
+        if (p.sep == 1) {
+            // tensor-product coordinates (resize.py:96-123): x_d = lin_d[o_d]
 #pragma unroll
-        for (int d = 0; d < D; ++d) { x[d] = (R)grid[base + (int)od[d]]; base += p.gshape[d]; }
+            for (int d = 0; d < D; ++d) { x[d] = (R)grid[base + (int)od[d]]; base += p.gshape[d]; }
+        } else {
+            // displacement field: x_d = o_d + disp (add_identity_grid_, api.py:490-513, in the grid's dtype)
+            const G *gp = grid + b * p.grid_sb + o * D;
+#pragma unroll
+            for (int d = 0; d < D; ++d) x[d] = (R)(G)(gp[d] + (G)od[d]);
+        }
         return;
     }
     const G *gp = grid + b * p.grid_sb + o * D;

@@ -21,6 +21,7 @@ FLAG_NO_FASTPATH = 1
 FLAG_ACCUMULATE = 2
 FLAG_FORCE_TILED = 4
 FLAG_SEPARABLE_GRID = 8
+FLAG_DISPLACEMENT = 16
 
 _DTYPE_CODE = {torch.float32: F32, torch.float64: F64, torch.bfloat16: BF16, torch.float16: F16}
 

@@ -63,12 +63,17 @@ def _unfold(out, info, mode):
     return out.reshape([*info['batch'], *info['channel'], *spatial, *feat])
 
 
-def grid_pull(input, grid, interpolation='linear', bound='zero', extrapolate=False, prefilter=False):
+def grid_pull(input, grid, interpolation='linear', bound='zero', extrapolate=False, prefilter=False,
+              displacement=False):
     """Sample an image at the coordinates of a deformation field.
 
     input (..., [channel], *inshape), grid (..., *outshape, dim) -> (..., [channel], *outshape).
     Non floating-point inputs are treated as label maps: every label is
     resampled as a soft label and the arg-max is returned (api.py:194-205).
+
+    `displacement=True` (extension, also on grid_push / grid_count / grid_grad): `grid` holds
+    voxel displacements and the identity lattice is added inside the kernel -- the fused form of
+    `grid_pull(input, add_identity_grid(disp))` (api.py:490-531), same values, one tensor pass less.
     """
     if backend.jitfields:
         raise RuntimeError('the jitfields backend is not part of the MI355X build')
@@ -83,18 +88,18 @@ def grid_pull(input, grid, interpolation='linear', bound='zero', extrapolate=Fal
             soft = (input == label).to(grid.dtype)
             if prefilter:
                 soft = spline_coeff_nd(soft, interpolation=interpolation, bound=bound, dim=dim, inplace=True)
-            soft = GridPull.apply(soft, grid, interpolation, bound, extrapolate)
+            soft = GridPull.apply(soft, grid, interpolation, bound, extrapolate, displacement)
             out[soft > pmax] = label
             pmax = torch.max(pmax, soft)
     else:
         if prefilter:
             input = spline_coeff_nd(input, interpolation=interpolation, bound=bound, dim=dim)
-        out = GridPull.apply(input, grid, interpolation, bound, extrapolate)
+        out = GridPull.apply(input, grid, interpolation, bound, extrapolate, displacement)
     return _unfold(out, info, 'pull')
 
 
 def grid_push(input, grid, shape=None, interpolation='linear', bound='zero', extrapolate=False,
-              prefilter=False):
+              prefilter=False, displacement=False):
     """Splat an image along a deformation field (adjoint of `grid_pull`).
 
     input (..., [channel], *inshape), grid (..., *inshape, dim) -> (..., [channel], *shape);
@@ -106,22 +111,23 @@ def grid_push(input, grid, shape=None, interpolation='linear', bound='zero', ext
     dim = grid.shape[-1]
     if shape is None:
         shape = tuple(input.shape[2:])
-    out = GridPush.apply(input, grid, shape, interpolation, bound, extrapolate)
+    out = GridPush.apply(input, grid, shape, interpolation, bound, extrapolate, displacement)
     if prefilter:
         out = spline_coeff_nd(out, interpolation=interpolation, bound=bound, dim=dim, inplace=True)
     return _unfold(out, info, 'push')
 
 
-def grid_count(grid, shape=None, interpolation='linear', bound='zero', extrapolate=False):
+def grid_count(grid, shape=None, interpolation='linear', bound='zero', extrapolate=False, displacement=False):
     """Splat ones: grid (..., *inshape, dim) -> (..., [1], *shape)."""
     if backend.jitfields:
         raise RuntimeError('the jitfields backend is not part of the MI355X build')
     grid, info = _fold(grid)
-    out = GridCount.apply(grid, shape, interpolation, bound, extrapolate)
+    out = GridCount.apply(grid, shape, interpolation, bound, extrapolate, displacement)
     return _unfold(out, info, 'count')
 
 
-def grid_grad(input, grid, interpolation='linear', bound='zero', extrapolate=False, prefilter=False):
+def grid_grad(input, grid, interpolation='linear', bound='zero', extrapolate=False, prefilter=False,
+              displacement=False):
     """Sample the spatial gradient of an image (voxel units):
     input (..., [channel], *inshape), grid (..., *outshape, dim) -> (..., [channel], *outshape, dim)."""
     if backend.jitfields:
@@ -130,7 +136,7 @@ def grid_grad(input, grid, interpolation='linear', bound='zero', extrapolate=Fal
     dim = grid.shape[-1]
     if prefilter:
         input = spline_coeff_nd(input, interpolation, bound, dim)
-    out = GridGrad.apply(input, grid, interpolation, bound, extrapolate)
+    out = GridGrad.apply(input, grid, interpolation, bound, extrapolate, displacement)
     return _unfold(out, info, 'grad')
 
 

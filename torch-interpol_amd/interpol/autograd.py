@@ -45,6 +45,12 @@ def _saved(ctx):
     return ctx.saved_tensors
 
 
+def _extra(displacement):
+    """Optional trailing `displacement` argument of the sampling Functions (an extension: the
+    reference's `apply` signatures stay valid).  -> (flag, number of extra inputs)."""
+    return (bool(displacement[0]) if displacement else False), len(displacement)
+
+
 def _options(bound, interpolation, extrapolate):
     return ([bound_to_code(b) for b in _as_list(bound)],
             [order_to_code(o) for o in _as_list(interpolation)],
@@ -56,9 +62,10 @@ class GridPull(torch.autograd.Function):
 
     @staticmethod
     @_fwd32
-    def forward(ctx, input, grid, interpolation, bound, extrapolate):
+    def forward(ctx, input, grid, interpolation, bound, extrapolate, *displacement):
         opt = _options(bound, interpolation, extrapolate)
-        output = ops.grid_pull(input, grid, *opt)
+        ctx.disp, ctx.nextra = _extra(displacement)
+        output = ops.grid_pull(input, grid, *opt, displacement=ctx.disp)
         ctx.opt = opt
         _save(ctx, input, grid)
         return output
@@ -69,8 +76,8 @@ class GridPull(torch.autograd.Function):
         input, grid = _saved(ctx)
         grad_input, grad_grid = ops.grid_pull_backward(
             grad, input, grid, *ctx.opt,
-            need_inp=ctx.needs_input_grad[0], need_grid=ctx.needs_input_grad[1])
-        return grad_input, grad_grid, None, None, None
+            need_inp=ctx.needs_input_grad[0], need_grid=ctx.needs_input_grad[1], displacement=ctx.disp)
+        return (grad_input, grad_grid, None, None, None) + (None,) * ctx.nextra
 
 
 class GridPush(torch.autograd.Function):
@@ -78,9 +85,10 @@ class GridPush(torch.autograd.Function):
 
     @staticmethod
     @_fwd32
-    def forward(ctx, input, grid, shape, interpolation, bound, extrapolate):
+    def forward(ctx, input, grid, shape, interpolation, bound, extrapolate, *displacement):
         opt = _options(bound, interpolation, extrapolate)
-        output = ops.grid_push(input, grid, shape, *opt)
+        ctx.disp, ctx.nextra = _extra(displacement)
+        output = ops.grid_push(input, grid, shape, *opt, displacement=ctx.disp)
         ctx.opt = opt
         _save(ctx, input, grid)
         return output
@@ -91,8 +99,8 @@ class GridPush(torch.autograd.Function):
         input, grid = _saved(ctx)
         grad_input, grad_grid = ops.grid_push_backward(
             grad, input, grid, *ctx.opt,
-            need_inp=ctx.needs_input_grad[0], need_grid=ctx.needs_input_grad[1])
-        return grad_input, grad_grid, None, None, None, None
+            need_inp=ctx.needs_input_grad[0], need_grid=ctx.needs_input_grad[1], displacement=ctx.disp)
+        return (grad_input, grad_grid, None, None, None, None) + (None,) * ctx.nextra
 
 
 class GridCount(torch.autograd.Function):
@@ -100,9 +108,10 @@ class GridCount(torch.autograd.Function):
 
     @staticmethod
     @_fwd32
-    def forward(ctx, grid, shape, interpolation, bound, extrapolate):
+    def forward(ctx, grid, shape, interpolation, bound, extrapolate, *displacement):
         opt = _options(bound, interpolation, extrapolate)
-        output = ops.grid_count(grid, shape, *opt)
+        ctx.disp, ctx.nextra = _extra(displacement)
+        output = ops.grid_count(grid, shape, *opt, displacement=ctx.disp)
         ctx.opt = opt
         ctx.save_for_backward(grid)
         return output
@@ -113,8 +122,8 @@ class GridCount(torch.autograd.Function):
         grid, = ctx.saved_tensors
         grad_grid = None
         if ctx.needs_input_grad[0]:
-            grad_grid = ops.grid_count_backward(grad, grid, *ctx.opt, need_grid=True)
-        return grad_grid, None, None, None, None
+            grad_grid = ops.grid_count_backward(grad, grid, *ctx.opt, need_grid=True, displacement=ctx.disp)
+        return (grad_grid, None, None, None, None) + (None,) * ctx.nextra
 
 
 class GridGrad(torch.autograd.Function):
@@ -122,9 +131,10 @@ class GridGrad(torch.autograd.Function):
 
     @staticmethod
     @_fwd32
-    def forward(ctx, input, grid, interpolation, bound, extrapolate):
+    def forward(ctx, input, grid, interpolation, bound, extrapolate, *displacement):
         opt = _options(bound, interpolation, extrapolate)
-        output = ops.grid_grad(input, grid, *opt)
+        ctx.disp, ctx.nextra = _extra(displacement)
+        output = ops.grid_grad(input, grid, *opt, displacement=ctx.disp)
         ctx.opt = opt
         _save(ctx, input, grid)
         return output
@@ -137,8 +147,8 @@ class GridGrad(torch.autograd.Function):
         if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
             grad_input, grad_grid = ops.grid_grad_backward(
                 grad, input, grid, *ctx.opt,
-                need_inp=ctx.needs_input_grad[0], need_grid=ctx.needs_input_grad[1])
-        return grad_input, grad_grid, None, None, None
+                need_inp=ctx.needs_input_grad[0], need_grid=ctx.needs_input_grad[1], displacement=ctx.disp)
+        return (grad_input, grad_grid, None, None, None) + (None,) * ctx.nextra
 
 
 class SplineCoeff(torch.autograd.Function):

@@ -25,32 +25,41 @@ from . import _hip
 from .codes import pad_codes
 
 
+def _dflag(displacement):
+    return _hip.FLAG_DISPLACEMENT if displacement else 0
+
+
+def _kw(displacement):
+    """extra kernel-table keywords (tables that predate the flag are still callable without it)"""
+    return {"displacement": True} if displacement else {}
+
+
 class _HipKernels:
     """Default kernel table: the gfx950 library behind the C-ABI."""
 
     @staticmethod
-    def pull(inp, grid, bound, order, extrapolate):
-        return _hip.gather("pull", inp, grid, bound, order, extrapolate)
+    def pull(inp, grid, bound, order, extrapolate, displacement=False):
+        return _hip.gather("pull", inp, grid, bound, order, extrapolate, flags=_dflag(displacement))
 
     @staticmethod
-    def grad(inp, grid, bound, order, extrapolate):
-        return _hip.gather("grad", inp, grid, bound, order, extrapolate)
+    def grad(inp, grid, bound, order, extrapolate, displacement=False):
+        return _hip.gather("grad", inp, grid, bound, order, extrapolate, flags=_dflag(displacement))
 
     @staticmethod
-    def hess(inp, grid, bound, order, extrapolate):
-        return _hip.gather("hess", inp, grid, bound, order, extrapolate)
+    def hess(inp, grid, bound, order, extrapolate, displacement=False):
+        return _hip.gather("hess", inp, grid, bound, order, extrapolate, flags=_dflag(displacement))
 
     @staticmethod
-    def push(inp, grid, shape, bound, order, extrapolate):
-        return _hip.scatter("push", inp, grid, shape, bound, order, extrapolate)
+    def push(inp, grid, shape, bound, order, extrapolate, displacement=False):
+        return _hip.scatter("push", inp, grid, shape, bound, order, extrapolate, flags=_dflag(displacement))
 
     @staticmethod
-    def count(grid, shape, bound, order, extrapolate):
-        return _hip.scatter("count", None, grid, shape, bound, order, extrapolate)
+    def count(grid, shape, bound, order, extrapolate, displacement=False):
+        return _hip.scatter("count", None, grid, shape, bound, order, extrapolate, flags=_dflag(displacement))
 
     @staticmethod
-    def pushgrad(inp, grid, shape, bound, order, extrapolate):
-        return _hip.scatter("pushgrad", inp, grid, shape, bound, order, extrapolate)
+    def pushgrad(inp, grid, shape, bound, order, extrapolate, displacement=False):
+        return _hip.scatter("pushgrad", inp, grid, shape, bound, order, extrapolate, flags=_dflag(displacement))
 
     @staticmethod
     def push_shared_(out, inp, grid, bound, order, extrapolate):
@@ -60,16 +69,16 @@ class _HipKernels:
                             flags=_hip.FLAG_ACCUMULATE, out=out, shared=True)
 
     @staticmethod
-    def pull_backward(grad, inp, grid, bound, order, extrapolate, need_inp, need_grid):
-        return _hip.pull_backward(grad, inp, grid, bound, order, extrapolate, need_inp, need_grid)
+    def pull_backward(grad, inp, grid, bound, order, extrapolate, need_inp, need_grid, displacement=False):
+        return _hip.pull_backward(grad, inp, grid, bound, order, extrapolate, need_inp, need_grid, flags=_dflag(displacement))
 
     @staticmethod
-    def push_backward(grad, inp, grid, bound, order, extrapolate, need_inp, need_grid):
-        return _hip.push_backward(grad, inp, grid, bound, order, extrapolate, need_inp, need_grid)
+    def push_backward(grad, inp, grid, bound, order, extrapolate, need_inp, need_grid, displacement=False):
+        return _hip.push_backward(grad, inp, grid, bound, order, extrapolate, need_inp, need_grid, flags=_dflag(displacement))
 
     @staticmethod
-    def count_backward(grad, grid, bound, order, extrapolate):
-        return _hip.push_backward(grad, None, grid, bound, order, extrapolate, False, True)[1]
+    def count_backward(grad, grid, bound, order, extrapolate, displacement=False):
+        return _hip.push_backward(grad, None, grid, bound, order, extrapolate, False, True, flags=_dflag(displacement))[1]
 
     @staticmethod
     def spline_filter_(data, bound, order, dim):
@@ -108,49 +117,49 @@ def _check_push_shapes(inp, grid, trailing=0):
         raise ValueError('Input and grid should have the same spatial shape')
 
 
-def grid_pull(inp, grid, bound, interpolation, extrapolate):
+def grid_pull(inp, grid, bound, interpolation, extrapolate, displacement=False):
     """(B,C,*in), (B,*out,D) -> (B,C,*out).   Reference pushpull.py:35-66."""
     bound, interpolation = _codes(grid, bound, interpolation)
-    return _kernels.pull(inp, grid, bound, interpolation, int(extrapolate))
+    return _kernels.pull(inp, grid, bound, interpolation, int(extrapolate), **_kw(displacement))
 
 
-def grid_push(inp, grid, shape, bound, interpolation, extrapolate):
+def grid_push(inp, grid, shape, bound, interpolation, extrapolate, displacement=False):
     """(B,C,*in), (B,*in,D) -> (B,C,*shape).   Reference pushpull.py:70-102."""
     bound, interpolation = _codes(grid, bound, interpolation)
     _check_push_shapes(inp, grid)
     shape = None if shape is None else list(shape)
-    return _kernels.push(inp, grid, shape, bound, interpolation, int(extrapolate))
+    return _kernels.push(inp, grid, shape, bound, interpolation, int(extrapolate), **_kw(displacement))
 
 
-def grid_count(grid, shape, bound, interpolation, extrapolate):
+def grid_count(grid, shape, bound, interpolation, extrapolate, displacement=False):
     """(B,*in,D) -> (B,1,*shape).   Reference pushpull.py:106-142."""
     bound, interpolation = _codes(grid, bound, interpolation)
     shape = None if shape is None else list(shape)
-    return _kernels.count(grid, shape, bound, interpolation, int(extrapolate))
+    return _kernels.count(grid, shape, bound, interpolation, int(extrapolate), **_kw(displacement))
 
 
-def grid_grad(inp, grid, bound, interpolation, extrapolate):
+def grid_grad(inp, grid, bound, interpolation, extrapolate, displacement=False):
     """(B,C,*in), (B,*out,D) -> (B,C,*out,D).   Reference pushpull.py:146-172."""
     bound, interpolation = _codes(grid, bound, interpolation)
-    return _kernels.grad(inp, grid, bound, interpolation, int(extrapolate))
+    return _kernels.grad(inp, grid, bound, interpolation, int(extrapolate), **_kw(displacement))
 
 
-def grid_pushgrad(inp, grid, shape, bound, interpolation, extrapolate):
+def grid_pushgrad(inp, grid, shape, bound, interpolation, extrapolate, displacement=False):
     """(B,C,*in,D), (B,*in,D) -> (B,C,*shape).   Reference pushpull.py:176-203."""
     bound, interpolation = _codes(grid, bound, interpolation)
     _check_push_shapes(inp, grid, trailing=1)
     shape = None if shape is None else list(shape)
-    return _kernels.pushgrad(inp, grid, shape, bound, interpolation, int(extrapolate))
+    return _kernels.pushgrad(inp, grid, shape, bound, interpolation, int(extrapolate), **_kw(displacement))
 
 
-def grid_hess(inp, grid, bound, interpolation, extrapolate):
+def grid_hess(inp, grid, bound, interpolation, extrapolate, displacement=False):
     """(B,C,*in), (B,*out,D) -> (B,C,*out,D,D).   Reference pushpull.py:207-233."""
     bound, interpolation = _codes(grid, bound, interpolation)
-    return _kernels.hess(inp, grid, bound, interpolation, int(extrapolate))
+    return _kernels.hess(inp, grid, bound, interpolation, int(extrapolate), **_kw(displacement))
 
 
 def grid_pull_backward(grad, inp, grid, bound, interpolation, extrapolate,
-                       need_inp=None, need_grid=None):
+                       need_inp=None, need_grid=None, displacement=False):
     """-> (grad_inp (B,C,*in) | None, grad_grid (B,*out,D) | None).
     Reference pushpull.py:237-258; gradients are only computed for the inputs
     that require them (pushpull.py:252-255)."""
@@ -159,11 +168,12 @@ def grid_pull_backward(grad, inp, grid, bound, interpolation, extrapolate,
     need_grid = grid.requires_grad if need_grid is None else need_grid
     if not (need_inp or need_grid):
         return None, None
-    return _kernels.pull_backward(grad, inp, grid, bound, interpolation, int(extrapolate), need_inp, need_grid)
+    return _kernels.pull_backward(grad, inp, grid, bound, interpolation, int(extrapolate), need_inp, need_grid,
+                                  **_kw(displacement))
 
 
 def grid_push_backward(grad, inp, grid, bound, interpolation, extrapolate,
-                       need_inp=None, need_grid=None):
+                       need_inp=None, need_grid=None, displacement=False):
     """-> (grad_inp (B,C,*in) | None, grad_grid (B,*in,D) | None).
     Reference pushpull.py:262-282."""
     bound, interpolation = _codes(grid, bound, interpolation)
@@ -171,20 +181,21 @@ def grid_push_backward(grad, inp, grid, bound, interpolation, extrapolate,
     need_grid = grid.requires_grad if need_grid is None else need_grid
     if not (need_inp or need_grid):
         return None, None
-    return _kernels.push_backward(grad, inp, grid, bound, interpolation, int(extrapolate), need_inp, need_grid)
+    return _kernels.push_backward(grad, inp, grid, bound, interpolation, int(extrapolate), need_inp, need_grid,
+                                  **_kw(displacement))
 
 
-def grid_count_backward(grad, grid, bound, interpolation, extrapolate, need_grid=None):
+def grid_count_backward(grad, grid, bound, interpolation, extrapolate, need_grid=None, displacement=False):
     """-> grad_grid (B,*in,D) | None.   Reference pushpull.py:286-299."""
     bound, interpolation = _codes(grid, bound, interpolation)
     need_grid = grid.requires_grad if need_grid is None else need_grid
     if not need_grid:
         return None
-    return _kernels.count_backward(grad, grid, bound, interpolation, int(extrapolate))
+    return _kernels.count_backward(grad, grid, bound, interpolation, int(extrapolate), **_kw(displacement))
 
 
 def grid_grad_backward(grad, inp, grid, bound, interpolation, extrapolate,
-                       need_inp=None, need_grid=None):
+                       need_inp=None, need_grid=None, displacement=False):
     """-> (grad_inp (B,C,*in) | None, grad_grid (B,*out,D) | None); only reached
     by double backward.   Reference pushpull.py:303-325."""
     dim = grid.shape[-1]
@@ -192,8 +203,8 @@ def grid_grad_backward(grad, inp, grid, bound, interpolation, extrapolate,
     need_grid = grid.requires_grad if need_grid is None else need_grid
     grad_inp = grad_grid = None
     if need_inp:
-        grad_inp = grid_pushgrad(grad, grid, inp.shape[-dim:], bound, interpolation, extrapolate)
+        grad_inp = grid_pushgrad(grad, grid, inp.shape[-dim:], bound, interpolation, extrapolate, displacement)
     if need_grid:
-        hess = grid_hess(inp, grid, bound, interpolation, extrapolate)
+        hess = grid_hess(inp, grid, bound, interpolation, extrapolate, displacement)
         grad_grid = (hess * grad.unsqueeze(-1)).sum(dim=[1, -2])
     return grad_inp, grad_grid
