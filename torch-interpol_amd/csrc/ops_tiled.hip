@@ -1031,13 +1031,27 @@ __device__ __forceinline__ bool scatter_channel(const KParams &p, const Lattice 
     const float inv_scale = __int_as_float((127 - 29 + ex) << 23);
 
     if (!finite || nslow > SLOWCAP) {
-        // pathological tile (non-finite data, or the deformation does not fit the box):
-        // per-thread float atomics straight to global memory
-#pragma unroll 1
-        for (int v = 0; v < C::VPT; ++v) {
-            const Sample<C> s = load_sample<C>(p, grid, b, g, tid, v);
-            if (!s.valid || (p.dbg & 2)) continue;
-            scatter_one_thread(L, vc, src_of(s), s.i0[0], s.i0[1], s.i0[2], s.t[0], s.t[1], s.t[2]);
+        // The deformation does not fit the box (expanding / very rough fields, config 4) or the
+        // data are non-finite: every sample of the tile goes the slow-list way -- one wave per
+        // sample, lanes = taps, float atomics straight to global memory.  A wave instruction then
+        // touches the (K+1)^2 rows of ONE stencil (contiguous runs of K+1 floats) instead of 64
+        // unrelated cache lines as with one sample per lane.
+        const int wave = tid >> 6, lane = tid & 63;
+        const int NTAP = (L.k[0] + 1) * (L.k[1] + 1) * (L.k[2] + 1);
+        for (int code = wave; code < C::NS; code += C::NT / 64) {
+            int ox, oy, oz;
+            sample_pos<C>(g, code / C::VPT, code % C::VPT, ox, oy, oz);
+            if (!(ox < g.gx && oy < g.gy && oz < g.gz) || (p.dbg & 2)) continue;     // wave-uniform
+            float x[3];
+            const int64_t o = slow_sample<C>(g, code, p, grid, b, x);
+            float sv = src_slow(o);
+            if (p.extrapolate != 1 && !coords_inb<C>(p, x)) sv *= 0.f;
+            for (int t0 = 0; t0 < NTAP; t0 += 64) {
+                int off;
+                const float w = tap_weight(L, x[0], x[1], x[2], t0 + lane, &off, nullptr);
+                if (t0 + lane < NTAP)
+                    __hip_atomic_fetch_add(vc + off, w * sv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
         }
         return box_is_zero;
     }
