@@ -588,7 +588,7 @@ def test_separable_grid_matches_dense_grid(dim, order):
         _same(ga, gd, 2e-6, ("pull_backward", dim, order, flags))
         gva = _hip.push_backward(vol, src, sep, b, o, 1, True, False, flags=flags)[0]
         gvd = _hip.push_backward(vol, src, dense, b, o, 1, True, False, flags=flags)[0]
-        assert torch.equal(gva, gvd), ("push_backward", dim, order, flags)
+        _same(gva, gvd, 2e-6, ("push_backward", dim, order, flags))      # sep: generic kernel, dense: tiled
     with pytest.raises(RuntimeError):
         _hip.pull_backward(src, vol, sep, b, o, 1, True, True)
 

@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """Per-phase cycle shares of the tiled push kernel (needs ops_tiled built with -DIP_PROF:
-   rm torch-interpol_amd/build/ops_tiled_f32.o && make -C torch-interpol_amd PROF=1)."""
+   rm torch-interpol_amd/build/ops_tiled_f32_[12].o && make -C torch-interpol_amd PROF=1)."""
 import os, sys, json, ctypes
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "torch-interpol_amd")); sys.path.insert(0, ROOT)
@@ -13,8 +13,9 @@ dev = torch.device("cuda", 0)
 sigma = float(sys.argv[1]) if len(sys.argv) > 1 else 2.0
 inp, grid = bench.make_inputs(4, 2, 256, sigma, dev, 1234)
 L = _hip.lib()
-fn = L.interpol_debug_prof_f32
-fn.argtypes = [ctypes.c_void_p, ctypes.c_int]
+FN = {"pull": L.interpol_debug_prof_f32_1, "push": L.interpol_debug_prof_f32_2}
+for f in FN.values():
+    f.argtypes = [ctypes.c_void_p, ctypes.c_int]
 buf = (ctypes.c_ulonglong * 16)()
 def run(op):
     if op == "push":
@@ -23,6 +24,7 @@ def run(op):
         _hip.gather("pull", inp, grid, [3] * 3, [3] * 3, 1)
     torch.cuda.synchronize()
 for op in ("push", "pull"):
+  fn = FN[op]
   run(op); fn(None, 1); run(op); fn(buf, 1)
   tot = sum(buf)
   print(op, json.dumps({"sigma": sigma, "total_cycles_per_block_sum": tot,

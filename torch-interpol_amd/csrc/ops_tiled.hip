@@ -73,11 +73,17 @@ __device__ __forceinline__ void prof_mark(int i)
 #ifndef IP_LDS_PAD
 #define IP_LDS_PAD 0
 #endif
-template <typename T_, int K_, bool ISO_, int D_, int TX_, int TY_, int TZ_, int NT_, int PZ_>
+template <typename T_, int K_, bool ISO_, int D_, int TX_, int TY_, int TZ_, int NT_, int PZ_, int GM_ = 0>
 struct Cfg {
     using T = T_;
     static constexpr bool ISO = ISO_;
     static constexpr int K = K_, D = D_, TX = TX_, TY = TY_, TZ = TZ_, NT = NT_, PZ = PZ_;
+    // Coordinate mode.  0: dense (B,*out,D) grid -- the hot kernels, nothing else in their way
+    // (they sit at the 128-VGPR limit: folding the other modes in at run time cost 0.3 ms of 2.5);
+    // 1: separable lattice (INTERPOL_FLAG_SEPARABLE_GRID), 2: displacement field
+    // (INTERPOL_FLAG_DISPLACEMENT) -- own instantiations of the forward kernels, see launch_*.
+    static constexpr int GM = GM_;
+    template <int G> using Mode = Cfg<T_, K_, ISO_, D_, TX_, TY_, TZ_, NT_, PZ_, G>;
     // LDS row stride in slots: odd, so that rows (x, y) of the box start in different banks
     static constexpr int PS = PZ_ + IP_LDS_PAD;
     static constexpr int NS = TX * TY * TZ;            // samples per tile
@@ -264,9 +270,13 @@ __device__ __noinline__ void scatter_one_thread(Lattice L, float *vc, float src,
 // offset in *off_out and, when grads != nullptr, the three derivative weights (times the
 // value weights of the other dims).  The degenerate x of a 2-D problem has order 0 and
 // weight bspline_w(0, .) = 1.
-__device__ __noinline__ float tap_weight(Lattice L, float gx_, float gy_, float gz_, int tap, int *off_out, float *grads)
+// KX, KC: compile-time orders along x and along y / z for ISO tiles (folds the tap decode and
+// the spline switch), -1 = runtime orders of L.
+template <int KX, int KC>
+__device__ __noinline__ float tap_weight_t(Lattice L, float gx_, float gy_, float gz_, int tap, int *off_out, float *grads)
 {
-    const int k1[3] = { L.k[0] + 1, L.k[1] + 1, L.k[2] + 1 };
+    const int kk[3] = { KX >= 0 ? KX : L.k[0], KC >= 0 ? KC : L.k[1], KC >= 0 ? KC : L.k[2] };
+    const int k1[3] = { kk[0] + 1, kk[1] + 1, kk[2] + 1 };
     const bool on = tap < k1[0] * k1[1] * k1[2];
     const int tp[3] = { on ? tap / (k1[1] * k1[2]) : 0, on ? (tap / k1[2]) % k1[1] : 0, on ? tap % k1[2] : 0 };
     const float g[3] = { gx_, gy_, gz_ };
@@ -275,13 +285,18 @@ __device__ __noinline__ float tap_weight(Lattice L, float gx_, float gy_, float 
 #pragma unroll
     for (int d = 0; d < 3; ++d) {
         int i0; float t;
-        split(L.k[d], g[d], i0, t);
-        if (L.n[d] == 1 && L.ss[d] == 0 && L.k[d] == 0) i0 = 0;       // degenerate dim: coordinate is a dummy
-        const long long pk = wrap_outofline(L.bound[d], i0 + tp[d], L.n[d]);
-        const float s = (float)(int)(pk >> 32);
-        w[d] = weight1(L.lin, L.k[d], t, tp[d]) * s;
-        dw[d] = grads ? wgrad1(L.lin, L.k[d], t, tp[d]) * s : 0.f;
-        off += (int)(pk & 0xffffffffll) * L.ss[d];
+        split(kk[d], g[d], i0, t);
+        if (L.n[d] == 1 && L.ss[d] == 0 && kk[d] == 0) i0 = 0;       // degenerate dim: coordinate is a dummy
+        const int idx = i0 + tp[d];
+        int widx = idx; float s = 1.f;
+        if ((unsigned)idx >= (unsigned)L.n[d] || (L.bound[d] == B_DST1 && idx == 0)) {   // border taps only: Bound.index / transform (dst1: sign 0 at index 0, quirk B-3)
+            const long long pk = wrap_outofline(L.bound[d], idx, L.n[d]);
+            widx = (int)(pk & 0xffffffffll);
+            s = (float)(int)(pk >> 32);
+        }
+        w[d] = weight1(L.lin, kk[d], t, tp[d]) * s;
+        dw[d] = grads ? wgrad1(L.lin, kk[d], t, tp[d]) * s : 0.f;
+        off += widx * L.ss[d];
     }
     *off_out = off;
     const float m = on ? 1.f : 0.f;
@@ -291,6 +306,12 @@ __device__ __noinline__ float tap_weight(Lattice L, float gx_, float gy_, float 
         grads[2] = m * w[0] * w[1] * dw[2];
     }
     return m * w[0] * w[1] * w[2];
+}
+// (call as tap_weight<C>(...) inside the kernels)
+template <typename C>
+__device__ __forceinline__ float tap_weight(const Lattice &L, float gx_, float gy_, float gz_, int tap, int *off_out, float *grads)
+{
+    return tap_weight_t<C::ISO ? C::KX : -1, C::ISO ? C::K : -1>(L, gx_, gy_, gz_, tap, off_out, grads);
 }
 
 // ---------------------------------------------------------------------------
@@ -356,20 +377,20 @@ __device__ __forceinline__ bool load_coords(const KParams &p, const float *__res
     const bool valid = ox < g.gx && oy < g.gy && oz < g.gz;
     ox = ox < g.gx ? ox : g.gx - 1; oy = oy < g.gy ? oy : g.gy - 1; oz = oz < g.gz ? oz : g.gz - 1;
     o = ((int64_t)ox * g.gy + oy) * g.gz + oz;
-    if (p.sep == 1) {
-        // tensor-product coordinates (INTERPOL_FLAG_SEPARABLE_GRID): lin_x | lin_y | lin_z back to back
+    if constexpr (C::GM == 1) {
+        // tensor-product coordinates: the vectors lin_x | lin_y | lin_z back to back
         x[0] = C::D == 3 ? grid[ox] : 0.f;
         x[1] = grid[(C::D == 3 ? g.gx : 0) + oy];
         x[2] = grid[(C::D == 3 ? g.gx : 0) + g.gy + oz];
-        return valid;
-    }
-    const float *gp = grid + b * p.grid_sb + o * C::D;
+    } else {
+        const float *gp = grid + b * p.grid_sb + o * C::D;
 #pragma unroll
-    for (int d = 0; d < 3; ++d) x[d] = C::pd(d) >= 0 ? gp[C::pd(d) < 0 ? 0 : C::pd(d)] : 0.f;
-    if (p.sep == 2) {   // displacement field (INTERPOL_FLAG_DISPLACEMENT): add the identity lattice
-        if (C::D == 3) x[0] += (float)ox;
-        x[1] += (float)oy;
-        x[2] += (float)oz;
+        for (int d = 0; d < 3; ++d) x[d] = C::pd(d) >= 0 ? gp[C::pd(d) < 0 ? 0 : C::pd(d)] : 0.f;
+        if constexpr (C::GM == 2) {                        // displacement field: add the identity lattice
+            if (C::D == 3) x[0] += (float)ox;
+            x[1] += (float)oy;
+            x[2] += (float)oz;
+        }
     }
     return valid;
 }
@@ -578,7 +599,7 @@ __device__ __forceinline__ int64_t slow_sample(const TileGeom &g, int code, cons
     int ox, oy, oz;
     sample_pos<C>(g, stid, sv, ox, oy, oz);
     const int64_t o = ((int64_t)ox * g.gy + oy) * g.gz + oz;
-    if (p.sep == 1) {
+    if (C::GM == 1) {
         x[0] = C::D == 3 ? grid[ox] : 0.f;
         x[1] = grid[(C::D == 3 ? g.gx : 0) + oy];
         x[2] = grid[(C::D == 3 ? g.gx : 0) + g.gy + oz];
@@ -587,7 +608,7 @@ __device__ __forceinline__ int64_t slow_sample(const TileGeom &g, int code, cons
     const float *gp = grid + b * p.grid_sb + o * C::D;
 #pragma unroll
     for (int d = 0; d < 3; ++d) x[d] = C::pd(d) >= 0 ? gp[C::pd(d) < 0 ? 0 : C::pd(d)] : 0.f;
-    if (p.sep == 2) {
+    if (C::GM == 2) {
         if (C::D == 3) x[0] += (float)ox;
         x[1] += (float)oy;
         x[2] += (float)oz;
@@ -763,7 +784,7 @@ __global__ __launch_bounds__(C::NT) void gather_tiled(KParams p, const typename 
                 float a[4] = { 0.f, 0.f, 0.f, 0.f };
                 for (int t0 = 0; t0 < NTAP; t0 += 64) {
                     int off; float gr[3];
-                    const float w = tap_weight(L, x[0], x[1], x[2], t0 + lane, &off, GRAD ? gr : nullptr);
+                    const float w = tap_weight<C>(L, x[0], x[1], x[2], t0 + lane, &off, GRAD ? gr : nullptr);
                     const float v = (t0 + lane < NTAP) ? Cvt<float, T>::ld(vc[off]) : 0.f;
                     if (!GRAD) a[0] += w * v;
                     else { a[1] += gr[0] * v; a[2] += gr[1] * v; a[3] += gr[2] * v; }
@@ -931,7 +952,7 @@ __global__ __launch_bounds__(C::NT) void pull2_tiled(KParams p, const typename C
                 float a0 = 0.f, a1 = 0.f;
                 for (int t0 = 0; t0 < NTAP; t0 += 64) {
                     int off;
-                    const float w = tap_weight(L, x[0], x[1], x[2], t0 + lane, &off, nullptr);
+                    const float w = tap_weight<C>(L, x[0], x[1], x[2], t0 + lane, &off, nullptr);
                     if (t0 + lane < NTAP) { a0 += w * Cvt<float, T>::ld(vc0[off]); a1 += w * Cvt<float, T>::ld(vc1[off]); }
                 }
                 const float m = (p.extrapolate != 1 && !coords_inb<C>(p, x)) ? 0.f : 1.f;
@@ -1048,7 +1069,7 @@ __device__ __forceinline__ bool scatter_channel(const KParams &p, const Lattice 
             if (p.extrapolate != 1 && !coords_inb<C>(p, x)) sv *= 0.f;
             for (int t0 = 0; t0 < NTAP; t0 += 64) {
                 int off;
-                const float w = tap_weight(L, x[0], x[1], x[2], t0 + lane, &off, nullptr);
+                const float w = tap_weight<C>(L, x[0], x[1], x[2], t0 + lane, &off, nullptr);
                 if (t0 + lane < NTAP)
                     __hip_atomic_fetch_add(vc + off, w * sv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
@@ -1067,7 +1088,7 @@ __device__ __forceinline__ bool scatter_channel(const KParams &p, const Lattice 
             if (p.extrapolate != 1 && !coords_inb<C>(p, x)) sv *= 0.f;
             for (int t0 = 0; t0 < NTAP; t0 += 64) {
                 int off;
-                const float w = tap_weight(L, x[0], x[1], x[2], t0 + lane, &off, nullptr);
+                const float w = tap_weight<C>(L, x[0], x[1], x[2], t0 + lane, &off, nullptr);
                 if (t0 + lane < NTAP)
                     __hip_atomic_fetch_add(vc + off, w * sv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
@@ -1261,7 +1282,7 @@ __device__ __forceinline__ bool scatter_pair(const KParams &p, const Lattice &L,
             if (p.extrapolate != 1 && !coords_inb<C>(p, x)) { sv0 *= 0.f; sv1 *= 0.f; }
             for (int t0 = 0; t0 < NTAP; t0 += 64) {
                 int off;
-                const float w = tap_weight(L, x[0], x[1], x[2], t0 + lane, &off, nullptr);
+                const float w = tap_weight<C>(L, x[0], x[1], x[2], t0 + lane, &off, nullptr);
                 if (t0 + lane < NTAP) {
                     __hip_atomic_fetch_add(vc0 + off, w * sv0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     __hip_atomic_fetch_add(vc1 + off, w * sv1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1479,7 +1500,7 @@ __global__ __launch_bounds__(C::NT) void pullbwd_tiled(KParams p, const typename
                     float a[3] = { 0.f, 0.f, 0.f };
                     for (int t0 = 0; t0 < NTAP; t0 += 64) {
                         int off; float gr[3];
-                        tap_weight(L, x[0], x[1], x[2], t0 + lane, &off, gr);
+                        tap_weight<C>(L, x[0], x[1], x[2], t0 + lane, &off, gr);
                         const float vv = (t0 + lane < NTAP) ? Cvt<float, T>::ld(vc[off]) : 0.f;
                         a[0] += gr[0] * vv; a[1] += gr[1] * vv; a[2] += gr[2] * vv;
                     }
@@ -1586,7 +1607,7 @@ __global__ __launch_bounds__(C::NT) void pushbwd_tiled(KParams p, const typename
                 float a[4] = { 0.f, 0.f, 0.f, 0.f };
                 for (int t0 = 0; t0 < NTAP; t0 += 64) {
                     int off; float gr[3];
-                    const float w = tap_weight(L, x[0], x[1], x[2], t0 + lane, &off, gr);
+                    const float w = tap_weight<C>(L, x[0], x[1], x[2], t0 + lane, &off, gr);
                     const float vv = (t0 + lane < NTAP) ? Cvt<float, T>::ld(vc[off]) : 0.f;
                     a[0] += w * vv; a[1] += gr[0] * vv; a[2] += gr[1] * vv; a[3] += gr[2] * vv;
                 }
@@ -1670,7 +1691,7 @@ static int big_lds(F kernel)
 #define IP_CHECK_LAUNCH() do { const hipError_t e_ = hipGetLastError(); return e_ == hipSuccess ? 1 : (int)e_; } while (0)
 
 template <typename C>
-static int launch_pull2(const interpol_problem *p, const KParams &k, const void *vol, const void *grid, void *val, hipStream_t st)
+static int launch_pull2_impl(const interpol_problem *p, const KParams &k, const void *vol, const void *grid, void *val, hipStream_t st)
 {
     using T = typename C::T;
     if constexpr (C::D == 3) {
@@ -1686,11 +1707,11 @@ static int launch_pull2(const interpol_problem *p, const KParams &k, const void 
 }
 
 template <typename C, bool GRAD>
-static int launch_gather(const interpol_problem *p, const KParams &k, const void *vol, const void *grid, void *val, hipStream_t st)
+static int launch_gather_impl(const interpol_problem *p, const KParams &k, const void *vol, const void *grid, void *val, hipStream_t st)
 {
     using T = typename C::T;
     // pull with an even channel count: two channels per LDS slot (unless disabled for A/B tests)
-    if (!GRAD && C::D == 3 && p->channels % 2 == 0 && !(k.dbg & 4)) return launch_pull2<C>(p, k, vol, grid, val, st);
+    if (!GRAD && C::D == 3 && p->channels % 2 == 0 && !(k.dbg & 4)) return launch_pull2_impl<C>(p, k, vol, grid, val, st);
     const int attr = big_lds<C>(gather_tiled<C, GRAD>);
     if (attr) return attr;
     const TileCount<C> t(p);
@@ -1700,7 +1721,7 @@ static int launch_gather(const interpol_problem *p, const KParams &k, const void
 }
 
 template <typename C>
-static int launch_push(const interpol_problem *p, const KParams &k, const void *val, const void *grid, void *vol, hipStream_t st)
+static int launch_push_impl(const interpol_problem *p, const KParams &k, const void *val, const void *grid, void *vol, hipStream_t st)
 {
     using T = typename C::T;
     const int attr = val ? big_lds<C>(push_tiled<C, false>) : big_lds<C>(push_tiled<C, true>);
@@ -1715,11 +1736,45 @@ static int launch_push(const interpol_problem *p, const KParams &k, const void *
     IP_CHECK_LAUNCH();
 }
 
+// Coordinate mode dispatch (Cfg::GM): the dense-grid instantiation, or the general one for
+// separable lattices / displacement fields (forward kernels only; the fused backward kernels
+// leave those modes to the generic kernels -- the backward of pull w.r.t. the image alone is a push).
+template <typename C, bool GRAD>
+static int launch_gather(const interpol_problem *p, const KParams &k, const void *vol, const void *grid, void *val, hipStream_t st)
+{
+    if (k.sep) {
+        // own instantiations for fp32 storage, 3-D, isotropic orders 1-3 (linear ... cubic resize
+        // and displacement fields); everything else in these modes runs the generic kernels --
+        // keeps the build short
+        if constexpr (std::is_same<typename C::T, float>::value && C::D == 3 && C::ISO && C::K <= 3) {
+            if (k.sep == 1) return launch_gather_impl<typename C::template Mode<1>, GRAD>(p, k, vol, grid, val, st);
+            return launch_gather_impl<typename C::template Mode<2>, GRAD>(p, k, vol, grid, val, st);
+        } else {
+            return 0;
+        }
+    }
+    return launch_gather_impl<C, GRAD>(p, k, vol, grid, val, st);
+}
+template <typename C>
+static int launch_push(const interpol_problem *p, const KParams &k, const void *val, const void *grid, void *vol, hipStream_t st)
+{
+    if (k.sep) {
+        if constexpr (std::is_same<typename C::T, float>::value && C::D == 3 && C::ISO && C::K <= 3) {
+            if (k.sep == 1) return launch_push_impl<typename C::template Mode<1>>(p, k, val, grid, vol, st);
+            return launch_push_impl<typename C::template Mode<2>>(p, k, val, grid, vol, st);
+        } else {
+            return 0;
+        }
+    }
+    return launch_push_impl<C>(p, k, val, grid, vol, st);
+}
+
 template <typename C>
 static int launch_pullbwd(const interpol_problem *p, const KParams &k, const void *gout, const void *vol, const void *grid,
                           void *gvol, void *ggrid, int64_t gsb, int64_t gsc, hipStream_t st)
 {
     using T = typename C::T;
+    if (k.sep) return 0;                                   // declined: generic kernels
     const int attr = big_lds<C>(pullbwd_tiled<C>);
     if (attr) return attr;
     const TileCount<C> t(p);
@@ -1734,6 +1789,7 @@ static int launch_pushbwd(const interpol_problem *p, const KParams &k, const voi
                           void *gval, void *ggrid, hipStream_t st)
 {
     using T = typename C::T;
+    if (k.sep) return 0;
     const int attr = big_lds<C>(pushbwd_tiled<C>);
     if (attr) return attr;
     const TileCount<C> t(p);
@@ -1773,6 +1829,7 @@ static TiledPick tiled_pick(const interpol_problem *p, const KParams &k)
         nt *= (p->grid_shape[d] + 7) / 8;
     }
     if (n < 4096 || nt > 0x7fffffff) return no;     // tiny problems: the generic kernel has less fixed cost
+    if ((uint64_t)n * (uint64_t)p->dim * 4ull > 0xffffffffull) return no;   // 32-bit byte offsets into one item's grid
     bool same = true; int mx = 0;
     for (int d = 0; d < p->dim; ++d) { same = same && k.order[d] == k.order[0]; mx = k.order[d] > mx ? k.order[d] : mx; }
     if (mx < 1 || mx > 7) return no;
@@ -1809,10 +1866,13 @@ static TiledPick tiled_pick(const interpol_problem *p, const KParams &k)
 #define IP_SYM2(a, b) a##b
 #define IP_SYM(a, b) IP_SYM2(a, b)
 
-// One translation unit per storage type (IP_TT / IP_TSFX given on the command line);
+// One translation unit per storage type (IP_TT / IP_TSFX given on the command line) and kernel
+// family (IP_TPART: 1 gathers, 2 scatters, 3 fused backward kernels; all when undefined), so
+// that the build spreads over the cores;
 // each returns 1 when it took the problem, 0 to decline (the generic kernels run).
 // 2-D gathers stay on the generic kernel: with (K+1)^2 taps per sample the direct gather is
 // already cheaper than staging a tile (measured at config 5: 1.36 ms generic vs 2.19 ms tiled).
+#if !defined(IP_TPART) || IP_TPART == 1
 int IP_SYM(try_fast_pull_, IP_TSFX)(const interpol_problem *p, const KParams &k, const void *vol, const void *grid, void *val, hipStream_t st)
 {
     if (p->dim != 3 && !(p->flags & INTERPOL_FLAG_FORCE_TILED)) return 0;
@@ -1825,12 +1885,18 @@ int IP_SYM(try_fast_grad_, IP_TSFX)(const interpol_problem *p, const KParams &k,
     IP_BY_ORDER(tiled::launch_gather, , true>(p, k, vol, grid, val, st))
 }
 
+#endif
+
+#if !defined(IP_TPART) || IP_TPART == 2
 // `vol` is the (already zero-filled or accumulating) FLOAT target; `val` == NULL means count.
 int IP_SYM(try_fast_push_, IP_TSFX)(const interpol_problem *p, const KParams &k, const void *val, const void *grid, void *vol, hipStream_t st)
 {
     IP_BY_ORDER(tiled::launch_push, >(p, k, val, grid, vol, st))
 }
 
+#endif
+
+#if !defined(IP_TPART) || IP_TPART == 3
 int IP_SYM(try_fast_pullbwd_, IP_TSFX)(const interpol_problem *p, const KParams &k, const void *gout, const void *vol, const void *grid,
                                        void *gvol, void *ggrid, int64_t gsb, int64_t gsc, hipStream_t st)
 {
@@ -1843,13 +1909,18 @@ int IP_SYM(try_fast_pushbwd_, IP_TSFX)(const interpol_problem *p, const KParams 
     if (p->dim != 3 && !(p->flags & INTERPOL_FLAG_FORCE_TILED)) return 0;
     IP_BY_ORDER(tiled::launch_pushbwd, >(p, k, gvol_out, val, grid, gval, ggrid, st))
 }
+#endif
 
 } // namespace ip
 
 #ifdef IP_PROF
-#define IP_PROF_NAME2(s) interpol_debug_prof_##s
-#define IP_PROF_NAME(s) IP_PROF_NAME2(s)
-extern "C" __attribute__((visibility("default"))) int IP_PROF_NAME(IP_TSFX)(unsigned long long *out, int reset)
+// one counter block per translation unit: interpol_debug_prof_<dtype>_<part>
+#ifndef IP_TPART
+#define IP_TPART 0
+#endif
+#define IP_PROF_NAME3(s, q) interpol_debug_prof_##s##_##q
+#define IP_PROF_NAME2(s, q) IP_PROF_NAME3(s, q)
+extern "C" __attribute__((visibility("default"))) int IP_PROF_NAME2(IP_TSFX, IP_TPART)(unsigned long long *out, int reset)
 {
     unsigned long long z[16] = { 0 };
     if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(ip::tiled::g_prof), sizeof z) != hipSuccess) return -1;

@@ -13,7 +13,8 @@ import torch
 from .sepgrid import SeparableGrid
 
 _PKG_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-LIB_PATH = os.path.join(_PKG_ROOT, "lib", "libinterpol_hip.so")
+# INTERPOL_HIP_LIB: another build of the same library (A/B timing of kernel variants)
+LIB_PATH = os.environ.get("INTERPOL_HIP_LIB") or os.path.join(_PKG_ROOT, "lib", "libinterpol_hip.so")
 
 ABI_VERSION = 1
 F32, F64, BF16, F16 = 0, 1, 2, 3
