@@ -164,6 +164,22 @@ int interpol_push_backward(const interpol_problem *p, const void *grad_vol_out, 
 int interpol_count_backward(const interpol_problem *p, const void *grad_vol_out, const void *grid,
                             void *grad_grid, void *stream);
 
+/* --- separable resampling ------------------------------------------------------
+ * interpol_resample_1d: one pass of a tensor-product resampling -- what `resize` / `restrict`
+ * (interpol/resize.py:13-119, restrict.py:9-121) compute through grid_pull / grid_push on
+ * `stack(meshgrid_ij(*lin), -1)`, factorised into D one-dimensional passes (K+1 taps per
+ * output instead of (K+1)^D; no grid tensor).  Contiguous (outer, n, inner) arrays.
+ *   adjoint == 0 : src (outer, n_lattice, inner), lin[n_samples] -> dst (outer, n_samples, inner)
+ *                  dst[b,s,c] = mask(lin[s]) * sum_j w_j sign_j src[b, wrap(i0+j), c]
+ *   adjoint == 1 : src (outer, n_samples, inner) -> dst (outer, n_lattice, inner), zero-filled
+ *                  here; the exact adjoint of the above (f32 / f64 only)
+ * `mode`: 0 nd, 1 iso1, 2 iso0 semantics -- decided by ALL dims of the D-dimensional
+ * operator (pushpull.py:48-66), so the caller passes it.  lin is float32 (float64 for F64
+ * data).  n_lattice * inner * sizeof(element) must be < 4 GiB, n_samples * inner < 2^32. */
+int interpol_resample_1d(int32_t dtype, int32_t lin_dtype, int32_t order, int32_t bound, int32_t extrapolate, int32_t mode,
+                         int32_t adjoint, int64_t outer, int64_t n_samples, int64_t n_lattice, int64_t inner,
+                         const void *src, const void *lin, void *dst, void *stream);
+
 /* --- prefilter -----------------------------------------------------------------
  * interpol_spline_filter replaces coeff.spline_coeff (interpol/coeff.py:288-313,
  * filter coeff.py:258-284): in-place interpolating-coefficient IIR along the

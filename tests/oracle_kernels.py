@@ -75,3 +75,17 @@ class OracleKernels:
     def spline_filter_(data, bound, order, dim):
         data.copy_(oracle.spline_coeff(data.detach(), bound, order, dim=dim))
         return data
+
+    @staticmethod
+    def resample1d(src, lin, dim, order, bound, extrapolate, mode, adjoint, n_lattice):
+        """1-D pass through the oracle's 1-D pull / push (batch = every other index)."""
+        x = src.detach().movedim(dim, -1)
+        lead = x.shape[:-1]
+        x = x.reshape(-1, 1, x.shape[-1])
+        grid = lin.detach().to(x.dtype).reshape(1, -1, 1).expand(x.shape[0], -1, 1)
+        if adjoint:
+            r = oracle.grid_push(x, grid, [int(n_lattice)], [bound], [order], extrapolate)
+        else:
+            r = oracle.grid_pull(x, grid, [bound], [order], extrapolate)
+        r = torch.as_tensor(r).to(src.dtype)
+        return r.reshape(*lead, r.shape[-1]).movedim(-1, dim).contiguous()

@@ -652,3 +652,34 @@ def test_displacement_flag_matches_identity_plus_displacement(dim):
     gb = torch.autograd.grad(bb.square().sum(), [x, d])
     _same(ga[0], gb[0], 1e-5, "api grad input")
     _same(ga[1], gb[1], 1e-5, "api grad displacement")
+
+
+@pytest.mark.parametrize("order", [0, 1, 2, 3, 5, 7])
+def test_resample1d_passes(order):
+    """interpol_resample_1d: forward == 1-D grid_pull along that dim (all bounds, extrapolate
+    modes, middle and last dims, fp64 / fp32 / bf16), adjoint == exact transpose (fp64 dot test)."""
+    from interpol import _hip
+    g = torch.Generator().manual_seed(order)
+    x = torch.randn([3, 13, 5, 11], generator=g, dtype=torch.float64).to(DEV)
+    for dim, n in ((1, 13), (3, 11), (2, 5)):
+        lin = (torch.linspace(-2.5, n + 1.5, 17, dtype=torch.float64) + 0.05 * torch.randn(17, generator=g, dtype=torch.float64)).to(DEV)
+        for bound in range(7):
+            for ex in (0, 1, 2):
+                mode = 1 if order == 1 else (2 if order == 0 else 0)
+                got = _hip.resample1d(x, lin, dim, order, bound, ex, mode)
+                xm = x.movedim(dim, -1).reshape(-1, 1, n)
+                ref = _hip.gather("pull", xm, lin.reshape(1, -1, 1), [bound], [order], ex)
+                ref = ref.reshape(*x.movedim(dim, -1).shape[:-1], 17).movedim(-1, dim)
+                _same(got, ref, 1e-12, ("fwd", order, dim, bound, ex))
+                y = torch.randn(got.shape, generator=g, dtype=torch.float64).to(DEV)
+                adj = _hip.resample1d(y, lin, dim, order, bound, ex, mode, adjoint=True, n_lattice=n)
+                lhs, rhs = float((got * y).sum()), float((x * adj).sum())
+                assert abs(lhs - rhs) <= 1e-10 * max(abs(lhs), abs(rhs), 1.0), ("adjoint", order, dim, bound, ex)
+        got32 = _hip.resample1d(x.float(), lin.float(), dim, order, 3, 1, 0)
+        _same(got32.double(), _hip.resample1d(x.float().double(), lin.float().double(), dim, order, 3, 1, 0),
+              5e-5 if order >= 6 else 1e-5, "f32")
+        gotbf = _hip.resample1d(x.bfloat16(), lin.float(), dim, order, 3, 1, 0)
+        assert gotbf.dtype == torch.bfloat16
+        _same(gotbf.double(), _hip.resample1d(x.bfloat16().double(), lin.float().double(), dim, order, 3, 1, 0), 1e-2, "bf16")
+    with pytest.raises(RuntimeError):
+        _hip.resample1d(y.bfloat16(), lin.float(), dim, order, 3, 1, 0, adjoint=True, n_lattice=n)

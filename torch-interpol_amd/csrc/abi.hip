@@ -34,6 +34,8 @@ IP_DECL2(f32) IP_DECL2(f64)
 #undef IP_DECL2
 
 int launch_filter(int dtype, const FilterParams &fp, void *data, hipStream_t st);
+int launch_resample1d(int dtype, int lin_f64, int order, const KParams &p, int adjoint, const void *src, const void *lin, void *dst,
+                      unsigned ns, unsigned inner, int64_t nl, int64_t outer, hipStream_t st);
 
 // fast paths (ops_tiled.hip, one translation unit per storage type); each returns 1 when it
 // took the problem, 0 to decline, <0 / >0 on error
@@ -466,6 +468,41 @@ int interpol_spline_filter(void *data, int32_t dtype, int64_t outer, int64_t n, 
     fp.gain = 1.;
     for (int i = 0; i < fp.npoles; ++i) fp.gain *= (1. - fp.pole[i]) * (1. - 1. / fp.pole[i]);   // coeff.py:69-73
     return launch_filter(dtype, fp, data, (hipStream_t)stream);
+}
+
+int interpol_resample_1d(int32_t dtype, int32_t lin_dtype, int32_t order, int32_t bound, int32_t extrapolate, int32_t mode,
+                         int32_t adjoint, int64_t outer, int64_t n_samples, int64_t n_lattice, int64_t inner,
+                         const void *src, const void *lin, void *dst, void *stream)
+{
+    if (!src || !lin || !dst) return INTERPOL_E_NULL;
+    if (dtype < 0 || dtype > 3 || (lin_dtype != INTERPOL_F32 && lin_dtype != INTERPOL_F64)) return INTERPOL_E_DTYPE;
+    if (order < 0 || order > 7) return INTERPOL_E_ORDER;
+    if (bound < 0 || bound > 6) return INTERPOL_E_BOUND;
+    if (extrapolate < 0 || extrapolate > 2) return INTERPOL_E_EXTRAP;
+    if (mode < 0 || mode > 2) return INTERPOL_E_SHAPE;
+    if (outer < 0 || n_samples < 0 || n_lattice < 1 || inner < 0 || n_lattice > 0x3fffffff) return INTERPOL_E_SHAPE;
+    const size_t es = esize(dtype);
+    if ((uint64_t)n_lattice * (uint64_t)inner * es > 0xffffffffull) return INTERPOL_E_SHAPE;
+    if ((uint64_t)n_samples * (uint64_t)inner > 0xffffffffull) return INTERPOL_E_SHAPE;
+    hipStream_t st = (hipStream_t)stream;
+    if (adjoint) {
+        const hipError_t e = hipMemsetAsync(dst, 0, (size_t)outer * (size_t)n_lattice * (size_t)inner * es, st);
+        if (e != hipSuccess) return (int)e;
+    }
+    if (outer == 0 || n_samples == 0 || inner == 0) return 0;
+    KParams k;
+    memset(&k, 0, sizeof(k));
+    k.dim = 1;
+    k.extrapolate = extrapolate;
+    k.mode = mode;
+    k.bound[0] = bound; k.order[0] = order; k.vol_n[0] = (int)n_lattice; k.vol_ss[0] = (int)((uint64_t)inner * es);
+    for (int d = 1; d < 3; ++d) { k.bound[d] = 1; k.vol_n[d] = 1; }
+    k.C = 1;
+    k.N = n_samples;
+    k.mask_lo = -(extrapolate == 2 ? 0.5 + 5e-2 : 5e-2);
+    k.mask_hi[0] = (double)(n_lattice - 1) + (extrapolate == 2 ? 0.5 + 5e-2 : 5e-2);
+    return launch_resample1d(dtype, lin_dtype == INTERPOL_F64, order, k, adjoint, src, lin, dst, (unsigned)n_samples, (unsigned)inner,
+                             n_lattice, outer, st);
 }
 
 // ---- host-side scalar primitives (no GPU) ------------------------------------

@@ -1,0 +1,94 @@
+// One-dimensional B-spline resampling along ONE dimension of a tensor viewed as
+// (outer, n, inner): the building block of `resize` / `restrict` on tensor-product lattices
+// (reference interpol/resize.py:96-117, restrict.py:88-118 build stack(meshgrid_ij(*lin), -1) and
+// call the D-dimensional grid_pull / grid_push: (K+1)^D taps per voxel).  The stencil of a
+// tensor-product lattice factorises, so D passes of K+1 taps give the same operator:
+//     forward : dst[b, s, c]  = mask(x_s) * sum_j w_j(x_s) sign_j src[b, wrap(i0_s + j), c]
+//     adjoint : dst[b, wrap(i0_s + j), c] += w_j(x_s) sign_j mask(x_s) src[b, s, c]
+// with x_s = lin[s]; weights, indices, signs and mask are those of csrc/stencil.hpp
+// (splines.py:30-80, bounds.py:30-89, nd.py:10-27).  One thread per (b, s, c): lanes run
+// along c when inner > 1 (coalesced rows, wave-uniform stencil), along s for the last dim.
+#include "../../include/interpol_hip.h"
+#include "stencil.hpp"
+#include <hip/hip_runtime.h>
+
+namespace ip {
+namespace {
+
+template <typename T> __device__ __forceinline__ T ld_b(const T *base, unsigned byte_off)
+{
+    return *reinterpret_cast<const T *>(reinterpret_cast<const char *>(base) + byte_off);
+}
+
+// grid: x = blocks over ns * inner, y = outer slices
+template <typename T, typename G, typename R, int K, bool ADJ>
+__global__ __launch_bounds__(256) void resample1d_kernel(KParams p, const T *__restrict__ src, const G *__restrict__ lin,
+                                                         T *__restrict__ dst, unsigned ns, unsigned inner, int64_t nl, int64_t outer)
+{
+    const unsigned r = blockIdx.x * 256u + threadIdx.x;
+    if (r >= ns * inner) return;
+    const unsigned s = r / inner, c = r - s * inner;
+    R x[1] = { (R)lin[s] };
+    Stencil<R, 1, K, true, NEED_W> st;
+    st.setup(p, x);
+    for (int64_t b = blockIdx.y; b < outer; b += gridDim.y) {
+        const T *sb = src + b * (ADJ ? (int64_t)ns : nl) * inner + c;
+        T *db = dst + b * (ADJ ? nl : (int64_t)ns) * inner + c;
+        if constexpr (!ADJ) {
+            R acc = R(0);
+#pragma unroll
+            for (int j = 0; j <= K; ++j) acc = st.w[0][j] * Cvt<R, T>::ld(ld_b(sb, st.off[0][j])) + acc;
+            db[(int64_t)s * inner] = Cvt<R, T>::st(acc * st.mask);
+        } else {
+            const R v = Cvt<R, T>::ld(sb[(int64_t)s * inner]) * st.mask;
+#pragma unroll
+            for (int j = 0; j <= K; ++j) {
+                T *q = reinterpret_cast<T *>(reinterpret_cast<char *>(db) + st.off[0][j]);
+                __hip_atomic_fetch_add(q, (T)(st.w[0][j] * v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+    }
+}
+
+template <typename T, typename G, typename R, bool ADJ>
+int launch_k(int order, const KParams &p, const void *src, const void *lin, void *dst, unsigned ns, unsigned inner, int64_t nl,
+             int64_t outer, hipStream_t st)
+{
+    const unsigned blocks = (unsigned)(((uint64_t)ns * inner + 255) / 256);
+    // The stencil of a thread depends on s only: every thread walks several outer slices with
+    // the same weights / offsets (its set-up costs ~100 instructions, a tap 2).  Enough slices
+    // in parallel to fill the chip (~16 K threads per CU), the rest in the loop.
+    int64_t ny = (int64_t)(4u << 20) / ((int64_t)blocks * 256) + 1;
+    ny = ny < outer ? ny : outer;
+    ny = ny < 65535 ? ny : 65535;
+    const dim3 grid(blocks, (unsigned)ny);
+#define IP_R1(KK) case KK: hipLaunchKernelGGL((resample1d_kernel<T, G, R, KK, ADJ>), grid, dim3(256), 0, st, p, (const T *)src, \
+                                              (const G *)lin, (T *)dst, ns, inner, nl, outer); break;
+    switch (order) { IP_R1(0) IP_R1(1) IP_R1(2) IP_R1(3) IP_R1(4) IP_R1(5) IP_R1(6) IP_R1(7) default: return INTERPOL_E_ORDER; }
+#undef IP_R1
+    const hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : (int)e;
+}
+
+} // namespace
+
+// Called by interpol_resample_1d (abi.hip).  16-bit storage: forward only.
+int launch_resample1d(int dtype, int lin_f64, int order, const KParams &p, int adjoint, const void *src, const void *lin, void *dst,
+                      unsigned ns, unsigned inner, int64_t nl, int64_t outer, hipStream_t st)
+{
+    if (dtype == INTERPOL_F64) {
+        if (!lin_f64) return INTERPOL_E_DTYPE;
+        return adjoint ? launch_k<double, double, double, true>(order, p, src, lin, dst, ns, inner, nl, outer, st)
+                       : launch_k<double, double, double, false>(order, p, src, lin, dst, ns, inner, nl, outer, st);
+    }
+    if (lin_f64) return INTERPOL_E_DTYPE;
+    if (dtype == INTERPOL_F32)
+        return adjoint ? launch_k<float, float, float, true>(order, p, src, lin, dst, ns, inner, nl, outer, st)
+                       : launch_k<float, float, float, false>(order, p, src, lin, dst, ns, inner, nl, outer, st);
+    if (adjoint) return INTERPOL_E_DTYPE;
+    if (dtype == INTERPOL_BF16) return launch_k<bf16_t, float, float, false>(order, p, src, lin, dst, ns, inner, nl, outer, st);
+    if (dtype == INTERPOL_F16) return launch_k<f16_t, float, float, false>(order, p, src, lin, dst, ns, inner, nl, outer, st);
+    return INTERPOL_E_DTYPE;
+}
+
+} // namespace ip

@@ -14,6 +14,7 @@ from .utils import identity_grid, add_identity_grid, add_identity_grid_, affine_
 from .resize import resize                                                                # noqa: F401
 from .restrict import restrict                                                            # noqa: F401
 from .sepgrid import SeparableGrid                                                        # noqa: F401
+from .separable import separable_pull, separable_push                                    # noqa: F401
 from . import backend                                                                     # noqa: F401
 
 __version__ = "0.1.0+mi355x"

@@ -30,7 +30,7 @@ _DTYPE_CODE = {torch.float32: F32, torch.float64: F64, torch.bfloat16: BF16, tor
 SYMBOLS = (
     "interpol_pull", "interpol_push", "interpol_count", "interpol_grad", "interpol_pushgrad",
     "interpol_hess", "interpol_pull_backward", "interpol_push_backward", "interpol_count_backward",
-    "interpol_spline_filter", "interpol_host_bound_index", "interpol_host_bound_sign",
+    "interpol_spline_filter", "interpol_resample_1d", "interpol_host_bound_index", "interpol_host_bound_sign",
     "interpol_host_weight", "interpol_host_weight_f32", "interpol_abi_version",
     "interpol_error_string", "interpol_kernel_name",
 )
@@ -87,9 +87,10 @@ def lib():
     L.interpol_push_backward.argtypes = [pp, vp, vp, vp, vp, vp, vp]
     L.interpol_count_backward.argtypes = [pp, vp, vp, vp, vp]
     L.interpol_spline_filter.argtypes = [vp, i32, i64, i64, i64, i32, i32, vp]
+    L.interpol_resample_1d.argtypes = [i32, i32, i32, i32, i32, i32, i32, i64, i64, i64, i64, vp, vp, vp, vp]
     for name in ("interpol_pull", "interpol_grad", "interpol_hess", "interpol_push", "interpol_pushgrad",
                  "interpol_count", "interpol_pull_backward", "interpol_push_backward",
-                 "interpol_count_backward", "interpol_spline_filter"):
+                 "interpol_count_backward", "interpol_spline_filter", "interpol_resample_1d"):
         getattr(L, name).restype = ctypes.c_int
     L.interpol_host_bound_index.argtypes = [i32, i32, i32]
     L.interpol_host_bound_index.restype = i32
@@ -436,3 +437,42 @@ def spline_filter_(data, bound, order, dim):
                                           int(bound), int(order), _stream(dev))
     _check(rc, "interpol_spline_filter")
     return data
+
+
+def resample1d(src, lin, dim, order, bound, extrapolate, mode, adjoint=False, n_lattice=None):
+    """One pass of a tensor-product resampling along `dim` (interpol_resample_1d).
+    forward: src (..., n_lattice, ...), lin (n_samples,) -> (..., n_samples, ...)
+    adjoint: src (..., n_samples, ...) -> (..., n_lattice, ...)   (f32 / f64)."""
+    dev = _require_gpu(src, lin)
+    if src.dtype not in _DTYPE_CODE:
+        raise TypeError("resample1d: unsupported dtype %s" % src.dtype)
+    src = src.contiguous()
+    ldt = torch.float64 if src.dtype == torch.float64 else torch.float32
+    lin = lin.detach().to(ldt).contiguous()
+    dim = dim % src.dim()
+    n = src.shape[dim]
+    outer = 1
+    for s_ in src.shape[:dim]:
+        outer *= s_
+    inner = 1
+    for s_ in src.shape[dim + 1:]:
+        inner *= s_
+    if adjoint:
+        if n != lin.numel():
+            raise ValueError("resample1d: the resampled dimension must match the lattice vector")
+        ns, nl = n, int(n_lattice)
+        oshape = list(src.shape[:dim]) + [nl] + list(src.shape[dim + 1:])
+    else:
+        ns, nl = lin.numel(), n
+        oshape = list(src.shape[:dim]) + [ns] + list(src.shape[dim + 1:])
+    dst = torch.empty(oshape, dtype=src.dtype, device=dev)
+    if dst.numel() == 0:
+        return dst
+    if src.numel() == 0:
+        return dst.zero_()
+    with torch.cuda.device(dev):
+        rc = lib().interpol_resample_1d(_DTYPE_CODE[src.dtype], _DTYPE_CODE[ldt], int(order), int(bound), int(extrapolate),
+                                        int(mode), int(bool(adjoint)), outer, ns, nl, inner,
+                                        _ptr(src), _ptr(lin), _ptr(dst), _stream(dev))
+    _check(rc, "interpol_resample_1d")
+    return dst

@@ -84,6 +84,10 @@ class _HipKernels:
     def spline_filter_(data, bound, order, dim):
         return _hip.spline_filter_(data, bound, order, dim)
 
+    @staticmethod
+    def resample1d(src, lin, dim, order, bound, extrapolate, mode, adjoint, n_lattice):
+        return _hip.resample1d(src, lin, dim, order, bound, extrapolate, mode, adjoint, n_lattice)
+
 
 _kernels = _HipKernels
 
@@ -208,3 +212,9 @@ def grid_grad_backward(grad, inp, grid, bound, interpolation, extrapolate,
         hess = grid_hess(inp, grid, bound, interpolation, extrapolate, displacement)
         grad_grid = (hess * grad.unsqueeze(-1)).sum(dim=[1, -2])
     return grad_inp, grad_grid
+
+
+def resample1d(src, lin, dim, order, bound, extrapolate, mode, adjoint=False, n_lattice=None):
+    """One 1-D pass of a tensor-product resampling along `dim` (see `separable.py`):
+    forward = pull along that dim at coordinates `lin`, adjoint = the matching push."""
+    return _kernels.resample1d(src, lin, dim, int(order), int(bound), int(extrapolate), int(mode), bool(adjoint), n_lattice)

@@ -3,7 +3,8 @@ Caller of the hot path; same signature and anchor conventions as the
 reference's `interpol/resize.py:13-119`."""
 import torch
 
-from .api import grid_pull
+from .api import grid_pull, spline_coeff_nd
+from .separable import separable_pull
 from .sepgrid import SeparableGrid
 from .utils import make_list
 
@@ -49,9 +50,14 @@ def resize(image, factor=None, shape=None, anchor='c', interpolation=1, prefilte
     kwargs.setdefault('extrapolate', True)
     kwargs.setdefault('interpolation', interpolation)
     kwargs.setdefault('prefilter', prefilter)
-    # the reference stacks meshgrid_ij(*lin) into a (*shape, dim) grid (resize.py:116); the
-    # kernels read the coordinate vectors themselves: same values, no grid tensor
+    # The reference stacks meshgrid_ij(*lin) into a (*shape, dim) grid and calls grid_pull
+    # (resize.py:116-117).  Here: no grid tensor; floating-point images are resampled by D
+    # one-dimensional passes (separable.py), label maps go through grid_pull on a SeparableGrid.
     if nb_dim <= 3 and image.dim() >= nb_dim:
+        if image.dtype.is_floating_point:
+            if kwargs['prefilter']:
+                image = spline_coeff_nd(image, interpolation=kwargs['interpolation'], bound=kwargs['bound'], dim=nb_dim)
+            return separable_pull(image, lin, kwargs['interpolation'], kwargs['bound'], kwargs['extrapolate'])
         return grid_pull(image, SeparableGrid(lin), **kwargs)
     grid = torch.stack(torch.meshgrid(*lin, indexing='ij'), dim=-1)
     return grid_pull(image, grid, **kwargs)

@@ -2,7 +2,8 @@
 path; same signature as the reference's `interpol/restrict.py:9-122`."""
 import torch
 
-from .api import grid_push
+from .api import grid_push, spline_coeff_nd
+from .separable import separable_push
 from .sepgrid import SeparableGrid
 from .utils import make_list
 
@@ -52,12 +53,17 @@ def restrict(image, factor=None, shape=None, anchor='c', interpolation=1, reduce
     kwargs.setdefault('extrapolate', True)
     kwargs.setdefault('interpolation', interpolation)
     kwargs.setdefault('prefilter', False)
-    # reference: stack(meshgrid_ij(*lin), -1) (restrict.py:117); see resize.py
-    if nb_dim <= 3 and image.dim() >= nb_dim:
-        grid = SeparableGrid(lin)
+    # reference: grid_push on stack(meshgrid_ij(*lin), -1) (restrict.py:117-118); see resize.py
+    if nb_dim <= 3 and image.dim() >= nb_dim and image.dtype in (torch.float32, torch.float64):
+        out = separable_push(image, lin, shape, kwargs['interpolation'], kwargs['bound'], kwargs['extrapolate'])
+        if kwargs['prefilter']:
+            out = spline_coeff_nd(out, interpolation=kwargs['interpolation'], bound=kwargs['bound'], dim=nb_dim, inplace=True)
     else:
-        grid = torch.stack(torch.meshgrid(*lin, indexing='ij'), dim=-1)
-    out = grid_push(image, grid, shape, **kwargs)
+        if nb_dim <= 3 and image.dim() >= nb_dim:
+            grid = SeparableGrid(lin)
+        else:
+            grid = torch.stack(torch.meshgrid(*lin, indexing='ij'), dim=-1)
+        out = grid_push(image, grid, shape, **kwargs)
     if not reduce_sum:
         out /= fullscale
     return out
