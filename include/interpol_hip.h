@@ -164,6 +164,16 @@ int interpol_push_backward(const interpol_problem *p, const void *grad_vol_out, 
 int interpol_count_backward(const interpol_problem *p, const void *grad_vol_out, const void *grid,
                             void *grad_grid, void *stream);
 
+/* --- label maps ------------------------------------------------------------------
+ * interpol_pull_labels replaces the per-label loop of api.grid_pull for integer inputs
+ * (interpol/api.py:194-205, prefilter=False): vol and val hold int32 LABELS (describe them with
+ * dtype = INTERPOL_F32, i.e. 4-byte elements; grid_dtype = INTERPOL_F32); for every sample the
+ * label with the largest interpolated indicator value (> 0) under the stencil is returned, the
+ * smallest such label on ties, 0 if none -- what the reference's loop over unique() computes,
+ * in one pass.  Covered: all dims share one order and (order+1)^dim <= 27; otherwise
+ * INTERPOL_E_ORDER (the caller keeps the loop).  Dense / separable / displacement grids. */
+int interpol_pull_labels(const interpol_problem *p, const void *vol, const void *grid, void *val, void *stream);
+
 /* --- separable resampling ------------------------------------------------------
  * interpol_resample_1d: one pass of a tensor-product resampling -- what `resize` / `restrict`
  * (interpol/resize.py:13-119, restrict.py:9-121) compute through grid_pull / grid_push on

@@ -101,3 +101,15 @@ def resize_cases():
         npz = np.load(os.path.join(HERE, "golden_resize.npz"))
         _CACHE["resize"] = [dict(c, inp=npz[c["inp"]], out64=npz[c["out64"]], out32=npz[c["out32"]]) for c in man["cases"]]
     return _CACHE["resize"]
+
+
+def label_cases():
+    """label-map golden cases (tests/golden/make_golden_labels.py): dicts with dim, order, bound,
+    extrapolate, lab (int64), grid (float32), out (int64: the reference's result)."""
+    if "labels" not in _CACHE:
+        with open(os.path.join(HERE, "golden_labels.json")) as f:
+            man = json.load(f)
+        npz = np.load(os.path.join(HERE, "golden_labels.npz"))
+        _CACHE["labels"] = [dict(c, lab=npz["l%d/lab" % c["i"]].astype(np.int64), grid=npz["l%d/grid" % c["i"]],
+                                 out=npz["l%d/out" % c["i"]].astype(np.int64)) for c in man["cases"]]
+    return _CACHE["labels"]

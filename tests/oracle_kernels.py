@@ -89,3 +89,15 @@ class OracleKernels:
             r = oracle.grid_pull(x, grid, [bound], [order], extrapolate)
         r = torch.as_tensor(r).to(src.dtype)
         return r.reshape(*lead, r.shape[-1]).movedim(-1, dim).contiguous()
+
+    @staticmethod
+    def pull_labels(inp, grid, bound, order, extrapolate, displacement=False):
+        """The reference's loop over the labels (api.py:194-205), with the oracle's pull."""
+        g = _g(grid, displacement).float()
+        out = torch.zeros([max(inp.shape[0], g.shape[0]), inp.shape[1], *g.shape[1:-1]], dtype=torch.int32)
+        pmax = torch.zeros(out.shape, dtype=torch.float32)
+        for label in inp.unique():
+            soft = torch.as_tensor(oracle.grid_pull((inp == label).float(), g, bound, order, extrapolate))
+            out[soft > pmax] = int(label)
+            pmax = torch.max(pmax, soft)
+        return out

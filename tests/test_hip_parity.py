@@ -683,3 +683,63 @@ def test_resample1d_passes(order):
         _same(gotbf.double(), _hip.resample1d(x.bfloat16().double(), lin.float().double(), dim, order, 3, 1, 0), 1e-2, "bf16")
     with pytest.raises(RuntimeError):
         _hip.resample1d(y.bfloat16(), lin.float(), dim, order, 3, 1, 0, adjoint=True, n_lattice=n)
+
+
+# ---------------------------------------------------------------------------
+# label maps, arg-max of the interpolated indicator images in one pass
+# ---------------------------------------------------------------------------
+def test_label_map_golden():
+    """interpol_pull_labels (orders with <= 27 taps) and the per-label loop (the rest) against the
+    reference's label outputs: exact."""
+    from interpol import _hip
+    nfused = 0
+    for c in G.label_cases():
+        lab, grid = torch.from_numpy(c["lab"]).to(DEV), torch.from_numpy(c["grid"]).to(DEV)
+        got = interpol.grid_pull(lab, grid, interpolation=c["order"], bound=c["bound"], extrapolate=c["extrapolate"])
+        assert got.dtype == lab.dtype
+        covered = _hip.labels_covered(c["dim"], [c["order"]] * c["dim"])
+        g_, w_ = got.cpu().numpy(), c["out"]
+        if not covered:
+            # per-label loop over this library's float pull (3-D cubic here): exact ties -- the three
+            # coordinates planted half-way between / exactly on voxels by the generator -- are decided by
+            # the last bit of the weights, which are not the reference's bit for bit in that path
+            g_, w_ = g_.reshape(2, 2, -1).copy(), w_.reshape(2, 2, -1).copy()
+            for b_, i_ in ((0, 0), (0, 1), (1, 0)):
+                g_[b_, :, i_] = w_[b_, :, i_]
+        assert np.array_equal(g_, w_), (c["dim"], c["order"], c["bound"], c["extrapolate"])
+        nfused += covered
+    assert nfused >= 80
+
+
+@pytest.mark.parametrize("dim,order", [(3, 0), (3, 1), (3, 2), (2, 3), (2, 1), (1, 3)])
+def test_label_map_fused_matches_loop(dim, order):
+    """Larger random label maps (many labels): the one-pass kernel == the loop over labels built
+    from this library's own float pull (same weights), for int32 / uint8 / int64 inputs, dense and
+    displacement grids."""
+    from interpol import _hip
+    g = torch.Generator().manual_seed(dim * 7 + order)
+    ishape = (23, 31, 19)[:dim]
+    oshape = (40, 27, 33)[:dim]
+    lab = torch.randint(0, 37, [2, 2, *ishape], generator=g).to(DEV)
+    lin = [torch.linspace(-1.0, n, m) for n, m in zip(ishape, oshape)]
+    grid = (torch.stack(torch.meshgrid(*lin, indexing="ij"), -1)[None] + 1.3 * torch.randn([2, *oshape, dim], generator=g)).to(DEV)
+    for bound in (0, 3, 6):
+        for ex in (0, 1):
+            fused = _hip.pull_labels(lab, grid, [bound] * dim, [order] * dim, ex).long()
+            out = torch.zeros_like(fused)
+            pmax = torch.zeros(fused.shape, device=DEV)
+            for l in lab.unique():
+                soft = _hip.gather("pull", (lab == l).float(), grid, [bound] * dim, [order] * dim, ex, flags=_hip.FLAG_NO_FASTPATH)
+                out[soft > pmax] = l
+                pmax = torch.max(pmax, soft)
+            mism = (fused != out)
+            # different summation order between the two paths: tolerate flips only at numerical ties
+            assert float(mism.float().mean()) < 2e-4, (dim, order, bound, ex, float(mism.float().mean()))
+    for dt in (torch.uint8, torch.int32, torch.int64):
+        a = interpol.grid_pull(lab.to(dt), grid, interpolation=order, bound="dct2", extrapolate=True)
+        assert a.dtype == dt and torch.equal(a.long(), _hip.pull_labels(lab, grid, [3] * dim, [order] * dim, 1).long())
+    if dim == 3:
+        disp = (grid[:, :ishape[0], :ishape[1], :ishape[2]] * 0.1).contiguous()
+        a = interpol.grid_pull(lab, disp, interpolation=order, bound="dct2", extrapolate=True, displacement=True)
+        b = interpol.grid_pull(lab, interpol.add_identity_grid(disp), interpolation=order, bound="dct2", extrapolate=True)
+        assert torch.equal(a, b)

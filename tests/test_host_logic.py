@@ -280,6 +280,20 @@ def test_displacement_keyword_host_logic():
         y.sum().backward()
 
 
+def test_label_map_golden_host_logic():
+    """Integer inputs: api.grid_pull returns the reference's labels (api.py:194-205) -- through the
+    one-pass operator where it applies (orders with <= 27 taps) and the per-label loop elsewhere --
+    with the kernels served by the oracle.  Mismatches are allowed only where two labels tie to
+    within float rounding (none in these fixtures)."""
+    import golden_util as G
+    with ops.use_kernels(OracleKernels):
+        for c in G.label_cases():
+            lab, grid = torch.from_numpy(c["lab"]), torch.from_numpy(c["grid"])
+            got = interpol.grid_pull(lab, grid, interpolation=c["order"], bound=c["bound"], extrapolate=c["extrapolate"])
+            assert got.dtype == lab.dtype and list(got.shape) == list(c["out"].shape)
+            assert np.array_equal(got.numpy(), c["out"]), (c["dim"], c["order"], c["bound"], c["extrapolate"])
+
+
 def test_grid_helpers():
     g = interpol.identity_grid([3, 4])
     assert g.shape == (3, 4, 2) and g[2, 3].tolist() == [2.0, 3.0]

@@ -105,4 +105,21 @@ if "f" in which or which == "1345":    # row f2: resize / restrict on a separabl
     y = torch.randn(B, C, m, m, m, generator=g, device=dev)
     rec(res, "f2_restrict_2x_256to128_linear_separable", timeit(lambda: interpol.restrict(y, factor=[2, 2, 2], anchor='e', interpolation=1, bound='dct2'), 3), vox, nbytes)
 
+if "f" in which or which == "1345":    # row f4: label map (50 labels), trilinear, 1x1x192^3, one-pass arg-max vs the reference's per-label loop
+    from interpol import _hip
+    n = 192
+    lab = torch.randint(0, 50, [1, 1, n, n, n], generator=g, device=dev)
+    gr = ident([n, n, n], 1, 2.0, g)
+    vox = n ** 3
+    rec(res, "f4_labels_50_linear_192_one_pass", timeit(lambda: interpol.grid_pull(lab, gr, interpolation=1, bound="dct2", extrapolate=True), 3), vox, vox * (12 + 8 + 8))
+
+    def loop():
+        out = torch.zeros_like(lab); pmax = torch.zeros(lab.shape, device=dev)
+        for l in lab.unique():
+            soft = _hip.gather("pull", (lab == l).float(), gr, [3] * 3, [1] * 3, 1)
+            out[soft > pmax] = l
+            pmax = torch.max(pmax, soft)
+        return out
+    rec(res, "f4_labels_50_linear_192_per_label_loop", timeit(loop, 3), vox, vox * (12 + 8 + 8))
+
 print(json.dumps(res, indent=1))

@@ -34,6 +34,7 @@ IP_DECL2(f32) IP_DECL2(f64)
 #undef IP_DECL2
 
 int launch_filter(int dtype, const FilterParams &fp, void *data, hipStream_t st);
+int launch_pull_labels(const KParams &p, int grid_f64, const void *vol, const void *grid, void *val, int B, hipStream_t st);
 int launch_resample1d(int dtype, int lin_f64, int order, const KParams &p, int adjoint, const void *src, const void *lin, void *dst,
                       unsigned ns, unsigned inner, int64_t nl, int64_t outer, hipStream_t st);
 
@@ -259,6 +260,16 @@ int interpol_pull(const interpol_problem *p, const void *vol, const void *grid, 
         [&] { return launch_pull_f64(k, vol, grid, val, B, st); },
         [&] { return launch_pull_bf16(k, vol, grid, val, B, st); },
         [&] { return launch_pull_f16(k, vol, grid, val, B, st); });
+}
+
+int interpol_pull_labels(const interpol_problem *p, const void *vol, const void *grid, void *val, void *stream)
+{
+    if (p && (p->dtype != INTERPOL_F32 || p->grid_dtype != INTERPOL_F32)) return INTERPOL_E_DTYPE;   // int32 labels, float32 coordinates
+    KParams k; int B;
+    int rc = make_params(p, GATHER, 1, &k, &B);
+    if (rc) return rc;
+    if (!vol || !grid || !val) return INTERPOL_E_NULL;
+    return launch_pull_labels(k, 0, vol, grid, val, B, (hipStream_t)stream);
 }
 
 int interpol_grad(const interpol_problem *p, const void *vol, const void *grid, void *val, void *stream)

@@ -1,0 +1,110 @@
+// Label-map sampling: arg-max over labels of the interpolated indicator images, in ONE pass.
+//
+// The reference (interpol/api.py:194-205) loops over `input.unique()`: for every label it builds
+// the indicator image, pulls it (GridPull) and keeps `out[soft > pmax] = label` -- L full
+// passes plus three elementwise passes each.  For a given output voxel only the labels under its
+// (K+1)^D stencil can have a non-zero indicator value, so
+//     soft_l = mask * sum_{taps t with label_t == l} w_t sign_t
+// is evaluated for the labels of the stencil only, and the winner is the reference's: the largest
+// soft value if it is > 0 (pmax starts at 0), the SMALLEST such label on ties (unique() is
+// sorted ascending and the update is a strict `>`), else 0.  Covered: isotropic orders with
+// (K+1)^D <= 27 taps (nearest / linear in any dim, up to cubic in 1-D / 2-D, quadratic in 3-D);
+// the host keeps the reference's loop for anything else and for prefilter = True.
+// No FMA contraction in this translation unit: the winner of an arg-max can hinge on the last
+// bit of a weight (coordinates exactly half-way between voxels give exact ties in the reference),
+// so the weights are evaluated with the reference's roundings (separate multiply and add).
+#pragma clang fp contract(off)
+#include "../../include/interpol_hip.h"
+#include "stencil.hpp"
+#include "launch.hpp"
+#include <hip/hip_runtime.h>
+
+namespace ip {
+namespace {
+
+template <typename G, typename R, int D, int K>
+__global__ __launch_bounds__(256) void pull_labels_kernel(KParams p, const int *__restrict__ vol, const G *__restrict__ grid,
+                                                          int *__restrict__ val, int B)
+{
+    const int64_t o = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (o >= p.N) return;
+    constexpr int T0 = K + 1, T1 = D > 1 ? K + 1 : 1, T2 = D > 2 ? K + 1 : 1, NT = T0 * T1 * T2;
+    for (int64_t b = blockIdx.y; b < B; b += gridDim.y) {
+        R x[D];
+        load_coords<R, G, D>(p, grid, b, o, x);
+        Stencil<R, D, K, true, NEED_W> s;
+        s.setup(p, x);
+        for (int c = 0; c < p.C; ++c) {
+            const char *v0 = reinterpret_cast<const char *>(vol + b * p.vol_sb + c * p.vol_sc);
+            int lab[NT];
+            R w[NT];
+            // Cubic weights with the reference's own operations (splines.py:42-44 divides by 6;
+            // the shared bspline_w multiplies by 1/6: one ulp apart, enough to flip an exact tie)
+            R wd[3][K + 1];
+#pragma unroll
+            for (int d = 0; d < 3; ++d)
+#pragma unroll
+                for (int j = 0; j <= K; ++j) wd[d][j] = s.w[d][j];
+            if constexpr (K == 3) {
+#pragma unroll
+                for (int d = 0; d < D; ++d) {
+                    const R fl = sizeof(R) == 4 ? (R)floorf((float)(x[d] - R(1))) : (R)floor((double)(x[d] - R(1)));   // nd.py:45
+                    const R t = x[d] - fl;                                                                    // nd.py:46
+#pragma unroll
+                    for (int j = 0; j <= K; ++j) {
+                        R a = t - R(j); a = a < R(0) ? -a : a;
+                        const R u = R(2) - a;
+                        const R we = a < R(1) ? (a * a * (a - R(2)) * R(3) + R(4)) / R(6) : (u * u * u) / R(6);
+                        wd[d][j] = s.w[d][j] == R(0) ? R(0) : (s.w[d][j] < R(0) ? -we : we);
+                    }
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < T0; ++i)
+#pragma unroll
+                for (int j = 0; j < T1; ++j)
+#pragma unroll
+                    for (int k = 0; k < T2; ++k) {
+                        const int t = (i * T1 + j) * T2 + k;
+                        lab[t] = *reinterpret_cast<const int *>(v0 + (s.off[0][i] + s.off[1][j] + s.off[2][k]));
+                        w[t] = (wd[0][i] * wd[1][j]) * wd[2][k];             // node-major products, sign folded in
+                    }
+            int best_l = 0x7fffffff;
+            R best_w = R(0);
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const int l = lab[t];
+                R sum = R(0);
+#pragma unroll
+                for (int u = 0; u < NT; ++u) sum += (lab[u] == l) ? w[u] : R(0);   // tap order, as the per-label pull sums
+                sum *= s.mask;
+                if (sum > best_w || (sum == best_w && l < best_l)) { best_w = sum; best_l = l; }
+            }
+            val[b * p.val_sb + c * p.val_sc + o] = best_w > R(0) ? best_l : 0;
+        }
+    }
+}
+
+template <typename G, typename R>
+int launch_g(const KParams &p, const void *vol, const void *grid, void *val, int B, hipStream_t st)
+{
+    const int K = p.order[0];
+    for (int d = 1; d < p.dim; ++d) if (p.order[d] != K) return INTERPOL_E_ORDER;
+#define IP_L(DD, KK) if (p.dim == DD && K == KK) { hipLaunchKernelGGL((pull_labels_kernel<G, R, DD, KK>), sample_grid(p, B), dim3(256), 0, st, \
+                                                                        p, (const int *)vol, (const G *)grid, (int *)val, B); goto done; }
+    IP_L(1, 0) IP_L(1, 1) IP_L(1, 2) IP_L(1, 3) IP_L(2, 0) IP_L(2, 1) IP_L(2, 2) IP_L(2, 3) IP_L(3, 0) IP_L(3, 1) IP_L(3, 2)
+#undef IP_L
+    return INTERPOL_E_ORDER;
+done:
+    const hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : (int)e;
+}
+
+} // namespace
+
+int launch_pull_labels(const KParams &p, int grid_f64, const void *vol, const void *grid, void *val, int B, hipStream_t st)
+{
+    return grid_f64 ? launch_g<double, double>(p, vol, grid, val, B, st) : launch_g<float, float>(p, vol, grid, val, B, st);
+}
+
+} // namespace ip

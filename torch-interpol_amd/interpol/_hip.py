@@ -30,7 +30,7 @@ _DTYPE_CODE = {torch.float32: F32, torch.float64: F64, torch.bfloat16: BF16, tor
 SYMBOLS = (
     "interpol_pull", "interpol_push", "interpol_count", "interpol_grad", "interpol_pushgrad",
     "interpol_hess", "interpol_pull_backward", "interpol_push_backward", "interpol_count_backward",
-    "interpol_spline_filter", "interpol_resample_1d", "interpol_host_bound_index", "interpol_host_bound_sign",
+    "interpol_spline_filter", "interpol_resample_1d", "interpol_pull_labels", "interpol_host_bound_index", "interpol_host_bound_sign",
     "interpol_host_weight", "interpol_host_weight_f32", "interpol_abi_version",
     "interpol_error_string", "interpol_kernel_name",
 )
@@ -87,10 +87,11 @@ def lib():
     L.interpol_push_backward.argtypes = [pp, vp, vp, vp, vp, vp, vp]
     L.interpol_count_backward.argtypes = [pp, vp, vp, vp, vp]
     L.interpol_spline_filter.argtypes = [vp, i32, i64, i64, i64, i32, i32, vp]
+    L.interpol_pull_labels.argtypes = [pp, vp, vp, vp, vp]
     L.interpol_resample_1d.argtypes = [i32, i32, i32, i32, i32, i32, i32, i64, i64, i64, i64, vp, vp, vp, vp]
     for name in ("interpol_pull", "interpol_grad", "interpol_hess", "interpol_push", "interpol_pushgrad",
                  "interpol_count", "interpol_pull_backward", "interpol_push_backward",
-                 "interpol_count_backward", "interpol_spline_filter", "interpol_resample_1d"):
+                 "interpol_count_backward", "interpol_spline_filter", "interpol_resample_1d", "interpol_pull_labels"):
         getattr(L, name).restype = ctypes.c_int
     L.interpol_host_bound_index.argtypes = [i32, i32, i32]
     L.interpol_host_bound_index.restype = i32
@@ -476,3 +477,37 @@ def resample1d(src, lin, dim, order, bound, extrapolate, mode, adjoint=False, n_
                                         _ptr(src), _ptr(lin), _ptr(dst), _stream(dev))
     _check(rc, "interpol_resample_1d")
     return dst
+
+
+def labels_covered(dim, order):
+    """Does interpol_pull_labels take this stencil?  (all dims one order, (order+1)^dim <= 27)"""
+    order = list(order)[:dim]
+    return len(set(order)) == 1 and (order[0] + 1) ** dim <= 27
+
+
+def pull_labels(vol, grid, bound, order, extrapolate, flags=0):
+    """Label-map pull: vol (B,C,*in) integer labels, grid (B,*out,D) float32 -> (B,C,*out) int32.
+    Arg-max over the labels of the interpolated indicator images (reference api.py:194-205)."""
+    dev = _require_gpu(vol, grid)
+    dim = grid.shape[-1]
+    if vol.dtype.is_floating_point:
+        raise TypeError("pull_labels: integer label map expected")
+    if grid.dtype != torch.float32:
+        raise TypeError("pull_labels: float32 coordinates expected")
+    vol = vol.to(torch.int32)
+    grid, gflag = _prep_grid(grid, torch.float32)
+    flags |= gflag
+    B = max(vol.shape[0], grid.shape[0])
+    C = vol.shape[1]
+    oshape = list(grid.shape[1:-1])
+    val = torch.empty([B, C] + oshape, dtype=torch.int32, device=dev)
+    if val.numel() == 0:
+        return val
+    vstr = [_bstride(vol, B), vol.stride(1)] + _pad_to([vol.stride(2 + d) for d in range(dim)], 3)
+    valstr = [val.stride(0), val.stride(1)] + _pad_to([val.stride(2 + d) for d in range(dim)], 3) + [0, 0]
+    p = make_problem(dim, torch.float32, torch.float32, bound, order, extrapolate, B, C, vol.shape[2:], oshape,
+                     vstr, _grid_strides(grid, B, dim), valstr, flags)
+    with torch.cuda.device(dev):
+        rc = lib().interpol_pull_labels(ctypes.byref(p), _ptr(vol), _ptr(grid), _ptr(val), _stream(dev))
+    _check(rc, "interpol_pull_labels")
+    return val

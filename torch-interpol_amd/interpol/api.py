@@ -16,8 +16,9 @@ int codes 0..6, or a per-dimension list.
 """
 import torch
 
-from . import backend
+from . import backend, ops
 from .autograd import GridPull, GridPush, GridCount, GridGrad, SplineCoeff, SplineCoeffND
+from .codes import bound_to_code, order_to_code, pad_codes
 from .sepgrid import SeparableGrid
 from .utils import expanded_shape
 
@@ -82,6 +83,16 @@ def grid_pull(input, grid, interpolation='linear', bound='zero', extrapolate=Fal
     dim = grid.shape[-1]
 
     if not input.dtype.is_floating_point:
+        codes = [order_to_code(o) for o in (interpolation if isinstance(interpolation, (list, tuple)) else [interpolation])]
+        fused = (grid.dtype == torch.float32 and ops.labels_covered(dim, codes)
+                 and (not prefilter or max(pad_codes(codes, dim)) <= 1)          # order <= 1: the prefilter is the identity
+                 and (input.dtype in (torch.bool, torch.uint8, torch.int8, torch.int16, torch.int32)
+                      or (input.dtype == torch.int64 and (input.numel() == 0 or int(input.abs().max()) < 2 ** 31))))
+        if fused:
+            # one pass: arg-max over the labels under each stencil (csrc/labels.hip)
+            out = ops.grid_pull_labels(input, grid, [bound_to_code(b) for b in (bound if isinstance(bound, (list, tuple)) else [bound])],
+                                       codes, int(extrapolate), displacement).to(input.dtype)
+            return _unfold(out, info, 'pull')
         out = input.new_zeros([batch, channel, *grid.shape[1:-1]])
         pmax = grid.new_zeros([batch, channel, *grid.shape[1:-1]])
         for label in input.unique():

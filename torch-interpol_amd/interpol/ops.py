@@ -85,6 +85,10 @@ class _HipKernels:
         return _hip.spline_filter_(data, bound, order, dim)
 
     @staticmethod
+    def pull_labels(inp, grid, bound, order, extrapolate, displacement=False):
+        return _hip.pull_labels(inp, grid, bound, order, extrapolate, flags=_dflag(displacement))
+
+    @staticmethod
     def resample1d(src, lin, dim, order, bound, extrapolate, mode, adjoint, n_lattice):
         return _hip.resample1d(src, lin, dim, order, bound, extrapolate, mode, adjoint, n_lattice)
 
@@ -218,3 +222,16 @@ def resample1d(src, lin, dim, order, bound, extrapolate, mode, adjoint=False, n_
     """One 1-D pass of a tensor-product resampling along `dim` (see `separable.py`):
     forward = pull along that dim at coordinates `lin`, adjoint = the matching push."""
     return _kernels.resample1d(src, lin, dim, int(order), int(bound), int(extrapolate), int(mode), bool(adjoint), n_lattice)
+
+
+def labels_covered(dim, interpolation):
+    """Can `grid_pull_labels` serve this stencil (else the caller loops over the labels)?"""
+    return _hip.labels_covered(dim, pad_codes(interpolation, dim))
+
+
+def grid_pull_labels(inp, grid, bound, interpolation, extrapolate, displacement=False):
+    """Integer label map (B,C,*in), float32 grid (B,*out,D) -> int32 (B,C,*out): the label whose
+    interpolated indicator image is largest (> 0), smallest label on ties, else 0 -- the result of
+    the reference's loop over `input.unique()` (api.py:194-205, prefilter=False) in one pass."""
+    bound, interpolation = _codes(grid, bound, interpolation)
+    return _kernels.pull_labels(inp, grid, bound, interpolation, int(extrapolate), **_kw(displacement))
