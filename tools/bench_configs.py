@@ -34,7 +34,7 @@ def ident(sp, B, sigma, g, dtype=torch.float32):
 
 res = {}
 g = torch.Generator(device=dev).manual_seed(1234)
-which = sys.argv[1:] or ["1", "3", "4", "5"]
+which = sys.argv[1:] or ["1", "3", "4", "5", "f"]
 
 if "1" in which:    # cfg1: 1x1x128x128 linear zero identity
     x = torch.randn(1, 1, 128, 128, device=dev)
@@ -85,7 +85,7 @@ if "5" in which:    # cfg5: 2-D, orders [2,3,5]->[2,3], bounds [dct1,dst2,zero]-
     rec(res, "cfg5_prefilter_bf16_o23_dct1dct2", timeit(lambda: interpol.spline_coeff_nd(x, [2, 3], ["dct1", "dct2"], 2), 3), vox, 2 * 2 * B * C * n * n * 2)
     rec(res, "cfg5_prefilter_f32_o23_dct1dct2", timeit(lambda: interpol.spline_coeff_nd(xf, [2, 3], ["dct1", "dct2"], 2), 3), vox, 2 * 2 * B * C * n * n * 4)
 
-if "f" in which or which == "1345":    # row f2: resize / restrict on a separable lattice vs the same call with a dense grid tensor
+if "f" in which:    # row f2: resize / restrict on a separable lattice vs the same call with a dense grid tensor
     B, C, n = 4, 2, 128
     x = torch.randn(B, C, n, n, n, generator=g, device=dev)
     kw = dict(factor=[2, 2, 2], anchor='e', interpolation=3, bound='dct2', prefilter=False)
@@ -105,7 +105,7 @@ if "f" in which or which == "1345":    # row f2: resize / restrict on a separabl
     y = torch.randn(B, C, m, m, m, generator=g, device=dev)
     rec(res, "f2_restrict_2x_256to128_linear_separable", timeit(lambda: interpol.restrict(y, factor=[2, 2, 2], anchor='e', interpolation=1, bound='dct2'), 3), vox, nbytes)
 
-if "f" in which or which == "1345":    # row f4: label map (50 labels), trilinear, 1x1x192^3, one-pass arg-max vs the reference's per-label loop
+if "f" in which:    # row f4: label map (50 labels), trilinear, 1x1x192^3, one-pass arg-max vs the reference's per-label loop
     from interpol import _hip
     n = 192
     lab = torch.randint(0, 50, [1, 1, n, n, n], generator=g, device=dev)

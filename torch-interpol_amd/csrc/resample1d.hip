@@ -11,6 +11,8 @@
 #include "../../include/interpol_hip.h"
 #include "stencil.hpp"
 #include <hip/hip_runtime.h>
+#include <cstdint>
+#include <type_traits>
 
 namespace ip {
 namespace {
@@ -50,11 +52,40 @@ __global__ __launch_bounds__(256) void resample1d_kernel(KParams p, const T *__r
     }
 }
 
+// fp32 forward pass, inner % 4 == 0: four consecutive c per thread, 16-byte loads and stores
+template <int K>
+__global__ __launch_bounds__(256) void resample1d_fwd_f32x4(KParams p, const float *__restrict__ src, const float *__restrict__ lin,
+                                                            float *__restrict__ dst, unsigned ns, unsigned inner4, int64_t nl, int64_t outer)
+{
+    const unsigned r = blockIdx.x * 256u + threadIdx.x;
+    if (r >= ns * inner4) return;
+    const unsigned s = r / inner4, c = (r - s * inner4) * 4u;
+    float x[1] = { lin[s] };
+    Stencil<float, 1, K, true, NEED_W> st;
+    st.setup(p, x);
+    const int64_t inner = (int64_t)inner4 * 4;
+    for (int64_t b = blockIdx.y; b < outer; b += gridDim.y) {
+        const float *sb = src + b * nl * inner + c;
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int j = 0; j <= K; ++j) {
+            const float4 v = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(sb) + st.off[0][j]);
+            const float w = st.w[0][j];
+            acc.x = w * v.x + acc.x; acc.y = w * v.y + acc.y; acc.z = w * v.z + acc.z; acc.w = w * v.w + acc.w;
+        }
+        const float m = st.mask;
+        *reinterpret_cast<float4 *>(dst + (b * ns + s) * inner + c) = make_float4(acc.x * m, acc.y * m, acc.z * m, acc.w * m);
+    }
+}
+
 template <typename T, typename G, typename R, bool ADJ>
 int launch_k(int order, const KParams &p, const void *src, const void *lin, void *dst, unsigned ns, unsigned inner, int64_t nl,
              int64_t outer, hipStream_t st)
 {
-    const unsigned blocks = (unsigned)(((uint64_t)ns * inner + 255) / 256);
+    constexpr bool VEC_OK = !ADJ && std::is_same<T, float>::value && std::is_same<G, float>::value;
+    const bool vec = VEC_OK && inner % 4 == 0 && ((uintptr_t)src % 16 == 0) && ((uintptr_t)dst % 16 == 0);
+    const unsigned cols = vec ? inner / 4 : inner;
+    const unsigned blocks = (unsigned)(((uint64_t)ns * cols + 255) / 256);
     // The stencil of a thread depends on s only: every thread walks several outer slices with
     // the same weights / offsets (its set-up costs ~100 instructions, a tap 2).  Enough slices
     // in parallel to fill the chip (~16 K threads per CU), the rest in the loop.
@@ -62,6 +93,16 @@ int launch_k(int order, const KParams &p, const void *src, const void *lin, void
     ny = ny < outer ? ny : outer;
     ny = ny < 65535 ? ny : 65535;
     const dim3 grid(blocks, (unsigned)ny);
+    if constexpr (VEC_OK) {
+        if (vec) {
+#define IP_R4(KK) case KK: hipLaunchKernelGGL((resample1d_fwd_f32x4<KK>), grid, dim3(256), 0, st, p, (const float *)src, \
+                                              (const float *)lin, (float *)dst, ns, cols, nl, outer); break;
+            switch (order) { IP_R4(0) IP_R4(1) IP_R4(2) IP_R4(3) IP_R4(4) IP_R4(5) IP_R4(6) IP_R4(7) default: return INTERPOL_E_ORDER; }
+#undef IP_R4
+            const hipError_t e4 = hipGetLastError();
+            return e4 == hipSuccess ? 0 : (int)e4;
+        }
+    }
 #define IP_R1(KK) case KK: hipLaunchKernelGGL((resample1d_kernel<T, G, R, KK, ADJ>), grid, dim3(256), 0, st, p, (const T *)src, \
                                               (const G *)lin, (T *)dst, ns, inner, nl, outer); break;
     switch (order) { IP_R1(0) IP_R1(1) IP_R1(2) IP_R1(3) IP_R1(4) IP_R1(5) IP_R1(6) IP_R1(7) default: return INTERPOL_E_ORDER; }
