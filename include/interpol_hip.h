@@ -111,6 +111,11 @@ typedef struct interpol_problem {
  * the exactly representable index).  grad_grid of the backward entry points is then the
  * gradient w.r.t. the displacement (identical values).  Not combinable with SEPARABLE_GRID. */
 #define INTERPOL_FLAG_DISPLACEMENT  16
+/* interpol_push only: the target has channels + 1 channels, (B, C+1, *shape); channel C receives
+ * the COUNT image (what interpol_count writes: the splatted ones, pushpull.py:106-142) in the same
+ * pass over the grid -- push followed by count on the same grid is the usual pairing (normalised
+ * splatting; SURVEY config 4).  vol_stride describe the (B, C+1, *shape) target. */
+#define INTERPOL_FLAG_WITH_COUNT    32
 
 /* --- forward operators -------------------------------------------------------
  * interpol_pull      replaces pushpull.grid_pull      (interpol/pushpull.py:35-66;

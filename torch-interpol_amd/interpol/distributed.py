@@ -57,9 +57,11 @@ def push_count_shared(input, grid, shape, interpolation='linear', bound='zero', 
     buf = torch.zeros([1, nch] + shape, dtype=dtype, device=grid.device)
     k = ops.kernels()
     if grid.shape[0] > 0:
-        if input is not None:
+        if input is not None and with_count:
+            k.push_shared_(buf, input, grid, b, o, ex, with_count=True)    # values and count in one pass over the grid
+        elif input is not None:
             k.push_shared_(buf[:, :C], input, grid, b, o, ex)
-        if with_count:
+        else:
             k.push_shared_(buf[:, C:], None, grid, b, o, ex)
     if reduce != 'none' and torch.distributed.is_available() and torch.distributed.is_initialized():
         if reduce == 'all':

@@ -62,11 +62,16 @@ class _HipKernels:
         return _hip.scatter("pushgrad", inp, grid, shape, bound, order, extrapolate, flags=_dflag(displacement))
 
     @staticmethod
-    def push_shared_(out, inp, grid, bound, order, extrapolate):
-        """out (1,C,*shape) += sum over the batch of push(inp, grid); count when inp is None."""
+    def push_shared_(out, inp, grid, bound, order, extrapolate, with_count=False):
+        """out (1,C,*shape) += sum over the batch of push(inp, grid); count when inp is None;
+        with_count: out has C + 1 channels, the last one accumulates the count in the same pass."""
         op = "count" if inp is None else "push"
         return _hip.scatter(op, inp, grid, list(out.shape[2:]), bound, order, extrapolate,
-                            flags=_hip.FLAG_ACCUMULATE, out=out, shared=True)
+                            flags=_hip.FLAG_ACCUMULATE, out=out, shared=True, with_count=with_count)
+
+    @staticmethod
+    def push_count(inp, grid, shape, bound, order, extrapolate, displacement=False):
+        return _hip.scatter("push", inp, grid, shape, bound, order, extrapolate, flags=_dflag(displacement), with_count=True)
 
     @staticmethod
     def pull_backward(grad, inp, grid, bound, order, extrapolate, need_inp, need_grid, displacement=False):
@@ -235,3 +240,12 @@ def grid_pull_labels(inp, grid, bound, interpolation, extrapolate, displacement=
     the reference's loop over `input.unique()` (api.py:194-205, prefilter=False) in one pass."""
     bound, interpolation = _codes(grid, bound, interpolation)
     return _kernels.pull_labels(inp, grid, bound, interpolation, int(extrapolate), **_kw(displacement))
+
+
+def grid_push_count(inp, grid, shape, bound, interpolation, extrapolate, displacement=False):
+    """(B,C,*in), (B,*in,D) -> (B,C+1,*shape): grid_push of `inp` in channels 0..C-1 and grid_count
+    of the same grid in channel C, from ONE pass over the grid (pushpull.py:70-102 + 106-142)."""
+    bound, interpolation = _codes(grid, bound, interpolation)
+    _check_push_shapes(inp, grid)
+    shape = None if shape is None else list(shape)
+    return _kernels.push_count(inp, grid, shape, bound, interpolation, int(extrapolate), **_kw(displacement))
