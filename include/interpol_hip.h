@@ -169,6 +169,20 @@ int interpol_push_backward(const interpol_problem *p, const void *grad_vol_out, 
 int interpol_count_backward(const interpol_problem *p, const void *grad_vol_out, const void *grid,
                             void *grad_grid, void *stream);
 
+/* --- target-stationary splatting -------------------------------------------------
+ * interpol_push_bricks: the same operator as interpol_push (pushpull.py:70-102; with
+ * INTERPOL_FLAG_WITH_COUNT also the count image, 106-142), organised for EXPANDING deformations
+ * (e.g. 128^3 sources splatted into a shared 512^3 target): the samples are binned by 16^3 target
+ * brick (count / scan / fill), every brick is accumulated in LDS by the one workgroup that owns
+ * it and stored once, instead of one global atomic per tap.  3-D, INTERPOL_F32 data and grid,
+ * channels (+1 with the count) <= 4, batch * samples < 2^32; otherwise INTERPOL_E_DTYPE /
+ * INTERPOL_E_DIM / INTERPOL_E_SHAPE and the caller uses interpol_push.  Honours ACCUMULATE,
+ * WITH_COUNT, SEPARABLE_GRID, DISPLACEMENT and the shared target (vol batch stride 0).
+ * `workspace`: device scratch of interpol_push_bricks_workspace(p) bytes (32 B per sample + counters). */
+int64_t interpol_push_bricks_workspace(const interpol_problem *p);
+int interpol_push_bricks(const interpol_problem *p, const void *val, const void *grid, void *vol,
+                         void *workspace, int64_t workspace_bytes, void *stream);
+
 /* --- label maps ------------------------------------------------------------------
  * interpol_pull_labels replaces the per-label loop of api.grid_pull for integer inputs
  * (interpol/api.py:194-205, prefilter=False): vol and val hold int32 LABELS (describe them with

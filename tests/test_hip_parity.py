@@ -773,3 +773,56 @@ def test_push_with_count_matches_separate_calls(dim, order, zoom):
         _hip.scatter("count", None, grid, tshape, b, o, 1, with_count=True)
     pc = ops.grid_push_count(src, grid, tshape, b, o, 1)
     assert torch.equal(pc, _hip.scatter("push", src, grid, tshape, b, o, 1, with_count=True)) or True
+
+
+@pytest.mark.parametrize("order,zoom,bound", [(3, 4.0, 1), (1, 3.0, 3), (2, 1.0, 6), (5, 2.0, 4), (0, 2.5, 0), (3, 0.5, 2)])
+def test_push_bricks_matches_push(order, zoom, bound):
+    """interpol_push_bricks (target-stationary, for expanding fields) == interpol_push: per-item and
+    shared targets, with and without the count channel, all extrapolation modes, accumulate."""
+    from interpol import _hip
+    g = torch.Generator().manual_seed(int(order * 10 + zoom))
+    sshape = (21, 26, 19)
+    tshape = [int(n * zoom) + 5 for n in sshape]
+    lin = [torch.arange(n, dtype=torch.float32) * zoom for n in sshape]
+    grid = (torch.stack(torch.meshgrid(*lin, indexing="ij"), -1)[None] + 1.7 * torch.randn([3, *sshape, 3], generator=g)).to(DEV)
+    b, o = [bound] * 3, [order] * 3
+    if order > 3:
+        with pytest.raises(ValueError):
+            _hip.push_bricks(torch.zeros([3, 1, *sshape], device=DEV), grid, tshape, b, o, 1)
+        return
+    for C in (1, 3):
+        src = torch.randn([3, C, *sshape], generator=g).to(DEV)
+        for ex in (0, 1, 2):
+            for wc in (False, True):
+                if C + wc > 4:
+                    continue
+                ref = _hip.scatter("push", src, grid, tshape, b, o, ex, flags=_hip.FLAG_NO_FASTPATH, with_count=wc)
+                got = _hip.push_bricks(src, grid, tshape, b, o, ex, with_count=wc)
+                _same(got, ref, 3e-6, ("bricks", order, zoom, bound, C, ex, wc))
+        sh = torch.ones([1, C + 1, *tshape], device=DEV)
+        _hip.push_bricks(src, grid, tshape, b, o, 1, flags=_hip.FLAG_ACCUMULATE, out=sh, shared=True, with_count=True)
+        want = 1 + _hip.scatter("push", src, grid, tshape, b, o, 1, flags=_hip.FLAG_NO_FASTPATH, with_count=True).sum(0, keepdim=True)
+        _same(sh, want, 1e-5, ("bricks shared", order, zoom, bound, C))
+    bad = src.clone()
+    bad[0, 0, 3, 4, 5] = float("inf")
+    got = _hip.push_bricks(bad, grid, tshape, b, o, 1)
+    ref = _hip.scatter("push", bad, grid, tshape, b, o, 1, flags=_hip.FLAG_NO_FASTPATH)
+    fin = torch.isfinite(ref) & torch.isfinite(got)
+    assert torch.equal(torch.isfinite(ref), torch.isfinite(got)) or float((torch.isfinite(ref) ^ torch.isfinite(got)).float().mean()) < 1e-3
+    _same(torch.where(fin, got, torch.zeros_like(got)), torch.where(fin, ref, torch.zeros_like(ref)), 1e-5, "bricks non-finite")
+
+
+def test_expanding_push_goes_through_bricks_at_api_level():
+    """grid_push into a target >= 8x larger than the sample lattice takes the target-stationary
+    kernels; the result is that of the scatter kernels (and gradients flow as usual)."""
+    from interpol import _hip
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(2, 2, 12, 14, 10, generator=g).to(DEV).requires_grad_(True)
+    grid = (interpol.identity_grid([12, 14, 10]) * 3.1 + 0.9 * torch.randn(2, 12, 14, 10, 3, generator=g)).to(DEV)
+    shape = [40, 45, 33]
+    assert ops.kernels().expanding(x, grid, shape, False, [3, 3, 3])
+    out = interpol.grid_push(x, grid, shape, interpolation=3, bound="dct2", extrapolate=True)
+    ref = _hip.scatter("push", x.detach(), grid, shape, [3] * 3, [3] * 3, 1, flags=_hip.FLAG_NO_FASTPATH)
+    _same(out.detach(), ref, 3e-6, "expanding push")
+    out.square().sum().backward()
+    assert x.grad is not None and torch.isfinite(x.grad).all()

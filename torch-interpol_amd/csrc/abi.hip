@@ -34,6 +34,9 @@ IP_DECL2(f32) IP_DECL2(f64)
 #undef IP_DECL2
 
 int launch_filter(int dtype, const FilterParams &fp, void *data, hipStream_t st);
+int64_t bricks_workspace_bytes(const KParams &p, int B, int shared);
+int launch_push_bricks(const KParams &p, int B, int shared, const void *val, const void *grid, void *vol,
+                       void *workspace, int64_t workspace_bytes, hipStream_t st);
 int launch_pull_labels(const KParams &p, int grid_f64, const void *vol, const void *grid, void *val, int B, hipStream_t st);
 int launch_resample1d(int dtype, int lin_f64, int order, const KParams &p, int adjoint, const void *src, const void *lin, void *dst,
                       unsigned ns, unsigned inner, int64_t nl, int64_t outer, hipStream_t st);
@@ -334,6 +337,43 @@ int interpol_push(const interpol_problem *p, const void *val, const void *grid, 
             [&] { return launch_push_bf16(kc, nullptr, grid, accc, B, st); },
             [&] { return launch_push_f16(kc, nullptr, grid, accc, B, st); });
     });
+}
+
+static int bricks_params(const interpol_problem *p, KParams *k, int *B)
+{
+    if (!p) return INTERPOL_E_NULL;
+    if (p->dim != 3) return INTERPOL_E_DIM;
+    if (p->dtype != INTERPOL_F32 || p->grid_dtype != INTERPOL_F32) return INTERPOL_E_DTYPE;
+    int rc = make_params(p, SCATTER, 1, k, B, true);
+    if (rc) return rc;
+    if (!vol_is_dense(p)) return INTERPOL_E_STRIDE;
+    k->cc = (p->flags & INTERPOL_FLAG_WITH_COUNT) ? 1 : 0;
+    if (k->C + k->cc > 4 || (uint64_t)*B * (uint64_t)k->N > 0xffffffffull) return INTERPOL_E_SHAPE;
+    return 0;
+}
+
+int64_t interpol_push_bricks_workspace(const interpol_problem *p)
+{
+    KParams k; int B;
+    const int rc = bricks_params(p, &k, &B);
+    if (rc) return rc;
+    return bricks_workspace_bytes(k, B, p->vol_stride[0] == 0);
+}
+
+int interpol_push_bricks(const interpol_problem *p, const void *val, const void *grid, void *vol,
+                         void *workspace, int64_t workspace_bytes, void *stream)
+{
+    KParams k; int B;
+    int rc = bricks_params(p, &k, &B);
+    if (rc) return rc;
+    if (!val || !grid || !vol || !workspace) return INTERPOL_E_NULL;
+    hipStream_t st = (hipStream_t)stream;
+    if (!(p->flags & INTERPOL_FLAG_ACCUMULATE)) {
+        const hipError_t e = hipMemsetAsync(vol, 0, (size_t)vol_numel(p) * 4, st);
+        if (e != hipSuccess) return (int)e;
+    }
+    rc = launch_push_bricks(k, B, p->vol_stride[0] == 0, val, grid, vol, workspace, workspace_bytes, st);
+    return rc == 1 ? 0 : (rc == 0 ? INTERPOL_E_SHAPE : rc);
 }
 
 int interpol_count(const interpol_problem *p, const void *grid, void *vol,

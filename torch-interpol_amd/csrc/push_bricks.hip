@@ -1,0 +1,340 @@
+// Target-stationary splatting ("bricks") for EXPANDING deformations (3-D, fp32).
+//
+// push / count scatter every sample to the (K+1)^3 lattice points of its stencil (nd.py:146-213).
+// When the deformation expands -- splatting 128^3 sources into a 512^3 target, SURVEY config 4 --
+// neighbouring samples own disjoint target voxels: a sample-stationary tile has nothing to merge
+// in LDS and every contribution becomes a global atomic (2.1 G of them for 8 sources, 32 ms).
+// Here the TARGET is cut into 16^3 bricks and each brick is owned by one workgroup:
+//   1. count : every sample adds 1 to the counter of each brick its stencil overlaps (<= 8);
+//              border samples (stencil leaving the lattice: boundary wrap) go to a separate list
+//              and are splatted tap-parallel with float atomics; per-channel max|src| is reduced
+//              on the way
+//   2. scan  : exclusive prefix of the counters -> list offsets
+//   3. fill  : the same walk writes the sample ids into the bricks' lists
+//   4. brick : a workgroup accumulates its brick in LDS -- 64-bit fixed point, ds_add_u64, all
+//              sources of the batch -- from the samples of its list (one THREAD per sample: its
+//              weights are computed once, then the taps that fall inside the brick are walked)
+//              and adds the brick to the target with plain coalesced read-modify-writes: it is
+//              the only writer.
+// Weights, first-tap indices and the extrapolation mask are those of csrc/stencil.hpp.
+#include "../../include/interpol_hip.h"
+#include "stencil.hpp"
+#include <hip/hip_runtime.h>
+
+namespace ip {
+namespace {
+
+constexpr int BS = 16, BSLOTS = BS * BS * BS;
+constexpr int HDR = 16;                       // workspace header (ints): [0..7] max|src| bits per channel, [8] border-list length
+
+struct Bricks {
+    int nb[3];                                // bricks per dim
+    int per_target;                           // nb[0] * nb[1] * nb[2]
+    int shared;                               // batch stride 0: one target for the whole batch
+    unsigned N;                               // samples per batch item
+    int *hdr, *counts, *offsets, *cursor;     // workspace
+    unsigned *list, *border;                  // per-brick sample lists; border samples
+    int *partial;                             // 8 x MAXPART partial maxima
+};
+
+// first tap and stencil coordinate of one dim (nd.py:45-46; iso0.py:12 rounds half to even)
+__device__ __forceinline__ void split1(const KParams &p, int d, float x, int &i0, float &t)
+{
+    const int k = p.order[d];
+    const float fl = (k == 0 && p.mode == MODE_ISO0) ? rintf(x) : floorf(x - 0.5f * (float)(k - 1));
+    t = x - fl;
+    const float flc = fl < -1073741824.f ? -1073741824.f : (fl > 1073741824.f ? 1073741824.f : fl);
+    i0 = (int)flc;
+}
+
+__device__ __forceinline__ float weight_of(const KParams &p, int d, float t, int j)
+{
+    const int k = p.order[d];
+    if (k == 1 && p.mode == MODE_ISO1) return j == 0 ? 1.f - t : t;            // iso1.py:19-20
+    return bspline_w<float>(k, t - (float)j);                                   // splines.py:30-80
+}
+
+// -> 0: masked out (contributes nothing), 1: interior (whole stencil inside the lattice, signs +1), 2: border
+__device__ __forceinline__ int classify(const KParams &p, const float *x, int *i0, float *t)
+{
+    bool inb = true, inside = true;
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        if (p.extrapolate != 1) inb = inb && x[d] > (float)p.mask_lo && x[d] < (float)p.mask_hi[d];   // nd.py:10-27
+        split1(p, d, x[d], i0[d], t[d]);
+        inside = inside && i0[d] >= (p.bound[d] == B_DST1 ? 1 : 0) && i0[d] + p.order[d] < p.vol_n[d];
+    }
+    return !inb ? 0 : (inside ? 1 : 2);
+}
+
+__device__ __forceinline__ int wave_max_i(int v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { const int u = __shfl_xor(v, o); v = u > v ? u : v; }
+    return v;
+}
+
+// max |src| per value channel, stage 1 of 2 (stage 2 in bricks_scan): blockIdx.y = channel,
+// each block reduces a strided share of the (B, N) values and writes one partial.
+constexpr int MAXPART = 256;
+__global__ __launch_bounds__(256) void bricks_max(KParams p, Bricks bk, const float *__restrict__ val, int B)
+{
+    __shared__ int red[4];
+    const int c = blockIdx.y;
+    int bits = 0;
+    for (int b = 0; b < B; ++b) {
+        const float *vc = val + (int64_t)b * p.val_sb + (int64_t)c * p.val_sc;
+        for (unsigned o = blockIdx.x * 256u + threadIdx.x; o < bk.N; o += MAXPART * 256u) {
+            const float a = __builtin_fabsf(vc[o]);
+            const int ab = (a != a) ? 0x7fc00000 : __float_as_int(a);      // NaN sticks
+            bits = ab > bits ? ab : bits;
+        }
+    }
+    bits = wave_max_i(bits);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = bits;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int i = 1; i < 4; ++i) bits = red[i] > bits ? red[i] : bits;
+        bk.partial[c * MAXPART + blockIdx.x] = bits;
+    }
+}
+
+// Steps 1 and 3: one thread per sample.
+template <bool FILL>
+__global__ __launch_bounds__(256) void bricks_walk(KParams p, Bricks bk, const float *__restrict__ val, const float *__restrict__ grid,
+                                                   float *__restrict__ vol, int B, int nch)
+{
+    const unsigned o = blockIdx.x * 256u + threadIdx.x;
+    const bool live = o < bk.N;
+    for (int b = blockIdx.y; b < B; b += gridDim.y) {
+        float x[3] = { 0.f, 0.f, 0.f };
+        int i0[3]; float t[3];
+        int cls = 0;
+        if (live) { load_coords<float, float, 3>(p, grid, b, o, x); cls = classify(p, x, i0, t); }
+        if (cls == 1) {
+            const int tb = bk.shared ? 0 : b;
+            const int bx0 = i0[0] / BS, bx1 = (i0[0] + p.order[0]) / BS;
+            const int by0 = i0[1] / BS, by1 = (i0[1] + p.order[1]) / BS;
+            const int bz0 = i0[2] / BS, bz1 = (i0[2] + p.order[2]) / BS;
+            for (int bx = bx0; bx <= bx1; ++bx)
+                for (int by = by0; by <= by1; ++by)
+                    for (int bz = bz0; bz <= bz1; ++bz) {
+                        const int br = tb * bk.per_target + (bx * bk.nb[1] + by) * bk.nb[2] + bz;
+                        if (FILL) bk.list[atomicAdd(&bk.cursor[br], 1)] = (unsigned)b * bk.N + o;
+                        else atomicAdd(&bk.counts[br], 1);
+                    }
+        }
+        if (!FILL) {
+            // border samples -> their own list, one counter update per wave
+            const unsigned long long m = __ballot(cls == 2);
+            if (m) {
+                int base = 0;
+                if ((threadIdx.x & 63) == 0) base = atomicAdd(&bk.hdr[8], __popcll(m));
+                base = __shfl(base, 0);
+                if (cls == 2) bk.border[base + __popcll(m & ((1ull << (threadIdx.x & 63)) - 1ull))] = (unsigned)b * bk.N + o;
+            }
+        }
+    }
+}
+
+// Border samples (stencil leaving the lattice): one wave per sample, lanes = taps, boundary wrap
+// per tap (bounds.py:30-89), float atomics straight to the target.
+__global__ __launch_bounds__(256) void bricks_border(KParams p, Bricks bk, const float *__restrict__ val, const float *__restrict__ grid,
+                                                     float *__restrict__ vol, int nch)
+{
+    const int lane = threadIdx.x & 63, nw = gridDim.x * 4;
+    const int k1[3] = { p.order[0] + 1, p.order[1] + 1, p.order[2] + 1 };
+    const int ntap = k1[0] * k1[1] * k1[2];
+    const int n = bk.hdr[8];
+    for (int e = blockIdx.x * 4 + (threadIdx.x >> 6); e < n; e += nw) {
+        const unsigned id = bk.border[e];
+        const unsigned b = id / bk.N, o = id - b * bk.N;
+        float x[3]; int i0[3]; float t[3];
+        load_coords<float, float, 3>(p, grid, (int64_t)b, (int64_t)o, x);
+        classify(p, x, i0, t);
+        float *vb = vol + (bk.shared ? 0 : (int64_t)b * p.vol_sb);
+        for (int t0 = 0; t0 < ntap; t0 += 64) {
+            const int tap = t0 + lane;
+            if (tap >= ntap) continue;
+            const int tp[3] = { tap / (k1[1] * k1[2]), (tap / k1[2]) % k1[1], tap % k1[2] };
+            float w = 1.f; int64_t off = 0;
+#pragma unroll
+            for (int d = 0; d < 3; ++d) {
+                const long long pk = wrap_outofline(p.bound[d], i0[d] + tp[d], p.vol_n[d]);
+                w *= weight_of(p, d, t[d], tp[d]) * (float)(int)(pk >> 32);
+                off += (int64_t)(int)(pk & 0xffffffffll) * (p.vol_ss[d] / 4);
+            }
+            for (int c = 0; c < nch; ++c) {
+                const float sv = c < p.C ? val[(int64_t)b * p.val_sb + c * p.val_sc + o] : 1.f;
+                __hip_atomic_fetch_add(vb + c * p.vol_sc + off, w * sv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+    }
+}
+
+// Step 2: exclusive scan of the counters (one workgroup; n is a few 10^4 .. 10^6)
+__global__ __launch_bounds__(1024) void bricks_scan(Bricks bk, int n, int nval)
+{
+    __shared__ int part[1024];
+    __shared__ int carry;
+    if (threadIdx.x == 0) carry = 0;
+    if ((int)threadIdx.x < nval) {                         // stage 2 of the channel maxima
+        int m = 0;
+        for (int i = 0; i < 256; ++i) { const int v = bk.partial[threadIdx.x * 256 + i]; m = v > m ? v : m; }
+        bk.hdr[threadIdx.x] = m;
+    }
+    __syncthreads();
+    for (int base = 0; base < n; base += 1024) {
+        const int i = base + threadIdx.x;
+        const int v = i < n ? bk.counts[i] : 0;
+        part[threadIdx.x] = v;
+        __syncthreads();
+        for (int s = 1; s < 1024; s <<= 1) {
+            const int u = threadIdx.x >= s ? part[threadIdx.x - s] : 0;
+            __syncthreads();
+            part[threadIdx.x] += u;
+            __syncthreads();
+        }
+        const int excl = carry + part[threadIdx.x] - v;
+        if (i < n) { bk.offsets[i] = excl; bk.cursor[i] = excl; }
+        __syncthreads();
+        if (threadIdx.x == 1023) carry += part[1023];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) bk.offsets[n] = carry;
+}
+
+// Step 4: one workgroup per brick (persistent), one thread per listed sample.
+template <int NCH, int K>
+__global__ __launch_bounds__(1024) void bricks_accumulate(KParams p, Bricks bk, const float *__restrict__ val, const float *__restrict__ grid,
+                                                          float *__restrict__ vol, int nbricks)
+{
+    extern __shared__ unsigned long long acc[];            // NCH x BSLOTS
+    const int tid = threadIdx.x;
+    // fixed-point scales: 2^e max|src| <= 2^30 (the count channel's source is 1)
+    float scale[NCH], inv[NCH]; bool finite[NCH];
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        const int bits = c < p.C ? bk.hdr[c] : 0x3f800000;
+        finite[c] = (bits & 0x7f800000) != 0x7f800000;
+        int ex = ((bits >> 23) & 0xff) - 127;
+        ex = ex < -90 ? -90 : ex;
+        scale[c] = __int_as_float((127 + 29 - ex) << 23);
+        inv[c] = __int_as_float((127 - 29 + ex) << 23);
+    }
+    for (int br = blockIdx.x; br < nbricks; br += gridDim.x) {
+        const int beg = bk.offsets[br], end = bk.offsets[br + 1];
+        if (beg == end) continue;                           // block-uniform
+        const int tb = br / bk.per_target, r = br - tb * bk.per_target;
+        const int bx = r / (bk.nb[1] * bk.nb[2]), by = (r / bk.nb[2]) % bk.nb[1], bz = r % bk.nb[2];
+        __syncthreads();
+        for (int e = tid; e < NCH * BSLOTS; e += 1024) acc[e] = 0ull;
+        __syncthreads();
+        float *vt = vol + (int64_t)tb * p.vol_sb;
+        for (int e = beg + tid; e < end; e += 1024) {
+            const unsigned id = bk.list[e];
+            const unsigned b = id / bk.N, o = id - b * bk.N;
+            float x[3]; int i0[3]; float t[3];
+            load_coords<float, float, 3>(p, grid, (int64_t)b, (int64_t)o, x);
+            classify(p, x, i0, t);
+            float sv[NCH];
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) sv[c] = (c < p.C ? val[(int64_t)b * p.val_sb + c * p.val_sc + o] : 1.f) * scale[c];
+            float wx[K + 1], wy[K + 1], wz[K + 1];
+#pragma unroll
+            for (int j = 0; j <= K; ++j) { wx[j] = weight_of(p, 0, t[0], j); wy[j] = weight_of(p, 1, t[1], j); wz[j] = weight_of(p, 2, t[2], j); }
+            const int ix0 = i0[0] - bx * BS, iy0 = i0[1] - by * BS, iz0 = i0[2] - bz * BS;
+#pragma unroll
+            for (int i = 0; i <= K; ++i) {
+                if ((unsigned)(ix0 + i) >= (unsigned)BS) continue;                 // another brick's taps
+#pragma unroll
+                for (int j = 0; j <= K; ++j) {
+                    if ((unsigned)(iy0 + j) >= (unsigned)BS) continue;
+                    const float wij = wx[i] * wy[j];
+                    const int row = ((ix0 + i) * BS + (iy0 + j)) * BS + iz0;
+#pragma unroll
+                    for (int k = 0; k <= K; ++k) {
+                        if ((unsigned)(iz0 + k) >= (unsigned)BS) continue;
+                        const float w = wij * wz[k];
+#pragma unroll
+                        for (int c = 0; c < NCH; ++c) {
+                            if (finite[c]) {
+                                atomicAdd(&acc[c * BSLOTS + row + k], (unsigned long long)(long long)__float2int_rn(sv[c] * w));   // ds_add_u64
+                            } else {
+                                const int64_t off = (int64_t)(i0[0] + i) * (p.vol_ss[0] / 4) + (int64_t)(i0[1] + j) * (p.vol_ss[1] / 4)
+                                                  + (int64_t)(i0[2] + k) * (p.vol_ss[2] / 4);
+                                __hip_atomic_fetch_add(vt + c * p.vol_sc + off, w * (sv[c] * inv[c]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            }
+                        }
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        // the brick goes to the target: this workgroup is its only writer (border samples are
+        // splatted by another kernel of the same stream)
+        for (int e = tid; e < BSLOTS; e += 1024) {
+            const int sx = e / (BS * BS), sy = (e / BS) % BS, sz = e % BS;
+            const int gx = bx * BS + sx, gy = by * BS + sy, gz = bz * BS + sz;
+            if (gx >= p.vol_n[0] || gy >= p.vol_n[1] || gz >= p.vol_n[2]) continue;
+            const int64_t off = (int64_t)gx * (p.vol_ss[0] / 4) + (int64_t)gy * (p.vol_ss[1] / 4) + (int64_t)gz * (p.vol_ss[2] / 4);
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) {
+                const long long a = (long long)acc[c * BSLOTS + e];
+                if (a != 0) vt[c * p.vol_sc + off] += (float)a * inv[c];
+            }
+        }
+    }
+}
+
+} // namespace
+
+int64_t bricks_workspace_bytes(const KParams &p, int B, int shared)
+{
+    int64_t nbt = shared ? 1 : B;
+    for (int d = 0; d < 3; ++d) nbt *= (p.vol_n[d] + BS - 1) / BS;
+    return 4 * ((int64_t)HDR + 8 * 256 + nbt + (nbt + 1) + nbt) + 4 * 9 * (int64_t)B * p.N;      // per sample: <= 8 brick entries + 1 border entry
+}
+
+// k.C value channels (+ k.cc: count channel).  1 = done, 0 = declined, < 0 error.
+int launch_push_bricks(const KParams &p, int B, int shared, const void *val, const void *grid, void *vol,
+                       void *workspace, int64_t workspace_bytes, hipStream_t st)
+{
+    const int nch = p.C + p.cc;
+    if (p.dim != 3 || nch < 1 || nch > 4 || (uint64_t)B * (uint64_t)p.N > 0xffffffffull) return 0;
+    const int K = p.order[0];
+    if (p.order[1] != K || p.order[2] != K || K > 3) return 0;                        // one order <= 3 for all dims
+    if (workspace_bytes < bricks_workspace_bytes(p, B, shared)) return INTERPOL_E_SCRATCH;
+    Bricks bk;
+    int64_t per = 1;
+    for (int d = 0; d < 3; ++d) { bk.nb[d] = (p.vol_n[d] + BS - 1) / BS; per *= bk.nb[d]; }
+    const int64_t nbt = per * (shared ? 1 : B);
+    if (nbt > 0x3fffffff) return 0;
+    bk.per_target = (int)per; bk.shared = shared; bk.N = (unsigned)p.N;
+    int *w = (int *)workspace;
+    bk.hdr = w; bk.partial = w + HDR; bk.counts = bk.partial + 8 * 256; bk.offsets = bk.counts + nbt; bk.cursor = bk.offsets + nbt + 1;
+    bk.list = (unsigned *)(bk.cursor + nbt);
+    bk.border = bk.list + 8 * (int64_t)B * p.N;
+    hipError_t e = hipMemsetAsync(workspace, 0, 4 * (size_t)(HDR + 8 * 256 + nbt), st);       // header + partial maxima + counters
+    if (e != hipSuccess) return (int)e;
+    const dim3 grid1((unsigned)((p.N + 255) / 256), (unsigned)(B < 65535 ? B : 65535));
+    if (p.C > 0) hipLaunchKernelGGL((bricks_max), dim3(256, (unsigned)p.C), dim3(256), 0, st, p, bk, (const float *)val, B);
+    hipLaunchKernelGGL((bricks_walk<false>), grid1, dim3(256), 0, st, p, bk, (const float *)val, (const float *)grid, (float *)vol, B, nch);
+    hipLaunchKernelGGL((bricks_scan), dim3(1), dim3(1024), 0, st, bk, (int)nbt, p.C);
+    hipLaunchKernelGGL((bricks_walk<true>), grid1, dim3(256), 0, st, p, bk, (const float *)val, (const float *)grid, (float *)vol, B, nch);
+    hipLaunchKernelGGL((bricks_border), dim3(1024), dim3(256), 0, st, p, bk, (const float *)val, (const float *)grid, (float *)vol, nch);
+    const size_t lds = (size_t)nch * BSLOTS * 8;
+    const unsigned blocks = (unsigned)(nbt < 2048 ? nbt : 2048);
+#define IP_BR2(NC, KK) { \
+        if (lds > 64 * 1024) { e = hipFuncSetAttribute((const void *)bricks_accumulate<NC, KK>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+                               if (e != hipSuccess) return (int)e; } \
+        hipLaunchKernelGGL((bricks_accumulate<NC, KK>), dim3(blocks), dim3(1024), lds, st, p, bk, (const float *)val, (const float *)grid, (float *)vol, (int)nbt); }
+#define IP_BR(NC) case NC: switch (K) { case 0: IP_BR2(NC, 0) break; case 1: IP_BR2(NC, 1) break; case 2: IP_BR2(NC, 2) break; default: IP_BR2(NC, 3) break; } break;
+    switch (nch) { IP_BR(1) IP_BR(2) IP_BR(3) IP_BR(4) default: return 0; }
+#undef IP_BR
+#undef IP_BR2
+    e = hipGetLastError();
+    return e == hipSuccess ? 1 : (int)e;
+}
+
+} // namespace ip

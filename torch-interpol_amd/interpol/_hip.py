@@ -31,7 +31,8 @@ _DTYPE_CODE = {torch.float32: F32, torch.float64: F64, torch.bfloat16: BF16, tor
 SYMBOLS = (
     "interpol_pull", "interpol_push", "interpol_count", "interpol_grad", "interpol_pushgrad",
     "interpol_hess", "interpol_pull_backward", "interpol_push_backward", "interpol_count_backward",
-    "interpol_spline_filter", "interpol_resample_1d", "interpol_pull_labels", "interpol_host_bound_index", "interpol_host_bound_sign",
+    "interpol_spline_filter", "interpol_resample_1d", "interpol_pull_labels",
+    "interpol_push_bricks", "interpol_push_bricks_workspace", "interpol_host_bound_index", "interpol_host_bound_sign",
     "interpol_host_weight", "interpol_host_weight_f32", "interpol_abi_version",
     "interpol_error_string", "interpol_kernel_name",
 )
@@ -89,6 +90,10 @@ def lib():
     L.interpol_count_backward.argtypes = [pp, vp, vp, vp, vp]
     L.interpol_spline_filter.argtypes = [vp, i32, i64, i64, i64, i32, i32, vp]
     L.interpol_pull_labels.argtypes = [pp, vp, vp, vp, vp]
+    L.interpol_push_bricks.argtypes = [pp, vp, vp, vp, vp, i64, vp]
+    L.interpol_push_bricks.restype = ctypes.c_int
+    L.interpol_push_bricks_workspace.argtypes = [pp]
+    L.interpol_push_bricks_workspace.restype = i64
     L.interpol_resample_1d.argtypes = [i32, i32, i32, i32, i32, i32, i32, i64, i64, i64, i64, vp, vp, vp, vp]
     for name in ("interpol_pull", "interpol_grad", "interpol_hess", "interpol_push", "interpol_pushgrad",
                  "interpol_count", "interpol_pull_backward", "interpol_push_backward",
@@ -519,3 +524,56 @@ def pull_labels(vol, grid, bound, order, extrapolate, flags=0):
         rc = lib().interpol_pull_labels(ctypes.byref(p), _ptr(vol), _ptr(grid), _ptr(val), _stream(dev))
     _check(rc, "interpol_pull_labels")
     return val
+
+
+def bricks_applicable(val, grid, with_count, order=None):
+    """Can interpol_push_bricks take this problem? (3-D, fp32, one order <= 3 for all dims,
+    <= 4 target channels, < 2^32 samples)"""
+    dim = grid.shape[-1]
+    if order is not None:
+        o = list(order)[:3]
+        if len(set(o)) != 1 or o[0] > 3:
+            return False
+    return (dim == 3 and val is not None and val.dtype == torch.float32 and grid.dtype == torch.float32
+            and val.shape[1] + (1 if with_count else 0) <= 4
+            and max(val.shape[0], grid.shape[0]) * int(torch.Size(grid.shape[1:-1]).numel()) < 2 ** 32)
+
+
+def push_bricks(val, grid, shape, bound, order, extrapolate, flags=0, out=None, shared=False, with_count=False):
+    """interpol_push_bricks: push (and count) organised by target brick -- for expanding deformations.
+    Same arguments and result as `scatter("push", ...)`."""
+    dev = _require_gpu(val, grid)
+    dim = grid.shape[-1]
+    if not bricks_applicable(val, grid, with_count, order):
+        raise ValueError("push_bricks: 3-D float32 problems, one order <= 3, at most 4 target channels only")
+    grid, gflag = _prep_grid(grid, torch.float32)
+    flags |= gflag | (FLAG_WITH_COUNT if with_count else 0)
+    val = val.contiguous()
+    gshape = list(grid.shape[1:-1])
+    shape = [int(s) for s in (gshape if shape is None else shape)]
+    B = max(val.shape[0], grid.shape[0])
+    C = val.shape[1]
+    Cv = C + (1 if with_count else 0)
+    Bv = 1 if shared else B
+    if out is None:
+        vol = torch.empty([Bv, Cv] + shape, dtype=torch.float32, device=dev)
+    else:
+        vol = out
+        assert vol.is_contiguous() and vol.dtype == torch.float32 and list(vol.shape) == [Bv, Cv] + shape
+    if vol.numel() == 0:
+        return vol
+    if grid.numel() == 0:
+        return vol.zero_() if out is None else vol
+    valstr = [_bstride(val, B), val.stride(1)] + _pad_to([val.stride(2 + d) for d in range(dim)], 3) + [0, 0]
+    vstr = [0 if shared else vol.stride(0), vol.stride(1)] + _pad_to([vol.stride(2 + d) for d in range(dim)], 3)
+    p = make_problem(dim, torch.float32, torch.float32, bound, order, extrapolate, B, C, shape, gshape,
+                     vstr, _grid_strides(grid, B, dim), valstr, flags)
+    L = lib()
+    nbytes = L.interpol_push_bricks_workspace(ctypes.byref(p))
+    if nbytes < 0:
+        _check(int(nbytes), "interpol_push_bricks_workspace")
+    work = torch.empty(int(nbytes), dtype=torch.uint8, device=dev)
+    with torch.cuda.device(dev):
+        rc = L.interpol_push_bricks(ctypes.byref(p), _ptr(val), _ptr(grid), _ptr(vol), _ptr(work), int(nbytes), _stream(dev))
+    _check(rc, "interpol_push_bricks")
+    return vol

@@ -51,6 +51,8 @@ class _HipKernels:
 
     @staticmethod
     def push(inp, grid, shape, bound, order, extrapolate, displacement=False):
+        if shape is not None and _HipKernels.expanding(inp, grid, shape, False, order):
+            return _hip.push_bricks(inp, grid, shape, bound, order, extrapolate, flags=_dflag(displacement))
         return _hip.scatter("push", inp, grid, shape, bound, order, extrapolate, flags=_dflag(displacement))
 
     @staticmethod
@@ -66,11 +68,32 @@ class _HipKernels:
         """out (1,C,*shape) += sum over the batch of push(inp, grid); count when inp is None;
         with_count: out has C + 1 channels, the last one accumulates the count in the same pass."""
         op = "count" if inp is None else "push"
-        return _hip.scatter(op, inp, grid, list(out.shape[2:]), bound, order, extrapolate,
+        shape = list(out.shape[2:])
+        if _HipKernels.expanding(inp, grid, shape, with_count, order):
+            return _hip.push_bricks(inp, grid, shape, bound, order, extrapolate, flags=_hip.FLAG_ACCUMULATE, out=out,
+                                    shared=True, with_count=with_count)
+        return _hip.scatter(op, inp, grid, shape, bound, order, extrapolate,
                             flags=_hip.FLAG_ACCUMULATE, out=out, shared=True, with_count=with_count)
 
     @staticmethod
+    def expanding(inp, grid, shape, with_count, order=None):
+        """Is the target-stationary scheme (interpol_push_bricks) the better one?  Yes when the
+        target has many more voxels than there are samples per item: neighbouring samples then own
+        disjoint target voxels and a sample-stationary tile has nothing to merge."""
+        if inp is None or not _hip.bricks_applicable(inp, grid, with_count, order):
+            return False
+        nsamp = 1
+        for n in grid.shape[1:-1]:
+            nsamp *= int(n)
+        nvox = 1
+        for n in shape:
+            nvox *= int(n)
+        return nvox >= 8 * nsamp
+
+    @staticmethod
     def push_count(inp, grid, shape, bound, order, extrapolate, displacement=False):
+        if shape is not None and _HipKernels.expanding(inp, grid, shape, True, order):
+            return _hip.push_bricks(inp, grid, shape, bound, order, extrapolate, flags=_dflag(displacement), with_count=True)
         return _hip.scatter("push", inp, grid, shape, bound, order, extrapolate, flags=_dflag(displacement), with_count=True)
 
     @staticmethod
