@@ -178,7 +178,7 @@ int interpol_count_backward(const interpol_problem *p, const void *grad_vol_out,
  * channels (+1 with the count) <= 4, batch * samples < 2^32; otherwise INTERPOL_E_DTYPE /
  * INTERPOL_E_DIM / INTERPOL_E_SHAPE and the caller uses interpol_push.  Honours ACCUMULATE,
  * WITH_COUNT, SEPARABLE_GRID, DISPLACEMENT and the shared target (vol batch stride 0).
- * `workspace`: device scratch of interpol_push_bricks_workspace(p) bytes (32 B per sample + counters). */
+ * `workspace`: device scratch of interpol_push_bricks_workspace(p) bytes (32 B per sample + 12 B per brick). */
 int64_t interpol_push_bricks_workspace(const interpol_problem *p);
 int interpol_push_bricks(const interpol_problem *p, const void *val, const void *grid, void *vol,
                          void *workspace, int64_t workspace_bytes, void *stream);

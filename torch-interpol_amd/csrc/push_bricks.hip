@@ -6,9 +6,9 @@
 // in LDS and every contribution becomes a global atomic (2.1 G of them for 8 sources, 32 ms).
 // Here the TARGET is cut into 16^3 bricks and each brick is owned by one workgroup:
 //   1. count : every sample adds 1 to the counter of each brick its stencil overlaps (<= 8);
-//              border samples (stencil leaving the lattice: boundary wrap) go to a separate list
-//              and are splatted tap-parallel with float atomics; per-channel max|src| is reduced
-//              on the way
+//              border samples (stencil leaving the lattice: boundary wrap) are left to a
+//              separate walk that splats them tap-parallel with float atomics; per-channel
+//              max|src| comes from a two-stage reduction
 //   2. scan  : exclusive prefix of the counters -> list offsets
 //   3. fill  : the same walk writes the sample ids into the bricks' lists
 //   4. brick : a workgroup accumulates its brick in LDS -- 64-bit fixed point, ds_add_u64, all
@@ -25,7 +25,7 @@ namespace ip {
 namespace {
 
 constexpr int BS = 16, BSLOTS = BS * BS * BS;
-constexpr int HDR = 16;                       // workspace header (ints): [0..7] max|src| bits per channel, [8] border-list length
+constexpr int HDR = 16;                       // workspace header (ints): [0..7] max|src| bits per channel
 
 struct Bricks {
     int nb[3];                                // bricks per dim
@@ -33,7 +33,7 @@ struct Bricks {
     int shared;                               // batch stride 0: one target for the whole batch
     unsigned N;                               // samples per batch item
     int *hdr, *counts, *offsets, *cursor;     // workspace
-    unsigned *list, *border;                  // per-brick sample lists; border samples
+    unsigned *list;                           // per-brick sample lists
     int *partial;                             // 8 x MAXPART partial maxima
 };
 
@@ -74,6 +74,44 @@ __device__ __forceinline__ int wave_max_i(int v)
     return v;
 }
 
+// The (at most two) bricks that the taps of one dim fall into, after the boundary condition
+// (bounds.py:30-89) for border samples.  Taps with sign 0 go nowhere.  Returns the number of
+// distinct bricks (0, 1, 2) or 3 when there are more than two (tiny lattices): such samples are
+// left to the atomic walk (bricks_border).
+__device__ __noinline__ int dim_bricks(int bound, int k, int n, int i0, bool border, int *b0, int *b1)
+{
+    if (!border) { *b0 = i0 / BS; *b1 = (i0 + k) / BS; return *b1 > *b0 ? 2 : 1; }
+    int cnt = 0;
+    for (int j = 0; j <= k; ++j) {
+        const long long pk = wrap_outofline(bound, i0 + j, n);
+        if ((int)(pk >> 32) == 0) continue;
+        const int br = (int)(pk & 0xffffffffll) / BS;
+        if (cnt == 0) { *b0 = br; cnt = 1; }
+        else if (br != *b0 && (cnt == 1 || br != *b1)) { if (cnt == 2) return 3; *b1 = br; cnt = 2; }
+    }
+    return cnt;
+}
+
+// arr[key] += (number of active lanes with this key), one atomic per distinct key of the wave;
+// returns the slot of this lane (old value + rank among the lanes of its key).
+__device__ __forceinline__ int wave_agg_add(int *arr, int key, bool active)
+{
+    const int lane = threadIdx.x & 63;
+    int result = 0;
+    unsigned long long todo = __ballot(active);
+    while (todo) {
+        const int leader = __ffsll((unsigned long long)todo) - 1;
+        const int k = __shfl(key, leader);
+        const unsigned long long same = __ballot(active && key == k);
+        int base = 0;
+        if (lane == leader) base = atomicAdd(&arr[k], __popcll(same));
+        base = __shfl(base, leader);
+        if (active && key == k) result = base + __popcll(same & ((1ull << lane) - 1ull));
+        todo &= ~same;
+    }
+    return result;
+}
+
 // max |src| per value channel, stage 1 of 2 (stage 2 in bricks_scan): blockIdx.y = channel,
 // each block reduces a strided share of the (B, N) values and writes one partial.
 constexpr int MAXPART = 256;
@@ -111,62 +149,83 @@ __global__ __launch_bounds__(256) void bricks_walk(KParams p, Bricks bk, const f
         int i0[3]; float t[3];
         int cls = 0;
         if (live) { load_coords<float, float, 3>(p, grid, b, o, x); cls = classify(p, x, i0, t); }
-        if (cls == 1) {
+        {
+            // The lanes of a wave are neighbouring samples: they mostly hit the same one or two
+            // bricks.  One counter update per distinct brick and wave (wave_agg_add), not per lane:
+            // same-address global atomics serialise.
             const int tb = bk.shared ? 0 : b;
-            const int bx0 = i0[0] / BS, bx1 = (i0[0] + p.order[0]) / BS;
-            const int by0 = i0[1] / BS, by1 = (i0[1] + p.order[1]) / BS;
-            const int bz0 = i0[2] / BS, bz1 = (i0[2] + p.order[2]) / BS;
-            for (int bx = bx0; bx <= bx1; ++bx)
-                for (int by = by0; by <= by1; ++by)
-                    for (int bz = bz0; bz <= bz1; ++bz) {
-                        const int br = tb * bk.per_target + (bx * bk.nb[1] + by) * bk.nb[2] + bz;
-                        if (FILL) bk.list[atomicAdd(&bk.cursor[br], 1)] = (unsigned)b * bk.N + o;
-                        else atomicAdd(&bk.counts[br], 1);
+            int bb[3][2] = { { 0, 0 }, { 0, 0 }, { 0, 0 } }, nb_[3] = { 0, 0, 0 };
+            bool in = cls != 0;
+            if (cls != 0) {
+#pragma unroll
+                for (int d = 0; d < 3; ++d) {
+                    if (cls == 1) {            // interior: no boundary condition to apply (the common case, inline)
+                        bb[d][0] = i0[d] / BS; bb[d][1] = (i0[d] + p.order[d]) / BS;
+                        nb_[d] = bb[d][1] > bb[d][0] ? 2 : 1;
+                    } else {
+                        nb_[d] = dim_bricks(p.bound[d], p.order[d], p.vol_n[d], i0[d], true, &bb[d][0], &bb[d][1]);
                     }
-        }
-        if (!FILL) {
-            // border samples -> their own list, one counter update per wave
-            const unsigned long long m = __ballot(cls == 2);
-            if (m) {
-                int base = 0;
-                if ((threadIdx.x & 63) == 0) base = atomicAdd(&bk.hdr[8], __popcll(m));
-                base = __shfl(base, 0);
-                if (cls == 2) bk.border[base + __popcll(m & ((1ull << (threadIdx.x & 63)) - 1ull))] = (unsigned)b * bk.N + o;
+                    in = in && nb_[d] >= 1 && nb_[d] <= 2;          // 0: nothing to splat; 3: left to bricks_border
+                }
+            }
+#pragma unroll
+            for (int corner = 0; corner < 8; ++corner) {
+                const int ex = corner >> 2, ey = (corner >> 1) & 1, ez = corner & 1;
+                const bool on = in && (!ex || nb_[0] == 2) && (!ey || nb_[1] == 2) && (!ez || nb_[2] == 2);
+                const int br = tb * bk.per_target + (bb[0][ex] * bk.nb[1] + bb[1][ey]) * bk.nb[2] + bb[2][ez];
+                const int pos = wave_agg_add(FILL ? bk.cursor : bk.counts, br, on);
+                if (FILL && on) bk.list[pos] = (unsigned)b * bk.N + o;
             }
         }
     }
 }
 
-// Border samples (stencil leaving the lattice): one wave per sample, lanes = taps, boundary wrap
-// per tap (bounds.py:30-89), float atomics straight to the target.
+// Border samples (stencil leaving the lattice).  Same walk as above -- every lane classifies its
+// own sample from a coalesced read -- then the wave takes its border samples one at a time, lanes =
+// taps, boundary wrap per tap (bounds.py:30-89), float atomics straight to the target.
 __global__ __launch_bounds__(256) void bricks_border(KParams p, Bricks bk, const float *__restrict__ val, const float *__restrict__ grid,
-                                                     float *__restrict__ vol, int nch)
+                                                     float *__restrict__ vol, int B, int nch)
 {
-    const int lane = threadIdx.x & 63, nw = gridDim.x * 4;
+    const unsigned o = blockIdx.x * 256u + threadIdx.x;
+    const int lane = threadIdx.x & 63;
     const int k1[3] = { p.order[0] + 1, p.order[1] + 1, p.order[2] + 1 };
     const int ntap = k1[0] * k1[1] * k1[2];
-    const int n = bk.hdr[8];
-    for (int e = blockIdx.x * 4 + (threadIdx.x >> 6); e < n; e += nw) {
-        const unsigned id = bk.border[e];
-        const unsigned b = id / bk.N, o = id - b * bk.N;
-        float x[3]; int i0[3]; float t[3];
-        load_coords<float, float, 3>(p, grid, (int64_t)b, (int64_t)o, x);
-        classify(p, x, i0, t);
-        float *vb = vol + (bk.shared ? 0 : (int64_t)b * p.vol_sb);
-        for (int t0 = 0; t0 < ntap; t0 += 64) {
-            const int tap = t0 + lane;
-            if (tap >= ntap) continue;
-            const int tp[3] = { tap / (k1[1] * k1[2]), (tap / k1[2]) % k1[1], tap % k1[2] };
-            float w = 1.f; int64_t off = 0;
+    for (int b = blockIdx.y; b < B; b += gridDim.y) {
+        float x[3] = { 0.f, 0.f, 0.f };
+        int i0[3] = { 0, 0, 0 }; float t[3] = { 0.f, 0.f, 0.f };
+        int cls = 0;
+        if (o < bk.N) { load_coords<float, float, 3>(p, grid, b, o, x); cls = classify(p, x, i0, t); }
+        bool far = false;                                  // more than two bricks along a dim: not in the lists
+        if (cls == 2) {
+            int u0, u1;
 #pragma unroll
-            for (int d = 0; d < 3; ++d) {
-                const long long pk = wrap_outofline(p.bound[d], i0[d] + tp[d], p.vol_n[d]);
-                w *= weight_of(p, d, t[d], tp[d]) * (float)(int)(pk >> 32);
-                off += (int64_t)(int)(pk & 0xffffffffll) * (p.vol_ss[d] / 4);
-            }
-            for (int c = 0; c < nch; ++c) {
-                const float sv = c < p.C ? val[(int64_t)b * p.val_sb + c * p.val_sc + o] : 1.f;
-                __hip_atomic_fetch_add(vb + c * p.vol_sc + off, w * sv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            for (int d = 0; d < 3; ++d) far = far || dim_bricks(p.bound[d], p.order[d], p.vol_n[d], i0[d], true, &u0, &u1) == 3;
+        }
+        unsigned long long todo = __ballot(far);
+        if (!todo) continue;
+        float sv[4] = { 1.f, 1.f, 1.f, 1.f };
+        if (far)
+            for (int c = 0; c < p.C; ++c) sv[c] = val[(int64_t)b * p.val_sb + c * p.val_sc + o];
+        float *vb = vol + (bk.shared ? 0 : (int64_t)b * p.vol_sb);
+        while (todo) {
+            const int j = __ffsll((unsigned long long)todo) - 1;
+            todo &= todo - 1;
+            const int q0[3] = { __shfl(i0[0], j), __shfl(i0[1], j), __shfl(i0[2], j) };
+            const float tt[3] = { __shfl(t[0], j), __shfl(t[1], j), __shfl(t[2], j) };
+            const float s4[4] = { __shfl(sv[0], j), __shfl(sv[1], j), __shfl(sv[2], j), __shfl(sv[3], j) };
+            for (int t0 = 0; t0 < ntap; t0 += 64) {
+                const int tap = t0 + lane;
+                if (tap >= ntap) continue;
+                const int tp[3] = { tap / (k1[1] * k1[2]), (tap / k1[2]) % k1[1], tap % k1[2] };
+                float w = 1.f; int64_t off = 0;
+#pragma unroll
+                for (int d = 0; d < 3; ++d) {
+                    const long long pk = wrap_outofline(p.bound[d], q0[d] + tp[d], p.vol_n[d]);
+                    w *= weight_of(p, d, tt[d], tp[d]) * (float)(int)(pk >> 32);
+                    off += (int64_t)(int)(pk & 0xffffffffll) * (p.vol_ss[d] / 4);
+                }
+                for (int c = 0; c < nch; ++c)
+                    __hip_atomic_fetch_add(vb + c * p.vol_sc + off, w * (c < p.C ? s4[c < 4 ? c : 3] : 1.f), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         }
     }
@@ -236,33 +295,47 @@ __global__ __launch_bounds__(1024) void bricks_accumulate(KParams p, Bricks bk, 
             const unsigned b = id / bk.N, o = id - b * bk.N;
             float x[3]; int i0[3]; float t[3];
             load_coords<float, float, 3>(p, grid, (int64_t)b, (int64_t)o, x);
-            classify(p, x, i0, t);
+            const int cls = classify(p, x, i0, t);
             float sv[NCH];
 #pragma unroll
             for (int c = 0; c < NCH; ++c) sv[c] = (c < p.C ? val[(int64_t)b * p.val_sb + c * p.val_sc + o] : 1.f) * scale[c];
             float wx[K + 1], wy[K + 1], wz[K + 1];
 #pragma unroll
             for (int j = 0; j <= K; ++j) { wx[j] = weight_of(p, 0, t[0], j); wy[j] = weight_of(p, 1, t[1], j); wz[j] = weight_of(p, 2, t[2], j); }
-            const int ix0 = i0[0] - bx * BS, iy0 = i0[1] - by * BS, iz0 = i0[2] - bz * BS;
+            // lattice index (relative to the brick) and sign of every tap; border samples wrap
+            int jx[K + 1], jy[K + 1], jz[K + 1];
 #pragma unroll
-            for (int i = 0; i <= K; ++i) {
-                if ((unsigned)(ix0 + i) >= (unsigned)BS) continue;                 // another brick's taps
+            for (int j = 0; j <= K; ++j) { jx[j] = i0[0] + j - bx * BS; jy[j] = i0[1] + j - by * BS; jz[j] = i0[2] + j - bz * BS; }
+            if (cls == 2) {
 #pragma unroll
                 for (int j = 0; j <= K; ++j) {
-                    if ((unsigned)(iy0 + j) >= (unsigned)BS) continue;
+                    const long long px = wrap_outofline(p.bound[0], i0[0] + j, p.vol_n[0]);
+                    const long long py = wrap_outofline(p.bound[1], i0[1] + j, p.vol_n[1]);
+                    const long long pz = wrap_outofline(p.bound[2], i0[2] + j, p.vol_n[2]);
+                    jx[j] = (int)(px & 0xffffffffll) - bx * BS; wx[j] *= (float)(int)(px >> 32);
+                    jy[j] = (int)(py & 0xffffffffll) - by * BS; wy[j] *= (float)(int)(py >> 32);
+                    jz[j] = (int)(pz & 0xffffffffll) - bz * BS; wz[j] *= (float)(int)(pz >> 32);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i <= K; ++i) {
+                if ((unsigned)jx[i] >= (unsigned)BS) continue;                     // another brick's taps
+#pragma unroll
+                for (int j = 0; j <= K; ++j) {
+                    if ((unsigned)jy[j] >= (unsigned)BS) continue;
                     const float wij = wx[i] * wy[j];
-                    const int row = ((ix0 + i) * BS + (iy0 + j)) * BS + iz0;
+                    const int row = (jx[i] * BS + jy[j]) * BS;
 #pragma unroll
                     for (int k = 0; k <= K; ++k) {
-                        if ((unsigned)(iz0 + k) >= (unsigned)BS) continue;
+                        if ((unsigned)jz[k] >= (unsigned)BS) continue;
                         const float w = wij * wz[k];
 #pragma unroll
                         for (int c = 0; c < NCH; ++c) {
                             if (finite[c]) {
-                                atomicAdd(&acc[c * BSLOTS + row + k], (unsigned long long)(long long)__float2int_rn(sv[c] * w));   // ds_add_u64
+                                atomicAdd(&acc[c * BSLOTS + row + jz[k]], (unsigned long long)(long long)__float2int_rn(sv[c] * w));   // ds_add_u64
                             } else {
-                                const int64_t off = (int64_t)(i0[0] + i) * (p.vol_ss[0] / 4) + (int64_t)(i0[1] + j) * (p.vol_ss[1] / 4)
-                                                  + (int64_t)(i0[2] + k) * (p.vol_ss[2] / 4);
+                                const int64_t off = (int64_t)(bx * BS + jx[i]) * (p.vol_ss[0] / 4) + (int64_t)(by * BS + jy[j]) * (p.vol_ss[1] / 4)
+                                                  + (int64_t)(bz * BS + jz[k]) * (p.vol_ss[2] / 4);
                                 __hip_atomic_fetch_add(vt + c * p.vol_sc + off, w * (sv[c] * inv[c]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                             }
                         }
@@ -293,7 +366,7 @@ int64_t bricks_workspace_bytes(const KParams &p, int B, int shared)
 {
     int64_t nbt = shared ? 1 : B;
     for (int d = 0; d < 3; ++d) nbt *= (p.vol_n[d] + BS - 1) / BS;
-    return 4 * ((int64_t)HDR + 8 * 256 + nbt + (nbt + 1) + nbt) + 4 * 9 * (int64_t)B * p.N;      // per sample: <= 8 brick entries + 1 border entry
+    return 4 * ((int64_t)HDR + 8 * 256 + nbt + (nbt + 1) + nbt) + 4 * 8 * (int64_t)B * p.N;      // per sample: <= 8 brick entries
 }
 
 // k.C value channels (+ k.cc: count channel).  1 = done, 0 = declined, < 0 error.
@@ -314,7 +387,6 @@ int launch_push_bricks(const KParams &p, int B, int shared, const void *val, con
     int *w = (int *)workspace;
     bk.hdr = w; bk.partial = w + HDR; bk.counts = bk.partial + 8 * 256; bk.offsets = bk.counts + nbt; bk.cursor = bk.offsets + nbt + 1;
     bk.list = (unsigned *)(bk.cursor + nbt);
-    bk.border = bk.list + 8 * (int64_t)B * p.N;
     hipError_t e = hipMemsetAsync(workspace, 0, 4 * (size_t)(HDR + 8 * 256 + nbt), st);       // header + partial maxima + counters
     if (e != hipSuccess) return (int)e;
     const dim3 grid1((unsigned)((p.N + 255) / 256), (unsigned)(B < 65535 ? B : 65535));
@@ -322,7 +394,7 @@ int launch_push_bricks(const KParams &p, int B, int shared, const void *val, con
     hipLaunchKernelGGL((bricks_walk<false>), grid1, dim3(256), 0, st, p, bk, (const float *)val, (const float *)grid, (float *)vol, B, nch);
     hipLaunchKernelGGL((bricks_scan), dim3(1), dim3(1024), 0, st, bk, (int)nbt, p.C);
     hipLaunchKernelGGL((bricks_walk<true>), grid1, dim3(256), 0, st, p, bk, (const float *)val, (const float *)grid, (float *)vol, B, nch);
-    hipLaunchKernelGGL((bricks_border), dim3(1024), dim3(256), 0, st, p, bk, (const float *)val, (const float *)grid, (float *)vol, nch);
+    hipLaunchKernelGGL((bricks_border), grid1, dim3(256), 0, st, p, bk, (const float *)val, (const float *)grid, (float *)vol, B, nch);
     const size_t lds = (size_t)nch * BSLOTS * 8;
     const unsigned blocks = (unsigned)(nbt < 2048 ? nbt : 2048);
 #define IP_BR2(NC, KK) { \
