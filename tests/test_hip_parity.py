@@ -462,7 +462,7 @@ def test_prefilter_kernels_against_oracle(dtype, tol, inner):
     """All three prefilter kernels (wave-per-line scan for contiguous lines, chunked
     thread-per-line for interleaved lines, serial fallback) vs the oracle."""
     g = torch.Generator().manual_seed(2024 + inner)
-    for n in (2, 3, 5, 17, 64, 65, 127, 128, 200, 512, 1000, 1024, 2048, 2500):
+    for n in (2, 3, 5, 17, 64, 65, 127, 128, 200, 256, 512, 1000, 1024, 2048, 2500):
         x = torch.randn([3, n, inner], generator=g, dtype=torch.float64).to(dtype)
         xd = x.to(DEV)
         for order in range(2, 8):

@@ -535,6 +535,7 @@ int interpol_spline_filter(void *data, int32_t dtype, int64_t outer, int64_t n, 
     }
     fp.gain = 1.;
     for (int i = 0; i < fp.npoles; ++i) fp.gain *= (1. - fp.pole[i]) * (1. - 1. / fp.pole[i]);   // coeff.py:69-73
+    make_pole_pre(fp);
     return launch_filter(dtype, fp, data, (hipStream_t)stream);
 }
 

@@ -39,10 +39,6 @@ __device__ __forceinline__ R powi(R base, int64_t e)
     return r;
 }
 
-// Horizon beyond which |pole|^i is below one ulp of anything (fp64): terms further away
-// are dropped from the initial-value sums that the reference extends over the whole line.
-__device__ __forceinline__ int64_t horizon(double pole) { return (int64_t)ceil(-44. / log(fabs(pole))); }
-
 // ---------------------------------------------------------------------------
 // Initial value of the causal recursion as a weighted sum  init = A * sum_i w(i) c[i] + B * c[0]
 // and final value of the anticausal one; `W` describes the weights so that both kernels can
@@ -61,30 +57,12 @@ struct InitW {
     R pf, ipf, pn, pn2;
     R scale, c0w;        // init = scale * sum + c0w * c[0]
 
-    __device__ __forceinline__ void make(int bound, double pole, int64_t n_)
+    // constants from the host (filter_params.hpp: make_pole_pre)
+    __device__ __forceinline__ void load(const PolePre &q, int64_t n_)
     {
-        n = n_;
-        pf = (R)(float)pole; ipf = R(1) / pf;
-        const int64_t max_iter = (int64_t)ceil(-30. / log(fabs(pole)));
-        if (bound == 0) {
-            if (max_iter < n) { kind = 0; m = max_iter; pn = 0; pn2 = 0; scale = R(1); c0w = R(0); }
-            else {
-                kind = 1; m = n;
-                const double polen = pow(pole, (double)(n - 1));
-                pn = (R)polen; pn2 = (R)(polen * polen);
-                scale = (R)(1. / (1. - polen * polen)); c0w = R(0);
-            }
-        } else if (bound == 1) {
-            kind = 2;
-            const double polen = pow(pole, (double)n);
-            pn = (R)polen; pn2 = 0;
-            const int64_t h = horizon(pole);
-            m = n <= 2 * h ? n : h;               // long lines: the mirrored tail is < 1e-19 of the head
-            scale = (R)(pole / (1. - polen * polen)); c0w = R(1);
-        } else {
-            kind = 3; m = max_iter < n ? max_iter : n; pn = 0; pn2 = 0;
-            scale = (R)(1. / (1. - pow(pole, (double)m))); c0w = R(0);
-        }
+        n = n_; kind = q.kind; m = q.m;
+        pf = (R)q.pf; ipf = R(1) / pf; pn = (R)q.pn; pn2 = (R)q.pn2;
+        scale = (R)q.scale; c0w = (R)q.c0w;
     }
     // does index i contribute, and with which weight?  (serial callers walk i upwards)
     __device__ __forceinline__ bool on(int64_t i) const
@@ -122,7 +100,7 @@ __global__ __launch_bounds__(256) void prefilter_strided(FilterParams fp, T *dat
     for (int ip = 0; ip < fp.npoles; ++ip) {
         const double pole = fp.pole[ip];
         const R p = (R)pole;
-        InitW<R> iw; iw.make(fp.bound, pole, n);
+        InitW<R> iw; iw.load(fp.pre[ip], n);
         // ---- initial value ----
         R sum = R(0);
         if (iw.kind == 3) {
@@ -157,13 +135,13 @@ __global__ __launch_bounds__(256) void prefilter_strided(FilterParams fp, T *dat
         }
         // ---- final value ----
         R fin;
-        if (fp.bound == 0) fin = (p * last2 + prev) * (R)(pole / (pole * pole - 1.));
-        else if (fp.bound == 1) fin = prev * (R)(pole / (pole - 1.));
+        if (fp.bound == 0) fin = (p * last2 + prev) * (R)fp.pre[ip].fin_mul;
+        else if (fp.bound == 1) fin = prev * (R)fp.pre[ip].fin_mul;
         else {
             R dot = R(0), pw = iw.pf * iw.pf;
             for (int64_t i = 0; i < iw.m - 1; ++i) { dot += Cvt<R, T>::ld(base[i * st]) * pw; pw *= iw.pf; }
             dot += p * prev;
-            fin = dot / (R)(pow(pole, (double)iw.m) - 1.);
+            fin = dot * (R)fp.pre[ip].fin_mul;
         }
         // ---- anticausal pass: d[i] = p (d[i+1] - c[i])  (coeff.py:280-281), chunked ----
         base[(n - 1) * st] = Cvt<R, T>::st(fin);
@@ -207,14 +185,32 @@ __global__ __launch_bounds__(256) void prefilter_wave(FilterParams fp, T *data)
     T *base = data + line * n;
     const int64_t i0 = (int64_t)lane * RPL;             // lane owns samples [i0, i0 + RPL)
     R c[RPL];
+    // The lane-blocked ownership is what the recursion wants, but read that way every load
+    // instruction would touch 64 different 64-byte segments.  Global accesses are therefore
+    // coalesced (point r * 64 + lane) and the wave's line is turned round through LDS, rows padded
+    // by one word (lane stride RPL + 1: conflict-free).
+    constexpr bool VIA_LDS = sizeof(R) == 4;
+    __shared__ float tr[VIA_LDS ? 4 * 64 * (RPL + 1) : 1];
+    float *trw = tr + (VIA_LDS ? (threadIdx.x >> 6) * 64 * (RPL + 1) : 0);
+    if constexpr (VIA_LDS) {
 #pragma unroll
-    for (int r = 0; r < RPL; ++r) c[r] = (i0 + r < n) ? Cvt<R, T>::ld(base[i0 + r]) * (R)fp.gain : R(0);   // coeff.py:268
+        for (int r = 0; r < RPL; ++r) {
+            const int i = r * 64 + lane;
+            trw[i + i / RPL] = (i < n) ? (float)(Cvt<R, T>::ld(base[i]) * (R)fp.gain) : 0.f;   // coeff.py:268
+        }
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int r = 0; r < RPL; ++r) c[r] = (R)trw[lane * (RPL + 1) + r];
+    } else {
+#pragma unroll
+        for (int r = 0; r < RPL; ++r) c[r] = (i0 + r < n) ? Cvt<R, T>::ld(base[i0 + r]) * (R)fp.gain : R(0);   // coeff.py:268
+    }
     const int last_lane = (int)((n - 1) / RPL), last_r = (int)((n - 1) % RPL);
 
     for (int ip = 0; ip < fp.npoles; ++ip) {
         const double pole = fp.pole[ip];
         const R p = (R)pole;
-        InitW<R> iw; iw.make(fp.bound, pole, n);
+        InitW<R> iw; iw.load(fp.pre[ip], n);
         // ---- initial value: wave-parallel weighted sum ----
         R part = R(0);
         {
@@ -268,8 +264,8 @@ __global__ __launch_bounds__(256) void prefilter_wave(FilterParams fp, T *data)
         c_last = shfl_(c_last, last_lane);
         c_last2 = shfl_(c_last2, last_r == 0 ? (last_lane > 0 ? last_lane - 1 : 0) : last_lane);
         R fin;
-        if (fp.bound == 0) fin = (p * c_last2 + c_last) * (R)(pole / (pole * pole - 1.));
-        else if (fp.bound == 1) fin = c_last * (R)(pole / (pole - 1.));
+        if (fp.bound == 0) fin = (p * c_last2 + c_last) * (R)fp.pre[ip].fin_mul;
+        else if (fp.bound == 1) fin = c_last * (R)fp.pre[ip].fin_mul;
         else {
             R dpart = R(0);
 #pragma unroll
@@ -278,7 +274,7 @@ __global__ __launch_bounds__(256) void prefilter_wave(FilterParams fp, T *data)
                 if (i < iw.m - 1) dpart += c[r] * powi(iw.pf, i + 2);
             }
             const R dot = wave_sum_r(dpart) + p * c_last;
-            fin = dot / (R)(pow(pole, (double)iw.m) - 1.);
+            fin = dot * (R)fp.pre[ip].fin_mul;
         }
         // ---- anticausal: d[i] = p (d[i+1] - c[i]);  d[n-1] = fin ----
         // write as d[i] = a[i] + p d[i+1] with a[i] = -p c[i]; samples >= n contribute nothing
@@ -311,8 +307,188 @@ __global__ __launch_bounds__(256) void prefilter_wave(FilterParams fp, T *data)
             }
         }
     }
+    if constexpr (VIA_LDS) {
+        __builtin_amdgcn_wave_barrier();
 #pragma unroll
-    for (int r = 0; r < RPL; ++r) if (i0 + r < n) base[i0 + r] = Cvt<R, T>::st(c[r]);
+        for (int r = 0; r < RPL; ++r) trw[lane * (RPL + 1) + r] = (float)c[r];
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int r = 0; r < RPL; ++r) {
+            const int i = r * 64 + lane;
+            if (i < n) base[i] = Cvt<R, T>::st((R)trw[i + i / RPL]);
+        }
+    } else {
+#pragma unroll
+        for (int r = 0; r < RPL; ++r) if (i0 + r < n) base[i0 + r] = Cvt<R, T>::st(c[r]);
+    }
+}
+
+// ===========================================================================
+// Kernel B', the common case of kernel B without its generality: the line fills the wave
+// exactly (n == 64 * RPL) and the initial value is a short leading sum (dct1 with n > max_iter,
+// dct2) -- no per-element range tests, pole powers by running products.  Same arithmetic.
+// ===========================================================================
+// the line (64 * RPL points, RPL consecutive ones per lane) filtered in registers
+template <typename R, int RPL>
+__device__ __forceinline__ void line_filter_full(R (&c)[RPL], const FilterParams &fp, int lane)
+{
+    constexpr int n = 64 * RPL;
+    const int i0 = lane * RPL;
+    for (int ip = 0; ip < fp.npoles; ++ip) {
+        const PolePre &q = fp.pre[ip];
+        const R p = (R)fp.pole[ip], pf = (R)q.pf;
+        // ---- initial value: leading sum over i < m (kind 0: pf^i; kind 2: pf^i + pn pf^(n-1-i) when m == n) ----
+        R part = R(0);
+        if (i0 < q.m) {
+            R pw = powi(pf, (int64_t)i0);
+            const bool mirror = q.kind == 2 && q.m == n;
+            R pwr = mirror ? powi(pf, (int64_t)(n - 1 - i0)) : R(0);
+            const R ipf = R(1) / pf, pn = (R)q.pn;
+#pragma unroll
+            for (int r = 0; r < RPL; ++r) {
+                if (i0 + r < q.m) part += c[r] * (mirror ? pw + pn * pwr : pw);
+                pw *= pf; pwr *= ipf;
+            }
+        }
+        const R sum = wave_sum_r(part);
+        const R c_first = shfl_(c[0], 0);
+        const R init = (R)q.scale * sum + (R)q.c0w * c_first;
+        // ---- causal: serial inside the lane, scan of the lane carries, fix-up ----
+        R run = lane == 0 ? init : c[0];
+        c[0] = run;
+#pragma unroll
+        for (int r = 1; r < RPL; ++r) { run = c[r] + p * run; c[r] = run; }
+        R tot = c[RPL - 1];
+        R mul = powi(p, (int64_t)RPL);
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const R up = shfl_up_(tot, d);
+            if (lane >= d) tot += mul * up;
+            mul *= mul;
+        }
+        R carry = shfl_up_(tot, 1);
+        if (lane == 0) carry = R(0);
+        {
+            R pw = p;
+#pragma unroll
+            for (int r = 0; r < RPL; ++r) { c[r] += pw * carry; pw *= p; }
+        }
+        // ---- final value (coeff.py:183-227): dct1 (p c[n-2] + c[n-1]) f, dct2 c[n-1] f ----
+        const R c_last = shfl_(c[RPL - 1], 63);
+        const R c_last2 = shfl_(c[RPL > 1 ? RPL - 2 : 0], 63);
+        const R fin = (fp.bound == 0 ? p * c_last2 + c_last : c_last) * (R)q.fin_mul;
+        // ---- anticausal: d[i] = p (d[i+1] - c[i]);  d[n-1] = fin ----
+        R runb = lane == 63 ? fin : -p * c[RPL - 1];
+        c[RPL - 1] = runb;
+#pragma unroll
+        for (int r = RPL - 2; r >= 0; --r) { runb = -p * c[r] + p * runb; c[r] = runb; }
+        R totb = c[0];
+        R mulb = powi(p, (int64_t)RPL);
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const R dn = shfl_dn_(totb, d);
+            if (lane + d < 64) totb += mulb * dn;
+            mulb *= mulb;
+        }
+        R carryb = shfl_dn_(totb, 1);
+        if (lane == 63) carryb = R(0);
+        {
+            R pw = p;
+#pragma unroll
+            for (int r = RPL - 1; r >= 0; --r) {
+                if (!(lane == 63 && r == RPL - 1)) c[r] += pw * carryb;
+                pw *= p;
+            }
+        }
+    }
+}
+
+template <typename T, typename R, int RPL>
+__global__ __launch_bounds__(256) void prefilter_wave_full(FilterParams fp, T *data)
+{
+    static_assert(sizeof(R) == 4, "float math only");
+    const int lane = threadIdx.x & 63;
+    const int64_t line = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (line >= fp.outer) return;
+    constexpr int n = 64 * RPL;
+    T *base = data + line * n;
+    R c[RPL];
+    __shared__ float tr[4 * 64 * (RPL + 1)];
+    float *trw = tr + (threadIdx.x >> 6) * 64 * (RPL + 1);
+#pragma unroll
+    for (int r = 0; r < RPL; ++r) {
+        const int i = r * 64 + lane;
+        trw[i + i / RPL] = Cvt<R, T>::ld(base[i]) * (R)fp.gain;                     // coeff.py:268
+    }
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int r = 0; r < RPL; ++r) c[r] = trw[lane * (RPL + 1) + r];
+    line_filter_full<R, RPL>(c, fp, lane);
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int r = 0; r < RPL; ++r) trw[lane * (RPL + 1) + r] = c[r];
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int r = 0; r < RPL; ++r) {
+        const int i = r * 64 + lane;
+        base[i] = Cvt<R, T>::st(trw[i + i / RPL]);
+    }
+}
+
+// ===========================================================================
+// Kernel A', interleaved lines (inner > 1) of 64 * RPL points with a short leading initial sum:
+// a workgroup stages a tile of TL neighbouring lines in LDS (the global accesses run along the
+// lines' interleaving, TL * sizeof(T) contiguous bytes per point), every wave filters whole lines
+// in registers as kernel B' does, and the tile goes back: ONE read and ONE write of the data for
+// all poles, instead of a latency-bound thread per line making two passes per pole.
+// LDS: TL rows of 64 * (RPL + 1) + 1 floats (odd pitch: the transposing accesses hit all banks).
+// ===========================================================================
+template <typename T, typename R, int RPL, int TL>
+__global__ __launch_bounds__(1024) void prefilter_tile(FilterParams fp, T *data, int tiles_per_outer)
+{
+    static_assert(sizeof(R) == 4, "float math only");
+    extern __shared__ float tile[];
+    constexpr int n = 64 * RPL, ROW = 64 * (RPL + 1) + 1;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t a = blockIdx.x / tiles_per_outer;
+    const int64_t l0 = (int64_t)(blockIdx.x % tiles_per_outer) * TL;
+    T *base = data + a * n * fp.inner + l0;
+    const int nl = fp.inner - l0 < TL ? (int)(fp.inner - l0) : TL;          // lines of this tile
+    for (int idx = tid; idx < n * TL; idx += 1024) {
+        const int i = idx / TL, l = idx % TL;
+        if (l < nl) tile[l * ROW + i + i / RPL] = Cvt<R, T>::ld(base[(int64_t)i * fp.inner + l]) * (R)fp.gain;   // coeff.py:268
+    }
+    __syncthreads();
+    for (int l = wave; l < nl; l += 16) {
+        float *row = tile + l * ROW;
+        R c[RPL];
+#pragma unroll
+        for (int r = 0; r < RPL; ++r) c[r] = row[lane * (RPL + 1) + r];
+        line_filter_full<R, RPL>(c, fp, lane);
+#pragma unroll
+        for (int r = 0; r < RPL; ++r) row[lane * (RPL + 1) + r] = c[r];
+    }
+    __syncthreads();
+    for (int idx = tid; idx < n * TL; idx += 1024) {
+        const int i = idx / TL, l = idx % TL;
+        if (l < nl) base[(int64_t)i * fp.inner + l] = Cvt<R, T>::st(tile[l * ROW + i + i / RPL]);
+    }
+}
+
+template <typename T, typename R, int RPL, int TL>
+static int launch_tile(const FilterParams &fp, void *data, hipStream_t st)
+{
+    const size_t lds = sizeof(float) * (size_t)TL * (64 * (RPL + 1) + 1);
+    static bool done = false;
+    if (!done && lds > 64 * 1024) {
+        const hipError_t e = hipFuncSetAttribute((const void *)prefilter_tile<T, R, RPL, TL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+        done = true;
+    }
+    const int tiles = (int)((fp.inner + TL - 1) / TL);
+    hipLaunchKernelGGL((prefilter_tile<T, R, RPL, TL>), dim3((unsigned)(fp.outer * tiles)), dim3(1024), lds, st, fp, (T *)data, tiles);
+    const hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : (int)e;
 }
 
 // ===========================================================================
@@ -330,7 +506,7 @@ __global__ __launch_bounds__(256) void prefilter_serial(FilterParams fp, T *data
     for (int ip = 0; ip < fp.npoles; ++ip) {
         const double pole = fp.pole[ip];
         const R p = (R)pole;
-        InitW<R> iw; iw.make(fp.bound, pole, n);
+        InitW<R> iw; iw.load(fp.pre[ip], n);
         R sum = R(0);
         for (int64_t i = 0; i < n; ++i) if (iw.on(i)) sum += Cvt<R, T>::ld(base[i * st]) * iw.w(i);
         R prev = iw.scale * sum + iw.c0w * Cvt<R, T>::ld(base[0]);
@@ -338,12 +514,12 @@ __global__ __launch_bounds__(256) void prefilter_serial(FilterParams fp, T *data
         R last2 = prev;
         for (int64_t i = 1; i < n; ++i) { last2 = prev; prev = Cvt<R, T>::ld(base[i * st]) + p * prev; base[i * st] = Cvt<R, T>::st(prev); }
         R fin;
-        if (fp.bound == 0) fin = (p * last2 + prev) * (R)(pole / (pole * pole - 1.));
-        else if (fp.bound == 1) fin = prev * (R)(pole / (pole - 1.));
+        if (fp.bound == 0) fin = (p * last2 + prev) * (R)fp.pre[ip].fin_mul;
+        else if (fp.bound == 1) fin = prev * (R)fp.pre[ip].fin_mul;
         else {
             R dot = R(0), pw = iw.pf * iw.pf;
             for (int64_t i = 0; i < iw.m - 1; ++i) { dot += Cvt<R, T>::ld(base[i * st]) * pw; pw *= iw.pf; }
-            fin = (dot + p * prev) / (R)(pow(pole, (double)iw.m) - 1.);
+            fin = (dot + p * prev) * (R)fp.pre[ip].fin_mul;
         }
         base[(n - 1) * st] = Cvt<R, T>::st(fin);
         R next = fin;
@@ -361,6 +537,30 @@ template <typename T, typename R>
 static int launch_filter_t(const FilterParams &fp, void *data, hipStream_t st)
 {
     const int64_t lines = fp.outer * fp.inner;
+    bool lead = sizeof(R) == 4 && fp.bound != 2;          // short leading initial sum (InitW kinds 0 and 2)
+    for (int ip = 0; ip < fp.npoles; ++ip) lead = lead && (fp.pre[ip].kind == 0 || fp.pre[ip].kind == 2);
+    if constexpr (sizeof(R) == 4) {
+        if (fp.inner == 1 && lead && (fp.n == 64 * 4 || fp.n == 64 * 8 || fp.n == 64 * 16 || fp.n == 64 * 32)) {
+            const dim3 g((unsigned)((fp.outer + 3) / 4));
+            if (fp.n == 64 * 4) hipLaunchKernelGGL((prefilter_wave_full<T, R, 4>), g, dim3(256), 0, st, fp, (T *)data);
+            else if (fp.n == 64 * 8) hipLaunchKernelGGL((prefilter_wave_full<T, R, 8>), g, dim3(256), 0, st, fp, (T *)data);
+            else if (fp.n == 64 * 16) hipLaunchKernelGGL((prefilter_wave_full<T, R, 16>), g, dim3(256), 0, st, fp, (T *)data);
+            else hipLaunchKernelGGL((prefilter_wave_full<T, R, 32>), g, dim3(256), 0, st, fp, (T *)data);
+            const hipError_t e0 = hipGetLastError();
+            return e0 == hipSuccess ? 0 : (int)e0;
+        }
+    }
+    if constexpr (sizeof(R) == 4) {
+        // interleaved lines: LDS tiles of TL lines (one pass over the data for all poles)
+        if (fp.inner >= 16 && lead && fp.outer * ((fp.inner + 15) / 16) < 0x7fffffff) {
+            // (wide tiles: TL * sizeof(T) contiguous bytes per point matter more than a second resident
+            //  workgroup -- measured 0.35 vs 0.43 ms with half-size tiles at 32x3x1024^2 fp32)
+            if (fp.n == 64 * 4) return launch_tile<T, R, 4, 64>(fp, data, st);
+            if (fp.n == 64 * 8) return launch_tile<T, R, 8, 64>(fp, data, st);
+            if (fp.n == 64 * 16) return launch_tile<T, R, 16, 32>(fp, data, st);
+            if (fp.n == 64 * 32) return launch_tile<T, R, 32, 16>(fp, data, st);
+        }
+    }
     if (fp.inner == 1 && fp.n <= 64 * 32 && fp.n >= 2) {
         if (fp.n <= 64 * 2) launch_wave<T, R, 2>(fp, data, st);
         else if (fp.n <= 64 * 4) launch_wave<T, R, 4>(fp, data, st);
