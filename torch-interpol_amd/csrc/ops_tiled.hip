@@ -1851,7 +1851,7 @@ template <typename T, bool ISO> struct Tile3<T, 4, ISO> { using type = Cfg<T, 4,
 template <typename T, bool ISO> struct Tile3<T, 5, ISO> { using type = Cfg<T, 5, ISO, 3, 8, 8, 16, 1024, 32>; };
 template <typename T, bool ISO> struct Tile3<T, 6, ISO> { using type = Cfg<T, 6, ISO, 3, 8, 8, 8, 512, 32>; };
 template <typename T, bool ISO> struct Tile3<T, 7, ISO> { using type = Cfg<T, 7, ISO, 3, 8, 8, 8, 512, 32>; };
-template <typename T, int K, bool ISO> struct Tile2 { using type = Cfg<T, K, ISO, 2, 1, 16, 32, 512, 64>; };
+template <typename T, int K, bool ISO> struct Tile2 { using type = Cfg<T, K, ISO, 2, 1, 32, 32, 1024, 64>; };
 
 } // namespace tiled
 
