@@ -1738,6 +1738,22 @@ static int launch_gather_impl(const interpol_problem *p, const KParams &k, const
     using T = typename C::T;
     // pull with an even channel count: two channels per LDS slot (unless disabled for A/B tests)
     if (!GRAD && C::D == 3 && p->channels % 2 == 0 && !(k.dbg & 4)) return launch_pull2_impl<C>(p, k, vol, grid, val, st);
+    if (!GRAD && C::D == 3 && p->channels >= 3 && !(k.dbg & 4)) {
+        // odd channel count: the pair kernel on the first C - 1 channels, this kernel on the last one
+        KParams kp = k;
+        kp.C = (int)p->channels - 1;
+        const int rc = launch_pull2_impl<C>(p, kp, vol, grid, val, st);
+        if (rc != 1) return rc;
+        KParams k1 = k;
+        k1.C = 1;
+        const int attr1 = big_lds<C>(gather_tiled<C, GRAD>);
+        if (attr1) return attr1;
+        const TileCount<C> t1(p);
+        hipLaunchKernelGGL((gather_tiled<C, GRAD>), t1.grid((int)p->batch), dim3(C::NT), smem_bytes<C>(), st, k1,
+                           (const T *)vol + (p->channels - 1) * k.vol_sc, (const float *)grid, (T *)val + (p->channels - 1) * k.val_sc,
+                           t1.gx, t1.gy, t1.gz, t1.nty, t1.ntz, t1.ntiles(), (int)p->batch);
+        IP_CHECK_LAUNCH();
+    }
     const int attr = big_lds<C>(gather_tiled<C, GRAD>);
     if (attr) return attr;
     const TileCount<C> t(p);
