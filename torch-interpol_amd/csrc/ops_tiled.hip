@@ -1920,6 +1920,16 @@ static TiledPick tiled_pick(const interpol_problem *p, const KParams &k)
         case 6: return FN<IP_T2(6, true) __VA_ARGS__;                                    \
         default: return FN<IP_T2(7, true) __VA_ARGS__; }
 
+// Trilinear gathers stay on the generic kernel: 8 taps per sample do not pay for staging a tile.
+// Measured (2x2x160^3): smooth field 0.08 (generic) vs 0.14 ms (tiled), i.i.d. sigma = 2 noise 0.26 vs
+// 0.20 ms -- the generic kernel runs at the HBM roofline on the fields the operator is used with.
+static bool linear_only(const interpol_problem *p, const KParams &k)
+{
+    if (p->flags & INTERPOL_FLAG_FORCE_TILED) return false;
+    for (int d = 0; d < p->dim; ++d) if (k.order[d] > 1) return false;
+    return true;
+}
+
 #define IP_SYM2(a, b) a##b
 #define IP_SYM(a, b) IP_SYM2(a, b)
 
@@ -1933,12 +1943,14 @@ static TiledPick tiled_pick(const interpol_problem *p, const KParams &k)
 int IP_SYM(try_fast_pull_, IP_TSFX)(const interpol_problem *p, const KParams &k, const void *vol, const void *grid, void *val, hipStream_t st)
 {
     if (p->dim != 3 && !(p->flags & INTERPOL_FLAG_FORCE_TILED)) return 0;
+    if (linear_only(p, k)) return 0;
     IP_BY_ORDER(tiled::launch_gather, , false>(p, k, vol, grid, val, st))
 }
 
 int IP_SYM(try_fast_grad_, IP_TSFX)(const interpol_problem *p, const KParams &k, const void *vol, const void *grid, void *val, hipStream_t st)
 {
     if (p->dim != 3 && !(p->flags & INTERPOL_FLAG_FORCE_TILED)) return 0;
+    if (linear_only(p, k)) return 0;
     IP_BY_ORDER(tiled::launch_gather, , true>(p, k, vol, grid, val, st))
 }
 
