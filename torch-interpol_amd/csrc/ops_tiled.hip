@@ -3,7 +3,7 @@
 // math), per-dim spline orders 0..7, any boundary / extrapolation mode.
 //   pull, grad            (gather)
 //   push, count           (scatter)
-//   pull_backward         (fused: scatter of grad_out + gathered grid gradient)
+//   pull / push backward  (fused: scatter or gather of the incoming gradient + grid gradient)
 //
 // Why: the generic kernels move every tap through the vector memory path; with
 // an arbitrary deformation each lane of a wave touches its own cache line, and a
@@ -11,24 +11,28 @@
 // ~21 G atomics/s).  At BASELINE config 2 that is 12 ms pull / 400 ms push
 // (~1 % / 0.06 % of the HBM roofline).
 //
-// Here one workgroup owns a TILE of TX x TY x TZ sample points:
-//   1. a block-wide min/max of the first-tap indices gives the bounding box of
-//      all stencil supports, clamped to what fits in LDS;
-//   2. gather: the box is staged global -> LDS with the boundary condition
-//      ALREADY APPLIED (wrapped offset and sign per box row / column / slice from
-//      three small tables): the tap loop needs no index wrapping at all and
-//      reads LDS (ds_read_b32), separable FMA accumulation;
-//   3. scatter: contributions are accumulated in the LDS box as 64-bit FIXED
-//      POINT with ds_add_u64 (ds_add_f32 retires 0.33 lanes/clk/CU on gfx950,
-//      ds_add_u64 4.6 -- tools/microbench/lds_atomics.hip), in passes over slabs
-//      of box rows, then each touched slot is flushed with ONE coalesced global
-//      atomic instead of (K+1)^D scattered ones;
-//   4. samples whose support leaves the staged box (large local deformation) go
-//      to a per-tile list handled tap-parallel by whole waves (lane = tap);
-//      pathological tiles fall back to per-thread global gathers / atomics.
-// One channel is resident at a time.  Per-sample quantities (floor index,
-// fraction) are recomputed from the coordinate grid in every phase instead of
-// being held in registers (register budget of a 1024-thread block).
+// Here one (persistent) workgroup owns a TILE of TX x TY x TZ sample points at a time:
+//   1. Box::build: a block-wide min/max of the first-tap indices gives the bounding box of
+//      all stencil supports, clamped to what fits in LDS; boundary tables (wrapped offset and
+//      sign per box row / column / slice); classification of the samples;
+//   2. gather: the box is staged global -> LDS with the boundary condition ALREADY APPLIED:
+//      the tap loop needs no index wrapping at all and reads LDS, separable FMA accumulation.
+//      pull2_tiled keeps TWO channels per 8-byte slot (one ds_read2_b64 per two z-taps of both);
+//   3. scatter: contributions are accumulated in the LDS box in FIXED POINT (ds_add_f32 retires
+//      0.33 lanes/clk/CU on gfx950, ds_add_u32 5.7, ds_add_u64 4.6 -- tools/microbench/
+//      lds_atomics.hip): two channels packed in one ds_add_u64 when the sample density bounds
+//      the sums (scatter_pair), else 32-bit or 64-bit single-channel modes (scatter_channel);
+//      each touched slot is then flushed with ONE coalesced global atomic instead of (K+1)^D
+//      scattered ones;
+//   4. an 8-byte box does not fit LDS for rough deformations: two passes split by the PARITY of
+//      the box row x (every sample has taps in both passes, no lane idles); one pass when it fits;
+//   5. samples whose support leaves the staged box (large local deformation) go to a per-tile
+//      list handled tap-parallel by whole waves (lane = tap); tiles whose list overflows
+//      (expanding deformations) are processed the same way entirely.
+// Per-sample quantities (floor index, fraction) are recomputed from the coordinate grid in
+// every phase instead of being held in registers (register budget of a 1024-thread block: the
+// kernels sit at 128 VGPRs, and variants -- coordinate modes Cfg::GM, push with count -- are
+// compile-time copies for that reason).
 //
 // Numerical definition: reference interpol/nd.py:80-143 (pull), 146-213 (push),
 // 216-288 (grad), pushpull.py:237-258 (pull backward); iso1.py for all-linear;
