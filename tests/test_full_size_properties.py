@@ -1,0 +1,147 @@
+"""GPU property tests at BASELINE.json's FULL configuration sizes (the oracle cannot run there in
+seconds): size-independent properties of the operators -- adjointness, partition of unity, mass
+conservation, count == push(1), linearity, identity exactness, the interpolation property of the
+prefilter -- plus agreement of the tiled and generic kernels on one batch item.  Tolerances are
+stated per check; sums are accumulated in float64."""
+import pytest
+import torch
+
+import interpol
+from interpol import _hip
+from interpol.distributed import push_count_shared
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _dot(a, b):
+    return float((a.double() * b.double()).sum())
+
+
+def _rel(a, b):
+    return float((a.double() - b.double()).abs().max()) / max(float(b.double().abs().max()), 1e-30)
+
+
+def _cfg2(seed=1234):
+    g = torch.Generator(device=DEV).manual_seed(seed)
+    inp = torch.randn([4, 2, 256, 256, 256], generator=g, device=DEV)
+    grid = torch.randn([4, 256, 256, 256, 3], generator=g, device=DEV).mul_(2.0)
+    grid += interpol.identity_grid([256] * 3, device=DEV)
+    return inp, grid
+
+
+def test_cfg2_full_size_pull_push_properties():
+    """configs[1]: 4x2x256^3 fp32, cubic, dct2, i.i.d. sigma = 2 deformation."""
+    inp, grid = _cfg2()
+    kw = dict(interpolation=3, bound="dct2", extrapolate=True)
+    out = interpol.grid_pull(inp, grid, **kw)
+    assert out.shape == inp.shape and torch.isfinite(out).all()
+    # adjointness <pull x, y> = <x, push y>  (float32 kernels: 1e-5 of the Cauchy-Schwarz scale)
+    y = torch.randn_like(out)
+    psh = interpol.grid_push(y, grid, **kw)
+    lhs, rhs = _dot(out, y), _dot(inp, psh)
+    scale = (float(out.double().norm()) * float(y.double().norm()))
+    assert abs(lhs - rhs) <= 1e-5 * scale, (lhs, rhs, scale)
+    # partition of unity: a constant image is reproduced (dct2 has no sign flips), extrapolate=True
+    one = torch.ones_like(inp[:, :1])
+    assert float((interpol.grid_pull(one, grid, **kw) - 1).abs().max()) < 1e-5
+    # count == push(1), and the splatted mass is conserved: sum(count) = number of samples
+    cnt = interpol.grid_count(grid, **kw)
+    assert _rel(cnt, interpol.grid_push(one, grid, **kw)) < 2e-6
+    n = grid[..., 0].numel()
+    assert abs(float(cnt.double().sum()) - n) < 1e-6 * n
+    assert abs(float(psh.double().sum()) - float(y.double().sum())) < 1e-5 * float(y.double().abs().sum())
+    # linearity of pull
+    x2 = torch.randn_like(inp)
+    lin = interpol.grid_pull(2.5 * inp + x2, grid, **kw)
+    assert _rel(lin, 2.5 * out + interpol.grid_pull(x2, grid, **kw)) < 1e-5
+    # tiled and generic kernels agree (one batch item; the generic push takes ~0.1 s)
+    b, o = [3] * 3, [3] * 3
+    assert _rel(out[:1], _hip.gather("pull", inp[:1], grid[:1], b, o, 1, flags=_hip.FLAG_NO_FASTPATH)) < 5e-6
+    assert _rel(psh[:1], _hip.scatter("push", y[:1], grid[:1], None, b, o, 1, flags=_hip.FLAG_NO_FASTPATH)) < 5e-6
+
+
+def test_cfg2_full_size_identity_and_prefilter():
+    inp, _ = _cfg2(7)
+    inp = inp[:2]
+    ident = interpol.identity_grid([256] * 3, device=DEV)[None].expand(2, -1, -1, -1, -1).contiguous()
+    # trilinear sampling on the identity lattice is exact
+    assert torch.equal(interpol.grid_pull(inp, ident, interpolation=1, bound="dct2", extrapolate=True), inp)
+    # nearest: bit-exact copy
+    assert torch.equal(interpol.grid_pull(inp, ident, interpolation=0, bound="dct2", extrapolate=True), inp)
+    # cubic with prefilter interpolates: the samples come back (fp32 recursion: 2e-5)
+    back = interpol.grid_pull(inp, ident, interpolation=3, bound="dct2", extrapolate=True, prefilter=True)
+    assert _rel(back, inp) < 2e-5
+    # displacement form of the same call
+    zero = torch.zeros_like(ident)
+    assert torch.equal(interpol.grid_pull(inp, zero, interpolation=1, bound="dct2", extrapolate=True, displacement=True), inp)
+
+
+def test_cfg3_full_size_grad_and_backward():
+    """configs[2]: 8x1x192^3 fp32, order 5, dft: grid_grad + autograd backward of grid_pull."""
+    g = torch.Generator(device=DEV).manual_seed(3)
+    n = 192
+    inp = torch.randn([8, 1, n, n, n], generator=g, device=DEV)
+    grid = torch.randn([8, n, n, n, 3], generator=g, device=DEV).mul_(2.0) + interpol.identity_grid([n] * 3, device=DEV)
+    kw = dict(interpolation=5, bound="dft", extrapolate=True)
+    # the gradient of a constant image vanishes (derivative weights sum to zero)
+    gc = interpol.grid_grad(torch.full_like(inp, 3.0), grid, **kw)
+    assert float(gc.abs().max()) < 5e-5
+    # backward of pull w.r.t. the image is its adjoint; w.r.t. the grid it is sum_c gout * grid_grad
+    x = inp.clone().requires_grad_(True)
+    gr = grid.clone().requires_grad_(True)
+    out = interpol.grid_pull(x, gr, **kw)
+    gout = torch.randn_like(out)
+    out.backward(gout)
+    lhs, rhs = _dot(out.detach(), gout), _dot(inp, x.grad)
+    assert abs(lhs - rhs) <= 1e-5 * float(out.detach().double().norm()) * float(gout.double().norm())
+    gg = interpol.grid_grad(inp, grid, **kw)                                   # (B, C, *out, 3)
+    want = (gg * gout.unsqueeze(-1)).sum(1)
+    assert _rel(gr.grad, want) < 2e-5
+
+
+def test_cfg4_full_size_shared_target_mass():
+    """configs[3]: sources 1x128^3 -> shared 512^3, order 3, replicate (8 sources: one GPU's share)."""
+    g = torch.Generator(device=DEV).manual_seed(4)
+    nsrc, n, m = 8, 128, 512
+    x = torch.randn(nsrc, 1, n, n, n, generator=g, device=DEV)
+    grid = torch.randn([nsrc, n, n, n, 3], generator=g, device=DEV).mul_(2.0)
+    grid += interpol.identity_grid([n] * 3, device=DEV) * ((m - 1) / (n - 1))
+    push, count = push_count_shared(x, grid, [m] * 3, interpolation=3, bound="replicate", extrapolate=True, reduce="none")
+    assert push.shape == (1, m, m, m) and count.shape == (1, m, m, m)
+    # replicate folds the weights back into the lattice: every sample deposits exactly its value / 1
+    nsamp = nsrc * n ** 3
+    assert abs(float(count.double().sum()) - nsamp) < 1e-6 * nsamp
+    assert abs(float(push.double().sum()) - float(x.double().sum())) < 1e-5 * float(x.double().abs().sum())
+    assert float(count.min()) >= 0
+    # the same result from the scatter kernels on one source (the brick path is the default here)
+    ref = _hip.scatter("push", x[:1], grid[:1], [m] * 3, [1] * 3, [3] * 3, 1, with_count=True)
+    one_p, one_c = push_count_shared(x[:1], grid[:1], [m] * 3, interpolation=3, bound="replicate", extrapolate=True, reduce="none")
+    assert _rel(one_p[None], ref[:, :1]) < 5e-6 and _rel(one_c[None], ref[:, 1:]) < 5e-6
+
+
+def test_cfg5_full_size_2d_bf16():
+    """configs[4] (one GPU's share: 32 of 256 images): 2-D 32x3x1024^2 bf16, orders [2,3,5]->[2,3],
+    bounds [dct1,dst2,zero]->[dct1,dst2], fp32 grid, spline_coeff_nd prefilter."""
+    g = torch.Generator(device=DEV).manual_seed(5)
+    B, C, n = 32, 3, 1024
+    x = torch.randn(B, C, n, n, generator=g, device=DEV).to(torch.bfloat16)
+    grid = torch.randn([B, n, n, 2], generator=g, device=DEV).mul_(2.0) + interpol.identity_grid([n, n], device=DEV)
+    kw = dict(interpolation=[2, 3, 5], bound=["dct1", "dst2", "zero"], extrapolate=True)
+    out = interpol.grid_pull(x, grid, **kw)
+    assert out.dtype == torch.bfloat16 and out.shape == x.shape
+    # bf16 storage, fp32 math: the result is the fp32 result rounded to bf16
+    ref = interpol.grid_pull(x.float(), grid, **kw)
+    assert _rel(out.float(), ref) < 1e-2
+    # adjointness in fp32 on the same grid
+    y = torch.randn(B, C, n, n, generator=g, device=DEV)
+    lhs, rhs = _dot(ref, y), _dot(x.float(), interpol.grid_push(y, grid, **kw))
+    assert abs(lhs - rhs) <= 1e-5 * float(ref.double().norm()) * float(y.double().norm())
+    # prefilter + sampling on the identity lattice interpolates (dct1 / dct2 along the two dims)
+    xf = x.float()
+    coeff = interpol.spline_coeff_nd(xf, interpolation=[2, 3], bound=["dct1", "dct2"], dim=2)
+    ident = interpol.identity_grid([n, n], device=DEV)[None].expand(B, -1, -1, -1).contiguous()
+    back = interpol.grid_pull(coeff, ident, interpolation=[2, 3], bound=["dct1", "dct2"], extrapolate=True)
+    assert _rel(back, xf) < 2e-5
+    cb = interpol.spline_coeff_nd(x, interpolation=[2, 3], bound=["dct1", "dct2"], dim=2)
+    assert cb.dtype == torch.bfloat16 and _rel(cb.float(), coeff) < 2e-2
