@@ -446,7 +446,11 @@ int interpol_pull_backward(const interpol_problem *p, const void *grad_out, cons
     rc = 0;
     if (!(p->flags & INTERPOL_FLAG_NO_FASTPATH)) {
         bool vol_done = false;
-        if (grad_vol && (!grad_grid || p->channels >= 2)) {   // (one channel + grid gradient: the fused kernel is faster)
+        // (one channel + grid gradient at orders <= 3: the fused kernel is faster; at orders >= 4 the
+        //  grid part has its own shifted-pair kernel and the split wins again: config 3 10.9 -> 8.x ms)
+        bool high = p->dim == 3 && p->order[0] >= 4;
+        for (int d = 1; d < p->dim; ++d) high = high && p->order[d] == p->order[0];
+        if (grad_vol && (!grad_grid || p->channels >= 2 || high)) {
             // gradient w.r.t. the image = push of grad_out (pushpull.py:252-253): the push kernels
             // (channel pairs per LDS atomic) beat the scatter half of the fused backward kernel
             // (4x2x256^3 cubic: 3.5 vs 5.3 ms; with the grid gradient 3.5 + 4.5 vs 8.6 ms fused)

@@ -1291,6 +1291,194 @@ __global__ __launch_bounds__(C::NT) void grad1s_tiled(KParams p, const typename 
     }
 }
 
+// ---------------------------------------------------------------------------
+// Grid gradient of pull (pushpull.py:256-257) with shifted pairs: grad1s_tiled with the
+// contraction  ggrid[b,o,d] = mask * sum_c gout[b,c,o] * d/dx_d pull(vol)[b,c,o]  folded in.
+// ---------------------------------------------------------------------------
+template <typename C>
+__global__ __launch_bounds__(C::NT) void gradc1s_tiled(KParams p, const typename C::T *__restrict__ gout, const typename C::T *__restrict__ vol,
+                                                       const float *__restrict__ grid, float *__restrict__ ggrid,
+                                                       int gx, int gy, int gz, int nty, int ntz, int ntiles, int nbatch)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    Smem &sm = *reinterpret_cast<Smem *>(smem_raw);
+    static_assert(C::D == 3 && C::ISO, "shifted-pair mode: 3-D, one compile-time order");
+    constexpr int K = C::K;
+    constexpr int BOX64 = C::BOXF / 2;
+    using T = typename C::T;
+    float2 *box2 = reinterpret_cast<float2 *>(sm.box);
+    const int tid = threadIdx.x;
+    const Lattice L = make_lattice<C>(p, (int)sizeof(T));
+    const WorkRange wr(ntiles * nbatch);
+    for (int work = wr.first; work < wr.end; work += wr.step) {
+    const int64_t b = work / ntiles;
+    const TileGeom g = tile_geom<C>(work % ntiles, gx, gy, gz, nty, ntz);
+    Box<C> box;
+    prof_mark(-1);
+    const unsigned fastmask = box.build(p, L, grid, b, g, sm);
+    const int nslow = sm.nslow;
+    prof_mark(0);
+    // Two passes per channel pair, split by the PARITY of the box row x (see scatter_pair):
+    // LDS row r = xh * S_y + y of pass ps holds box row x = 2 xh + ps.  Every sample reads taps
+    // in both passes (i = par, par + 2, ... with par = (x0 ^ ps) & 1): no lane idles.
+    // A box small enough for one pass (smooth deformations: S ~ tile + K) is staged whole.
+    static_assert(((C::CAPX + 1) / 2) * C::CAPY * C::PS <= BOX64, "half box must fit the 8-byte slots");
+    const int xmul = box.S[0] * box.S[1] * C::PS <= BOX64 ? 1 : 2;
+
+    float gg[C::VPT][3];
+#pragma unroll
+    for (int v = 0; v < C::VPT; ++v) { gg[v][0] = 0.f; gg[v][1] = 0.f; gg[v][2] = 0.f; }
+    for (int c = 0; c < p.C; ++c) {
+        const T *vc0 = vol + b * p.vol_sb + c * p.vol_sc;
+        const T *gc = gout + b * p.val_sb + c * p.val_sc;
+        float acc[C::VPT][3];
+#pragma unroll
+        for (int v = 0; v < C::VPT; ++v) { acc[v][0] = 0.f; acc[v][1] = 0.f; acc[v][2] = 0.f; }
+        for (int ps = 0; ps < xmul; ++ps) {
+            const int nxh = xmul == 1 ? box.S[0] : (box.S[0] - ps + 1) >> 1;
+            const int r_n = nxh * box.S[1];
+            __syncthreads();                           // previous pass's readers are done
+            for (int r = tid; r < r_n; r += C::NT) {
+                const int xh = r / box.S[1], y = r - xh * box.S[1];
+                const int x = xmul * xh + ps;
+                sm.rowtab[r] = make_int2(sm.taboff[0][x] + sm.taboff[1][y], __float_as_int(sm.tabsgn[0][x] * sm.tabsgn[1][y]));
+            }
+            __syncthreads();
+            {   // stage the rows of this parity: slot z = (v[z], v[z+1]), the neighbour from lane + 1
+                constexpr int U = 4, RSTEP = C::NT / C::PZ;
+                const int z = tid % C::PZ;
+                const bool zin = z < box.S[2];
+                const int oz = zin ? sm.taboff[2][z] : 0;
+                const float sz = zin ? sm.tabsgn[2][z] : 0.f;
+                for (int r0 = tid / C::PZ; r0 < r_n; r0 += RSTEP * U) {
+                    float v0[U], sg[U];
+#pragma unroll
+                    for (int u = 0; u < U; ++u) {
+                        const int r = r0 + u * RSTEP;
+                        const bool on = zin && r < r_n;
+                        const int2 rt = sm.rowtab[r < r_n ? r : 0];
+                        const int off = on ? rt.x + oz : 0;
+                        sg[u] = on ? __int_as_float(rt.y) * sz : 0.f;
+                        v0[u] = on ? Cvt<float, T>::ld(vc0[off]) : 0.f;
+                    }
+#pragma unroll
+                    for (int u = 0; u < U; ++u) {
+                        const int r = r0 + u * RSTEP;
+                        const float sv = v0[u] * sg[u];
+                        const float nb = __shfl_down(sv, 1);           // z + 1 (same row: PZ divides 64); unused for the last z
+                        if (zin && r < r_n) box2[r * C::PS + z] = make_float2(sv, nb);
+                    }
+                }
+            }
+            __syncthreads();
+            prof_mark(5);
+#pragma unroll
+            for (int v = 0; v < C::VPT; ++v) {
+                if (!((fastmask >> v) & 1)) continue;
+                const Sample<C> s = load_sample<C>(p, grid, b, g, tid, v);
+                const int x0 = s.i0[0] - box.lo[0];
+                const int par = xmul == 1 ? 0 : (x0 ^ ps) & 1;
+                float wx[K + 2], wy[K + 1], wz[K + 1], gx_[K + 2], gy_[K + 1], gz_[K + 1];
+                weights<K>(L.lin, L.k[0], s.t[0], wx); weights<K>(L.lin, L.k[1], s.t[1], wy); weights<K>(L.lin, L.k[2], s.t[2], wz);
+                wgrads<K>(L.lin, L.k[0], s.t[0], gx_); wgrads<K>(L.lin, L.k[1], s.t[1], gy_); wgrads<K>(L.lin, L.k[2], s.t[2], gz_);
+                wx[K + 1] = 0.f; gx_[K + 1] = 0.f;
+                const int r0 = (xmul == 1 ? x0 : (x0 + par) >> 1) * box.S[1] + (s.i0[1] - box.lo[1]);
+                const float2 *bp = box2 + r0 * C::PS + (s.i0[2] - box.lo[2]);
+#pragma unroll
+                for (int ii = 0; ii <= K; ++ii) {
+                    // tap i = par + xmul * ii of this sample lives in LDS row r0 + ii * S_y
+                    if (par + xmul * ii > (C::ISO ? K : L.k[0])) continue;     // uniform but for the last i of even tap counts
+                    const float w2 = par ? wx[2 * ii + 1 <= K ? 2 * ii + 1 : K + 1] : wx[2 * ii <= K ? 2 * ii : K + 1];
+                    const float wxi = xmul == 1 ? wx[ii] : w2;
+                    const float g2 = par ? gx_[2 * ii + 1 <= K ? 2 * ii + 1 : K + 1] : gx_[2 * ii <= K ? 2 * ii : K + 1];
+                    const float gxi = xmul == 1 ? gx_[ii] : g2;
+                    float pW = 0.f, pGy = 0.f, pGz = 0.f;
+#pragma unroll
+                    for (int j = 0; j <= K; ++j) {
+                        const float2 *rp = bp + (ii * box.S[1] + j) * C::PS;
+                        float rW = 0.f, rG = 0.f;
+#pragma unroll
+                        for (int k = 0; k <= K; k += 2) {
+                            const float2 t2 = rp[k];                       // ds_read_b64: taps k and k + 1
+                            rW = __builtin_fmaf(wz[k], t2.x, rW);
+                            rG = __builtin_fmaf(gz_[k], t2.x, rG);
+                            if (k + 1 <= K) {
+                                rW = __builtin_fmaf(wz[k + 1 <= K ? k + 1 : K], t2.y, rW);
+                                rG = __builtin_fmaf(gz_[k + 1 <= K ? k + 1 : K], t2.y, rG);
+                            }
+                        }
+                        pW = __builtin_fmaf(wy[j], rW, pW);
+                        pGy = __builtin_fmaf(gy_[j], rW, pGy);
+                        pGz = __builtin_fmaf(wy[j], rG, pGz);
+                    }
+                    acc[v][0] = __builtin_fmaf(gxi, pW, acc[v][0]);
+                    acc[v][1] = __builtin_fmaf(wxi, pGy, acc[v][1]);
+                    acc[v][2] = __builtin_fmaf(wxi, pGz, acc[v][2]);
+                }
+            }
+            prof_mark(6);
+        }
+        // outputs of the fast samples
+#pragma unroll
+        for (int v = 0; v < C::VPT; ++v) {
+            const bool fast = (fastmask >> v) & 1;
+            if (!fast && nslow <= SLOWCAP) continue;
+            const Sample<C> s = load_sample<C>(p, grid, b, g, tid, v);
+            if (!s.valid) continue;
+            float r[3] = { acc[v][0], acc[v][1], acc[v][2] };
+            if (!fast) {   // slow list overflowed: per-thread global gather
+#pragma unroll
+                for (int d = 0; d < 3; ++d) r[d] = gather_one_thread<T>(L, vc0, s.i0[0], s.i0[1], s.i0[2], s.t[0], s.t[1], s.t[2], d);
+            }
+            const float gv = Cvt<float, T>::ld(gc[s.o]);
+            const float go = (p.extrapolate != 1 && !s.inb) ? 0.f * gv : gv;
+#pragma unroll
+            for (int d = 0; d < 3; ++d) gg[v][d] = __builtin_fmaf(r[d], go, gg[v][d]);
+        }
+        // slow list: one wave per sample, lanes = taps
+        if (nslow > 0 && nslow <= SLOWCAP) {
+            const int wave = tid >> 6, lane = tid & 63;
+            const int NTAP = (L.k[0] + 1) * (L.k[1] + 1) * (L.k[2] + 1);
+            for (int sidx = wave; sidx < nslow; sidx += C::NT / 64) {
+                float x[3];
+                const int64_t o = slow_sample<C>(g, sm.slow[sidx], p, grid, b, x);
+                float a3[3] = { 0.f, 0.f, 0.f };
+                for (int t0 = 0; t0 < NTAP; t0 += 64) {
+                    int off; float gr[3];
+                    tap_weight<C>(L, x[0], x[1], x[2], t0 + lane, &off, gr);
+                    const float vv = (t0 + lane < NTAP) ? Cvt<float, T>::ld(vc0[off]) : 0.f;
+                    a3[0] += gr[0] * vv; a3[1] += gr[1] * vv; a3[2] += gr[2] * vv;
+                }
+                const float go = (p.extrapolate != 1 && !coords_inb<C>(p, x)) ? 0.f : Cvt<float, T>::ld(gc[o]);
+#pragma unroll
+                for (int d = 0; d < 3; ++d) {
+                    const float rr = wave_sum(a3[d]);
+                    if (lane == 0) {            // the same lane of the same wave owns a slow sample for every channel
+                        float *q = ggrid + (b * p.N + o) * 3 + d;
+                        *q = (c == 0 ? 0.f : *q) + rr * go;
+                    }
+                }
+            }
+        }
+        prof_mark(7);
+    }
+    // sum over the channels of grad_out * d pull / d grid (pushpull.py:256-257), fast samples
+#pragma unroll
+    for (int v = 0; v < C::VPT; ++v) {
+        const bool fast = (fastmask >> v) & 1;
+        if (!fast && nslow <= SLOWCAP) continue;       // slow-list samples were written above
+        int ox, oy, oz;
+        sample_pos<C>(g, tid, v, ox, oy, oz);
+        if (!(ox < gx && oy < gy && oz < gz)) continue;
+        const int64_t o = ((int64_t)ox * gy + oy) * gz + oz;
+        float *q = ggrid + (b * p.N + o) * 3;
+#pragma unroll
+        for (int d = 0; d < 3; ++d) q[d] = gg[v][d];
+    }
+    __syncthreads();                                   // the next tile reuses the LDS tables / lists
+    }
+}
+
 // floor(x + 0.5) in one instruction (v_cvt_i32_f32 truncates; rndne + cvt would be two)
 __device__ __forceinline__ int cvt_rpi(float x)
 {
@@ -2197,6 +2385,18 @@ static int launch_pullbwd(const interpol_problem *p, const KParams &k, const voi
 {
     using T = typename C::T;
     if (k.sep) return 0;                                   // declined: generic kernels
+    if constexpr (C::D == 3 && C::ISO && C::VPT == 1) {
+        if (!gvol && ggrid && !(k.dbg & 16)) {
+            // grid gradient alone, high orders: the shifted-pair gather
+            const int attr1 = big_lds<C>(gradc1s_tiled<C>);
+            if (attr1) return attr1;
+            const TileCount<C> t1(p);
+            hipLaunchKernelGGL((gradc1s_tiled<C>), t1.grid((int)p->batch), dim3(C::NT), smem_bytes<C>(), st,
+                               k, (const T *)gout, (const T *)vol, (const float *)grid, (float *)ggrid,
+                               t1.gx, t1.gy, t1.gz, t1.nty, t1.ntz, t1.ntiles(), (int)p->batch);
+            IP_CHECK_LAUNCH();
+        }
+    }
     const int attr = big_lds<C>(pullbwd_tiled<C>);
     if (attr) return attr;
     const TileCount<C> t(p);
