@@ -1,0 +1,32 @@
+#!/usr/bin/env python
+"""Per-phase cycle shares of the class-sorted tile kernels.  Needs a library whose ops_sorted
+objects were built with -DIP_PROF (INTERPOL_HIP_LIB=.../libinterpol_hip_prof.so)."""
+import os, sys, json, ctypes
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "torch-interpol_amd")); sys.path.insert(0, ROOT)
+import torch, interpol
+from interpol import _hip
+import bench
+
+NAMES = {"pull": ["build:read sorted", "stage", "taps", "unsort+store+slow", "build:coords", "build:split+minmax", "build:tables+classify", "build:scan+holes", "build:records"],
+         "push": ["build+sort", "taps", "flush", "slow"]}
+dev = torch.device("cuda", 0)
+sigma = float(sys.argv[1]) if len(sys.argv) > 1 else 2.0
+inp, grid = bench.make_inputs(4, 2, 256, sigma, dev, 1234)
+L = _hip.lib()
+fn = L.interpol_debug_prof_sorted_f32
+fn.argtypes = [ctypes.c_void_p, ctypes.c_int]
+buf = (ctypes.c_ulonglong * 16)()
+def run(op):
+    if op == "push":
+        _hip.scatter("push", inp, grid, None, [3] * 3, [3] * 3, 1)
+    else:
+        _hip.gather("pull", inp, grid, [3] * 3, [3] * 3, 1, flags=int(sys.argv[3]) << 8 if len(sys.argv) > 3 else 0)
+    torch.cuda.synchronize()
+for op in sys.argv[2:] or ["pull"]:
+    flags = int(sys.argv[3]) << 8 if len(sys.argv) > 3 else 0
+    run(op); fn(None, 1); run(op); fn(buf, 1)
+    tot = sum(buf)
+    names = NAMES[op]
+    print(op, json.dumps({"sigma": sigma, "cycles_per_block_avg": tot / 512,
+          "share": {names[i] if i < len(names) else str(i): round(buf[i] / tot, 4) for i in range(16) if buf[i]}}))

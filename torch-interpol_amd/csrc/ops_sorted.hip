@@ -1,0 +1,813 @@
+// ===========================================================================
+// ops_sorted.hip -- LDS tiles with CLASS-SORTED lanes: 3-D, one spline order 2..3 for all
+// dims, f32 / bf16 / f16 storage (fp32 math), any boundary / extrapolation mode.
+//   pull  (gather)   : reference interpol/nd.py:80-143
+//   push, count      : reference interpol/nd.py:146-213, pushpull.py:106-142   (see push section)
+//
+// Why another tile family.  The tap loop of a tiled gather reads (K+1)^3 LDS slots per sample at
+// lane-uniform offsets from a per-lane base slot.  With an arbitrary deformation the bases of the
+// 64 lanes of a wave are unrelated and the reads collide on the LDS banks: measured on gfx950
+// (tools/microbench/lds_gather.hip) 7.6 clk per ds_read_b64 wave instruction with random bases,
+// 25 clk per ds_read2_b64 -- against 2.7 clk when, inside each 32-lane bank group of the
+// instruction, the lanes hold 32 DISTINCT values of (base slot mod 32).  All taps of a sample add
+// the same offset in every lane, so a lane assignment that is conflict-free for the base is
+// conflict-free for the whole stencil.  Hence:
+//
+//   1. a 512-thread workgroup owns a tile of 16^3 samples (8 per thread), two workgroups per CU
+//      (75 KiB of LDS each): while one stages or sorts, the other runs its tap loop;
+//   2. the samples of the tile are COUNTING-SORTED by class q = (base slot) mod 32 and dealt to
+//      the lanes so that lane l of every half wave holds class l: rank r of class q goes to half-
+//      wave slot r, lane q.  Classes hold 128 samples on average; the surplus of an over-full
+//      class fills the holes left by the under-full ones (those half-wave slots pay a two-way
+//      conflict), so every thread still processes 8 samples;
+//   3. the box of lattice points the tile's stencils touch (<= 32 x 32 x 34, tile + K + halo) is
+//      staged through LDS in FOUR PASSES over the residues of the box plane x mod 4: a cubic
+//      stencil has exactly one x-tap in every pass, the partial sums stay in registers.  A pass
+//      holds 8 planes of 32 rows of 34 slots of 8 bytes (two channels per slot, one ds_read_b64
+//      feeds both): 69 632 B.  The plane pitch (32 * 34 slots) is a multiple of 32 slots, so the
+//      class of a sample, (2 y0 + z0) mod 32, is the same in every pass; the row pitch 34 makes y0
+//      count, which keeps the classes evenly filled for smooth deformations (where z0 alone takes
+//      16 values) as well as for rough ones;
+//   4. the boundary condition is applied while staging (wrapped offset and sign per box row /
+//      column / slice, bounds.py:30-89): the tap loop is 16 ds_read_b64 at immediate offsets + 21
+//      packed FMAs per sample and pass;
+//   5. results return to the natural order through LDS and are stored coalesced;
+//   6. samples whose support leaves the (clamped) box are handled tap-parallel by whole waves from
+//      global memory (tile_common.hpp), pathological tiles per thread -- always correct.
+// ===========================================================================
+#include "../../include/interpol_hip.h"
+#include "stencil.hpp"
+#include "tile_common.hpp"
+#include <type_traits>
+#include <stdlib.h>
+
+#ifndef IP_PREFETCH
+#define IP_PREFETCH 0
+#endif
+
+namespace ip {
+namespace sorted {
+
+using tiled::Lattice;
+using tiled::split;
+using tiled::wave_max;
+using tiled::wave_min;
+using tiled::wave_sum;
+using tiled::WorkRange;
+
+constexpr int NT = 512;                         // threads per workgroup
+constexpr int TS = 16;                          // tile edge (samples)
+constexpr int NS = TS * TS * TS;                // samples per tile
+constexpr int VPT = NS / NT;                    // samples per thread
+constexpr int CAPX = 32, CAPY = 32, CAPZ = 36;  // box capacity (lattice points)
+constexpr int PZ = 36;                          // row pitch (8-byte slots)
+constexpr int PLANE = CAPY * PZ;                // plane pitch: 1152 = 36 * 32 slots
+constexpr int NPL = CAPX / 4;                   // planes resident per pass
+constexpr int BOXSLOTS = NPL * PLANE;           // 9216 slots = 73728 B
+constexpr int NCLS = 32;                        // classes = 8-byte bank pairs
+constexpr int NSLOT = NS / NCLS;                // half-wave slots per class
+constexpr int SLOWCAP = 512;
+constexpr int TABCAP = (BOXSLOTS * 8 - NS * 16) / 2;   // surplus samples the hole table can place (2048)
+static_assert(PLANE % NCLS == 0, "the plane pitch must keep the class pass-independent");
+static_assert(NS * 16 <= BOXSLOTS * 8, "sample records alias the box");
+
+struct Smem {
+    int   taboff[3][40];       // wrapped lattice offset (elements) of box plane / row / slice
+    float tabsgn[3][40];       // boundary sign of the same
+    int   lo[3], hi[3];        // block reductions of the first-tap indices
+    int   nslow, pad[1];
+    int   cnt[NCLS + 4];       // samples per class; [NCLS] collects the samples outside the box
+    int   ooff[NCLS];          // surplus samples of the classes before this one
+    unsigned short slow[SLOWCAP];
+    float2 box[BOXSLOTS];      // aliased: float4 rec[NS] + unsigned short holes[TABCAP]; float2 out[NS]
+};
+
+#ifdef IP_PROF
+__device__ unsigned long long g_prof[16];
+#endif
+__device__ __forceinline__ void prof_mark(int i)
+{
+#ifdef IP_PROF
+    __shared__ unsigned long long t0;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned long long n = clock64();
+        if (i >= 0) atomicAdd(&g_prof[i], n - t0);
+        t0 = n;
+    }
+#endif
+}
+
+// A value the optimiser cannot see through.  The kernels are persistent loops (tiles > channel
+// pairs > passes) whose phases all derive addresses from the thread index: left alone, LICM hoists
+// every such value to the outermost level and the register allocator spills them by the hundred.
+// Re-deriving them from an opaque copy at the top of a phase costs a few VALU operations.
+__device__ __forceinline__ int opaque(int v) { asm volatile("" : "+v"(v)); return v; }
+
+typedef float f2 __attribute__((ext_vector_type(2)));
+
+// The 16 LDS reads of one x-plane of a stencil (4 rows of 4 slots, row pitch PZ), both channels per
+// read, as ONE block of ds_read_b64 at immediate offsets.  Written in assembly because the compiler
+// (a) merges neighbouring reads into ds_read2_b64, which costs 3x more per byte on gfx950, and
+// (b) interleaves the unrolled samples until their read results spill.  The block waits for its own
+// reads (results handed to the compiler must be complete: it may move or spill them); the latency is
+// covered by the other waves of the SIMD.
+static_assert(PZ == 36, "the immediate offsets below are (row * PZ + k) * 8");
+#define IP_RD(o, off) "ds_read_b64 %" #o ", %16 offset:" #off "\n\t"
+__device__ __forceinline__ void stencil_reads(unsigned addr, f2 (&v)[16])
+{
+    asm volatile(IP_RD(0, 0) IP_RD(1, 8) IP_RD(2, 16) IP_RD(3, 24)
+                 IP_RD(4, 288) IP_RD(5, 296) IP_RD(6, 304) IP_RD(7, 312)
+                 IP_RD(8, 576) IP_RD(9, 584) IP_RD(10, 592) IP_RD(11, 600)
+                 IP_RD(12, 864) IP_RD(13, 872) IP_RD(14, 880) IP_RD(15, 888)
+                 "s_waitcnt lgkmcnt(0)"
+                 : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]), "=&v"(v[4]), "=&v"(v[5]), "=&v"(v[6]), "=&v"(v[7]),
+                   "=&v"(v[8]), "=&v"(v[9]), "=&v"(v[10]), "=&v"(v[11]), "=&v"(v[12]), "=&v"(v[13]), "=&v"(v[14]), "=&v"(v[15])
+                 : "v"(addr) : "memory");
+}
+#undef IP_RD
+
+// exclusive prefix sum over the 32 lanes of each half wave (both halves hold the same data)
+__device__ __forceinline__ int half_excl_scan(int v, int &total)
+{
+    const int lane = __lane_id() & 31;
+    int s = v;
+#pragma unroll
+    for (int o = 1; o < 32; o <<= 1) {
+        const int t = __shfl_up(s, o, 32);
+        if (lane >= o) s += t;
+    }
+    total = __shfl(s, 31, 32);
+    return s - v;
+}
+
+struct TileGeom { int gx, gy, gz, ox0, oy0, oz0; };
+__device__ __forceinline__ TileGeom tile_geom(int tile, int gx, int gy, int gz, int nty, int ntz)
+{
+    const int tzi = tile % ntz; tile /= ntz;
+    return TileGeom{ gx, gy, gz, (tile / nty) * TS, (tile % nty) * TS, tzi * TS };
+}
+
+// natural order: sample `id` of the tile -> position in the sample grid
+__device__ __forceinline__ void sample_pos(const TileGeom &g, int id, int &ox, int &oy, int &oz)
+{
+    ox = g.ox0 + (id >> 8); oy = g.oy0 + ((id >> 4) & 15); oz = g.oz0 + (id & 15);
+}
+
+// GM: 0 dense (B,*out,3) grid, 1 separable lattice (three coordinate vectors back to back),
+// 2 displacement field (identity added in registers, api.py:490-513)
+template <int GM>
+__device__ __forceinline__ void load_xyz(const KParams &p, const float *__restrict__ grid, int64_t b, const TileGeom &g,
+                                         int ox, int oy, int oz, float *x)
+{
+    if (GM == 1) {
+        x[0] = grid[ox]; x[1] = grid[g.gx + oy]; x[2] = grid[g.gx + g.gy + oz];
+    } else {
+        const float *gp = grid + b * p.grid_sb + (((int64_t)ox * g.gy + oy) * g.gz + oz) * 3;
+        x[0] = gp[0]; x[1] = gp[1]; x[2] = gp[2];
+        if (GM == 2) { x[0] += (float)ox; x[1] += (float)oy; x[2] += (float)oz; }
+    }
+}
+
+// four consecutive elements as floats (one 16-byte load for fp32, 8 bytes for the 16-bit types;
+// 4-byte / 2-byte alignment is all that is asked for)
+template <typename T>
+__device__ __forceinline__ float4 ld4(const T *p)
+{
+    if constexpr (std::is_same<T, float>::value) {
+        typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
+        const f4u v = *reinterpret_cast<const f4u *>(p);
+        return make_float4(v.x, v.y, v.z, v.w);
+    } else {
+        typedef unsigned short h4u __attribute__((ext_vector_type(4), aligned(2)));
+        const h4u v = *reinterpret_cast<const h4u *>(p);
+        T e[4];
+        __builtin_memcpy(e, &v, 8);
+        return make_float4(Cvt<float, T>::ld(e[0]), Cvt<float, T>::ld(e[1]), Cvt<float, T>::ld(e[2]), Cvt<float, T>::ld(e[3]));
+    }
+}
+
+template <typename T>
+__device__ __forceinline__ void st4(T *p, float4 v)
+{
+    if constexpr (std::is_same<T, float>::value) {
+        typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
+        *reinterpret_cast<f4u *>(p) = f4u{ v.x, v.y, v.z, v.w };
+    } else {
+        typedef unsigned short h4u __attribute__((ext_vector_type(4), aligned(2)));
+        const T e[4] = { Cvt<float, T>::st(v.x), Cvt<float, T>::st(v.y), Cvt<float, T>::st(v.z), Cvt<float, T>::st(v.w) };
+        h4u w;
+        __builtin_memcpy(&w, e, 8);
+        *reinterpret_cast<h4u *>(p) = w;
+    }
+}
+
+// extrapolation mask of a sample (nd.py:10-27): 1 or 0
+__device__ __forceinline__ float inb_mask(const KParams &p, const float *x)
+{
+    if (p.extrapolate == 1) return 1.f;
+    const bool inb = x[0] > (float)p.mask_lo && x[0] < (float)p.mask_hi[0] && x[1] > (float)p.mask_lo
+                  && x[1] < (float)p.mask_hi[1] && x[2] > (float)p.mask_lo && x[2] < (float)p.mask_hi[2];
+    return inb ? 1.f : 0.f;
+}
+
+// The K + 1 weights of the y- and z-stencils of a sample at once (packed math: component x of
+// the vectors is y, component y is z), from the stencil coordinates t = x - i0 (nd.py:46,
+// splines.py:30-80).  With t in [(K-1)/2, (K+1)/2) every tap sits on a known polynomial piece, so
+// the |t - j| tests of the per-tap form fold away: 12 packed operations for both cubic stencils.
+template <int K>
+__device__ __forceinline__ void weights_yz(f2 t, f2 *w)
+{
+    if (K == 3) {
+        // t in [1, 2): u = t - 1 in [0, 1), v = 1 - u;  taps at distances 1 + u, u, v, 1 + v
+        const f2 u = t - 1.f, v = 2.f - t;
+        const f2 u2 = u * u, v2 = v * v;
+        w[0] = (v2 * v) * (1.f / 6.f);
+        w[3] = (u2 * u) * (1.f / 6.f);
+        w[1] = u2 * (u * 0.5f - 1.f) + 2.f / 3.f;
+        w[2] = v2 * (v * 0.5f - 1.f) + 2.f / 3.f;
+    } else {
+        // K == 2, t in [0.5, 1.5): taps at distances t, |t - 1|, 2 - t
+        const f2 a = 1.5f - t, c = t - 0.5f, m = t - 1.f;
+        w[0] = (a * a) * 0.5f;
+        w[1] = 0.75f - m * m;
+        w[2] = (c * c) * 0.5f;
+        w[3] = f2{ 0.f, 0.f };
+    }
+}
+// one weight, tap i (branch-free form of splines.py:30-44)
+template <int K>
+__device__ __forceinline__ float weight_x(float t, int i)
+{
+    const float d = __builtin_fabsf(t - (float)i);
+    if (K == 3) {
+        const float e = 2.f - d;
+        const float near = __builtin_fmaf(d * d, __builtin_fmaf(d, 0.5f, -1.f), 2.f / 3.f), far = (e * e * e) * (1.f / 6.f);
+        return d < 1.f ? near : far;
+    } else {
+        const float e = 1.5f - d;
+        const float near = 0.75f - d * d, far = 0.5f * (e * e);
+        return i > 2 ? 0.f : (d < 0.5f ? near : far);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Tile set-up shared by the gather and scatter kernels: coordinates (natural order), bounding
+// box, boundary tables, classification, counting sort.  Leaves in registers the thread's 8
+// SORTED samples (coordinates + natural id) and, for the natural order, which of the thread's
+// own samples are fast / must be handled by the thread itself.
+// ---------------------------------------------------------------------------
+template <int K, int GM>
+struct Tile {
+    int lo[3], S[3];
+    // sorted samples: stencil coordinates t = x - i0 per dim and the packed key
+    //   bits 0-4 x0 (first box plane), 5-15 y0 * PZ + z0 (slot inside a plane), 16-27 natural id,
+    //   28 extrapolation mask (nd.py:10-27), 29 slot holds a sample
+    float tx[VPT]; f2 tyz[VPT];
+    int   key[VPT];
+    unsigned fastmask, selfmask;       // natural order: sample v is in the sorted set / is left to this thread
+
+    // coordinates of the thread's 8 samples (natural order).  Issued one tile ahead by the kernels:
+    // the HBM round trip is covered by the previous tile's output phase.
+    __device__ __forceinline__ static void load(const KParams &p, const float *__restrict__ grid, int64_t b, const TileGeom &g,
+                                                const int tid, float (&c)[VPT][3])
+    {
+        const bool full = g.ox0 + TS <= g.gx && g.oy0 + TS <= g.gy && g.oz0 + TS <= g.gz;     // block-uniform
+        if (GM == 0 && full) {
+            // one address per thread; its samples lie two x-planes apart
+            const float *gp = grid + b * p.grid_sb + (((int64_t)(g.ox0 + (tid >> 8)) * g.gy + (g.oy0 + ((tid >> 4) & 15))) * g.gz + (g.oz0 + (tid & 15))) * 3;
+            const int64_t step = (int64_t)g.gy * g.gz * 6;
+#pragma unroll
+            for (int v = 0; v < VPT; ++v) { c[v][0] = gp[v * step]; c[v][1] = gp[v * step + 1]; c[v][2] = gp[v * step + 2]; }
+        } else {
+#pragma unroll
+            for (int v = 0; v < VPT; ++v) {
+                int ox, oy, oz;
+                sample_pos(g, tid + NT * v, ox, oy, oz);
+                // unconditional loads from a clamped position: the compiler batches them (one exposed round trip)
+                ox = ox < g.gx ? ox : g.gx - 1; oy = oy < g.gy ? oy : g.gy - 1; oz = oz < g.gz ? oz : g.gz - 1;
+                load_xyz<GM>(p, grid, b, g, ox, oy, oz, c[v]);
+            }
+        }
+    }
+
+    __device__ __forceinline__ void build(const KParams &p, const Lattice &L, const TileGeom &g, Smem &sm, const int tid, float (&c)[VPT][3])
+    {
+        if (tid < 3) { sm.lo[tid] = 0x7fffffff; sm.hi[tid] = -0x7fffffff; }
+        if (tid == 0) sm.nslow = 0;
+        if (tid <= NCLS) sm.cnt[tid] = 0;
+        // (Everything here runs once per sample and is counted in VALU instructions: the kernels are
+        // bound by their issue rate, 4 cycles per wave instruction.)
+        unsigned validmask = (1u << VPT) - 1u, inbmask = (1u << VPT) - 1u;
+        const bool full = g.ox0 + TS <= g.gx && g.oy0 + TS <= g.gy && g.oz0 + TS <= g.gz;     // block-uniform
+        if (!full) {
+            validmask = 0;
+#pragma unroll
+            for (int v = 0; v < VPT; ++v) {
+                int ox, oy, oz;
+                sample_pos(g, tid + NT * v, ox, oy, oz);
+                if (ox < g.gx && oy < g.gy && oz < g.gz) validmask |= 1u << v;
+            }
+        }
+        __syncthreads();
+        prof_mark(4);
+        if (p.extrapolate != 1) {                                    // nd.py:10-27
+            inbmask = 0;
+#pragma unroll
+            for (int v = 0; v < VPT; ++v)
+                if (c[v][0] > (float)p.mask_lo && c[v][0] < (float)p.mask_hi[0] && c[v][1] > (float)p.mask_lo && c[v][1] < (float)p.mask_hi[1]
+                    && c[v][2] > (float)p.mask_lo && c[v][2] < (float)p.mask_hi[2])
+                    inbmask |= 1u << v;
+        }
+        // ---- first-tap index (kept as a float: exact, and it saturates nowhere) and stencil coordinate
+        // i0 = floor(x - (K-1)/2), t = x - i0  (nd.py:45-46); block min / max of i0
+        float fl[VPT][3];
+        float fmn[3] = { 3e38f, 3e38f, 3e38f }, fmx[3] = { -3e38f, -3e38f, -3e38f };
+#pragma unroll
+        for (int v = 0; v < VPT; ++v) {
+#pragma unroll
+            for (int d = 0; d < 3; ++d) {
+                fl[v][d] = floorf(c[v][d] - 0.5f * (float)(K - 1));
+                c[v][d] -= fl[v][d];                                 // c becomes t
+                const float fv = ((validmask >> v) & 1) ? fl[v][d] : fmn[d];     // (folds away for full tiles)
+                fmn[d] = __builtin_fminf(fmn[d], fv);
+                fmx[d] = __builtin_fmaxf(fmx[d], ((validmask >> v) & 1) ? fl[v][d] : fmx[d]);
+            }
+        }
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            const float lim = 1073741824.f;
+            const int a = wave_min(__float2int_rz(__builtin_fmaxf(__builtin_fminf(fmn[d], lim), -lim)));
+            const int e = wave_max(__float2int_rz(__builtin_fmaxf(__builtin_fminf(fmx[d], lim), -lim)));
+            if ((tid & 63) == 0) { atomicMin(&sm.lo[d], a); atomicMax(&sm.hi[d], e); }
+        }
+        __syncthreads();
+        prof_mark(5);
+        const int cap[3] = { CAPX, CAPY, CAPZ };
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            int l = sm.lo[d], h = sm.hi[d] + K;           // supports span [l, h]
+            if (h < l) { l = 0; h = 0; }                   // tile without valid samples
+            int sz_ = h - l + 1;
+            if (sz_ > cap[d]) { l += (sz_ - cap[d]) / 2; sz_ = cap[d]; }   // keep the centre; the rest goes to the slow list
+            lo[d] = l; S[d] = sz_;
+        }
+        // boundary tables: box slot -> wrapped lattice offset and sign (bounds.py:30-89), one wave per dim
+        {
+            const int d = tid >> 6, slot = tid & 63;
+            const int Sd = d == 0 ? S[0] : d == 1 ? S[1] : S[2];
+            if (d < 3 && slot < Sd) {
+                const int bd = d == 0 ? L.bound[0] : d == 1 ? L.bound[1] : L.bound[2];
+                const int ld = d == 0 ? lo[0] : d == 1 ? lo[1] : lo[2];
+                const int nd = d == 0 ? L.n[0] : d == 1 ? L.n[1] : L.n[2];
+                const int sd = d == 0 ? L.ss[0] : d == 1 ? L.ss[1] : L.ss[2];
+                const long long pk = wrap_outofline(bd, ld + slot, nd);
+                sm.taboff[d][slot] = (int)(pk & 0xffffffffll) * sd;
+                sm.tabsgn[d][slot] = (float)(int)(pk >> 32);
+            }
+        }
+        // ---- classification + histogram.  In the box <=> lo <= i0 <= lo + S - K - 1 in every dim.  Every
+        // sample does ONE returning LDS add, unconditionally (the ranks of the 8 samples come back
+        // together): on its class counter, or on the spare counter cnt[NCLS] when it is not in the box.
+        const float flo[3] = { (float)lo[0], (float)lo[1], (float)lo[2] };
+        const float fhi[3] = { (float)(lo[0] + S[0] - K - 1), (float)(lo[1] + S[1] - K - 1), (float)(lo[2] + S[2] - K - 1) };
+        fastmask = 0; selfmask = 0;
+        int kq[VPT], rk[VPT];
+#pragma unroll
+        for (int v = 0; v < VPT; ++v) {
+            const bool in = (fl[v][0] >= flo[0]) & (fl[v][0] <= fhi[0]) & (fl[v][1] >= flo[1]) & (fl[v][1] <= fhi[1])
+                          & (fl[v][2] >= flo[2]) & (fl[v][2] <= fhi[2]) & (bool)((validmask >> v) & 1);
+            const int x0 = __float2int_rz(fl[v][0]) - lo[0], y0 = __float2int_rz(fl[v][1]) - lo[1], z0 = __float2int_rz(fl[v][2]) - lo[2];
+            const int yz = y0 * PZ + z0;                             // slot inside a plane; (y0 * PZ + z0) mod 32 = class
+            kq[v] = (x0 & 31) | ((yz & 2047) << 5) | ((tid + NT * v) << 16) | (int)(((inbmask >> v) & 1) << 28) | (1 << 29);
+            if (in) fastmask |= 1u << v;
+            rk[v] = atomicAdd(&sm.cnt[in ? (yz & (NCLS - 1)) : NCLS], 1);
+        }
+        if ((validmask & ~fastmask) != 0) {                          // (rare) out-of-box samples: slow list
+#pragma unroll
+            for (int v = 0; v < VPT; ++v) {
+                if (!(((validmask & ~fastmask) >> v) & 1)) continue;
+                const int slot = atomicAdd(&sm.nslow, 1);
+                if (slot < SLOWCAP) sm.slow[slot] = (unsigned short)(tid + NT * v);
+                else selfmask |= 1u << v;
+            }
+        }
+        __syncthreads();
+        prof_mark(6);
+        // holes and surplus: class q offers max(0, NSLOT - cnt) holes and has max(0, cnt - NSLOT) surplus samples
+        const int q_l = tid & 31;
+        const int cq = sm.cnt[q_l];
+        const int holes = cq < NSLOT ? NSLOT - cq : 0, surplus = cq > NSLOT ? cq - NSLOT : 0;
+        int nholes, nsurplus;
+        const int hoff = half_excl_scan(holes, nholes);
+        const int soff = half_excl_scan(surplus, nsurplus);
+        if (tid < NCLS) sm.ooff[tid] = soff;
+        unsigned short *holetab = reinterpret_cast<unsigned short *>(reinterpret_cast<unsigned char *>(sm.box) + NS * 16);
+        {
+            // hole m of class q_l: half-wave slot cq + m, lane q_l -- listed while surplus samples remain
+            const int lim = nsurplus < TABCAP ? nsurplus : TABCAP;
+            for (int m = tid >> 5; m < holes && hoff + m < lim; m += NT / 32)
+                holetab[hoff + m] = (unsigned short)((cq + m) * 32 + q_l);
+        }
+        const int placed = nsurplus < TABCAP ? nsurplus : TABCAP;
+        const int filled = placed - hoff < 0 ? 0 : (placed - hoff > holes ? holes : placed - hoff);
+        const int cnteff = (cq < NSLOT ? cq : NSLOT) + filled;       // occupied half-wave slots of lane q_l
+        __syncthreads();
+        prof_mark(7);
+        float4 *rec = reinterpret_cast<float4 *>(sm.box);
+#pragma unroll
+        for (int v = 0; v < VPT; ++v) {
+            if (!((fastmask >> v) & 1)) continue;
+            const int q = (kq[v] >> 5) & 31, r = rk[v];
+            int pos = r * 32 + q;
+            if (r >= NSLOT) {                                        // surplus sample: into a hole
+                const int o = sm.ooff[q] + r - NSLOT;
+                pos = o < TABCAP ? (int)holetab[o] : -1;
+                if (pos < 0) { fastmask &= ~(1u << v); selfmask |= 1u << v; continue; }   // pathological tile
+            }
+            rec[pos] = make_float4(c[v][0], c[v][1], c[v][2], __int_as_float(kq[v]));
+        }
+        __syncthreads();
+        prof_mark(8);
+#pragma unroll
+        for (int j = 0; j < VPT; ++j) {
+            const float4 r = rec[tid + NT * j];                      // half-wave slot (tid >> 5) + 16 j, lane tid & 31
+            const bool on = (tid >> 5) + (NT / 32) * j < cnteff;
+            // an empty slot reads the box corner (a harmless address) and is dropped at the end
+            tx[j] = on ? r.x : 0.5f * (float)(K - 1) + 0.25f;
+            tyz[j] = on ? f2{ r.y, r.z } : f2{ 0.5f * (float)(K - 1) + 0.25f, 0.5f * (float)(K - 1) + 0.25f };
+            key[j] = on ? __float_as_int(r.w) : 0;
+        }
+        __syncthreads();                                             // the records make way for the box
+    }
+};
+
+// One out-of-box sample gathered tap-parallel by a wave: lane = tap; returns this lane's products
+// for the two channels (to be summed over the wave) and the sample's extrapolation mask.
+template <typename T, int K, int GM>
+__device__ __forceinline__ void slow_taps(const KParams &p, const Lattice &L, const float *__restrict__ grid, int64_t b, const TileGeom &g,
+                                          int id, int lane, const T *__restrict__ vc0, const T *__restrict__ vc1, float &a0, float &a1, float &m)
+{
+    int ox, oy, oz; float x[3];
+    sample_pos(g, id, ox, oy, oz);
+    load_xyz<GM>(p, grid, b, g, ox, oy, oz, x);
+    int off;
+    const float w = tiled::tap_weight_t<K, K>(L, x[0], x[1], x[2], lane, &off, nullptr);
+    a0 = 0.f; a1 = 0.f;
+    if (lane < (K + 1) * (K + 1) * (K + 1)) { a0 = w * Cvt<float, T>::ld(vc0[off]); a1 = w * Cvt<float, T>::ld(vc1[off]); }
+    m = inb_mask(p, x);
+}
+
+// ---------------------------------------------------------------------------
+// pull: val[b,c,o] = mask * sum_taps w vol        (nd.py:80-143)
+// ---------------------------------------------------------------------------
+template <typename T, int K, int GM>
+__global__ __launch_bounds__(NT, 4) void pull_sorted(KParams p, const T *__restrict__ vol, const float *__restrict__ grid,
+                                                     T *__restrict__ val, int gx, int gy, int gz, int nty, int ntz, int ntiles, int nbatch, int desync)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    Smem &sm = *reinterpret_cast<Smem *>(smem_raw);
+    // Two workgroups share a CU and run the same phases at the same pace: left alone they stay in
+    // lockstep (both waiting for memory, then both computing).  The second half of the grid starts
+    // late by about half a tile, so that one computes while the other stages.
+    if ((blockIdx.x >> 3) >= (gridDim.x >> 4))
+        for (int i = 0; i < desync; ++i) __builtin_amdgcn_s_sleep(127);
+    Lattice L;
+#pragma unroll
+    for (int d = 0; d < 3; ++d) { L.bound[d] = p.bound[d]; L.n[d] = p.vol_n[d]; L.ss[d] = p.vol_ss[d] / (int)sizeof(T); L.k[d] = K; }
+    L.lin = 0;
+    const WorkRange wr(ntiles * nbatch);
+    float cnext[VPT][3];                                             // coordinates, loaded one tile ahead
+    for (int work = wr.first; work < wr.end; work += wr.step) {
+        // the thread index is made opaque per tile: everything derived from it would otherwise be
+        // hoisted out of the persistent loop and held (spilled) across all phases
+        const int tid = opaque((int)threadIdx.x);
+        const int64_t b = work / ntiles;
+        int tile = work % ntiles;
+        const TileGeom g = tile_geom(tile, gx, gy, gz, nty, ntz);
+        prof_mark(-1);
+        Tile<K, GM> tl;
+        if (!IP_PREFETCH || work == wr.first) Tile<K, GM>::load(p, grid, b, g, tid, cnext);
+        tl.build(p, L, g, sm, tid, cnext);
+        const int nslow = sm.nslow < SLOWCAP ? sm.nslow : SLOWCAP;
+        // rows of the box are contiguous runs of the lattice's unit-stride dim, sign +1 throughout
+        // (dst1 has sign 0 at index 0 -- quirk B-3 -- so its run must start at 1)
+        const bool zlin = L.ss[2] == 1 && tl.lo[2] >= (L.bound[2] == B_DST1 ? 1 : 0) && tl.lo[2] + tl.S[2] <= L.n[2];
+        prof_mark(0);
+
+        for (int c = 0; ; c += 2) {
+            const bool two = c + 1 < p.C;
+            const T *vc0 = vol + b * p.vol_sb + c * p.vol_sc;
+            const T *vc1 = two ? vc0 + p.vol_sc : vc0;
+            T *oc0 = val + b * p.val_sb + c * p.val_sc;
+            T *oc1 = oc0 + p.val_sc;
+            f2 acc[VPT];
+#pragma unroll
+            for (int j = 0; j < VPT; ++j) acc[j] = f2{ 0.f, 0.f };
+
+            for (int ps = 0; ps < 4; ++ps) {
+                const int tid = opaque((int)threadIdx.x);
+                const int npl = (tl.S[0] - ps + 3) >> 2;            // box planes x = ps, ps + 4, ...
+                // stage: slot (xq * 32 + y) * PZ + z = (sign * c0, sign * c1) of the wrapped lattice point
+                const int nrow = npl * CAPY;
+                const int omask = (p.dbg & 64) ? 0x3fff : -1;       // ablation: loads from a 64 KiB window
+                __syncthreads();                                     // the previous pass's readers are done
+                if (p.dbg & 1) {
+                } else if (zlin) {
+                    // the box's z-range lies inside the lattice and z is the unit-stride dim: rows are
+                    // contiguous runs.  A thread moves QUADS of 4 slots: two 16-byte loads (one per
+                    // channel), two 16-byte LDS stores.  (Narrow loads are what the vector L1 is slow at:
+                    // it looks up one tag per cycle whatever the width -- 4-byte loads of the row ends
+                    // alone cost as much as all the quads.)  ALL loads of the pass are issued before the
+                    // first store: one exposed round trip.
+                    const int nq = (tl.S[2] + 3) >> 2;               // quads per row; the last one is shifted to END at S_z
+                    constexpr int QPR = PZ / 4, NU = (NPL * CAPY * QPR + NT - 1) / NT;
+                    float4 a0[NU], a1[NU]; float sg[NU];
+#pragma unroll
+                    for (int u = 0; u < NU; ++u) {
+                        const int e = tid + NT * u, r = e / QPR, qd = e - r * QPR;
+                        const bool on = qd < nq && r < nrow && (r & 31) < tl.S[1];
+                        const int xr = on ? 4 * (r >> 5) + ps : 0, yr = on ? r & 31 : 0;
+                        const int zs = 4 * qd + 4 <= tl.S[2] ? 4 * qd : tl.S[2] - 4;
+                        const int off = (on ? sm.taboff[0][xr] + sm.taboff[1][yr] + tl.lo[2] + zs : 0) & omask;
+                        sg[u] = sm.tabsgn[0][xr] * sm.tabsgn[1][yr];
+                        a0[u] = ld4<T>(vc0 + off);
+                        a1[u] = ld4<T>(vc1 + off);
+                    }
+#pragma unroll
+                    for (int u = 0; u < NU; ++u) {
+                        const int e = tid + NT * u, r = e / QPR, qd = e - r * QPR;
+                        if (qd < nq && r < nrow && (r & 31) < tl.S[1]) {
+                            const int zs = 4 * qd + 4 <= tl.S[2] ? 4 * qd : tl.S[2] - 4;
+                            float2 *dst = sm.box + r * PZ + zs;
+                            if (!(zs & 1)) {
+                                reinterpret_cast<float4 *>(dst)[0] = make_float4(a0[u].x * sg[u], a1[u].x * sg[u], a0[u].y * sg[u], a1[u].y * sg[u]);
+                                reinterpret_cast<float4 *>(dst)[1] = make_float4(a0[u].z * sg[u], a1[u].z * sg[u], a0[u].w * sg[u], a1[u].w * sg[u]);
+                            } else {                                 // shifted last quad of an odd extent: 8-byte stores
+                                dst[0] = make_float2(a0[u].x * sg[u], a1[u].x * sg[u]); dst[1] = make_float2(a0[u].y * sg[u], a1[u].y * sg[u]);
+                                dst[2] = make_float2(a0[u].z * sg[u], a1[u].z * sg[u]); dst[3] = make_float2(a0[u].w * sg[u], a1[u].w * sg[u]);
+                            }
+                        }
+                    }
+                } else {
+                    // general case (the box wraps in z, or z is strided): slot by slot through the z table
+                    constexpr int U = 8;
+                    const int z = tid & 31;
+                    const bool zin = z < tl.S[2];
+                    const int oz = zin ? sm.taboff[2][z] : 0;
+                    const float sgz = zin ? sm.tabsgn[2][z] : 0.f;
+                    for (int r0 = tid >> 5; r0 < nrow; r0 += (NT / 32) * U) {
+                        float v0[U], v1[U], sg[U];
+#pragma unroll
+                        for (int u = 0; u < U; ++u) {
+                            const int r = r0 + u * (NT / 32);
+                            const bool on = zin && r < nrow && (r & 31) < tl.S[1];
+                            const int xr = on ? 4 * (r >> 5) + ps : 0, yr = on ? r & 31 : 0;
+                            const int off = on ? sm.taboff[0][xr] + sm.taboff[1][yr] + oz : 0;
+                            sg[u] = on ? sm.tabsgn[0][xr] * sm.tabsgn[1][yr] * sgz : 0.f;
+                            v0[u] = Cvt<float, T>::ld(vc0[off]);
+                            v1[u] = Cvt<float, T>::ld(vc1[off]);
+                        }
+#pragma unroll
+                        for (int u = 0; u < U; ++u) {
+                            const int r = r0 + u * (NT / 32);
+                            if (zin && r < nrow && (r & 31) < tl.S[1]) sm.box[r * PZ + z] = make_float2(v0[u] * sg[u], v1[u] * sg[u]);
+                        }
+                    }
+                    for (int e = tid; tl.S[2] > 32 && e < nrow * 4; e += NT) {      // slices 32 ... 35
+                        const int r = e >> 2, z2 = 32 + (e & 3);
+                        if ((r & 31) < tl.S[1] && z2 < tl.S[2]) {
+                            const int xr = 4 * (r >> 5) + ps, yr = r & 31;
+                            const int off = sm.taboff[0][xr] + sm.taboff[1][yr] + sm.taboff[2][z2];
+                            const float sgn = sm.tabsgn[0][xr] * sm.tabsgn[1][yr] * sm.tabsgn[2][z2];
+                            sm.box[r * PZ + z2] = make_float2(Cvt<float, T>::ld(vc0[off]) * sgn, Cvt<float, T>::ld(vc1[off]) * sgn);
+                        }
+                    }
+                }
+                __syncthreads();
+                prof_mark(1);
+                if (p.dbg & 2) continue;
+                const unsigned boxaddr = (unsigned)(size_t)(__attribute__((address_space(3))) void *)(sm.box);
+#pragma unroll
+                for (int j = 0; j < VPT; ++j) {
+                    // (opaque per pass: the weights are recomputed -- hoisted out of the pass loop they
+                    // would be 9 more live values per sample, i.e. spilled)
+                    float tx = tl.tx[j]; f2 tyz = tl.tyz[j];
+                    asm volatile("" : "+v"(tx), "+v"(tyz));
+                    const int key = tl.key[j];
+                    const int x0 = key & 31;
+                    const int i = (ps - x0) & 3;                     // the x-tap of this pass
+                    const int xq = (x0 + (K == 3 || i <= K ? i : 0)) >> 2;
+                    f2 t2[16];
+                    stencil_reads(boxaddr + 8u * (unsigned)(xq * PLANE + ((key >> 5) & 2047)), t2);
+                    const float wxi = weight_x<K>(tx, i);
+                    f2 w[4];
+                    weights_yz<K>(tyz, w);
+                    f2 pp = { 0.f, 0.f };
+#pragma unroll
+                    for (int jy = 0; jy <= K; ++jy) {
+                        f2 q = { 0.f, 0.f };
+#pragma unroll
+                        for (int k = 0; k <= K; ++k) q = f2{ w[k].y, w[k].y } * t2[4 * jy + k] + q;
+                        pp = f2{ w[jy].x, w[jy].x } * q + pp;
+                    }
+                    acc[j] = f2{ wxi, wxi } * pp + acc[j];
+                    // the sums are pinned here: otherwise the FMAs sink past the pass loop's back edge and
+                    // the read results of several samples stay live across the barriers (spilled)
+                    asm volatile("" : "+v"(acc[j]));
+                }
+                prof_mark(2);
+            }
+            // The output phase, as two copies: after the LAST channel pair the sorted records are dead,
+            // which frees the registers that hold the next tile's coordinates meanwhile.
+            auto emit = [&](auto last_tag) {
+            constexpr bool LAST = decltype(last_tag)::value;
+            // back to the natural order through LDS
+            __syncthreads();
+            const int tid = opaque((int)threadIdx.x);
+            if (IP_PREFETCH && LAST && work + wr.step < wr.end) {
+                // the next tile's coordinates: in flight during the output phase
+                const int nw = work + wr.step;
+                Tile<K, GM>::load(p, grid, nw / ntiles, tile_geom(nw % ntiles, gx, gy, gz, nty, ntz), tid, cnext);
+            }
+            float2 *outb = sm.box;
+#pragma unroll
+            for (int j = 0; j < VPT; ++j) {
+                if (!((tl.key[j] >> 29) & 1)) continue;
+                const float m = (float)((tl.key[j] >> 28) & 1);      // nd.py:139-140
+                outb[(tl.key[j] >> 16) & (NS - 1)] = make_float2(acc[j].x * m, acc[j].y * m);
+            }
+            // out-of-box samples: one wave per sample, lanes = taps, straight from global memory
+            if (nslow > 0) {
+                const int wave = tid >> 6, lane = tid & 63;
+                for (int sidx = wave; sidx < nslow; sidx += NT / 64) {
+                    float a0, a1, m;
+                    slow_taps<T, K, GM>(p, L, grid, b, g, sm.slow[sidx], lane, vc0, vc1, a0, a1, m);
+                    a0 = wave_sum(a0); a1 = wave_sum(a1);
+                    if (lane == 0) outb[sm.slow[sidx]] = make_float2(a0 * m, a1 * m);
+                }
+            }
+            // pathological tiles (slow list or hole table overflowed): the thread gathers its sample itself
+            if (tl.selfmask) {
+                for (int v = 0; v < VPT; ++v) {
+                    if (!((tl.selfmask >> v) & 1)) continue;
+                    int ox, oy, oz; float x[3];
+                    sample_pos(g, tid + NT * v, ox, oy, oz);
+                    load_xyz<GM>(p, grid, b, g, ox, oy, oz, x);
+                    int ii[3]; float tt[3];
+#pragma unroll
+                    for (int d = 0; d < 3; ++d) split(K, x[d], ii[d], tt[d]);
+                    const float m = inb_mask(p, x);
+                    outb[tid + NT * v] = make_float2(m * tiled::gather_one_thread<T>(L, vc0, ii[0], ii[1], ii[2], tt[0], tt[1], tt[2], -1),
+                                                     m * tiled::gather_one_thread<T>(L, vc1, ii[0], ii[1], ii[2], tt[0], tt[1], tt[2], -1));
+                }
+            }
+            __syncthreads();
+            if (g.ox0 + TS <= g.gx && g.oy0 + TS <= g.gy && g.oz0 + TS <= g.gz) {
+                // whole tile: 16-byte stores of four z-neighbours (narrow stores are issue-bound)
+#pragma unroll
+                for (int u = 0; u < NS / 4 / NT; ++u) {
+                    const int qi = tid + NT * u;                     // quad: x = qi >> 6, y = (qi >> 2) & 15, z = 4 (qi & 3)
+                    const float4 *src = reinterpret_cast<const float4 *>(outb + 4 * qi);
+                    const float4 lo_ = src[0], hi_ = src[1];
+                    const int64_t o = ((int64_t)(g.ox0 + (qi >> 6)) * g.gy + (g.oy0 + ((qi >> 2) & 15))) * g.gz + (g.oz0 + 4 * (qi & 3));
+                    st4<T>(oc0 + o, make_float4(lo_.x, lo_.z, hi_.x, hi_.z));
+                    if (two) st4<T>(oc1 + o, make_float4(lo_.y, lo_.w, hi_.y, hi_.w));
+                }
+            } else {
+#pragma unroll
+                for (int v = 0; v < VPT; ++v) {
+                    int ox, oy, oz;
+                    sample_pos(g, tid + NT * v, ox, oy, oz);
+                    if (!(ox < g.gx && oy < g.gy && oz < g.gz)) continue;
+                    const int64_t o = ((int64_t)ox * g.gy + oy) * g.gz + oz;
+                    const float2 r = outb[tid + NT * v];
+                    oc0[o] = Cvt<float, T>::st(r.x);
+                    if (two) oc1[o] = Cvt<float, T>::st(r.y);
+                }
+            }
+            };
+            if (c + 2 >= p.C) { emit(std::true_type{}); prof_mark(3); break; }
+            emit(std::false_type{});
+            prof_mark(3);
+        }
+        __syncthreads();                                             // the next tile reuses the LDS tables / lists
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Launchers
+// ---------------------------------------------------------------------------
+static int cu_count()
+{
+    static int cus = 0;
+    if (!cus) {
+        int dev = 0; hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
+        if (cus <= 0) cus = 256;
+    }
+    return cus;
+}
+
+// Kernels that need more than 64 KiB of dynamic LDS opt in, once per kernel and device.
+template <auto Kernel>
+static int big_lds(size_t bytes)
+{
+    static bool done[64] = { false };
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+    if (done[dev]) return 0;
+    const hipError_t e = hipFuncSetAttribute((const void *)Kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e != hipSuccess) return (int)e;
+    done[dev] = true;
+    return 0;
+}
+
+static int desync_sleeps()
+{
+    static int n = -1;
+    if (n < 0) { const char *e = getenv("INTERPOL_DESYNC"); n = e ? atoi(e) : 3; }
+    return n;
+}
+
+struct TileCount {
+    int gx, gy, gz, ntx, nty, ntz;
+    explicit TileCount(const interpol_problem *p)
+    {
+        gx = (int)p->grid_shape[0]; gy = (int)p->grid_shape[1]; gz = (int)p->grid_shape[2];
+        ntx = (gx + TS - 1) / TS; nty = (gy + TS - 1) / TS; ntz = (gz + TS - 1) / TS;
+    }
+    int ntiles() const { return ntx * nty * ntz; }
+    dim3 grid(int B) const
+    {
+        const long long total = (long long)ntiles() * B, want = 2ll * cu_count();
+        return dim3((unsigned)(total < want ? total : want), 1u);
+    }
+};
+
+template <typename T, int K, int GM>
+static int launch_pull(const interpol_problem *p, const KParams &k, const void *vol, const void *grid, void *val, hipStream_t st)
+{
+    const int attr = big_lds<pull_sorted<T, K, GM>>(sizeof(Smem));
+    if (attr) return attr;
+    const TileCount t(p);
+    hipLaunchKernelGGL((pull_sorted<T, K, GM>), t.grid((int)p->batch), dim3(NT), sizeof(Smem), st,
+                       k, (const T *)vol, (const float *)grid, (T *)val, t.gx, t.gy, t.gz, t.nty, t.ntz, t.ntiles(), (int)p->batch, desync_sleeps());
+    const hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 1 : (int)e;
+}
+
+} // namespace sorted
+
+// Eligibility: 3-D, one order 2..3 for all dims, enough samples, 32-bit offsets into one item's grid.
+static int sorted_order(const interpol_problem *p, const KParams &k)
+{
+    if (p->dim != 3 || p->batch > 65535) return -1;
+    if (k.dbg & 32) return -1;                                     // A/B switch: the natural-order tiles of ops_tiled.hip
+    int64_t n = 1, nt = p->batch;
+    for (int d = 0; d < 3; ++d) {
+        if (p->grid_shape[d] > 0x7fffffff / 4) return -1;
+        n *= p->grid_shape[d];
+        nt *= (p->grid_shape[d] + 15) / 16;
+    }
+    if (n < 4096 || nt > 0x7fffffff) return -1;
+    if ((uint64_t)n * 12ull > 0xffffffffull) return -1;
+    if (k.order[0] != k.order[1] || k.order[0] != k.order[2]) return -1;
+    if (k.order[0] < 2 || k.order[0] > 3) return -1;
+    return k.order[0];
+}
+
+#define IP_SYM2(a, b) a##b
+#define IP_SYM(a, b) IP_SYM2(a, b)
+
+// returns 1 when it took the problem, 0 to decline, anything else: error
+int IP_SYM(try_sorted_pull_, IP_TSFX)(const interpol_problem *p, const KParams &k, const void *vol, const void *grid, void *val, hipStream_t st)
+{
+    const int K = sorted_order(p, k);
+    if (K < 0) return 0;
+    using T = IP_TT;
+    if (k.sep) {
+        if constexpr (std::is_same<T, float>::value) {
+            if (K == 3) return k.sep == 1 ? sorted::launch_pull<T, 3, 1>(p, k, vol, grid, val, st) : sorted::launch_pull<T, 3, 2>(p, k, vol, grid, val, st);
+            return k.sep == 1 ? sorted::launch_pull<T, 2, 1>(p, k, vol, grid, val, st) : sorted::launch_pull<T, 2, 2>(p, k, vol, grid, val, st);
+        } else {
+            return 0;
+        }
+    }
+    if (K == 3) return sorted::launch_pull<T, 3, 0>(p, k, vol, grid, val, st);
+    return sorted::launch_pull<T, 2, 0>(p, k, vol, grid, val, st);
+}
+
+} // namespace ip
+
+#ifdef IP_PROF
+#define IP_PROF_NAME3(s) interpol_debug_prof_sorted_##s
+#define IP_PROF_NAME2(s) IP_PROF_NAME3(s)
+extern "C" __attribute__((visibility("default"))) int IP_PROF_NAME2(IP_TSFX)(unsigned long long *out, int reset)
+{
+    unsigned long long z[16] = { 0 };
+    if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(ip::sorted::g_prof), sizeof z) != hipSuccess) return -1;
+    if (reset && hipMemcpyToSymbol(HIP_SYMBOL(ip::sorted::g_prof), z, sizeof z) != hipSuccess) return -1;
+    return 0;
+}
+#endif
