@@ -41,6 +41,23 @@ for (B, C, shp, gshp) in [(2, 2, (33, 38, 45), (33, 38, 45)), (1, 3, (20, 50, 17
                     res[key] = max(res.get(key, 0.0), e)
                     if e > 2e-6:
                         print("MISMATCH", B, C, shp, gshp, sigma, order, bound, ext, e)
+                    if "push" in sys.argv:
+                        v = torch.randn(B, C, *gshp, device=dev)
+                        for op, args in (("push", (v,)), ("count", ())):
+                            a = _hip.scatter(op, v if op == "push" else None, g, list(shp), [bound] * 3, [order] * 3, ext)
+                            r = _hip.scatter(op, v if op == "push" else None, g, list(shp), [bound] * 3, [order] * 3, ext, flags=_hip.FLAG_NO_FASTPATH)
+                            e = relerr(a, r)
+                            key = op + "_max_relerr_vs_generic"
+                            res[key] = max(res.get(key, 0.0), e)
+                            if e > 1e-5:
+                                print("MISMATCH", op, B, C, shp, gshp, sigma, order, bound, ext, e)
+                        a = _hip.scatter("push", v, g, list(shp), [bound] * 3, [order] * 3, ext, with_count=True)
+                        r = _hip.scatter("push", v, g, list(shp), [bound] * 3, [order] * 3, ext, with_count=True, flags=_hip.FLAG_NO_FASTPATH)
+                        a = a if torch.is_tensor(a) else torch.cat([x.flatten() for x in a]); r = r if torch.is_tensor(r) else torch.cat([x.flatten() for x in r])
+                        e = relerr(a, r)
+                        res["pushcount_max_relerr_vs_generic"] = max(res.get("pushcount_max_relerr_vs_generic", 0.0), e)
+                        if e > 1e-5:
+                            print("MISMATCH pushcount", B, C, shp, gshp, sigma, order, bound, ext, e)
 print(json.dumps(res))
 # timing at config 2
 B, C, n = 4, 2, 256
@@ -52,4 +69,12 @@ for sigma in (2.0, 0.0):
     a = _hip.gather("pull", inp, grid, [3] * 3, [3] * 3, 1)
     r = _hip.gather("pull", inp, grid, [3] * 3, [3] * 3, 1, flags=32 << 8)
     t["relerr_vs_r1"] = relerr(a, r)
-    print("sigma", sigma, json.dumps({k: round(v, 6) for k, v in t.items()}))
+    if "push" in sys.argv:
+        t["push_sorted"] = timeit(lambda: _hip.scatter("push", inp, grid, None, [3] * 3, [3] * 3, 1))
+        t["push_tiled_r1"] = timeit(lambda: _hip.scatter("push", inp, grid, None, [3] * 3, [3] * 3, 1, flags=32 << 8))
+        a = _hip.scatter("push", inp, grid, None, [3] * 3, [3] * 3, 1)
+        r = _hip.scatter("push", inp, grid, None, [3] * 3, [3] * 3, 1, flags=32 << 8)
+        t["push_relerr_vs_r1"] = relerr(a, r)
+        t["count_sorted"] = timeit(lambda: _hip.scatter("count", None, grid, [n] * 3, [3] * 3, [3] * 3, 1))
+        t["count_tiled_r1"] = timeit(lambda: _hip.scatter("count", None, grid, [n] * 3, [3] * 3, [3] * 3, 1, flags=32 << 8))
+    print("sigma", sigma, json.dumps({k: float("%.4g" % v) for k, v in t.items()}))

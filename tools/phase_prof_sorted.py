@@ -9,7 +9,7 @@ from interpol import _hip
 import bench
 
 NAMES = {"pull": ["build:read sorted", "stage", "taps", "unsort+store+slow", "build:coords", "build:split+minmax", "build:tables+classify", "build:scan+holes", "build:records"],
-         "push": ["build+sort", "taps", "flush", "slow"]}
+         "push": ["density+zero", "taps", "flush", "slow+self", "sources+scale", "build:split+minmax", "build:tables+classify", "build:scan+holes", "build:records"]}
 dev = torch.device("cuda", 0)
 sigma = float(sys.argv[1]) if len(sys.argv) > 1 else 2.0
 inp, grid = bench.make_inputs(4, 2, 256, sigma, dev, 1234)

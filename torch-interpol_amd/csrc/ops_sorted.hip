@@ -39,11 +39,6 @@
 #include "stencil.hpp"
 #include "tile_common.hpp"
 #include <type_traits>
-#include <stdlib.h>
-
-#ifndef IP_PREFETCH
-#define IP_PREFETCH 0
-#endif
 
 namespace ip {
 namespace sorted {
@@ -76,9 +71,11 @@ struct Smem {
     float tabsgn[3][40];       // boundary sign of the same
     int   lo[3], hi[3];        // block reductions of the first-tap indices
     int   nslow, pad[1];
+    int   cmax[8];             // scatter kernels: float bits of max |source| of the tile, per channel of the pair
     int   cnt[NCLS + 4];       // samples per class; [NCLS] collects the samples outside the box
     int   ooff[NCLS];          // surplus samples of the classes before this one
     unsigned short slow[SLOWCAP];
+    int2  rowtab[NPL * CAPY];  // scatter kernels, per resident row of the pass: { taboff_x + taboff_y, bits of sign_x * sign_y }
     float2 box[BOXSLOTS];      // aliased: float4 rec[NS] + unsigned short holes[TABCAP]; float2 out[NS]
 };
 
@@ -267,8 +264,7 @@ struct Tile {
     int   key[VPT];
     unsigned fastmask, selfmask;       // natural order: sample v is in the sorted set / is left to this thread
 
-    // coordinates of the thread's 8 samples (natural order).  Issued one tile ahead by the kernels:
-    // the HBM round trip is covered by the previous tile's output phase.
+    // coordinates of the thread's 8 samples (natural order)
     __device__ __forceinline__ static void load(const KParams &p, const float *__restrict__ grid, int64_t b, const TileGeom &g,
                                                 const int tid, float (&c)[VPT][3])
     {
@@ -463,21 +459,15 @@ __device__ __forceinline__ void slow_taps(const KParams &p, const Lattice &L, co
 // ---------------------------------------------------------------------------
 template <typename T, int K, int GM>
 __global__ __launch_bounds__(NT, 4) void pull_sorted(KParams p, const T *__restrict__ vol, const float *__restrict__ grid,
-                                                     T *__restrict__ val, int gx, int gy, int gz, int nty, int ntz, int ntiles, int nbatch, int desync)
+                                                     T *__restrict__ val, int gx, int gy, int gz, int nty, int ntz, int ntiles, int nbatch)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     Smem &sm = *reinterpret_cast<Smem *>(smem_raw);
-    // Two workgroups share a CU and run the same phases at the same pace: left alone they stay in
-    // lockstep (both waiting for memory, then both computing).  The second half of the grid starts
-    // late by about half a tile, so that one computes while the other stages.
-    if ((blockIdx.x >> 3) >= (gridDim.x >> 4))
-        for (int i = 0; i < desync; ++i) __builtin_amdgcn_s_sleep(127);
     Lattice L;
 #pragma unroll
     for (int d = 0; d < 3; ++d) { L.bound[d] = p.bound[d]; L.n[d] = p.vol_n[d]; L.ss[d] = p.vol_ss[d] / (int)sizeof(T); L.k[d] = K; }
     L.lin = 0;
     const WorkRange wr(ntiles * nbatch);
-    float cnext[VPT][3];                                             // coordinates, loaded one tile ahead
     for (int work = wr.first; work < wr.end; work += wr.step) {
         // the thread index is made opaque per tile: everything derived from it would otherwise be
         // hoisted out of the persistent loop and held (spilled) across all phases
@@ -487,7 +477,8 @@ __global__ __launch_bounds__(NT, 4) void pull_sorted(KParams p, const T *__restr
         const TileGeom g = tile_geom(tile, gx, gy, gz, nty, ntz);
         prof_mark(-1);
         Tile<K, GM> tl;
-        if (!IP_PREFETCH || work == wr.first) Tile<K, GM>::load(p, grid, b, g, tid, cnext);
+        float cnext[VPT][3];
+        Tile<K, GM>::load(p, grid, b, g, tid, cnext);
         tl.build(p, L, g, sm, tid, cnext);
         const int nslow = sm.nslow < SLOWCAP ? sm.nslow : SLOWCAP;
         // rows of the box are contiguous runs of the lattice's unit-stride dim, sign +1 throughout
@@ -618,24 +609,17 @@ __global__ __launch_bounds__(NT, 4) void pull_sorted(KParams p, const T *__restr
                 }
                 prof_mark(2);
             }
-            // The output phase, as two copies: after the LAST channel pair the sorted records are dead,
-            // which frees the registers that hold the next tile's coordinates meanwhile.
-            auto emit = [&](auto last_tag) {
-            constexpr bool LAST = decltype(last_tag)::value;
+            {
             // back to the natural order through LDS
             __syncthreads();
             const int tid = opaque((int)threadIdx.x);
-            if (IP_PREFETCH && LAST && work + wr.step < wr.end) {
-                // the next tile's coordinates: in flight during the output phase
-                const int nw = work + wr.step;
-                Tile<K, GM>::load(p, grid, nw / ntiles, tile_geom(nw % ntiles, gx, gy, gz, nty, ntz), tid, cnext);
-            }
             float2 *outb = sm.box;
 #pragma unroll
             for (int j = 0; j < VPT; ++j) {
-                if (!((tl.key[j] >> 29) & 1)) continue;
-                const float m = (float)((tl.key[j] >> 28) & 1);      // nd.py:139-140
-                outb[(tl.key[j] >> 16) & (NS - 1)] = make_float2(acc[j].x * m, acc[j].y * m);
+                const int key = opaque(tl.key[j]);                   // (else the address and the mask are computed -- and spilled -- before the passes)
+                if (!((key >> 29) & 1)) continue;
+                const float m = (float)((key >> 28) & 1);            // nd.py:139-140
+                outb[(key >> 16) & (NS - 1)] = make_float2(acc[j].x * m, acc[j].y * m);
             }
             // out-of-box samples: one wave per sample, lanes = taps, straight from global memory
             if (nslow > 0) {
@@ -686,9 +670,278 @@ __global__ __launch_bounds__(NT, 4) void pull_sorted(KParams p, const T *__restr
                     if (two) oc1[o] = Cvt<float, T>::st(r.y);
                 }
             }
-            };
-            if (c + 2 >= p.C) { emit(std::true_type{}); prof_mark(3); break; }
-            emit(std::false_type{});
+            }
+            prof_mark(3);
+            if (c + 2 >= p.C) break;
+            prof_mark(3);
+        }
+        __syncthreads();                                             // the next tile reuses the LDS tables / lists
+    }
+}
+
+
+// ===========================================================================
+// push / count : vol[b,c,tap] += w * mask * val[b,c,o]      (nd.py:146-213, pushpull.py:106-142)
+//
+// Same tiles, same sort.  The contributions of a tile are accumulated in the LDS box in FIXED
+// POINT (LDS float atomics retire 0.3 lanes/clk on gfx950, integer ones 20x that -- and with
+// class-sorted lanes a ds_add_u64 costs 6.3 clk instead of 12.6: tools/microbench/lds_gather.hip),
+// two channels per 64-bit slot:  W += (q1 << 32) + sext(q0),  q = floor(src * w * 2^(29-ex-hb) + 1/2),
+// where 2^ex bounds the tile's |src| (per channel) and hb is the headroom that the measured sample
+// density demands (tiled::headroom32): neither 32-bit field can overflow, so they separate exactly
+// at the flush, lo = (int32) W, hi = (W - lo) >> 32.  After every pass (box planes x = ps mod 4)
+// the touched slots are added to the target with coalesced global atomics (slot sign applied,
+// several slots may alias one lattice point under the boundary condition) and re-zeroed.
+// Tiles the 32-bit fields cannot serve (strongly contracting deformations: density too high for the
+// precision rule; non-finite sources) scatter tap-parallel straight to global memory, like the
+// samples that fall outside the box.
+//   MODE 0: values, 1: count (sources are ones; the target has one channel), 2: values + count in
+//   one pass (INTERPOL_FLAG_WITH_COUNT: the target has C + 1 channels, the last receives the count)
+// ===========================================================================
+// the 4 LDS adds of one row of one x-plane of a stencil, at immediate offsets
+static_assert(PZ == 36, "the immediate offsets below are (row * PZ + k) * 8");
+#define IP_ADDROW(R) \
+template <> __device__ __forceinline__ void row_adds<R>(unsigned addr, unsigned long long v0, unsigned long long v1, unsigned long long v2, unsigned long long v3) \
+{ \
+    asm volatile("ds_add_u64 %0, %1 offset:%5\n\tds_add_u64 %0, %2 offset:%6\n\tds_add_u64 %0, %3 offset:%7\n\tds_add_u64 %0, %4 offset:%8" \
+                 :: "v"(addr), "v"(v0), "v"(v1), "v"(v2), "v"(v3), "n"(R * PZ * 8), "n"(R * PZ * 8 + 8), "n"(R * PZ * 8 + 16), "n"(R * PZ * 8 + 24) : "memory"); \
+}
+template <int R> __device__ __forceinline__ void row_adds(unsigned addr, unsigned long long v0, unsigned long long v1, unsigned long long v2, unsigned long long v3);
+IP_ADDROW(0) IP_ADDROW(1) IP_ADDROW(2) IP_ADDROW(3)
+#undef IP_ADDROW
+
+template <typename T, int K, int GM, int MODE>
+__global__ __launch_bounds__(NT, 4) void push_sorted(KParams p, const T *__restrict__ val, const float *__restrict__ grid,
+                                                     float *__restrict__ vol, int gx, int gy, int gz, int nty, int ntz, int ntiles, int nbatch)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    Smem &sm = *reinterpret_cast<Smem *>(smem_raw);
+    Lattice L;
+#pragma unroll
+    for (int d = 0; d < 3; ++d) { L.bound[d] = p.bound[d]; L.n[d] = p.vol_n[d]; L.ss[d] = p.vol_ss[d] / 4; L.k[d] = K; }   // the target is float
+    L.lin = 0;
+    const int nch = MODE == 1 ? 1 : p.C + (MODE == 2 ? 1 : 0);       // target channels
+    const WorkRange wr(ntiles * nbatch, false);
+    float cnext[VPT][3];
+    for (int work = wr.first; work < wr.end; work += wr.step) {
+        const int tid = opaque((int)threadIdx.x);
+        const int64_t b = work / ntiles;
+        const TileGeom g = tile_geom(work % ntiles, gx, gy, gz, nty, ntz);
+        prof_mark(-1);
+        Tile<K, GM> tl;
+        Tile<K, GM>::load(p, grid, b, g, tid, cnext);
+        tl.build(p, L, g, sm, tid, cnext);
+        const int nslow = sm.nslow < SLOWCAP ? sm.nslow : SLOWCAP;
+        // ---- sample density: the largest number of sorted samples that share a first-tap cell bounds
+        // what any lattice point can receive.  Counted in the (free) box: 16-bit counters, two per word.
+        unsigned *cnt32 = reinterpret_cast<unsigned *>(sm.box);
+        {
+            float4 *z4 = reinterpret_cast<float4 *>(sm.box);
+            for (int e = tid; e < BOXSLOTS / 2; e += NT) z4[e] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (tid == 0) { sm.hi[0] = 0; }
+            if (tid < 8) sm.cmax[tid] = 0;
+        }
+        __syncthreads();
+        int cell[VPT];
+#pragma unroll
+        for (int j = 0; j < VPT; ++j) {
+            cell[j] = (tl.key[j] & 31) * PLANE + ((tl.key[j] >> 5) & 2047);
+            if ((tl.key[j] >> 29) & 1) atomicAdd(&cnt32[cell[j] >> 1], 1u << (16 * (cell[j] & 1)));
+        }
+        __syncthreads();
+        {
+            int m = 0;
+#pragma unroll
+            for (int j = 0; j < VPT; ++j) {
+                const int cv = (int)((cnt32[cell[j] >> 1] >> (16 * (cell[j] & 1))) & 0xffffu);
+                m = ((tl.key[j] >> 29) & 1) && cv > m ? cv : m;
+            }
+            m = wave_max(m);
+            if ((tid & 63) == 0 && m > 0) atomicMax(&sm.hi[0], m);
+        }
+        __syncthreads();
+        const int hb = tiled::headroom32(L, sm.hi[0]);                // < 0: the 32-bit fields are not precise enough here
+        {
+            float4 *z4 = reinterpret_cast<float4 *>(sm.box);
+            for (int e = tid; e < BOXSLOTS / 2; e += NT) z4[e] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        prof_mark(0);
+
+        for (int c = 0; c < nch; c += 2) {
+            const int tid = opaque((int)threadIdx.x);
+            const bool two = c + 1 < nch;
+            // channel c (and c + 1) of this batch item; ones: the count image
+            const bool ones0 = MODE == 1 || (MODE == 2 && c >= p.C), ones1 = MODE == 1 || (MODE == 2 && c + 1 >= p.C);
+            const T *ic0 = ones0 ? nullptr : val + b * p.val_sb + c * p.val_sc;
+            const T *ic1 = (ones1 || !two) ? nullptr : val + b * p.val_sb + (c + 1) * p.val_sc;
+            float *vc0 = vol + b * p.vol_sb + c * p.vol_sc;
+            float *vc1 = two ? vc0 + p.vol_sc : vc0;
+            // sources of the thread's sorted samples (masked: nd.py:201-203), and their block maxima
+            f2 src[VPT];
+            float am0 = 0.f, am1 = 0.f;
+#pragma unroll
+            for (int j = 0; j < VPT; ++j) {
+                int ox, oy, oz;
+                sample_pos(g, (tl.key[j] >> 16) & (NS - 1), ox, oy, oz);
+                const int64_t o = ((int64_t)ox * g.gy + oy) * g.gz + oz;
+                // (unconditional loads -- an empty slot has id 0, a valid position: the 16 loads go out together)
+                const bool on = (tl.key[j] >> 29) & 1;
+                const float m = (float)((tl.key[j] >> 28) & 1);
+                float s0 = ones0 ? 1.f : Cvt<float, T>::ld(ic0[o]);
+                float s1 = !two ? 0.f : (ones1 ? 1.f : Cvt<float, T>::ld(ic1[o]));
+                s0 = on ? s0 * m : 0.f; s1 = on ? s1 * m : 0.f;
+                src[j] = f2{ s0, s1 };
+                const float a0 = __builtin_fabsf(s0), a1 = __builtin_fabsf(s1);
+                am0 = (a0 > am0 || a0 != a0) ? a0 : am0;             // NaN sticks
+                am1 = (a1 > am1 || a1 != a1) ? a1 : am1;
+            }
+            {
+                const int b0 = wave_max(__float_as_int(am0)), b1 = wave_max(__float_as_int(am1));   // non-negative floats (and NaN) order like ints
+                if ((tid & 63) == 0) { if (b0) atomicMax(&sm.cmax[0], b0); if (b1) atomicMax(&sm.cmax[1], b1); }
+            }
+            __syncthreads();                                         // maxima complete; the box is zero
+            const int mb0 = sm.cmax[0], mb1 = sm.cmax[1];
+            const bool fin = (mb0 & 0x7f800000) != 0x7f800000 && (mb1 & 0x7f800000) != 0x7f800000;
+            const bool fixedpt = hb >= 0 && fin && !(p.dbg & 8);
+            int ex0 = ((mb0 >> 23) & 0xff) - 127, ex1 = ((mb1 >> 23) & 0xff) - 127;
+            ex0 = ex0 < -90 ? -90 : ex0; ex1 = ex1 < -90 ? -90 : ex1;
+            const int hbc = hb < 0 ? 0 : hb;
+            const f2 scale = { mb0 ? __int_as_float((127 + 29 - ex0 - hbc) << 23) : 0.f, mb1 ? __int_as_float((127 + 29 - ex1 - hbc) << 23) : 0.f };
+            const float inv0 = __int_as_float((127 - 29 + ex0 + hbc) << 23), inv1 = __int_as_float((127 - 29 + ex1 + hbc) << 23);
+            prof_mark(4);
+            if (fixedpt) {
+                const unsigned boxaddr = (unsigned)(size_t)(__attribute__((address_space(3))) void *)(sm.box);
+                for (int ps = 0; ps < 4; ++ps) {
+                    const int tid = opaque((int)threadIdx.x);
+                    if (tid < NPL * CAPY) {                          // row table of this pass (read by the flush)
+                        const int xr = 4 * (tid >> 5) + ps, yr = tid & 31;
+                        if (xr < tl.S[0] && yr < tl.S[1])
+                            sm.rowtab[tid] = make_int2(sm.taboff[0][xr] + sm.taboff[1][yr], __float_as_int(sm.tabsgn[0][xr] * sm.tabsgn[1][yr]));
+                    }
+                    if (!(p.dbg & 2)) {
+#pragma unroll
+                    for (int j = 0; j < VPT; ++j) {
+                        float tx = tl.tx[j]; f2 tyz = tl.tyz[j];
+                        asm volatile("" : "+v"(tx), "+v"(tyz));
+                        const int key = tl.key[j];
+                        const int x0 = key & 31;
+                        const int i = (ps - x0) & 3;                 // the x-tap of this pass
+                        const int xq = (x0 + (K == 3 || i <= K ? i : 0)) >> 2;
+                        const unsigned addr = boxaddr + 8u * (unsigned)(xq * PLANE + ((key >> 5) & 2047));
+                        const float wxi = weight_x<K>(tx, i);
+                        f2 w[4];
+                        weights_yz<K>(tyz, w);
+                        const f2 sx = src[j] * scale * f2{ wxi, wxi };
+#pragma unroll
+                        for (int jy = 0; jy <= K; ++jy) {
+                            const f2 sy = sx * f2{ w[jy].x, w[jy].x };
+                            unsigned long long v[4];
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) {
+                                const f2 pr = sy * f2{ w[k].y, w[k].y };
+                                const int q0 = tiled::cvt_rpi(pr.x), q1 = tiled::cvt_rpi(pr.y);
+                                // (q1 << 32) + sext(q0): low word q0, high word q1 + (q0 < 0 ? -1 : 0)
+                                v[k] = ((unsigned long long)(unsigned)(q1 + (q0 >> 31)) << 32) | (unsigned)q0;
+                            }
+                            if (jy == 0) row_adds<0>(addr, v[0], v[1], v[2], v[3]);
+                            else if (jy == 1) row_adds<1>(addr, v[0], v[1], v[2], v[3]);
+                            else if (jy == 2) row_adds<2>(addr, v[0], v[1], v[2], v[3]);
+                            else row_adds<3>(addr, v[0], v[1], v[2], v[3]);
+                        }
+                    }
+                    }
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    __syncthreads();
+                    prof_mark(1);
+                    if (!(p.dbg & 1)) {
+                        // flush the planes of this pass: fixed point -> float, slot sign, one global atomic per touched
+                        // slot and channel; touched slots are re-zeroed on the way.  Lanes run along z (a wave
+                        // instruction covers whole rows: the L2 performs atomics line by line), 14 rows at a time.
+                        const int npl = (tl.S[0] - ps + 3) >> 2;
+                        const int nrow = npl * CAPY;
+                        // (32 lanes per row, a second sweep for slices >= 32: 36-lane rows cost 25 % more)
+                        for (int zb = 0; zb < tl.S[2]; zb += 32) {
+                        const int z = zb + (tid & 31), rr = tid >> 5;
+                        if (z < tl.S[2]) {
+                            const int offz = sm.taboff[2][z];
+                            const float f0 = inv0 * sm.tabsgn[2][z], f1 = inv1 * sm.tabsgn[2][z];
+                            for (int r = rr; r < nrow; r += NT / 32) {
+                                if ((r & 31) >= tl.S[1]) continue;
+                                long long *sp = reinterpret_cast<long long *>(sm.box + r * PZ + z);
+                                const long long a = *sp;
+                                if (a == 0) continue;
+                                *sp = 0ll;
+                                const int2 rt = sm.rowtab[r];
+                                const int lo_ = (int)(a & 0xffffffffll);
+                                const int hi_ = (int)((a - (long long)lo_) >> 32);
+                                const int off = rt.x + offz;
+                                const float sg = __int_as_float(rt.y);
+                                if (lo_ != 0) __hip_atomic_fetch_add(vc0 + off, (float)lo_ * (f0 * sg), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                if (hi_ != 0) __hip_atomic_fetch_add(vc1 + off, (float)hi_ * (f1 * sg), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            }
+                        }
+                        }
+                    }
+                    __syncthreads();
+                    prof_mark(2);
+                }
+            } else {
+                // no fixed point for this tile: every sorted sample tap-parallel, one wave per sample (lanes =
+                // taps), float atomics straight to global memory
+                const int lane = tid & 63;
+                for (int j = 0; j < VPT; ++j) {
+                    for (int l = 0; l < 64; ++l) {
+                        const int key = __shfl(tl.key[j], l);
+                        if (!((key >> 29) & 1)) continue;            // wave-uniform
+                        const float tx = __shfl(tl.tx[j], l), ty = __shfl(tl.tyz[j].x, l), tz = __shfl(tl.tyz[j].y, l);
+                        const float s0 = __shfl(src[j].x, l), s1 = __shfl(src[j].y, l);
+                        // coordinates back from (first tap, t): x = i0 + t
+                        const int yz = (key >> 5) & 2047;
+                        const float x = (float)(tl.lo[0] + (key & 31)) + tx, y = (float)(tl.lo[1] + yz / PZ) + ty, z = (float)(tl.lo[2] + yz % PZ) + tz;
+                        int off;
+                        const float wt = tiled::tap_weight_t<K, K>(L, x, y, z, lane, &off, nullptr);
+                        if (lane < (K + 1) * (K + 1) * (K + 1)) {
+                            __hip_atomic_fetch_add(vc0 + off, wt * s0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            if (two) __hip_atomic_fetch_add(vc1 + off, wt * s1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        }
+                    }
+                }
+            }
+            // out-of-box samples: one wave per sample, lanes = taps
+            if (nslow > 0 || tl.selfmask) {
+                const int wave = tid >> 6, lane = tid & 63;
+                for (int sidx = wave; sidx < nslow; sidx += NT / 64) {
+                    int ox, oy, oz; float x[3];
+                    sample_pos(g, sm.slow[sidx], ox, oy, oz);
+                    load_xyz<GM>(p, grid, b, g, ox, oy, oz, x);
+                    const int64_t o = ((int64_t)ox * g.gy + oy) * g.gz + oz;
+                    const float m = inb_mask(p, x);
+                    const float s0 = (ones0 ? 1.f : Cvt<float, T>::ld(ic0[o])) * m;
+                    const float s1 = !two ? 0.f : (ones1 ? 1.f : Cvt<float, T>::ld(ic1[o])) * m;
+                    int off;
+                    const float wt = tiled::tap_weight_t<K, K>(L, x[0], x[1], x[2], lane, &off, nullptr);
+                    if (lane < (K + 1) * (K + 1) * (K + 1)) {
+                        __hip_atomic_fetch_add(vc0 + off, wt * s0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if (two) __hip_atomic_fetch_add(vc1 + off, wt * s1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                }
+                // pathological tiles (slow list or hole table overflowed): the thread scatters its sample itself
+                for (int v = 0; v < VPT; ++v) {
+                    if (!((tl.selfmask >> v) & 1)) continue;
+                    int ox, oy, oz; float x[3];
+                    sample_pos(g, tid + NT * v, ox, oy, oz);
+                    load_xyz<GM>(p, grid, b, g, ox, oy, oz, x);
+                    const int64_t o = ((int64_t)ox * g.gy + oy) * g.gz + oz;
+                    int ii[3]; float tt[3];
+#pragma unroll
+                    for (int d = 0; d < 3; ++d) split(K, x[d], ii[d], tt[d]);
+                    const float m = inb_mask(p, x);
+                    tiled::scatter_one_thread(L, vc0, (ones0 ? 1.f : Cvt<float, T>::ld(ic0[o])) * m, ii[0], ii[1], ii[2], tt[0], tt[1], tt[2]);
+                    if (two) tiled::scatter_one_thread(L, vc1, (ones1 ? 1.f : Cvt<float, T>::ld(ic1[o])) * m, ii[0], ii[1], ii[2], tt[0], tt[1], tt[2]);
+                }
+            }
+            __syncthreads();
+            if (tid < 8) sm.cmax[tid] = 0;                           // for the next channel pair
             prof_mark(3);
         }
         __syncthreads();                                             // the next tile reuses the LDS tables / lists
@@ -723,13 +976,6 @@ static int big_lds(size_t bytes)
     return 0;
 }
 
-static int desync_sleeps()
-{
-    static int n = -1;
-    if (n < 0) { const char *e = getenv("INTERPOL_DESYNC"); n = e ? atoi(e) : 3; }
-    return n;
-}
-
 struct TileCount {
     int gx, gy, gz, ntx, nty, ntz;
     explicit TileCount(const interpol_problem *p)
@@ -752,7 +998,27 @@ static int launch_pull(const interpol_problem *p, const KParams &k, const void *
     if (attr) return attr;
     const TileCount t(p);
     hipLaunchKernelGGL((pull_sorted<T, K, GM>), t.grid((int)p->batch), dim3(NT), sizeof(Smem), st,
-                       k, (const T *)vol, (const float *)grid, (T *)val, t.gx, t.gy, t.gz, t.nty, t.ntz, t.ntiles(), (int)p->batch, desync_sleeps());
+                       k, (const T *)vol, (const float *)grid, (T *)val, t.gx, t.gy, t.gz, t.nty, t.ntz, t.ntiles(), (int)p->batch);
+    const hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 1 : (int)e;
+}
+
+// `vol` is the zero-filled (or accumulating) FLOAT target; val == NULL: count
+template <typename T, int K, int GM>
+static int launch_push(const interpol_problem *p, const KParams &k, const void *val, const void *grid, void *vol, hipStream_t st)
+{
+    const TileCount t(p);
+#define IP_LAUNCH_PUSH(MODE)                                                                                          \
+    {                                                                                                                 \
+        const int attr = big_lds<push_sorted<T, K, GM, MODE>>(sizeof(Smem));                                          \
+        if (attr) return attr;                                                                                        \
+        hipLaunchKernelGGL((push_sorted<T, K, GM, MODE>), t.grid((int)p->batch), dim3(NT), sizeof(Smem), st,          \
+                           k, (const T *)val, (const float *)grid, (float *)vol, t.gx, t.gy, t.gz, t.nty, t.ntz, t.ntiles(), (int)p->batch); \
+    }
+    if (!val) IP_LAUNCH_PUSH(1)
+    else if (k.cc) IP_LAUNCH_PUSH(2)
+    else IP_LAUNCH_PUSH(0)
+#undef IP_LAUNCH_PUSH
     const hipError_t e = hipGetLastError();
     return e == hipSuccess ? 1 : (int)e;
 }
@@ -796,6 +1062,27 @@ int IP_SYM(try_sorted_pull_, IP_TSFX)(const interpol_problem *p, const KParams &
     }
     if (K == 3) return sorted::launch_pull<T, 3, 0>(p, k, vol, grid, val, st);
     return sorted::launch_pull<T, 2, 0>(p, k, vol, grid, val, st);
+}
+
+// Not the default yet: at BASELINE config 2 the class-sorted scatter ties with the natural-order
+// tiles of ops_tiled.hip (3.6 ms both: the tap loop drops from 1.8 to 0.7 ms, but the flush -- 1.2 G
+// global atomics for the tile halos, the same in both -- is then exposed).  dbg bit 128 selects it.
+int IP_SYM(try_sorted_push_, IP_TSFX)(const interpol_problem *p, const KParams &k, const void *val, const void *grid, void *vol, hipStream_t st)
+{
+    if (!(k.dbg & 128)) return 0;
+    const int K = sorted_order(p, k);
+    if (K < 0) return 0;
+    using T = IP_TT;
+    if (k.sep) {
+        if constexpr (std::is_same<T, float>::value) {
+            if (K == 3) return k.sep == 1 ? sorted::launch_push<T, 3, 1>(p, k, val, grid, vol, st) : sorted::launch_push<T, 3, 2>(p, k, val, grid, vol, st);
+            return k.sep == 1 ? sorted::launch_push<T, 2, 1>(p, k, val, grid, vol, st) : sorted::launch_push<T, 2, 2>(p, k, val, grid, vol, st);
+        } else {
+            return 0;
+        }
+    }
+    if (K == 3) return sorted::launch_push<T, 3, 0>(p, k, val, grid, vol, st);
+    return sorted::launch_push<T, 2, 0>(p, k, val, grid, vol, st);
 }
 
 } // namespace ip

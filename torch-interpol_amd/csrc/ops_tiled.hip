@@ -1281,34 +1281,6 @@ __global__ __launch_bounds__(C::NT) void gradc1s_tiled(KParams p, const typename
     }
 }
 
-// floor(x + 0.5) in one instruction (v_cvt_i32_f32 truncates; rndne + cvt would be two)
-__device__ __forceinline__ int cvt_rpi(float x)
-{
-    int q;
-    asm("v_cvt_rpi_i32_f32 %0, %1" : "=v"(q) : "v"(x));
-    return q;
-}
-
-// Headroom bits of the 32-bit fixed-point scatter (see scatter_channel), or -1 when 32 bits
-// would not be precise enough for this tile (large sample density / many taps).
-__device__ __forceinline__ int headroom32(const Lattice &L, int dmax)
-{
-    const float wsum[8] = { 1.f, 2.f, 1.75f, 1.6666667f, 1.5989584f, 1.55f, 1.5110244f, 1.4793651f };
-    float cb = (float)(dmax > 0 ? dmax : 1);
-    int ntap = 1;
-#pragma unroll
-    for (int d = 0; d < 3; ++d) {
-        float ws = 1.f;
-#pragma unroll
-        for (int o = 0; o < 8; ++o) ws = (L.k[d] == o) ? wsum[o] : ws;
-        cb *= ws;
-        ntap *= L.k[d] + 1;
-    }
-    const int hb = ((__float_as_int(cb * 1.0001f) >> 23) & 0xff) - 126;     // cb < 2^hb
-    if (hb < 0 || hb > 20) return -1;
-    return (float)(1 << hb) * sqrtf((float)ntap) <= 1032.f ? hb : -1;
-}
-
 // ---------------------------------------------------------------------------
 // Scatter of one channel: src(sample) * weights -> target, through the LDS box in
 // 64-bit fixed point.  Shared by push / count and by the fused pull backward.
@@ -2330,10 +2302,16 @@ int IP_SYM(try_fast_grad_, IP_TSFX)(const interpol_problem *p, const KParams &k,
 
 #endif
 
+int IP_SYM(try_sorted_push_, IP_TSFX)(const interpol_problem *p, const KParams &k, const void *val, const void *grid, void *vol, hipStream_t st);
+
 #if !defined(IP_TPART) || IP_TPART == 2
 // `vol` is the (already zero-filled or accumulating) FLOAT target; `val` == NULL means count.
 int IP_SYM(try_fast_push_, IP_TSFX)(const interpol_problem *p, const KParams &k, const void *val, const void *grid, void *vol, hipStream_t st)
 {
+    {
+        const int rc = IP_SYM(try_sorted_push_, IP_TSFX)(p, k, val, grid, vol, st);
+        if (rc != 0) return rc;
+    }
     IP_BY_ORDER(tiled::launch_push, >(p, k, val, grid, vol, st))
 }
 

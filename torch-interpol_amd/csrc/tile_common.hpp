@@ -215,5 +215,34 @@ struct WorkRange {
     }
 };
 
+// floor(x + 0.5) in one instruction (v_cvt_i32_f32 truncates; rndne + cvt would be two)
+__device__ __forceinline__ int cvt_rpi(float x)
+{
+    int q;
+    asm("v_cvt_rpi_i32_f32 %0, %1" : "=v"(q) : "v"(x));
+    return q;
+}
+
+// Headroom bits of the 32-bit fixed-point scatter (see scatter_channel), or -1 when 32 bits
+// would not be precise enough for this tile (large sample density / many taps).
+__device__ __forceinline__ int headroom32(const Lattice &L, int dmax)
+{
+    const float wsum[8] = { 1.f, 2.f, 1.75f, 1.6666667f, 1.5989584f, 1.55f, 1.5110244f, 1.4793651f };
+    float cb = (float)(dmax > 0 ? dmax : 1);
+    int ntap = 1;
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        float ws = 1.f;
+#pragma unroll
+        for (int o = 0; o < 8; ++o) ws = (L.k[d] == o) ? wsum[o] : ws;
+        cb *= ws;
+        ntap *= L.k[d] + 1;
+    }
+    const int hb = ((__float_as_int(cb * 1.0001f) >> 23) & 0xff) - 126;     // cb < 2^hb
+    if (hb < 0 || hb > 20) return -1;
+    return (float)(1 << hb) * sqrtf((float)ntap) <= 1032.f ? hb : -1;
+}
+
+
 } // namespace tiled
 } // namespace ip
