@@ -29,6 +29,16 @@ def api():
     return _CACHE["api"]
 
 
+def mid():
+    """Mid-size cases (>= 4096 samples: they reach the LDS-tile kernels), tests/golden/make_golden_mid.py.
+    Returns (manifest, arrays); inputs are float32, expected outputs the reference's float64 results
+    stored as float32."""
+    if "mid" not in _CACHE:
+        with open(os.path.join(HERE, "golden_mid.json")) as f:
+            _CACHE["mid"] = (json.load(f), np.load(os.path.join(HERE, "golden_mid.npz")))
+    return _CACHE["mid"]
+
+
 def arr(name, dtype=np.float64):
     return np.asarray(arrays()[name], dtype=dtype)
 

@@ -137,6 +137,14 @@ def test_cfg5_full_size_2d_bf16():
     y = torch.randn(B, C, n, n, generator=g, device=DEV)
     lhs, rhs = _dot(ref, y), _dot(x.float(), interpol.grid_push(y, grid, **kw))
     assert abs(lhs - rhs) <= 1e-5 * float(ref.double().norm()) * float(y.double().norm())
+    # bf16 PUSH at full size: bf16 in / out, fp32 accumulation, narrowed once
+    pb = interpol.grid_push(x, grid, **kw)
+    assert pb.dtype == torch.bfloat16 and pb.shape == x.shape
+    pf = interpol.grid_push(x.float(), grid, **kw)
+    assert _rel(pb.float(), pf) < 1e-2
+    lhs, rhs = _dot(interpol.grid_pull(y, grid, **kw), x.float()), _dot(y, pf)          # <pull y, x> = <y, push x>
+    assert abs(lhs - rhs) <= 1e-5 * float(y.double().norm()) * float(pf.double().norm())
+    del pb, pf
     # prefilter + sampling on the identity lattice interpolates (dct1 / dct2 along the two dims)
     xf = x.float()
     coeff = interpol.spline_coeff_nd(xf, interpolation=[2, 3], bound=["dct1", "dct2"], dim=2)

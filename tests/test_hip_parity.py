@@ -641,6 +641,21 @@ def test_displacement_flag_matches_identity_plus_displacement(dim):
             gb = _hip.pull_backward(vol, vol, grid, b, o, 1, True, True, flags=flags)
             _same(ga[0], gb[0], 2e-6, ("pull_backward vol", dim, flags))
             _same(ga[1], gb[1], 1e-6, ("pull_backward grid", dim, flags))
+    # ... and against the ORACLE on identity + displacement (the kernels above could agree and both be wrong)
+    vol = torch.randn([2, 2, *shape], generator=g)
+    disp = 1.7 * torch.randn([2, *shape, dim], generator=g)
+    gnp = (disp + interpol.identity_grid(shape)).numpy()              # same float add as add_identity_grid_ (api.py:490-513)
+    b, o = [3] * dim, [3] * dim
+    for flags in (_hip.FLAG_NO_FASTPATH, 0, _hip.FLAG_FORCE_TILED):
+        fd = flags | _hip.FLAG_DISPLACEMENT
+        G.assert_close(_hip.gather("pull", vol.to(DEV), disp.to(DEV), b, o, 0, flags=fd).cpu().numpy(),
+                       oracle.grid_pull(vol.numpy(), gnp, b, o, 0), rtol=1e-5, atol_rel=1e-5, what=("pull vs oracle", dim, flags))
+        G.assert_close(_hip.gather("grad", vol.to(DEV), disp.to(DEV), b, o, 1, flags=fd).cpu().numpy(),
+                       oracle.grid_grad(vol.numpy(), gnp, b, o, 1), rtol=1e-5, atol_rel=1e-5, what=("grad vs oracle", dim, flags))
+        G.assert_close(_hip.scatter("push", vol.to(DEV), disp.to(DEV), list(shape), b, o, 2, flags=fd).cpu().numpy(),
+                       oracle.grid_push(vol.numpy(), gnp, list(shape), b, o, 2), rtol=1e-5, atol_rel=1e-5, what=("push vs oracle", dim, flags))
+        G.assert_close(_hip.scatter("count", None, disp.to(DEV), list(shape), b, o, 1, flags=fd).cpu().numpy(),
+                       oracle.grid_count(gnp, list(shape), b, o, 1), rtol=1e-5, atol_rel=1e-5, what=("count vs oracle", dim, flags))
     # API level, with autograd through the displacement
     x = torch.randn(1, 2, 20, 22, 24, device=DEV, requires_grad=True)
     d = (torch.randn(1, 20, 22, 24, 3, device=DEV) * 2).requires_grad_(True)
@@ -771,8 +786,13 @@ def test_push_with_count_matches_separate_calls(dim, order, zoom):
     _same(lp.float(), _hip.scatter("push", src.bfloat16().float(), grid, tshape, b, o, 1, with_count=True), 1e-2, "bf16")
     with pytest.raises(ValueError):
         _hip.scatter("count", None, grid, tshape, b, o, 1, with_count=True)
-    pc = ops.grid_push_count(src, grid, tshape, b, o, 1)
-    assert torch.equal(pc, _hip.scatter("push", src, grid, tshape, b, o, 1, with_count=True)) or True
+    pc = ops.grid_push_count(src, grid, tshape, b, o, 1)       # the operator seam: same call (atomic-order rounding)
+    assert list(pc.shape) == [2, C + 1, *tshape]
+    _same(pc, _hip.scatter("push", src, grid, tshape, b, o, 1, with_count=True), 2e-6, "grid_push_count at the operator seam")
+    ref_p = oracle.grid_push(src.cpu().numpy(), grid.cpu().numpy(), tshape, b, o, 1)
+    ref_c = oracle.grid_count(grid.cpu().numpy(), tshape, b, o, 1)
+    G.assert_close(pc[:, :C].cpu().numpy(), ref_p, rtol=1e-5, atol_rel=1e-5, what="grid_push_count values vs oracle")
+    G.assert_close(pc[:, C:].cpu().numpy(), ref_c, rtol=1e-5, atol_rel=1e-5, what="grid_push_count count vs oracle")
 
 
 @pytest.mark.parametrize("order,zoom,bound", [(3, 4.0, 1), (1, 3.0, 3), (2, 1.0, 6), (5, 2.0, 4), (0, 2.5, 0), (3, 0.5, 2)])
@@ -826,3 +846,68 @@ def test_expanding_push_goes_through_bricks_at_api_level():
     _same(out.detach(), ref, 3e-6, "expanding push")
     out.square().sum().backward()
     assert x.grad is not None and torch.isfinite(x.grad).all()
+
+
+# ---------------------------------------------------------------------------
+# Mid-size vectors generated from the reference (tests/golden/make_golden_mid.py): >= 4096 sample
+# points per case, so the LDS-tile kernels meet reference data directly -- through every kernel
+# family that can serve the case.
+# ---------------------------------------------------------------------------
+_DBG_NATURAL_TILES = 32 << 8       # interpol_problem.flags >> 8: the natural-order tiles of ops_tiled.hip
+_DBG_SORTED_SCATTER = 128 << 8     # the class-sorted scatter of ops_sorted.hip
+
+
+def _run_mid(c, npz, flags, dtype):
+    from interpol import _hip
+    from interpol.codes import pad_codes
+    ins = {k: torch.from_numpy(np.asarray(npz[v])).to(DEV) for k, v in c["inputs"].items()}
+    b, o, e = pad_codes(c["bound"], c["dim"]), pad_codes(c["order"], c["dim"]), c["extrapolate"]   # jit_utils.py:9-15
+    if "inp" in ins:
+        ins["inp"] = ins["inp"].to(dtype)
+    if c["op"] in ("pull", "grad"):
+        return _hip.gather(c["op"], ins["inp"], ins["grid"], b, o, e, flags=flags)
+    return _hip.scatter(c["op"], ins.get("inp"), ins["grid"], c["shape"], b, o, e, flags=flags)
+
+
+@pytest.mark.parametrize("variant,flags", [("default", 0), ("force_tiled", 4), ("natural_tiles", 4 | _DBG_NATURAL_TILES),
+                                           ("sorted_scatter", _DBG_SORTED_SCATTER), ("generic", 1)])
+def test_golden_mid_fp32(variant, flags):
+    man, npz = G.mid()
+    n = 0
+    for c in man["cases"]:
+        got = _run_mid(c, npz, flags, torch.float32)
+        assert got.dtype == torch.float32
+        G.assert_close(got.cpu().numpy(), npz[c["output"]], rtol=1e-5, atol_rel=1e-5, what=(variant, c["tag"], c["op"], c["order"], c["bound"], c["extrapolate"]))
+        n += 1
+    assert n >= 80
+
+
+@pytest.mark.parametrize("flags", [0, 4])
+def test_golden_mid_bf16_storage(flags):
+    """config 5 in miniature: bf16 images (the stored values are bf16-representable), fp32 grid and
+    math; expectation = the reference on the same values in float64."""
+    man, npz = G.mid()
+    n = 0
+    for c in man["cases"]:
+        if c["storage"] != "bf16":
+            continue
+        got = _run_mid(c, npz, flags, torch.bfloat16)
+        assert got.dtype == torch.bfloat16
+        G.assert_close(got.float().cpu().numpy(), npz[c["output"]], rtol=1e-2, atol_rel=1e-2, what=(c["tag"], c["op"]))
+        n += 1
+    assert n == 2
+
+
+def test_golden_mid_backward():
+    """autograd of grid_pull / grid_push at sizes that reach the tile kernels vs the reference's autograd."""
+    man, npz = G.mid()
+    for c in man["backward"]:
+        f = lambda k: torch.from_numpy(np.asarray(npz[c[k]])).to(DEV)
+        kw = dict(interpolation=c["interpolation"], bound=c["bound"], extrapolate=c["extrapolate"])
+        inp = f("inp").requires_grad_(True)
+        grid = f("grid").requires_grad_(True)
+        y = interpol.grid_pull(inp, grid, **kw) if c["fn"] == "grid_pull" else interpol.grid_push(inp, grid, c["shape"], **kw)
+        G.assert_close(y.detach().cpu().numpy(), npz[c["out"]], rtol=1e-5, atol_rel=1e-5, what=(c["fn"], c["interpolation"], "out"))
+        y.backward(f("gout"))
+        G.assert_close(inp.grad.cpu().numpy(), npz[c["grad_inp"]], rtol=1e-5, atol_rel=3e-5, what=(c["fn"], c["interpolation"], "grad_inp"))
+        G.assert_close(grid.grad.cpu().numpy(), npz[c["grad_grid"]], rtol=1e-5, atol_rel=3e-5, what=(c["fn"], c["interpolation"], "grad_grid"))

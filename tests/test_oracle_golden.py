@@ -95,3 +95,36 @@ def test_kat_1d():
     for ex in (0, 1, 2):
         got = oracle.grid_pull(x, c2, [1], [1], ex).reshape(-1)
         assert np.allclose(got, api["kat"]["extrap%d" % ex], atol=1e-14)
+
+
+def test_mid_size_cases():
+    """The oracle against the mid-size reference vectors (the ones that reach the tile kernels on the GPU)."""
+    man, npz = G.mid()
+    assert len(man["cases"]) >= 80
+    for c in man["cases"]:
+        ins = {k: np.asarray(npz[v], dtype=np.float64) for k, v in c["inputs"].items()}
+        b, o, e = c["bound"], c["order"], c["extrapolate"]
+        if c["op"] == "pull":
+            got = oracle.grid_pull(ins["inp"], ins["grid"], b, o, e)
+        elif c["op"] == "grad":
+            got = oracle.grid_grad(ins["inp"], ins["grid"], b, o, e)
+        elif c["op"] == "push":
+            got = oracle.grid_push(ins["inp"], ins["grid"], c["shape"], b, o, e)
+        else:
+            got = oracle.grid_count(ins["grid"], c["shape"], b, o, e)
+        # expected values were stored as float32: 6e-8 relative
+        G.assert_close(got, npz[c["output"]], rtol=2e-7, atol_rel=2e-7, what=str(c))
+
+
+def test_mid_size_backward():
+    from interpol_codes import to_int_lists
+    man, npz = G.mid()
+    for c in man["backward"]:
+        b, o = to_int_lists(c["bound"], c["interpolation"])
+        f = lambda k: np.asarray(npz[c[k]], dtype=np.float64)
+        if c["fn"] == "grid_pull":
+            gi, gg = oracle.grid_pull_backward(f("gout"), f("inp"), f("grid"), b, o, 1)
+        else:
+            gi, gg = oracle.grid_push_backward(f("gout"), f("inp"), f("grid"), b, o, 1)
+        G.assert_close(gi, npz[c["grad_inp"]], rtol=2e-7, atol_rel=2e-7, what=c["fn"] + " grad_inp")
+        G.assert_close(gg, npz[c["grad_grid"]], rtol=2e-7, atol_rel=2e-7, what=c["fn"] + " grad_grid")
