@@ -78,6 +78,84 @@ def cpu_baseline(n_sample, C, sigma, order, bound):
     }
 
 
+def config4(args, world, rank, device, dist):
+    """BASELINE configs[3]: `--sources` volumes 1x128^3 pushed + counted into ONE shared 512^3 target
+    (order 3, replicate), the sources sharded over the ranks; every rank accumulates its shard into a
+    local target (push and count stacked: one buffer), then ONE sum-reduce over RCCL.  Kernel, zero-fill
+    and reduce are timed separately; value = source voxels of ALL ranks per second."""
+    import interpol
+    from interpol.distributed import push_count_shared, shard_range
+    n, m = 128, 512
+    lo, hi = shard_range(args.sources, rank, world)
+    g = torch.Generator(device=device).manual_seed(1234 + rank)
+    nsrc = hi - lo
+    x = torch.randn([nsrc, 1, n, n, n], generator=g, device=device)
+    grid = torch.randn([nsrc, n, n, n, 3], generator=g, device=device).mul_(args.sigma)
+    grid += interpol.identity_grid([n] * 3, device=device) * ((m - 1) / (n - 1))
+    kw = dict(interpolation=3, bound="replicate", extrapolate=True)
+
+    def step(ev=None):
+        if ev is not None:
+            ev[0].record()
+        push, count = push_count_shared(x, grid, [m] * 3, reduce="none", **kw)     # zero-fill + kernels
+        if ev is not None:
+            ev[1].record()
+        if dist is not None:
+            dist.all_reduce(push._base)          # push and count are views of ONE buffer: one 1.07 GB message
+        if ev is not None:
+            ev[2].record()
+        return push, count
+
+    for _ in range(max(1, args.warmup)):
+        step()
+    events = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(args.steps)]
+    fill_ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+    scratch = torch.empty([1, 2, m, m, m], device=device)
+    torch.cuda.synchronize()
+    fill_ev[0].record(); scratch.zero_(); fill_ev[1].record()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        step(events[k])
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t)
+    local_ms = sorted(e[0].elapsed_time(e[1]) for e in events)
+    red_ms = sorted(e[1].elapsed_time(e[2]) for e in events)
+    med = lambda v: v[len(v) // 2]
+    fill_ms = fill_ev[0].elapsed_time(fill_ev[1])
+    if rank == 0:
+        src_vox = args.sources * n ** 3
+        bytes_local = nsrc * n ** 3 * 16 + 2 * m ** 3 * 4                    # sources (12 B grid + 4 B value) + two targets written
+        kern_ms = med(local_ms) - fill_ms
+        print(json.dumps({
+            "metric": "M source vox/s, grid_push + grid_count of %d sources 1x128^3 into one shared 512^3 target" % args.sources,
+            "value": round(src_vox / (elapsed / args.steps) / 1e6, 1), "unit": "Mvox/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 4), "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "BASELINE configs[3]: %d sources 1x128^3 -> shared 512^3, cubic, replicate, grid = identity * 511/127 + N(0,%g^2); "
+                                   "sources batch-sharded over %d rank(s), one all_reduce of the stacked push + count buffer (1.07 GB)"
+                                   % (args.sources, args.sigma, world),
+                       "sources_per_rank": nsrc, "parallelism": "batch-sharded x%d + RCCL all_reduce" % world},
+            "local_ms_median": round(med(local_ms), 4), "zero_fill_ms": round(fill_ms, 4), "kernels_ms_median": round(kern_ms, 4),
+            "reduce_ms_median": round(med(red_ms), 4) if dist is not None else None,
+            "roofline": {"bound": "hbm", "kernel": "push_bricks pipeline (one rank's share)", "achieved": round(bytes_local / (kern_ms * 1e-3) / 1e9, 1),
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(bytes_local / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                         "traffic": None, "algorithmic_bytes_per_launch": bytes_local, "avg_launch_ms": round(kern_ms, 4)},
+        }))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -94,13 +172,30 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=256, help="edge of the CPU-baseline sample volume (0 = skip)")
     ap.add_argument("--no-fastpath", action="store_true", help="force the generic kernels")
     ap.add_argument("--no-extras", action="store_true", help="skip the smooth / identity deformation timings")
+    ap.add_argument("--config", type=int, default=2, choices=[2, 4],
+                    help="BASELINE.json configuration: 2 = pull + push of a batch (the headline), "
+                         "4 = 64 sources 1x128^3 pushed + counted into ONE shared 512^3 target, batch-sharded, one RCCL reduce")
+    ap.add_argument("--sources", type=int, default=64, help="config 4: number of source volumes (all ranks together)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus != world and world > 1:
-        raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (args.gpus, world))
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N`: launch the N ranks ourselves (one process per GPU, RCCL over xGMI)
+        import socket
+        import subprocess
+        if torch.cuda.device_count() < args.gpus:
+            raise SystemExit("--gpus %d but only %d GPU(s) visible" % (args.gpus, torch.cuda.device_count()))
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        raise SystemExit(subprocess.call(cmd, env=env))
+    if args.gpus != world:
+        raise SystemExit("--gpus %d does not match WORLD_SIZE %d: fewer ranks than asked for" % (args.gpus, world))
     device = torch.device("cuda", local_rank)
     torch.cuda.set_device(device)
     dist = None
@@ -113,6 +208,11 @@ def main():
     from interpol import _hip
     from interpol.codes import bound_to_code
     _hip.lib()                                   # the HIP extension must be there: no fallback
+
+    if dist is not None and dist.get_world_size() != args.gpus:
+        raise SystemExit("RCCL sees %d ranks, --gpus %d" % (dist.get_world_size(), args.gpus))
+    if args.config == 4:
+        return config4(args, world, rank, device, dist)
 
     B, C, n = args.batch, args.channels, args.size
     inp, grid = make_inputs(B, C, n, args.sigma, device, 1234 + rank)
@@ -166,6 +266,7 @@ def main():
     push_ms = sorted(e[1].elapsed_time(e[2]) for e in events)
     pull_avg = sum(pull_ms) / len(pull_ms)
     push_avg = sum(push_ms) / len(push_ms)
+    pull_med, push_med = pull_ms[len(pull_ms) // 2], push_ms[len(push_ms) // 2]
 
     vox_rank = B * n ** 3
     ms_per_step = 1e3 * elapsed / args.steps
@@ -178,11 +279,14 @@ def main():
     dom_ms = max(push_avg, pull_avg)
     dom_bytes = bytes_push if dom == "grid_push" else bytes_pull
     achieved = dom_bytes / (dom_ms * 1e-3) / 1e9
-    traffic = None
+    # HBM-side bytes of the same launch: NOT measured in this run -- read from the committed PMC summary
+    # (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of tools/pmc_workload.py, see profiles/)
+    traffic, traffic_source = None, None
     pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if os.path.exists(pmc):
         try:
             traffic = json.load(open(pmc)).get(dom)
+            traffic_source = "profiles/pmc_traffic.json (separate rocprofv3 --pmc passes, not this run)"
         except Exception:
             traffic = None
 
@@ -197,11 +301,15 @@ def main():
                                    % (B, C, n, args.order, args.bound, args.sigma, args.grid),
                        "batch_per_gpu": B, "channels": C, "shape": [n, n, n], "parallelism": "batch-sharded x%d" % world},
             "pull_ms": round(pull_avg, 4), "push_ms": round(push_avg, 4),
+            "pull_ms_median": round(pull_med, 4), "push_ms_median": round(push_med, 4),
+            "timing_note": "HIP events on the launch stream around each op inside the timed region; the op allocates its "
+                           "output (caching allocator) and grid_push includes the zero-fill of its target",
             "pull_mvox_s": round(vox_rank / pull_avg / 1e3, 1), "push_mvox_s": round(vox_rank / push_avg / 1e3, 1),
             "pull_frac_hbm": round(bytes_pull / (pull_avg * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
             "push_frac_hbm": round(bytes_push / (push_avg * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                         "traffic_source": traffic_source,
                          "algorithmic_bytes_per_launch": dom_bytes, "avg_launch_ms": round(dom_ms, 4)},
         }
         if world == 1 and args.grid == "random" and not args.no_extras:

@@ -38,15 +38,38 @@ def _worker(rank, world, port, tmp):
         pulled = interpol.grid_pull(inp[lo:hi], grid[lo:hi], interpolation=3, bound="dct2", extrapolate=True)
         p2, c2 = push_count_shared(inp[lo:hi], grid[lo:hi], [m, m, m], interpolation=3, bound="replicate",
                                    extrapolate=True, reduce="dst", dst=1)
+        # ONE volume (B = 1): the output-grid axis 0 is split into slabs instead
+        from interpol.distributed import grid_pull_slabs, slab_range
+        one_inp, one_grid = inp[:1], grid[:1, :, :, :5] * 0.4
+        slab = grid_pull_slabs(one_inp, one_grid, interpolation=3, bound="dct2", extrapolate=True)
+        a, b_ = slab_range(one_grid, rank, world)
+        local = grid_pull_slabs(one_inp, one_grid, gather=False, interpolation=3, bound="dct2", extrapolate=True)
+        assert local.shape[2] == b_ - a
     gathered = [None] * world
     dist.all_gather_object(gathered, pulled.numpy())
     if rank == 0:
         np.savez(tmp, push=push.numpy(), count=count.numpy(), pulled=np.concatenate(gathered, 0),
-                 inp=inp.numpy(), grid=grid.numpy())
+                 inp=inp.numpy(), grid=grid.numpy(), slab=slab.numpy(), one_grid=one_grid.numpy())
     if rank == 1:
         np.savez(tmp + ".dst", push=p2.numpy(), count=c2.numpy())
     dist.barrier()
     dist.destroy_process_group()
+
+
+def test_shared_target_dtype_rules():
+    """mixed image / grid dtypes promote like the per-item API; low-precision targets are refused loudly."""
+    sys.path.insert(0, HERE)
+    from interpol import ops
+    from interpol.distributed import push_count_shared
+    from oracle_kernels import OracleKernels
+    g = torch.Generator().manual_seed(1)
+    inp = torch.randn([2, 1, 5, 5, 5], generator=g)
+    grid = (torch.rand([2, 5, 5, 5, 3], generator=g, dtype=torch.float64) * 4)
+    with ops.use_kernels(OracleKernels):
+        push, count = push_count_shared(inp, grid, [6, 6, 6], interpolation=1, bound="zero", extrapolate=True, reduce="none")
+        assert push.dtype == torch.float64 and count.dtype == torch.float64
+        with pytest.raises(ValueError):
+            push_count_shared(inp.bfloat16(), grid.float(), [6, 6, 6], reduce="none")
 
 
 def test_shard_range():
@@ -75,6 +98,8 @@ def test_push_count_shared_gloo_world2(tmp_path):
     assert np.abs(r["count"] - want_count).max() < 1e-12 * np.abs(want_count).max()
     want_pull = np.asarray(oracle.grid_pull(r["inp"], r["grid"], [3], [3], 1))
     assert np.array_equal(r["pulled"], want_pull)          # batch sharding == full-batch result
+    want_slab = np.asarray(oracle.grid_pull(r["inp"][:1], r["one_grid"], [3], [3], 1))
+    assert np.array_equal(r["slab"], want_slab)            # output-grid slabs == unsharded result, bit for bit
     d = np.load(tmp + ".dst.npz")
     assert np.abs(d["push"] - want_push).max() < 1e-12 * np.abs(want_push).max()
     assert np.abs(d["count"] - want_count).max() < 1e-12 * np.abs(want_count).max()

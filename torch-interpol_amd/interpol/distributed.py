@@ -27,6 +27,38 @@ def shard_range(n_items, rank, world_size):
     return start, start + base + (1 if rank < rem else 0)
 
 
+def slab_range(grid, rank, world_size):
+    """[start, stop) of the slab of the OUTPUT-GRID axis 0 (`grid.shape[1]`) owned by `rank`: the
+    split for a single huge volume (B = 1), where the batch axis has nothing to shard.  Every
+    sample point is independent (reference interpol/nd.py:95-106), so a rank that pulls
+    `grid[:, start:stop]` from the (replicated) image gets exactly the rows `start:stop` of the
+    full result; for push / count a rank splats its slab of sources into a private full-size target
+    (`push_count_shared` with the slabs as the local shard) and the targets are summed."""
+    return shard_range(grid.shape[1], rank, world_size)
+
+
+def grid_pull_slabs(input, grid, rank=None, world_size=None, group=None, gather=True, **kw):
+    """grid_pull of ONE volume sharded over the output-grid axis 0: each rank samples its slab of
+    `grid`; `gather=True` all-gathers the slabs (every rank returns the full result, bit-identical
+    to the unsharded call), else the local slab is returned.  `kw` as for `interpol.grid_pull`."""
+    from . import api
+    dist = torch.distributed
+    if rank is None:
+        rank = dist.get_rank(group) if dist.is_initialized() else 0
+    if world_size is None:
+        world_size = dist.get_world_size(group) if dist.is_initialized() else 1
+    sd = grid.dim() - 1 - grid.shape[-1]                 # axis of the first spatial dim of the grid
+    lo, hi = shard_range(grid.shape[sd], rank, world_size)
+    local = api.grid_pull(input, grid.narrow(sd, lo, hi - lo), **kw)
+    if not gather or world_size == 1:
+        return local
+    od = local.dim() - grid.shape[-1]                    # the same axis in the output
+    sizes = [shard_range(grid.shape[sd], r, world_size) for r in range(world_size)]
+    parts = [local.new_empty(list(local.shape[:od]) + [b - a] + list(local.shape[od + 1:])) for a, b in sizes]
+    dist.all_gather(parts, local.contiguous(), group=group)
+    return torch.cat(parts, od)
+
+
 def _as_list(x):
     return list(x) if isinstance(x, (list, tuple)) else [x]
 
@@ -52,7 +84,15 @@ def push_count_shared(input, grid, shape, interpolation='linear', bound='zero', 
     nch = C + (1 if with_count else 0)
     if nch == 0:
         raise ValueError('nothing to do: no input and with_count=False')
-    dtype = grid.dtype if input is None else input.dtype
+    # the accumulation dtype is the one the kernels promote to (an fp32 image with an fp64 grid
+    # accumulates in fp64, as the per-item API does)
+    if input is None:
+        dtype = grid.dtype
+    else:
+        dtype = torch.promote_types(input.dtype, grid.dtype) if grid.dtype == torch.float64 else input.dtype
+        input = input.to(dtype)
+    if dtype in (torch.bfloat16, torch.float16):
+        raise ValueError('push_count_shared accumulates in the target: use a float32 / float64 image (low-precision targets cannot accumulate)')
     # push and count share one buffer -> one collective message
     buf = torch.zeros([1, nch] + shape, dtype=dtype, device=grid.device)
     k = ops.kernels()
