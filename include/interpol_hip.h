@@ -96,7 +96,8 @@ typedef struct interpol_problem {
 
 /* flags */
 #define INTERPOL_FLAG_NO_FASTPATH   1   /* force the generic kernels (testing)           */
-#define INTERPOL_FLAG_ACCUMULATE    2   /* push/count/pushgrad: do not zero the target    */
+#define INTERPOL_FLAG_ACCUMULATE    2   /* push/count/pushgrad: do not zero the target (fp32 / fp64 targets only:
+                                           INTERPOL_E_DTYPE for bf16 / f16, which are narrowed once) */
 #define INTERPOL_FLAG_FORCE_TILED   4   /* take the LDS-tiled kernel wherever one exists (testing) */
 /* Separable (tensor-product) coordinates, the grids of resize / restrict (resize.py:96-123,
  * restrict.py:88-117: `stack(meshgrid_ij(*lin), -1)`): `grid` points to the D coordinate vectors

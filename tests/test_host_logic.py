@@ -307,3 +307,38 @@ def test_grid_helpers():
     assert torch.allclose(a[..., 0], 2 * g[..., 0] + 1) and torch.allclose(a[..., 1], g[..., 1] - 1)
     with pytest.raises(ValueError):
         interpol.affine_grid(mat, [3, 4, 5])
+
+
+def test_double_backward_flows_through_the_operators():
+    """create_graph=True: the backward passes are composed from the differentiable Functions
+    (reference pushpull.py:237-325 is plain torch and differentiates twice); third order through
+    grid_grad is refused loudly instead of being dropped."""
+    import interpol
+    torch.manual_seed(3)
+    x = torch.randn(1, 2, 5, 6, dtype=torch.float64, requires_grad=True)
+    g = (torch.rand(1, 4, 3, 2, dtype=torch.float64) * 3 + 0.7).requires_grad_(True)
+    kw = dict(interpolation=3, bound="dct2", extrapolate=True)
+    with ops.use_kernels(OracleKernels):
+        assert torch.autograd.gradgradcheck(lambda a, b: interpol.grid_pull(a, b, **kw), (x, g), atol=1e-6, rtol=1e-4)
+        v = torch.randn(1, 2, 4, 3, dtype=torch.float64, requires_grad=True)
+        assert torch.autograd.gradgradcheck(lambda a, b: interpol.grid_push(a, b, [5, 6], **kw), (v, g), atol=1e-6, rtol=1e-4)
+        assert torch.autograd.gradgradcheck(lambda b: interpol.grid_count(b, [5, 6], **kw), (g,), atol=1e-6, rtol=1e-4)
+        # a gradient penalty: d/dx |d pull / d grid|^2 exists and matches finite differences
+        y = interpol.grid_pull(x, g, **kw)
+        gg, = torch.autograd.grad(y.sum(), g, create_graph=True)
+        pen = gg.square().sum()
+        gx, = torch.autograd.grad(pen, x)
+        eps = 1e-6
+        d = torch.randn_like(x)
+
+        def penalty(xx):
+            gg2, = torch.autograd.grad(interpol.grid_pull(xx, g, **kw).sum(), g, create_graph=True)
+            return gg2.square().sum()
+        fd = (penalty(x + eps * d) - penalty(x - eps * d)) / (2 * eps)
+        fd = float(fd.detach())
+        assert abs(fd - float((gx * d).sum())) < 1e-5 * max(1.0, abs(fd))
+        # third order through grid_grad's backward: not implemented -> raises
+        z = interpol.grid_grad(x, g, **kw)
+        g1, = torch.autograd.grad(z.square().sum(), g, create_graph=True)
+        with pytest.raises(RuntimeError):
+            torch.autograd.grad(g1.sum(), g)

@@ -203,6 +203,7 @@ static int scatter_driver(const interpol_problem *p, int trailing, bool need_val
     if (!vol_is_dense(p)) return INTERPOL_E_STRIDE;
     const int64_t numel = vol_numel(p);
     const bool lowp = (p->dtype == INTERPOL_BF16 || p->dtype == INTERPOL_F16);
+    if (lowp && (p->flags & INTERPOL_FLAG_ACCUMULATE)) return INTERPOL_E_DTYPE;   // a 16-bit target is narrowed once, it cannot accumulate
     void *acc = vol;
     if (lowp) {
         if (!scratch) return INTERPOL_E_NULL;
@@ -216,7 +217,6 @@ static int scatter_driver(const interpol_problem *p, int trailing, bool need_val
     rc = launch(k, B, acc);
     if (rc) return rc;
     if (lowp) {
-        // NB: with INTERPOL_FLAG_ACCUMULATE the low-precision target is overwritten, not accumulated
         rc = p->dtype == INTERPOL_BF16 ? launch_narrow_bf16(acc, vol, numel, st) : launch_narrow_f16(acc, vol, numel, st);
     }
     return rc;

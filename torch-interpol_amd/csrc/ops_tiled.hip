@@ -1987,17 +1987,23 @@ struct TileCount {
     }
 };
 
-// Kernels that need more than 64 KiB of dynamic LDS must opt in, once per device.
+// Kernels that need more than 64 KiB of dynamic LDS must opt in, once per KERNEL and device.  (The
+// cache is keyed on the kernel's address: the function-pointer TYPE is shared by every kernel of a
+// family, a static per template instantiation would opt in only the first one launched.)
 template <typename C, typename F>
 static int big_lds(F kernel)
 {
-    static bool done[64] = { false };
+    struct Seen { const void *fn; int dev; };
+    static Seen seen[256];
+    static int nseen = 0;
     int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
-    if (done[dev]) return 0;
-    const hipError_t e = hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_bytes<C>());
+    if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+    const void *fn = (const void *)kernel;
+    for (int i = 0; i < nseen; ++i)
+        if (seen[i].fn == fn && seen[i].dev == dev) return 0;
+    const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_bytes<C>());
     if (e != hipSuccess) return (int)e;
-    done[dev] = true;
+    if (nseen < 256) { seen[nseen].fn = fn; seen[nseen].dev = dev; ++nseen; }     // (a lost race only repeats the call)
     return 0;
 }
 

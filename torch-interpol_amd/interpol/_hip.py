@@ -299,6 +299,9 @@ def scatter(op, val, grid, shape, bound, order, extrapolate, flags=0, out=None, 
     dim = grid.shape[-1]
     if dim not in (1, 2, 3):
         raise NotImplementedError("interpol (MI355X build): only 1-D, 2-D and 3-D grids are supported")
+    from . import backend
+    if backend.want_exact_scatter():
+        flags |= FLAG_NO_FASTPATH                       # float atomics, like the reference's scatter_add_
     dt, gdt = common_dtypes(val, grid)
     out_dt = dt
     if op == "pushgrad" and dt in (torch.bfloat16, torch.float16):
@@ -329,7 +332,11 @@ def scatter(op, val, grid, shape, bound, order, extrapolate, flags=0, out=None, 
         vol = torch.empty([Bv, Cv] + shape, dtype=dt, device=dev)
     else:
         vol = out
-        assert vol.is_contiguous() and vol.dtype == dt and list(vol.shape) == [Bv, Cv] + shape
+        if not (vol.is_contiguous() and vol.dtype == dt and list(vol.shape) == [Bv, Cv] + shape):
+            raise ValueError("scatter target: expected a contiguous %s tensor of shape %s, got %s %s"
+                             % (dt, [Bv, Cv] + shape, vol.dtype, list(vol.shape)))
+        if (flags & FLAG_ACCUMULATE) and dt in (torch.bfloat16, torch.float16):
+            raise ValueError("FLAG_ACCUMULATE needs a float32 / float64 target (a low-precision target is narrowed once, not accumulated)")
     if vol.numel() == 0:
         return vol.to(out_dt)
     if grid.numel() == 0:
@@ -356,6 +363,9 @@ def pull_backward(gout, vol, grid, bound, order, extrapolate, need_vol, need_gri
     """Fused backward of pull: (grad_vol (B,C,*in) | None, grad_grid (B,*out,D) | None)."""
     dev = _require_gpu(gout, vol, grid)
     dim = grid.shape[-1]
+    from . import backend
+    if backend.want_exact_scatter() and need_vol:
+        flags |= FLAG_NO_FASTPATH                       # grad_vol is a scatter
     dt, gdt = common_dtypes(vol, grid)
     vol = vol.to(dt)
     gout = gout.to(dt)
@@ -530,6 +540,9 @@ def bricks_applicable(val, grid, with_count, order=None):
     """Can interpol_push_bricks take this problem? (3-D, fp32, one order <= 3 for all dims,
     <= 4 target channels, < 2^32 samples)"""
     dim = grid.shape[-1]
+    from . import backend
+    if backend.want_exact_scatter():                     # the brick kernels accumulate in fixed point too
+        return False
     if order is not None:
         o = list(order)[:3]
         if len(set(o)) != 1 or o[0] > 3:

@@ -13,6 +13,12 @@ channel axis.  Coordinates are in voxels, component d addresses spatial dim d.
 | 'dst1' ('antimirror') | 'dst2' ('antireflect') | 'dft' ('wrap'), their aliases,
 int codes 0..6, or a per-dimension list.
 `extrapolate`: False/0 (zero outside the field of view), True/1, or 2 ('hist').
+
+Size limits of this build (the reference has none): one (batch, channel) image -- input of the
+gathers, target of the scatters -- must span less than 4 GiB of byte offsets (1024^3 fp32 is just
+over, 812^3 fp64 too), spatial strides must stay below 2 GiB, D <= 3, CUDA (HIP) tensors only.
+Larger problems raise `ValueError: ... bad or too large extent` from the C-ABI; split them along a
+spatial axis (e.g. `interpol.distributed.grid_pull_slabs` for the sample grid) before calling.
 """
 import torch
 

@@ -51,6 +51,18 @@ def _extra(displacement):
     return (bool(displacement[0]) if displacement else False), len(displacement)
 
 
+def _higher_order():
+    """Inside a `backward`: is a graph being recorded (create_graph=True)?  Then the gradients must
+    themselves be differentiable: the backward is composed from the Functions of this module (as the
+    reference's backward is composed from differentiable torch ops, pushpull.py:237-325) instead of
+    calling the fused kernels, whose outputs carry no graph."""
+    return torch.is_grad_enabled()
+
+
+def _extra_args(ctx):
+    return (ctx.disp,) if ctx.nextra else ()
+
+
 def _options(bound, interpolation, extrapolate):
     return ([bound_to_code(b) for b in _as_list(bound)],
             [order_to_code(o) for o in _as_list(interpolation)],
@@ -74,6 +86,15 @@ class GridPull(torch.autograd.Function):
     @_bwd
     def backward(ctx, grad):
         input, grid = _saved(ctx)
+        if _higher_order():
+            # pull backward = push of the gradient & contraction of grid_grad (pushpull.py:237-258)
+            bound, interpolation, extrapolate = ctx.opt
+            grad_input = grad_grid = None
+            if ctx.needs_input_grad[0]:
+                grad_input = GridPush.apply(grad, grid, list(input.shape[2:]), interpolation, bound, extrapolate, *_extra_args(ctx))
+            if ctx.needs_input_grad[1]:
+                grad_grid = (GridGrad.apply(input, grid, interpolation, bound, extrapolate, *_extra_args(ctx)) * grad.unsqueeze(-1)).sum(1)
+            return (grad_input, grad_grid, None, None, None) + (None,) * ctx.nextra
         grad_input, grad_grid = ops.grid_pull_backward(
             grad, input, grid, *ctx.opt,
             need_inp=ctx.needs_input_grad[0], need_grid=ctx.needs_input_grad[1], displacement=ctx.disp)
@@ -97,6 +118,15 @@ class GridPush(torch.autograd.Function):
     @_bwd
     def backward(ctx, grad):
         input, grid = _saved(ctx)
+        if _higher_order():
+            # push backward = pull of the gradient & contraction of its grid_grad (pushpull.py:262-292)
+            bound, interpolation, extrapolate = ctx.opt
+            grad_input = grad_grid = None
+            if ctx.needs_input_grad[0]:
+                grad_input = GridPull.apply(grad, grid, interpolation, bound, extrapolate, *_extra_args(ctx))
+            if ctx.needs_input_grad[1]:
+                grad_grid = (GridGrad.apply(grad, grid, interpolation, bound, extrapolate, *_extra_args(ctx)) * input.unsqueeze(-1)).sum(1)
+            return (grad_input, grad_grid, None, None, None, None) + (None,) * ctx.nextra
         grad_input, grad_grid = ops.grid_push_backward(
             grad, input, grid, *ctx.opt,
             need_inp=ctx.needs_input_grad[0], need_grid=ctx.needs_input_grad[1], displacement=ctx.disp)
@@ -121,7 +151,11 @@ class GridCount(torch.autograd.Function):
     def backward(ctx, grad):
         grid, = ctx.saved_tensors
         grad_grid = None
-        if ctx.needs_input_grad[0]:
+        if ctx.needs_input_grad[0] and _higher_order():
+            # count backward = grid_grad of the gradient, summed over its channel (pushpull.py:296-325)
+            bound, interpolation, extrapolate = ctx.opt
+            grad_grid = GridGrad.apply(grad, grid, interpolation, bound, extrapolate, *_extra_args(ctx)).sum(1)
+        elif ctx.needs_input_grad[0]:
             grad_grid = ops.grid_count_backward(grad, grid, *ctx.opt, need_grid=True, displacement=ctx.disp)
         return (grad_grid, None, None, None, None) + (None,) * ctx.nextra
 
@@ -140,6 +174,7 @@ class GridGrad(torch.autograd.Function):
         return output
 
     @staticmethod
+    @torch.autograd.function.once_differentiable      # third-order terms are not implemented: raise instead of dropping them
     @_bwd
     def backward(ctx, grad):
         input, grid = _saved(ctx)
@@ -166,6 +201,8 @@ class SplineCoeff(torch.autograd.Function):
     @_bwd
     def backward(ctx, grad):
         # the filter is symmetric: backward == forward (autograd.py:300-305)
+        if _higher_order():
+            return SplineCoeff.apply(grad, *ctx.opt, False), None, None, None, None
         return _spline_coeff(grad, *ctx.opt, inplace=False), None, None, None, None
 
 
@@ -183,4 +220,6 @@ class SplineCoeffND(torch.autograd.Function):
     @staticmethod
     @_bwd
     def backward(ctx, grad):
+        if _higher_order():
+            return SplineCoeffND.apply(grad, *ctx.opt, False), None, None, None, None
         return _spline_coeff_nd(grad, *ctx.opt, inplace=False), None, None, None, None
