@@ -117,6 +117,14 @@ typedef struct interpol_problem {
  * pass over the grid -- push followed by count on the same grid is the usual pairing (normalised
  * splatting; SURVEY config 4).  vol_stride describe the (B, C+1, *shape) target. */
 #define INTERPOL_FLAG_WITH_COUNT    32
+/* interpol_push / interpol_count: organise the scatter TARGET-STATIONARY (push_binned.hip): the samples
+ * are first binned by the lattice brick of their first tap, then every brick is accumulated by one
+ * workgroup.  Its cost does not depend on the deformation (6 - 7 ms at 4x2x256^3 cubic for i.i.d.
+ * displacements of sigma = 0.5 ... 6 voxels), whereas the sample-stationary tiles (the default: 2.8 /
+ * 3.5 / 5.0 / 8.6 / 126 ms at sigma = 0.5 / 2 / 3 / 4 / 6) need the stencils of a 16^3 tile of samples
+ * to fit a 32^3 LDS box: set it for very rough deformations.  Needs the workspace announced by
+ * interpol_scatter_workspace(); ignored (tiles / generic kernels) when it does not apply. */
+#define INTERPOL_FLAG_BINNED_SCATTER 64
 
 /* --- forward operators -------------------------------------------------------
  * interpol_pull      replaces pushpull.grid_pull      (interpol/pushpull.py:35-66;
@@ -137,7 +145,15 @@ typedef struct interpol_problem {
  * Low-precision scatter: for dtype BF16/F16 the push-type operators need a
  * float accumulation buffer `scratch` of batch*channels*prod(vol_shape) floats
  * (scratch_bytes = that * 4); pass NULL/0 for F32/F64.
+ *
+ * Workspace of the scatters: with INTERPOL_FLAG_BINNED_SCATTER, interpol_push / interpol_count first
+ * bin the samples by target brick (push_binned.hip), which needs room for the sorted records:
+ * interpol_scatter_workspace(p, count_only) returns the number of bytes `scratch` must then have
+ * (it INCLUDES the fp32 accumulator of a BF16 / F16 target, which comes first), or 0 when the
+ * organisation does not apply.  With a smaller (or no) scratch the operators fall back to the
+ * tiled / generic scatters: same results.
  * --------------------------------------------------------------------------- */
+int64_t interpol_scatter_workspace(const interpol_problem *p, int32_t count_only);
 int interpol_pull(const interpol_problem *p, const void *vol, const void *grid, void *val, void *stream);
 int interpol_push(const interpol_problem *p, const void *val, const void *grid, void *vol,
                   void *scratch, int64_t scratch_bytes, void *stream);

@@ -866,11 +866,16 @@ def _run_mid(c, npz, flags, dtype):
         ins["inp"] = ins["inp"].to(dtype)
     if c["op"] in ("pull", "grad"):
         return _hip.gather(c["op"], ins["inp"], ins["grid"], b, o, e, flags=flags)
+    if c["op"] == "push" and flags == 64 and ins["inp"].shape[1] > 1:
+        # the binned scatter with the count channel riding along, too
+        both = _hip.scatter("push", ins["inp"], ins["grid"], c["shape"], b, o, e, flags=flags, with_count=True)
+        cnt = _hip.scatter("count", None, ins["grid"], c["shape"], b, o, e, flags=1)
+        assert float((both[:, -1:] - cnt).abs().max()) <= 1e-5 * float(cnt.abs().max())
     return _hip.scatter(c["op"], ins.get("inp"), ins["grid"], c["shape"], b, o, e, flags=flags)
 
 
 @pytest.mark.parametrize("variant,flags", [("default", 0), ("force_tiled", 4), ("natural_tiles", 4 | _DBG_NATURAL_TILES),
-                                           ("sorted_scatter", _DBG_SORTED_SCATTER), ("generic", 1)])
+                                           ("sorted_scatter", _DBG_SORTED_SCATTER), ("binned_scatter", 64), ("generic", 1)])
 def test_golden_mid_fp32(variant, flags):
     man, npz = G.mid()
     n = 0
@@ -941,3 +946,41 @@ def test_scatter_dynamic_range_and_exact_switch():
     rel = np.abs(ex - want)[small] / np.maximum(np.abs(want)[small], 1e-9)
     assert np.median(rel) < 1e-6 and rel.max() < 1e-3
     G.assert_close(exc, oracle.grid_count(grid.double().numpy(), [n] * 3, [3], [3], 1), rtol=1e-5, atol_rel=1e-6, what="exact count")
+
+
+def test_binned_scatter_rough_deformation_and_modes():
+    """interpol_push / interpol_count with INTERPOL_FLAG_BINNED_SCATTER (target-stationary, push_binned.hip)
+    against the oracle: a deformation far too rough for the tiles (sigma = 7 voxels), every bound, samples far
+    outside the field of view, the count channel, a shared target, bf16 storage, the backend switch."""
+    from interpol import _hip, backend
+    g = torch.Generator().manual_seed(21)
+    shp, gshp = (40, 36, 44), (34, 40, 38)
+    for sigma, C in ((7.0, 2), (1.0, 3)):
+        src = torch.randn([2, C, *gshp], generator=g)
+        ident = interpol.identity_grid(gshp) * torch.tensor([(n - 1) / (m - 1) for n, m in zip(shp, gshp)])
+        grid = ident[None] + sigma * torch.randn([2, *gshp, 3], generator=g)
+        grid[0, 0, 0, :5] = torch.tensor([-300.0, 900.0, 50.0])          # far outside: scattered directly
+        for bound in range(7):
+            for order, ex in ((3, 1), (2, 0)):
+                b, o = [bound] * 3, [order] * 3
+                got = _hip.scatter("push", src.to(DEV), grid.to(DEV), list(shp), b, o, ex, flags=_hip.FLAG_BINNED_SCATTER, with_count=True)
+                wp = oracle.grid_push(src.numpy(), grid.numpy(), list(shp), b, o, ex)
+                wc = oracle.grid_count(grid.numpy(), list(shp), b, o, ex)
+                G.assert_close(got[:, :C].cpu().numpy(), wp, rtol=1e-5, atol_rel=1e-5, what=("binned push", sigma, bound, order, ex))
+                G.assert_close(got[:, C:].cpu().numpy(), wc, rtol=1e-5, atol_rel=1e-5, what=("binned count channel", sigma, bound, order, ex))
+        got = _hip.scatter("count", None, grid.to(DEV), list(shp), [3] * 3, [3] * 3, 1, flags=_hip.FLAG_BINNED_SCATTER)
+        G.assert_close(got.cpu().numpy(), oracle.grid_count(grid.numpy(), list(shp), [3], [3], 1), rtol=1e-5, atol_rel=1e-5, what="binned count")
+        sh = torch.zeros([1, C, *shp], device=DEV)
+        _hip.scatter("push", src.to(DEV), grid.to(DEV), list(shp), [1] * 3, [3] * 3, 1, flags=_hip.FLAG_BINNED_SCATTER | _hip.FLAG_ACCUMULATE, out=sh, shared=True)
+        G.assert_close(sh.cpu().numpy(), oracle.grid_push(src.numpy(), grid.numpy(), list(shp), [1], [3], 1).sum(0, keepdims=True),
+                       rtol=1e-5, atol_rel=1e-5, what="binned shared target")
+        lp = _hip.scatter("push", src.to(DEV).bfloat16(), grid.to(DEV), list(shp), [3] * 3, [3] * 3, 1, flags=_hip.FLAG_BINNED_SCATTER)
+        assert lp.dtype == torch.bfloat16
+        G.assert_close(lp.float().cpu().numpy(), oracle.grid_push(src.bfloat16().float().numpy(), grid.numpy(), list(shp), [3], [3], 1),
+                       rtol=1e-2, atol_rel=1e-2, what="binned bf16")
+    backend.rough_deformations = True
+    try:
+        a = interpol.grid_push(src.to(DEV), grid.to(DEV), shp, interpolation=3, bound="dct2", extrapolate=True)
+    finally:
+        backend.rough_deformations = False
+    G.assert_close(a.cpu().numpy(), oracle.grid_push(src.numpy(), grid.numpy(), list(shp), [3], [3], 1), rtol=1e-5, atol_rel=1e-5, what="backend switch")

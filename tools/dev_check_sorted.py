@@ -70,10 +70,12 @@ for sigma in (2.0, 0.0):
     r = _hip.gather("pull", inp, grid, [3] * 3, [3] * 3, 1, flags=32 << 8)
     t["relerr_vs_r1"] = relerr(a, r)
     if "push" in sys.argv:
-        t["push_sorted"] = timeit(lambda: _hip.scatter("push", inp, grid, None, [3] * 3, [3] * 3, 1))
+        t["push_binned"] = timeit(lambda: _hip.scatter("push", inp, grid, None, [3] * 3, [3] * 3, 1))
+        t["push_sorted"] = timeit(lambda: _hip.scatter("push", inp, grid, None, [3] * 3, [3] * 3, 1, flags=(32 | 128) << 8))
         t["push_tiled_r1"] = timeit(lambda: _hip.scatter("push", inp, grid, None, [3] * 3, [3] * 3, 1, flags=32 << 8))
         a = _hip.scatter("push", inp, grid, None, [3] * 3, [3] * 3, 1)
         r = _hip.scatter("push", inp, grid, None, [3] * 3, [3] * 3, 1, flags=32 << 8)
+        t["count_binned"] = timeit(lambda: _hip.scatter("count", None, grid, [n] * 3, [3] * 3, [3] * 3, 1))
         t["push_relerr_vs_r1"] = relerr(a, r)
         t["count_sorted"] = timeit(lambda: _hip.scatter("count", None, grid, [n] * 3, [3] * 3, [3] * 3, 1))
         t["count_tiled_r1"] = timeit(lambda: _hip.scatter("count", None, grid, [n] * 3, [3] * 3, [3] * 3, 1, flags=32 << 8))

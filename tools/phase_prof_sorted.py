@@ -9,12 +9,12 @@ from interpol import _hip
 import bench
 
 NAMES = {"pull": ["build:read sorted", "stage", "taps", "unsort+store+slow", "build:coords", "build:split+minmax", "build:tables+classify", "build:scan+holes", "build:records"],
-         "push": ["density+zero", "taps", "flush", "slow+self", "sources+scale", "build:split+minmax", "build:tables+classify", "build:scan+holes", "build:records"]}
+         "push": ["load records", "hist+cells", "scan+density", "exchange+read", "sources+scale", "taps", "flush"]}
 dev = torch.device("cuda", 0)
 sigma = float(sys.argv[1]) if len(sys.argv) > 1 else 2.0
 inp, grid = bench.make_inputs(4, 2, 256, sigma, dev, 1234)
 L = _hip.lib()
-fn = L.interpol_debug_prof_sorted_f32
+fn = L.interpol_debug_prof_binned_f32 if (sys.argv[2:] and sys.argv[2] == "push") else L.interpol_debug_prof_sorted_f32
 fn.argtypes = [ctypes.c_void_p, ctypes.c_int]
 buf = (ctypes.c_ulonglong * 16)()
 def run(op):

@@ -54,6 +54,13 @@ int launch_resample1d(int dtype, int lin_f64, int order, const KParams &p, int a
 IP_DECL_TILED(f32) IP_DECL_TILED(bf16) IP_DECL_TILED(f16)
 #undef IP_DECL_TILED
 
+// binned (target-stationary) scatter for same-resolution deformations (push_binned.hip)
+#define IP_DECL_BINNED(sfx)                                                                                            \
+    int try_binned_push_##sfx(const interpol_problem *, const KParams &, const void *, const void *, void *, void *, int64_t, hipStream_t); \
+    int64_t binned_workspace_bytes_##sfx(const interpol_problem *, const KParams &, bool);
+IP_DECL_BINNED(f32) IP_DECL_BINNED(bf16) IP_DECL_BINNED(f16)
+#undef IP_DECL_BINNED
+
 #define IP_TILED_BY_DTYPE(NAME, ...)                                                     \
     switch (p->dtype) {                                                                  \
     case INTERPOL_F32: return NAME##_f32(__VA_ARGS__);                                   \
@@ -72,6 +79,10 @@ static int try_fast_pullbwd(const interpol_problem *p, const KParams &k, const v
 static int try_fast_pushbwd(const interpol_problem *p, const KParams &k, const void *gvol_out, const void *val, const void *grid,
                             void *gval, void *ggrid, hipStream_t st)
 { IP_TILED_BY_DTYPE(try_fast_pushbwd, p, k, gvol_out, val, grid, gval, ggrid, st) }
+
+static int try_binned_push(const interpol_problem *p, const KParams &k, const void *val, const void *grid, void *vol,
+                           void *ws, int64_t ws_bytes, hipStream_t st)
+{ IP_TILED_BY_DTYPE(try_binned_push, p, k, val, grid, vol, ws, ws_bytes, st) }
 
 static size_t esize(int dtype) { return dtype == INTERPOL_F64 ? 8 : (dtype == INTERPOL_F32 ? 4 : 2); }
 static size_t acc_esize(int dtype) { return dtype == INTERPOL_F64 ? 8 : 4; }
@@ -205,16 +216,23 @@ static int scatter_driver(const interpol_problem *p, int trailing, bool need_val
     const bool lowp = (p->dtype == INTERPOL_BF16 || p->dtype == INTERPOL_F16);
     if (lowp && (p->flags & INTERPOL_FLAG_ACCUMULATE)) return INTERPOL_E_DTYPE;   // a 16-bit target is narrowed once, it cannot accumulate
     void *acc = vol;
+    // scratch = [fp32 accumulator of a 16-bit target, 256-byte aligned size] [workspace of the binned scatter]
+    void *ws = scratch;
+    int64_t ws_bytes = scratch ? scratch_bytes : 0;
     if (lowp) {
         if (!scratch) return INTERPOL_E_NULL;
         if (scratch_bytes < numel * 4) return INTERPOL_E_SCRATCH;
         acc = scratch;
+        const int64_t used = (numel * 4 + 255) & ~(int64_t)255;
+        ws = (char *)scratch + used;
+        ws_bytes = scratch_bytes - used;
     }
+    if (ws_bytes <= 0) { ws = nullptr; ws_bytes = 0; }
     if (!(p->flags & INTERPOL_FLAG_ACCUMULATE) || lowp) {
         hipError_t e = hipMemsetAsync(acc, 0, (size_t)numel * acc_esize(p->dtype), st);
         if (e != hipSuccess) return (int)e;
     }
-    rc = launch(k, B, acc);
+    rc = launch(k, B, acc, ws, ws_bytes);
     if (rc) return rc;
     if (lowp) {
         rc = p->dtype == INTERPOL_BF16 ? launch_narrow_bf16(acc, vol, numel, st) : launch_narrow_f16(acc, vol, numel, st);
@@ -313,11 +331,13 @@ int interpol_push(const interpol_problem *p, const void *val, const void *grid, 
 {
     hipStream_t st = (hipStream_t)stream;
     const bool with_count = p && (p->flags & INTERPOL_FLAG_WITH_COUNT);
-    return scatter_driver(p, 1, true, val, grid, vol, scratch, scratch_bytes, st, [&](const KParams &k0, int B, void *acc) {
+    return scatter_driver(p, 1, true, val, grid, vol, scratch, scratch_bytes, st, [&](const KParams &k0, int B, void *acc, void *ws, int64_t ws_bytes) {
         KParams k = k0;
         k.cc = with_count ? 1 : 0;
         if (!(p->flags & INTERPOL_FLAG_NO_FASTPATH)) {
-            int rc = try_fast_push(p, k, val, grid, acc, st);       // the tiled kernel splats values and count in one pass
+            int rc = try_binned_push(p, k, val, grid, acc, ws, ws_bytes, st);     // needs its workspace: interpol_scatter_workspace
+            if (rc != 0) return rc == 1 ? 0 : rc;
+            rc = try_fast_push(p, k, val, grid, acc, st);           // the tiled kernel splats values and count in one pass
             if (rc != 0) return rc == 1 ? 0 : rc;
         }
         k.cc = 0;
@@ -376,15 +396,35 @@ int interpol_push_bricks(const interpol_problem *p, const void *val, const void 
     return rc == 1 ? 0 : (rc == 0 ? INTERPOL_E_SHAPE : rc);
 }
 
+int64_t interpol_scatter_workspace(const interpol_problem *p, int32_t count_only)
+{
+    KParams k; int B;
+    if (!p || (p->flags & INTERPOL_FLAG_NO_FASTPATH)) return 0;
+    if (make_params(p, SCATTER, 1, &k, &B, !count_only)) return 0;
+    k.cc = (!count_only && (p->flags & INTERPOL_FLAG_WITH_COUNT)) ? 1 : 0;
+    int64_t ws = 0;
+    switch (p->dtype) {
+    case INTERPOL_F32: ws = binned_workspace_bytes_f32(p, k, count_only != 0); break;
+    case INTERPOL_BF16: ws = binned_workspace_bytes_bf16(p, k, count_only != 0); break;
+    case INTERPOL_F16: ws = binned_workspace_bytes_f16(p, k, count_only != 0); break;
+    default: return 0;
+    }
+    if (ws <= 0) return 0;
+    const bool lowp = (p->dtype == INTERPOL_BF16 || p->dtype == INTERPOL_F16);
+    return ws + (lowp ? ((vol_numel(p) * 4 + 255) & ~(int64_t)255) : 0);
+}
+
 int interpol_count(const interpol_problem *p, const void *grid, void *vol,
                    void *scratch, int64_t scratch_bytes, void *stream)
 {
     if (p && p->channels != 1) return INTERPOL_E_SHAPE;
     if (p && (p->flags & INTERPOL_FLAG_WITH_COUNT)) return INTERPOL_E_STRIDE;      // interpol_push only
     hipStream_t st = (hipStream_t)stream;
-    return scatter_driver(p, 1, false, nullptr, grid, vol, scratch, scratch_bytes, st, [&](const KParams &k, int B, void *acc) {
+    return scatter_driver(p, 1, false, nullptr, grid, vol, scratch, scratch_bytes, st, [&](const KParams &k, int B, void *acc, void *ws, int64_t ws_bytes) {
         if (!(p->flags & INTERPOL_FLAG_NO_FASTPATH)) {
-            int rc = try_fast_push(p, k, nullptr, grid, acc, st);
+            int rc = try_binned_push(p, k, nullptr, grid, acc, ws, ws_bytes, st);
+            if (rc != 0) return rc == 1 ? 0 : rc;
+            rc = try_fast_push(p, k, nullptr, grid, acc, st);
             if (rc != 0) return rc == 1 ? 0 : rc;
         }
         return by_dtype(p->dtype,
@@ -401,7 +441,7 @@ int interpol_pushgrad(const interpol_problem *p, const void *val, const void *gr
     if (p && p->dtype != INTERPOL_F32 && p->dtype != INTERPOL_F64) return INTERPOL_E_DTYPE;
     if (p && (p->flags & INTERPOL_FLAG_WITH_COUNT)) return INTERPOL_E_STRIDE;      // interpol_push only
     hipStream_t st = (hipStream_t)stream;
-    return scatter_driver(p, p ? p->dim : 1, true, val, grid, vol, scratch, scratch_bytes, st, [&](const KParams &k, int B, void *acc) {
+    return scatter_driver(p, p ? p->dim : 1, true, val, grid, vol, scratch, scratch_bytes, st, [&](const KParams &k, int B, void *acc, void *, int64_t) {
         return p->dtype == INTERPOL_F32 ? launch_pushgrad_f32(k, val, grid, acc, B, st)
                                         : launch_pushgrad_f64(k, val, grid, acc, B, st);
     });

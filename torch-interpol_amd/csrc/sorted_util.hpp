@@ -1,0 +1,202 @@
+// ===========================================================================
+// sorted_util.hpp -- helpers shared by the class-sorted tile kernels (ops_sorted.hip) and the
+// binned scatter (push_binned.hip): optimisation fences, packed float pairs, 32-lane scans,
+// tile geometry of the sample grid, coordinate loads, 16-byte loads / stores, the extrapolation
+// mask, the weights of a stencil in packed form, phase profiling, launch helpers.
+// ===========================================================================
+#pragma once
+#include "../../include/interpol_hip.h"
+#include "stencil.hpp"
+#include "tile_common.hpp"
+#include <type_traits>
+
+namespace ip {
+namespace sorted {
+
+using tiled::Lattice;
+using tiled::split;
+using tiled::wave_max;
+using tiled::wave_min;
+using tiled::wave_sum;
+using tiled::WorkRange;
+
+constexpr int TS = 16;                          // edge of a tile of the sample grid
+
+#ifdef IP_PROF
+static __device__ unsigned long long g_prof[16];
+#endif
+__device__ __forceinline__ void prof_mark(int i)
+{
+#ifdef IP_PROF
+    __shared__ unsigned long long t0;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned long long n = clock64();
+        if (i >= 0) atomicAdd(&g_prof[i], n - t0);
+        t0 = n;
+    }
+#endif
+}
+
+// A value the optimiser cannot see through.  The kernels are persistent loops (tiles > channel
+// pairs > passes) whose phases all derive addresses from the thread index: left alone, LICM hoists
+// every such value to the outermost level and the register allocator spills them by the hundred.
+// Re-deriving them from an opaque copy at the top of a phase costs a few VALU operations.
+__device__ __forceinline__ int opaque(int v) { asm volatile("" : "+v"(v)); return v; }
+
+typedef float f2 __attribute__((ext_vector_type(2)));
+
+// exclusive prefix sum over the 32 lanes of each half wave (both halves hold the same data)
+__device__ __forceinline__ int half_excl_scan(int v, int &total)
+{
+    const int lane = __lane_id() & 31;
+    int s = v;
+#pragma unroll
+    for (int o = 1; o < 32; o <<= 1) {
+        const int t = __shfl_up(s, o, 32);
+        if (lane >= o) s += t;
+    }
+    total = __shfl(s, 31, 32);
+    return s - v;
+}
+
+struct TileGeom { int gx, gy, gz, ox0, oy0, oz0; };
+__device__ __forceinline__ TileGeom tile_geom(int tile, int gx, int gy, int gz, int nty, int ntz)
+{
+    const int tzi = tile % ntz; tile /= ntz;
+    return TileGeom{ gx, gy, gz, (tile / nty) * TS, (tile % nty) * TS, tzi * TS };
+}
+
+// natural order: sample `id` of the tile -> position in the sample grid
+__device__ __forceinline__ void sample_pos(const TileGeom &g, int id, int &ox, int &oy, int &oz)
+{
+    ox = g.ox0 + (id >> 8); oy = g.oy0 + ((id >> 4) & 15); oz = g.oz0 + (id & 15);
+}
+
+// GM: 0 dense (B,*out,3) grid, 1 separable lattice (three coordinate vectors back to back),
+// 2 displacement field (identity added in registers, api.py:490-513)
+template <int GM>
+__device__ __forceinline__ void load_xyz(const KParams &p, const float *__restrict__ grid, int64_t b, const TileGeom &g,
+                                         int ox, int oy, int oz, float *x)
+{
+    if (GM == 1) {
+        x[0] = grid[ox]; x[1] = grid[g.gx + oy]; x[2] = grid[g.gx + g.gy + oz];
+    } else {
+        const float *gp = grid + b * p.grid_sb + (((int64_t)ox * g.gy + oy) * g.gz + oz) * 3;
+        x[0] = gp[0]; x[1] = gp[1]; x[2] = gp[2];
+        if (GM == 2) { x[0] += (float)ox; x[1] += (float)oy; x[2] += (float)oz; }
+    }
+}
+
+// four consecutive elements as floats (one 16-byte load for fp32, 8 bytes for the 16-bit types;
+// 4-byte / 2-byte alignment is all that is asked for)
+template <typename T>
+__device__ __forceinline__ float4 ld4(const T *p)
+{
+    if constexpr (std::is_same<T, float>::value) {
+        typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
+        const f4u v = *reinterpret_cast<const f4u *>(p);
+        return make_float4(v.x, v.y, v.z, v.w);
+    } else {
+        typedef unsigned short h4u __attribute__((ext_vector_type(4), aligned(2)));
+        const h4u v = *reinterpret_cast<const h4u *>(p);
+        T e[4];
+        __builtin_memcpy(e, &v, 8);
+        return make_float4(Cvt<float, T>::ld(e[0]), Cvt<float, T>::ld(e[1]), Cvt<float, T>::ld(e[2]), Cvt<float, T>::ld(e[3]));
+    }
+}
+
+template <typename T>
+__device__ __forceinline__ void st4(T *p, float4 v)
+{
+    if constexpr (std::is_same<T, float>::value) {
+        typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
+        *reinterpret_cast<f4u *>(p) = f4u{ v.x, v.y, v.z, v.w };
+    } else {
+        typedef unsigned short h4u __attribute__((ext_vector_type(4), aligned(2)));
+        const T e[4] = { Cvt<float, T>::st(v.x), Cvt<float, T>::st(v.y), Cvt<float, T>::st(v.z), Cvt<float, T>::st(v.w) };
+        h4u w;
+        __builtin_memcpy(&w, e, 8);
+        *reinterpret_cast<h4u *>(p) = w;
+    }
+}
+
+// extrapolation mask of a sample (nd.py:10-27): 1 or 0
+__device__ __forceinline__ float inb_mask(const KParams &p, const float *x)
+{
+    if (p.extrapolate == 1) return 1.f;
+    const bool inb = x[0] > (float)p.mask_lo && x[0] < (float)p.mask_hi[0] && x[1] > (float)p.mask_lo
+                  && x[1] < (float)p.mask_hi[1] && x[2] > (float)p.mask_lo && x[2] < (float)p.mask_hi[2];
+    return inb ? 1.f : 0.f;
+}
+
+// The K + 1 weights of the y- and z-stencils of a sample at once (packed math: component x of
+// the vectors is y, component y is z), from the stencil coordinates t = x - i0 (nd.py:46,
+// splines.py:30-80).  With t in [(K-1)/2, (K+1)/2) every tap sits on a known polynomial piece, so
+// the |t - j| tests of the per-tap form fold away: 12 packed operations for both cubic stencils.
+template <int K>
+__device__ __forceinline__ void weights_yz(f2 t, f2 *w)
+{
+    if (K == 3) {
+        // t in [1, 2): u = t - 1 in [0, 1), v = 1 - u;  taps at distances 1 + u, u, v, 1 + v
+        const f2 u = t - 1.f, v = 2.f - t;
+        const f2 u2 = u * u, v2 = v * v;
+        w[0] = (v2 * v) * (1.f / 6.f);
+        w[3] = (u2 * u) * (1.f / 6.f);
+        w[1] = u2 * (u * 0.5f - 1.f) + 2.f / 3.f;
+        w[2] = v2 * (v * 0.5f - 1.f) + 2.f / 3.f;
+    } else {
+        // K == 2, t in [0.5, 1.5): taps at distances t, |t - 1|, 2 - t
+        const f2 a = 1.5f - t, c = t - 0.5f, m = t - 1.f;
+        w[0] = (a * a) * 0.5f;
+        w[1] = 0.75f - m * m;
+        w[2] = (c * c) * 0.5f;
+        w[3] = f2{ 0.f, 0.f };
+    }
+}
+// one weight, tap i (branch-free form of splines.py:30-44)
+template <int K>
+__device__ __forceinline__ float weight_x(float t, int i)
+{
+    const float d = __builtin_fabsf(t - (float)i);
+    if (K == 3) {
+        const float e = 2.f - d;
+        const float near = __builtin_fmaf(d * d, __builtin_fmaf(d, 0.5f, -1.f), 2.f / 3.f), far = (e * e * e) * (1.f / 6.f);
+        return d < 1.f ? near : far;
+    } else {
+        const float e = 1.5f - d;
+        const float near = 0.75f - d * d, far = 0.5f * (e * e);
+        return i > 2 ? 0.f : (d < 0.5f ? near : far);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Launch helpers
+// ---------------------------------------------------------------------------
+static int cu_count()
+{
+    static int cus = 0;
+    if (!cus) {
+        int dev = 0; hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
+        if (cus <= 0) cus = 256;
+    }
+    return cus;
+}
+
+// Kernels that need more than 64 KiB of dynamic LDS opt in, once per kernel and device.
+template <auto Kernel>
+static int big_lds(size_t bytes)
+{
+    static bool done[64] = { false };
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+    if (done[dev]) return 0;
+    const hipError_t e = hipFuncSetAttribute((const void *)Kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e != hipSuccess) return (int)e;
+    done[dev] = true;
+    return 0;
+}
+
+} // namespace sorted
+} // namespace ip

@@ -24,6 +24,7 @@ FLAG_FORCE_TILED = 4
 FLAG_SEPARABLE_GRID = 8
 FLAG_DISPLACEMENT = 16
 FLAG_WITH_COUNT = 32
+FLAG_BINNED_SCATTER = 64
 
 _DTYPE_CODE = {torch.float32: F32, torch.float64: F64, torch.bfloat16: BF16, torch.float16: F16}
 
@@ -34,7 +35,7 @@ SYMBOLS = (
     "interpol_spline_filter", "interpol_resample_1d", "interpol_pull_labels",
     "interpol_push_bricks", "interpol_push_bricks_workspace", "interpol_host_bound_index", "interpol_host_bound_sign",
     "interpol_host_weight", "interpol_host_weight_f32", "interpol_abi_version",
-    "interpol_error_string", "interpol_kernel_name",
+    "interpol_error_string", "interpol_kernel_name", "interpol_scatter_workspace",
 )
 
 
@@ -94,6 +95,8 @@ def lib():
     L.interpol_push_bricks.restype = ctypes.c_int
     L.interpol_push_bricks_workspace.argtypes = [pp]
     L.interpol_push_bricks_workspace.restype = i64
+    L.interpol_scatter_workspace.argtypes = [pp, i32]
+    L.interpol_scatter_workspace.restype = i64
     L.interpol_resample_1d.argtypes = [i32, i32, i32, i32, i32, i32, i32, i64, i64, i64, i64, vp, vp, vp, vp]
     for name in ("interpol_pull", "interpol_grad", "interpol_hess", "interpol_push", "interpol_pushgrad",
                  "interpol_count", "interpol_pull_backward", "interpol_push_backward",
@@ -302,6 +305,8 @@ def scatter(op, val, grid, shape, bound, order, extrapolate, flags=0, out=None, 
     from . import backend
     if backend.want_exact_scatter():
         flags |= FLAG_NO_FASTPATH                       # float atomics, like the reference's scatter_add_
+    elif backend.rough_deformations and op in ("push", "count"):
+        flags |= FLAG_BINNED_SCATTER                    # target-stationary organisation (csrc/push_binned.hip)
     dt, gdt = common_dtypes(val, grid)
     out_dt = dt
     if op == "pushgrad" and dt in (torch.bfloat16, torch.float16):
@@ -341,14 +346,19 @@ def scatter(op, val, grid, shape, bound, order, extrapolate, flags=0, out=None, 
         return vol.to(out_dt)
     if grid.numel() == 0:
         return vol.zero_().to(out_dt) if out is None else vol
-    scratch, sbytes = None, 0
-    if dt in (torch.bfloat16, torch.float16):
-        scratch = torch.empty(vol.numel(), dtype=torch.float32, device=dev)
-        sbytes = scratch.numel() * 4
     vstr = [0 if shared else vol.stride(0), vol.stride(1)] + _pad_to([vol.stride(2 + d) for d in range(dim)], 3)
     p = make_problem(dim, dt, gdt, bound, order, extrapolate, B, C, shape, gshape,
                      vstr, _grid_strides(grid, B, dim), valstr, flags)
     L = lib()
+    # scratch: the fp32 accumulator of a 16-bit target, followed by the workspace of the binned
+    # organisation when the library wants one for this problem (interpol_hip.h)
+    scratch, sbytes = None, 0
+    if op in ("push", "count"):
+        sbytes = int(L.interpol_scatter_workspace(ctypes.byref(p), 1 if op == "count" else 0))
+    if dt in (torch.bfloat16, torch.float16):
+        sbytes = max(sbytes, vol.numel() * 4)
+    if sbytes > 0:
+        scratch = torch.empty(sbytes, dtype=torch.uint8, device=dev)
     with torch.cuda.device(dev):
         if op == "count":
             rc = L.interpol_count(ctypes.byref(p), _ptr(grid), _ptr(vol), _ptr(scratch), sbytes, _stream(dev))

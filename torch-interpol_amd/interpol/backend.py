@@ -13,6 +13,14 @@ jitfields = False
 # reference's scatter_add_ -- two orders of magnitude slower at BASELINE config 2.
 exact_scatter = False
 
+# grid_push / grid_count of VERY rough deformations (displacements that differ by more than ~8 voxels
+# between neighbouring samples): the default scatter works on 16^3 tiles of samples whose stencils must
+# fit a 32^3 box in LDS, and slows down sharply beyond that (4x2x256^3 cubic, i.i.d. displacements of
+# sigma = 2 / 3 / 4 / 6 voxels: 3.5 / 5.0 / 8.6 / 126 ms).  `rough_deformations = True` selects the
+# target-stationary organisation (csrc/push_binned.hip) whose cost does not depend on the deformation
+# (6 - 7 ms in all those cases); it takes 24 bytes of workspace per sample point.
+rough_deformations = False
+
 
 def want_exact_scatter():
     import os
