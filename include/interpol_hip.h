@@ -125,6 +125,12 @@ typedef struct interpol_problem {
  * to fit a 32^3 LDS box: set it for very rough deformations.  Needs the workspace announced by
  * interpol_scatter_workspace(); ignored (tiles / generic kernels) when it does not apply. */
 #define INTERPOL_FLAG_BINNED_SCATTER 64
+/* The sample coordinates are an AFFINE function of the sample index, x = A o + t -- the fused form of
+ * affine_grid (api.py:534-572) followed by the operator: `grid` points to ONE D x (D+1) matrix [A | t]
+ * (grid_dtype, row-major), evaluated in registers as ((A_d0 o_0) + A_d1 o_1 ...) + t_d with fused
+ * multiply-adds; grid_stride is ignored and no (B,*out,D) grid is read (-4 D bytes per sample).  Not
+ * combinable with SEPARABLE_GRID / DISPLACEMENT; no grad_grid (INTERPOL_E_STRIDE), like SEPARABLE_GRID. */
+#define INTERPOL_FLAG_AFFINE_GRID   128
 
 /* --- forward operators -------------------------------------------------------
  * interpol_pull      replaces pushpull.grid_pull      (interpol/pushpull.py:35-66;

@@ -984,3 +984,51 @@ def test_binned_scatter_rough_deformation_and_modes():
     finally:
         backend.rough_deformations = False
     G.assert_close(a.cpu().numpy(), oracle.grid_push(src.numpy(), grid.numpy(), list(shp), [3], [3], 1), rtol=1e-5, atol_rel=1e-5, what="backend switch")
+
+
+# ---------------------------------------------------------------------------
+# SURVEY 8 row f3, second half: affine lattices evaluated in the kernels (INTERPOL_FLAG_AFFINE_GRID)
+# ---------------------------------------------------------------------------
+@pytest.mark.parametrize("dim", [1, 2, 3])
+def test_affine_grid_in_kernel_matches_oracle_on_dense_affine_grid(dim):
+    """interpol.AffineGrid(mat, shape) == oracle(x, affine_grid(mat, shape)) (reference api.py:534-572):
+    pull / grad / push / count, generic + tile kernels, fp32 and fp64.  The matrix entries are dyadic so
+    that every product and partial sum of A o + t is exact in float32: the in-kernel coordinates are then
+    bit-identical to the dense grid whatever the summation order, and the usual 1e-5 tolerance applies."""
+    from interpol import _hip
+    g = torch.Generator().manual_seed(90 + dim)
+    shp = (41, 36, 44)[:dim]
+    oshp = (37, 40, 35)[:dim]
+    A = torch.tensor([[0.875, 0.125, -0.0625], [-0.125, 1.0625, 0.25], [0.0625, -0.1875, 0.9375]])[:dim, :dim]
+    t = torch.tensor([2.5, -1.75, 3.125])[:dim]
+    mat = torch.cat([A, t[:, None]], 1)
+    dense = interpol.affine_grid(mat, oshp)[None]                      # (1, *oshp, D)
+    lazy = interpol.AffineGrid(mat, oshp)
+    assert torch.equal(lazy.dense(), dense)                            # exact products: identical coordinates
+    vol = torch.randn([2, 3, *shp], generator=g)
+    src = torch.randn([2, 3, *oshp], generator=g)
+    dn = dense.expand(2, *oshp, dim).contiguous().numpy()
+    for bound, order, ex in ((3, 3, 1), (6, 2, 0), (1, 1, 2), (4, 3, 1), (0, 5, 1)):
+        b, o = [bound] * dim, [order] * dim
+        for dtype, tol in ((torch.float32, 1e-5), (torch.float64, 1e-11)):
+            for flags in ((_hip.FLAG_NO_FASTPATH, 0, _hip.FLAG_FORCE_TILED) if dtype == torch.float32 else (0,)):
+                v, s_ = vol.to(DEV, dtype), src.to(DEV, dtype)
+                lz = lazy.to(DEV, dtype)
+                what = (dim, bound, order, ex, str(dtype), flags)
+                G.assert_close(_hip.gather("pull", v, lz, b, o, ex, flags=flags).cpu().numpy(),
+                               oracle.grid_pull(vol.double().numpy(), dn.astype(np.float64), b, o, ex), rtol=tol, atol_rel=tol, what=("pull",) + what)
+                G.assert_close(_hip.gather("grad", v, lz, b, o, ex, flags=flags).cpu().numpy(),
+                               oracle.grid_grad(vol.double().numpy(), dn.astype(np.float64), b, o, ex), rtol=tol, atol_rel=tol, what=("grad",) + what)
+                G.assert_close(_hip.scatter("push", s_, lz, list(shp), b, o, ex, flags=flags).cpu().numpy(),
+                               oracle.grid_push(src.double().numpy(), dn.astype(np.float64), list(shp), b, o, ex), rtol=tol, atol_rel=tol, what=("push",) + what)
+    # API level: the lazy lattice broadcasts over the batch like a grid without batch dims; gradients reach the image
+    x = torch.randn([2, 3, *shp], generator=g).to(DEV).requires_grad_(True)
+    kw = dict(interpolation=3, bound="dct2", extrapolate=True)
+    a = interpol.grid_pull(x, lazy.to(DEV), **kw)
+    bb = interpol.grid_pull(x, dense[0].to(DEV), **kw)
+    _same(a.detach(), bb.detach(), 1e-6, "api pull on an AffineGrid")
+    ga, = torch.autograd.grad(a.square().sum(), x)
+    gb, = torch.autograd.grad(bb.square().sum(), x)
+    _same(ga, gb, 1e-5, "api grad input through an AffineGrid")
+    cnt = interpol.grid_count(lazy.to(DEV), shp, **kw)
+    _same(cnt, interpol.grid_count(dense[0].to(DEV), shp, **kw), 1e-5, "api count on an AffineGrid")

@@ -342,3 +342,25 @@ def test_double_backward_flows_through_the_operators():
         g1, = torch.autograd.grad(z.square().sum(), g, create_graph=True)
         with pytest.raises(RuntimeError):
             torch.autograd.grad(g1.sum(), g)
+
+
+def test_affine_grid_lazy_lattice_host_logic():
+    """AffineGrid quacks like a constant (1, *shape, D) grid: shape conventions, no gradient, dense() equals
+    the reference construction affine_grid(mat, shape) when the products are exact."""
+    import interpol
+    mat = torch.tensor([[0.5, 0.25, 1.5], [-0.125, 1.0, 2.0]], dtype=torch.float64)
+    lz = interpol.AffineGrid(mat, [7, 9])
+    assert tuple(lz.shape) == (1, 7, 9, 2) and lz.dim() == 4 and not lz.requires_grad
+    assert torch.equal(lz.dense()[0], interpol.affine_grid(mat, [7, 9]))
+    x = torch.randn(3, 2, 5, 6, dtype=torch.float64, requires_grad=True)
+    with ops.use_kernels(OracleKernels):
+        y = interpol.grid_pull(x, lz, interpolation=2, bound="dct1", extrapolate=True)
+        assert y.shape == (3, 2, 7, 9)
+        want = interpol.grid_pull(x, interpol.affine_grid(mat, [7, 9]), interpolation=2, bound="dct1", extrapolate=True)
+        assert torch.allclose(y, want, rtol=0, atol=1e-13)
+        y.sum().backward()
+        assert x.grad is not None
+        c = interpol.grid_count(lz, [5, 6], interpolation=1, bound="zero", extrapolate=True)
+        assert c.shape == (5, 6)
+    with pytest.raises(ValueError):
+        interpol.AffineGrid(torch.zeros(2, 3, 4), [3, 3, 3])

@@ -136,13 +136,17 @@ static int make_params(const interpol_problem *p, Role role, int trailing, KPara
     k->vol_sb = p->vol_stride[0];
     k->vol_sc = p->vol_stride[1];
     // grid: spatial dims contiguous (row-major), component stride 1
-    if ((p->flags & INTERPOL_FLAG_SEPARABLE_GRID) && (p->flags & INTERPOL_FLAG_DISPLACEMENT)) return INTERPOL_E_STRIDE;
-    if (p->flags & (INTERPOL_FLAG_SEPARABLE_GRID | INTERPOL_FLAG_DISPLACEMENT)) {
+    {
+        const int modes = ((p->flags & INTERPOL_FLAG_SEPARABLE_GRID) ? 1 : 0) + ((p->flags & INTERPOL_FLAG_DISPLACEMENT) ? 1 : 0)
+                        + ((p->flags & INTERPOL_FLAG_AFFINE_GRID) ? 1 : 0);
+        if (modes > 1) return INTERPOL_E_STRIDE;                     // one coordinate source at a time
+    }
+    if (p->flags & (INTERPOL_FLAG_SEPARABLE_GRID | INTERPOL_FLAG_DISPLACEMENT | INTERPOL_FLAG_AFFINE_GRID)) {
         if (N > 0xffffffffll) return INTERPOL_E_SHAPE;               // the sample index is split in 32 bits
-        k->sep = (p->flags & INTERPOL_FLAG_SEPARABLE_GRID) ? 1 : 2;
+        k->sep = (p->flags & INTERPOL_FLAG_SEPARABLE_GRID) ? 1 : ((p->flags & INTERPOL_FLAG_DISPLACEMENT) ? 2 : 3);
         for (int d = 0; d < 3; ++d) k->gshape[d] = d < p->dim ? (int)p->grid_shape[d] : 1;
     }
-    if (p->flags & INTERPOL_FLAG_SEPARABLE_GRID) {
+    if (p->flags & (INTERPOL_FLAG_SEPARABLE_GRID | INTERPOL_FLAG_AFFINE_GRID)) {
         k->grid_sb = 0;
     } else {
         int64_t expect = p->dim;
@@ -455,7 +459,7 @@ int interpol_pull_backward(const interpol_problem *p, const void *grad_out, cons
     if (rc) return rc;
     if (!grad_out || !vol || !grid) return INTERPOL_E_NULL;
     if (!grad_vol && !grad_grid) return 0;
-    if (grad_grid && (p->flags & INTERPOL_FLAG_SEPARABLE_GRID)) return INTERPOL_E_STRIDE;   // no per-sample grid to differentiate
+    if (grad_grid && (p->flags & (INTERPOL_FLAG_SEPARABLE_GRID | INTERPOL_FLAG_AFFINE_GRID))) return INTERPOL_E_STRIDE;   // no per-sample grid to differentiate
     hipStream_t st = (hipStream_t)stream;
     // grad_vol is a dense (B, C, *vol_shape) buffer; vol must be spatially contiguous so
     // that both share tap offsets (channel / batch strides are free)
@@ -538,7 +542,7 @@ int interpol_push_backward(const interpol_problem *p, const void *grad_vol_out, 
     if (rc) return rc;
     if (!grad_vol_out || !val || !grid) return INTERPOL_E_NULL;
     if (!grad_val && !grad_grid) return 0;
-    if (grad_grid && (p->flags & INTERPOL_FLAG_SEPARABLE_GRID)) return INTERPOL_E_STRIDE;
+    if (grad_grid && (p->flags & (INTERPOL_FLAG_SEPARABLE_GRID | INTERPOL_FLAG_AFFINE_GRID))) return INTERPOL_E_STRIDE;
     hipStream_t st = (hipStream_t)stream;
     if (!(p->flags & INTERPOL_FLAG_NO_FASTPATH)) {
         if (grad_val && !grad_grid) {
@@ -563,7 +567,7 @@ int interpol_count_backward(const interpol_problem *p, const void *grad_vol_out,
     int rc = make_params(p, GATHER, 1, &k, &B, false);
     if (rc) return rc;
     if (!grad_vol_out || !grid || !grad_grid) return INTERPOL_E_NULL;
-    if (p->flags & INTERPOL_FLAG_SEPARABLE_GRID) return INTERPOL_E_STRIDE;
+    if (p->flags & (INTERPOL_FLAG_SEPARABLE_GRID | INTERPOL_FLAG_AFFINE_GRID)) return INTERPOL_E_STRIDE;
     hipStream_t st = (hipStream_t)stream;
     if (!(p->flags & INTERPOL_FLAG_NO_FASTPATH)) {
         rc = try_fast_pushbwd(p, k, grad_vol_out, nullptr, grid, nullptr, grad_grid, st);

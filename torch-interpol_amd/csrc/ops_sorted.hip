@@ -871,8 +871,10 @@ int IP_SYM(try_sorted_pull_, IP_TSFX)(const interpol_problem *p, const KParams &
     using T = IP_TT;
     if (k.sep) {
         if constexpr (std::is_same<T, float>::value) {
-            if (K == 3) return k.sep == 1 ? sorted::launch_pull<T, 3, 1>(p, k, vol, grid, val, st) : sorted::launch_pull<T, 3, 2>(p, k, vol, grid, val, st);
-            return k.sep == 1 ? sorted::launch_pull<T, 2, 1>(p, k, vol, grid, val, st) : sorted::launch_pull<T, 2, 2>(p, k, vol, grid, val, st);
+            if (K == 3) return k.sep == 1 ? sorted::launch_pull<T, 3, 1>(p, k, vol, grid, val, st)
+                             : (k.sep == 2 ? sorted::launch_pull<T, 3, 2>(p, k, vol, grid, val, st) : sorted::launch_pull<T, 3, 3>(p, k, vol, grid, val, st));
+            return k.sep == 1 ? sorted::launch_pull<T, 2, 1>(p, k, vol, grid, val, st)
+                 : (k.sep == 2 ? sorted::launch_pull<T, 2, 2>(p, k, vol, grid, val, st) : sorted::launch_pull<T, 2, 3>(p, k, vol, grid, val, st));
         } else {
             return 0;
         }
@@ -890,6 +892,7 @@ int IP_SYM(try_sorted_push_, IP_TSFX)(const interpol_problem *p, const KParams &
     const int K = sorted_order(p, k);
     if (K < 0) return 0;
     using T = IP_TT;
+    if (k.sep == 3) return 0;                                        // affine lattices: the generic scatter
     if (k.sep) {
         if constexpr (std::is_same<T, float>::value) {
             if (K == 3) return k.sep == 1 ? sorted::launch_push<T, 3, 1>(p, k, val, grid, vol, st) : sorted::launch_push<T, 3, 2>(p, k, val, grid, vol, st);

@@ -2132,6 +2132,7 @@ static int launch_push_impl(const interpol_problem *p, const KParams &k, const v
 template <typename C, bool GRAD>
 static int launch_gather(const interpol_problem *p, const KParams &k, const void *vol, const void *grid, void *val, hipStream_t st)
 {
+    if (k.sep == 3) return 0;                              // affine lattices: class-sorted tiles or generic kernels
     if (k.sep) {
         // own instantiations for fp32 storage, 3-D, isotropic orders 1-3 (linear ... cubic resize
         // and displacement fields); everything else in these modes runs the generic kernels --
@@ -2148,6 +2149,7 @@ static int launch_gather(const interpol_problem *p, const KParams &k, const void
 template <typename C>
 static int launch_push(const interpol_problem *p, const KParams &k, const void *val, const void *grid, void *vol, hipStream_t st)
 {
+    if (k.sep == 3) return 0;
     if (k.sep) {
         if constexpr (std::is_same<typename C::T, float>::value && C::D == 3 && C::ISO && C::K <= 3) {
             if (k.sep == 1) return launch_push_impl<typename C::template Mode<1>>(p, k, val, grid, vol, st);

@@ -544,7 +544,7 @@ int IP_SYM(try_binned_push_, IP_TSFX)(const interpol_problem *p, const KParams &
 {
     using namespace binned;
     using T = IP_TT;
-    if (!workspace || !binned_eligible(p, k)) return 0;
+    if (!workspace || k.sep == 3 || !binned_eligible(p, k)) return 0;
     const bool count_only = val == nullptr;
     const int nch = count_only ? 1 : k.C + (k.cc ? 1 : 0);
     Workspace w;

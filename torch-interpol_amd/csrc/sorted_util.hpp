@@ -74,13 +74,19 @@ __device__ __forceinline__ void sample_pos(const TileGeom &g, int id, int &ox, i
 }
 
 // GM: 0 dense (B,*out,3) grid, 1 separable lattice (three coordinate vectors back to back),
-// 2 displacement field (identity added in registers, api.py:490-513)
+// 2 displacement field (identity added in registers, api.py:490-513), 3 affine lattice (api.py:534-572)
 template <int GM>
 __device__ __forceinline__ void load_xyz(const KParams &p, const float *__restrict__ grid, int64_t b, const TileGeom &g,
                                          int ox, int oy, int oz, float *x)
 {
     if (GM == 1) {
         x[0] = grid[ox]; x[1] = grid[g.gx + oy]; x[2] = grid[g.gx + g.gy + oz];
+    } else if (GM == 3) {
+        // affine lattice (affine_grid, api.py:534-572): the 3 x 4 matrix [A | t] behind `grid` (uniform: scalar loads);
+        // same operation order as the generic kernels (stencil.hpp)
+#pragma unroll
+        for (int d = 0; d < 3; ++d)
+            x[d] = __builtin_fmaf(grid[4 * d + 2], (float)oz, __builtin_fmaf(grid[4 * d + 1], (float)oy, grid[4 * d] * (float)ox)) + grid[4 * d + 3];
     } else {
         const float *gp = grid + b * p.grid_sb + (((int64_t)ox * g.gy + oy) * g.gz + oz) * 3;
         x[0] = gp[0]; x[1] = gp[1]; x[2] = gp[2];

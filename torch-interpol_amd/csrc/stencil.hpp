@@ -171,6 +171,9 @@ struct Stencil {
     }
 };
 
+__device__ __forceinline__ float  coord_fma(float a, float b, float c)    { return __builtin_fmaf(a, b, c); }
+__device__ __forceinline__ double coord_fma(double a, double b, double c) { return __builtin_fma(a, b, c); }
+
 // Coordinates of sample `o` of batch item `b`.
 template <typename R, typename G, int D>
 __device__ __forceinline__ void load_coords(const KParams &p, const G *grid, int64_t b, int64_t o, R *x)
@@ -186,6 +189,15 @@ __device__ __forceinline__ void load_coords(const KParams &p, const G *grid, int
             // tensor-product coordinates (resize.py:96-123): x_d = lin_d[o_d]
 #pragma unroll
             for (int d = 0; d < D; ++d) { x[d] = (R)grid[base + (int)od[d]]; base += p.gshape[d]; }
+        } else if (p.sep == 3) {
+            // affine lattice (affine_grid, api.py:534-572): x = A o + t, the D x (D+1) matrix [A | t] behind `grid`
+#pragma unroll
+            for (int d = 0; d < D; ++d) {
+                G s = grid[d * (D + 1)] * (G)od[0];
+#pragma unroll
+                for (int e = 1; e < D; ++e) s = coord_fma(grid[d * (D + 1) + e], (G)od[e], s);
+                x[d] = (R)(G)(s + grid[d * (D + 1) + D]);
+            }
         } else {
             // displacement field: x_d = o_d + disp (add_identity_grid_, api.py:490-513, in the grid's dtype)
             const G *gp = grid + b * p.grid_sb + o * D;

@@ -13,7 +13,7 @@ from .api import (pull, push, count, grid_pull, grid_push, grid_count, grid_grad
 from .utils import identity_grid, add_identity_grid, add_identity_grid_, affine_grid     # noqa: F401
 from .resize import resize                                                                # noqa: F401
 from .restrict import restrict                                                            # noqa: F401
-from .sepgrid import SeparableGrid                                                        # noqa: F401
+from .sepgrid import SeparableGrid, AffineGrid                                            # noqa: F401
 from .separable import separable_pull, separable_push                                    # noqa: F401
 from . import backend                                                                     # noqa: F401
 

@@ -10,7 +10,7 @@ import os
 
 import torch
 
-from .sepgrid import SeparableGrid
+from .sepgrid import SeparableGrid, AffineGrid, LazyGrid
 
 _PKG_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 # INTERPOL_HIP_LIB: another build of the same library (A/B timing of kernel variants)
@@ -25,6 +25,7 @@ FLAG_SEPARABLE_GRID = 8
 FLAG_DISPLACEMENT = 16
 FLAG_WITH_COUNT = 32
 FLAG_BINNED_SCATTER = 64
+FLAG_AFFINE_GRID = 128
 
 _DTYPE_CODE = {torch.float32: F32, torch.float64: F64, torch.bfloat16: BF16, torch.float16: F16}
 
@@ -252,8 +253,8 @@ class _PackedLattice:
 
 def _prep_grid(grid, gdt):
     """-> (grid object to pass on, extra flags)."""
-    if isinstance(grid, SeparableGrid):
-        return _PackedLattice(grid, gdt), FLAG_SEPARABLE_GRID
+    if isinstance(grid, LazyGrid):
+        return _PackedLattice(grid, gdt), (FLAG_AFFINE_GRID if isinstance(grid, AffineGrid) else FLAG_SEPARABLE_GRID)
     grid = grid.to(gdt)
     if not _spatially_contiguous(grid, 1):
         grid = grid.contiguous()
@@ -382,7 +383,7 @@ def pull_backward(gout, vol, grid, bound, order, extrapolate, need_vol, need_gri
     grid_c, gflag = _prep_grid(grid, gdt)
     flags |= gflag
     if gflag and need_grid:
-        raise RuntimeError("interpol: a SeparableGrid is a constant lattice, it has no gradient")
+        raise RuntimeError("interpol: a SeparableGrid / AffineGrid is a constant lattice, it has no gradient")
     if not _spatially_contiguous(vol, 2):
         vol = vol.contiguous()
     if not _spatially_contiguous(gout, 2):
@@ -420,7 +421,7 @@ def push_backward(gvol_out, val, grid, bound, order, extrapolate, need_val, need
     grid_c, gflag = _prep_grid(grid, gdt)
     flags |= gflag
     if gflag and need_grid:
-        raise RuntimeError("interpol: a SeparableGrid is a constant lattice, it has no gradient")
+        raise RuntimeError("interpol: a SeparableGrid / AffineGrid is a constant lattice, it has no gradient")
     gshape = list(grid_c.shape[1:-1])
     B = max(gvol_out.shape[0], grid_c.shape[0])
     C = gvol_out.shape[1]

@@ -25,7 +25,7 @@ import torch
 from . import backend, ops
 from .autograd import GridPull, GridPush, GridCount, GridGrad, SplineCoeff, SplineCoeffND
 from .codes import bound_to_code, order_to_code, pad_codes
-from .sepgrid import SeparableGrid
+from .sepgrid import SeparableGrid, AffineGrid, LazyGrid
 from .utils import expanded_shape
 
 __all__ = ['pull', 'push', 'count', 'grid_pull', 'grid_push', 'grid_count', 'grid_grad',
@@ -37,13 +37,15 @@ def _fold(grid, input=None, mode=None):
     (B, C, *spatial) / (B, *spatial, dim).  Same cases as the reference's
     `_preproc` (interpol/api.py:93-130)."""
     dim = grid.shape[-1]
+    if input is None and isinstance(grid, LazyGrid):     # constant lattice: no batch dims, nothing to reshape
+        return grid, dict(batch=[], channel=[], dim=dim)
     if input is None:
         spatial = grid.shape[-dim - 1:-1]
         batch = grid.shape[:-dim - 1]
         info = dict(batch=list(batch), channel=[1] if batch else [], dim=dim)
         return grid.reshape([-1, *spatial, dim]), info
 
-    sep = isinstance(grid, SeparableGrid)            # constant tensor-product lattice: no batch dims
+    sep = isinstance(grid, LazyGrid)            # constant tensor-product lattice: no batch dims
     grid_spatial = grid.shape[-dim - 1:-1]
     grid_batch = () if sep else grid.shape[:-dim - 1]
     input_spatial = input.shape[-dim:]

@@ -11,7 +11,7 @@ import torch
 from . import ops
 from .coeff import _spline_coeff, _spline_coeff_nd
 from .codes import bound_to_code, order_to_code
-from .sepgrid import SeparableGrid
+from .sepgrid import SeparableGrid, AffineGrid, LazyGrid
 
 try:                                    # torch >= 2.4
     from torch.amp import custom_fwd, custom_bwd
@@ -31,7 +31,7 @@ def _as_list(x):
 
 def _save(ctx, input, grid):
     """save_for_backward with a constant SeparableGrid kept as a plain attribute."""
-    if isinstance(grid, SeparableGrid):
+    if isinstance(grid, LazyGrid):
         ctx.sep = grid
         ctx.save_for_backward(input)
     else:
