@@ -7,9 +7,9 @@
 //     soft_l = mask * sum_{taps t with label_t == l} w_t sign_t
 // is evaluated for the labels of the stencil only, and the winner is the reference's: the largest
 // soft value if it is > 0 (pmax starts at 0), the SMALLEST such label on ties (unique() is
-// sorted ascending and the update is a strict `>`), else 0.  Covered: isotropic orders with
-// (K+1)^D <= 27 taps (nearest / linear in any dim, up to cubic in 1-D / 2-D, quadratic in 3-D);
-// the host keeps the reference's loop for anything else and for prefilter = True.
+// sorted ascending and the update is a strict `>`), else 0.  Covered: isotropic orders 0..3 in
+// 1 / 2 / 3 dims (up to the 64 taps of the 3-D cubic, pull_labels_wide_kernel); the host keeps the
+// reference's loop for anything else and for prefilter = True.
 // No FMA contraction in this translation unit: the winner of an arg-max can hinge on the last
 // bit of a weight (coordinates exactly half-way between voxels give exact ties in the reference),
 // so the weights are evaluated with the reference's roundings (separate multiply and add).
@@ -85,6 +85,84 @@ __global__ __launch_bounds__(256) void pull_labels_kernel(KParams p, const int *
     }
 }
 
+// The same arg-max for stencils of up to 64 taps (3-D cubic).  Comparing every tap's label with every
+// other's is 4096 compare-adds per voxel there; instead the DISTINCT labels under the stencil are
+// visited one by one (usually one to four of them): take the first tap not yet accounted for, sum the
+// weights of all taps that carry its label -- in tap order, adding exact zeros for the others, i.e. the
+// very sum the per-label pull forms -- and strike those taps off.  Weights are re-formed on the fly as
+// (wx wy) wz, the node-major product of the reference.
+template <typename G, typename R, int D, int K>
+__global__ __launch_bounds__(256) void pull_labels_wide_kernel(KParams p, const int *__restrict__ vol, const G *__restrict__ grid,
+                                                               int *__restrict__ val, int B)
+{
+    const int64_t o = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (o >= p.N) return;
+    constexpr int T0 = K + 1, T1 = D > 1 ? K + 1 : 1, T2 = D > 2 ? K + 1 : 1, NT = T0 * T1 * T2;
+    static_assert(NT <= 64, "one bit per tap");
+    for (int64_t b = blockIdx.y; b < B; b += gridDim.y) {
+        R x[D];
+        load_coords<R, G, D>(p, grid, b, o, x);
+        Stencil<R, D, K, true, NEED_W> s;
+        s.setup(p, x);
+        R wd[3][K + 1];
+#pragma unroll
+        for (int d = 0; d < 3; ++d)
+#pragma unroll
+            for (int j = 0; j <= K; ++j) wd[d][j] = s.w[d][j];
+        if constexpr (K == 3) {                                      // the reference's own operations (see above)
+#pragma unroll
+            for (int d = 0; d < D; ++d) {
+                const R fl = sizeof(R) == 4 ? (R)floorf((float)(x[d] - R(1))) : (R)floor((double)(x[d] - R(1)));
+                const R t = x[d] - fl;
+#pragma unroll
+                for (int j = 0; j <= K; ++j) {
+                    R a = t - R(j); a = a < R(0) ? -a : a;
+                    const R u = R(2) - a;
+                    const R we = a < R(1) ? (a * a * (a - R(2)) * R(3) + R(4)) / R(6) : (u * u * u) / R(6);
+                    wd[d][j] = s.w[d][j] == R(0) ? R(0) : (s.w[d][j] < R(0) ? -we : we);
+                }
+            }
+        }
+        R wxy[T0 * T1];
+#pragma unroll
+        for (int i = 0; i < T0; ++i)
+#pragma unroll
+            for (int j = 0; j < T1; ++j) wxy[i * T1 + j] = wd[0][i] * wd[1][j];
+        for (int c = 0; c < p.C; ++c) {
+            const char *v0 = reinterpret_cast<const char *>(vol + b * p.vol_sb + c * p.vol_sc);
+            int lab[NT];
+#pragma unroll
+            for (int i = 0; i < T0; ++i)
+#pragma unroll
+                for (int j = 0; j < T1; ++j)
+#pragma unroll
+                    for (int k = 0; k < T2; ++k)
+                        lab[(i * T1 + j) * T2 + k] = *reinterpret_cast<const int *>(v0 + (s.off[0][i] + s.off[1][j] + s.off[2][k]));
+            unsigned long long todo = NT == 64 ? ~0ull : ((1ull << (NT & 63)) - 1ull);
+            int best_l = 0x7fffffff;
+            R best_w = R(0);
+            while (todo) {
+                const int t = __ffsll((long long)todo) - 1;          // first tap not accounted for
+                int l = lab[0];
+#pragma unroll
+                for (int u = 1; u < NT; ++u) l = (t == u) ? lab[u] : l;
+                R sum = R(0);
+                unsigned lo_hit = 0u, hi_hit = 0u;
+#pragma unroll
+                for (int u = 0; u < NT; ++u) {
+                    const bool m = lab[u] == l;
+                    sum += m ? wxy[u / T2] * wd[2][u % T2] : R(0);   // tap order, as the per-label pull sums
+                    if (u < 32) lo_hit |= m ? (1u << u) : 0u; else hi_hit |= m ? (1u << (u - 32)) : 0u;
+                }
+                todo &= ~(((unsigned long long)hi_hit << 32) | lo_hit);
+                sum *= s.mask;
+                if (sum > best_w || (sum == best_w && l < best_l)) { best_w = sum; best_l = l; }
+            }
+            val[b * p.val_sb + c * p.val_sc + o] = best_w > R(0) ? best_l : 0;
+        }
+    }
+}
+
 template <typename G, typename R>
 int launch_g(const KParams &p, const void *vol, const void *grid, void *val, int B, hipStream_t st)
 {
@@ -94,6 +172,10 @@ int launch_g(const KParams &p, const void *vol, const void *grid, void *val, int
                                                                         p, (const int *)vol, (const G *)grid, (int *)val, B); goto done; }
     IP_L(1, 0) IP_L(1, 1) IP_L(1, 2) IP_L(1, 3) IP_L(2, 0) IP_L(2, 1) IP_L(2, 2) IP_L(2, 3) IP_L(3, 0) IP_L(3, 1) IP_L(3, 2)
 #undef IP_L
+    if (p.dim == 3 && K == 3) {
+        hipLaunchKernelGGL((pull_labels_wide_kernel<G, R, 3, 3>), sample_grid(p, B), dim3(256), 0, st, p, (const int *)vol, (const G *)grid, (int *)val, B);
+        goto done;
+    }
     return INTERPOL_E_ORDER;
 done:
     const hipError_t e = hipGetLastError();

@@ -514,9 +514,9 @@ def resample1d(src, lin, dim, order, bound, extrapolate, mode, adjoint=False, n_
 
 
 def labels_covered(dim, order):
-    """Does interpol_pull_labels take this stencil?  (all dims one order, (order+1)^dim <= 27)"""
+    """Does interpol_pull_labels take this stencil?  (all dims one order <= 3: up to the 64 taps of the 3-D cubic)"""
     order = list(order)[:dim]
-    return len(set(order)) == 1 and (order[0] + 1) ** dim <= 27
+    return len(set(order)) == 1 and order[0] <= 3
 
 
 def pull_labels(vol, grid, bound, order, extrapolate, flags=0):
