@@ -2288,10 +2288,17 @@ static bool linear_only(const interpol_problem *p, const KParams &k)
 // already cheaper than staging a tile (measured at config 5: 1.36 ms generic vs 2.19 ms tiled).
 // class-sorted tiles (ops_sorted.hip): 3-D, one order 2..3; declines everything else
 int IP_SYM(try_sorted_pull_, IP_TSFX)(const interpol_problem *p, const KParams &k, const void *vol, const void *grid, void *val, hipStream_t st);
+// lean 2-D tiles (ops_tiled2d.hip): per-dim orders 1..3
+int IP_SYM(try_tiled2d_pull_, IP_TSFX)(const interpol_problem *p, const KParams &k, const void *vol, const void *grid, void *val, hipStream_t st);
+int IP_SYM(try_tiled2d_push_, IP_TSFX)(const interpol_problem *p, const KParams &k, const void *val, const void *grid, void *vol, hipStream_t st);
 
 #if !defined(IP_TPART) || IP_TPART == 1
 int IP_SYM(try_fast_pull_, IP_TSFX)(const interpol_problem *p, const KParams &k, const void *vol, const void *grid, void *val, hipStream_t st)
 {
+    if (p->dim == 2) {
+        const int rc = IP_SYM(try_tiled2d_pull_, IP_TSFX)(p, k, vol, grid, val, st);
+        if (rc != 0) return rc;
+    }
     if (p->dim != 3 && !(p->flags & INTERPOL_FLAG_FORCE_TILED)) return 0;
     if (linear_only(p, k)) return 0;
     {
@@ -2317,7 +2324,7 @@ int IP_SYM(try_sorted_push_, IP_TSFX)(const interpol_problem *p, const KParams &
 int IP_SYM(try_fast_push_, IP_TSFX)(const interpol_problem *p, const KParams &k, const void *val, const void *grid, void *vol, hipStream_t st)
 {
     {
-        const int rc = IP_SYM(try_sorted_push_, IP_TSFX)(p, k, val, grid, vol, st);
+        const int rc = p->dim == 2 ? IP_SYM(try_tiled2d_push_, IP_TSFX)(p, k, val, grid, vol, st) : IP_SYM(try_sorted_push_, IP_TSFX)(p, k, val, grid, vol, st);
         if (rc != 0) return rc;
     }
     IP_BY_ORDER(tiled::launch_push, >(p, k, val, grid, vol, st))
