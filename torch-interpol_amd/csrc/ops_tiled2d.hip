@@ -6,17 +6,23 @@
 // A 2-D stencil has at most 16 taps: the work per sample is small, so what decides the speed is the
 // fixed cost per tile (the 3-D tile machinery of ops_tiled.hip loses to the generic kernel in 2-D for
 // that reason) and the width of the memory accesses.  Hence:
-//   * one workgroup of 256 threads per tile of 32 x 32 pixels, ~35 KiB of LDS: four workgroups per CU
-//     cover each other's global-memory waits; nothing is sorted, nothing is done in passes;
+//   * one workgroup of 256 threads per tile of 32 x 32 pixels, ~35 KiB of LDS, three (pull) or four (push)
+//     workgroups per CU; nothing is sorted, nothing is done in passes;
 //   * a thread owns FOUR NEIGHBOURING pixels of a row: coordinates, sources and results move as 16- / 32-
 //     byte accesses (narrow accesses are what the vector memory path is slow at), and so do the rows of
-//     the box when they are contiguous in memory;
+//     the box when they are contiguous in memory -- as stored, without conversion: the boundary sign
+//     (bounds.py:30-89) is a flip / clear of bits;
 //   * the bounding box of the tile's stencils (<= 64 x 64 lattice points; beyond: the sample gathers /
-//     scatters straight from / to global memory) is staged ONCE with the boundary condition applied
-//     (bounds.py:30-89); an 8-byte LDS slot holds ALL channels of a lattice point that fit -- four
-//     16-bit values or two floats -- so one ds_read_b64 per tap feeds them all;
+//     scatters straight from / to global memory, out of line) is staged ONCE; an 8-byte LDS slot holds
+//     ALL channels of a lattice point that fit -- four 16-bit values or two floats -- so one ds_read_b64
+//     per tap feeds them all (config 5: 3 channels, packed FMAs on two of them);
 //   * push / count accumulate pairs of channels in the LDS box in packed 32-bit fixed point (see
 //     ops_sorted.hip) and add the box to the float target with coalesced global atomics.
+// Measured at config 5 (32 x 3 x 1024^2 bf16, orders [2, 3], sigma = 2): the kernels are bound by the
+// number of instructions issued per tile (SQ_INSTS_VALU ~ 940 / wave for pull, VALU active ~ 50 % with
+// every phase -- set-up 0.13, coordinates 0.08, staging 0.13, taps 0.15, stores 0.09 ms -- adding up),
+// not by HBM or by latency: prefetching the next tile's coordinates in persistent workgroups changed
+// nothing.  push: LDS atomics 0.65 ms + flush (global atomics) 0.3 ms of 1.05 ms.
 // ===========================================================================
 #include "sorted_util.hpp"
 
@@ -61,15 +67,63 @@ __device__ __forceinline__ void weights1d(float t, float *w)
     for (int j = 0; j <= 3; ++j) w[j] = j <= K ? bspline_w<float>(K, t - (float)j) : 0.f;
 }
 
+// the K + 1 weights of a stencil coordinate t (closed forms of splines.py:30-44 on the interval `split` produces)
+template <int K>
+__device__ __forceinline__ void wts(float t, float *w)
+{
+    if (K == 1) { w[0] = 1.f - t; w[1] = t; w[2] = 0.f; w[3] = 0.f; }
+    else if (K == 2) {
+        // t in [0.5, 1.5): taps at distances t, |t - 1|, 2 - t
+        const float a = 1.5f - t, c = t - 0.5f, m = t - 1.f;
+        w[0] = (a * a) * 0.5f; w[1] = __builtin_fmaf(-m, m, 0.75f); w[2] = (c * c) * 0.5f; w[3] = 0.f;
+    } else {
+        // t in [1, 2): u = t - 1, v = 1 - u; taps at distances 1 + u, u, v, 1 + v
+        const float u = t - 1.f, v = 2.f - t, u2 = u * u, v2 = v * v;
+        w[0] = (v2 * v) * (1.f / 6.f); w[3] = (u2 * u) * (1.f / 6.f);
+        w[1] = __builtin_fmaf(u2, __builtin_fmaf(u, 0.5f, -1.f), 2.f / 3.f);
+        w[2] = __builtin_fmaf(v2, __builtin_fmaf(v, 0.5f, -1.f), 2.f / 3.f);
+    }
+}
+
+// `split` of tile_common.hpp with the order known and a one-instruction clamp
+template <int K>
+__device__ __forceinline__ void splitk(float x, int &i0, float &t)
+{
+    const float fl = floorf(x - 0.5f * (float)(K - 1));
+    t = x - fl;
+    i0 = (int)__builtin_amdgcn_fmed3f(fl, -1073741824.f, 1073741824.f);
+}
+
 // channels per 8-byte slot, pack / unpack
 template <typename T> struct Slot;
 template <> struct Slot<float> {
     static constexpr int NC = 2;
+    static constexpr unsigned SIGN = 0x80000000u;
+    typedef unsigned RawQ __attribute__((ext_vector_type(4)));                 // four consecutive values of one channel, as stored
+    static __device__ __forceinline__ RawQ ldq(const float *p) { typedef unsigned u4u __attribute__((ext_vector_type(4), aligned(4))); return *reinterpret_cast<const u4u *>(p); }
+    // the four slots of a quad from the raw quads of the channels: word 0 of slot k = channel 0, word 1 = channel 1
+    static __device__ __forceinline__ void slots(const RawQ *a, unsigned (&w)[4][2])
+    {
+        w[0][0] = a[0].x; w[1][0] = a[0].y; w[2][0] = a[0].z; w[3][0] = a[0].w;
+        w[0][1] = a[1].x; w[1][1] = a[1].y; w[2][1] = a[1].z; w[3][1] = a[1].w;
+    }
     static __device__ __forceinline__ unsigned long long pack(const float *v) { return ((unsigned long long)__float_as_uint(v[1]) << 32) | __float_as_uint(v[0]); }
     static __device__ __forceinline__ void unpack(unsigned long long s, float *v) { v[0] = __uint_as_float((unsigned)s); v[1] = __uint_as_float((unsigned)(s >> 32)); }
+    static __device__ __forceinline__ void unpack2(unsigned long long s, f2 &a, f2 &b) { a = f2{ __uint_as_float((unsigned)s), __uint_as_float((unsigned)(s >> 32)) }; b = f2{ 0.f, 0.f }; }
 };
 template <> struct Slot<bf16_t> {
     static constexpr int NC = 4;
+    static constexpr unsigned SIGN = 0x80008000u;
+    typedef unsigned RawQ __attribute__((ext_vector_type(2)));
+    static __device__ __forceinline__ RawQ ldq(const bf16_t *p) { typedef unsigned u2u __attribute__((ext_vector_type(2), aligned(2))); return *reinterpret_cast<const u2u *>(p); }
+    // word 0 of slot k = channels 0 | 1 << 16, word 1 = channels 2 | 3 << 16
+    static __device__ __forceinline__ void slots(const RawQ *a, unsigned (&w)[4][2])
+    {
+        w[0][0] = __builtin_amdgcn_perm(a[1].x, a[0].x, 0x05040100u); w[1][0] = __builtin_amdgcn_perm(a[1].x, a[0].x, 0x07060302u);
+        w[2][0] = __builtin_amdgcn_perm(a[1].y, a[0].y, 0x05040100u); w[3][0] = __builtin_amdgcn_perm(a[1].y, a[0].y, 0x07060302u);
+        w[0][1] = __builtin_amdgcn_perm(a[3].x, a[2].x, 0x05040100u); w[1][1] = __builtin_amdgcn_perm(a[3].x, a[2].x, 0x07060302u);
+        w[2][1] = __builtin_amdgcn_perm(a[3].y, a[2].y, 0x05040100u); w[3][1] = __builtin_amdgcn_perm(a[3].y, a[2].y, 0x07060302u);
+    }
     static __device__ __forceinline__ unsigned long long pack(const float *v)
     {
         unsigned long long s = 0;
@@ -83,9 +137,26 @@ template <> struct Slot<bf16_t> {
         v[0] = __uint_as_float(lo << 16); v[1] = __uint_as_float(lo & 0xffff0000u);
         v[2] = __uint_as_float(hi << 16); v[3] = __uint_as_float(hi & 0xffff0000u);
     }
+    static __device__ __forceinline__ void unpack2(unsigned long long s, f2 &a, f2 &b)
+    {
+        const unsigned lo = (unsigned)s, hi = (unsigned)(s >> 32);
+        a = f2{ __uint_as_float(lo << 16), __uint_as_float(lo & 0xffff0000u) };
+        b = f2{ __uint_as_float(hi << 16), __uint_as_float(hi & 0xffff0000u) };
+    }
 };
 template <> struct Slot<f16_t> {
     static constexpr int NC = 4;
+    static constexpr unsigned SIGN = 0x80008000u;
+    typedef unsigned RawQ __attribute__((ext_vector_type(2)));
+    static __device__ __forceinline__ RawQ ldq(const f16_t *p) { typedef unsigned u2u __attribute__((ext_vector_type(2), aligned(2))); return *reinterpret_cast<const u2u *>(p); }
+    // word 0 of slot k = channels 0 | 1 << 16, word 1 = channels 2 | 3 << 16
+    static __device__ __forceinline__ void slots(const RawQ *a, unsigned (&w)[4][2])
+    {
+        w[0][0] = __builtin_amdgcn_perm(a[1].x, a[0].x, 0x05040100u); w[1][0] = __builtin_amdgcn_perm(a[1].x, a[0].x, 0x07060302u);
+        w[2][0] = __builtin_amdgcn_perm(a[1].y, a[0].y, 0x05040100u); w[3][0] = __builtin_amdgcn_perm(a[1].y, a[0].y, 0x07060302u);
+        w[0][1] = __builtin_amdgcn_perm(a[3].x, a[2].x, 0x05040100u); w[1][1] = __builtin_amdgcn_perm(a[3].x, a[2].x, 0x07060302u);
+        w[2][1] = __builtin_amdgcn_perm(a[3].y, a[2].y, 0x05040100u); w[3][1] = __builtin_amdgcn_perm(a[3].y, a[2].y, 0x07060302u);
+    }
     static __device__ __forceinline__ unsigned long long pack(const float *v)
     {
         unsigned long long s = 0;
@@ -98,6 +169,7 @@ template <> struct Slot<f16_t> {
 #pragma unroll
         for (int c = 0; c < 4; ++c) { const unsigned short u = (unsigned short)(s >> (16 * c)); f16_t h; __builtin_memcpy(&h, &u, 2); v[c] = (float)h; }
     }
+    static __device__ __forceinline__ void unpack2(unsigned long long s, f2 &a, f2 &b) { float v[4]; unpack(s, v); a = f2{ v[0], v[1] }; b = f2{ v[2], v[3] }; }
 };
 
 // pixel v of thread tid: row tid >> 3, column 4 (tid & 7) + v
@@ -108,33 +180,46 @@ template <int K0, int K1, int GM>
 struct Tile2 {
     int lo[2], S[2];
     float t0[VPT], t1[VPT];
-    int   y0[VPT], z0[VPT];          // first taps relative to the box (valid when the `in` bit is set)
+    int   cell[VPT];                 // first tap's slot in the box (slot 0 unless the `in` bit is set)
     unsigned valid, in, inb;
 
-    __device__ __forceinline__ void build(const KParams &p, const Lattice &L, const float *__restrict__ grid, int64_t b,
-                                          int gy, int gz, int oy0, int oz0, Smem &sm, float (&c)[VPT][2])
+    // the coordinates of the thread's four pixels (issued, not waited for: `build` consumes them)
+    static __device__ __forceinline__ void load(const KParams &p, const float *__restrict__ grid, int64_t b,
+                                                int gy, int gz, int oy0, int oz0, float (&c)[VPT][2])
     {
-        const int tid = threadIdx.x;
-        if (tid < 2) { sm.lo[tid] = 0x7fffffff; sm.hi[tid] = -0x7fffffff; }
-        valid = 0; inb = 0;
+        const int tid = opaque((int)threadIdx.x);
         if (GM == 0 && oy0 + TY <= gy && oz0 + TZ <= gz) {
             // whole tile: the thread's four pixels are 32 contiguous bytes of the grid
             typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
             int oy, oz;
             px_pos(tid, 0, oy0, oz0, oy, oz);
             const f4u *gp = reinterpret_cast<const f4u *>(grid + b * p.grid_sb + ((int64_t)oy * gz + oz) * 2);
-            const f4u a = gp[0], e = gp[1];
+            f4u a, e;
+            if (p.dbg & 8) { a = f4u{ (float)oy, (float)oz, (float)oy, (float)oz + 1.f }; e = f4u{ (float)oy, (float)oz + 2.f, (float)oy, (float)oz + 3.f }; }
+            else { a = gp[0]; e = gp[1]; }
             c[0][0] = a.x; c[0][1] = a.y; c[1][0] = a.z; c[1][1] = a.w; c[2][0] = e.x; c[2][1] = e.y; c[3][0] = e.z; c[3][1] = e.w;
-            valid = 0xf;
         } else {
 #pragma unroll
             for (int v = 0; v < VPT; ++v) {
                 int oy, oz;
                 px_pos(tid, v, oy0, oz0, oy, oz);
-                if (oy < gy && oz < gz) valid |= 1u << v;
                 oy = oy < gy ? oy : gy - 1; oz = oz < gz ? oz : gz - 1;
                 load_yz<GM>(p, grid, b, gy, gz, oy, oz, c[v]);
             }
+        }
+    }
+
+    __device__ __forceinline__ void build(const KParams &p, const Lattice &L, const float (&c)[VPT][2],
+                                          int gy, int gz, int oy0, int oz0, Smem &sm)
+    {
+        const int tid = opaque((int)threadIdx.x);
+        if (tid < 2) { sm.lo[tid] = 0x7fffffff; sm.hi[tid] = -0x7fffffff; }
+        valid = 0; inb = 0;
+#pragma unroll
+        for (int v = 0; v < VPT; ++v) {
+            int oy, oz;
+            px_pos(tid, v, oy0, oz0, oy, oz);
+            if (oy < gy && oz < gz) valid |= 1u << v;
         }
         __syncthreads();
         int i0[VPT][2];
@@ -143,8 +228,8 @@ struct Tile2 {
         for (int v = 0; v < VPT; ++v) {
             if (p.extrapolate == 1 || (c[v][0] > (float)p.mask_lo && c[v][0] < (float)p.mask_hi[0] && c[v][1] > (float)p.mask_lo && c[v][1] < (float)p.mask_hi[1]))
                 inb |= 1u << v;
-            split(K0, c[v][0], i0[v][0], t0[v]);
-            split(K1, c[v][1], i0[v][1], t1[v]);
+            splitk<K0>(c[v][0], i0[v][0], t0[v]);
+            splitk<K1>(c[v][1], i0[v][1], t1[v]);
             if ((valid >> v) & 1) {
 #pragma unroll
                 for (int d = 0; d < 2; ++d) { mn[d] = i0[v][d] < mn[d] ? i0[v][d] : mn[d]; mx[d] = i0[v][d] > mx[d] ? i0[v][d] : mx[d]; }
@@ -161,6 +246,7 @@ struct Tile2 {
         for (int d = 0; d < 2; ++d) {
             int l = sm.lo[d], h = sm.hi[d] + kd[d];
             if (h < l) { l = 0; h = 0; }
+            if (d == 1) l &= ~3;                       // rows of the box start on a quad of the lattice: aligned wide accesses
             int sz_ = h - l + 1;
             if (sz_ > CAP) { l += (sz_ - CAP) / 2; sz_ = CAP; }
             lo[d] = l; S[d] = sz_;
@@ -168,17 +254,24 @@ struct Tile2 {
         if (tid < 2 * CAP) {
             const int d = tid >> 6, slot = tid & 63;
             if (slot < (d ? S[1] : S[0])) {
-                const long long pk = wrap_outofline(L.bound[1 + d], (d ? lo[1] : lo[0]) + slot, L.n[1 + d]);
-                sm.taboff[d][slot] = (int)(pk & 0xffffffffll) * L.ss[1 + d];
-                sm.tabsgn[d][slot] = (float)(int)(pk >> 32);
+                const int l = d ? lo[1] : lo[0], sz_ = d ? S[1] : S[0];
+                if (l >= (L.bound[1 + d] == B_DST1 ? 1 : 0) && l + sz_ <= L.n[1 + d]) {
+                    // the box is inside the lattice along this dim: no wrapping (and no integer division)
+                    sm.taboff[d][slot] = (l + slot) * L.ss[1 + d];
+                    sm.tabsgn[d][slot] = 1.f;
+                } else {
+                    const long long pk = wrap_outofline(L.bound[1 + d], l + slot, L.n[1 + d]);
+                    sm.taboff[d][slot] = (int)(pk & 0xffffffffll) * L.ss[1 + d];
+                    sm.tabsgn[d][slot] = (float)(int)(pk >> 32);
+                }
             }
         }
-        in = 0;
+        in = 0; inb &= valid;
 #pragma unroll
         for (int v = 0; v < VPT; ++v) {
-            y0[v] = i0[v][0] - lo[0]; z0[v] = i0[v][1] - lo[1];
-            if (((valid >> v) & 1) && y0[v] >= 0 && y0[v] + K0 < S[0] && z0[v] >= 0 && z0[v] + K1 < S[1]) in |= 1u << v;
-            else { y0[v] = 0; z0[v] = 0; }
+            const int y0 = i0[v][0] - lo[0], z0 = i0[v][1] - lo[1];
+            cell[v] = 0;
+            if (((valid >> v) & 1) && y0 >= 0 && y0 + K0 < S[0] && z0 >= 0 && z0 + K1 < S[1]) { in |= 1u << v; cell[v] = y0 * PZ + z0; }
         }
         __syncthreads();
     }
@@ -203,55 +296,62 @@ __global__ __launch_bounds__(NT, 3) void pull2d(KParams p, const T *__restrict__
 {
     __shared__ Smem sm;
     constexpr int NC = Slot<T>::NC;
+    const Lattice L = lattice2d(p, (int)sizeof(T), K0, K1);
     const int tid = threadIdx.x;
     const int64_t b = blockIdx.x / ntiles;
     const int tile = blockIdx.x % ntiles;
     const int oy0 = (tile / ntz) * TY, oz0 = (tile % ntz) * TZ;
-    const Lattice L = lattice2d(p, (int)sizeof(T), K0, K1);
     Tile2<K0, K1, GM> tl;
-    float c[VPT][2];
-    tl.build(p, L, grid, b, gy, gz, oy0, oz0, sm, c);
+    prof_mark(-1);
+    {
+        float c[VPT][2];
+        Tile2<K0, K1, GM>::load(p, grid, b, gy, gz, oy0, oz0, c);
+        tl.build(p, L, c, gy, gz, oy0, oz0, sm);
+    }
+    prof_mark(0);
     // the box's columns are contiguous runs of the unit-stride dim, sign +1 (dst1: sign 0 at index 0, quirk B-3)
     const bool zlin = L.ss[2] == 1 && tl.S[1] >= 4 && tl.lo[1] >= (L.bound[2] == B_DST1 ? 1 : 0) && tl.lo[1] + tl.S[1] <= L.n[2];
     for (int cg = 0; cg < p.C; cg += NC) {
+        // (opaque copies: nothing below is to be hoisted out of this loop and kept -- spilled -- across it)
+        const int tid = opaque((int)threadIdx.x);
         const int nc = p.C - cg < NC ? p.C - cg : NC;
         const T *vb = vol + b * p.vol_sb + cg * p.vol_sc;
         // stage the box: slot (y, z) = the nc channels of the wrapped lattice point, sign applied
+        if (p.dbg & 1) { } else
         if (zlin) {
             // rows are contiguous runs of the lattice: quads of 4 slots, one wide load per channel; all the
             // loads of the tile are in flight together
-            const int nq = (tl.S[1] + 3) >> 2;                        // the last quad is shifted to END at S_z
-            constexpr int QPR = CAP / 4, NU = (CAP * QPR + NT - 1) / NT;
-            float4 a[NU][NC]; float sg[NU];
+            // (values travel as stored: the boundary sign is a flip / clear of bits, no conversion; channels
+            //  the image does not have repeat channel 0 and are never stored)
+            {
+                const int nq = (tl.S[1] + 3) >> 2;                    // the last quad is shifted to END at S_z
+                constexpr int QPR = CAP / 4, NU = (CAP * QPR + NT - 1) / NT;
+                typename Slot<T>::RawQ a[NU][NC]; float sg[NU];
 #pragma unroll
-            for (int u = 0; u < NU; ++u) {
-                const int e = tid + NT * u, y = e / QPR, qd = e - y * QPR;
-                const bool on = y < tl.S[0] && qd < nq;
-                const int zs = 4 * qd + 4 <= tl.S[1] ? 4 * qd : tl.S[1] - 4;
-                const int off = on ? sm.taboff[0][y] + tl.lo[1] + zs : 0;
-                sg[u] = on ? sm.tabsgn[0][y] : 0.f;
+                for (int u = 0; u < NU; ++u) {
+                    const int e = tid + NT * u, y = e / QPR, qd = e - y * QPR;
+                    const bool on = y < tl.S[0] && qd < nq;
+                    const int zs = 4 * qd + 4 <= tl.S[1] ? 4 * qd : tl.S[1] - 4;
+                    const unsigned off = on ? (unsigned)(sm.taboff[0][y] + tl.lo[1] + zs) : 0u;
+                    sg[u] = on ? sm.tabsgn[0][y] : 0.f;
 #pragma unroll
-                for (int ch = 0; ch < NC; ++ch) a[u][ch] = ld4<T>(vb + (ch < nc ? ch : 0) * p.vol_sc + off);
-            }
-#pragma unroll
-            for (int u = 0; u < NU; ++u) {
-                const int e = tid + NT * u, y = e / QPR, qd = e - y * QPR;
-                if (!(y < tl.S[0] && qd < nq)) continue;
-                const int zs = 4 * qd + 4 <= tl.S[1] ? 4 * qd : tl.S[1] - 4;
-                unsigned long long s4[4];
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    float v[4];
-#pragma unroll
-                    for (int ch = 0; ch < NC; ++ch) {
-                        const float x = k == 0 ? a[u][ch].x : (k == 1 ? a[u][ch].y : (k == 2 ? a[u][ch].z : a[u][ch].w));
-                        v[ch] = ch < nc ? x * sg[u] : 0.f;
-                    }
-                    s4[k] = Slot<T>::pack(v);
+                    for (int ch = 0; ch < NC; ++ch) a[u][ch] = Slot<T>::ldq(vb + (ch < nc ? ch : 0) * p.vol_sc + off);
                 }
-                unsigned long long *dst = sm.box + y * PZ + zs;
-                if (!(zs & 1)) { reinterpret_cast<ulonglong2 *>(dst)[0] = ulonglong2{ s4[0], s4[1] }; reinterpret_cast<ulonglong2 *>(dst)[1] = ulonglong2{ s4[2], s4[3] }; }
-                else { dst[0] = s4[0]; dst[1] = s4[1]; dst[2] = s4[2]; dst[3] = s4[3]; }
+#pragma unroll
+                for (int u = 0; u < NU; ++u) {
+                    const int e = tid + NT * u, y = e / QPR, qd = e - y * QPR;
+                    if (!(y < tl.S[0] && qd < nq)) continue;
+                    const int zs = 4 * qd + 4 <= tl.S[1] ? 4 * qd : tl.S[1] - 4;
+                    unsigned w[4][2];
+                    Slot<T>::slots(a[u], w);
+                    unsigned long long s4[4];
+                    const unsigned flip = sg[u] < 0.f ? Slot<T>::SIGN : 0u, m = sg[u] != 0.f ? 0xffffffffu : 0u;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) s4[k] = ((unsigned long long)((w[k][1] ^ flip) & m) << 32) | ((w[k][0] ^ flip) & m);
+                    unsigned long long *d = sm.box + y * PZ + zs;
+                    if (!(zs & 1)) { reinterpret_cast<ulonglong2 *>(d)[0] = ulonglong2{ s4[0], s4[1] }; reinterpret_cast<ulonglong2 *>(d)[1] = ulonglong2{ s4[2], s4[3] }; }
+                    else { d[0] = s4[0]; d[1] = s4[1]; d[2] = s4[2]; d[3] = s4[3]; }
+                }
             }
         } else {
             // general case (the box wraps, or strided columns): slot by slot through the tables, U at a time
@@ -280,47 +380,53 @@ __global__ __launch_bounds__(NT, 3) void pull2d(KParams p, const T *__restrict__
             }
         }
         __syncthreads();
+        prof_mark(1);
         float res[VPT][4];
+        // NCU = channels of the slot that are computed (the slot of a 16-bit type holds 4, config 5 has 3)
+        auto taps = [&](auto ncu_) {
+            constexpr int NCU = decltype(ncu_)::value;
 #pragma unroll
-        for (int v = 0; v < VPT; ++v) {
-#pragma unroll
-            for (int ch = 0; ch < 4; ++ch) res[v][ch] = 0.f;
-            if (!((tl.valid >> v) & 1)) continue;
-            float acc[4] = { 0.f, 0.f, 0.f, 0.f };
-            if ((tl.in >> v) & 1) {
+            for (int v = 0; v < VPT; ++v) {
+                // (samples whose stencil is not in the box read slot 0 and are redone below: no branch here)
                 float w0[4], w1[4];
-                if (L.lin) { w0[0] = 1.f - tl.t0[v]; w0[1] = tl.t0[v]; w1[0] = 1.f - tl.t1[v]; w1[1] = tl.t1[v]; w0[2] = w0[3] = w1[2] = w1[3] = 0.f; }
-                else { weights1d<K0>(tl.t0[v], w0); weights1d<K1>(tl.t1[v], w1); }
+                float t0 = tl.t0[v], t1 = tl.t1[v];
+                asm volatile("" : "+v"(t0), "+v"(t1));
+                if (L.lin) { w0[0] = 1.f - t0; w0[1] = t0; w1[0] = 1.f - t1; w1[1] = t1; w0[2] = w0[3] = w1[2] = w1[3] = 0.f; }
+                else { wts<K0>(t0, w0); wts<K1>(t1, w1); }
                 // (volatile LDS pointer: keeps single ds_read_b64 -- a merged ds_read2_b64 costs 3x more per byte on gfx950)
                 const volatile __attribute__((address_space(3))) unsigned long long *bp =
-                    (const volatile __attribute__((address_space(3))) unsigned long long *)(sm.box) + tl.y0[v] * PZ + tl.z0[v];
+                    (const volatile __attribute__((address_space(3))) unsigned long long *)(sm.box) + opaque(tl.cell[v]);
+                f2 acc01 = { 0.f, 0.f }, acc23 = { 0.f, 0.f };
 #pragma unroll
                 for (int i = 0; i <= K0; ++i) {
-                    float r[4] = { 0.f, 0.f, 0.f, 0.f };
+                    f2 r01 = { 0.f, 0.f }, r23 = { 0.f, 0.f };
 #pragma unroll
                     for (int j = 0; j <= K1; ++j) {
-                        float u[4] = { 0.f, 0.f, 0.f, 0.f };
-                        Slot<T>::unpack(bp[i * PZ + j], u);
-#pragma unroll
-                        for (int ch = 0; ch < NC; ++ch) r[ch] = __builtin_fmaf(w1[j], u[ch], r[ch]);
+                        f2 u01, u23;
+                        Slot<T>::unpack2(bp[i * PZ + j], u01, u23);
+                        const f2 w = { w1[j], w1[j] };
+                        r01 = __builtin_elementwise_fma(w, u01, r01);
+                        if (NCU == 3) r23.x = __builtin_fmaf(w1[j], u23.x, r23.x);
+                        if (NCU == 4) r23 = __builtin_elementwise_fma(w, u23, r23);
                     }
-#pragma unroll
-                    for (int ch = 0; ch < NC; ++ch) acc[ch] = __builtin_fmaf(w0[i], r[ch], acc[ch]);
+                    const f2 w = { w0[i], w0[i] };
+                    acc01 = __builtin_elementwise_fma(w, r01, acc01);
+                    if (NCU == 3) acc23.x = __builtin_fmaf(w0[i], r23.x, acc23.x);
+                    if (NCU == 4) acc23 = __builtin_elementwise_fma(w, r23, acc23);
                 }
-            } else {
-                // stencil outside the (clamped) box: gather from global memory
-                int iy, iz; float ty, tz;
-                split(K0, c[v][0], iy, ty); split(K1, c[v][1], iz, tz);
-                for (int ch = 0; ch < nc; ++ch) acc[ch] = tiled::gather_one_thread<T>(L, vb + ch * p.vol_sc, 0, iy, iz, 0.f, ty, tz, -1);
+                const float m = (float)((tl.inb >> v) & 1);
+                res[v][0] = acc01.x * m; res[v][1] = acc01.y * m; res[v][2] = acc23.x * m; res[v][3] = acc23.y * m;
+                __builtin_amdgcn_sched_barrier(0);          // one pixel's reads in flight at a time: 48 hoisted reads would not fit the registers
             }
-            const float m = (float)((tl.inb >> v) & 1);
-#pragma unroll
-            for (int ch = 0; ch < NC; ++ch) res[v][ch] = acc[ch] * m;
-        }
+        };
+        if (p.dbg & 2) { for (int v = 0; v < VPT; ++v) for (int ch = 0; ch < 4; ++ch) res[v][ch] = tl.t0[v]; } else
+        if (NC == 4 && nc == 3) taps(std::integral_constant<int, 3>{}); else taps(std::integral_constant<int, NC>{});
+        prof_mark(2);
         {
             int oy, oz;
             px_pos(tid, 0, oy0, oz0, oy, oz);
             T *ob = val + b * p.val_sb + cg * p.val_sc + (int64_t)oy * gz + oz;
+            if (p.dbg & 4) { if (res[0][0] == 123.f) ob[0] = Cvt<float, T>::st(res[1][1] + res[2][2] + res[3][0] + res[0][1] + res[1][2]); } else
             if (tl.valid == 0xf) {
 #pragma unroll
                 for (int ch = 0; ch < NC; ++ch) if (ch < nc) st4<T>(ob + ch * p.val_sc, make_float4(res[0][ch], res[1][ch], res[2][ch], res[3][ch]));
@@ -331,8 +437,23 @@ __global__ __launch_bounds__(NT, 3) void pull2d(KParams p, const T *__restrict__
 #pragma unroll
                         for (int ch = 0; ch < NC; ++ch) if (ch < nc) ob[ch * p.val_sc + v] = Cvt<float, T>::st(res[v][ch]);
             }
+            // stencils outside the (clamped) box: gathered from global memory, one by one (the coordinates are read
+            // again: nothing of this rare path stays live across the hot one)
+            if (tl.in != tl.valid) {
+#pragma unroll 1
+                for (int v = 0; v < VPT; ++v) {
+                    if (!(((tl.valid & ~tl.in) >> v) & 1)) continue;
+                    float x[2]; int iy, iz; float ty, tz;
+                    load_yz<GM>(p, grid, b, gy, gz, oy, oz + v, x);
+                    split(K0, x[0], iy, ty); split(K1, x[1], iz, tz);
+                    const float m = (float)((tl.inb >> v) & 1);
+                    for (int ch = 0; ch < nc; ++ch)
+                        ob[ch * p.val_sc + v] = Cvt<float, T>::st(m * tiled::gather_one_thread<T>(L, vb + ch * p.vol_sc, 0, iy, iz, 0.f, ty, tz, -1));
+                }
+            }
         }
         __syncthreads();
+        prof_mark(3);
     }
 }
 
@@ -340,7 +461,7 @@ __global__ __launch_bounds__(NT, 3) void pull2d(KParams p, const T *__restrict__
 // push / count: MODE 0 values, 1 count, 2 values + count (one more target channel)
 // ---------------------------------------------------------------------------
 template <typename T, int K0, int K1, int GM, int MODE>
-__global__ __launch_bounds__(NT, 3) void push2d(KParams p, const T *__restrict__ val, const float *__restrict__ grid, float *__restrict__ vol,
+__global__ __launch_bounds__(NT, 4) void push2d(KParams p, const T *__restrict__ val, const float *__restrict__ grid, float *__restrict__ vol,
                                              int gy, int gz, int ntz, int ntiles)
 {
     __shared__ Smem sm;
@@ -350,74 +471,75 @@ __global__ __launch_bounds__(NT, 3) void push2d(KParams p, const T *__restrict__
     const int oy0 = (tile / ntz) * TY, oz0 = (tile % ntz) * TZ;
     const Lattice L = lattice2d(p, 4, K0, K1);
     Tile2<K0, K1, GM> tl;
-    float c[VPT][2];
     for (int e = tid; e < BOXSLOTS; e += NT) sm.box[e] = 0ull;
     if (tid == 0) sm.dmax = 0;
     if (tid < 2) sm.cmax[tid] = 0;
-    tl.build(p, L, grid, b, gy, gz, oy0, oz0, sm, c);
+    const int nch = MODE == 1 ? 1 : p.C + (MODE == 2 ? 1 : 0);
+    int oy, oz;
+    px_pos(tid, 0, oy0, oz0, oy, oz);
+    const bool whole = oy0 + TY <= gy && oz0 + TZ <= gz;                  // whole tile: sources move as quads
+    const T *sp = val + b * p.val_sb + (int64_t)(oy < gy ? oy : gy - 1) * gz + (whole ? oz : 0);
+    // sources of a channel (ones for the count channel): issued early, they travel with the coordinates
+    auto sources = [&](int ch) -> float4 {
+        if (MODE == 1 || ch >= p.C) return make_float4(1.f, 1.f, 1.f, 1.f);
+        const T *q = sp + ch * p.val_sc;
+        if (whole) return ld4<T>(q);
+        float r[4];
+#pragma unroll
+        for (int v = 0; v < VPT; ++v) r[v] = Cvt<float, T>::ld(q[oz + v < gz ? oz + v : gz - 1]);
+        return make_float4(r[0], r[1], r[2], r[3]);
+    };
+    float4 sv0 = sources(0), sv1 = sources(1 < nch ? 1 : 0);
+    prof_mark(-1);
+    {
+        float c[VPT][2];
+        Tile2<K0, K1, GM>::load(p, grid, b, gy, gz, oy0, oz0, c);
+        tl.build(p, L, c, gy, gz, oy0, oz0, sm);
+    }
+    prof_mark(4);
     // density: samples per first-tap cell (16-bit counters in the box, cleared again)
     {
         unsigned *cnt32 = reinterpret_cast<unsigned *>(sm.box);
-        int cell[VPT];
 #pragma unroll
-        for (int v = 0; v < VPT; ++v) {
-            cell[v] = tl.y0[v] * PZ + tl.z0[v];
-            if ((tl.in >> v) & 1) atomicAdd(&cnt32[cell[v] >> 1], 1u << (16 * (cell[v] & 1)));
-        }
+        for (int v = 0; v < VPT; ++v)
+            if ((tl.in >> v) & 1) atomicAdd(&cnt32[tl.cell[v] >> 1], 1u << (16 * (tl.cell[v] & 1)));
         __syncthreads();
         int m = 0;
 #pragma unroll
         for (int v = 0; v < VPT; ++v) {
-            const int cv = (int)((cnt32[cell[v] >> 1] >> (16 * (cell[v] & 1))) & 0xffffu);
+            const int cv = (int)((cnt32[tl.cell[v] >> 1] >> (16 * (tl.cell[v] & 1))) & 0xffffu);
             m = ((tl.in >> v) & 1) && cv > m ? cv : m;
         }
         m = wave_max(m);
         if ((tid & 63) == 0 && m > 0) atomicMax(&sm.dmax, m);
         __syncthreads();
 #pragma unroll
-        for (int v = 0; v < VPT; ++v) if ((tl.in >> v) & 1) cnt32[cell[v] >> 1] = 0u;
+        for (int v = 0; v < VPT; ++v) if ((tl.in >> v) & 1) cnt32[tl.cell[v] >> 1] = 0u;
     }
-    const int nch = MODE == 1 ? 1 : p.C + (MODE == 2 ? 1 : 0);
+    prof_mark(5);
     for (int cg = 0; cg < nch; cg += 2) {
         const bool two = cg + 1 < nch;
-        const bool ones0 = MODE == 1 || (MODE == 2 && cg >= p.C), ones1 = MODE == 1 || (MODE == 2 && cg + 1 >= p.C);
         float *vc0 = vol + b * p.vol_sb + cg * p.vol_sc;
         float *vc1 = two ? vc0 + p.vol_sc : vc0;
         f2 src[VPT];
         float am0 = 0.f, am1 = 0.f;
-        float4 sv0 = make_float4(1.f, 1.f, 1.f, 1.f), sv1 = sv0;
-        if (tl.valid == 0xf) {
-            int oy, oz;
-            px_pos(tid, 0, oy0, oz0, oy, oz);
-            const int64_t o = (int64_t)oy * gz + oz;
-            if (!ones0) sv0 = ld4<T>(val + b * p.val_sb + cg * p.val_sc + o);
-            if (two && !ones1) sv1 = ld4<T>(val + b * p.val_sb + (cg + 1) * p.val_sc + o);
-        }
 #pragma unroll
         for (int v = 0; v < VPT; ++v) {
-            int oy, oz;
-            px_pos(tid, v, oy0, oz0, oy, oz);
-            oy = oy < gy ? oy : gy - 1; oz = oz < gz ? oz : gz - 1;
-            const int64_t o = (int64_t)oy * gz + oz;
-            const float m = ((tl.valid >> v) & 1) ? (float)((tl.inb >> v) & 1) : 0.f;
-            float r0 = v == 0 ? sv0.x : (v == 1 ? sv0.y : (v == 2 ? sv0.z : sv0.w)), r1 = v == 0 ? sv1.x : (v == 1 ? sv1.y : (v == 2 ? sv1.z : sv1.w));
-            if (tl.valid != 0xf) {
-                r0 = ones0 ? 1.f : Cvt<float, T>::ld(val[b * p.val_sb + cg * p.val_sc + o]);
-                r1 = (!two || ones1) ? 1.f : Cvt<float, T>::ld(val[b * p.val_sb + (cg + 1) * p.val_sc + o]);
-            }
-            const float s0 = r0 * m;
-            const float s1 = !two ? 0.f : r1 * m;
-            src[v] = f2{ ((tl.valid >> v) & 1) ? s0 : 0.f, ((tl.valid >> v) & 1) ? s1 : 0.f };
+            const float m = (float)((tl.inb >> v) & 1);
+            const float r0 = v == 0 ? sv0.x : (v == 1 ? sv0.y : (v == 2 ? sv0.z : sv0.w)), r1 = v == 0 ? sv1.x : (v == 1 ? sv1.y : (v == 2 ? sv1.z : sv1.w));
+            src[v] = f2{ r0 * m, two ? r1 * m : 0.f };
             if ((tl.in >> v) & 1) {
                 const float a0 = __builtin_fabsf(src[v].x), a1 = __builtin_fabsf(src[v].y);
                 am0 = (a0 > am0 || a0 != a0) ? a0 : am0; am1 = (a1 > am1 || a1 != a1) ? a1 : am1;
             }
         }
+        if (cg + 2 < nch) { sv0 = sources(cg + 2); sv1 = sources(cg + 3 < nch ? cg + 3 : cg + 2); }   // next pair: in flight during the taps
         {
             const int m0 = wave_max(__float_as_int(am0)), m1 = wave_max(__float_as_int(am1));
             if ((tid & 63) == 0) { if (m0) atomicMax(&sm.cmax[0], m0); if (m1) atomicMax(&sm.cmax[1], m1); }
         }
         __syncthreads();
+        prof_mark(6);
         const int hb = tiled::headroom32(L, sm.dmax);
         const int mb0 = sm.cmax[0], mb1 = sm.cmax[1];
         const bool fixedpt = hb >= 0 && (mb0 & 0x7f800000) != 0x7f800000 && (mb1 & 0x7f800000) != 0x7f800000;
@@ -426,14 +548,16 @@ __global__ __launch_bounds__(NT, 3) void push2d(KParams p, const T *__restrict__
         const int hbc = hb < 0 ? 0 : hb;
         const f2 scale = { mb0 ? __int_as_float((127 + 29 - ex0 - hbc) << 23) : 0.f, mb1 ? __int_as_float((127 + 29 - ex1 - hbc) << 23) : 0.f };
         const float inv0 = __int_as_float((127 - 29 + ex0 + hbc) << 23), inv1 = __int_as_float((127 - 29 + ex1 + hbc) << 23);
+        if (fixedpt && !(p.dbg & 1)) {
 #pragma unroll
-        for (int v = 0; v < VPT; ++v) {
-            if (!((tl.valid >> v) & 1)) continue;
-            float w0[4], w1[4];
-            if (L.lin) { w0[0] = 1.f - tl.t0[v]; w0[1] = tl.t0[v]; w1[0] = 1.f - tl.t1[v]; w1[1] = tl.t1[v]; w0[2] = w0[3] = w1[2] = w1[3] = 0.f; }
-            else { weights1d<K0>(tl.t0[v], w0); weights1d<K1>(tl.t1[v], w1); }
-            if (fixedpt && ((tl.in >> v) & 1)) {
-                unsigned long long *bp = sm.box + tl.y0[v] * PZ + tl.z0[v];
+            for (int v = 0; v < VPT; ++v) {
+                if (!((tl.in >> v) & 1)) continue;
+                float w0[4], w1[4];
+                float t0 = tl.t0[v], t1 = tl.t1[v];
+                asm volatile("" : "+v"(t0), "+v"(t1));          // (not to be hoisted out of the channel loop)
+                if (L.lin) { w0[0] = 1.f - t0; w0[1] = t0; w1[0] = 1.f - t1; w1[1] = t1; w0[2] = w0[3] = w1[2] = w1[3] = 0.f; }
+                else { wts<K0>(t0, w0); wts<K1>(t1, w1); }
+                unsigned long long *bp = sm.box + opaque(tl.cell[v]);
                 const f2 ss = src[v] * scale;
 #pragma unroll
                 for (int i = 0; i <= K0; ++i) {
@@ -445,16 +569,29 @@ __global__ __launch_bounds__(NT, 3) void push2d(KParams p, const T *__restrict__
                         atomicAdd(bp + i * PZ + j, ((unsigned long long)(unsigned)(q1 + (q0 >> 31)) << 32) | (unsigned)q0);
                     }
                 }
-            } else {
-                // outside the box, or no fixed point for this tile: float atomics straight to the target
-                int iy, iz; float ty, tz;
-                split(K0, c[v][0], iy, ty); split(K1, c[v][1], iz, tz);
-                tiled::scatter_one_thread(L, vc0, src[v].x, 0, iy, iz, 0.f, ty, tz);
-                if (two) tiled::scatter_one_thread(L, vc1, src[v].y, 0, iy, iz, 0.f, ty, tz);
+            }
+        }
+        // stencils outside the (clamped) box, or no fixed point for this tile: float atomics straight to the target,
+        // one sample at a time (coordinates and sources are read again: nothing of this rare path stays live above)
+        if (!fixedpt || tl.in != tl.valid) {
+#pragma unroll 1
+            for (int v = 0; v < VPT; ++v) {
+                if (!((tl.valid >> v) & 1) || (fixedpt && ((tl.in >> v) & 1))) continue;
+                float x[2]; int iy, iz; float ty, tz;
+                load_yz<GM>(p, grid, b, gy, gz, oy, oz + v, x);
+                split(K0, x[0], iy, ty); split(K1, x[1], iz, tz);
+                const float m = (float)((tl.inb >> v) & 1);
+                const float s0 = (MODE == 1 || cg >= p.C) ? m : m * Cvt<float, T>::ld(val[b * p.val_sb + cg * p.val_sc + (int64_t)oy * gz + oz + v]);
+                tiled::scatter_one_thread(L, vc0, s0, 0, iy, iz, 0.f, ty, tz);
+                if (two) {
+                    const float s1 = (MODE == 1 || cg + 1 >= p.C) ? m : m * Cvt<float, T>::ld(val[b * p.val_sb + (cg + 1) * p.val_sc + (int64_t)oy * gz + oz + v]);
+                    tiled::scatter_one_thread(L, vc1, s1, 0, iy, iz, 0.f, ty, tz);
+                }
             }
         }
         __syncthreads();
-        if (fixedpt) {
+        prof_mark(7);
+        if (fixedpt && !(p.dbg & 2)) {
             const int nslot = tl.S[0] * 64;
             for (int e = tid; e < nslot; e += NT) {
                 const int y = e >> 6, z = e & 63;
@@ -471,6 +608,7 @@ __global__ __launch_bounds__(NT, 3) void push2d(KParams p, const T *__restrict__
             }
         }
         __syncthreads();
+        prof_mark(8);
         if (tid < 2) sm.cmax[tid] = 0;
     }
 }
@@ -539,5 +677,17 @@ int IP_SYM(try_tiled2d_push_, IP_TSFX)(const interpol_problem *p, const KParams 
     const hipError_t e = hipGetLastError();
     return e == hipSuccess ? 1 : (int)e;
 }
+
+#ifdef IP_PROF
+#define IP_PROF_NAME3(s) interpol_debug_prof_t2d_##s
+#define IP_PROF_NAME2(s) IP_PROF_NAME3(s)
+extern "C" __attribute__((visibility("default"))) int IP_PROF_NAME2(IP_TSFX)(unsigned long long *out, int reset)
+{
+    unsigned long long z[16] = { 0 };
+    if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(ip::sorted::g_prof), sizeof z) != hipSuccess) return -1;
+    if (reset && hipMemcpyToSymbol(HIP_SYMBOL(ip::sorted::g_prof), z, sizeof z) != hipSuccess) return -1;
+    return 0;
+}
+#endif
 
 } // namespace ip

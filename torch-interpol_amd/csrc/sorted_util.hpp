@@ -120,6 +120,15 @@ __device__ __forceinline__ void st4(T *p, float4 v)
         *reinterpret_cast<f4u *>(p) = f4u{ v.x, v.y, v.z, v.w };
     } else {
         typedef unsigned short h4u __attribute__((ext_vector_type(4), aligned(2)));
+        if constexpr (std::is_same<T, bf16_t>::value) {
+            typedef __bf16 b4 __attribute__((ext_vector_type(4)));
+            typedef float f4 __attribute__((ext_vector_type(4)));
+            const b4 h = __builtin_convertvector((f4{ v.x, v.y, v.z, v.w }), b4);
+            h4u w;
+            __builtin_memcpy(&w, &h, 8);
+            *reinterpret_cast<h4u *>(p) = w;
+            return;
+        }
         const T e[4] = { Cvt<float, T>::st(v.x), Cvt<float, T>::st(v.y), Cvt<float, T>::st(v.z), Cvt<float, T>::st(v.w) };
         h4u w;
         __builtin_memcpy(&w, e, 8);

@@ -25,8 +25,13 @@ template <> struct Cvt<float, f16_t>   { static IP_HD float ld(f16_t v) { return
 template <> struct Cvt<float, bf16_t> {
     static IP_HD float ld(bf16_t v) { return __uint_as_float(((unsigned)v.u) << 16); }
     static IP_HD bf16_t st(float f) {            // round to nearest even, NaN kept quiet
-        unsigned x = __float_as_uint(f);
         bf16_t r;
+#if defined(__HIP_DEVICE_COMPILE__)
+        const __bf16 h = (__bf16)f;              // v_cvt_pk_bf16_f32 on gfx950
+        __builtin_memcpy(&r.u, &h, 2);
+        return r;
+#endif
+        unsigned x = __float_as_uint(f);
         if ((x & 0x7fffffffu) > 0x7f800000u) { r.u = (unsigned short)((x >> 16) | 0x40); return r; }
         x += 0x7fffu + ((x >> 16) & 1u);
         r.u = (unsigned short)(x >> 16);
