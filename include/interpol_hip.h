@@ -240,6 +240,11 @@ int interpol_resample_1d(int32_t dtype, int32_t lin_dtype, int32_t order, int32_
  * --------------------------------------------------------------------------- */
 int interpol_spline_filter(void *data, int32_t dtype, int64_t outer, int64_t n, int64_t inner,
                            int32_t bound, int32_t order, void *stream);
+/* The same filter reading `src` and writing `data` (same layout, no overlap unless src == data): the
+ * first filtered dimension of an out-of-place spline_coeff_nd (coeff.py:317-347) then costs one read
+ * and one write instead of a copy followed by an in-place pass. */
+int interpol_spline_filter_to(const void *src, void *data, int32_t dtype, int64_t outer, int64_t n, int64_t inner,
+                              int32_t bound, int32_t order, void *stream);
 
 /* --- host-side helpers (no GPU needed) ------------------------------------------
  * The exact scalar primitives the kernels use, compiled for the host so they

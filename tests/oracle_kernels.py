@@ -75,8 +75,8 @@ class OracleKernels:
         return oracle.grid_count_backward(grad.detach(), _g(grid, displacement), bound, order, extrapolate)
 
     @staticmethod
-    def spline_filter_(data, bound, order, dim):
-        data.copy_(oracle.spline_coeff(data.detach(), bound, order, dim=dim))
+    def spline_filter_(data, bound, order, dim, src=None):
+        data.copy_(oracle.spline_coeff((data if src is None else src).detach(), bound, order, dim=dim))
         return data
 
     @staticmethod

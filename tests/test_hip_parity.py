@@ -473,6 +473,26 @@ def test_prefilter_kernels_against_oracle(dtype, tol, inner):
                 assert err < tol, (n, inner, order, bound, err)
 
 
+def test_prefilter_out_of_place_reads_source_writes_result():
+    """spline_coeff / spline_coeff_nd out of place (interpol_spline_filter_to): the source is left untouched and the
+    result is bit-identical to the in-place call, through the fused kernels and the copy-first fallbacks."""
+    g = torch.Generator().manual_seed(77)
+    for shape, dim in (([6, 256, 1], 1), ([2, 512, 40], 1), ([3, 100, 7], 1), ([2, 3, 256, 256], 2), ([2, 65, 33], 2)):
+        for dtype in (torch.float32, torch.bfloat16, torch.float64):
+            x = torch.randn(shape, generator=g).to(dtype).to(DEV)
+            keep = x.clone()
+            for order in (0, 2, 3, 5):
+                if len(shape) == 3 and dim == 1:
+                    out = interpol.spline_coeff(x, interpolation=order, bound="dct2", dim=1)
+                    ref = interpol.spline_coeff(x.clone(), interpolation=order, bound="dct2", dim=1, inplace=True)
+                else:
+                    out = interpol.spline_coeff_nd(x, interpolation=[order, 3], bound=["dct1", "dft"], dim=dim)
+                    ref = interpol.spline_coeff_nd(x.clone(), interpolation=[order, 3], bound=["dct1", "dft"], dim=dim, inplace=True)
+                assert torch.equal(x, keep), (shape, dtype, order)
+                assert out.data_ptr() != x.data_ptr()
+                assert torch.equal(out, ref), (shape, dtype, order)
+
+
 @pytest.mark.parametrize("order", [1, 2, 3, 5, 7])
 @pytest.mark.parametrize("sigma", [0.0, 2.0, 9.0])
 def test_tiled_pull_channel_pairs_match_generic(order, sigma):

@@ -33,7 +33,7 @@ IP_DECL(f32) IP_DECL(f64) IP_DECL(bf16) IP_DECL(f16)
 IP_DECL2(f32) IP_DECL2(f64)
 #undef IP_DECL2
 
-int launch_filter(int dtype, const FilterParams &fp, void *data, hipStream_t st);
+int launch_filter(int dtype, const FilterParams &fp, const void *src, void *data, hipStream_t st);
 int64_t bricks_workspace_bytes(const KParams &p, int B, int shared);
 int launch_push_bricks(const KParams &p, int B, int shared, const void *val, const void *grid, void *vol,
                        void *workspace, int64_t workspace_bytes, hipStream_t st);
@@ -583,14 +583,26 @@ int interpol_count_backward(const interpol_problem *p, const void *grad_vol_out,
 int interpol_spline_filter(void *data, int32_t dtype, int64_t outer, int64_t n, int64_t inner,
                            int32_t bound, int32_t order, void *stream)
 {
-    if (!data) return INTERPOL_E_NULL;
+    return interpol_spline_filter_to(data, data, dtype, outer, n, inner, bound, order, stream);
+}
+
+int interpol_spline_filter_to(const void *src, void *data, int32_t dtype, int64_t outer, int64_t n, int64_t inner,
+                              int32_t bound, int32_t order, void *stream)
+{
+    if (!data || !src) return INTERPOL_E_NULL;
     if (dtype < 0 || dtype > 3) return INTERPOL_E_DTYPE;
     if (order < 0 || order > 7) return INTERPOL_E_ORDER;
     if (bound < 0 || bound > 6) return INTERPOL_E_BOUND;
     if (outer < 0 || n < 0 || inner < 0) return INTERPOL_E_SHAPE;
-    if (order < 2) return 0;                                  // coeff.py:306-307
-    if (bound == 4 || bound == 5) return INTERPOL_E_PREFILTER;   // coeff.py:243-244
-    if (n <= 1 || outer == 0 || inner == 0) return 0;         // coeff.py:264-265
+    if (order >= 2 && (bound == 4 || bound == 5)) return INTERPOL_E_PREFILTER;   // coeff.py:243-244
+    if (order < 2 || n <= 1 || outer == 0 || inner == 0) {    // coeff.py:306-307, 264-265: the identity
+        if (src != data && outer * n * inner > 0) {
+            const size_t esz = dtype == 0 ? 4 : (dtype == 1 ? 8 : 2);
+            const hipError_t e = hipMemcpyAsync(data, src, esz * (size_t)(outer * n * inner), hipMemcpyDeviceToDevice, (hipStream_t)stream);
+            return e == hipSuccess ? 0 : (int)e;
+        }
+        return 0;
+    }
     FilterParams fp;
     fp.outer = outer; fp.n = n; fp.inner = inner;
     fp.bound = (bound == 0 || bound == 2) ? 0 : ((bound == 1 || bound == 3) ? 1 : 2);   // coeff.py:237-242
@@ -616,7 +628,7 @@ int interpol_spline_filter(void *data, int32_t dtype, int64_t outer, int64_t n, 
     fp.gain = 1.;
     for (int i = 0; i < fp.npoles; ++i) fp.gain *= (1. - fp.pole[i]) * (1. - 1. / fp.pole[i]);   // coeff.py:69-73
     make_pole_pre(fp);
-    return launch_filter(dtype, fp, data, (hipStream_t)stream);
+    return launch_filter(dtype, fp, src, data, (hipStream_t)stream);
 }
 
 int interpol_resample_1d(int32_t dtype, int32_t lin_dtype, int32_t order, int32_t bound, int32_t extrapolate, int32_t mode,

@@ -404,7 +404,7 @@ __device__ __forceinline__ void line_filter_full(R (&c)[RPL], const FilterParams
 }
 
 template <typename T, typename R, int RPL>
-__global__ __launch_bounds__(256) void prefilter_wave_full(FilterParams fp, T *data)
+__global__ __launch_bounds__(256) void prefilter_wave_full(FilterParams fp, const T *src, T *data)
 {
     static_assert(sizeof(R) == 4, "float math only");
     const int lane = threadIdx.x & 63;
@@ -412,26 +412,65 @@ __global__ __launch_bounds__(256) void prefilter_wave_full(FilterParams fp, T *d
     if (line >= fp.outer) return;
     constexpr int n = 64 * RPL;
     T *base = data + line * n;
+    const T *from = src + line * n;                 // == base for the in-place call
     R c[RPL];
-    __shared__ float tr[4 * 64 * (RPL + 1)];
-    float *trw = tr + (threadIdx.x >> 6) * 64 * (RPL + 1);
+    constexpr int BYTES = RPL * (int)sizeof(T);
+    if constexpr (BYTES > 32) {
+        // long lane runs: element-wise coalesced accesses, transposed through LDS (a lane reading 64 contiguous
+        // bytes of its own touches a cache line per lane and instruction: measured 0.157 -> 0.185 ms at 1024 fp32)
+        __shared__ float tr[4 * 64 * (RPL + 1)];
+        float *trw = tr + (threadIdx.x >> 6) * 64 * (RPL + 1);
 #pragma unroll
-    for (int r = 0; r < RPL; ++r) {
-        const int i = r * 64 + lane;
-        trw[i + i / RPL] = Cvt<R, T>::ld(base[i]) * (R)fp.gain;                     // coeff.py:268
+        for (int r = 0; r < RPL; ++r) {
+            const int i = r * 64 + lane;
+            trw[i + i / RPL] = Cvt<R, T>::ld(from[i]) * (R)fp.gain;                     // coeff.py:268
+        }
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int r = 0; r < RPL; ++r) c[r] = trw[lane * (RPL + 1) + r];
+        line_filter_full<R, RPL>(c, fp, lane);
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int r = 0; r < RPL; ++r) trw[lane * (RPL + 1) + r] = c[r];
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int r = 0; r < RPL; ++r) {
+            const int i = r * 64 + lane;
+            base[i] = Cvt<R, T>::st(trw[i + i / RPL]);
+        }
+        return;
     }
-    __builtin_amdgcn_wave_barrier();
+    // lane l owns the RPL consecutive samples l * RPL ...: up to 32 bytes, they move as 8- / 16-byte pieces of
+    // the lane's own contiguous run (wide per-lane accesses, no transposition through LDS: 0.133 -> 0.10 ms at
+    // 1024 bf16)
+    constexpr int PIECE = BYTES % 16 == 0 ? 16 : 8, NP = BYTES / PIECE, EPP = PIECE / (int)sizeof(T);
+    static_assert(BYTES % PIECE == 0, "lane run");
+    typedef unsigned piece_t __attribute__((ext_vector_type(PIECE / 4), aligned(sizeof(T) < 4 ? sizeof(T) : 4)));
+    {
+        const piece_t *fp_ = reinterpret_cast<const piece_t *>(from + lane * RPL);
+        piece_t raw[NP];
 #pragma unroll
-    for (int r = 0; r < RPL; ++r) c[r] = trw[lane * (RPL + 1) + r];
+        for (int q = 0; q < NP; ++q) raw[q] = fp_[q];
+#pragma unroll
+        for (int q = 0; q < NP; ++q) {
+            T e[EPP];
+            __builtin_memcpy(e, &raw[q], PIECE);
+#pragma unroll
+            for (int k = 0; k < EPP; ++k) c[q * EPP + k] = Cvt<R, T>::ld(e[k]) * (R)fp.gain;          // coeff.py:268
+        }
+    }
     line_filter_full<R, RPL>(c, fp, lane);
-    __builtin_amdgcn_wave_barrier();
+    {
+        piece_t *tp = reinterpret_cast<piece_t *>(base + lane * RPL);
 #pragma unroll
-    for (int r = 0; r < RPL; ++r) trw[lane * (RPL + 1) + r] = c[r];
-    __builtin_amdgcn_wave_barrier();
+        for (int q = 0; q < NP; ++q) {
+            T e[EPP];
 #pragma unroll
-    for (int r = 0; r < RPL; ++r) {
-        const int i = r * 64 + lane;
-        base[i] = Cvt<R, T>::st(trw[i + i / RPL]);
+            for (int k = 0; k < EPP; ++k) e[k] = Cvt<R, T>::st(c[q * EPP + k]);
+            piece_t raw;
+            __builtin_memcpy(&raw, e, PIECE);
+            tp[q] = raw;
+        }
     }
 }
 
@@ -443,50 +482,76 @@ __global__ __launch_bounds__(256) void prefilter_wave_full(FilterParams fp, T *d
 // all poles, instead of a latency-bound thread per line making two passes per pole.
 // LDS: TL rows of 64 * (RPL + 1) + 1 floats (odd pitch: the transposing accesses hit all banks).
 // ===========================================================================
-template <typename T, typename R, int RPL, int TL>
-__global__ __launch_bounds__(1024) void prefilter_tile(FilterParams fp, T *data, int tiles_per_outer)
+// LDS element: the storage type for 16-bit data (exact on the way in, and the rounding the store would apply
+// anyway on the way out), float otherwise: twice the lines per tile.
+template <typename T, typename R, int RPL, int TL, int NT>
+__global__ __launch_bounds__(NT) void prefilter_tile(FilterParams fp, const T *src, T *data, int tiles_per_outer)
 {
     static_assert(sizeof(R) == 4, "float math only");
-    extern __shared__ float tile[];
+    typedef typename std::conditional<sizeof(T) == 2, T, float>::type S;
+    extern __shared__ float tile_raw[];
+    S *tile = reinterpret_cast<S *>(tile_raw);
     constexpr int n = 64 * RPL, ROW = 64 * (RPL + 1) + 1;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int64_t a = blockIdx.x / tiles_per_outer;
     const int64_t l0 = (int64_t)(blockIdx.x % tiles_per_outer) * TL;
     T *base = data + a * n * fp.inner + l0;
+    const T *from = src + a * n * fp.inner + l0;    // == base for the in-place call
     const int nl = fp.inner - l0 < TL ? (int)(fp.inner - l0) : TL;          // lines of this tile
-    for (int idx = tid; idx < n * TL; idx += 1024) {
-        const int i = idx / TL, l = idx % TL;
-        if (l < nl) tile[l * ROW + i + i / RPL] = Cvt<R, T>::ld(base[(int64_t)i * fp.inner + l]) * (R)fp.gain;   // coeff.py:268
+    // (U loads in flight per thread before the first LDS write: a rolled load -> write loop pays one
+    //  memory round trip per element -- 0.35 -> 0.20 ms at 32x3x1024^2)
+    constexpr int IT = n * TL / NT, U = IT < 16 ? IT : 16;
+    static_assert(n * TL % NT == 0 && IT % U == 0, "tile geometry");
+#pragma unroll 1
+    for (int k0 = 0; k0 < IT; k0 += U) {
+        T v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int idx = tid + NT * (k0 + u), i = idx / TL, l = idx % TL;
+            v[u] = from[(int64_t)i * fp.inner + (l < nl ? l : 0)];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int idx = tid + NT * (k0 + u), i = idx / TL, l = idx % TL;
+            if (l < nl) {
+                if constexpr (sizeof(T) == 2) tile[l * ROW + i + i / RPL] = v[u];
+                else tile[l * ROW + i + i / RPL] = Cvt<R, T>::ld(v[u]);
+            }
+        }
     }
     __syncthreads();
-    for (int l = wave; l < nl; l += 16) {
-        float *row = tile + l * ROW;
+    for (int l = wave; l < nl; l += NT / 64) {
+        S *row = tile + l * ROW;
         R c[RPL];
 #pragma unroll
-        for (int r = 0; r < RPL; ++r) c[r] = row[lane * (RPL + 1) + r];
+        for (int r = 0; r < RPL; ++r) c[r] = Cvt<R, S>::ld(row[lane * (RPL + 1) + r]) * (R)fp.gain;   // coeff.py:268
         line_filter_full<R, RPL>(c, fp, lane);
 #pragma unroll
-        for (int r = 0; r < RPL; ++r) row[lane * (RPL + 1) + r] = c[r];
+        for (int r = 0; r < RPL; ++r) row[lane * (RPL + 1) + r] = Cvt<R, S>::st(c[r]);
     }
     __syncthreads();
-    for (int idx = tid; idx < n * TL; idx += 1024) {
+#pragma unroll 4
+    for (int idx = tid; idx < n * TL; idx += NT) {
         const int i = idx / TL, l = idx % TL;
-        if (l < nl) base[(int64_t)i * fp.inner + l] = Cvt<R, T>::st(tile[l * ROW + i + i / RPL]);
+        if (l < nl) {
+            if constexpr (sizeof(T) == 2) base[(int64_t)i * fp.inner + l] = tile[l * ROW + i + i / RPL];
+            else base[(int64_t)i * fp.inner + l] = Cvt<R, T>::st(tile[l * ROW + i + i / RPL]);
+        }
     }
 }
 
-template <typename T, typename R, int RPL, int TL>
-static int launch_tile(const FilterParams &fp, void *data, hipStream_t st)
+template <typename T, typename R, int RPL, int TL, int NT>
+static int launch_tile(const FilterParams &fp, const void *src, void *data, hipStream_t st)
 {
-    const size_t lds = sizeof(float) * (size_t)TL * (64 * (RPL + 1) + 1);
+    const size_t lds = (sizeof(T) == 2 ? 2 : 4) * (size_t)TL * (64 * (RPL + 1) + 1);
     static bool done = false;
     if (!done && lds > 64 * 1024) {
-        const hipError_t e = hipFuncSetAttribute((const void *)prefilter_tile<T, R, RPL, TL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        const hipError_t e = hipFuncSetAttribute((const void *)prefilter_tile<T, R, RPL, TL, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
         done = true;
     }
     const int tiles = (int)((fp.inner + TL - 1) / TL);
-    hipLaunchKernelGGL((prefilter_tile<T, R, RPL, TL>), dim3((unsigned)(fp.outer * tiles)), dim3(1024), lds, st, fp, (T *)data, tiles);
+    hipLaunchKernelGGL((prefilter_tile<T, R, RPL, TL, NT>), dim3((unsigned)(fp.outer * tiles)), dim3(NT), lds, st, fp, (const T *)src, (T *)data, tiles);
     const hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : (int)e;
 }
@@ -534,7 +599,7 @@ static void launch_wave(const FilterParams &fp, void *data, hipStream_t st)
 }
 
 template <typename T, typename R>
-static int launch_filter_t(const FilterParams &fp, void *data, hipStream_t st)
+static int launch_filter_t(const FilterParams &fp, const void *src, void *data, hipStream_t st)
 {
     const int64_t lines = fp.outer * fp.inner;
     bool lead = sizeof(R) == 4 && fp.bound != 2;          // short leading initial sum (InitW kinds 0 and 2)
@@ -542,10 +607,10 @@ static int launch_filter_t(const FilterParams &fp, void *data, hipStream_t st)
     if constexpr (sizeof(R) == 4) {
         if (fp.inner == 1 && lead && (fp.n == 64 * 4 || fp.n == 64 * 8 || fp.n == 64 * 16 || fp.n == 64 * 32)) {
             const dim3 g((unsigned)((fp.outer + 3) / 4));
-            if (fp.n == 64 * 4) hipLaunchKernelGGL((prefilter_wave_full<T, R, 4>), g, dim3(256), 0, st, fp, (T *)data);
-            else if (fp.n == 64 * 8) hipLaunchKernelGGL((prefilter_wave_full<T, R, 8>), g, dim3(256), 0, st, fp, (T *)data);
-            else if (fp.n == 64 * 16) hipLaunchKernelGGL((prefilter_wave_full<T, R, 16>), g, dim3(256), 0, st, fp, (T *)data);
-            else hipLaunchKernelGGL((prefilter_wave_full<T, R, 32>), g, dim3(256), 0, st, fp, (T *)data);
+            if (fp.n == 64 * 4) hipLaunchKernelGGL((prefilter_wave_full<T, R, 4>), g, dim3(256), 0, st, fp, (const T *)src, (T *)data);
+            else if (fp.n == 64 * 8) hipLaunchKernelGGL((prefilter_wave_full<T, R, 8>), g, dim3(256), 0, st, fp, (const T *)src, (T *)data);
+            else if (fp.n == 64 * 16) hipLaunchKernelGGL((prefilter_wave_full<T, R, 16>), g, dim3(256), 0, st, fp, (const T *)src, (T *)data);
+            else hipLaunchKernelGGL((prefilter_wave_full<T, R, 32>), g, dim3(256), 0, st, fp, (const T *)src, (T *)data);
             const hipError_t e0 = hipGetLastError();
             return e0 == hipSuccess ? 0 : (int)e0;
         }
@@ -553,13 +618,19 @@ static int launch_filter_t(const FilterParams &fp, void *data, hipStream_t st)
     if constexpr (sizeof(R) == 4) {
         // interleaved lines: LDS tiles of TL lines (one pass over the data for all poles)
         if (fp.inner >= 16 && lead && fp.outer * ((fp.inner + 15) / 16) < 0x7fffffff) {
-            // (wide tiles: TL * sizeof(T) contiguous bytes per point matter more than a second resident
-            //  workgroup -- measured 0.35 vs 0.43 ms with half-size tiles at 32x3x1024^2 fp32)
-            if (fp.n == 64 * 4) return launch_tile<T, R, 4, 64>(fp, data, st);
-            if (fp.n == 64 * 8) return launch_tile<T, R, 8, 64>(fp, data, st);
-            if (fp.n == 64 * 16) return launch_tile<T, R, 16, 32>(fp, data, st);
-            if (fp.n == 64 * 32) return launch_tile<T, R, 32, 16>(fp, data, st);
+            // (wide tiles: TL * sizeof(T) contiguous bytes per point matter more than a second resident workgroup --
+            //  measured at 32x3x1024^2: fp32 0.22 ms with TL = 32 / 1024 threads vs 0.27 with TL = 16 / 512 threads x 2)
+            constexpr int W = sizeof(T) == 2 ? 2 : 1;               // 16-bit data: LDS holds the storage type, twice the lines
+            if (fp.n == 64 * 4) return launch_tile<T, R, 4, 64 * W, 1024>(fp, src, data, st);
+            if (fp.n == 64 * 8) return launch_tile<T, R, 8, 64 * W, 1024>(fp, src, data, st);
+            if (fp.n == 64 * 16) return launch_tile<T, R, 16, 32 * W, 1024>(fp, src, data, st);
+            if (fp.n == 64 * 32) return launch_tile<T, R, 32, 16 * W, 1024>(fp, src, data, st);
         }
+    }
+    if (src != data) {
+        // the remaining kernels filter in place: copy first
+        const hipError_t ec = hipMemcpyAsync(data, src, sizeof(T) * (size_t)(fp.outer * fp.n * fp.inner), hipMemcpyDeviceToDevice, st);
+        if (ec != hipSuccess) return (int)ec;
     }
     if (fp.inner == 1 && fp.n <= 64 * 32 && fp.n >= 2) {
         if (fp.n <= 64 * 2) launch_wave<T, R, 2>(fp, data, st);
@@ -576,13 +647,13 @@ static int launch_filter_t(const FilterParams &fp, void *data, hipStream_t st)
     return e == hipSuccess ? 0 : (int)e;
 }
 
-int launch_filter(int dtype, const FilterParams &fp, void *data, hipStream_t st)
+int launch_filter(int dtype, const FilterParams &fp, const void *src, void *data, hipStream_t st)
 {
     switch (dtype) {
-    case 0: return launch_filter_t<float, float>(fp, data, st);
-    case 1: return launch_filter_t<double, double>(fp, data, st);
-    case 2: return launch_filter_t<bf16_t, float>(fp, data, st);
-    case 3: return launch_filter_t<f16_t, float>(fp, data, st);
+    case 0: return launch_filter_t<float, float>(fp, src, data, st);
+    case 1: return launch_filter_t<double, double>(fp, src, data, st);
+    case 2: return launch_filter_t<bf16_t, float>(fp, src, data, st);
+    case 3: return launch_filter_t<f16_t, float>(fp, src, data, st);
     default: return -4;
     }
 }

@@ -33,7 +33,7 @@ _DTYPE_CODE = {torch.float32: F32, torch.float64: F64, torch.bfloat16: BF16, tor
 SYMBOLS = (
     "interpol_pull", "interpol_push", "interpol_count", "interpol_grad", "interpol_pushgrad",
     "interpol_hess", "interpol_pull_backward", "interpol_push_backward", "interpol_count_backward",
-    "interpol_spline_filter", "interpol_resample_1d", "interpol_pull_labels",
+    "interpol_spline_filter", "interpol_spline_filter_to", "interpol_resample_1d", "interpol_pull_labels",
     "interpol_push_bricks", "interpol_push_bricks_workspace", "interpol_host_bound_index", "interpol_host_bound_sign",
     "interpol_host_weight", "interpol_host_weight_f32", "interpol_abi_version",
     "interpol_error_string", "interpol_kernel_name", "interpol_scatter_workspace",
@@ -91,6 +91,7 @@ def lib():
     L.interpol_push_backward.argtypes = [pp, vp, vp, vp, vp, vp, vp]
     L.interpol_count_backward.argtypes = [pp, vp, vp, vp, vp]
     L.interpol_spline_filter.argtypes = [vp, i32, i64, i64, i64, i32, i32, vp]
+    L.interpol_spline_filter_to.argtypes = [vp, vp, i32, i64, i64, i64, i32, i32, vp]
     L.interpol_pull_labels.argtypes = [pp, vp, vp, vp, vp]
     L.interpol_push_bricks.argtypes = [pp, vp, vp, vp, vp, i64, vp]
     L.interpol_push_bricks.restype = ctypes.c_int
@@ -101,7 +102,7 @@ def lib():
     L.interpol_resample_1d.argtypes = [i32, i32, i32, i32, i32, i32, i32, i64, i64, i64, i64, vp, vp, vp, vp]
     for name in ("interpol_pull", "interpol_grad", "interpol_hess", "interpol_push", "interpol_pushgrad",
                  "interpol_count", "interpol_pull_backward", "interpol_push_backward",
-                 "interpol_count_backward", "interpol_spline_filter", "interpol_resample_1d", "interpol_pull_labels"):
+                 "interpol_count_backward", "interpol_spline_filter", "interpol_spline_filter_to", "interpol_resample_1d", "interpol_pull_labels"):
         getattr(L, name).restype = ctypes.c_int
     L.interpol_host_bound_index.argtypes = [i32, i32, i32]
     L.interpol_host_bound_index.restype = i32
@@ -453,12 +454,16 @@ def push_backward(gvol_out, val, grid, bound, order, extrapolate, need_val, need
     return gval, ggrid
 
 
-def spline_filter_(data, bound, order, dim):
-    """In-place prefilter of `data` (contiguous) along dimension `dim`."""
-    dev = _require_gpu(data)
+def spline_filter_(data, bound, order, dim, src=None):
+    """Prefilter of `data` (contiguous) along dimension `dim`: in place, or -- `src` given, same shape
+    and dtype, contiguous, not overlapping -- reading `src` and writing `data`."""
+    dev = _require_gpu(data) if src is None else _require_gpu(data, src)
     if data.dtype not in _DTYPE_CODE:
         raise TypeError("spline_coeff: unsupported dtype %s" % data.dtype)
-    assert data.is_contiguous()
+    if not data.is_contiguous():
+        raise ValueError("spline_filter_: `data` must be contiguous")
+    if src is not None and (src.shape != data.shape or src.dtype != data.dtype or not src.is_contiguous()):
+        raise ValueError("spline_filter_: `src` must match `data` (shape, dtype, contiguous)")
     dim = dim % data.dim()
     n = data.shape[dim]
     outer = 1
@@ -468,8 +473,12 @@ def spline_filter_(data, bound, order, dim):
     for s in data.shape[dim + 1:]:
         inner *= s
     with torch.cuda.device(dev):
-        rc = lib().interpol_spline_filter(_ptr(data), _DTYPE_CODE[data.dtype], outer, n, inner,
-                                          int(bound), int(order), _stream(dev))
+        if src is None:
+            rc = lib().interpol_spline_filter(_ptr(data), _DTYPE_CODE[data.dtype], outer, n, inner,
+                                              int(bound), int(order), _stream(dev))
+        else:
+            rc = lib().interpol_spline_filter_to(_ptr(src), _ptr(data), _DTYPE_CODE[data.dtype], outer, n, inner,
+                                                 int(bound), int(order), _stream(dev))
     _check(rc, "interpol_spline_filter")
     return data
 

@@ -20,10 +20,12 @@ def _spline_coeff(inp, bound, order, dim=-1, inplace=False):
     if inp.dim() == 0:
         return inp if inplace else inp.clone()
     if inplace and inp.is_contiguous():
-        out = inp
+        out = ops.kernels().spline_filter_(inp, bound, order, dim)
+    elif inp.is_contiguous():
+        # out of place: the kernel reads `inp` and writes the result (no copy first)
+        out = ops.kernels().spline_filter_(inp.new_empty(inp.shape), bound, order, dim, src=inp)
     else:
-        out = inp.contiguous() if not inp.is_contiguous() else inp.clone()
-    ops.kernels().spline_filter_(out, bound, order, dim)
+        out = ops.kernels().spline_filter_(inp.contiguous(), bound, order, dim)
     if inplace and out is not inp:
         inp.copy_(out)
         return inp
@@ -43,13 +45,16 @@ def _spline_coeff_nd(inp, bound, order, dim=None, inplace=False):
         raise NotImplementedError
     if any(b in (4, 5) and o > 1 for b, o in zip(bound, order)):
         raise NotImplementedError('spline prefilter is not implemented for dst1/dst2 boundaries')
+    todo = [(d, b, o) for d, (b, o) in enumerate(zip(bound, order)) if o > 1]
     if inplace and inp.is_contiguous():
-        out = inp
+        out, src = inp, None
+    elif inp.is_contiguous() and todo:
+        out, src = inp.new_empty(inp.shape), inp        # the first pass reads `inp` and writes `out` (no copy first)
     else:
-        out = inp.contiguous() if not inp.is_contiguous() else inp.clone()
-    for d, (b, o) in enumerate(zip(bound, order)):
-        if o > 1:
-            ops.kernels().spline_filter_(out, b, o, -dim + d)
+        out, src = (inp.contiguous() if not inp.is_contiguous() else inp.clone()), None
+    for d, b, o in todo:
+        ops.kernels().spline_filter_(out, b, o, -dim + d, src=src)
+        src = None
     if inplace and out is not inp:
         inp.copy_(out)
         return inp

@@ -109,8 +109,8 @@ class _HipKernels:
         return _hip.push_backward(grad, None, grid, bound, order, extrapolate, False, True, flags=_dflag(displacement))[1]
 
     @staticmethod
-    def spline_filter_(data, bound, order, dim):
-        return _hip.spline_filter_(data, bound, order, dim)
+    def spline_filter_(data, bound, order, dim, src=None):
+        return _hip.spline_filter_(data, bound, order, dim, src=src)
 
     @staticmethod
     def pull_labels(inp, grid, bound, order, extrapolate, displacement=False):
