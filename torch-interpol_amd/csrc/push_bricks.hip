@@ -54,6 +54,25 @@ __device__ __forceinline__ float weight_of(const KParams &p, int d, float t, int
     return bspline_w<float>(k, t - (float)j);                                   // splines.py:30-80
 }
 
+// the K + 1 weights of a stencil coordinate: closed forms of splines.py:30-44 on the interval of `split1` for the
+// quadratic and cubic splines, the generic evaluation otherwise
+template <int K>
+__device__ __forceinline__ void stencil_weights(const KParams &p, int d, float t, float *w)
+{
+    if (K == 3) {
+        const float u = t - 1.f, v = 2.f - t, u2 = u * u, v2 = v * v;          // t in [1, 2)
+        w[0] = (v2 * v) * (1.f / 6.f); w[3] = (u2 * u) * (1.f / 6.f);
+        w[1] = __builtin_fmaf(u2, __builtin_fmaf(u, 0.5f, -1.f), 2.f / 3.f);
+        w[2] = __builtin_fmaf(v2, __builtin_fmaf(v, 0.5f, -1.f), 2.f / 3.f);
+    } else if (K == 2) {
+        const float a = 1.5f - t, c = t - 0.5f, m = t - 1.f;                     // t in [0.5, 1.5)
+        w[0] = (a * a) * 0.5f; w[1] = __builtin_fmaf(-m, m, 0.75f); w[2] = (c * c) * 0.5f;
+    } else {
+#pragma unroll
+        for (int j = 0; j <= K; ++j) w[j] = weight_of(p, d, t, j);
+    }
+}
+
 // -> 0: masked out (contributes nothing), 1: interior (whole stencil inside the lattice, signs +1), 2: border
 __device__ __forceinline__ int classify(const KParams &p, const float *x, int *i0, float *t)
 {
@@ -92,26 +111,6 @@ __device__ __noinline__ int dim_bricks(int bound, int k, int n, int i0, bool bor
     return cnt;
 }
 
-// arr[key] += (number of active lanes with this key), one atomic per distinct key of the wave;
-// returns the slot of this lane (old value + rank among the lanes of its key).
-__device__ __forceinline__ int wave_agg_add(int *arr, int key, bool active)
-{
-    const int lane = threadIdx.x & 63;
-    int result = 0;
-    unsigned long long todo = __ballot(active);
-    while (todo) {
-        const int leader = __ffsll((unsigned long long)todo) - 1;
-        const int k = __shfl(key, leader);
-        const unsigned long long same = __ballot(active && key == k);
-        int base = 0;
-        if (lane == leader) base = atomicAdd(&arr[k], __popcll(same));
-        base = __shfl(base, leader);
-        if (active && key == k) result = base + __popcll(same & ((1ull << lane) - 1ull));
-        todo &= ~same;
-    }
-    return result;
-}
-
 // max |src| per value channel, stage 1 of 2 (stage 2 in bricks_scan): blockIdx.y = channel,
 // each block reduces a strided share of the (B, N) values and writes one partial.
 constexpr int MAXPART = 256;
@@ -137,46 +136,98 @@ __global__ __launch_bounds__(256) void bricks_max(KParams p, Bricks bk, const fl
     }
 }
 
-// Steps 1 and 3: one thread per sample.
+// Steps 1 and 3: one thread per sample.  A workgroup's 256 samples are neighbours: they hit a few dozen
+// distinct bricks.  The (brick -> samples of this workgroup) counts are merged in an LDS hash table first and
+// ONE global atomic per distinct brick and workgroup reserves the list positions; same-address global atomics
+// serialise, and a per-wave merge loop pays one atomic round trip per distinct brick, one after the other
+// (measured at config 4, 8 sources: count + fill 2.55 ms that way).
+// hdr[8] is set when a sample spans more than two bricks along a dim (tiny lattices): only then has
+// bricks_border anything to do.
+constexpr int HS = 2048;                        // hash slots = the most insertions of a chunk (256 samples x 8 bricks): probing ends
 template <bool FILL>
 __global__ __launch_bounds__(256) void bricks_walk(KParams p, Bricks bk, const float *__restrict__ val, const float *__restrict__ grid,
                                                    float *__restrict__ vol, int B, int nch)
 {
-    const unsigned o = blockIdx.x * 256u + threadIdx.x;
-    const bool live = o < bk.N;
-    for (int b = blockIdx.y; b < B; b += gridDim.y) {
-        float x[3] = { 0.f, 0.f, 0.f };
-        int i0[3]; float t[3];
-        int cls = 0;
-        if (live) { load_coords<float, float, 3>(p, grid, b, o, x); cls = classify(p, x, i0, t); }
+    __shared__ int hkey[HS], hcnt[HS], used[HS], nused;
+    // persistent workgroups over (batch item, chunk of 256 samples); the next chunk's coordinates are fetched
+    // while this one is processed
+    const unsigned cpb = (bk.N + 255u) / 256u;                      // chunks per batch item
+    const unsigned total = cpb * (unsigned)B;
+    for (int e = threadIdx.x; e < HS; e += 256) { hkey[e] = -1; hcnt[e] = 0; }
+    if (threadIdx.x == 0) nused = 0;
+    float xn[3] = { 0.f, 0.f, 0.f };
+    if (blockIdx.x < total) {
+        const unsigned b = blockIdx.x / cpb, o = (blockIdx.x - b * cpb) * 256u + threadIdx.x;
+        if (o < bk.N) load_coords<float, float, 3>(p, grid, (int64_t)b, (int64_t)o, xn);
+    }
+    __syncthreads();
+    for (unsigned w = blockIdx.x; w < total; w += gridDim.x) {
+        const int b = (int)(w / cpb);
+        const unsigned o = (w - (unsigned)b * cpb) * 256u + threadIdx.x;
+        const bool live = o < bk.N;
+        const float x[3] = { xn[0], xn[1], xn[2] };
         {
-            // The lanes of a wave are neighbouring samples: they mostly hit the same one or two
-            // bricks.  One counter update per distinct brick and wave (wave_agg_add), not per lane:
-            // same-address global atomics serialise.
-            const int tb = bk.shared ? 0 : b;
-            int bb[3][2] = { { 0, 0 }, { 0, 0 }, { 0, 0 } }, nb_[3] = { 0, 0, 0 };
-            bool in = cls != 0;
-            if (cls != 0) {
-#pragma unroll
-                for (int d = 0; d < 3; ++d) {
-                    if (cls == 1) {            // interior: no boundary condition to apply (the common case, inline)
-                        bb[d][0] = i0[d] / BS; bb[d][1] = (i0[d] + p.order[d]) / BS;
-                        nb_[d] = bb[d][1] > bb[d][0] ? 2 : 1;
-                    } else {
-                        nb_[d] = dim_bricks(p.bound[d], p.order[d], p.vol_n[d], i0[d], true, &bb[d][0], &bb[d][1]);
-                    }
-                    in = in && nb_[d] >= 1 && nb_[d] <= 2;          // 0: nothing to splat; 3: left to bricks_border
-                }
-            }
-#pragma unroll
-            for (int corner = 0; corner < 8; ++corner) {
-                const int ex = corner >> 2, ey = (corner >> 1) & 1, ez = corner & 1;
-                const bool on = in && (!ex || nb_[0] == 2) && (!ey || nb_[1] == 2) && (!ez || nb_[2] == 2);
-                const int br = tb * bk.per_target + (bb[0][ex] * bk.nb[1] + bb[1][ey]) * bk.nb[2] + bb[2][ez];
-                const int pos = wave_agg_add(FILL ? bk.cursor : bk.counts, br, on);
-                if (FILL && on) bk.list[pos] = (unsigned)b * bk.N + o;
+            const unsigned wn = w + gridDim.x;
+            if (wn < total) {
+                const unsigned bn = wn / cpb, on = (wn - bn * cpb) * 256u + threadIdx.x;
+                if (on < bk.N) load_coords<float, float, 3>(p, grid, (int64_t)bn, (int64_t)on, xn);
             }
         }
+        int i0[3]; float t[3];
+        int cls = 0;
+        if (live) cls = classify(p, x, i0, t);
+        const int tb = bk.shared ? 0 : b;
+        int bb[3][2] = { { 0, 0 }, { 0, 0 }, { 0, 0 } }, nb_[3] = { 0, 0, 0 };
+        bool in = cls != 0;
+        if (cls != 0) {
+#pragma unroll
+            for (int d = 0; d < 3; ++d) {
+                if (cls == 1) {            // interior: no boundary condition to apply (the common case, inline)
+                    bb[d][0] = i0[d] / BS; bb[d][1] = (i0[d] + p.order[d]) / BS;
+                    nb_[d] = bb[d][1] > bb[d][0] ? 2 : 1;
+                } else {
+                    nb_[d] = dim_bricks(p.bound[d], p.order[d], p.vol_n[d], i0[d], true, &bb[d][0], &bb[d][1]);
+                    if (!FILL && nb_[d] == 3) bk.hdr[8] = 1;
+                }
+                in = in && nb_[d] >= 1 && nb_[d] <= 2;          // 0: nothing to splat; 3: left to bricks_border
+            }
+        }
+        int slot[8], rank[8];
+#pragma unroll
+        for (int corner = 0; corner < 8; ++corner) {
+            const int ex = corner >> 2, ey = (corner >> 1) & 1, ez = corner & 1;
+            const bool on = in && (!ex || nb_[0] == 2) && (!ey || nb_[1] == 2) && (!ez || nb_[2] == 2);
+            slot[corner] = -1; rank[corner] = 0;
+            if (on) {
+                const int br = tb * bk.per_target + (bb[0][ex] * bk.nb[1] + bb[1][ey]) * bk.nb[2] + bb[2][ez];
+                int sl = (int)(((unsigned)br * 2654435761u) >> 21) & (HS - 1);
+                while (true) {
+                    const int prev = atomicCAS(&hkey[sl], -1, br);
+                    if (prev == -1) used[atomicAdd(&nused, 1)] = sl;      // a new key of this chunk
+                    if (prev == -1 || prev == br) break;
+                    sl = (sl + 1) & (HS - 1);
+                }
+                slot[corner] = sl;
+                rank[corner] = atomicAdd(&hcnt[sl], 1);
+            }
+        }
+        __syncthreads();
+        const int nu = nused;
+        for (int e = threadIdx.x; e < nu; e += 256) {
+            const int sl = used[e], key = hkey[sl];
+            if (FILL) hcnt[sl] = atomicAdd(&bk.cursor[key], hcnt[sl]);
+            else __hip_atomic_fetch_add(&bk.counts[key], hcnt[sl], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __syncthreads();
+        if (FILL) {
+#pragma unroll
+            for (int corner = 0; corner < 8; ++corner)
+                if (slot[corner] >= 0) bk.list[hcnt[slot[corner]] + rank[corner]] = (unsigned)b * bk.N + o;
+            __syncthreads();
+        }
+        for (int e = threadIdx.x; e < nu; e += 256) { const int sl = used[e]; hkey[sl] = -1; hcnt[sl] = 0; }   // only what was touched
+        if (threadIdx.x == 0) nused = 0;
+        __syncthreads();
     }
 }
 
@@ -186,6 +237,7 @@ __global__ __launch_bounds__(256) void bricks_walk(KParams p, Bricks bk, const f
 __global__ __launch_bounds__(256) void bricks_border(KParams p, Bricks bk, const float *__restrict__ val, const float *__restrict__ grid,
                                                      float *__restrict__ vol, int B, int nch)
 {
+    if (bk.hdr[8] == 0) return;                            // no sample spans more than two bricks along a dim (bricks_walk)
     const unsigned o = blockIdx.x * 256u + threadIdx.x;
     const int lane = threadIdx.x & 63;
     const int k1[3] = { p.order[0] + 1, p.order[1] + 1, p.order[2] + 1 };
@@ -300,8 +352,7 @@ __global__ __launch_bounds__(1024) void bricks_accumulate(KParams p, Bricks bk, 
 #pragma unroll
             for (int c = 0; c < NCH; ++c) sv[c] = (c < p.C ? val[(int64_t)b * p.val_sb + c * p.val_sc + o] : 1.f) * scale[c];
             float wx[K + 1], wy[K + 1], wz[K + 1];
-#pragma unroll
-            for (int j = 0; j <= K; ++j) { wx[j] = weight_of(p, 0, t[0], j); wy[j] = weight_of(p, 1, t[1], j); wz[j] = weight_of(p, 2, t[2], j); }
+            stencil_weights<K>(p, 0, t[0], wx); stencil_weights<K>(p, 1, t[1], wy); stencil_weights<K>(p, 2, t[2], wz);
             // lattice index (relative to the brick) and sign of every tap; border samples wrap
             int jx[K + 1], jy[K + 1], jz[K + 1];
 #pragma unroll
@@ -346,15 +397,26 @@ __global__ __launch_bounds__(1024) void bricks_accumulate(KParams p, Bricks bk, 
         __syncthreads();
         // the brick goes to the target: this workgroup is its only writer (border samples are
         // splatted by another kernel of the same stream)
-        for (int e = tid; e < BSLOTS; e += 1024) {
+        // (all the reads of the thread's voxels first, then the writes: one memory round trip, not one per voxel)
+        constexpr int NV = BSLOTS / 1024;
+        float cur[NV][NCH]; int64_t offs[NV];
+#pragma unroll
+        for (int u = 0; u < NV; ++u) {
+            const int e = tid + 1024 * u;
             const int sx = e / (BS * BS), sy = (e / BS) % BS, sz = e % BS;
             const int gx = bx * BS + sx, gy = by * BS + sy, gz = bz * BS + sz;
-            if (gx >= p.vol_n[0] || gy >= p.vol_n[1] || gz >= p.vol_n[2]) continue;
-            const int64_t off = (int64_t)gx * (p.vol_ss[0] / 4) + (int64_t)gy * (p.vol_ss[1] / 4) + (int64_t)gz * (p.vol_ss[2] / 4);
+            offs[u] = (gx >= p.vol_n[0] || gy >= p.vol_n[1] || gz >= p.vol_n[2]) ? -1
+                    : (int64_t)gx * (p.vol_ss[0] / 4) + (int64_t)gy * (p.vol_ss[1] / 4) + (int64_t)gz * (p.vol_ss[2] / 4);
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) cur[u][c] = offs[u] >= 0 ? vt[c * p.vol_sc + offs[u]] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < NV; ++u) {
+            if (offs[u] < 0) continue;
 #pragma unroll
             for (int c = 0; c < NCH; ++c) {
-                const long long a = (long long)acc[c * BSLOTS + e];
-                if (a != 0) vt[c * p.vol_sc + off] += (float)a * inv[c];
+                const long long a = (long long)acc[c * BSLOTS + tid + 1024 * u];
+                if (a != 0) vt[c * p.vol_sc + offs[u]] = cur[u][c] + (float)a * inv[c];
             }
         }
     }
@@ -390,10 +452,13 @@ int launch_push_bricks(const KParams &p, int B, int shared, const void *val, con
     hipError_t e = hipMemsetAsync(workspace, 0, 4 * (size_t)(HDR + 8 * 256 + nbt), st);       // header + partial maxima + counters
     if (e != hipSuccess) return (int)e;
     const dim3 grid1((unsigned)((p.N + 255) / 256), (unsigned)(B < 65535 ? B : 65535));
+    const uint64_t chunks = (uint64_t)((p.N + 255) / 256) * (uint64_t)B;
+    if (chunks > 0xffffffffull) return 0;
+    const dim3 gridw((unsigned)(chunks < 4096 ? chunks : 4096));          // persistent walkers (4096 vs exactly-resident 1536: 0.59 vs 0.63 ms)
     if (p.C > 0) hipLaunchKernelGGL((bricks_max), dim3(256, (unsigned)p.C), dim3(256), 0, st, p, bk, (const float *)val, B);
-    hipLaunchKernelGGL((bricks_walk<false>), grid1, dim3(256), 0, st, p, bk, (const float *)val, (const float *)grid, (float *)vol, B, nch);
+    hipLaunchKernelGGL((bricks_walk<false>), gridw, dim3(256), 0, st, p, bk, (const float *)val, (const float *)grid, (float *)vol, B, nch);
     hipLaunchKernelGGL((bricks_scan), dim3(1), dim3(1024), 0, st, bk, (int)nbt, p.C);
-    hipLaunchKernelGGL((bricks_walk<true>), grid1, dim3(256), 0, st, p, bk, (const float *)val, (const float *)grid, (float *)vol, B, nch);
+    hipLaunchKernelGGL((bricks_walk<true>), gridw, dim3(256), 0, st, p, bk, (const float *)val, (const float *)grid, (float *)vol, B, nch);
     hipLaunchKernelGGL((bricks_border), grid1, dim3(256), 0, st, p, bk, (const float *)val, (const float *)grid, (float *)vol, B, nch);
     const size_t lds = (size_t)nch * BSLOTS * 8;
     const unsigned blocks = (unsigned)(nbt < 2048 ? nbt : 2048);
