@@ -315,9 +315,12 @@ __global__ __launch_bounds__(1024) void bricks_scan(Bricks bk, int n, int nval)
     if (threadIdx.x == 0) bk.offsets[n] = carry;
 }
 
-// Step 4: one workgroup per brick (persistent), one thread per listed sample.
-template <int NCH, int K>
-__global__ __launch_bounds__(1024) void bricks_accumulate(KParams p, Bricks bk, const float *__restrict__ val, const float *__restrict__ grid,
+// Step 4: one workgroup per brick (persistent), one thread per listed sample.  ACC_NT = 512: two workgroups fit a CU
+// (73 VGPRs, 64 KiB of LDS for two channels) and overlap each other's list / flush phases -- better for short lists
+// (config 4, 8 sources: 2.37 -> 2.0 ms); long lists (64 sources: ~6800 samples per brick) do better with one
+// workgroup of 1024 threads (23.9 vs 29.0 ms).
+template <int NCH, int K, int ACC_NT>
+__global__ __launch_bounds__(ACC_NT) void bricks_accumulate(KParams p, Bricks bk, const float *__restrict__ val, const float *__restrict__ grid,
                                                           float *__restrict__ vol, int nbricks)
 {
     extern __shared__ unsigned long long acc[];            // NCH x BSLOTS
@@ -339,10 +342,10 @@ __global__ __launch_bounds__(1024) void bricks_accumulate(KParams p, Bricks bk, 
         const int tb = br / bk.per_target, r = br - tb * bk.per_target;
         const int bx = r / (bk.nb[1] * bk.nb[2]), by = (r / bk.nb[2]) % bk.nb[1], bz = r % bk.nb[2];
         __syncthreads();
-        for (int e = tid; e < NCH * BSLOTS; e += 1024) acc[e] = 0ull;
+        for (int e = tid; e < NCH * BSLOTS; e += ACC_NT) acc[e] = 0ull;
         __syncthreads();
         float *vt = vol + (int64_t)tb * p.vol_sb;
-        for (int e = beg + tid; e < end; e += 1024) {
+        for (int e = beg + tid; e < end; e += ACC_NT) {
             const unsigned id = bk.list[e];
             const unsigned b = id / bk.N, o = id - b * bk.N;
             float x[3]; int i0[3]; float t[3];
@@ -398,11 +401,11 @@ __global__ __launch_bounds__(1024) void bricks_accumulate(KParams p, Bricks bk, 
         // the brick goes to the target: this workgroup is its only writer (border samples are
         // splatted by another kernel of the same stream)
         // (all the reads of the thread's voxels first, then the writes: one memory round trip, not one per voxel)
-        constexpr int NV = BSLOTS / 1024;
+        constexpr int NV = BSLOTS / ACC_NT;
         float cur[NV][NCH]; int64_t offs[NV];
 #pragma unroll
         for (int u = 0; u < NV; ++u) {
-            const int e = tid + 1024 * u;
+            const int e = tid + ACC_NT * u;
             const int sx = e / (BS * BS), sy = (e / BS) % BS, sz = e % BS;
             const int gx = bx * BS + sx, gy = by * BS + sy, gz = bz * BS + sz;
             offs[u] = (gx >= p.vol_n[0] || gy >= p.vol_n[1] || gz >= p.vol_n[2]) ? -1
@@ -415,7 +418,7 @@ __global__ __launch_bounds__(1024) void bricks_accumulate(KParams p, Bricks bk, 
             if (offs[u] < 0) continue;
 #pragma unroll
             for (int c = 0; c < NCH; ++c) {
-                const long long a = (long long)acc[c * BSLOTS + tid + 1024 * u];
+                const long long a = (long long)acc[c * BSLOTS + tid + ACC_NT * u];
                 if (a != 0) vt[c * p.vol_sc + offs[u]] = cur[u][c] + (float)a * inv[c];
             }
         }
@@ -462,14 +465,17 @@ int launch_push_bricks(const KParams &p, int B, int shared, const void *val, con
     hipLaunchKernelGGL((bricks_border), grid1, dim3(256), 0, st, p, bk, (const float *)val, (const float *)grid, (float *)vol, B, nch);
     const size_t lds = (size_t)nch * BSLOTS * 8;
     const unsigned blocks = (unsigned)(nbt < 2048 ? nbt : 2048);
-#define IP_BR2(NC, KK) { \
-        if (lds > 64 * 1024) { e = hipFuncSetAttribute((const void *)bricks_accumulate<NC, KK>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+    const bool long_lists = (double)B * (double)p.N * 2. > 3000. * (double)nbt;       // estimated samples per brick list
+#define IP_BR3(NC, KK, NTH) { \
+        if (lds > 64 * 1024) { e = hipFuncSetAttribute((const void *)bricks_accumulate<NC, KK, NTH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
                                if (e != hipSuccess) return (int)e; } \
-        hipLaunchKernelGGL((bricks_accumulate<NC, KK>), dim3(blocks), dim3(1024), lds, st, p, bk, (const float *)val, (const float *)grid, (float *)vol, (int)nbt); }
+        hipLaunchKernelGGL((bricks_accumulate<NC, KK, NTH>), dim3(blocks), dim3(NTH), lds, st, p, bk, (const float *)val, (const float *)grid, (float *)vol, (int)nbt); }
+#define IP_BR2(NC, KK) { if (long_lists) IP_BR3(NC, KK, 1024) else IP_BR3(NC, KK, 512) }
 #define IP_BR(NC) case NC: switch (K) { case 0: IP_BR2(NC, 0) break; case 1: IP_BR2(NC, 1) break; case 2: IP_BR2(NC, 2) break; default: IP_BR2(NC, 3) break; } break;
     switch (nch) { IP_BR(1) IP_BR(2) IP_BR(3) IP_BR(4) default: return 0; }
 #undef IP_BR
 #undef IP_BR2
+#undef IP_BR3
     e = hipGetLastError();
     return e == hipSuccess ? 1 : (int)e;
 }
