@@ -122,4 +122,35 @@ if "f" in which:    # row f4: label map (50 labels), trilinear, 1x1x192^3, one-p
         return out
     rec(res, "f4_labels_50_linear_192_per_label_loop", timeit(loop, 3), vox, vox * (12 + 8 + 8))
 
+    rec(res, "f4_labels_50_cubic_192_one_pass_64_taps", timeit(lambda: interpol.grid_pull(lab, gr, interpolation=3, bound="dct2", extrapolate=True), 3), vox, vox * (12 + 8 + 8))
+
+if "f" in which:    # row f3: affine lattice evaluated in the kernel vs a dense affine grid tensor (4x2x256^3 cubic)
+    B, C, n = 4, 2, 256
+    x = torch.randn(B, C, n, n, n, generator=g, device=dev)
+    mat = torch.tensor([[0.98, 0.05, -0.03, 1.5], [-0.04, 1.01, 0.02, -2.0], [0.03, -0.02, 0.99, 0.7]], device=dev)
+    ag = interpol.AffineGrid(mat, [n, n, n])
+    vox = B * n ** 3
+    kw = dict(interpolation=3, bound="dct2", extrapolate=True)
+    rec(res, "f3_affine_in_kernel_pull_256_cubic", timeit(lambda: interpol.grid_pull(x, ag, **kw), 3), vox, 2 * B * C * n ** 3 * 4)
+    dense = ag.dense().reshape(1, n, n, n, 3).expand(B, n, n, n, 3).contiguous()
+    rec(res, "f3_affine_dense_grid_pull_256_cubic", timeit(lambda: interpol.grid_pull(x, dense, **kw), 3), vox, 2 * B * C * n ** 3 * 4 + vox * 12)
+    del dense, x
+
+if "r" in which:    # config 2 vs the roughness of the deformation: identity + sigma * iid noise (voxels)
+    import bench
+    from interpol import backend
+    for sigma in (0.0, 0.5, 1.0, 2.0, 3.0, 4.0, 6.0):
+        inp, grid = bench.make_inputs(4, 2, 256, sigma, dev, 1234)
+        kw = dict(interpolation=3, bound="dct2", extrapolate=True)
+        vox = 4 * 256 ** 3
+        nb = vox * 12 + 2 * 4 * 2 * 256 ** 3 * 4
+        rec(res, "cfg2_pull_sigma_%g" % sigma, timeit(lambda: interpol.grid_pull(inp, grid, **kw), 3), vox, nb)
+        rec(res, "cfg2_push_sigma_%g" % sigma, timeit(lambda: interpol.grid_push(inp, grid, **kw), 3), vox, nb)
+        backend.rough_deformations = True
+        try:
+            rec(res, "cfg2_push_binned_sigma_%g" % sigma, timeit(lambda: interpol.grid_push(inp, grid, **kw), 3), vox, nb)
+        finally:
+            backend.rough_deformations = False
+        del inp, grid
+
 print(json.dumps(res, indent=1))

@@ -45,27 +45,61 @@ for name in ("bench.json", "other_configs.json"):
             text = "\n".join(l for l in text.splitlines() if l.startswith("{"))
             [json.loads(l) for l in text.splitlines()]     # or one object per line
         open(os.path.join(dst, rnd + "_" + name), "w").write(text.rstrip() + "\n")
-f, w = dbs("pmc_FETCH_SIZE"), dbs("pmc_WRITE_SIZE")
-if f and w:
+# --- HBM traffic from the FETCH_SIZE / WRITE_SIZE passes ---------------------------------------------------
+# stage 1 (on the GPU box, where the rocprofv3 databases are): raw per-dispatch counters -> pmc_raw.json
+# stage 2 (anywhere): pmc_raw.json -> <round>_pmc_hbm_traffic.txt + pmc_traffic.json
+ALG_READ = {   # algorithmic HBM read bytes per launch at BASELINE config 2 (4 x 2 x 256^3 fp32, fp32 grid): grid + source
+    "grid_pull": 4 * 256 ** 3 * 12 + 4 * 2 * 256 ** 3 * 4,
+    "grid_push": 4 * 256 ** 3 * 12 + 4 * 2 * 256 ** 3 * 4,
+}
+KERNEL = {"grid_pull": "pull_sorted", "grid_push": "push_tiled"}
+raw_path = os.path.join(src, "pmc_raw.json")
+if all(dbs("pmc_%s_s%s" % (c, sg)) for c in ("FETCH_SIZE", "WRITE_SIZE") for sg in ("2.0", "0.0")):
+    raw = {}
+    for sg in ("2.0", "0.0"):
+        for c in ("FETCH_SIZE", "WRITE_SIZE"):
+            db = dbs("pmc_%s_s%s" % (c, sg))[0]
+            for key, sub in list(KERNEL.items()) + [("copy", "copyBuffer")]:
+                raw["%s|%s|%s" % (key, c, sg)] = counter(db, c, sub)
+    json.dump(raw, open(raw_path, "w"), indent=1)
+if os.path.exists(raw_path):
+    raw = json.load(open(raw_path))
     buf = io.StringIO()
-    buf.write("# rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separate passes) -- python tools/pmc_workload.py\n"
-              "# per-dispatch values summed over the counter's instances, KB.  Calibration in the same run:\n"
-              "#   __amd_rocclr_copyBuffer copies 524288 KB with 16 B/lane loads: FETCH_SIZE reports 1/2 of the bytes (gfx950\n"
-              "#   under-count, MI355X_MICROARCH.md sec. HBM); the 4 B/lane elementwise add reading 786432 KB reports ~786470 KB\n"
-              "#   (factor 1); WRITE_SIZE is exact.  The tiled kernels stage with 4 B/lane loads -> factor 1 is used.\n")
-    out = {"_comment": "HBM-side bytes per launch at BASELINE config 2 from rocprofv3 PMC passes (profiles/%s_pmc_hbm_traffic.txt): "
-                       "FETCH_SIZE*1024 (factor 1, calibrated in the same run) + WRITE_SIZE*1024" % rnd}
-    rows = []
-    for key, sub in (("grid_pull", "pull2_tiled"), ("grid_push", "push_tiled"), ("copy_calibration_16B_per_lane", "copyBuffer"),
-                     ("add_calibration_4B_per_lane", "CUDAFunctor_add")):
-        fk, wk = counter(f[0], "FETCH_SIZE", sub), counter(w[0], "WRITE_SIZE", sub)
-        rows.append((key, sub, fk, wk))
-        if key.startswith("grid_") and fk is not None and wk is not None:
-            out[key] = int((fk + wk) * 1024)
-            out[key + "_detail"] = {"fetch_KB": round(fk, 1), "write_KB": round(wk, 1)}
-    buf.write("%-32s %-20s %16s %16s\n" % ("what", "kernel contains", "FETCH_SIZE_KB", "WRITE_SIZE_KB"))
-    for key, sub, fk, wk in rows:
-        buf.write("%-32s %-20s %16s %16s\n" % (key, sub, "%.1f" % fk if fk is not None else "-", "%.1f" % wk if wk is not None else "-"))
+    buf.write("# rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE (separate passes) -- python tools/pmc_workload.py <sigma>\n"
+              "# per-dispatch values summed over the counter's instances, KB (tools/profile_round.sh %s pmc; raw values: pmc_raw.json).\n"
+              "# Corrections (MI355X_MICROARCH.md sec. HBM: FETCH_SIZE reports 1/2 of wide coalesced reads on gfx950, other widths and\n"
+              "# WRITE_SIZE are to be calibrated on a known byte count in one's own access pattern):\n"
+              "#  * WRITE_SIZE: exact -- __amd_rocclr_copyBuffer of the same run writes 524288 KB and reports 524288.0 KB: factor 1.\n"
+              "#  * FETCH_SIZE: the SAME kernel at the identity deformation (sigma = 0), where every input byte is fetched once and the\n"
+              "#    reads are grid + source = 1342 MB: factor = 1342 MB / counter(sigma = 0).  pull_sorted mixes 16-byte staging loads\n"
+              "#    (counted 1/2) with 4-byte coordinate loads: factor 1.41; push_tiled reads with 4-byte loads only: factor 1.01.\n"
+              "# The push target is never read: its float atomics are executed memory-side and counted as writes (write-through of the\n"
+              "# tile halos: 1.40 GB at the identity, 2.78 GB at sigma = 2 for a 0.54 GB target).\n" % tag)
+    out = {"_comment": "HBM-side bytes per launch at BASELINE config 2 (sigma = 2) from rocprofv3 PMC passes (profiles/%s_pmc_hbm_traffic.txt): "
+                       "FETCH_SIZE KB x 1024 x the factor calibrated on the same kernel at the identity deformation + WRITE_SIZE KB x 1024 (exact per "
+                       "the copy calibration of the same run)" % rnd}
+    buf.write("%-10s %-12s %8s %15s %15s %8s %16s\n" % ("op", "kernel", "counter", "KB at sigma=0", "KB at sigma=2", "factor", "bytes at sigma=2"))
+    for key, sub in KERNEL.items():
+        f0, f2 = raw.get("%s|FETCH_SIZE|0.0" % key), raw.get("%s|FETCH_SIZE|2.0" % key)
+        w0, w2 = raw.get("%s|WRITE_SIZE|0.0" % key), raw.get("%s|WRITE_SIZE|2.0" % key)
+        if not f0 or f2 is None or w2 is None:
+            continue
+        fac = ALG_READ[key] / (f0 * 1024.0)
+        rd, wr = f2 * 1024.0 * fac, w2 * 1024.0
+        buf.write("%-10s %-12s %8s %15.1f %15.1f %8.3f %16d\n" % (key, sub, "FETCH", f0, f2, fac, rd))
+        buf.write("%-10s %-12s %8s %15.1f %15.1f %8.3f %16d\n" % (key, sub, "WRITE", w0 or 0, w2, 1.0, wr))
+        out[key] = int(rd + wr)
+        out[key + "_detail"] = {"read_bytes": int(rd), "write_bytes": int(wr), "fetch_factor": round(fac, 3),
+                                "fetch_KB_sigma0": round(f0, 1), "fetch_KB_sigma2": round(f2, 1), "write_KB_sigma0": round(w0 or 0, 1), "write_KB_sigma2": round(w2, 1)}
+    for c in ("FETCH_SIZE", "WRITE_SIZE"):
+        v = raw.get("copy|%s|2.0" % c)
+        if v is not None:
+            buf.write("%-10s %-12s %8s %15s %15.1f   (copies 524288 KB with 16 B/lane accesses)\n" % ("copy", "copyBuffer", c[:5], "-", v))
     open(os.path.join(dst, rnd + "_pmc_hbm_traffic.txt"), "w").write(buf.getvalue())
     json.dump(out, open(os.path.join(dst, "pmc_traffic.json"), "w"), indent=1)
+for name, target in (("phase_split.txt", "_phase_split.txt"), ("micro_lds_gather.txt", "_micro_lds_gather.txt"), ("micro_lds_atomics.txt", "_micro_lds_atomics.txt"),
+                     (os.path.join("sq_cfg2", "sq_counters.txt"), "_sq_counters_cfg2.txt"), (os.path.join("sq_cfg5", "sq_counters.txt"), "_sq_counters_cfg5.txt")):
+    pth = os.path.join(src, name)
+    if os.path.exists(pth) and os.path.getsize(pth):
+        open(os.path.join(dst, rnd + target), "w").write(open(pth).read())
 print(os.listdir(dst))

@@ -23,8 +23,6 @@ GROUPS = [
     ["TCP_TCC_READ_REQ_LATENCY_sum", "TCP_TCC_READ_REQ_sum"],
     ["TCP_PENDING_STALL_CYCLES_sum", "TCP_TOTAL_CACHE_ACCESSES_sum"],
     ["SQ_INST_LEVEL_VMEM", "SQ_INST_LEVEL_LDS", "SQ_LEVEL_WAVES"],
-    ["FETCH_SIZE"],
-    ["WRITE_SIZE"],
 ]
 Q = """select s.kernel_name, p.name, avg(t.v), count(*) from
          (select e.event_id as ev, e.pmc_id as pid, sum(e.value) as v from rocpd_pmc_event e group by e.event_id, e.pmc_id) t
