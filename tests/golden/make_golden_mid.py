@@ -94,13 +94,13 @@ def backward(tag, fn, inp0, grid0, order, bound, shape=None, seed=0):
 
 def main():
     # ---- BASELINE configurations in miniature
-    # cfg2: cubic / dct2, two channels, 24^3
+    # cfg2: cubic / dct2, two channels, 20^3
     inp, grid, nin, ngr = inputs("cfg2", 1, 2, (20, 20, 20), (20, 20, 20), 2.0, 1234)
     for op in ("pull", "push", "count", "grad"):
         add("cfg2", op, inp, grid, nin, ngr, [3], [3], 1, (20, 20, 20))
     backward("cfg2", "grid_pull", inp, grid, 3, "dct2", seed=1)
     backward("cfg2", "grid_push", inp, grid, 3, "dct2", shape=[20, 20, 20], seed=2)
-    # cfg3: order 5 / dft, one channel, 24^3: grad, pull and the backward of pull
+    # cfg3: order 5 / dft, one channel, 18^3: grad, pull and the backward of pull
     inp, grid, nin, ngr = inputs("cfg3", 1, 1, (18, 18, 18), (18, 18, 18), 2.0, 1235)
     for op in ("pull", "grad", "push"):
         add("cfg3", op, inp, grid, nin, ngr, [6], [5], 1, (18, 18, 18))

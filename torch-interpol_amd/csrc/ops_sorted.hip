@@ -14,18 +14,18 @@
 // conflict-free for the whole stencil.  Hence:
 //
 //   1. a 512-thread workgroup owns a tile of 16^3 samples (8 per thread), two workgroups per CU
-//      (75 KiB of LDS each): while one stages or sorts, the other runs its tap loop;
+//      (76 KiB of LDS each): while one stages or sorts, the other runs its tap loop;
 //   2. the samples of the tile are COUNTING-SORTED by class q = (base slot) mod 32 and dealt to
 //      the lanes so that lane l of every half wave holds class l: rank r of class q goes to half-
 //      wave slot r, lane q.  Classes hold 128 samples on average; the surplus of an over-full
 //      class fills the holes left by the under-full ones (those half-wave slots pay a two-way
 //      conflict), so every thread still processes 8 samples;
-//   3. the box of lattice points the tile's stencils touch (<= 32 x 32 x 34, tile + K + halo) is
+//   3. the box of lattice points the tile's stencils touch (<= 32 x 32 x 36, tile + K + halo) is
 //      staged through LDS in FOUR PASSES over the residues of the box plane x mod 4: a cubic
 //      stencil has exactly one x-tap in every pass, the partial sums stay in registers.  A pass
-//      holds 8 planes of 32 rows of 34 slots of 8 bytes (two channels per slot, one ds_read_b64
-//      feeds both): 69 632 B.  The plane pitch (32 * 34 slots) is a multiple of 32 slots, so the
-//      class of a sample, (2 y0 + z0) mod 32, is the same in every pass; the row pitch 34 makes y0
+//      holds 8 planes of 32 rows of 36 slots of 8 bytes (two channels per slot, one ds_read_b64
+//      feeds both): 73 728 B.  The plane pitch (32 * 36 slots) is a multiple of 32 slots, so the
+//      class of a sample, (4 y0 + z0) mod 32, is the same in every pass; the row pitch 36 makes y0
 //      count, which keeps the classes evenly filled for smooth deformations (where z0 alone takes
 //      16 values) as well as for rough ones;
 //   4. the boundary condition is applied while staging (wrapped offset and sign per box row /

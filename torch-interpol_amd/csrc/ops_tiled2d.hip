@@ -20,9 +20,9 @@
 //     ops_sorted.hip) and add the box to the float target with coalesced global atomics.
 // Measured at config 5 (32 x 3 x 1024^2 bf16, orders [2, 3], sigma = 2): the kernels are bound by the
 // number of instructions issued per tile (SQ_INSTS_VALU ~ 940 / wave for pull, VALU active ~ 50 % with
-// every phase -- set-up 0.13, coordinates 0.08, staging 0.13, taps 0.15, stores 0.09 ms -- adding up),
-// not by HBM or by latency: prefetching the next tile's coordinates in persistent workgroups changed
-// nothing.  push: LDS atomics 0.65 ms + flush (global atomics) 0.3 ms of 1.05 ms.
+// every phase -- staging 0.17, coordinates 0.12, taps 0.10, stores 0.08 ms, set-up 0.14: profiles/
+// r02_phase_split.txt -- adding up), not by HBM or by latency: prefetching the next tile's coordinates in
+// persistent workgroups changed nothing.  push: LDS atomics 0.55 ms + flush (global atomics) 0.45 ms of 1.05 ms.
 // ===========================================================================
 #include "sorted_util.hpp"
 
