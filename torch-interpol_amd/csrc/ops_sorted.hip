@@ -618,24 +618,40 @@ __global__ __launch_bounds__(NT, 4) void push_sorted(KParams p, const T *__restr
             const T *ic1 = (ones1 || !two) ? nullptr : val + b * p.val_sb + (c + 1) * p.val_sc;
             float *vc0 = vol + b * p.vol_sb + c * p.vol_sc;
             float *vc1 = two ? vc0 + p.vol_sc : vc0;
-            // sources of the thread's sorted samples (masked: nd.py:201-203), and their block maxima
+            // sources of the tile in the natural order -- coalesced; the sorted order would be 16 scattered 4-byte loads
+            // per thread (measured: 37 % of the kernel) -- handed to the sorted lanes through the (zero, free) box
             f2 src[VPT];
             float am0 = 0.f, am1 = 0.f;
+            {
+                float2 *srcb = reinterpret_cast<float2 *>(sm.box);
+                float s0[VPT], s1[VPT];
 #pragma unroll
-            for (int j = 0; j < VPT; ++j) {
-                int ox, oy, oz;
-                sample_pos(g, (tl.key[j] >> 16) & (NS - 1), ox, oy, oz);
-                const int64_t o = ((int64_t)ox * g.gy + oy) * g.gz + oz;
-                // (unconditional loads -- an empty slot has id 0, a valid position: the 16 loads go out together)
-                const bool on = (tl.key[j] >> 29) & 1;
-                const float m = (float)((tl.key[j] >> 28) & 1);
-                float s0 = ones0 ? 1.f : Cvt<float, T>::ld(ic0[o]);
-                float s1 = !two ? 0.f : (ones1 ? 1.f : Cvt<float, T>::ld(ic1[o]));
-                s0 = on ? s0 * m : 0.f; s1 = on ? s1 * m : 0.f;
-                src[j] = f2{ s0, s1 };
-                const float a0 = __builtin_fabsf(s0), a1 = __builtin_fabsf(s1);
-                am0 = (a0 > am0 || a0 != a0) ? a0 : am0;             // NaN sticks
-                am1 = (a1 > am1 || a1 != a1) ? a1 : am1;
+                for (int v = 0; v < VPT; ++v) {
+                    int ox, oy, oz;
+                    sample_pos(g, tid + NT * v, ox, oy, oz);
+                    const bool ok = ox < g.gx && oy < g.gy && oz < g.gz;
+                    const int64_t o = ok ? ((int64_t)ox * g.gy + oy) * g.gz + oz : 0;
+                    s0[v] = ones0 ? 1.f : Cvt<float, T>::ld(ic0[o]);
+                    s1[v] = !two ? 0.f : (ones1 ? 1.f : Cvt<float, T>::ld(ic1[o]));
+                }
+#pragma unroll
+                for (int v = 0; v < VPT; ++v) srcb[tid + NT * v] = make_float2(s0[v], s1[v]);
+                __syncthreads();
+#pragma unroll
+                for (int j = 0; j < VPT; ++j) {
+                    const bool on = (tl.key[j] >> 29) & 1;
+                    const float m = (float)((tl.key[j] >> 28) & 1);                  // masked: nd.py:201-203
+                    const float2 sv = srcb[(tl.key[j] >> 16) & (NS - 1)];
+                    const float a = on ? sv.x * m : 0.f, c_ = on ? sv.y * m : 0.f;
+                    src[j] = f2{ a, c_ };
+                    const float a0 = __builtin_fabsf(a), a1 = __builtin_fabsf(c_);
+                    am0 = (a0 > am0 || a0 != a0) ? a0 : am0;             // NaN sticks
+                    am1 = (a1 > am1 || a1 != a1) ? a1 : am1;
+                }
+                __syncthreads();
+                float4 *z4 = reinterpret_cast<float4 *>(sm.box);
+#pragma unroll
+                for (int v = 0; v < NS / 2 / NT; ++v) z4[tid + NT * v] = make_float4(0.f, 0.f, 0.f, 0.f);   // the box is zero again
             }
             {
                 const int b0 = wave_max(__float_as_int(am0)), b1 = wave_max(__float_as_int(am1));   // non-negative floats (and NaN) order like ints
@@ -701,28 +717,54 @@ __global__ __launch_bounds__(NT, 4) void push_sorted(KParams p, const T *__restr
                         // instruction covers whole rows: the L2 performs atomics line by line), 14 rows at a time.
                         const int npl = (tl.S[0] - ps + 3) >> 2;
                         const int nrow = npl * CAPY;
-                        // (32 lanes per row, a second sweep for slices >= 32: 36-lane rows cost 25 % more)
-                        for (int zb = 0; zb < tl.S[2]; zb += 32) {
-                        const int z = zb + (tid & 31), rr = tid >> 5;
-                        if (z < tl.S[2]) {
-                            const int offz = sm.taboff[2][z];
-                            const float f0 = inv0 * sm.tabsgn[2][z], f1 = inv1 * sm.tabsgn[2][z];
-                            for (int r = rr; r < nrow; r += NT / 32) {
-                                if ((r & 31) >= tl.S[1]) continue;
-                                long long *sp = reinterpret_cast<long long *>(sm.box + r * PZ + z);
-                                const long long a = *sp;
-                                if (a == 0) continue;
-                                *sp = 0ll;
+                        // All the slots of the thread are read in one batch -- slices z < 32: 32 lanes per row, sixteen rows per
+                        // thread; the up to four slices z >= 32: four lanes per row, two rows per thread -- and for tiles inside
+                        // the lattice (no wrapping, sign +1: the common case) the target offsets are arithmetic, not table reads.
+                        // Measured (tools/ablate_sorted.py pushs, config 2, sigma = 2): the global atomics of the flush are free
+                        // (3.46 ms with or without them); what costs is the FIRST LDS read after the tap loop: the tap loop alone
+                        // takes 0.83 ms, any read of the box after it another 1.65 ms (0.15 ms when the tap loop is disabled;
+                        // independent of what is read, in how many round trips, and of the tile order) -- the LDS retires the
+                        // no-return atomics from the wave's counter long before it has executed them: the true cost of the
+                        // 4.3 G pair contributions is ~2.5 ms of LDS time (~19 clk per wave instruction and CU, twice the rate of
+                        // the microbenchmark's uniformly random slots: here ~7 adds per pass land on every resident slot), sorted
+                        // or not, and it shows wherever the first dependent LDS access is.
+                        const bool inside = tl.lo[0] >= (L.bound[0] == B_DST1 ? 1 : 0) && tl.lo[0] + tl.S[0] <= L.n[0]
+                                         && tl.lo[1] >= (L.bound[1] == B_DST1 ? 1 : 0) && tl.lo[1] + tl.S[1] <= L.n[1]
+                                         && tl.lo[2] >= (L.bound[2] == B_DST1 ? 1 : 0) && tl.lo[2] + tl.S[2] <= L.n[2];
+                        constexpr int RS = NT / 32, UF = NPL * CAPY / RS, RS2 = NT / 4, UF2 = NPL * CAPY / RS2;
+                        const int z1 = tid & 31, rr1 = tid >> 5, z2 = 32 + (tid & 3), rr2 = tid >> 2;
+                        long long a1[UF], a2[UF2];
+#pragma unroll
+                        for (int u = 0; u < UF; ++u) {
+                            const int r = rr1 + u * RS;
+                            a1[u] = (r < nrow && (r & 31) < tl.S[1] && z1 < tl.S[2]) ? *reinterpret_cast<long long *>(sm.box + r * PZ + z1) : 0ll;
+                        }
+#pragma unroll
+                        for (int u = 0; u < UF2; ++u) {
+                            const int r = rr2 + u * RS2;
+                            a2[u] = (r < nrow && (r & 31) < tl.S[1] && z2 < tl.S[2]) ? *reinterpret_cast<long long *>(sm.box + r * PZ + z2) : 0ll;
+                        }
+                        auto flush_slot = [&](int r, int z, long long a) {
+                            *reinterpret_cast<long long *>(sm.box + r * PZ + z) = 0ll;
+                            if (p.dbg & 4) return;                     // (ablation: everything but the global atomics)
+                            int off; float sg;
+                            if (inside) {
+                                off = (tl.lo[0] + 4 * (r >> 5) + ps) * L.ss[0] + (tl.lo[1] + (r & 31)) * L.ss[1] + (tl.lo[2] + z) * L.ss[2];
+                                sg = 1.f;
+                            } else {
                                 const int2 rt = sm.rowtab[r];
-                                const int lo_ = (int)(a & 0xffffffffll);
-                                const int hi_ = (int)((a - (long long)lo_) >> 32);
-                                const int off = rt.x + offz;
-                                const float sg = __int_as_float(rt.y);
-                                if (lo_ != 0) __hip_atomic_fetch_add(vc0 + off, (float)lo_ * (f0 * sg), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                                if (hi_ != 0) __hip_atomic_fetch_add(vc1 + off, (float)hi_ * (f1 * sg), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                off = rt.x + sm.taboff[2][z];
+                                sg = __int_as_float(rt.y) * sm.tabsgn[2][z];
                             }
-                        }
-                        }
+                            const int lo_ = (int)(a & 0xffffffffll);
+                            const int hi_ = (int)((a - (long long)lo_) >> 32);
+                            if (lo_ != 0) __hip_atomic_fetch_add(vc0 + off, (float)lo_ * (inv0 * sg), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            if (hi_ != 0) __hip_atomic_fetch_add(vc1 + off, (float)hi_ * (inv1 * sg), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        };
+#pragma unroll
+                        for (int u = 0; u < UF; ++u) if (a1[u] != 0) flush_slot(rr1 + u * RS, z1, a1[u]);
+#pragma unroll
+                        for (int u = 0; u < UF2; ++u) if (a2[u] != 0) flush_slot(rr2 + u * RS2, z2, a2[u]);
                     }
                     __syncthreads();
                     prof_mark(2);
