@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """Ablation timings of the class-sorted tile kernels (debug bits of interpol_problem.flags >> 8:
-1 no staging / flush, 2 no tap loop, 4 flush without its global atomics, 64 staging loads from a 64 KiB window;
+1 no staging / flush, 2 no tap loop, 4 flush without its global atomics, 16 flush every slot of the box, 64 staging loads from a 64 KiB window;
    op "pushs" = push_sorted, switch 128)."""
 import os, sys, json
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -31,5 +31,6 @@ for sigma in (2.0, 0.0):
             res["pushs_" + name] = timeit(lambda: _hip.scatter("push", inp, grid, None, [3] * 3, [3] * 3, 1, flags=flags | (128 << 8)))
             if name == "full":
                 res["pushs_flush_without_global_atomics"] = timeit(lambda: _hip.scatter("push", inp, grid, None, [3] * 3, [3] * 3, 1, flags=flags | ((128 + 4) << 8)))
-            if name == "full":
+    if "pushs" in ops:
+        res["pushs_no_taps_but_an_atomic_for_every_slot"] = timeit(lambda: _hip.scatter("push", inp, grid, None, [3] * 3, [3] * 3, 1, flags=(2 + 16 + 128) << 8))
     print("sigma", sigma, json.dumps({k: round(v, 3) for k, v in res.items()}))

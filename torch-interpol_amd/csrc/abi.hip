@@ -131,7 +131,7 @@ static int make_params(const interpol_problem *p, Role role, int trailing, KPara
     // pushpull.py:48-66 : all orders 1 -> iso1 semantics, all 0 -> iso0, else nd
     k->mode = all1 ? MODE_ISO1 : (all0 ? MODE_ISO0 : MODE_ND);
     k->C = (int)p->channels;
-    k->dbg = (p->flags >> 8) & 0xff;
+    k->dbg = (p->flags >> 8) & 0xffff;
     k->N = N;
     k->vol_sb = p->vol_stride[0];
     k->vol_sc = p->vol_stride[1];

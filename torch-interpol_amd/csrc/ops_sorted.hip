@@ -717,54 +717,60 @@ __global__ __launch_bounds__(NT, 4) void push_sorted(KParams p, const T *__restr
                         // instruction covers whole rows: the L2 performs atomics line by line), 14 rows at a time.
                         const int npl = (tl.S[0] - ps + 3) >> 2;
                         const int nrow = npl * CAPY;
-                        // All the slots of the thread are read in one batch -- slices z < 32: 32 lanes per row, sixteen rows per
-                        // thread; the up to four slices z >= 32: four lanes per row, two rows per thread -- and for tiles inside
-                        // the lattice (no wrapping, sign +1: the common case) the target offsets are arithmetic, not table reads.
-                        // Measured (tools/ablate_sorted.py pushs, config 2, sigma = 2): the global atomics of the flush are free
-                        // (3.46 ms with or without them); what costs is the FIRST LDS read after the tap loop: the tap loop alone
-                        // takes 0.83 ms, any read of the box after it another 1.65 ms (0.15 ms when the tap loop is disabled;
-                        // independent of what is read, in how many round trips, and of the tile order) -- the LDS retires the
-                        // no-return atomics from the wave's counter long before it has executed them: the true cost of the
-                        // 4.3 G pair contributions is ~2.5 ms of LDS time (~19 clk per wave instruction and CU, twice the rate of
-                        // the microbenchmark's uniformly random slots: here ~7 adds per pass land on every resident slot), sorted
-                        // or not, and it shows wherever the first dependent LDS access is.
-                        const bool inside = tl.lo[0] >= (L.bound[0] == B_DST1 ? 1 : 0) && tl.lo[0] + tl.S[0] <= L.n[0]
-                                         && tl.lo[1] >= (L.bound[1] == B_DST1 ? 1 : 0) && tl.lo[1] + tl.S[1] <= L.n[1]
-                                         && tl.lo[2] >= (L.bound[2] == B_DST1 ? 1 : 0) && tl.lo[2] + tl.S[2] <= L.n[2];
-                        constexpr int RS = NT / 32, UF = NPL * CAPY / RS, RS2 = NT / 4, UF2 = NPL * CAPY / RS2;
-                        const int z1 = tid & 31, rr1 = tid >> 5, z2 = 32 + (tid & 3), rr2 = tid >> 2;
-                        long long a1[UF], a2[UF2];
-#pragma unroll
-                        for (int u = 0; u < UF; ++u) {
-                            const int r = rr1 + u * RS;
-                            a1[u] = (r < nrow && (r & 31) < tl.S[1] && z1 < tl.S[2]) ? *reinterpret_cast<long long *>(sm.box + r * PZ + z1) : 0ll;
-                        }
-#pragma unroll
-                        for (int u = 0; u < UF2; ++u) {
-                            const int r = rr2 + u * RS2;
-                            a2[u] = (r < nrow && (r & 31) < tl.S[1] && z2 < tl.S[2]) ? *reinterpret_cast<long long *>(sm.box + r * PZ + z2) : 0ll;
-                        }
-                        auto flush_slot = [&](int r, int z, long long a) {
+                        // Slices z < 32 go 32 lanes per row, two rows per instruction, four rows read before the first is used; the
+                        // (up to four) slices z >= 32 go four lanes per row, sixteen rows per instruction -- not one nearly empty
+                        // instruction per row pair.  (Reading ALL the thread's slots in one batch pushed the kernel into scratch:
+                        // 0.93 -> 1.48 ms for everything else.)
+                        // Measured (tools/ablate_sorted.py pushs, profiles/r02_push_ablation.txt; config 2, sigma = 2): set-up +
+                        // sources 0.94 ms, tap loop 0.80, LDS side of the flush 0.17, its global atomics 1.55 -- additive: the L2
+                        // retires ~0.33 G float lane-atomics per ms chip-wide (one per clock and channel), however they are
+                        // coalesced, ordered over the tiles, or overlapped (fetching the next tile's coordinates before the last
+                        // flush, or starting half the workgroups half a tile late, changed nothing).
+                        auto flush_slot = [&](int r, int z, int offz, float f0, float f1, long long a) {
                             *reinterpret_cast<long long *>(sm.box + r * PZ + z) = 0ll;
                             if (p.dbg & 4) return;                     // (ablation: everything but the global atomics)
-                            int off; float sg;
-                            if (inside) {
-                                off = (tl.lo[0] + 4 * (r >> 5) + ps) * L.ss[0] + (tl.lo[1] + (r & 31)) * L.ss[1] + (tl.lo[2] + z) * L.ss[2];
-                                sg = 1.f;
-                            } else {
-                                const int2 rt = sm.rowtab[r];
-                                off = rt.x + sm.taboff[2][z];
-                                sg = __int_as_float(rt.y) * sm.tabsgn[2][z];
-                            }
+                            const int2 rt = sm.rowtab[r];
                             const int lo_ = (int)(a & 0xffffffffll);
                             const int hi_ = (int)((a - (long long)lo_) >> 32);
-                            if (lo_ != 0) __hip_atomic_fetch_add(vc0 + off, (float)lo_ * (inv0 * sg), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                            if (hi_ != 0) __hip_atomic_fetch_add(vc1 + off, (float)hi_ * (inv1 * sg), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            const int off = rt.x + offz;
+                            const float sg = __int_as_float(rt.y);
+                            if (lo_ != 0) __hip_atomic_fetch_add(vc0 + off, (float)lo_ * (f0 * sg), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            if (hi_ != 0) __hip_atomic_fetch_add(vc1 + off, (float)hi_ * (f1 * sg), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         };
+                        {
+                            const int z = tid & 31, rr = tid >> 5;
+                            if (z < tl.S[2]) {
+                                const int offz = sm.taboff[2][z];
+                                const float f0 = inv0 * sm.tabsgn[2][z], f1 = inv1 * sm.tabsgn[2][z];
+                                constexpr int RS = NT / 32, UF = 4;
+                                for (int r0 = rr; r0 < nrow; r0 += UF * RS) {
+                                    long long a[UF];
 #pragma unroll
-                        for (int u = 0; u < UF; ++u) if (a1[u] != 0) flush_slot(rr1 + u * RS, z1, a1[u]);
+                                    for (int u = 0; u < UF; ++u) {
+                                        const int r = r0 + u * RS;
+                                        a[u] = (r < nrow && (r & 31) < tl.S[1]) ? *reinterpret_cast<long long *>(sm.box + r * PZ + z) : 0ll;
+                                    }
 #pragma unroll
-                        for (int u = 0; u < UF2; ++u) if (a2[u] != 0) flush_slot(rr2 + u * RS2, z2, a2[u]);
+                                    for (int u = 0; u < UF; ++u) {
+                                        if (a[u] != 0) flush_slot(r0 + u * RS, z, offz, f0, f1, a[u]);
+                                        else if ((p.dbg & 16) && r0 + u * RS < nrow && ((r0 + u * RS) & 31) < tl.S[1])     // (ablation: an atomic for every slot of the box, touched or not)
+                                            flush_slot(r0 + u * RS, z, offz, f0, f1, 0x100000001ll);
+                                    }
+                                }
+                            }
+                        }
+                        if (tl.S[2] > 32) {
+                            const int z = 32 + (tid & 3), rr = tid >> 2;
+                            if (z < tl.S[2]) {
+                                const int offz = sm.taboff[2][z];
+                                const float f0 = inv0 * sm.tabsgn[2][z], f1 = inv1 * sm.tabsgn[2][z];
+                                for (int r = rr; r < nrow; r += NT / 4) {
+                                    if ((r & 31) >= tl.S[1]) continue;
+                                    const long long a = *reinterpret_cast<long long *>(sm.box + r * PZ + z);
+                                    if (a != 0) flush_slot(r, z, offz, f0, f1, a);
+                                }
+                            }
+                        }
                     }
                     __syncthreads();
                     prof_mark(2);
