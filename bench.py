@@ -196,13 +196,19 @@ def main():
         raise SystemExit(subprocess.call(cmd, env=env))
     if args.gpus != world:
         raise SystemExit("--gpus %d does not match WORLD_SIZE %d: fewer ranks than asked for" % (args.gpus, world))
-    device = torch.device("cuda", local_rank)
+    # INTERPOL_BENCH_BACKEND=gloo: a dry run of the N > 1 control flow on a box with fewer GPUs (ranks share devices, the
+    # collectives go through the host); never a measurement
+    backend = os.environ.get("INTERPOL_BENCH_BACKEND", "nccl")
+    device = torch.device("cuda", local_rank if backend == "nccl" else local_rank % max(torch.cuda.device_count(), 1))
     torch.cuda.set_device(device)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=device)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group(backend)
 
     import interpol
     from interpol import _hip
