@@ -184,6 +184,45 @@ def test_against_oracle_medium(dim, order, bound):
         oracle.set_threads(1)
 
 
+@pytest.mark.parametrize("bound", [0, 1, 2, 3, 4, 5, 6])
+def test_fast_kernels_against_oracle_all_bounds(bound):
+    """The round-2 fast paths straight against the oracle (not against the generic kernels), every boundary
+    condition x extrapolation mode, problems large enough for the tiles and with the deformation pushing samples
+    across the lattice border: class-sorted 3-D pull (orders 2, 3, two and three channels), the tiled push / count
+    next to it, and the lean 2-D tiles (every order pair from 1..3) for pull, push and count."""
+    oracle.set_threads(8)
+    try:
+        # 3-D: 36 x 30 x 40 samples (> 4096: tiles), lattice 33 x 38 x 29, sigma 2.5 around a scaled identity
+        for order, C in ((3, 2), (2, 3)):
+            ishape, oshape = (33, 38, 29), (36, 30, 40)
+            inp, grid = _rand_problem(1, C, ishape, oshape, 2.5, seed=300 + 10 * bound + order)
+            src = torch.randn([1, C, *oshape], generator=torch.Generator().manual_seed(9 + bound))
+            b, o = [bound], [order]
+            rtol, atol_rel = G.fp32_tol(o)
+            for ex in (1, 0, 2):
+                got = ops.grid_pull(inp.to(DEV), grid.to(DEV), b, o, ex).cpu().numpy()
+                G.assert_close(got, oracle.grid_pull(inp.double(), grid.double(), b, o, ex), rtol, atol_rel, ("pull3", order, bound, ex))
+                got = ops.grid_push(src.to(DEV), grid.to(DEV), list(ishape), b, o, ex).cpu().numpy()
+                G.assert_close(got, oracle.grid_push(src.double(), grid.double(), list(ishape), b, o, ex), rtol, atol_rel, ("push3", order, bound, ex))
+        # 2-D: 70 x 90 samples, lattice 61 x 83, mixed orders; the second dim takes the next boundary condition
+        for o0 in (1, 2, 3):
+            for o1 in (1, 2, 3):
+                ishape, oshape = (61, 83), (70, 90)
+                inp, grid = _rand_problem(2, 3, ishape, oshape, 2.5, seed=500 + 100 * bound + 10 * o0 + o1)
+                src = torch.randn([2, 3, *oshape], generator=torch.Generator().manual_seed(o0 + 3 * o1))
+                b, o = [bound, (bound + 3) % 7], [o0, o1]
+                rtol, atol_rel = G.fp32_tol(o)
+                ex = (o0 + o1 + bound) % 3
+                got = ops.grid_pull(inp.to(DEV), grid.to(DEV), b, o, ex).cpu().numpy()
+                G.assert_close(got, oracle.grid_pull(inp.double(), grid.double(), b, o, ex), rtol, atol_rel, ("pull2", o, b, ex))
+                got = ops.grid_push(src.to(DEV), grid.to(DEV), list(ishape), b, o, ex).cpu().numpy()
+                G.assert_close(got, oracle.grid_push(src.double(), grid.double(), list(ishape), b, o, ex), rtol, atol_rel, ("push2", o, b, ex))
+                got = ops.grid_count(grid.to(DEV), list(ishape), b, o, ex).cpu().numpy()
+                G.assert_close(got, oracle.grid_count(grid.double(), list(ishape), b, o, ex), rtol, atol_rel, ("count2", o, b, ex))
+    finally:
+        oracle.set_threads(1)
+
+
 def test_strided_and_broadcast_inputs():
     inp, grid = _rand_problem(2, 4, (20, 22, 24), (9, 10, 11), 1.5, seed=77)
     b, o = [3, 6, 1], [3, 2, 1]
