@@ -223,6 +223,42 @@ def test_fast_kernels_against_oracle_all_bounds(bound):
         oracle.set_threads(1)
 
 
+@pytest.mark.parametrize("dim,order", [(3, 1), (3, 3), (3, 5), (2, 2), (2, 3)])
+def test_fused_backward_kernels_against_oracle(dim, order):
+    """pull / push / count backward (grad_input AND grad_grid: the fused tiled kernels, the split push + grid-gradient
+    form of orders >= 4, the adjoint-operator shortcut when only one gradient is asked for) against the oracle's
+    compositions (pushpull.py:237-299), medium sizes, three boundary conditions, extrapolate 0 and 1."""
+    ishape, oshape = ((29, 34, 31), (36, 30, 40))[0][:dim], ((29, 34, 31), (36, 30, 40))[1][:dim]
+    if dim == 2:
+        ishape, oshape = (61, 83), (70, 90)
+    oracle.set_threads(8)
+    try:
+        for bound in (3, 6, 4):
+            inp, grid = _rand_problem(2, 2, ishape, oshape, 2.0, seed=40 * dim + order + bound)
+            gen = torch.Generator().manual_seed(17 + bound)
+            gout = torch.randn([2, 2, *oshape], generator=gen)
+            gvol = torch.randn([2, 2, *ishape], generator=gen)
+            b, o = [bound], [order]
+            rtol, atol_rel = G.fp32_tol(o)
+            for ex in (1, 0):
+                want_i, want_g = oracle.grid_pull_backward(gout.double(), inp.double(), grid.double(), b, o, ex)
+                gi, gg = ops.grid_pull_backward(gout.to(DEV), inp.to(DEV), grid.to(DEV), b, o, ex, need_inp=True, need_grid=True)
+                G.assert_close(gi.cpu().numpy(), want_i, rtol, atol_rel, ("pull bwd inp", dim, order, bound, ex))
+                G.assert_close(gg.cpu().numpy(), want_g, rtol, 2 * atol_rel, ("pull bwd grid", dim, order, bound, ex))
+                gi1, _ = ops.grid_pull_backward(gout.to(DEV), inp.to(DEV), grid.to(DEV), b, o, ex, need_inp=True, need_grid=False)
+                G.assert_close(gi1.cpu().numpy(), want_i, rtol, atol_rel, ("pull bwd inp only", dim, order, bound, ex))
+                # push: val lives on the sample grid, the target has the lattice's shape
+                want_i, want_g = oracle.grid_push_backward(gvol.double(), gout.double(), grid.double(), b, o, ex)
+                gi, gg = ops.grid_push_backward(gvol.to(DEV), gout.to(DEV), grid.to(DEV), b, o, ex, need_inp=True, need_grid=True)
+                G.assert_close(gi.cpu().numpy(), want_i, rtol, atol_rel, ("push bwd inp", dim, order, bound, ex))
+                G.assert_close(gg.cpu().numpy(), want_g, rtol, 2 * atol_rel, ("push bwd grid", dim, order, bound, ex))
+                want_g = oracle.grid_count_backward(gvol[:, :1].double(), grid.double(), b, o, ex)
+                gg = ops.grid_count_backward(gvol[:, :1].contiguous().to(DEV), grid.to(DEV), b, o, ex, need_grid=True)
+                G.assert_close(gg.cpu().numpy(), want_g, rtol, 2 * atol_rel, ("count bwd", dim, order, bound, ex))
+    finally:
+        oracle.set_threads(1)
+
+
 def test_strided_and_broadcast_inputs():
     inp, grid = _rand_problem(2, 4, (20, 22, 24), (9, 10, 11), 1.5, seed=77)
     b, o = [3, 6, 1], [3, 2, 1]
@@ -889,6 +925,39 @@ def test_push_bricks_matches_push(order, zoom, bound):
     fin = torch.isfinite(ref) & torch.isfinite(got)
     assert torch.equal(torch.isfinite(ref), torch.isfinite(got)) or float((torch.isfinite(ref) ^ torch.isfinite(got)).float().mean()) < 1e-3
     _same(torch.where(fin, got, torch.zeros_like(got)), torch.where(fin, ref, torch.zeros_like(ref)), 1e-5, "bricks non-finite")
+
+
+@pytest.mark.parametrize("bound", [0, 1, 2, 3, 4, 5, 6])
+def test_push_bricks_and_binned_push_against_oracle(bound):
+    """The two target-stationary organisations straight against the oracle, every boundary condition:
+    interpol_push_bricks (expanding field, push + count, border samples wrapping back into the lattice) and the
+    binned push (INTERPOL_FLAG_BINNED_SCATTER, rough field)."""
+    from interpol import _hip
+    oracle.set_threads(8)
+    try:
+        g = torch.Generator().manual_seed(70 + bound)
+        sshape, tshape = (14, 12, 16), [45, 40, 50]
+        src = torch.randn([2, 2, *sshape], generator=g)
+        grid = interpol.identity_grid(list(sshape)) * 3.2 - 1.5 + 1.2 * torch.randn(2, *sshape, 3, generator=g)
+        for order in (1, 3):
+            b, o = [bound], [order]
+            rtol, atol_rel = G.fp32_tol(o)
+            for ex in (1, 0):
+                got = _hip.push_bricks(src.to(DEV), grid.to(DEV), tshape, b * 3, o * 3, ex, with_count=True).cpu().numpy()
+                G.assert_close(got[:, :2], oracle.grid_push(src.double(), grid.double(), tshape, b, o, ex), rtol, atol_rel, ("bricks push", order, bound, ex))
+                G.assert_close(got[:, 2:], oracle.grid_count(grid.double(), tshape, b, o, ex), rtol, atol_rel, ("bricks count", order, bound, ex))
+        # binned push: 30 x 28 x 34 samples (> 4096), rough field (sigma 5)
+        sshape = (30, 28, 34)
+        src = torch.randn([1, 2, *sshape], generator=g)
+        grid = interpol.identity_grid(list(sshape))[None] + 5.0 * torch.randn(1, *sshape, 3, generator=g)
+        for order in (2, 3):
+            b, o = [bound], [order]
+            rtol, atol_rel = G.fp32_tol(o)
+            ex = (bound + order) % 3
+            got = _hip.scatter("push", src.to(DEV), grid.to(DEV), list(sshape), b * 3, o * 3, ex, flags=_hip.FLAG_BINNED_SCATTER).cpu().numpy()
+            G.assert_close(got, oracle.grid_push(src.double(), grid.double(), list(sshape), b, o, ex), rtol, atol_rel, ("binned push", order, bound, ex))
+    finally:
+        oracle.set_threads(1)
 
 
 def test_expanding_push_goes_through_bricks_at_api_level():
