@@ -714,12 +714,14 @@ __global__ __launch_bounds__(C::NT) void pull2_tiled(KParams p, const typename C
 #pragma unroll
                     for (int j = 0; j <= K; ++j) {
                         if (!C::ISO && j > L.k[1]) continue;
-                        const float2 *rp = bp + (ii * box.S[1] + j) * C::PS;
+                        const volatile __attribute__((address_space(3))) unsigned long long *rp =       // (single ds_read_b64: see pull1s_tiled)
+                            (const volatile __attribute__((address_space(3))) unsigned long long *)(bp + (ii * box.S[1] + j) * C::PS);
                         float q0 = 0.f, q1 = 0.f;
 #pragma unroll
                         for (int k = 0; k <= K; ++k) {
                             if (!C::ISO && k > L.k[2]) continue;
-                            const float2 t2 = rp[k];                       // ds_read_b64: both channels
+                            const unsigned long long raw = rp[k];          // ds_read_b64: both channels
+                            const float2 t2 = make_float2(__uint_as_float((unsigned)raw), __uint_as_float((unsigned)(raw >> 32)));
                             q0 = __builtin_fmaf(wz[k], t2.x, q0);
                             q1 = __builtin_fmaf(wz[k], t2.y, q1);
                         }
@@ -873,11 +875,15 @@ __global__ __launch_bounds__(C::NT) void pull1s_tiled(KParams p, const typename 
                     float p0 = 0.f;
 #pragma unroll
                     for (int j = 0; j <= K; ++j) {
-                        const float2 *rp = bp + (ii * box.S[1] + j) * C::PS;
+                        // (volatile LDS pointer: keeps single ds_read_b64 -- a compiler-merged ds_read2_b64 costs 25 clk per
+                        //  wave instruction against 2 x 7.6 with random lane bases, tools/microbench/lds_gather.hip)
+                        const volatile __attribute__((address_space(3))) unsigned long long *rp =
+                            (const volatile __attribute__((address_space(3))) unsigned long long *)(bp + (ii * box.S[1] + j) * C::PS);
                         float q0 = 0.f;
 #pragma unroll
                         for (int k = 0; k <= K; k += 2) {
-                            const float2 t2 = rp[k];                       // ds_read_b64: taps k and k + 1
+                            const unsigned long long raw = rp[k];          // ds_read_b64: taps k and k + 1
+                            const float2 t2 = make_float2(__uint_as_float((unsigned)raw), __uint_as_float((unsigned)(raw >> 32)));
                             q0 = __builtin_fmaf(wz[k], t2.x, q0);
                             if (k + 1 <= K) q0 = __builtin_fmaf(wz[k + 1 <= K ? k + 1 : K], t2.y, q0);
                         }
@@ -1026,11 +1032,13 @@ __global__ __launch_bounds__(C::NT) void grad1s_tiled(KParams p, const typename 
                     float pW = 0.f, pGy = 0.f, pGz = 0.f;
 #pragma unroll
                     for (int j = 0; j <= K; ++j) {
-                        const float2 *rp = bp + (ii * box.S[1] + j) * C::PS;
+                        const volatile __attribute__((address_space(3))) unsigned long long *rp =       // (single ds_read_b64: see pull1s_tiled)
+                            (const volatile __attribute__((address_space(3))) unsigned long long *)(bp + (ii * box.S[1] + j) * C::PS);
                         float rW = 0.f, rG = 0.f;
 #pragma unroll
                         for (int k = 0; k <= K; k += 2) {
-                            const float2 t2 = rp[k];                       // ds_read_b64: taps k and k + 1
+                            const unsigned long long raw = rp[k];          // ds_read_b64: taps k and k + 1
+                            const float2 t2 = make_float2(__uint_as_float((unsigned)raw), __uint_as_float((unsigned)(raw >> 32)));
                             rW = __builtin_fmaf(wz[k], t2.x, rW);
                             rG = __builtin_fmaf(gz_[k], t2.x, rG);
                             if (k + 1 <= K) {
@@ -1197,11 +1205,13 @@ __global__ __launch_bounds__(C::NT) void gradc1s_tiled(KParams p, const typename
                     float pW = 0.f, pGy = 0.f, pGz = 0.f;
 #pragma unroll
                     for (int j = 0; j <= K; ++j) {
-                        const float2 *rp = bp + (ii * box.S[1] + j) * C::PS;
+                        const volatile __attribute__((address_space(3))) unsigned long long *rp =       // (single ds_read_b64: see pull1s_tiled)
+                            (const volatile __attribute__((address_space(3))) unsigned long long *)(bp + (ii * box.S[1] + j) * C::PS);
                         float rW = 0.f, rG = 0.f;
 #pragma unroll
                         for (int k = 0; k <= K; k += 2) {
-                            const float2 t2 = rp[k];                       // ds_read_b64: taps k and k + 1
+                            const unsigned long long raw = rp[k];          // ds_read_b64: taps k and k + 1
+                            const float2 t2 = make_float2(__uint_as_float((unsigned)raw), __uint_as_float((unsigned)(raw >> 32)));
                             rW = __builtin_fmaf(wz[k], t2.x, rW);
                             rG = __builtin_fmaf(gz_[k], t2.x, rG);
                             if (k + 1 <= K) {
