@@ -670,7 +670,12 @@ def test_separable_grid_matches_dense_grid(dim, order):
         for op in ("pull", "grad"):
             a = _hip.gather(op, vol, sep, b, o, 1, flags=flags)
             d = _hip.gather(op, vol, dense, b, o, 1, flags=flags)
-            assert torch.equal(a, d), (op, dim, order, flags)
+            if order >= 4 and dim == 3 and flags != _hip.FLAG_NO_FASTPATH:
+                # the separable lattice runs the generic kernel at orders >= 4, the dense grid the tiles, whose two
+                # parity passes sum the x-taps in another order: equal to rounding, not bit for bit
+                _same(a, d, 2e-6, (op, dim, order, flags))
+            else:
+                assert torch.equal(a, d), (op, dim, order, flags)
         src = torch.randn([2, 4, *oshape], generator=torch.Generator().manual_seed(1)).to(DEV)
         a = _hip.scatter("push", src, sep, list(ishape), b, o, 0, flags=flags)
         d = _hip.scatter("push", src, dense, list(ishape), b, o, 0, flags=flags)
