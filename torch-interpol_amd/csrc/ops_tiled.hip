@@ -2025,6 +2025,8 @@ static int big_lds(F kernel)
 template <typename C> struct WideTile { using type = C; };
 template <typename T, bool ISO, int GM> struct WideTile<Cfg<T, 4, ISO, 3, 8, 8, 16, 1024, 32, GM>> { using type = Cfg<T, 4, ISO, 3, 16, 16, 16, 1024, 32, GM>; };
 template <typename T, bool ISO, int GM> struct WideTile<Cfg<T, 5, ISO, 3, 8, 8, 16, 1024, 32, GM>> { using type = Cfg<T, 5, ISO, 3, 16, 16, 16, 1024, 32, GM>; };
+template <typename T, bool ISO, int GM> struct WideTile<Cfg<T, 6, ISO, 3, 8, 8, 8, 512, 32, GM>> { using type = Cfg<T, 6, ISO, 3, 8, 16, 16, 512, 32, GM>; };
+template <typename T, bool ISO, int GM> struct WideTile<Cfg<T, 7, ISO, 3, 8, 8, 8, 512, 32, GM>> { using type = Cfg<T, 7, ISO, 3, 8, 16, 16, 512, 32, GM>; };
 
 template <typename C0>
 static int launch_pull2_impl(const interpol_problem *p, const KParams &k, const void *vol, const void *grid, void *val, hipStream_t st)
