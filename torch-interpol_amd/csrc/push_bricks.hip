@@ -185,6 +185,14 @@ __global__ __launch_bounds__(256) void bricks_walk(KParams p, Bricks bk, const f
                 if (cls == 1) {            // interior: no boundary condition to apply (the common case, inline)
                     bb[d][0] = i0[d] / BS; bb[d][1] = (i0[d] + p.order[d]) / BS;
                     nb_[d] = bb[d][1] > bb[d][0] ? 2 : 1;
+                } else if (p.bound[d] == B_REPLICATE || p.bound[d] == B_ZERO) {
+                    // clamping boundaries inline (the out-of-line table walk below cost 0.3 ms of each 0.6 ms pass at
+                    // config 4, where 4.6 % of the samples touch the border): the taps land on [lo, hi], <= 2 bricks
+                    const int n1 = p.vol_n[d] - 1, a = i0[d], e = i0[d] + p.order[d];
+                    const int lo_ = a < 0 ? 0 : (a > n1 ? n1 : a), hi_ = e < 0 ? 0 : (e > n1 ? n1 : e);
+                    const bool none = p.bound[d] == B_ZERO && (e < 0 || a > n1);          // every tap has sign 0
+                    bb[d][0] = lo_ / BS; bb[d][1] = hi_ / BS;
+                    nb_[d] = none ? 0 : (bb[d][1] > bb[d][0] ? 2 : 1);
                 } else {
                     nb_[d] = dim_bricks(p.bound[d], p.order[d], p.vol_n[d], i0[d], true, &bb[d][0], &bb[d][1]);
                     if (!FILL && nb_[d] == 3) bk.hdr[8] = 1;
@@ -361,14 +369,25 @@ __global__ __launch_bounds__(ACC_NT) void bricks_accumulate(KParams p, Bricks bk
 #pragma unroll
             for (int j = 0; j <= K; ++j) { jx[j] = i0[0] + j - bx * BS; jy[j] = i0[1] + j - by * BS; jz[j] = i0[2] + j - bz * BS; }
             if (cls == 2) {
+                // (clamping boundaries inline, the others through the out-of-line boundary switch)
+                auto wrap1 = [&](int d, int i, int &idx, float &sgn) {
+                    const int bd = p.bound[d], n = p.vol_n[d];
+                    if (bd == B_REPLICATE || bd == B_ZERO) {
+                        const bool in = (unsigned)i < (unsigned)n;
+                        idx = i < 0 ? 0 : (i >= n ? n - 1 : i);
+                        sgn = (bd == B_ZERO && !in) ? 0.f : 1.f;
+                    } else {
+                        const long long pk = wrap_outofline(bd, i, n);
+                        idx = (int)(pk & 0xffffffffll); sgn = (float)(int)(pk >> 32);
+                    }
+                };
 #pragma unroll
                 for (int j = 0; j <= K; ++j) {
-                    const long long px = wrap_outofline(p.bound[0], i0[0] + j, p.vol_n[0]);
-                    const long long py = wrap_outofline(p.bound[1], i0[1] + j, p.vol_n[1]);
-                    const long long pz = wrap_outofline(p.bound[2], i0[2] + j, p.vol_n[2]);
-                    jx[j] = (int)(px & 0xffffffffll) - bx * BS; wx[j] *= (float)(int)(px >> 32);
-                    jy[j] = (int)(py & 0xffffffffll) - by * BS; wy[j] *= (float)(int)(py >> 32);
-                    jz[j] = (int)(pz & 0xffffffffll) - bz * BS; wz[j] *= (float)(int)(pz >> 32);
+                    int ix_, iy_, iz_; float sx_, sy_, sz_;
+                    wrap1(0, i0[0] + j, ix_, sx_); wrap1(1, i0[1] + j, iy_, sy_); wrap1(2, i0[2] + j, iz_, sz_);
+                    jx[j] = ix_ - bx * BS; wx[j] *= sx_;
+                    jy[j] = iy_ - by * BS; wy[j] *= sy_;
+                    jz[j] = iz_ - bz * BS; wz[j] *= sz_;
                 }
             }
 #pragma unroll
