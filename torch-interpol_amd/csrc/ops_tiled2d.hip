@@ -297,7 +297,6 @@ __global__ __launch_bounds__(NT, 3) void pull2d(KParams p, const T *__restrict__
     __shared__ Smem sm;
     constexpr int NC = Slot<T>::NC;
     const Lattice L = lattice2d(p, (int)sizeof(T), K0, K1);
-    const int tid = threadIdx.x;
     const int64_t b = blockIdx.x / ntiles;
     const int tile = blockIdx.x % ntiles;
     const int oy0 = (tile / ntz) * TY, oz0 = (tile % ntz) * TZ;
