@@ -591,19 +591,30 @@ __global__ __launch_bounds__(NT, 4) void push2d(KParams p, const T *__restrict__
         __syncthreads();
         prof_mark(7);
         if (fixedpt && !(p.dbg & 2)) {
-            const int nslot = tl.S[0] * 64;
-            for (int e = tid; e < nslot; e += NT) {
-                const int y = e >> 6, z = e & 63;
-                if (z >= tl.S[1]) continue;
-                const long long a = (long long)sm.box[y * PZ + z];
-                if (a == 0) continue;
-                sm.box[y * PZ + z] = 0ull;
-                const int lo_ = (int)(a & 0xffffffffll);
-                const int hi_ = (int)((a - (long long)lo_) >> 32);
-                const int off = sm.taboff[0][y] + sm.taboff[1][z];
-                const float sg = sm.tabsgn[0][y] * sm.tabsgn[1][z];
-                if (lo_ != 0) __hip_atomic_fetch_add(vc0 + off, (float)lo_ * (inv0 * sg), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (hi_ != 0) __hip_atomic_fetch_add(vc1 + off, (float)hi_ * (inv1 * sg), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            // (a thread keeps its column z = tid & 63 and walks the rows four at a time: the slots of a batch are read
+            //  before the first is used, the column's table entries once)
+            const int z = tid & 63;
+            if (z < tl.S[1]) {
+                const int offz = sm.taboff[1][z];
+                const float sgz = sm.tabsgn[1][z];
+                constexpr int RS = NT / 64, UF = 4;
+                for (int y0 = tid >> 6; y0 < tl.S[0]; y0 += RS * UF) {
+                    long long a[UF];
+#pragma unroll
+                    for (int u = 0; u < UF; ++u) a[u] = y0 + u * RS < tl.S[0] ? (long long)sm.box[(y0 + u * RS) * PZ + z] : 0ll;
+#pragma unroll
+                    for (int u = 0; u < UF; ++u) {
+                        if (a[u] == 0) continue;
+                        const int y = y0 + u * RS;
+                        sm.box[y * PZ + z] = 0ull;
+                        const int lo_ = (int)(a[u] & 0xffffffffll);
+                        const int hi_ = (int)((a[u] - (long long)lo_) >> 32);
+                        const int off = sm.taboff[0][y] + offz;
+                        const float sg = sm.tabsgn[0][y] * sgz;
+                        if (lo_ != 0) __hip_atomic_fetch_add(vc0 + off, (float)lo_ * (inv0 * sg), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if (hi_ != 0) __hip_atomic_fetch_add(vc1 + off, (float)hi_ * (inv1 * sg), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                }
             }
         }
         __syncthreads();
