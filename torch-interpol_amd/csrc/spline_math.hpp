@@ -26,8 +26,10 @@ template <typename R> IP_HD R rabs(R x) { return x < R(0) ? -x : x; }
 // --------------------------------------------------------------------------
 // B-spline value (splines.py:30-80).  |t| <= (order+1)/2 is the caller's job.
 // --------------------------------------------------------------------------
+// `piece` >= 0 names the polynomial piece the caller KNOWS |t| to lie in (0 = innermost): the tiled kernels know it per
+// tap from the interval of the stencil coordinate, and with a compile-time piece the other pieces are never evaluated.
 template <typename R>
-IP_HD R bspline_w(int order, R t)
+IP_HD R bspline_w(int order, R t, int piece = -1)
 {
     R x = rabs(t);
     switch (order) {
@@ -35,11 +37,11 @@ IP_HD R bspline_w(int order, R t)
     case 1: return R(1) - x;
     case 2: {
         R u = R(1.5) - x;
-        return x < R(0.5) ? R(0.75) - x * x : R(0.5) * (u * u);
+        { const R lo = R(0.75) - x * x, up = R(0.5) * (u * u); return piece < 0 ? (x < R(0.5) ? lo : up) : (piece == 0 ? lo : up); }
     }
     case 3: {
         R u = R(2) - x;
-        return x < R(1) ? (x * x * (x - R(2)) * R(3) + R(4)) * R(1. / 6.) : (u * u * u) * R(1. / 6.);
+        { const R lo = (x * x * (x - R(2)) * R(3) + R(4)) * R(1. / 6.), up = (u * u * u) * R(1. / 6.); return piece < 0 ? (x < R(1) ? lo : up) : (piece == 0 ? lo : up); }
     }
     case 4: {
         R x2 = x * x;
@@ -47,7 +49,7 @@ IP_HD R bspline_w(int order, R t)
         R mid = x * (x * (x * (R(5) - x) * R(1. / 6.) - R(1.25)) + R(5. / 24.)) + R(55. / 96.);
         R u = x - R(2.5); u = u * u;
         R up = (u * u) * R(1. / 24.);
-        return x < R(0.5) ? lo : (x < R(1.5) ? mid : up);
+        return piece < 0 ? (x < R(0.5) ? lo : (x < R(1.5) ? mid : up)) : (piece == 0 ? lo : (piece == 1 ? mid : up));
     }
     case 5: {
         R x2 = x * x;
@@ -55,7 +57,7 @@ IP_HD R bspline_w(int order, R t)
         R mid = x * (x * (x * (x * (x * R(1. / 24.) - R(0.375)) + R(1.25)) - R(1.75)) + R(0.625)) + R(0.425);
         R u = R(3) - x; R u2 = u * u;
         R up = (u * u2 * u2) * R(1. / 120.);
-        return x < R(1) ? lo : (x < R(2) ? mid : up);
+        return piece < 0 ? (x < R(1) ? lo : (x < R(2) ? mid : up)) : (piece == 0 ? lo : (piece == 1 ? mid : up));
     }
     case 6: {
         R x2 = x * x;
@@ -64,7 +66,7 @@ IP_HD R bspline_w(int order, R t)
         R mu = x * (x * (x * (x * (x * (R(7. / 60.) - x * R(1. / 120.)) - R(0.65625)) + R(133. / 72.)) - R(2.5703125)) + R(1267. / 960.)) + R(1379. / 7680.);
         R u = x - R(3.5); R u3 = u * u * u;
         R up = (u3 * u3) * R(1. / 720.);
-        return x < R(0.5) ? lo : (x < R(1.5) ? ml : (x < R(2.5) ? mu : up));
+        return piece < 0 ? (x < R(0.5) ? lo : (x < R(1.5) ? ml : (x < R(2.5) ? mu : up))) : (piece == 0 ? lo : (piece == 1 ? ml : (piece == 2 ? mu : up)));
     }
     case 7: {
         R x2 = x * x;
@@ -73,7 +75,7 @@ IP_HD R bspline_w(int order, R t)
         R mu = x * (x * (x * (x * (x * (x * (x * R(1. / 720.) - R(1. / 36.)) + R(7. / 30.)) - R(19. / 18.)) + R(49. / 18.)) - R(23. / 6.)) + R(217. / 90.)) - R(139. / 630.);
         R u = R(4) - x; R u3 = u * u * u;
         R up = (u3 * u3 * u) * R(1. / 5040.);
-        return x < R(1) ? lo : (x < R(2) ? ml : (x < R(3) ? mu : up));
+        return piece < 0 ? (x < R(1) ? lo : (x < R(2) ? ml : (x < R(3) ? mu : up))) : (piece == 0 ? lo : (piece == 1 ? ml : (piece == 2 ? mu : up)));
     }
     default: return R(0);
     }
@@ -86,17 +88,17 @@ IP_HD R bspline_w(int order, R t)
 // all-linear path (iso1.py) uses the correct -1/+1 and never calls this.
 // --------------------------------------------------------------------------
 template <typename R>
-IP_HD R bspline_g(int order, R t)
+IP_HD R bspline_g(int order, R t, int piece = -1)
 {
     R s = t > R(0) ? R(1) : (t < R(0) ? R(-1) : R(0));
     R x = rabs(t);
     R r;
     switch (order) {
     case 1: r = R(1); break;
-    case 2: r = x < R(0.5) ? R(-2) * x : x - R(1.5); break;
+    case 2: { const R lo = R(-2) * x, up = x - R(1.5); r = piece < 0 ? (x < R(0.5) ? lo : up) : (piece == 0 ? lo : up); break; }
     case 3: {
         R u = R(2) - x;
-        r = x < R(1) ? x * (x * R(1.5) - R(2)) : R(-0.5) * (u * u);
+        { const R lo = x * (x * R(1.5) - R(2)), up = R(-0.5) * (u * u); r = piece < 0 ? (x < R(1) ? lo : up) : (piece == 0 ? lo : up); }
         break;
     }
     case 4: {
@@ -104,7 +106,7 @@ IP_HD R bspline_g(int order, R t)
         R lo = x * (x * x - R(1.25));
         R mid = x * (x * (x * R(-2. / 3.) + R(2.5)) - R(2.5)) + R(5. / 24.);
         R up = (u * u * u) * R(1. / 48.);
-        r = x < R(0.5) ? lo : (x < R(1.5) ? mid : up);
+        r = piece < 0 ? (x < R(0.5) ? lo : (x < R(1.5) ? mid : up)) : (piece == 0 ? lo : (piece == 1 ? mid : up));
         break;
     }
     case 5: {
@@ -112,7 +114,7 @@ IP_HD R bspline_g(int order, R t)
         R lo = x * (x * (x * (x * R(-5. / 12.) + R(1))) - R(1));
         R mid = x * (x * (x * (x * R(5. / 24.) - R(1.5)) + R(3.75)) - R(3.5)) + R(0.625);
         R up = (u * u) * R(-1. / 24.);
-        r = x < R(1) ? lo : (x < R(2) ? mid : up);
+        r = piece < 0 ? (x < R(1) ? lo : (x < R(2) ? mid : up)) : (piece == 0 ? lo : (piece == 1 ? mid : up));
         break;
     }
     case 6: {
@@ -122,7 +124,7 @@ IP_HD R bspline_g(int order, R t)
         R ml = x * (x * (x * (x * (x * R(0.125) - R(35. / 48.)) + R(1.3125)) - R(35. / 96.)) - R(0.7109375)) - R(7. / 768.);
         R mu = x * (x * (x * (x * (x * R(-1. / 20.) + R(7. / 12.)) - R(2.625)) + R(133. / 24.)) - R(5.140625)) + R(1267. / 960.);
         R up = (u * u2 * u2) * R(1. / 3840.);
-        r = x < R(0.5) ? lo : (x < R(1.5) ? ml : (x < R(2.5) ? mu : up));
+        r = piece < 0 ? (x < R(0.5) ? lo : (x < R(1.5) ? ml : (x < R(2.5) ? mu : up))) : (piece == 0 ? lo : (piece == 1 ? ml : (piece == 2 ? mu : up)));
         break;
     }
     case 7: {
@@ -132,7 +134,7 @@ IP_HD R bspline_g(int order, R t)
         R ml = x * (x * (x * (x * (x * (x * R(-7. / 240.) + R(3. / 10.)) - R(7. / 6.)) + R(2)) - R(7. / 6.)) - R(1. / 5.)) - R(7. / 90.);
         R mu = x * (x * (x * (x * (x * (x * R(7. / 720.) - R(1. / 6.)) + R(7. / 6.)) - R(38. / 9.)) + R(49. / 6.)) - R(23. / 3.)) + R(217. / 90.);
         R up = (u3 * u3) * R(-1. / 720.);
-        r = x < R(1) ? lo : (x < R(2) ? ml : (x < R(3) ? mu : up));
+        r = piece < 0 ? (x < R(1) ? lo : (x < R(2) ? ml : (x < R(3) ? mu : up))) : (piece == 0 ? lo : (piece == 1 ? ml : (piece == 2 ? mu : up)));
         break;
     }
     default: return R(0);
