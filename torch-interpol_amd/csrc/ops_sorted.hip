@@ -523,6 +523,269 @@ __global__ __launch_bounds__(NT, 4) void pull_sorted(KParams p, const T *__restr
 
 
 // ===========================================================================
+// Grid gradient of pull (backward of grid_pull with respect to the grid, pushpull.py:256-257):
+//   ggrid[b,o,d] = mask * sum_c gout[b,c,o] * d/dx_d pull(vol[b,c])(x_o)
+// The class-sorted gather of pull_sorted with the channels contracted per tap and three derivative sums.
+// ===========================================================================
+template <typename T, int K, int GM>
+__global__ __launch_bounds__(NT, 4) void gradc_sorted(KParams p, const T *__restrict__ vol, const T *__restrict__ gout, const float *__restrict__ grid,
+                                                      float *__restrict__ ggrid, int gx, int gy, int gz, int nty, int ntz, int ntiles, int nbatch)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    Smem &sm = *reinterpret_cast<Smem *>(smem_raw);
+    Lattice L;
+#pragma unroll
+    for (int d = 0; d < 3; ++d) { L.bound[d] = p.bound[d]; L.n[d] = p.vol_n[d]; L.ss[d] = p.vol_ss[d] / (int)sizeof(T); L.k[d] = K; }
+    L.lin = 0;
+    const WorkRange wr(ntiles * nbatch);
+    for (int work = wr.first; work < wr.end; work += wr.step) {
+        // the thread index is made opaque per tile: everything derived from it would otherwise be
+        // hoisted out of the persistent loop and held (spilled) across all phases
+        const int tid = opaque((int)threadIdx.x);
+        const int64_t b = work / ntiles;
+        int tile = work % ntiles;
+        const TileGeom g = tile_geom(tile, gx, gy, gz, nty, ntz);
+        prof_mark(-1);
+        Tile<K, GM> tl;
+        float cnext[VPT][3];
+        Tile<K, GM>::load(p, grid, b, g, tid, cnext);
+        tl.build(p, L, g, sm, tid, cnext);
+        const int nslow = sm.nslow < SLOWCAP ? sm.nslow : SLOWCAP;
+        // rows of the box are contiguous runs of the lattice's unit-stride dim, sign +1 throughout
+        // (dst1 has sign 0 at index 0 -- quirk B-3 -- so its run must start at 1)
+        const bool zlin = L.ss[2] == 1 && tl.lo[2] >= (L.bound[2] == B_DST1 ? 1 : 0) && tl.lo[2] + tl.S[2] <= L.n[2];
+        prof_mark(0);
+        float ag[VPT][3];                                            // grid gradient of the thread's sorted samples, all channels
+#pragma unroll
+        for (int j = 0; j < VPT; ++j) { ag[j][0] = 0.f; ag[j][1] = 0.f; ag[j][2] = 0.f; }
+
+        for (int c = 0; ; c += 2) {
+            const bool two = c + 1 < p.C;
+            const T *vc0 = vol + b * p.vol_sb + c * p.vol_sc;
+            const T *vc1 = two ? vc0 + p.vol_sc : vc0;
+            // grad_out of the pair in the natural order (coalesced), handed to the sorted lanes through the box
+            f2 go[VPT];
+            {
+                const T *gc0 = gout + b * p.val_sb + c * p.val_sc;
+                const T *gc1 = two ? gc0 + p.val_sc : gc0;
+                float2 *srcb = sm.box;
+                float g0[VPT], g1[VPT];
+#pragma unroll
+                for (int v = 0; v < VPT; ++v) {
+                    int ox, oy, oz;
+                    sample_pos(g, tid + NT * v, ox, oy, oz);
+                    const bool ok = ox < g.gx && oy < g.gy && oz < g.gz;
+                    const int64_t o = ok ? ((int64_t)ox * g.gy + oy) * g.gz + oz : 0;
+                    g0[v] = Cvt<float, T>::ld(gc0[o]);
+                    g1[v] = two ? Cvt<float, T>::ld(gc1[o]) : 0.f;
+                }
+                __syncthreads();                                     // the box is free (previous pair's readers are done)
+#pragma unroll
+                for (int v = 0; v < VPT; ++v) srcb[tid + NT * v] = make_float2(g0[v], g1[v]);
+                __syncthreads();
+#pragma unroll
+                for (int j = 0; j < VPT; ++j) {
+                    const float2 sv = srcb[(tl.key[j] >> 16) & (NS - 1)];
+                    const bool on = (tl.key[j] >> 29) & 1;
+                    go[j] = f2{ on ? sv.x : 0.f, on ? sv.y : 0.f };
+                }
+            }
+
+            for (int ps = 0; ps < 4; ++ps) {
+                const int tid = opaque((int)threadIdx.x);
+                const int npl = (tl.S[0] - ps + 3) >> 2;            // box planes x = ps, ps + 4, ...
+                // stage: slot (xq * 32 + y) * PZ + z = (sign * c0, sign * c1) of the wrapped lattice point
+                const int nrow = npl * CAPY;
+                const int omask = (p.dbg & 64) ? 0x3fff : -1;       // ablation: loads from a 64 KiB window
+                __syncthreads();                                     // the previous pass's readers are done
+                if (p.dbg & 1) {
+                } else if (zlin) {
+                    // the box's z-range lies inside the lattice and z is the unit-stride dim: rows are
+                    // contiguous runs.  A thread moves QUADS of 4 slots: two 16-byte loads (one per
+                    // channel), two 16-byte LDS stores.  (Narrow loads are what the vector L1 is slow at:
+                    // it looks up one tag per cycle whatever the width -- 4-byte loads of the row ends
+                    // alone cost as much as all the quads.)  ALL loads of the pass are issued before the
+                    // first store: one exposed round trip.
+                    const int nq = (tl.S[2] + 3) >> 2;               // quads per row; the last one is shifted to END at S_z
+                    constexpr int QPR = PZ / 4, NU = (NPL * CAPY * QPR + NT - 1) / NT;
+                    float4 a0[NU], a1[NU]; float sg[NU];
+#pragma unroll
+                    for (int u = 0; u < NU; ++u) {
+                        const int e = tid + NT * u, r = e / QPR, qd = e - r * QPR;
+                        const bool on = qd < nq && r < nrow && (r & 31) < tl.S[1];
+                        const int xr = on ? 4 * (r >> 5) + ps : 0, yr = on ? r & 31 : 0;
+                        const int zs = 4 * qd + 4 <= tl.S[2] ? 4 * qd : tl.S[2] - 4;
+                        const int off = (on ? sm.taboff[0][xr] + sm.taboff[1][yr] + tl.lo[2] + zs : 0) & omask;
+                        sg[u] = sm.tabsgn[0][xr] * sm.tabsgn[1][yr];
+                        a0[u] = ld4<T>(vc0 + off);
+                        a1[u] = ld4<T>(vc1 + off);
+                    }
+#pragma unroll
+                    for (int u = 0; u < NU; ++u) {
+                        const int e = tid + NT * u, r = e / QPR, qd = e - r * QPR;
+                        if (qd < nq && r < nrow && (r & 31) < tl.S[1]) {
+                            const int zs = 4 * qd + 4 <= tl.S[2] ? 4 * qd : tl.S[2] - 4;
+                            float2 *dst = sm.box + r * PZ + zs;
+                            if (!(zs & 1)) {
+                                reinterpret_cast<float4 *>(dst)[0] = make_float4(a0[u].x * sg[u], a1[u].x * sg[u], a0[u].y * sg[u], a1[u].y * sg[u]);
+                                reinterpret_cast<float4 *>(dst)[1] = make_float4(a0[u].z * sg[u], a1[u].z * sg[u], a0[u].w * sg[u], a1[u].w * sg[u]);
+                            } else {                                 // shifted last quad of an odd extent: 8-byte stores
+                                dst[0] = make_float2(a0[u].x * sg[u], a1[u].x * sg[u]); dst[1] = make_float2(a0[u].y * sg[u], a1[u].y * sg[u]);
+                                dst[2] = make_float2(a0[u].z * sg[u], a1[u].z * sg[u]); dst[3] = make_float2(a0[u].w * sg[u], a1[u].w * sg[u]);
+                            }
+                        }
+                    }
+                } else {
+                    // general case (the box wraps in z, or z is strided): slot by slot through the z table
+                    constexpr int U = 8;
+                    const int z = tid & 31;
+                    const bool zin = z < tl.S[2];
+                    const int oz = zin ? sm.taboff[2][z] : 0;
+                    const float sgz = zin ? sm.tabsgn[2][z] : 0.f;
+                    for (int r0 = tid >> 5; r0 < nrow; r0 += (NT / 32) * U) {
+                        float v0[U], v1[U], sg[U];
+#pragma unroll
+                        for (int u = 0; u < U; ++u) {
+                            const int r = r0 + u * (NT / 32);
+                            const bool on = zin && r < nrow && (r & 31) < tl.S[1];
+                            const int xr = on ? 4 * (r >> 5) + ps : 0, yr = on ? r & 31 : 0;
+                            const int off = on ? sm.taboff[0][xr] + sm.taboff[1][yr] + oz : 0;
+                            sg[u] = on ? sm.tabsgn[0][xr] * sm.tabsgn[1][yr] * sgz : 0.f;
+                            v0[u] = Cvt<float, T>::ld(vc0[off]);
+                            v1[u] = Cvt<float, T>::ld(vc1[off]);
+                        }
+#pragma unroll
+                        for (int u = 0; u < U; ++u) {
+                            const int r = r0 + u * (NT / 32);
+                            if (zin && r < nrow && (r & 31) < tl.S[1]) sm.box[r * PZ + z] = make_float2(v0[u] * sg[u], v1[u] * sg[u]);
+                        }
+                    }
+                    for (int e = tid; tl.S[2] > 32 && e < nrow * 4; e += NT) {      // slices 32 ... 35
+                        const int r = e >> 2, z2 = 32 + (e & 3);
+                        if ((r & 31) < tl.S[1] && z2 < tl.S[2]) {
+                            const int xr = 4 * (r >> 5) + ps, yr = r & 31;
+                            const int off = sm.taboff[0][xr] + sm.taboff[1][yr] + sm.taboff[2][z2];
+                            const float sgn = sm.tabsgn[0][xr] * sm.tabsgn[1][yr] * sm.tabsgn[2][z2];
+                            sm.box[r * PZ + z2] = make_float2(Cvt<float, T>::ld(vc0[off]) * sgn, Cvt<float, T>::ld(vc1[off]) * sgn);
+                        }
+                    }
+                }
+                __syncthreads();
+                prof_mark(1);
+                if (p.dbg & 2) continue;
+                const unsigned boxaddr = (unsigned)(size_t)(__attribute__((address_space(3))) void *)(sm.box);
+#pragma unroll
+                for (int j = 0; j < VPT; ++j) {
+                    // (opaque per pass: the weights are recomputed -- hoisted out of the pass loop they
+                    // would be 9 more live values per sample, i.e. spilled)
+                    float tx = tl.tx[j]; f2 tyz = tl.tyz[j];
+                    asm volatile("" : "+v"(tx), "+v"(tyz));
+                    const int key = tl.key[j];
+                    const int x0 = key & 31;
+                    const int i = (ps - x0) & 3;                     // the x-tap of this pass
+                    const int xq = (x0 + (K == 3 || i <= K ? i : 0)) >> 2;
+                    f2 t2[16];
+                    stencil_reads(boxaddr + 8u * (unsigned)(xq * PLANE + ((key >> 5) & 2047)), t2);
+                    const float wxi = weight_x<K>(tx, i), gxi = wgrad_x<K>(tx, i);
+                    f2 w[4], dq[4];
+                    weights_yz<K>(tyz, w);
+                    wgrads_yz<K>(tyz, dq);
+                    // channels contracted with grad_out FIRST (s = g0 v0 + g1 v1 per tap), then the three derivative sums
+                    // of a single image (pushpull.py:256-257)
+                    float pp = 0.f, ppy = 0.f, ppz = 0.f;
+#pragma unroll
+                    for (int jy = 0; jy <= K; ++jy) {
+                        float q = 0.f, qz = 0.f;
+#pragma unroll
+                        for (int k = 0; k <= K; ++k) {
+                            const float sgl = __builtin_fmaf(go[j].y, t2[4 * jy + k].y, go[j].x * t2[4 * jy + k].x);
+                            q = __builtin_fmaf(w[k].y, sgl, q);
+                            qz = __builtin_fmaf(dq[k].y, sgl, qz);
+                        }
+                        pp = __builtin_fmaf(w[jy].x, q, pp);
+                        ppy = __builtin_fmaf(dq[jy].x, q, ppy);
+                        ppz = __builtin_fmaf(w[jy].x, qz, ppz);
+                    }
+                    ag[j][0] = __builtin_fmaf(gxi, pp, ag[j][0]);
+                    ag[j][1] = __builtin_fmaf(wxi, ppy, ag[j][1]);
+                    ag[j][2] = __builtin_fmaf(wxi, ppz, ag[j][2]);
+                    asm volatile("" : "+v"(ag[j][0]), "+v"(ag[j][1]), "+v"(ag[j][2]));
+                }
+                prof_mark(2);
+            }
+            prof_mark(3);
+            if (c + 2 >= p.C) break;
+        }
+        {
+            // back to the natural order through LDS: (gx, gy, gz, -) per sample
+            __syncthreads();
+            const int tid = opaque((int)threadIdx.x);
+            float4 *outb = reinterpret_cast<float4 *>(sm.box);
+#pragma unroll
+            for (int j = 0; j < VPT; ++j) {
+                const int key = opaque(tl.key[j]);
+                if (!((key >> 29) & 1)) continue;
+                const float m = (float)((key >> 28) & 1);            // pushpull.py:256-257 with the mask of nd.py:139-140
+                outb[(key >> 16) & (NS - 1)] = make_float4(ag[j][0] * m, ag[j][1] * m, ag[j][2] * m, 0.f);
+            }
+            // out-of-box samples: one wave per sample, lanes = taps, all channels, straight from global memory
+            if (nslow > 0) {
+                const int wave = tid >> 6, lane = tid & 63;
+                for (int sidx = wave; sidx < nslow; sidx += NT / 64) {
+                    int ox, oy, oz; float x[3];
+                    sample_pos(g, sm.slow[sidx], ox, oy, oz);
+                    load_xyz<GM>(p, grid, b, g, ox, oy, oz, x);
+                    const int64_t o = ((int64_t)ox * g.gy + oy) * g.gz + oz;
+                    int off; float gr[3];
+                    tiled::tap_weight_t<K, K>(L, x[0], x[1], x[2], lane, &off, gr);
+                    float sgl = 0.f;
+                    if (lane < (K + 1) * (K + 1) * (K + 1))
+                        for (int cc = 0; cc < p.C; ++cc)
+                            sgl = __builtin_fmaf(Cvt<float, T>::ld(gout[b * p.val_sb + cc * p.val_sc + o]), Cvt<float, T>::ld(vol[b * p.vol_sb + cc * p.vol_sc + off]), sgl);
+                    const float m = inb_mask(p, x);
+                    const float a0 = wave_sum(gr[0] * sgl), a1 = wave_sum(gr[1] * sgl), a2 = wave_sum(gr[2] * sgl);
+                    if (lane == 0) outb[sm.slow[sidx]] = make_float4(a0 * m, a1 * m, a2 * m, 0.f);
+                }
+            }
+            // pathological tiles (slow list or hole table overflowed): the thread gathers its sample itself
+            if (tl.selfmask) {
+                for (int v = 0; v < VPT; ++v) {
+                    if (!((tl.selfmask >> v) & 1)) continue;
+                    int ox, oy, oz; float x[3];
+                    sample_pos(g, tid + NT * v, ox, oy, oz);
+                    load_xyz<GM>(p, grid, b, g, ox, oy, oz, x);
+                    const int64_t o = ((int64_t)ox * g.gy + oy) * g.gz + oz;
+                    int ii[3]; float tt[3];
+#pragma unroll
+                    for (int d = 0; d < 3; ++d) split(K, x[d], ii[d], tt[d]);
+                    const float m = inb_mask(p, x);
+                    float a[3] = { 0.f, 0.f, 0.f };
+                    for (int cc = 0; cc < p.C; ++cc) {
+                        const float gv = Cvt<float, T>::ld(gout[b * p.val_sb + cc * p.val_sc + o]);
+                        for (int d = 0; d < 3; ++d)
+                            a[d] = __builtin_fmaf(gv, tiled::gather_one_thread<T>(L, vol + b * p.vol_sb + cc * p.vol_sc, ii[0], ii[1], ii[2], tt[0], tt[1], tt[2], d), a[d]);
+                    }
+                    outb[tid + NT * v] = make_float4(a[0] * m, a[1] * m, a[2] * m, 0.f);
+                }
+            }
+            __syncthreads();
+            float *gb = ggrid + b * p.grid_sb;
+#pragma unroll
+            for (int v = 0; v < VPT; ++v) {
+                int ox, oy, oz;
+                sample_pos(g, tid + NT * v, ox, oy, oz);
+                if (!(ox < g.gx && oy < g.gy && oz < g.gz)) continue;
+                const int64_t o = ((int64_t)ox * g.gy + oy) * g.gz + oz;
+                const float4 r = outb[tid + NT * v];
+                gb[3 * o] = r.x; gb[3 * o + 1] = r.y; gb[3 * o + 2] = r.z;
+            }
+        }
+        __syncthreads();                                             // the next tile reuses the LDS tables / lists
+    }
+}
+
+
+// ===========================================================================
 // push / count : vol[b,c,tap] += w * mask * val[b,c,o]      (nd.py:146-213, pushpull.py:106-142)
 //
 // Same tiles, same sort.  The contributions of a tile are accumulated in the LDS box in FIXED
@@ -868,6 +1131,18 @@ static int launch_pull(const interpol_problem *p, const KParams &k, const void *
     return e == hipSuccess ? 1 : (int)e;
 }
 
+template <typename T, int K, int GM>
+static int launch_gradc(const interpol_problem *p, const KParams &k, const void *gout, const void *vol, const void *grid, void *ggrid, hipStream_t st)
+{
+    const int attr = big_lds<gradc_sorted<T, K, GM>>(sizeof(Smem));
+    if (attr) return attr;
+    const TileCount t(p);
+    hipLaunchKernelGGL((gradc_sorted<T, K, GM>), t.grid((int)p->batch), dim3(NT), sizeof(Smem), st,
+                       k, (const T *)vol, (const T *)gout, (const float *)grid, (float *)ggrid, t.gx, t.gy, t.gz, t.nty, t.ntz, t.ntiles(), (int)p->batch);
+    const hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 1 : (int)e;
+}
+
 // `vol` is the zero-filled (or accumulating) FLOAT target; val == NULL: count
 template <typename T, int K, int GM>
 static int launch_push(const interpol_problem *p, const KParams &k, const void *val, const void *grid, void *vol, hipStream_t st)
@@ -929,6 +1204,26 @@ int IP_SYM(try_sorted_pull_, IP_TSFX)(const interpol_problem *p, const KParams &
     }
     if (K == 3) return sorted::launch_pull<T, 3, 0>(p, k, vol, grid, val, st);
     return sorted::launch_pull<T, 2, 0>(p, k, vol, grid, val, st);
+}
+
+// grid gradient of pull alone (the image gradient of the same backward is a push of grad_out): dense grids and
+// displacement fields; 1 when it took the problem, 0 to decline
+int IP_SYM(try_sorted_gradc_, IP_TSFX)(const interpol_problem *p, const KParams &k, const void *gout, const void *vol, const void *grid, void *ggrid, hipStream_t st)
+{
+    const int K = sorted_order(p, k);
+    if (K < 0 || (k.dbg & 16)) return 0;
+    using T = IP_TT;
+    if (k.sep == 2) {
+        if constexpr (std::is_same<T, float>::value) {
+            if (K == 3) return sorted::launch_gradc<T, 3, 2>(p, k, gout, vol, grid, ggrid, st);
+            return sorted::launch_gradc<T, 2, 2>(p, k, gout, vol, grid, ggrid, st);
+        } else {
+            return 0;
+        }
+    }
+    if (k.sep) return 0;
+    if (K == 3) return sorted::launch_gradc<T, 3, 0>(p, k, gout, vol, grid, ggrid, st);
+    return sorted::launch_gradc<T, 2, 0>(p, k, gout, vol, grid, ggrid, st);
 }
 
 // Not the default yet: at BASELINE config 2 the class-sorted scatter ties with the natural-order

@@ -2312,6 +2312,7 @@ static bool linear_only(const interpol_problem *p, const KParams &k)
 // already cheaper than staging a tile (measured at config 5: 1.36 ms generic vs 2.19 ms tiled).
 // class-sorted tiles (ops_sorted.hip): 3-D, one order 2..3; declines everything else
 int IP_SYM(try_sorted_pull_, IP_TSFX)(const interpol_problem *p, const KParams &k, const void *vol, const void *grid, void *val, hipStream_t st);
+int IP_SYM(try_sorted_gradc_, IP_TSFX)(const interpol_problem *p, const KParams &k, const void *gout, const void *vol, const void *grid, void *ggrid, hipStream_t st);
 // lean 2-D tiles (ops_tiled2d.hip): per-dim orders 1..3
 int IP_SYM(try_tiled2d_pull_, IP_TSFX)(const interpol_problem *p, const KParams &k, const void *vol, const void *grid, void *val, hipStream_t st);
 int IP_SYM(try_tiled2d_push_, IP_TSFX)(const interpol_problem *p, const KParams &k, const void *val, const void *grid, void *vol, hipStream_t st);
@@ -2363,6 +2364,11 @@ int IP_SYM(try_fast_pullbwd_, IP_TSFX)(const interpol_problem *p, const KParams 
     // 2-D, grid gradient only: a gather like 2-D pull / grad -- the generic kernel is faster there
     // (config 5 shape: 1.7 vs 2.9 ms)
     if (p->dim != 3 && !gvol && !(p->flags & INTERPOL_FLAG_FORCE_TILED)) return 0;
+    if (p->dim == 3 && !gvol && ggrid) {
+        // grid gradient alone, 3-D quadratic / cubic: the class-sorted gather (ops_sorted.hip)
+        const int rc = IP_SYM(try_sorted_gradc_, IP_TSFX)(p, k, gout, vol, grid, ggrid, st);
+        if (rc != 0) return rc;
+    }
     IP_BY_ORDER(tiled::launch_pullbwd, >(p, k, gout, vol, grid, gvol, ggrid, gsb, gsc, st))
 }
 

@@ -185,6 +185,37 @@ __device__ __forceinline__ float weight_x(float t, int i)
     }
 }
 
+// derivatives of the same weights with respect to the stencil coordinate (splines.py:90-139 on the interval of `split`)
+template <int K>
+__device__ __forceinline__ void wgrads_yz(f2 t, f2 *g)
+{
+    if (K == 3) {
+        const f2 u = t - 1.f, v = 2.f - t;
+        g[0] = (v * v) * -0.5f;
+        g[3] = (u * u) * 0.5f;
+        g[1] = u * (u * 1.5f - 2.f);
+        g[2] = v * (v * -1.5f + 2.f);
+    } else {
+        // K == 2: w0 = a^2 / 2 (a = 1.5 - t), w1 = 0.75 - m^2 (m = t - 1), w2 = c^2 / 2 (c = t - 0.5)
+        g[0] = t - 1.5f;
+        g[1] = (t - 1.f) * -2.f;
+        g[2] = t - 0.5f;
+        g[3] = f2{ 0.f, 0.f };
+    }
+}
+template <int K>
+__device__ __forceinline__ float wgrad_x(float t, int i)
+{
+    const float x = t - (float)i, d = __builtin_fabsf(x);
+    const float s = x > 0.f ? 1.f : (x < 0.f ? -1.f : 0.f);
+    if (K == 3) {
+        const float e = 2.f - d;
+        return (d < 1.f ? d * __builtin_fmaf(d, 1.5f, -2.f) : -0.5f * (e * e)) * s;
+    } else {
+        return i > 2 ? 0.f : (d < 0.5f ? -2.f * d : d - 1.5f) * s;
+    }
+}
+
 // ---------------------------------------------------------------------------
 // Launch helpers
 // ---------------------------------------------------------------------------
