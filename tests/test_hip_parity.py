@@ -442,7 +442,11 @@ def test_tiled_scatter_matches_generic(dim, order, sigma):
         _same(gvol, want_gvol, 1e-5, ("bwd gvol", dim, bound, ex, order, sigma))
         _same(ggrid, want_ggrid, 2e-5 if order < 6 else 1e-4, ("bwd ggrid", dim, bound, ex, order, sigma))
         only_grid = _hip.pull_backward(src, vol, grid, b, o, ex, False, True)
-        assert only_grid[0] is None and torch.equal(only_grid[1], ggrid)
+        assert only_grid[0] is None
+        # (not bit for bit: in tiles whose slow list overflows -- the far-outside samples of this problem blow the box up --
+        #  WHICH samples are gathered tap-parallel by a wave and which by their own thread depends on the order of LDS atomics,
+        #  and the two paths sum the taps in different orders)
+        _same(only_grid[1], ggrid, 1e-6, ("bwd ggrid alone", dim, bound, ex, order, sigma))
         only_vol = _hip.pull_backward(src, vol, grid, b, o, ex, True, False)
         assert only_vol[1] is None
         _same(only_vol[0], want_gvol, 1e-5, "bwd gvol only")

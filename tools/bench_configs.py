@@ -34,7 +34,7 @@ def ident(sp, B, sigma, g, dtype=torch.float32):
 
 res = {}
 g = torch.Generator(device=dev).manual_seed(1234)
-which = sys.argv[1:] or ["1", "3", "4", "5", "f"]
+which = sys.argv[1:] or ["1", "3", "4", "5", "f", "b"]
 
 if "1" in which:    # cfg1: 1x1x128x128 linear zero identity
     x = torch.randn(1, 1, 128, 128, device=dev)
@@ -135,6 +135,20 @@ if "f" in which:    # row f3: affine lattice evaluated in the kernel vs a dense 
     dense = ag.dense().reshape(1, n, n, n, 3).expand(B, n, n, n, 3).contiguous()
     rec(res, "f3_affine_dense_grid_pull_256_cubic", timeit(lambda: interpol.grid_pull(x, dense, **kw), 3), vox, 2 * B * C * n ** 3 * 4 + vox * 12)
     del dense, x
+
+if "b" in which:    # backward of pull at config 2's shape (4x2x256^3 cubic dct2, sigma 2): the training step of a registration
+    import bench
+    from interpol import _hip
+    inp, grid = bench.make_inputs(4, 2, 256, 2.0, dev, 1234)
+    gout = torch.randn_like(inp)
+    vox = 4 * 256 ** 3
+    nb = vox * 12 + 3 * 4 * 2 * 256 ** 3 * 4
+    B3, O3 = [3] * 3, [3] * 3
+    rec(res, "cfg2shape_pull_backward_both_cubic", timeit(lambda: _hip.pull_backward(gout, inp, grid, B3, O3, 1, True, True), 3), vox, nb + vox * 12)
+    rec(res, "cfg2shape_pull_backward_grid_only_cubic", timeit(lambda: _hip.pull_backward(gout, inp, grid, B3, O3, 1, False, True), 3), vox, nb)
+    rec(res, "cfg2shape_pull_backward_grid_only_cubic_natural_tiles", timeit(lambda: _hip.pull_backward(gout, inp, grid, B3, O3, 1, False, True, flags=16 << 8), 3), vox, nb)
+    rec(res, "cfg2shape_grid_grad_cubic", timeit(lambda: _hip.gather("grad", inp, grid, B3, O3, 1), 3), vox, vox * 12 + 4 * 4 * 2 * 256 ** 3 * 4)
+    del inp, grid, gout
 
 if "r" in which:    # config 2 vs the roughness of the deformation: identity + sigma * iid noise (voxels)
     import bench

@@ -21,7 +21,7 @@ sq)
   PMC_OPS=pull,push timeout 1500 python $R/tools/pmc_sq.py $TAG/sq_cfg2 2.0 > $O/sq_cfg2.log 2>&1
   PMC_OPS=pull2d,push2d PMC_GROUPS=0,1,2,3,6,7,10,11,12,13 timeout 1500 python $R/tools/pmc_sq.py $TAG/sq_cfg5 2.0 > $O/sq_cfg5.log 2>&1 ;;
 other)
-  timeout 1500 python $R/tools/bench_configs.py 1 3 4 5 f r > $O/other_configs.json 2> $O/other_configs.err ;;
+  timeout 1500 python $R/tools/bench_configs.py 1 3 4 5 f b r > $O/other_configs.json 2> $O/other_configs.err ;;
 phase)
   export INTERPOL_HIP_LIB=$R/torch-interpol_amd/lib/libinterpol_hip_prof.so
   for s in 2.0 0.0; do

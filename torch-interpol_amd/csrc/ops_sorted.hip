@@ -770,14 +770,27 @@ __global__ __launch_bounds__(NT, 4) void gradc_sorted(KParams p, const T *__rest
             }
             __syncthreads();
             float *gb = ggrid + b * p.grid_sb;
+            if (g.ox0 + TS <= g.gx && g.oy0 + TS <= g.gy && g.oz0 + TS <= g.gz) {
+                // whole tile: four z-neighbours = 12 contiguous floats, three 16-byte stores
 #pragma unroll
-            for (int v = 0; v < VPT; ++v) {
-                int ox, oy, oz;
-                sample_pos(g, tid + NT * v, ox, oy, oz);
-                if (!(ox < g.gx && oy < g.gy && oz < g.gz)) continue;
-                const int64_t o = ((int64_t)ox * g.gy + oy) * g.gz + oz;
-                const float4 r = outb[tid + NT * v];
-                gb[3 * o] = r.x; gb[3 * o + 1] = r.y; gb[3 * o + 2] = r.z;
+                for (int u = 0; u < NS / 4 / NT; ++u) {
+                    const int qi = tid + NT * u;                     // quad: x = qi >> 6, y = (qi >> 2) & 15, z = 4 (qi & 3)
+                    const float4 r0 = outb[4 * qi], r1 = outb[4 * qi + 1], r2 = outb[4 * qi + 2], r3 = outb[4 * qi + 3];
+                    const int64_t o = ((int64_t)(g.ox0 + (qi >> 6)) * g.gy + (g.oy0 + ((qi >> 2) & 15))) * g.gz + (g.oz0 + 4 * (qi & 3));
+                    st4<float>(gb + 3 * o, make_float4(r0.x, r0.y, r0.z, r1.x));
+                    st4<float>(gb + 3 * o + 4, make_float4(r1.y, r1.z, r2.x, r2.y));
+                    st4<float>(gb + 3 * o + 8, make_float4(r2.z, r3.x, r3.y, r3.z));
+                }
+            } else {
+#pragma unroll
+                for (int v = 0; v < VPT; ++v) {
+                    int ox, oy, oz;
+                    sample_pos(g, tid + NT * v, ox, oy, oz);
+                    if (!(ox < g.gx && oy < g.gy && oz < g.gz)) continue;
+                    const int64_t o = ((int64_t)ox * g.gy + oy) * g.gz + oz;
+                    const float4 r = outb[tid + NT * v];
+                    gb[3 * o] = r.x; gb[3 * o + 1] = r.y; gb[3 * o + 2] = r.z;
+                }
             }
         }
         __syncthreads();                                             // the next tile reuses the LDS tables / lists

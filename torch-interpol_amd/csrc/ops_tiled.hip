@@ -2337,6 +2337,9 @@ int IP_SYM(try_fast_grad_, IP_TSFX)(const interpol_problem *p, const KParams &k,
 {
     if (p->dim != 3 && !(p->flags & INTERPOL_FLAG_FORCE_TILED)) return 0;
     if (linear_only(p, k)) return 0;
+    // (a class-sorted grad kernel -- three packed derivative sums per sample -- was tried: 3.3 vs 3.7 ms at config 2's shape
+    //  for cubic, sigma = 2, but 2.9 vs 2.5 ms at the identity and 3.7 vs 2.3 ms for quadratic: 48 accumulator registers
+    //  spill.  The grid-gradient kernel, which contracts the channels first, is the one that pays: ops_sorted.hip)
     IP_BY_ORDER(tiled::launch_gather, , true>(p, k, vol, grid, val, st))
 }
 
