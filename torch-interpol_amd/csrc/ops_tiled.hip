@@ -2313,6 +2313,7 @@ static bool linear_only(const interpol_problem *p, const KParams &k)
 // class-sorted tiles (ops_sorted.hip): 3-D, one order 2..3; declines everything else
 int IP_SYM(try_sorted_pull_, IP_TSFX)(const interpol_problem *p, const KParams &k, const void *vol, const void *grid, void *val, hipStream_t st);
 int IP_SYM(try_sorted_gradc_, IP_TSFX)(const interpol_problem *p, const KParams &k, const void *gout, const void *vol, const void *grid, void *ggrid, hipStream_t st);
+int IP_SYM(try_fast_pull_, IP_TSFX)(const interpol_problem *p, const KParams &k, const void *vol, const void *grid, void *val, hipStream_t st);
 // lean 2-D tiles (ops_tiled2d.hip): per-dim orders 1..3
 int IP_SYM(try_tiled2d_pull_, IP_TSFX)(const interpol_problem *p, const KParams &k, const void *vol, const void *grid, void *val, hipStream_t st);
 int IP_SYM(try_tiled2d_push_, IP_TSFX)(const interpol_problem *p, const KParams &k, const void *val, const void *grid, void *vol, hipStream_t st);
@@ -2379,6 +2380,19 @@ int IP_SYM(try_fast_pushbwd_, IP_TSFX)(const interpol_problem *p, const KParams 
                                        const void *grid, void *gval, void *ggrid, hipStream_t st)
 {
     if (p->dim != 3 && !(p->flags & INTERPOL_FLAG_FORCE_TILED)) return 0;
+    if (p->dim == 3 && val && ggrid) {
+        // 3-D quadratic / cubic: the grid gradient of push IS the grid gradient of pull with the roles of the two
+        // images swapped (pushpull.py:278-281 vs 256-257) -- the class-sorted gather -- and the value gradient a pull
+        // of grad_vol_out (4x2x256^3 cubic: 1.4 + 2.5 ms instead of 4.5 fused)
+        const int rc = IP_SYM(try_sorted_gradc_, IP_TSFX)(p, k, /* grad_out := */ val, /* vol := */ gvol_out, grid, ggrid, st);
+        if (rc != 0 && rc != 1) return rc;
+        if (rc == 1) {
+            if (!gval) return 1;
+            const int rc2 = IP_SYM(try_fast_pull_, IP_TSFX)(p, k, gvol_out, grid, gval, st);
+            if (rc2 != 0) return rc2;
+            ggrid = nullptr;                                         // (declined: the fused kernel below does the values only)
+        }
+    }
     IP_BY_ORDER(tiled::launch_pushbwd, >(p, k, gvol_out, val, grid, gval, ggrid, st))
 }
 #endif
