@@ -147,6 +147,7 @@ if "b" in which:    # backward of pull at config 2's shape (4x2x256^3 cubic dct2
     rec(res, "cfg2shape_pull_backward_both_cubic", timeit(lambda: _hip.pull_backward(gout, inp, grid, B3, O3, 1, True, True), 3), vox, nb + vox * 12)
     rec(res, "cfg2shape_pull_backward_grid_only_cubic", timeit(lambda: _hip.pull_backward(gout, inp, grid, B3, O3, 1, False, True), 3), vox, nb)
     rec(res, "cfg2shape_pull_backward_grid_only_cubic_natural_tiles", timeit(lambda: _hip.pull_backward(gout, inp, grid, B3, O3, 1, False, True, flags=16 << 8), 3), vox, nb)
+    rec(res, "cfg2shape_push_backward_both_cubic", timeit(lambda: _hip.push_backward(gout, inp, grid, B3, O3, 1, True, True), 3), vox, nb + vox * 12)
     rec(res, "cfg2shape_grid_grad_cubic", timeit(lambda: _hip.gather("grad", inp, grid, B3, O3, 1), 3), vox, vox * 12 + 4 * 4 * 2 * 256 ** 3 * 4)
     del inp, grid, gout
 
