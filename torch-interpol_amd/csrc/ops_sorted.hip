@@ -576,8 +576,8 @@ __global__ __launch_bounds__(NT, 4) void gradc_sorted(KParams p, const T *__rest
                     sample_pos(g, tid + NT * v, ox, oy, oz);
                     const bool ok = ox < g.gx && oy < g.gy && oz < g.gz;
                     const int64_t o = ok ? ((int64_t)ox * g.gy + oy) * g.gz + oz : 0;
-                    g0[v] = Cvt<float, T>::ld(gc0[o]);
-                    g1[v] = two ? Cvt<float, T>::ld(gc1[o]) : 0.f;
+                    g0[v] = gout ? Cvt<float, T>::ld(gc0[o]) : 1.f;             // (no grad_out: ones -- the backward of count)
+                    g1[v] = two ? (gout ? Cvt<float, T>::ld(gc1[o]) : 1.f) : 0.f;
                 }
                 __syncthreads();                                     // the box is free (previous pair's readers are done)
 #pragma unroll
@@ -741,7 +741,7 @@ __global__ __launch_bounds__(NT, 4) void gradc_sorted(KParams p, const T *__rest
                     float sgl = 0.f;
                     if (lane < (K + 1) * (K + 1) * (K + 1))
                         for (int cc = 0; cc < p.C; ++cc)
-                            sgl = __builtin_fmaf(Cvt<float, T>::ld(gout[b * p.val_sb + cc * p.val_sc + o]), Cvt<float, T>::ld(vol[b * p.vol_sb + cc * p.vol_sc + off]), sgl);
+                            sgl = __builtin_fmaf(gout ? Cvt<float, T>::ld(gout[b * p.val_sb + cc * p.val_sc + o]) : 1.f, Cvt<float, T>::ld(vol[b * p.vol_sb + cc * p.vol_sc + off]), sgl);
                     const float m = inb_mask(p, x);
                     const float a0 = wave_sum(gr[0] * sgl), a1 = wave_sum(gr[1] * sgl), a2 = wave_sum(gr[2] * sgl);
                     if (lane == 0) outb[sm.slow[sidx]] = make_float4(a0 * m, a1 * m, a2 * m, 0.f);
@@ -761,7 +761,7 @@ __global__ __launch_bounds__(NT, 4) void gradc_sorted(KParams p, const T *__rest
                     const float m = inb_mask(p, x);
                     float a[3] = { 0.f, 0.f, 0.f };
                     for (int cc = 0; cc < p.C; ++cc) {
-                        const float gv = Cvt<float, T>::ld(gout[b * p.val_sb + cc * p.val_sc + o]);
+                        const float gv = gout ? Cvt<float, T>::ld(gout[b * p.val_sb + cc * p.val_sc + o]) : 1.f;
                         for (int d = 0; d < 3; ++d)
                             a[d] = __builtin_fmaf(gv, tiled::gather_one_thread<T>(L, vol + b * p.vol_sb + cc * p.vol_sc, ii[0], ii[1], ii[2], tt[0], tt[1], tt[2], d), a[d]);
                     }
