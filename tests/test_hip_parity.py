@@ -452,6 +452,32 @@ def test_tiled_scatter_matches_generic(dim, order, sigma):
         _same(only_vol[0], want_gvol, 1e-5, "bwd gvol only")
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
+def test_tiled2d_grid_gradient_matches_generic(dtype):
+    """2-D backward passes (pull, push and count: the lean gradc2d tile kernel, channels contracted with grad_out per tap)
+    vs the generic fused kernels: mixed orders, every bound, the three extrapolate modes, ragged tiles, several channel counts."""
+    from interpol import _hip
+    gen = torch.Generator().manual_seed(23)
+    for (B, C, shp, gshp) in [(2, 3, (70, 90), (70, 90)), (1, 5, (40, 130), (100, 77)), (2, 1, (33, 65), (90, 70))]:
+        x = torch.randn([B, C, *shp], generator=gen).to(DEV).to(dtype)
+        v = torch.randn([B, C, *gshp], generator=gen).to(DEV).to(dtype)
+        gv = torch.randn([B, C, *shp], generator=gen).to(DEV).to(dtype)
+        scale = (torch.tensor(shp) - 1.0) / (torch.tensor(gshp) - 1.0)
+        for sigma in (0.0, 2.0, 12.0):
+            g = (interpol.identity_grid(gshp)[None] * scale + sigma * torch.randn([B, *gshp, 2], generator=gen)).to(DEV)
+            for o in ([1, 3], [2, 3], [3, 1], [2, 2]):
+                for bound in range(7):
+                    ex = (o[0] + bound) % 3
+                    b = [bound, (bound + 2) % 7]
+                    fast = _hip.pull_backward(v, x, g, b, o, ex, False, True)[1]
+                    slow = _hip.pull_backward(v, x, g, b, o, ex, False, True, flags=_hip.FLAG_NO_FASTPATH)[1]
+                    _same(fast, slow, 3e-6, ("pull bwd 2d", dtype, C, sigma, o, b, ex))
+                    fast = _hip.push_backward(gv, v, g, b, o, ex, True, True)
+                    slow = _hip.push_backward(gv, v, g, b, o, ex, True, True, flags=_hip.FLAG_NO_FASTPATH)
+                    _same(fast[1], slow[1], 3e-6, ("push bwd 2d grid", dtype, C, sigma, o, b, ex))
+                    _same(fast[0].float(), slow[0].float(), 1e-2 if dtype != torch.float32 else 1e-5, ("push bwd 2d val", dtype, C, sigma, o, b, ex))
+
+
 def test_tiled_scatter_nonfinite_sources_keep_ieee_semantics():
     from interpol import _hip
     vol, grid, tshape, sshape = _tiled_problem(3, 1.0, seed=5)

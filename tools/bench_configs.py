@@ -83,6 +83,13 @@ if "5" in which:    # cfg5: 2-D, orders [2,3,5]->[2,3], bounds [dct1,dst2,zero]-
     xf = x.float()
     rec(res, "cfg5_pull_f32_o23", timeit(lambda: interpol.grid_pull(xf, gr, **kw), 3), vox, vox * (8 + C * 4) + B * C * n * n * 4)
     rec(res, "cfg5_prefilter_bf16_o23_dct1dct2", timeit(lambda: interpol.spline_coeff_nd(x, [2, 3], ["dct1", "dct2"], 2), 3), vox, 2 * 2 * B * C * n * n * 2)
+    from interpol import _hip
+    b2, o2 = [2, 5], [2, 3]
+    nb = vox * (16 + 2 * C * 2)
+    rec(res, "cfg5_pull_backward_grid_only_bf16_o23", timeit(lambda: _hip.pull_backward(x, x, gr, b2, o2, 1, False, True), 3), vox, nb)
+    rec(res, "cfg5_pull_backward_grid_only_bf16_o23_generic", timeit(lambda: _hip.pull_backward(x, x, gr, b2, o2, 1, False, True, flags=_hip.FLAG_NO_FASTPATH), 3), vox, nb)
+    rec(res, "cfg5_pull_backward_both_bf16_o23", timeit(lambda: _hip.pull_backward(x, x, gr, b2, o2, 1, True, True), 3), vox, nb + vox * C * 4)
+    rec(res, "cfg5_push_backward_both_bf16_o23", timeit(lambda: _hip.push_backward(x, x, gr, b2, o2, 1, True, True), 3), vox, nb + vox * C * 2)
     rec(res, "cfg5_prefilter_f32_o23_dct1dct2", timeit(lambda: interpol.spline_coeff_nd(xf, [2, 3], ["dct1", "dct2"], 2), 3), vox, 2 * 2 * B * C * n * n * 4)
 
 if "f" in which:    # row f2: resize / restrict on a separable lattice vs the same call with a dense grid tensor

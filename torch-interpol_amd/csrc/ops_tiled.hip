@@ -2317,6 +2317,7 @@ int IP_SYM(try_fast_pull_, IP_TSFX)(const interpol_problem *p, const KParams &k,
 // lean 2-D tiles (ops_tiled2d.hip): per-dim orders 1..3
 int IP_SYM(try_tiled2d_pull_, IP_TSFX)(const interpol_problem *p, const KParams &k, const void *vol, const void *grid, void *val, hipStream_t st);
 int IP_SYM(try_tiled2d_push_, IP_TSFX)(const interpol_problem *p, const KParams &k, const void *val, const void *grid, void *vol, hipStream_t st);
+int IP_SYM(try_tiled2d_gradc_, IP_TSFX)(const interpol_problem *p, const KParams &k, const void *gout, const void *vol, const void *grid, void *ggrid, hipStream_t st);
 
 #if !defined(IP_TPART) || IP_TPART == 1
 int IP_SYM(try_fast_pull_, IP_TSFX)(const interpol_problem *p, const KParams &k, const void *vol, const void *grid, void *val, hipStream_t st)
@@ -2365,8 +2366,13 @@ int IP_SYM(try_fast_push_, IP_TSFX)(const interpol_problem *p, const KParams &k,
 int IP_SYM(try_fast_pullbwd_, IP_TSFX)(const interpol_problem *p, const KParams &k, const void *gout, const void *vol, const void *grid,
                                        void *gvol, void *ggrid, int64_t gsb, int64_t gsc, hipStream_t st)
 {
-    // 2-D, grid gradient only: a gather like 2-D pull / grad -- the generic kernel is faster there
-    // (config 5 shape: 1.7 vs 2.9 ms)
+    if (p->dim == 2 && !gvol && ggrid) {
+        // 2-D, grid gradient only, orders 1..3: the lean tile with the channels contracted per tap (ops_tiled2d.hip)
+        const int rc = IP_SYM(try_tiled2d_gradc_, IP_TSFX)(p, k, gout, vol, grid, ggrid, st);
+        if (rc != 0) return rc;
+    }
+    // 2-D, grid gradient only, other orders: a gather like 2-D pull / grad -- the generic kernel is faster than the
+    // round-1 tiles there (config 5 shape: 1.7 vs 2.9 ms)
     if (p->dim != 3 && !gvol && !(p->flags & INTERPOL_FLAG_FORCE_TILED)) return 0;
     if (p->dim == 3 && !gvol && ggrid) {
         // grid gradient alone, 3-D quadratic / cubic: the class-sorted gather (ops_sorted.hip)
@@ -2379,6 +2385,17 @@ int IP_SYM(try_fast_pullbwd_, IP_TSFX)(const interpol_problem *p, const KParams 
 int IP_SYM(try_fast_pushbwd_, IP_TSFX)(const interpol_problem *p, const KParams &k, const void *gvol_out, const void *val,
                                        const void *grid, void *gval, void *ggrid, hipStream_t st)
 {
+    if (p->dim == 2 && ggrid && (val || !gval)) {
+        // 2-D, orders 1..3: the same split as in 3-D below, with the lean tiles
+        const int rc = IP_SYM(try_tiled2d_gradc_, IP_TSFX)(p, k, val, gvol_out, grid, ggrid, st);
+        if (rc != 0 && rc != 1) return rc;
+        if (rc == 1) {
+            if (!gval) return 1;
+            const int rc2 = IP_SYM(try_fast_pull_, IP_TSFX)(p, k, gvol_out, grid, gval, st);
+            if (rc2 != 0) return rc2;
+            ggrid = nullptr;
+        }
+    }
     if (p->dim != 3 && !(p->flags & INTERPOL_FLAG_FORCE_TILED)) return 0;
     if (p->dim == 3 && ggrid && (val || !gval)) {                  // (val == NULL: the backward of count, grad_out of ones)
         // 3-D quadratic / cubic: the grid gradient of push IS the grid gradient of pull with the roles of the two

@@ -85,6 +85,23 @@ __device__ __forceinline__ void wts(float t, float *w)
     }
 }
 
+// derivatives of the same weights with respect to t (splines.py:90-139; order 1 outside the all-linear mode keeps the
+// reference's sign quirk B-4 through tiled::wgrad1)
+template <int K>
+__device__ __forceinline__ void dwts(int lin, float t, float *g)
+{
+    if (K == 3) {
+        const float u = t - 1.f, v = 2.f - t;
+        g[0] = -0.5f * (v * v); g[3] = 0.5f * (u * u);
+        g[1] = u * __builtin_fmaf(u, 1.5f, -2.f);
+        g[2] = v * __builtin_fmaf(v, -1.5f, 2.f);
+    } else if (K == 2) {
+        g[0] = t - 1.5f; g[1] = (t - 1.f) * -2.f; g[2] = t - 0.5f; g[3] = 0.f;
+    } else {
+        g[0] = tiled::wgrad1(lin, 1, t, 0); g[1] = tiled::wgrad1(lin, 1, t, 1); g[2] = 0.f; g[3] = 0.f;
+    }
+}
+
 // `split` of tile_common.hpp with the order known and a one-instruction clamp
 template <int K>
 __device__ __forceinline__ void splitk(float x, int &i0, float &t)
@@ -457,6 +474,199 @@ __global__ __launch_bounds__(NT, 3) void pull2d(KParams p, const T *__restrict__
 }
 
 // ---------------------------------------------------------------------------
+// grid gradient of pull (pushpull.py:256-257), 2-D: ggrid[b,o,d] = mask * sum_c gout[b,c,o] * d/dx_d pull(vol[b,c])(x_o);
+// gout == NULL: ones (the backward of count).  The tile of pull2d with the channels contracted per tap.
+// ---------------------------------------------------------------------------
+template <typename T, int K0, int K1, int GM>
+__global__ __launch_bounds__(NT, 3) void gradc2d(KParams p, const T *__restrict__ vol, const T *__restrict__ gout, const float *__restrict__ grid,
+                                              float *__restrict__ ggrid, int gy, int gz, int ntz, int ntiles)
+{
+    __shared__ Smem sm;
+    constexpr int NC = Slot<T>::NC;
+    const Lattice L = lattice2d(p, (int)sizeof(T), K0, K1);
+    const int64_t b = blockIdx.x / ntiles;
+    const int tile = blockIdx.x % ntiles;
+    const int oy0 = (tile / ntz) * TY, oz0 = (tile % ntz) * TZ;
+    Tile2<K0, K1, GM> tl;
+    prof_mark(-1);
+    {
+        float c[VPT][2];
+        Tile2<K0, K1, GM>::load(p, grid, b, gy, gz, oy0, oz0, c);
+        tl.build(p, L, c, gy, gz, oy0, oz0, sm);
+    }
+    prof_mark(0);
+    // the box's columns are contiguous runs of the unit-stride dim, sign +1 (dst1: sign 0 at index 0, quirk B-3)
+    const bool zlin = L.ss[2] == 1 && tl.S[1] >= 4 && tl.lo[1] >= (L.bound[2] == B_DST1 ? 1 : 0) && tl.lo[1] + tl.S[1] <= L.n[2];
+    float gg[VPT][2];                                            // grid gradient of the thread's pixels, all channels
+#pragma unroll
+    for (int v = 0; v < VPT; ++v) { gg[v][0] = 0.f; gg[v][1] = 0.f; }
+    for (int cg = 0; cg < p.C; cg += NC) {
+        // (opaque copies: nothing below is to be hoisted out of this loop and kept -- spilled -- across it)
+        const int tid = opaque((int)threadIdx.x);
+        const int nc = p.C - cg < NC ? p.C - cg : NC;
+        const T *vb = vol + b * p.vol_sb + cg * p.vol_sc;
+        // stage the box: slot (y, z) = the nc channels of the wrapped lattice point, sign applied
+        if (p.dbg & 1) { } else
+        if (zlin) {
+            // rows are contiguous runs of the lattice: quads of 4 slots, one wide load per channel; all the
+            // loads of the tile are in flight together
+            // (values travel as stored: the boundary sign is a flip / clear of bits, no conversion; channels
+            //  the image does not have repeat channel 0 and are never stored)
+            {
+                const int nq = (tl.S[1] + 3) >> 2;                    // the last quad is shifted to END at S_z
+                constexpr int QPR = CAP / 4, NU = (CAP * QPR + NT - 1) / NT;
+                typename Slot<T>::RawQ a[NU][NC]; float sg[NU];
+#pragma unroll
+                for (int u = 0; u < NU; ++u) {
+                    const int e = tid + NT * u, y = e / QPR, qd = e - y * QPR;
+                    const bool on = y < tl.S[0] && qd < nq;
+                    const int zs = 4 * qd + 4 <= tl.S[1] ? 4 * qd : tl.S[1] - 4;
+                    const unsigned off = on ? (unsigned)(sm.taboff[0][y] + tl.lo[1] + zs) : 0u;
+                    sg[u] = on ? sm.tabsgn[0][y] : 0.f;
+#pragma unroll
+                    for (int ch = 0; ch < NC; ++ch) a[u][ch] = Slot<T>::ldq(vb + (ch < nc ? ch : 0) * p.vol_sc + off);
+                }
+#pragma unroll
+                for (int u = 0; u < NU; ++u) {
+                    const int e = tid + NT * u, y = e / QPR, qd = e - y * QPR;
+                    if (!(y < tl.S[0] && qd < nq)) continue;
+                    const int zs = 4 * qd + 4 <= tl.S[1] ? 4 * qd : tl.S[1] - 4;
+                    unsigned w[4][2];
+                    Slot<T>::slots(a[u], w);
+                    unsigned long long s4[4];
+                    const unsigned flip = sg[u] < 0.f ? Slot<T>::SIGN : 0u, m = sg[u] != 0.f ? 0xffffffffu : 0u;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) s4[k] = ((unsigned long long)((w[k][1] ^ flip) & m) << 32) | ((w[k][0] ^ flip) & m);
+                    unsigned long long *d = sm.box + y * PZ + zs;
+                    if (!(zs & 1)) { reinterpret_cast<ulonglong2 *>(d)[0] = ulonglong2{ s4[0], s4[1] }; reinterpret_cast<ulonglong2 *>(d)[1] = ulonglong2{ s4[2], s4[3] }; }
+                    else { d[0] = s4[0]; d[1] = s4[1]; d[2] = s4[2]; d[3] = s4[3]; }
+                }
+            }
+        } else {
+            // general case (the box wraps, or strided columns): slot by slot through the tables, U at a time
+            const int nslot = tl.S[0] * 64;
+            constexpr int U = 4;
+            for (int e0 = tid; e0 < nslot; e0 += NT * U) {
+                float v[U][4]; float sg[U]; bool on[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const int e = e0 + NT * u;
+                    const int y = e >> 6, z = e & 63;
+                    on[u] = e < nslot && z < tl.S[1];
+                    const int off = on[u] ? sm.taboff[0][y] + sm.taboff[1][z] : 0;
+                    sg[u] = on[u] ? sm.tabsgn[0][y] * sm.tabsgn[1][z] : 0.f;
+#pragma unroll
+                    for (int ch = 0; ch < NC; ++ch) v[u][ch] = Cvt<float, T>::ld(vb[(ch < nc ? ch : 0) * p.vol_sc + off]);
+                }
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const int e = e0 + NT * u;
+                    if (!on[u]) continue;
+#pragma unroll
+                    for (int ch = 0; ch < NC; ++ch) v[u][ch] = ch < nc ? v[u][ch] * sg[u] : 0.f;
+                    sm.box[(e >> 6) * PZ + (e & 63)] = Slot<T>::pack(v[u]);
+                }
+            }
+        }
+        __syncthreads();
+        prof_mark(1);
+        // grad_out of the group's channels at the thread's four pixels (ones: the backward of count)
+        float4 gv[NC];
+        {
+            int oy, oz;
+            px_pos(tid, 0, oy0, oz0, oy, oz);
+#pragma unroll
+            for (int ch = 0; ch < NC; ++ch) {
+                gv[ch] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (ch >= nc) continue;
+                if (!gout) { gv[ch] = make_float4(1.f, 1.f, 1.f, 1.f); continue; }
+                const T *gp = gout + b * p.val_sb + (cg + ch) * p.val_sc + (int64_t)(oy < gy ? oy : gy - 1) * gz;
+                if (tl.valid == 0xf) gv[ch] = ld4<T>(gp + oz);
+                else {
+                    float r[4];
+#pragma unroll
+                    for (int v = 0; v < VPT; ++v) r[v] = Cvt<float, T>::ld(gp[oz + v < gz ? oz + v : gz - 1]);
+                    gv[ch] = make_float4(r[0], r[1], r[2], r[3]);
+                }
+            }
+        }
+        // channels contracted with grad_out per tap, then the two derivative sums of that single image (pushpull.py:256-257)
+#pragma unroll
+        for (int v = 0; v < VPT; ++v) {
+            float w0[4], w1[4], d0[4], d1[4];
+            float t0 = tl.t0[v], t1 = tl.t1[v];
+            asm volatile("" : "+v"(t0), "+v"(t1));
+            if (L.lin) { w0[0] = 1.f - t0; w0[1] = t0; w1[0] = 1.f - t1; w1[1] = t1; w0[2] = w0[3] = w1[2] = w1[3] = 0.f; }
+            else { wts<K0>(t0, w0); wts<K1>(t1, w1); }
+            dwts<K0>(L.lin, t0, d0); dwts<K1>(L.lin, t1, d1);
+            float g[4];
+#pragma unroll
+            for (int ch = 0; ch < NC; ++ch) g[ch] = v == 0 ? gv[ch].x : (v == 1 ? gv[ch].y : (v == 2 ? gv[ch].z : gv[ch].w));
+            const volatile __attribute__((address_space(3))) unsigned long long *bp =
+                (const volatile __attribute__((address_space(3))) unsigned long long *)(sm.box) + opaque(tl.cell[v]);
+            float ay = 0.f, az = 0.f;
+#pragma unroll
+            for (int i = 0; i <= K0; ++i) {
+                float r = 0.f, rz = 0.f;
+#pragma unroll
+                for (int j = 0; j <= K1; ++j) {
+                    float u[4] = { 0.f, 0.f, 0.f, 0.f };
+                    Slot<T>::unpack(bp[i * PZ + j], u);
+                    float sgl = g[0] * u[0];
+#pragma unroll
+                    for (int ch = 1; ch < NC; ++ch) sgl = __builtin_fmaf(g[ch], u[ch], sgl);
+                    r = __builtin_fmaf(w1[j], sgl, r);
+                    rz = __builtin_fmaf(d1[j], sgl, rz);
+                }
+                ay = __builtin_fmaf(d0[i], r, ay);
+                az = __builtin_fmaf(w0[i], rz, az);
+            }
+            if ((tl.in >> v) & 1) { gg[v][0] += ay; gg[v][1] += az; }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        prof_mark(2);
+        __syncthreads();
+        prof_mark(3);
+    }
+    {
+        const int tid = opaque((int)threadIdx.x);
+        int oy, oz;
+        px_pos(tid, 0, oy0, oz0, oy, oz);
+        // stencils outside the (clamped) box: gathered from global memory, one by one, all channels
+        if (tl.in != tl.valid) {
+#pragma unroll 1
+            for (int v = 0; v < VPT; ++v) {
+                if (!(((tl.valid & ~tl.in) >> v) & 1)) continue;
+                float x[2]; int iy, iz; float ty, tz;
+                load_yz<GM>(p, grid, b, gy, gz, oy, oz + v, x);
+                split(K0, x[0], iy, ty); split(K1, x[1], iz, tz);
+                float a0 = 0.f, a1 = 0.f;
+                for (int ch = 0; ch < p.C; ++ch) {
+                    const float gvs = gout ? Cvt<float, T>::ld(gout[b * p.val_sb + ch * p.val_sc + (int64_t)oy * gz + oz + v]) : 1.f;
+                    a0 = __builtin_fmaf(gvs, tiled::gather_one_thread<T>(L, vol + b * p.vol_sb + ch * p.vol_sc, 0, iy, iz, 0.f, ty, tz, 1), a0);
+                    a1 = __builtin_fmaf(gvs, tiled::gather_one_thread<T>(L, vol + b * p.vol_sb + ch * p.vol_sc, 0, iy, iz, 0.f, ty, tz, 2), a1);
+                }
+                gg[v][0] = a0; gg[v][1] = a1;
+            }
+        }
+        float *ob = ggrid + b * p.grid_sb + ((int64_t)oy * gz + oz) * 2;
+        float m[VPT];
+#pragma unroll
+        for (int v = 0; v < VPT; ++v) m[v] = (float)((tl.inb >> v) & 1);
+        if (tl.valid == 0xf) {
+            st4<float>(ob, make_float4(gg[0][0] * m[0], gg[0][1] * m[0], gg[1][0] * m[1], gg[1][1] * m[1]));
+            st4<float>(ob + 4, make_float4(gg[2][0] * m[2], gg[2][1] * m[2], gg[3][0] * m[3], gg[3][1] * m[3]));
+        } else {
+#pragma unroll
+            for (int v = 0; v < VPT; ++v)
+                if ((tl.valid >> v) & 1) { ob[2 * v] = gg[v][0] * m[v]; ob[2 * v + 1] = gg[v][1] * m[v]; }
+        }
+    }
+}
+
+
+
+// ---------------------------------------------------------------------------
 // push / count: MODE 0 values, 1 count, 2 values + count (one more target channel)
 // ---------------------------------------------------------------------------
 template <typename T, int K0, int K1, int GM, int MODE>
@@ -661,6 +871,26 @@ int IP_SYM(try_tiled2d_pull_, IP_TSFX)(const interpol_problem *p, const KParams 
                            (const float *)grid, (T *)val, gy, gz, ntz, ntiles); })
     if (k.sep == 0) IP_PULL2D(0); else if (k.sep == 1) IP_PULL2D(1); else if (k.sep == 2) IP_PULL2D(2); else IP_PULL2D(3);
 #undef IP_PULL2D
+    if (!rc) return 0;
+    const hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 1 : (int)e;
+}
+
+// grid gradient of pull / push (roles swapped) / count (gout == NULL), dense grids and displacement fields
+int IP_SYM(try_tiled2d_gradc_, IP_TSFX)(const interpol_problem *p, const KParams &k, const void *gout, const void *vol, const void *grid, void *ggrid, hipStream_t st)
+{
+    using namespace t2d;
+    using T = IP_TT;
+    if (!t2d_eligible(p, k) || (k.sep != 0 && k.sep != 2) || (k.dbg & 16)) return 0;
+    const int gy = (int)p->grid_shape[0], gz = (int)p->grid_shape[1];
+    const int nty = (gy + TY - 1) / TY, ntz = (gz + TZ - 1) / TZ, ntiles = nty * ntz;
+    const dim3 g((unsigned)(ntiles * (int)p->batch));
+    int rc;
+#define IP_GRADC2D(GM) rc = by_orders<T, GM>(k.order[0], k.order[1], [&](auto k0, auto k1) {                             \
+        hipLaunchKernelGGL((gradc2d<T, decltype(k0)::value, decltype(k1)::value, GM>), g, dim3(NT), 0, st, k, (const T *)vol, \
+                           (const T *)gout, (const float *)grid, (float *)ggrid, gy, gz, ntz, ntiles); })
+    if (k.sep == 0) IP_GRADC2D(0); else IP_GRADC2D(2);
+#undef IP_GRADC2D
     if (!rc) return 0;
     const hipError_t e = hipGetLastError();
     return e == hipSuccess ? 1 : (int)e;
