@@ -478,6 +478,58 @@ def test_tiled2d_grid_gradient_matches_generic(dtype):
                     _same(fast[0].float(), slow[0].float(), 1e-2 if dtype != torch.float32 else 1e-5, ("push bwd 2d val", dtype, C, sigma, o, b, ex))
 
 
+@pytest.mark.parametrize("dim,order,dtype", [(3, 3, torch.float32), (3, 2, torch.bfloat16), (3, 1, torch.float32), (3, 5, torch.float32),
+                                             (3, 7, torch.float32), (2, 3, torch.float32), (2, 2, torch.bfloat16), (2, 1, torch.float16)])
+def test_stretched_tiles_are_handed_back_to_the_generic_kernels(dim, order, dtype):
+    """Zoomed lattices (stride 2.2 / 3.1 plus a little noise: a 16^3 sample tile spans more lattice points than its LDS box
+    holds): the tile kernels hand such tiles back to the generic kernel of the operator (csrc/defer.hip).  Every operator,
+    with the hand-back (default), without it (debug switch 256: the in-kernel fallbacks) and the generic kernels alone must
+    agree; so must a problem where only SOME tiles are stretched, ragged tiles, batch > 1, masked extrapolation."""
+    from interpol import _hip
+    NOHB = 256 << 8
+    gen = torch.Generator().manual_seed(100 * dim + order)
+    ishape = (90, 70, 85)[3 - dim:] if dim == 3 else (200, 170)
+    oshape = (38, 33, 45)[3 - dim:] if dim == 3 else (90, 75)
+    B, C = 2, 3
+    vol = torch.randn([B, C, *ishape], generator=gen).to(DEV).to(dtype)
+    src = torch.randn([B, C, *oshape], generator=gen).to(DEV).to(dtype)
+    gvo = torch.randn([B, C, *ishape], generator=gen).to(DEV).to(dtype)
+    ident = interpol.identity_grid(oshape)
+    half = ident.clone()
+    half[..., 0] = torch.where(ident[..., 0] > oshape[0] / 2, ident[..., 0] * 2.6 - 0.8 * oshape[0], ident[..., 0])   # stretched in one half only
+    lowp = dtype != torch.float32
+    tol = 2e-2 if lowp else (1e-5 if order < 6 else 1e-4)
+    for grid0, ex in ((ident * 2.2, 1), (ident * 3.1 - 4.0, 0), (half, 2)):
+        grid = (grid0[None] + 0.05 * torch.randn([B, *oshape, dim], generator=gen)).to(DEV)
+        for bound in (3, 0, 6):
+            b, o = [bound] * dim, [order] * dim
+            for op in ("pull", "grad"):
+                ref = _hip.gather(op, vol, grid, b, o, ex, flags=_hip.FLAG_NO_FASTPATH).float()
+                for fl in (0, NOHB):
+                    _same(_hip.gather(op, vol, grid, b, o, ex, flags=fl).float(), ref, tol, (op, dim, order, dtype, bound, ex, fl))
+            for op in ("push", "count"):
+                ref = _hip.scatter(op, src if op == "push" else None, grid, list(ishape), b, o, ex, flags=_hip.FLAG_NO_FASTPATH).float()
+                for fl in (0, NOHB):
+                    _same(_hip.scatter(op, src if op == "push" else None, grid, list(ishape), b, o, ex, flags=fl).float(), ref, tol, (op, dim, order, dtype, bound, ex, fl))
+            for need in ((True, True), (False, True), (True, False)):
+                ref = _hip.pull_backward(src, vol, grid, b, o, ex, *need, flags=_hip.FLAG_NO_FASTPATH)
+                for fl in (0, NOHB):
+                    got = _hip.pull_backward(src, vol, grid, b, o, ex, *need, flags=fl)
+                    for x, y in zip(got, ref):
+                        assert (x is None) == (y is None)
+                        if x is not None:
+                            _same(x.float(), y.float(), tol, ("pull bwd", need, dim, order, dtype, bound, ex, fl))
+                ref = _hip.push_backward(gvo, src, grid, b, o, ex, *need, flags=_hip.FLAG_NO_FASTPATH)
+                for fl in (0, NOHB):
+                    got = _hip.push_backward(gvo, src, grid, b, o, ex, *need, flags=fl)
+                    for x, y in zip(got, ref):
+                        if x is not None:
+                            _same(x.float(), y.float(), tol, ("push bwd", need, dim, order, dtype, bound, ex, fl))
+            ref = _hip.push_backward(gvo[:, :1].contiguous(), None, grid, b, o, ex, False, True, flags=_hip.FLAG_NO_FASTPATH)[1]
+            for fl in (0, NOHB):
+                _same(_hip.push_backward(gvo[:, :1].contiguous(), None, grid, b, o, ex, False, True, flags=fl)[1], ref, tol, ("count bwd", dim, order, dtype, bound, ex, fl))
+
+
 def test_tiled_scatter_nonfinite_sources_keep_ieee_semantics():
     from interpol import _hip
     vol, grid, tshape, sshape = _tiled_problem(3, 1.0, seed=5)

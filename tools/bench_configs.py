@@ -175,4 +175,22 @@ if "r" in which:    # config 2 vs the roughness of the deformation: identity + s
             backend.rough_deformations = False
         del inp, grid
 
+if "r" in which:    # SURVEY 8(d)'s smooth variant: 12^3 control points, sigma = 2 / 8 voxels, cubic-upsampled displacement (a registration field)
+    import bench
+    for amp in (2.0, 8.0):
+        inp, grid = bench.make_inputs(4, 2, 256, 0.0, dev, 1234)
+        ctrl = torch.randn(4, 3, 12, 12, 12, generator=g, device=dev) * amp
+        disp = interpol.resize(ctrl, shape=[256] * 3, anchor="e", interpolation=3, bound="dct2", prefilter=True)
+        grid = grid + disp.permute(0, 2, 3, 4, 1)
+        del ctrl, disp
+        kw = dict(interpolation=3, bound="dct2", extrapolate=True)
+        vox = 4 * 256 ** 3
+        nb = vox * 12 + 2 * 4 * 2 * 256 ** 3 * 4
+        rec(res, "cfg2_pull_smooth_field_amp_%g" % amp, timeit(lambda: interpol.grid_pull(inp, grid, **kw), 3), vox, nb)
+        rec(res, "cfg2_push_smooth_field_amp_%g" % amp, timeit(lambda: interpol.grid_push(inp, grid, **kw), 3), vox, nb)
+        gout = torch.randn_like(inp)
+        from interpol import _hip
+        rec(res, "cfg2_pull_backward_both_smooth_field_amp_%g" % amp, timeit(lambda: _hip.pull_backward(gout, inp, grid, [3] * 3, [3] * 3, 1, True, True), 3), vox, nb + vox * 12 + 4 * 2 * 256 ** 3 * 4)
+        del inp, grid, gout
+
 print(json.dumps(res, indent=1))

@@ -144,7 +144,10 @@ static int make_params(const interpol_problem *p, Role role, int trailing, KPara
     if (p->flags & (INTERPOL_FLAG_SEPARABLE_GRID | INTERPOL_FLAG_DISPLACEMENT | INTERPOL_FLAG_AFFINE_GRID)) {
         if (N > 0xffffffffll) return INTERPOL_E_SHAPE;               // the sample index is split in 32 bits
         k->sep = (p->flags & INTERPOL_FLAG_SEPARABLE_GRID) ? 1 : ((p->flags & INTERPOL_FLAG_DISPLACEMENT) ? 2 : 3);
-        for (int d = 0; d < 3; ++d) k->gshape[d] = d < p->dim ? (int)p->grid_shape[d] : 1;
+    }
+    for (int d = 0; d < 3; ++d) {
+        if (d < p->dim && p->grid_shape[d] > 0x7fffffffll) return INTERPOL_E_SHAPE;
+        k->gshape[d] = d < p->dim ? (int)p->grid_shape[d] : 1;
     }
     if (p->flags & (INTERPOL_FLAG_SEPARABLE_GRID | INTERPOL_FLAG_AFFINE_GRID)) {
         k->grid_sb = 0;

@@ -53,6 +53,56 @@ template <typename AccT> __device__ __forceinline__ void atomic_add(AccT *base, 
 // compiler issues the gathers a row at a time instead of all (K+1)^D up front
 #define IP_ROW_END do { if (Taps<D, KMAX>::T0 * Taps<D, KMAX>::T1 * Taps<D, KMAX>::T2 > 16) __builtin_amdgcn_sched_barrier(0); } while (0)
 
+// ---------------------------------------------------------------------------
+// Which samples a thread visits.
+//   DEF == false : sample o = blockIdx.x * BLOCK + threadIdx.x of the batch items blockIdx.y, + gridDim.y, ...
+//   DEF == true  : the samples of the tiles that an LDS-tiled kernel handed back (TileList, stencil.hpp: deformations
+//                  too rough for its box).  Persistent blocks walk
+//                  the descriptor list; the 256 threads of a block share a tile, z fastest.
+// ---------------------------------------------------------------------------
+template <bool DEF, int D> struct SampleIter;
+template <int D> struct SampleIter<false, D> {
+    int64_t b, o; bool ok;
+    __device__ __forceinline__ SampleIter(const KParams &p, int B, const TileList &)
+    {
+        o = (int64_t)blockIdx.x * BLOCK + threadIdx.x; b = blockIdx.y; ok = o < p.N && b < B;
+    }
+    __device__ __forceinline__ void next(const KParams &, int B, const TileList &) { b += gridDim.y; ok = b < B; }
+};
+template <int D> struct SampleIter<true, D> {
+    int64_t b, o; bool ok;
+    int w, s, c[3]; bool have;
+    __device__ __forceinline__ SampleIter(const KParams &p, int B, const TileList &tl) { w = blockIdx.x; have = false; next(p, B, tl); }
+    __device__ __forceinline__ void next(const KParams &p, int, const TileList &tl)
+    {
+        const int ns = tl.e[0] * tl.e[1] * tl.e[2];
+        for (;;) {
+            if (w >= tl.nwork) { ok = false; return; }
+            if (!have) {
+                const unsigned long long d = tl.desc[w];
+                if (!(d >> 63)) { w += gridDim.x; continue; }
+                b = (int64_t)((d >> 42) & 0xfffffull);
+                c[0] = (int)((d >> 28) & 0x3fffull) * tl.e[0]; c[1] = (int)((d >> 14) & 0x3fffull) * tl.e[1]; c[2] = (int)(d & 0x3fffull) * tl.e[2];
+                have = true; s = threadIdx.x;
+            } else {
+                s += BLOCK;
+            }
+            if (s >= ns) { have = false; w += gridDim.x; continue; }
+            // tile dims (x, y, z) are the LAST D dims of the kernel families: problem dim d <-> tile dim d + 3 - D
+            int r = s, pos[3];
+            pos[2] = c[2] + r % tl.e[2]; r /= tl.e[2];
+            pos[1] = c[1] + r % tl.e[1]; r /= tl.e[1];
+            pos[0] = c[0] + r;
+            bool in = true; int64_t lin = 0;
+#pragma unroll
+            for (int d = 0; d < D; ++d) { const int q = pos[d + 3 - D]; in = in && q < p.gshape[d]; lin = lin * p.gshape[d] + q; }
+            if (!in) continue;
+            o = lin; ok = true; return;
+        }
+    }
+};
+#define IP_FOR_SAMPLES for (SampleIter<DEF, D> it_(p, B, tl); it_.ok; it_.next(p, B, tl))
+
 template <typename S> __device__ __forceinline__ void opaque(S &s)
 {
 #pragma unroll
@@ -62,13 +112,12 @@ template <typename S> __device__ __forceinline__ void opaque(S &s)
 // ---------------------------------------------------------------------------
 // pull : val[b,c,o] = mask * sum_taps w * vol[b,c,tap]          (nd.py:80-143)
 // ---------------------------------------------------------------------------
-template <typename T, typename G, typename R, int D, int KMAX, bool ISO>
+template <typename T, typename G, typename R, int D, int KMAX, bool ISO, bool DEF = false>
 __global__ __launch_bounds__(BLOCK) void pull_generic(KParams p, const T *__restrict__ vol,
-                                                      const G *__restrict__ grid, T *__restrict__ val, int B)
+                                                      const G *__restrict__ grid, T *__restrict__ val, int B, TileList tl)
 {
-    const int64_t o = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
-    if (o >= p.N) return;
-    for (int64_t b = blockIdx.y; b < B; b += gridDim.y) {
+    IP_FOR_SAMPLES {
+        const int64_t b = it_.b, o = it_.o;
         R x[D];
         load_coords<R, G, D>(p, grid, b, o, x);
         Stencil<R, D, KMAX, ISO, NEED_W> s;
@@ -99,13 +148,12 @@ __global__ __launch_bounds__(BLOCK) void pull_generic(KParams p, const T *__rest
 // ---------------------------------------------------------------------------
 // grad : val[b,c,o,d] = mask * sum_taps (g_d prod_{e!=d} w_e) * vol[b,c,tap]   (nd.py:216-288)
 // ---------------------------------------------------------------------------
-template <typename T, typename G, typename R, int D, int KMAX, bool ISO>
+template <typename T, typename G, typename R, int D, int KMAX, bool ISO, bool DEF = false>
 __global__ __launch_bounds__(BLOCK) void grad_generic(KParams p, const T *__restrict__ vol,
-                                                      const G *__restrict__ grid, T *__restrict__ val, int B)
+                                                      const G *__restrict__ grid, T *__restrict__ val, int B, TileList tl)
 {
-    const int64_t o = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
-    if (o >= p.N) return;
-    for (int64_t b = blockIdx.y; b < B; b += gridDim.y) {
+    IP_FOR_SAMPLES {
+        const int64_t b = it_.b, o = it_.o;
         R x[D];
         load_coords<R, G, D>(p, grid, b, o, x);
         Stencil<R, D, KMAX, ISO, NEED_G> s;
@@ -205,13 +253,12 @@ __global__ __launch_bounds__(BLOCK) void hess_generic(KParams p, const T *__rest
 //   AccT is the accumulation type of the target buffer (float for f32/bf16/f16
 //   storage, double for f64); the target is zero-filled by the caller side.
 // ---------------------------------------------------------------------------
-template <typename T, typename G, typename R, typename AccT, int D, int KMAX, bool ISO, bool COUNT>
+template <typename T, typename G, typename R, typename AccT, int D, int KMAX, bool ISO, bool COUNT, bool DEF = false>
 __global__ __launch_bounds__(BLOCK) void push_generic(KParams p, const T *__restrict__ val,
-                                                      const G *__restrict__ grid, AccT *__restrict__ vol, int B)
+                                                      const G *__restrict__ grid, AccT *__restrict__ vol, int B, TileList tl)
 {
-    const int64_t o = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
-    if (o >= p.N) return;
-    for (int64_t b = blockIdx.y; b < B; b += gridDim.y) {
+    IP_FOR_SAMPLES {
+        const int64_t b = it_.b, o = it_.o;
         R x[D];
         load_coords<R, G, D>(p, grid, b, o, x);
         Stencil<R, D, KMAX, ISO, NEED_W> s;
@@ -285,16 +332,15 @@ __global__ __launch_bounds__(BLOCK) void pushgrad_generic(KParams p, const T *__
 // replaces push + grad + a (B,C,N,D) temporary + a channel reduction.
 // Either output may be NULL (requires_grad-driven skipping, pushpull.py:252-255).
 // ---------------------------------------------------------------------------
-template <typename T, typename G, typename R, typename AccT, int D, int KMAX, bool ISO>
+template <typename T, typename G, typename R, typename AccT, int D, int KMAX, bool ISO, bool DEF = false>
 __global__ __launch_bounds__(BLOCK) void pullbwd_generic(KParams p, const T *__restrict__ gout, const T *__restrict__ vol,
                                                          const G *__restrict__ grid, AccT *__restrict__ gvol,
-                                                         G *__restrict__ ggrid, int B, int64_t gvol_sb, int64_t gvol_sc)
+                                                         G *__restrict__ ggrid, int B, int64_t gvol_sb, int64_t gvol_sc, TileList tl)
 {
     // gvol has vol's spatial layout (host guarantees both spatially contiguous) but AccT elements
     constexpr unsigned ACC_SCALE = sizeof(AccT) / sizeof(T);
-    const int64_t o = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
-    if (o >= p.N) return;
-    for (int64_t b = blockIdx.y; b < B; b += gridDim.y) {
+    IP_FOR_SAMPLES {
+        const int64_t b = it_.b, o = it_.o;
         R x[D];
         load_coords<R, G, D>(p, grid, b, o, x);
         Stencil<R, D, KMAX, ISO, NEED_G> s;
@@ -349,14 +395,13 @@ __global__ __launch_bounds__(BLOCK) void pullbwd_generic(KParams p, const T *__r
 //   ggrid[b,o,d] = mask * sum_c val[b,c,o] * sum_taps (g_d prod w) gvol_out[b,c,tap]
 // COUNT: val == all ones (grid_count_backward).  Either output may be NULL.
 // ---------------------------------------------------------------------------
-template <typename T, typename G, typename R, int D, int KMAX, bool ISO, bool COUNT>
+template <typename T, typename G, typename R, int D, int KMAX, bool ISO, bool COUNT, bool DEF = false>
 __global__ __launch_bounds__(BLOCK) void pushbwd_generic(KParams p, const T *__restrict__ gvol_out, const T *__restrict__ val,
                                                          const G *__restrict__ grid, T *__restrict__ gval,
-                                                         G *__restrict__ ggrid, int B)
+                                                         G *__restrict__ ggrid, int B, TileList tl)
 {
-    const int64_t o = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
-    if (o >= p.N) return;
-    for (int64_t b = blockIdx.y; b < B; b += gridDim.y) {
+    IP_FOR_SAMPLES {
+        const int64_t b = it_.b, o = it_.o;
         R x[D];
         load_coords<R, G, D>(p, grid, b, o, x);
         Stencil<R, D, KMAX, ISO, NEED_G> s;

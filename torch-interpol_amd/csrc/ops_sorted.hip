@@ -51,6 +51,8 @@ constexpr int BOXSLOTS = NPL * PLANE;           // 9216 slots = 73728 B
 constexpr int NCLS = 32;                        // classes = 8-byte bank pairs
 constexpr int NSLOT = NS / NCLS;                // half-wave slots per class
 constexpr int SLOWCAP = 512;
+constexpr int HANDBACK = NS / 8;                // out-of-box samples beyond which the generic kernel takes a (smooth) tile, defer.hip;
+                                                // measured: tools/handback_sweep.py, profiles/r02_handback.txt
 constexpr int TABCAP = (BOXSLOTS * 8 - NS * 16) / 2;   // surplus samples the hole table can place (2048)
 static_assert(PLANE % NCLS == 0, "the plane pitch must keep the class pass-independent");
 static_assert(NS * 16 <= BOXSLOTS * 8, "sample records alias the box");
@@ -301,7 +303,8 @@ __device__ __forceinline__ void slow_taps(const KParams &p, const Lattice &L, co
 // ---------------------------------------------------------------------------
 template <typename T, int K, int GM>
 __global__ __launch_bounds__(NT, 4) void pull_sorted(KParams p, const T *__restrict__ vol, const float *__restrict__ grid,
-                                                     T *__restrict__ val, int gx, int gy, int gz, int nty, int ntz, int ntiles, int nbatch)
+                                                     T *__restrict__ val, int gx, int gy, int gz, int nty, int ntz, int ntiles, int nbatch,
+                                                     unsigned long long *__restrict__ defer)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     Smem &sm = *reinterpret_cast<Smem *>(smem_raw);
@@ -323,6 +326,12 @@ __global__ __launch_bounds__(NT, 4) void pull_sorted(KParams p, const T *__restr
         Tile<K, GM>::load(p, grid, b, g, tid, cnext);
         tl.build(p, L, g, sm, tid, cnext);
         const int nslow = sm.nslow < SLOWCAP ? sm.nslow : SLOWCAP;
+        if (defer) {                                                 // (block-uniform) too rough for the box: the generic kernel takes the tile, defer.hip
+            bool hand_back = sm.nslow > (HANDBACK << ((p.dbg >> 9) & 7));
+            if (hand_back) hand_back = tiled::tile_smooth(p, grid, b, 3, g.ox0, g.oy0, g.oz0, TS, TS, TS, g.gx, g.gy, g.gz, sm.hi);
+            if (tid == 0) defer[work] = hand_back ? tile_desc(b, g.ox0 / TS, g.oy0 / TS, g.oz0 / TS) : 0ull;
+            if (hand_back) { __syncthreads(); continue; }
+        }
         // rows of the box are contiguous runs of the lattice's unit-stride dim, sign +1 throughout
         // (dst1 has sign 0 at index 0 -- quirk B-3 -- so its run must start at 1)
         const bool zlin = L.ss[2] == 1 && tl.lo[2] >= (L.bound[2] == B_DST1 ? 1 : 0) && tl.lo[2] + tl.S[2] <= L.n[2];
@@ -529,7 +538,8 @@ __global__ __launch_bounds__(NT, 4) void pull_sorted(KParams p, const T *__restr
 // ===========================================================================
 template <typename T, int K, int GM>
 __global__ __launch_bounds__(NT, 4) void gradc_sorted(KParams p, const T *__restrict__ vol, const T *__restrict__ gout, const float *__restrict__ grid,
-                                                      float *__restrict__ ggrid, int gx, int gy, int gz, int nty, int ntz, int ntiles, int nbatch)
+                                                      float *__restrict__ ggrid, int gx, int gy, int gz, int nty, int ntz, int ntiles, int nbatch,
+                                                      unsigned long long *__restrict__ defer)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     Smem &sm = *reinterpret_cast<Smem *>(smem_raw);
@@ -551,6 +561,12 @@ __global__ __launch_bounds__(NT, 4) void gradc_sorted(KParams p, const T *__rest
         Tile<K, GM>::load(p, grid, b, g, tid, cnext);
         tl.build(p, L, g, sm, tid, cnext);
         const int nslow = sm.nslow < SLOWCAP ? sm.nslow : SLOWCAP;
+        if (defer) {                                                 // (block-uniform) too rough for the box: the generic kernel takes the tile, defer.hip
+            bool hand_back = sm.nslow > (HANDBACK << ((p.dbg >> 9) & 7));
+            if (hand_back) hand_back = tiled::tile_smooth(p, grid, b, 3, g.ox0, g.oy0, g.oz0, TS, TS, TS, g.gx, g.gy, g.gz, sm.hi);
+            if (tid == 0) defer[work] = hand_back ? tile_desc(b, g.ox0 / TS, g.oy0 / TS, g.oz0 / TS) : 0ull;
+            if (hand_back) { __syncthreads(); continue; }
+        }
         // rows of the box are contiguous runs of the lattice's unit-stride dim, sign +1 throughout
         // (dst1 has sign 0 at index 0 -- quirk B-3 -- so its run must start at 1)
         const bool zlin = L.ss[2] == 1 && tl.lo[2] >= (L.bound[2] == B_DST1 ? 1 : 0) && tl.lo[2] + tl.S[2] <= L.n[2];
@@ -830,7 +846,8 @@ IP_ADDROW(0) IP_ADDROW(1) IP_ADDROW(2) IP_ADDROW(3)
 
 template <typename T, int K, int GM, int MODE>
 __global__ __launch_bounds__(NT, 4) void push_sorted(KParams p, const T *__restrict__ val, const float *__restrict__ grid,
-                                                     float *__restrict__ vol, int gx, int gy, int gz, int nty, int ntz, int ntiles, int nbatch)
+                                                     float *__restrict__ vol, int gx, int gy, int gz, int nty, int ntz, int ntiles, int nbatch,
+                                                     unsigned long long *__restrict__ defer)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     Smem &sm = *reinterpret_cast<Smem *>(smem_raw);
@@ -850,6 +867,12 @@ __global__ __launch_bounds__(NT, 4) void push_sorted(KParams p, const T *__restr
         Tile<K, GM>::load(p, grid, b, g, tid, cnext);
         tl.build(p, L, g, sm, tid, cnext);
         const int nslow = sm.nslow < SLOWCAP ? sm.nslow : SLOWCAP;
+        if (defer) {                                                 // (block-uniform) too rough for the box: the generic kernel takes the tile, defer.hip
+            bool hand_back = sm.nslow > (HANDBACK << ((p.dbg >> 9) & 7));
+            if (hand_back) hand_back = tiled::tile_smooth(p, grid, b, 3, g.ox0, g.oy0, g.oz0, TS, TS, TS, g.gx, g.gy, g.gz, sm.hi);
+            if (tid == 0) defer[work] = hand_back ? tile_desc(b, g.ox0 / TS, g.oy0 / TS, g.oz0 / TS) : 0ull;
+            if (hand_back) { __syncthreads(); continue; }
+        }
         // ---- sample density: the largest number of sorted samples that share a first-tap cell bounds
         // what any lattice point can receive.  Counted in the (free) box: 16-bit counters, two per word.
         unsigned *cnt32 = reinterpret_cast<unsigned *>(sm.box);
@@ -1138,10 +1161,13 @@ static int launch_pull(const interpol_problem *p, const KParams &k, const void *
     const int attr = big_lds<pull_sorted<T, K, GM>>(sizeof(Smem));
     if (attr) return attr;
     const TileCount t(p);
+    const Defer df(k, st, t.ntiles(), p->batch, t.ntx, t.nty, t.ntz, TS, TS, TS);
     hipLaunchKernelGGL((pull_sorted<T, K, GM>), t.grid((int)p->batch), dim3(NT), sizeof(Smem), st,
-                       k, (const T *)vol, (const float *)grid, (T *)val, t.gx, t.gy, t.gz, t.nty, t.ntz, t.ntiles(), (int)p->batch);
+                       k, (const T *)vol, (const float *)grid, (T *)val, t.gx, t.gy, t.gz, t.nty, t.ntz, t.ntiles(), (int)p->batch, df.desc);
     const hipError_t e = hipGetLastError();
-    return e == hipSuccess ? 1 : (int)e;
+    if (e != hipSuccess) return (int)e;
+    const int rc = df.desc ? DeferOps<T>::pull(k, vol, grid, val, df.tl, st) : 0;
+    return rc ? rc : 1;
 }
 
 template <typename T, int K, int GM>
@@ -1150,10 +1176,13 @@ static int launch_gradc(const interpol_problem *p, const KParams &k, const void 
     const int attr = big_lds<gradc_sorted<T, K, GM>>(sizeof(Smem));
     if (attr) return attr;
     const TileCount t(p);
+    const Defer df(k, st, t.ntiles(), p->batch, t.ntx, t.nty, t.ntz, TS, TS, TS);
     hipLaunchKernelGGL((gradc_sorted<T, K, GM>), t.grid((int)p->batch), dim3(NT), sizeof(Smem), st,
-                       k, (const T *)vol, (const T *)gout, (const float *)grid, (float *)ggrid, t.gx, t.gy, t.gz, t.nty, t.ntz, t.ntiles(), (int)p->batch);
+                       k, (const T *)vol, (const T *)gout, (const float *)grid, (float *)ggrid, t.gx, t.gy, t.gz, t.nty, t.ntz, t.ntiles(), (int)p->batch, df.desc);
     const hipError_t e = hipGetLastError();
-    return e == hipSuccess ? 1 : (int)e;
+    if (e != hipSuccess) return (int)e;
+    const int rc = df.template gradc<T>(k, gout, vol, grid, ggrid, st);
+    return rc ? rc : 1;
 }
 
 // `vol` is the zero-filled (or accumulating) FLOAT target; val == NULL: count
@@ -1161,19 +1190,22 @@ template <typename T, int K, int GM>
 static int launch_push(const interpol_problem *p, const KParams &k, const void *val, const void *grid, void *vol, hipStream_t st)
 {
     const TileCount t(p);
+    const Defer df(k, st, t.ntiles(), p->batch, t.ntx, t.nty, t.ntz, TS, TS, TS);
 #define IP_LAUNCH_PUSH(MODE)                                                                                          \
     {                                                                                                                 \
         const int attr = big_lds<push_sorted<T, K, GM, MODE>>(sizeof(Smem));                                          \
         if (attr) return attr;                                                                                        \
         hipLaunchKernelGGL((push_sorted<T, K, GM, MODE>), t.grid((int)p->batch), dim3(NT), sizeof(Smem), st,          \
-                           k, (const T *)val, (const float *)grid, (float *)vol, t.gx, t.gy, t.gz, t.nty, t.ntz, t.ntiles(), (int)p->batch); \
+                           k, (const T *)val, (const float *)grid, (float *)vol, t.gx, t.gy, t.gz, t.nty, t.ntz, t.ntiles(), (int)p->batch, df.desc); \
     }
     if (!val) IP_LAUNCH_PUSH(1)
     else if (k.cc) IP_LAUNCH_PUSH(2)
     else IP_LAUNCH_PUSH(0)
 #undef IP_LAUNCH_PUSH
     const hipError_t e = hipGetLastError();
-    return e == hipSuccess ? 1 : (int)e;
+    if (e != hipSuccess) return (int)e;
+    const int rc = df.template push<T>(k, val, grid, vol, st);
+    return rc ? rc : 1;
 }
 
 } // namespace sorted

@@ -161,6 +161,21 @@ struct TileGeom {
     int ox0, oy0, oz0;         // tile origin
 };
 
+// Stretched beyond the box (more than 1/8 of the tile's samples outside it, smooth coordinates): the tile is handed back to the generic kernel
+// of the operator (defer.hip) instead of crawling through the per-thread fallback.  Block-uniform; every work item
+// writes its descriptor.  Call after Box::build.
+template <typename C>
+__device__ __forceinline__ bool hand_back(unsigned long long *defer, int work, int64_t b, const TileGeom &g, int nslow, const KParams &p,
+                                          const float *__restrict__ grid, Smem &sm)
+{
+    if (!defer) return false;
+    bool hb = nslow > ((C::NS / 8) << ((p.dbg >> 9) & 7));      // measured: tools/handback_sweep.py, profiles/r02_handback.txt
+    if (hb) hb = tile_smooth(p, grid, b, C::D, g.ox0, g.oy0, g.oz0, C::TX, C::TY, C::TZ, g.gx, g.gy, g.gz, sm.hi);
+    if (threadIdx.x == 0) defer[work] = hb ? tile_desc(b, g.ox0 / C::TX, g.oy0 / C::TY, g.oz0 / C::TZ) : 0ull;
+    if (hb) __syncthreads();                           // everyone has read sm.nslow before the next tile's build resets it
+    return hb;
+}
+
 template <typename C>
 __device__ __forceinline__ void sample_pos(const TileGeom &g, int tid, int v, int &ox, int &oy, int &oz)
 {
@@ -530,7 +545,7 @@ __device__ __forceinline__ void gather_box(const Smem &sm, const Box<C> &box, co
 // ---------------------------------------------------------------------------
 template <typename C, bool GRAD>
 __global__ __launch_bounds__(C::NT) void gather_tiled(KParams p, const typename C::T *__restrict__ vol, const float *__restrict__ grid,
-                                                      typename C::T *__restrict__ val, int gx, int gy, int gz, int nty, int ntz, int ntiles, int nbatch)
+                                                      typename C::T *__restrict__ val, int gx, int gy, int gz, int nty, int ntz, int ntiles, int nbatch, unsigned long long *__restrict__ defer)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     Smem &sm = *reinterpret_cast<Smem *>(smem_raw);
@@ -547,6 +562,7 @@ __global__ __launch_bounds__(C::NT) void gather_tiled(KParams p, const typename 
     Box<C> box;
     const unsigned fastmask = box.build(p, L, grid, b, g, sm);
     const int nslow = sm.nslow;
+    if (hand_back<C>(defer, work, b, g, nslow, p, grid, sm)) continue;
 
     for (int c = 0; c < p.C; ++c) {
         const T *vc = vol + b * p.vol_sb + c * p.vol_sc;
@@ -621,7 +637,7 @@ __global__ __launch_bounds__(C::NT) void gather_tiled(KParams p, const typename 
 template <typename C>
 __global__ __launch_bounds__(C::NT) void pull2_tiled(KParams p, const typename C::T *__restrict__ vol, const float *__restrict__ grid,
                                                      typename C::T *__restrict__ val, int gx, int gy, int gz, int nty, int ntz,
-                                                     int ntiles, int nbatch)
+                                                     int ntiles, int nbatch, unsigned long long *__restrict__ defer)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     Smem &sm = *reinterpret_cast<Smem *>(smem_raw);
@@ -640,6 +656,7 @@ __global__ __launch_bounds__(C::NT) void pull2_tiled(KParams p, const typename C
     prof_mark(-1);
     const unsigned fastmask = box.build(p, L, grid, b, g, sm);
     const int nslow = sm.nslow;
+    if (hand_back<C>(defer, work, b, g, nslow, p, grid, sm)) continue;
     prof_mark(0);
     // Two passes per channel pair, split by the PARITY of the box row x (see scatter_pair):
     // LDS row r = xh * S_y + y of pass ps holds box row x = 2 xh + ps.  Every sample reads taps
@@ -784,7 +801,7 @@ __global__ __launch_bounds__(C::NT) void pull2_tiled(KParams p, const typename C
 template <typename C>
 __global__ __launch_bounds__(C::NT) void pull1s_tiled(KParams p, const typename C::T *__restrict__ vol, const float *__restrict__ grid,
                                                      typename C::T *__restrict__ val, int gx, int gy, int gz, int nty, int ntz,
-                                                     int ntiles, int nbatch)
+                                                     int ntiles, int nbatch, unsigned long long *__restrict__ defer)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     Smem &sm = *reinterpret_cast<Smem *>(smem_raw);
@@ -803,6 +820,7 @@ __global__ __launch_bounds__(C::NT) void pull1s_tiled(KParams p, const typename 
     prof_mark(-1);
     const unsigned fastmask = box.build(p, L, grid, b, g, sm);
     const int nslow = sm.nslow;
+    if (hand_back<C>(defer, work, b, g, nslow, p, grid, sm)) continue;
     prof_mark(0);
     // Two passes per channel pair, split by the PARITY of the box row x (see scatter_pair):
     // LDS row r = xh * S_y + y of pass ps holds box row x = 2 xh + ps.  Every sample reads taps
@@ -938,7 +956,7 @@ __global__ __launch_bounds__(C::NT) void pull1s_tiled(KParams p, const typename 
 template <typename C>
 __global__ __launch_bounds__(C::NT) void grad1s_tiled(KParams p, const typename C::T *__restrict__ vol, const float *__restrict__ grid,
                                                      typename C::T *__restrict__ val, int gx, int gy, int gz, int nty, int ntz,
-                                                     int ntiles, int nbatch)
+                                                     int ntiles, int nbatch, unsigned long long *__restrict__ defer)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     Smem &sm = *reinterpret_cast<Smem *>(smem_raw);
@@ -957,6 +975,7 @@ __global__ __launch_bounds__(C::NT) void grad1s_tiled(KParams p, const typename 
     prof_mark(-1);
     const unsigned fastmask = box.build(p, L, grid, b, g, sm);
     const int nslow = sm.nslow;
+    if (hand_back<C>(defer, work, b, g, nslow, p, grid, sm)) continue;
     prof_mark(0);
     // Two passes per channel pair, split by the PARITY of the box row x (see scatter_pair):
     // LDS row r = xh * S_y + y of pass ps holds box row x = 2 xh + ps.  Every sample reads taps
@@ -1108,7 +1127,7 @@ __global__ __launch_bounds__(C::NT) void grad1s_tiled(KParams p, const typename 
 template <typename C>
 __global__ __launch_bounds__(C::NT) void gradc1s_tiled(KParams p, const typename C::T *__restrict__ gout, const typename C::T *__restrict__ vol,
                                                        const float *__restrict__ grid, float *__restrict__ ggrid,
-                                                       int gx, int gy, int gz, int nty, int ntz, int ntiles, int nbatch)
+                                                       int gx, int gy, int gz, int nty, int ntz, int ntiles, int nbatch, unsigned long long *__restrict__ defer)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     Smem &sm = *reinterpret_cast<Smem *>(smem_raw);
@@ -1127,6 +1146,7 @@ __global__ __launch_bounds__(C::NT) void gradc1s_tiled(KParams p, const typename
     prof_mark(-1);
     const unsigned fastmask = box.build(p, L, grid, b, g, sm);
     const int nslow = sm.nslow;
+    if (hand_back<C>(defer, work, b, g, nslow, p, grid, sm)) continue;
     prof_mark(0);
     // Two passes per channel pair, split by the PARITY of the box row x (see scatter_pair):
     // LDS row r = xh * S_y + y of pass ps holds box row x = 2 xh + ps.  Every sample reads taps
@@ -1692,7 +1712,7 @@ __device__ __forceinline__ bool scatter_pair(const KParams &p, const Lattice &L,
 template <typename C, bool COUNT, bool WC = false>
 __global__ __launch_bounds__(C::NT) void push_tiled(KParams p, const typename C::T *__restrict__ val, const float *__restrict__ grid,
                                                     float *__restrict__ vol, int gx, int gy, int gz, int nty, int ntz,
-                                                    int ntiles, int nbatch)
+                                                    int ntiles, int nbatch, unsigned long long *__restrict__ defer)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     Smem &sm = *reinterpret_cast<Smem *>(smem_raw);
@@ -1711,6 +1731,7 @@ __global__ __launch_bounds__(C::NT) void push_tiled(KParams p, const typename C:
         const int nslow = sm.nslow, dmax = sm.dmax;
         prof_mark(0);
         clean = true;                                  // Box::build leaves the box zeroed
+        if (hand_back<C>(defer, work, b, g, nslow, p, grid, sm)) continue;
         const int nch = p.C + (WC ? 1 : 0);
         for (int c = 0; c < nch; ++c) {
             float *vc = vol + b * p.vol_sb + c * p.vol_sc;
@@ -1766,7 +1787,7 @@ template <typename C>
 __global__ __launch_bounds__(C::NT) void pullbwd_tiled(KParams p, const typename C::T *__restrict__ gout, const typename C::T *__restrict__ vol,
                                                        const float *__restrict__ grid, float *__restrict__ gvol,
                                                        float *__restrict__ ggrid, int64_t gvol_sb, int64_t gvol_sc,
-                                                       int gx, int gy, int gz, int nty, int ntz, int ntiles, int nbatch)
+                                                       int gx, int gy, int gz, int nty, int ntz, int ntiles, int nbatch, unsigned long long *__restrict__ defer)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     Smem &sm = *reinterpret_cast<Smem *>(smem_raw);
@@ -1781,6 +1802,7 @@ __global__ __launch_bounds__(C::NT) void pullbwd_tiled(KParams p, const typename
     Box<C> box;
     const unsigned fastmask = box.template build<true>(p, L, grid, b, g, sm);
     const int nslow = sm.nslow, dmax = sm.dmax;
+    if (hand_back<C>(defer, work, b, g, nslow, p, grid, sm)) continue;
 
     float gg[C::VPT][3];
 #pragma unroll
@@ -1874,7 +1896,7 @@ template <typename C>
 __global__ __launch_bounds__(C::NT) void pushbwd_tiled(KParams p, const typename C::T *__restrict__ gvol_out,
                                                        const typename C::T *__restrict__ val, const float *__restrict__ grid,
                                                        typename C::T *__restrict__ gval, float *__restrict__ ggrid,
-                                                       int gx, int gy, int gz, int nty, int ntz, int ntiles, int nbatch)
+                                                       int gx, int gy, int gz, int nty, int ntz, int ntiles, int nbatch, unsigned long long *__restrict__ defer)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     Smem &sm = *reinterpret_cast<Smem *>(smem_raw);
@@ -1889,6 +1911,7 @@ __global__ __launch_bounds__(C::NT) void pushbwd_tiled(KParams p, const typename
     Box<C> box;
     const unsigned fastmask = box.build(p, L, grid, b, g, sm);
     const int nslow = sm.nslow;
+    if (hand_back<C>(defer, work, b, g, nslow, p, grid, sm)) continue;
     float gg[C::VPT][3];
 #pragma unroll
     for (int v = 0; v < C::VPT; ++v) { gg[v][0] = 0.f; gg[v][1] = 0.f; gg[v][2] = 0.f; }
@@ -2018,6 +2041,10 @@ static int big_lds(F kernel)
 }
 
 #define IP_CHECK_LAUNCH() do { const hipError_t e_ = hipGetLastError(); return e_ == hipSuccess ? 1 : (int)e_; } while (0)
+// ... then the generic kernel of the operator on the tiles handed back (defer.hip)
+#define IP_CHECK_LAUNCH_THEN(deferred) do { const hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return (int)e_; \
+                                            const int rc_ = (deferred); return rc_ ? rc_ : 1; } while (0)
+#define IP_DEFER(df, t, CC) const Defer df(k, st, (t).ntiles(), p->batch, (t).ntx, (t).nty, (t).ntz, CC::TX, CC::TY, CC::TZ)
 
 // Orders 4 - 5: the pull kernels take tiles of 16 x 8 x 16 samples (two per thread) instead of the 8 x 8 x 16 of the
 // other kernels of these orders: less halo staged per sample (config 3 pull 3.55 -> 2.91 ms); the gradient and scatter
@@ -2037,9 +2064,10 @@ static int launch_pull2_impl(const interpol_problem *p, const KParams &k, const 
         const int attr = big_lds<C>(pull2_tiled<C>);
         if (attr) return attr;
         const TileCount<C> t(p);
+        IP_DEFER(df, t, C);
         hipLaunchKernelGGL((pull2_tiled<C>), t.grid((int)p->batch), dim3(C::NT), smem_bytes<C>(), st,
-                           k, (const T *)vol, (const float *)grid, (T *)val, t.gx, t.gy, t.gz, t.nty, t.ntz, t.ntiles(), (int)p->batch);
-        IP_CHECK_LAUNCH();
+                           k, (const T *)vol, (const float *)grid, (T *)val, t.gx, t.gy, t.gz, t.nty, t.ntz, t.ntiles(), (int)p->batch, df.desc);
+        IP_CHECK_LAUNCH_THEN(df.desc ? DeferOps<T>::pull(k, vol, grid, val, df.tl, st) : 0);
     } else {
         return 0;
     }
@@ -2055,9 +2083,10 @@ static int launch_pull1s_impl(const interpol_problem *p, const KParams &k, const
         const int attr = big_lds<C>(pull1s_tiled<C>);
         if (attr) return attr;
         const TileCount<C> t(p);
+        IP_DEFER(df, t, C);
         hipLaunchKernelGGL((pull1s_tiled<C>), t.grid((int)p->batch), dim3(C::NT), smem_bytes<C>(), st,
-                           k, (const T *)vol, (const float *)grid, (T *)val, t.gx, t.gy, t.gz, t.nty, t.ntz, t.ntiles(), (int)p->batch);
-        IP_CHECK_LAUNCH();
+                           k, (const T *)vol, (const float *)grid, (T *)val, t.gx, t.gy, t.gz, t.nty, t.ntz, t.ntiles(), (int)p->batch, df.desc);
+        IP_CHECK_LAUNCH_THEN(df.desc ? DeferOps<T>::pull(k, vol, grid, val, df.tl, st) : 0);
     } else {
         return 0;
     }
@@ -2072,9 +2101,10 @@ static int launch_grad1s_impl(const interpol_problem *p, const KParams &k, const
         const int attr = big_lds<C>(grad1s_tiled<C>);
         if (attr) return attr;
         const TileCount<C> t(p);
+        IP_DEFER(df, t, C);
         hipLaunchKernelGGL((grad1s_tiled<C>), t.grid((int)p->batch), dim3(C::NT), smem_bytes<C>(), st,
-                           k, (const T *)vol, (const float *)grid, (T *)val, t.gx, t.gy, t.gz, t.nty, t.ntz, t.ntiles(), (int)p->batch);
-        IP_CHECK_LAUNCH();
+                           k, (const T *)vol, (const float *)grid, (T *)val, t.gx, t.gy, t.gz, t.nty, t.ntz, t.ntiles(), (int)p->batch, df.desc);
+        IP_CHECK_LAUNCH_THEN(df.desc ? DeferOps<T>::grad(k, vol, grid, val, df.tl, st) : 0);
     } else {
         return 0;
     }
@@ -2104,17 +2134,19 @@ static int launch_gather_impl(const interpol_problem *p, const KParams &k, const
         const int attr1 = big_lds<C>(gather_tiled<C, GRAD>);
         if (attr1) return attr1;
         const TileCount<C> t1(p);
+        IP_DEFER(df1, t1, C);
         hipLaunchKernelGGL((gather_tiled<C, GRAD>), t1.grid((int)p->batch), dim3(C::NT), smem_bytes<C>(), st, k1,
                            (const T *)vol + (p->channels - 1) * k.vol_sc, (const float *)grid, (T *)val + (p->channels - 1) * k.val_sc,
-                           t1.gx, t1.gy, t1.gz, t1.nty, t1.ntz, t1.ntiles(), (int)p->batch);
-        IP_CHECK_LAUNCH();
+                           t1.gx, t1.gy, t1.gz, t1.nty, t1.ntz, t1.ntiles(), (int)p->batch, df1.desc);
+        IP_CHECK_LAUNCH_THEN(df1.desc ? DeferOps<T>::pull(k1, (const T *)vol + (p->channels - 1) * k.vol_sc, grid, (T *)val + (p->channels - 1) * k.val_sc, df1.tl, st) : 0);
     }
     const int attr = big_lds<C>(gather_tiled<C, GRAD>);
     if (attr) return attr;
     const TileCount<C> t(p);
+    IP_DEFER(df, t, C);
     hipLaunchKernelGGL((gather_tiled<C, GRAD>), t.grid((int)p->batch), dim3(C::NT), smem_bytes<C>(), st,
-                       k, (const T *)vol, (const float *)grid, (T *)val, t.gx, t.gy, t.gz, t.nty, t.ntz, t.ntiles(), (int)p->batch);
-    IP_CHECK_LAUNCH();
+                       k, (const T *)vol, (const float *)grid, (T *)val, t.gx, t.gy, t.gz, t.nty, t.ntz, t.ntiles(), (int)p->batch, df.desc);
+    IP_CHECK_LAUNCH_THEN(!df.desc ? 0 : (GRAD ? DeferOps<T>::grad(k, vol, grid, val, df.tl, st) : DeferOps<T>::pull(k, vol, grid, val, df.tl, st)));
 }
 
 template <typename C0>
@@ -2130,9 +2162,10 @@ static int launch_push_impl(const interpol_problem *p, const KParams &k, const v
             const int attr = big_lds<C>(push_tiled<C, false, true>);
             if (attr) return attr;
             const TileCount<C> t(p);
+            IP_DEFER(df, t, C);
             hipLaunchKernelGGL((push_tiled<C, false, true>), t.grid((int)p->batch), dim3(C::NT), smem_bytes<C>(), st,
-                               k, (const T *)val, (const float *)grid, (float *)vol, t.gx, t.gy, t.gz, t.nty, t.ntz, t.ntiles(), (int)p->batch);
-            IP_CHECK_LAUNCH();
+                               k, (const T *)val, (const float *)grid, (float *)vol, t.gx, t.gy, t.gz, t.nty, t.ntz, t.ntiles(), (int)p->batch, df.desc);
+            IP_CHECK_LAUNCH_THEN(df.template push<T>(k, val, grid, vol, st));
         } else {
             return 0;
         }
@@ -2140,13 +2173,14 @@ static int launch_push_impl(const interpol_problem *p, const KParams &k, const v
     const int attr = val ? big_lds<C>(push_tiled<C, false>) : big_lds<C>(push_tiled<C, true>);
     if (attr) return attr;
     const TileCount<C> t(p);
+    IP_DEFER(df, t, C);
     if (val)
         hipLaunchKernelGGL((push_tiled<C, false>), t.grid((int)p->batch), dim3(C::NT), smem_bytes<C>(), st,
-                           k, (const T *)val, (const float *)grid, (float *)vol, t.gx, t.gy, t.gz, t.nty, t.ntz, t.ntiles(), (int)p->batch);
+                           k, (const T *)val, (const float *)grid, (float *)vol, t.gx, t.gy, t.gz, t.nty, t.ntz, t.ntiles(), (int)p->batch, df.desc);
     else
         hipLaunchKernelGGL((push_tiled<C, true>), t.grid((int)p->batch), dim3(C::NT), smem_bytes<C>(), st,
-                           k, (const T *)nullptr, (const float *)grid, (float *)vol, t.gx, t.gy, t.gz, t.nty, t.ntz, t.ntiles(), (int)p->batch);
-    IP_CHECK_LAUNCH();
+                           k, (const T *)nullptr, (const float *)grid, (float *)vol, t.gx, t.gy, t.gz, t.nty, t.ntz, t.ntiles(), (int)p->batch, df.desc);
+    IP_CHECK_LAUNCH_THEN(df.template push<T>(k, val, grid, vol, st));
 }
 
 // Coordinate mode dispatch (Cfg::GM): the dense-grid instantiation, or the general one for
@@ -2197,19 +2231,21 @@ static int launch_pullbwd(const interpol_problem *p, const KParams &k, const voi
             const int attr1 = big_lds<CW>(gradc1s_tiled<CW>);
             if (attr1) return attr1;
             const TileCount<CW> t1(p);
+            IP_DEFER(df1, t1, CW);
             hipLaunchKernelGGL((gradc1s_tiled<CW>), t1.grid((int)p->batch), dim3(CW::NT), smem_bytes<CW>(), st,
                                k, (const T *)gout, (const T *)vol, (const float *)grid, (float *)ggrid,
-                               t1.gx, t1.gy, t1.gz, t1.nty, t1.ntz, t1.ntiles(), (int)p->batch);
-            IP_CHECK_LAUNCH();
+                               t1.gx, t1.gy, t1.gz, t1.nty, t1.ntz, t1.ntiles(), (int)p->batch, df1.desc);
+            IP_CHECK_LAUNCH_THEN(df1.template gradc<T>(k, gout, vol, grid, ggrid, st));
         }
     }
     const int attr = big_lds<C>(pullbwd_tiled<C>);
     if (attr) return attr;
     const TileCount<C> t(p);
+    IP_DEFER(df, t, C);
     hipLaunchKernelGGL((pullbwd_tiled<C>), t.grid((int)p->batch), dim3(C::NT), smem_bytes<C>(), st,
                        k, (const T *)gout, (const T *)vol, (const float *)grid, (float *)gvol, (float *)ggrid,
-                       gsb, gsc, t.gx, t.gy, t.gz, t.nty, t.ntz, t.ntiles(), (int)p->batch);
-    IP_CHECK_LAUNCH();
+                       gsb, gsc, t.gx, t.gy, t.gz, t.nty, t.ntz, t.ntiles(), (int)p->batch, df.desc);
+    IP_CHECK_LAUNCH_THEN(df.desc ? DeferOps<T>::pullbwd(k, gout, vol, grid, gvol, ggrid, gsb, gsc, df.tl, st) : 0);
 }
 
 template <typename C>
@@ -2221,10 +2257,11 @@ static int launch_pushbwd(const interpol_problem *p, const KParams &k, const voi
     const int attr = big_lds<C>(pushbwd_tiled<C>);
     if (attr) return attr;
     const TileCount<C> t(p);
+    IP_DEFER(df, t, C);
     hipLaunchKernelGGL((pushbwd_tiled<C>), t.grid((int)p->batch), dim3(C::NT), smem_bytes<C>(), st,
                        k, (const T *)gvol_out, (const T *)val, (const float *)grid, (T *)gval, (float *)ggrid,
-                       t.gx, t.gy, t.gz, t.nty, t.ntz, t.ntiles(), (int)p->batch);
-    IP_CHECK_LAUNCH();
+                       t.gx, t.gy, t.gz, t.nty, t.ntz, t.ntiles(), (int)p->batch, df.desc);
+    IP_CHECK_LAUNCH_THEN(df.desc ? DeferOps<T>::pushbwd(k, gvol_out, val, grid, gval, ggrid, df.tl, st) : 0);
 }
 
 // Tile shapes: the box must hold tile + K + 2 * halo lattice points per dim.

@@ -42,7 +42,7 @@ struct Smem {
     float tabsgn[2][CAP];
     int   lo[2], hi[2];
     int   cmax[2];
-    int   dmax, pad;
+    int   dmax, nout;               // nout: valid pixels of the tile whose stencil leaves the box
     unsigned long long box[BOXSLOTS];
 };
 
@@ -231,6 +231,7 @@ struct Tile2 {
     {
         const int tid = opaque((int)threadIdx.x);
         if (tid < 2) { sm.lo[tid] = 0x7fffffff; sm.hi[tid] = -0x7fffffff; }
+        if (tid == 0) sm.nout = 0;
         valid = 0; inb = 0;
 #pragma unroll
         for (int v = 0; v < VPT; ++v) {
@@ -290,6 +291,7 @@ struct Tile2 {
             cell[v] = 0;
             if (((valid >> v) & 1) && y0 >= 0 && y0 + K0 < S[0] && z0 >= 0 && z0 + K1 < S[1]) { in |= 1u << v; cell[v] = y0 * PZ + z0; }
         }
+        if (valid & ~in) atomicAdd(&sm.nout, __popc(valid & ~in));     // (none for smooth deformations)
         __syncthreads();
     }
 };
@@ -309,7 +311,7 @@ __device__ __forceinline__ Lattice lattice2d(const KParams &p, int esz, int k0, 
 // ---------------------------------------------------------------------------
 template <typename T, int K0, int K1, int GM>
 __global__ __launch_bounds__(NT, 3) void pull2d(KParams p, const T *__restrict__ vol, const float *__restrict__ grid, T *__restrict__ val,
-                                             int gy, int gz, int ntz, int ntiles)
+                                             int gy, int gz, int ntz, int ntiles, unsigned long long *__restrict__ defer)
 {
     __shared__ Smem sm;
     constexpr int NC = Slot<T>::NC;
@@ -323,6 +325,12 @@ __global__ __launch_bounds__(NT, 3) void pull2d(KParams p, const T *__restrict__
         float c[VPT][2];
         Tile2<K0, K1, GM>::load(p, grid, b, gy, gz, oy0, oz0, c);
         tl.build(p, L, c, gy, gz, oy0, oz0, sm);
+    }
+    if (defer) {                                    // (block-uniform) too rough for the box: the generic kernel takes the tile, defer.hip
+        bool hand_back = sm.nout > ((NS / 64) << ((p.dbg >> 9) & 7));                  // (a wave pays the per-thread fallback of its slowest lane)
+        if (hand_back) hand_back = tiled::tile_smooth(p, grid, b, 2, 0, oy0, oz0, 1, TY, TZ, 1, gy, gz, sm.hi);
+        if (threadIdx.x == 0) defer[blockIdx.x] = hand_back ? tile_desc(b, 0, oy0 / TY, oz0 / TZ) : 0ull;
+        if (hand_back) return;
     }
     prof_mark(0);
     // the box's columns are contiguous runs of the unit-stride dim, sign +1 (dst1: sign 0 at index 0, quirk B-3)
@@ -479,7 +487,7 @@ __global__ __launch_bounds__(NT, 3) void pull2d(KParams p, const T *__restrict__
 // ---------------------------------------------------------------------------
 template <typename T, int K0, int K1, int GM>
 __global__ __launch_bounds__(NT, 3) void gradc2d(KParams p, const T *__restrict__ vol, const T *__restrict__ gout, const float *__restrict__ grid,
-                                              float *__restrict__ ggrid, int gy, int gz, int ntz, int ntiles)
+                                              float *__restrict__ ggrid, int gy, int gz, int ntz, int ntiles, unsigned long long *__restrict__ defer)
 {
     __shared__ Smem sm;
     constexpr int NC = Slot<T>::NC;
@@ -493,6 +501,12 @@ __global__ __launch_bounds__(NT, 3) void gradc2d(KParams p, const T *__restrict_
         float c[VPT][2];
         Tile2<K0, K1, GM>::load(p, grid, b, gy, gz, oy0, oz0, c);
         tl.build(p, L, c, gy, gz, oy0, oz0, sm);
+    }
+    if (defer) {                                    // (block-uniform) too rough for the box: the generic kernel takes the tile, defer.hip
+        bool hand_back = sm.nout > ((NS / 64) << ((p.dbg >> 9) & 7));                  // (a wave pays the per-thread fallback of its slowest lane)
+        if (hand_back) hand_back = tiled::tile_smooth(p, grid, b, 2, 0, oy0, oz0, 1, TY, TZ, 1, gy, gz, sm.hi);
+        if (threadIdx.x == 0) defer[blockIdx.x] = hand_back ? tile_desc(b, 0, oy0 / TY, oz0 / TZ) : 0ull;
+        if (hand_back) return;
     }
     prof_mark(0);
     // the box's columns are contiguous runs of the unit-stride dim, sign +1 (dst1: sign 0 at index 0, quirk B-3)
@@ -671,7 +685,7 @@ __global__ __launch_bounds__(NT, 3) void gradc2d(KParams p, const T *__restrict_
 // ---------------------------------------------------------------------------
 template <typename T, int K0, int K1, int GM, int MODE>
 __global__ __launch_bounds__(NT, 4) void push2d(KParams p, const T *__restrict__ val, const float *__restrict__ grid, float *__restrict__ vol,
-                                             int gy, int gz, int ntz, int ntiles)
+                                             int gy, int gz, int ntz, int ntiles, unsigned long long *__restrict__ defer)
 {
     __shared__ Smem sm;
     const int tid = threadIdx.x;
@@ -704,6 +718,12 @@ __global__ __launch_bounds__(NT, 4) void push2d(KParams p, const T *__restrict__
         float c[VPT][2];
         Tile2<K0, K1, GM>::load(p, grid, b, gy, gz, oy0, oz0, c);
         tl.build(p, L, c, gy, gz, oy0, oz0, sm);
+    }
+    if (defer) {                                    // (block-uniform) too rough for the box: the generic kernel takes the tile, defer.hip
+        bool hand_back = sm.nout > ((NS / 64) << ((p.dbg >> 9) & 7));                  // (a wave pays the per-thread fallback of its slowest lane)
+        if (hand_back) hand_back = tiled::tile_smooth(p, grid, b, 2, 0, oy0, oz0, 1, TY, TZ, 1, gy, gz, sm.hi);
+        if (threadIdx.x == 0) defer[blockIdx.x] = hand_back ? tile_desc(b, 0, oy0 / TY, oz0 / TZ) : 0ull;
+        if (hand_back) return;
     }
     prof_mark(4);
     // density: samples per first-tap cell (16-bit counters in the box, cleared again)
@@ -865,15 +885,18 @@ int IP_SYM(try_tiled2d_pull_, IP_TSFX)(const interpol_problem *p, const KParams 
     const int gy = (int)p->grid_shape[0], gz = (int)p->grid_shape[1];
     const int nty = (gy + TY - 1) / TY, ntz = (gz + TZ - 1) / TZ, ntiles = nty * ntz;
     const dim3 g((unsigned)(ntiles * (int)p->batch));
+    const Defer df(k, st, ntiles, p->batch, 1, nty, ntz, 1, TY, TZ);
     int rc;
 #define IP_PULL2D(GM) rc = by_orders<T, GM>(k.order[0], k.order[1], [&](auto k0, auto k1) {                             \
         hipLaunchKernelGGL((pull2d<T, decltype(k0)::value, decltype(k1)::value, GM>), g, dim3(NT), 0, st, k, (const T *)vol, \
-                           (const float *)grid, (T *)val, gy, gz, ntz, ntiles); })
+                           (const float *)grid, (T *)val, gy, gz, ntz, ntiles, df.desc); })
     if (k.sep == 0) IP_PULL2D(0); else if (k.sep == 1) IP_PULL2D(1); else if (k.sep == 2) IP_PULL2D(2); else IP_PULL2D(3);
 #undef IP_PULL2D
     if (!rc) return 0;
     const hipError_t e = hipGetLastError();
-    return e == hipSuccess ? 1 : (int)e;
+    if (e != hipSuccess) return (int)e;
+    const int rd = df.desc ? DeferOps<T>::pull(k, vol, grid, val, df.tl, st) : 0;
+    return rd ? rd : 1;
 }
 
 // grid gradient of pull / push (roles swapped) / count (gout == NULL), dense grids and displacement fields
@@ -885,15 +908,18 @@ int IP_SYM(try_tiled2d_gradc_, IP_TSFX)(const interpol_problem *p, const KParams
     const int gy = (int)p->grid_shape[0], gz = (int)p->grid_shape[1];
     const int nty = (gy + TY - 1) / TY, ntz = (gz + TZ - 1) / TZ, ntiles = nty * ntz;
     const dim3 g((unsigned)(ntiles * (int)p->batch));
+    const Defer df(k, st, ntiles, p->batch, 1, nty, ntz, 1, TY, TZ);
     int rc;
 #define IP_GRADC2D(GM) rc = by_orders<T, GM>(k.order[0], k.order[1], [&](auto k0, auto k1) {                             \
         hipLaunchKernelGGL((gradc2d<T, decltype(k0)::value, decltype(k1)::value, GM>), g, dim3(NT), 0, st, k, (const T *)vol, \
-                           (const T *)gout, (const float *)grid, (float *)ggrid, gy, gz, ntz, ntiles); })
+                           (const T *)gout, (const float *)grid, (float *)ggrid, gy, gz, ntz, ntiles, df.desc); })
     if (k.sep == 0) IP_GRADC2D(0); else IP_GRADC2D(2);
 #undef IP_GRADC2D
     if (!rc) return 0;
     const hipError_t e = hipGetLastError();
-    return e == hipSuccess ? 1 : (int)e;
+    if (e != hipSuccess) return (int)e;
+    const int rd = df.template gradc<T>(k, gout, vol, grid, ggrid, st);
+    return rd ? rd : 1;
 }
 
 int IP_SYM(try_tiled2d_push_, IP_TSFX)(const interpol_problem *p, const KParams &k, const void *val, const void *grid, void *vol, hipStream_t st)
@@ -905,17 +931,20 @@ int IP_SYM(try_tiled2d_push_, IP_TSFX)(const interpol_problem *p, const KParams 
     const int nty = (gy + TY - 1) / TY, ntz = (gz + TZ - 1) / TZ, ntiles = nty * ntz;
     const dim3 g((unsigned)(ntiles * (int)p->batch));
     const int mode = !val ? 1 : (k.cc ? 2 : 0);
+    const Defer df(k, st, ntiles, p->batch, 1, nty, ntz, 1, TY, TZ);
     int rc;
 #define IP_PUSH2D(GM, MODE) rc = by_orders<T, GM>(k.order[0], k.order[1], [&](auto k0, auto k1) {                       \
         hipLaunchKernelGGL((push2d<T, decltype(k0)::value, decltype(k1)::value, GM, MODE>), g, dim3(NT), 0, st, k, (const T *)val, \
-                           (const float *)grid, (float *)vol, gy, gz, ntz, ntiles); })
+                           (const float *)grid, (float *)vol, gy, gz, ntz, ntiles, df.desc); })
 #define IP_PUSH2D_GM(MODE) { if (k.sep == 0) IP_PUSH2D(0, MODE); else if (k.sep == 1) IP_PUSH2D(1, MODE); else if (k.sep == 2) IP_PUSH2D(2, MODE); else IP_PUSH2D(3, MODE); }
     if (mode == 0) IP_PUSH2D_GM(0) else if (mode == 1) IP_PUSH2D_GM(1) else IP_PUSH2D_GM(2)
 #undef IP_PUSH2D_GM
 #undef IP_PUSH2D
     if (!rc) return 0;
     const hipError_t e = hipGetLastError();
-    return e == hipSuccess ? 1 : (int)e;
+    if (e != hipSuccess) return (int)e;
+    const int rd = df.template push<T>(k, val, grid, vol, st);
+    return rd ? rd : 1;
 }
 
 #ifdef IP_PROF

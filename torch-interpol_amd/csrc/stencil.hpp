@@ -61,6 +61,15 @@ struct KParams {
     double mask_hi[3];      // n-1+threshold
 };
 
+// Tiles that an LDS-tiled kernel hands back to the generic kernels (defer.hip): one 64-bit descriptor per (tile, batch
+// item) work item -- bit 63: handed back; batch item (20 bits), tile coordinates x, y, z (14 bits each) -- and the
+// tile extents.  desc == NULL: every sample (the plain generic launch).
+struct TileList { const unsigned long long *desc; int nwork; int e[3]; };
+__host__ __device__ inline unsigned long long tile_desc(int64_t b, int cx, int cy, int cz)
+{
+    return (1ull << 63) | ((unsigned long long)b << 42) | ((unsigned long long)cx << 28) | ((unsigned long long)cy << 14) | (unsigned long long)cz;
+}
+
 enum { MODE_ND = 0, MODE_ISO1 = 1, MODE_ISO0 = 2 };
 enum { NEED_W = 0, NEED_G = 1, NEED_H = 2 };
 

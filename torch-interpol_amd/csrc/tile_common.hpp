@@ -9,6 +9,7 @@
 // ===========================================================================
 #pragma once
 #include "stencil.hpp"
+#include "defer.hpp"
 
 namespace ip {
 namespace tiled {
@@ -207,6 +208,37 @@ __device__ __noinline__ float tap_weight_t(Lattice L, float gx_, float gy_, floa
 // 1.49 ms; the scatters LOSE, 2.31 -> 2.51 ms -- neighbouring tiles then flush their halos
 // into the same L2 lines at the same time -- so the scatter kernels keep the strided order.)
 // ---------------------------------------------------------------------------
+// Part of the hand-back decision (defer.hip), evaluated only for tiles with many samples outside the box: is the
+// deformation SMOOTH over the tile (a zoom, a large but regular displacement)?  Then neighbouring samples share their
+// lattice neighbourhood and the generic kernel serves the tile well.  Under rough (i.i.d.) coordinates it would thrash
+// the caches and the tile keeps its samples: the in-box majority still runs from LDS.  Measure: mean absolute second
+// difference of the coordinates along the last dim, summed over the dims, below one voxel.  Separable / affine lattices
+// and displacement fields count as smooth.  Block-uniform; `acc`: two free ints of LDS.
+__device__ __forceinline__ bool tile_smooth(const KParams &p, const float *__restrict__ grid, int64_t b, int D, int ox0, int oy0, int oz0,
+                                            int ex, int ey, int ez, int gx, int gy, int gz, int *acc)
+{
+    if (p.sep) return true;
+    if (threadIdx.x < 2) acc[threadIdx.x] = 0;
+    __syncthreads();
+    float s = 0.f; int n = 0;
+    for (int id = threadIdx.x; id < ex * ey * ez; id += 2 * (int)blockDim.x) {      // a sample of the tile is plenty
+        int r = id;
+        const int dz = r % ez; r /= ez;
+        const int dy = r % ey, dx = r / ey;
+        const int ox = ox0 + dx, oy = oy0 + dy, oz = oz0 + dz;
+        if (ox >= gx || oy >= gy || oz + 2 >= gz || dz + 2 >= ez) continue;
+        const float *q = grid + b * p.grid_sb + (((int64_t)ox * gy + oy) * gz + oz) * D;
+        for (int d = 0; d < D; ++d) s += __builtin_fabsf(q[d] - 2.f * q[D + d] + q[2 * D + d]);
+        ++n;
+    }
+    s = s < 1e4f ? s : 1e4f;                           // (also catches NaN)
+    if (n) { atomicAdd(&acc[0], (int)(s * 16.f)); atomicAdd(&acc[1], n); }
+    __syncthreads();
+    const bool smooth = acc[0] < acc[1] * 16 || acc[1] == 0;
+    __syncthreads();
+    return smooth;
+}
+
 struct WorkRange {
     int first, end, step;
     __device__ __forceinline__ explicit WorkRange(int total, bool by_xcd = true)
