@@ -487,6 +487,7 @@ def test_stretched_tiles_are_handed_back_to_the_generic_kernels(dim, order, dtyp
     agree; so must a problem where only SOME tiles are stretched, ragged tiles, batch > 1, masked extrapolation."""
     from interpol import _hip
     NOHB = 256 << 8
+    BWD = (0, NOHB, _hip.FLAG_FORCE_TILED, _hip.FLAG_FORCE_TILED | NOHB)       # (3-D trilinear backward: generic unless forced)
     gen = torch.Generator().manual_seed(100 * dim + order)
     ishape = (90, 70, 85)[3 - dim:] if dim == 3 else (200, 170)
     oshape = (38, 33, 45)[3 - dim:] if dim == 3 else (90, 75)
@@ -513,20 +514,20 @@ def test_stretched_tiles_are_handed_back_to_the_generic_kernels(dim, order, dtyp
                     _same(_hip.scatter(op, src if op == "push" else None, grid, list(ishape), b, o, ex, flags=fl).float(), ref, tol, (op, dim, order, dtype, bound, ex, fl))
             for need in ((True, True), (False, True), (True, False)):
                 ref = _hip.pull_backward(src, vol, grid, b, o, ex, *need, flags=_hip.FLAG_NO_FASTPATH)
-                for fl in (0, NOHB):
+                for fl in BWD:
                     got = _hip.pull_backward(src, vol, grid, b, o, ex, *need, flags=fl)
                     for x, y in zip(got, ref):
                         assert (x is None) == (y is None)
                         if x is not None:
                             _same(x.float(), y.float(), tol, ("pull bwd", need, dim, order, dtype, bound, ex, fl))
                 ref = _hip.push_backward(gvo, src, grid, b, o, ex, *need, flags=_hip.FLAG_NO_FASTPATH)
-                for fl in (0, NOHB):
+                for fl in BWD:
                     got = _hip.push_backward(gvo, src, grid, b, o, ex, *need, flags=fl)
                     for x, y in zip(got, ref):
                         if x is not None:
                             _same(x.float(), y.float(), tol, ("push bwd", need, dim, order, dtype, bound, ex, fl))
             ref = _hip.push_backward(gvo[:, :1].contiguous(), None, grid, b, o, ex, False, True, flags=_hip.FLAG_NO_FASTPATH)[1]
-            for fl in (0, NOHB):
+            for fl in BWD:
                 _same(_hip.push_backward(gvo[:, :1].contiguous(), None, grid, b, o, ex, False, True, flags=fl)[1], ref, tol, ("count bwd", dim, order, dtype, bound, ex, fl))
 
 
