@@ -8,7 +8,8 @@
 
 namespace ip {
 
-unsigned long long *defer_buffer(hipStream_t st, int64_t nwork, int64_t batch, int ntx, int nty, int ntz);
+// the descriptor list of this stream for a launch of `nwork` work items (desc == NULL: no hand-back), stamped with a fresh launch number
+DeferArgs defer_buffer(hipStream_t st, int64_t nwork, int64_t batch, int ntx, int nty, int ntz);
 
 #define IP_DEFER_DECL(sfx) \
 int launch_pull_deferred_##sfx(const KParams &p, const void *vol, const void *grid, void *val, const TileList &tl, hipStream_t st); \
@@ -38,12 +39,14 @@ IP_DEFER_OPS(float, f32) IP_DEFER_OPS(bf16_t, bf16) IP_DEFER_OPS(f16_t, f16)
 
 struct Defer {
     unsigned long long *desc;
+    DeferArgs args;
     TileList tl;
     // nwork = ntiles * batch work items of tiles ex x ey x ez (kernel dims x, y, z: the LAST dims of the problem)
     Defer(const KParams &k, hipStream_t st, int64_t ntiles, int64_t batch, int ntx, int nty, int ntz, int ex, int ey, int ez)
     {
-        desc = (k.dbg & 256) ? nullptr : defer_buffer(st, ntiles * batch, batch, ntx, nty, ntz);     // dbg 256: A/B switch, no hand-back
-        tl.desc = desc; tl.nwork = (int)(ntiles * batch); tl.e[0] = ex; tl.e[1] = ey; tl.e[2] = ez;
+        args = (k.dbg & 256) ? DeferArgs{ nullptr, nullptr, nullptr, 0u } : defer_buffer(st, ntiles * batch, batch, ntx, nty, ntz);     // dbg 256: A/B switch, no hand-back
+        desc = args.desc;
+        tl.desc = desc; tl.gen = args.gen; tl.cur = args.cur; tl.nwork = (int)(ntiles * batch); tl.e[0] = ex; tl.e[1] = ey; tl.e[2] = ez;
     }
     // push / count / push + count (k.cc) of the handed-back tiles into the float accumulator `acc`; val == NULL: count
     template <typename T> int push(const KParams &k, const void *val, const void *grid, void *acc, hipStream_t st) const

@@ -72,15 +72,22 @@ template <int D> struct SampleIter<false, D> {
 template <int D> struct SampleIter<true, D> {
     int64_t b, o; bool ok;
     int w, s, c[3]; bool have;
-    __device__ __forceinline__ SampleIter(const KParams &p, int B, const TileList &tl) { w = blockIdx.x; have = false; next(p, B, tl); }
+    __device__ __forceinline__ SampleIter(const KParams &p, int B, const TileList &tl)
+    {
+        // nothing handed back to this block (the usual case): one parallel look at its descriptors, not a serial walk
+        int any = 0;
+        for (int ww = blockIdx.x + threadIdx.x * gridDim.x; ww < tl.nwork; ww += BLOCK * gridDim.x) any |= (int)(tl.gen[ww] == tl.cur);
+        if (!__syncthreads_or(any)) { ok = false; return; }
+        w = blockIdx.x; have = false; next(p, B, tl);
+    }
     __device__ __forceinline__ void next(const KParams &p, int, const TileList &tl)
     {
         const int ns = tl.e[0] * tl.e[1] * tl.e[2];
         for (;;) {
             if (w >= tl.nwork) { ok = false; return; }
             if (!have) {
+                if (tl.gen[w] != tl.cur) { w += gridDim.x; continue; }
                 const unsigned long long d = tl.desc[w];
-                if (!(d >> 63)) { w += gridDim.x; continue; }
                 b = (int64_t)((d >> 42) & 0xfffffull);
                 c[0] = (int)((d >> 28) & 0x3fffull) * tl.e[0]; c[1] = (int)((d >> 14) & 0x3fffull) * tl.e[1]; c[2] = (int)(d & 0x3fffull) * tl.e[2];
                 have = true; s = threadIdx.x;

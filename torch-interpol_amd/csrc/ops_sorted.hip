@@ -304,7 +304,7 @@ __device__ __forceinline__ void slow_taps(const KParams &p, const Lattice &L, co
 template <typename T, int K, int GM>
 __global__ __launch_bounds__(NT, 4) void pull_sorted(KParams p, const T *__restrict__ vol, const float *__restrict__ grid,
                                                      T *__restrict__ val, int gx, int gy, int gz, int nty, int ntz, int ntiles, int nbatch,
-                                                     unsigned long long *__restrict__ defer)
+                                                     DeferArgs defer)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     Smem &sm = *reinterpret_cast<Smem *>(smem_raw);
@@ -326,11 +326,11 @@ __global__ __launch_bounds__(NT, 4) void pull_sorted(KParams p, const T *__restr
         Tile<K, GM>::load(p, grid, b, g, tid, cnext);
         tl.build(p, L, g, sm, tid, cnext);
         const int nslow = sm.nslow < SLOWCAP ? sm.nslow : SLOWCAP;
-        if (defer) {                                                 // (block-uniform) too rough for the box: the generic kernel takes the tile, defer.hip
+        if (defer.flag) {                                                 // (block-uniform) too rough for the box: the generic kernel takes the tile, defer.hip
             bool hand_back = sm.nslow > (HANDBACK << ((p.dbg >> 9) & 7));
             if (hand_back) hand_back = tiled::tile_smooth(p, grid, b, 3, g.ox0, g.oy0, g.oz0, TS, TS, TS, g.gx, g.gy, g.gz, sm.hi);
-            if (tid == 0) defer[work] = hand_back ? tile_desc(b, g.ox0 / TS, g.oy0 / TS, g.oz0 / TS) : 0ull;
-            if (hand_back) { __syncthreads(); continue; }
+            if (hand_back && tid == 0) defer_mark(defer, work, tile_desc(b, g.ox0 / TS, g.oy0 / TS, g.oz0 / TS));
+            if (hand_back && defer.desc) { __syncthreads(); continue; }
         }
         // rows of the box are contiguous runs of the lattice's unit-stride dim, sign +1 throughout
         // (dst1 has sign 0 at index 0 -- quirk B-3 -- so its run must start at 1)
@@ -539,7 +539,7 @@ __global__ __launch_bounds__(NT, 4) void pull_sorted(KParams p, const T *__restr
 template <typename T, int K, int GM>
 __global__ __launch_bounds__(NT, 4) void gradc_sorted(KParams p, const T *__restrict__ vol, const T *__restrict__ gout, const float *__restrict__ grid,
                                                       float *__restrict__ ggrid, int gx, int gy, int gz, int nty, int ntz, int ntiles, int nbatch,
-                                                      unsigned long long *__restrict__ defer)
+                                                      DeferArgs defer)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     Smem &sm = *reinterpret_cast<Smem *>(smem_raw);
@@ -561,11 +561,11 @@ __global__ __launch_bounds__(NT, 4) void gradc_sorted(KParams p, const T *__rest
         Tile<K, GM>::load(p, grid, b, g, tid, cnext);
         tl.build(p, L, g, sm, tid, cnext);
         const int nslow = sm.nslow < SLOWCAP ? sm.nslow : SLOWCAP;
-        if (defer) {                                                 // (block-uniform) too rough for the box: the generic kernel takes the tile, defer.hip
+        if (defer.flag) {                                                 // (block-uniform) too rough for the box: the generic kernel takes the tile, defer.hip
             bool hand_back = sm.nslow > (HANDBACK << ((p.dbg >> 9) & 7));
             if (hand_back) hand_back = tiled::tile_smooth(p, grid, b, 3, g.ox0, g.oy0, g.oz0, TS, TS, TS, g.gx, g.gy, g.gz, sm.hi);
-            if (tid == 0) defer[work] = hand_back ? tile_desc(b, g.ox0 / TS, g.oy0 / TS, g.oz0 / TS) : 0ull;
-            if (hand_back) { __syncthreads(); continue; }
+            if (hand_back && tid == 0) defer_mark(defer, work, tile_desc(b, g.ox0 / TS, g.oy0 / TS, g.oz0 / TS));
+            if (hand_back && defer.desc) { __syncthreads(); continue; }
         }
         // rows of the box are contiguous runs of the lattice's unit-stride dim, sign +1 throughout
         // (dst1 has sign 0 at index 0 -- quirk B-3 -- so its run must start at 1)
@@ -847,7 +847,7 @@ IP_ADDROW(0) IP_ADDROW(1) IP_ADDROW(2) IP_ADDROW(3)
 template <typename T, int K, int GM, int MODE>
 __global__ __launch_bounds__(NT, 4) void push_sorted(KParams p, const T *__restrict__ val, const float *__restrict__ grid,
                                                      float *__restrict__ vol, int gx, int gy, int gz, int nty, int ntz, int ntiles, int nbatch,
-                                                     unsigned long long *__restrict__ defer)
+                                                     DeferArgs defer)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     Smem &sm = *reinterpret_cast<Smem *>(smem_raw);
@@ -867,11 +867,11 @@ __global__ __launch_bounds__(NT, 4) void push_sorted(KParams p, const T *__restr
         Tile<K, GM>::load(p, grid, b, g, tid, cnext);
         tl.build(p, L, g, sm, tid, cnext);
         const int nslow = sm.nslow < SLOWCAP ? sm.nslow : SLOWCAP;
-        if (defer) {                                                 // (block-uniform) too rough for the box: the generic kernel takes the tile, defer.hip
+        if (defer.flag) {                                                 // (block-uniform) too rough for the box: the generic kernel takes the tile, defer.hip
             bool hand_back = sm.nslow > (HANDBACK << ((p.dbg >> 9) & 7));
             if (hand_back) hand_back = tiled::tile_smooth(p, grid, b, 3, g.ox0, g.oy0, g.oz0, TS, TS, TS, g.gx, g.gy, g.gz, sm.hi);
-            if (tid == 0) defer[work] = hand_back ? tile_desc(b, g.ox0 / TS, g.oy0 / TS, g.oz0 / TS) : 0ull;
-            if (hand_back) { __syncthreads(); continue; }
+            if (hand_back && tid == 0) defer_mark(defer, work, tile_desc(b, g.ox0 / TS, g.oy0 / TS, g.oz0 / TS));
+            if (hand_back && defer.desc) { __syncthreads(); continue; }
         }
         // ---- sample density: the largest number of sorted samples that share a first-tap cell bounds
         // what any lattice point can receive.  Counted in the (free) box: 16-bit counters, two per word.
@@ -1163,7 +1163,7 @@ static int launch_pull(const interpol_problem *p, const KParams &k, const void *
     const TileCount t(p);
     const Defer df(k, st, t.ntiles(), p->batch, t.ntx, t.nty, t.ntz, TS, TS, TS);
     hipLaunchKernelGGL((pull_sorted<T, K, GM>), t.grid((int)p->batch), dim3(NT), sizeof(Smem), st,
-                       k, (const T *)vol, (const float *)grid, (T *)val, t.gx, t.gy, t.gz, t.nty, t.ntz, t.ntiles(), (int)p->batch, df.desc);
+                       k, (const T *)vol, (const float *)grid, (T *)val, t.gx, t.gy, t.gz, t.nty, t.ntz, t.ntiles(), (int)p->batch, df.args);
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) return (int)e;
     const int rc = df.desc ? DeferOps<T>::pull(k, vol, grid, val, df.tl, st) : 0;
@@ -1178,7 +1178,7 @@ static int launch_gradc(const interpol_problem *p, const KParams &k, const void 
     const TileCount t(p);
     const Defer df(k, st, t.ntiles(), p->batch, t.ntx, t.nty, t.ntz, TS, TS, TS);
     hipLaunchKernelGGL((gradc_sorted<T, K, GM>), t.grid((int)p->batch), dim3(NT), sizeof(Smem), st,
-                       k, (const T *)vol, (const T *)gout, (const float *)grid, (float *)ggrid, t.gx, t.gy, t.gz, t.nty, t.ntz, t.ntiles(), (int)p->batch, df.desc);
+                       k, (const T *)vol, (const T *)gout, (const float *)grid, (float *)ggrid, t.gx, t.gy, t.gz, t.nty, t.ntz, t.ntiles(), (int)p->batch, df.args);
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) return (int)e;
     const int rc = df.template gradc<T>(k, gout, vol, grid, ggrid, st);
@@ -1196,7 +1196,7 @@ static int launch_push(const interpol_problem *p, const KParams &k, const void *
         const int attr = big_lds<push_sorted<T, K, GM, MODE>>(sizeof(Smem));                                          \
         if (attr) return attr;                                                                                        \
         hipLaunchKernelGGL((push_sorted<T, K, GM, MODE>), t.grid((int)p->batch), dim3(NT), sizeof(Smem), st,          \
-                           k, (const T *)val, (const float *)grid, (float *)vol, t.gx, t.gy, t.gz, t.nty, t.ntz, t.ntiles(), (int)p->batch, df.desc); \
+                           k, (const T *)val, (const float *)grid, (float *)vol, t.gx, t.gy, t.gz, t.nty, t.ntz, t.ntiles(), (int)p->batch, df.args); \
     }
     if (!val) IP_LAUNCH_PUSH(1)
     else if (k.cc) IP_LAUNCH_PUSH(2)

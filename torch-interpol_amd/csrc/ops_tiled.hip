@@ -162,16 +162,16 @@ struct TileGeom {
 };
 
 // Stretched beyond the box (more than 1/8 of the tile's samples outside it, smooth coordinates): the tile is handed back to the generic kernel
-// of the operator (defer.hip) instead of crawling through the per-thread fallback.  Block-uniform; every work item
-// writes its descriptor.  Call after Box::build.
+// of the operator (defer.hip) instead of crawling through the per-thread fallback.  Block-uniform.  Call after Box::build.
 template <typename C>
-__device__ __forceinline__ bool hand_back(unsigned long long *defer, int work, int64_t b, const TileGeom &g, int nslow, const KParams &p,
+__device__ __forceinline__ bool hand_back(const DeferArgs &defer, int work, int64_t b, const TileGeom &g, int nslow, const KParams &p,
                                           const float *__restrict__ grid, Smem &sm)
 {
-    if (!defer) return false;
+    if (!defer.flag) return false;
     bool hb = nslow > ((C::NS / 8) << ((p.dbg >> 9) & 7));      // measured: tools/handback_sweep.py, profiles/r02_handback.txt
     if (hb) hb = tile_smooth(p, grid, b, C::D, g.ox0, g.oy0, g.oz0, C::TX, C::TY, C::TZ, g.gx, g.gy, g.gz, sm.hi);
-    if (threadIdx.x == 0) defer[work] = hb ? tile_desc(b, g.ox0 / C::TX, g.oy0 / C::TY, g.oz0 / C::TZ) : 0ull;
+    if (hb && threadIdx.x == 0) defer_mark(defer, work, tile_desc(b, g.ox0 / C::TX, g.oy0 / C::TY, g.oz0 / C::TZ));
+    hb = hb && defer.desc != nullptr;
     if (hb) __syncthreads();                           // everyone has read sm.nslow before the next tile's build resets it
     return hb;
 }
@@ -545,7 +545,7 @@ __device__ __forceinline__ void gather_box(const Smem &sm, const Box<C> &box, co
 // ---------------------------------------------------------------------------
 template <typename C, bool GRAD>
 __global__ __launch_bounds__(C::NT) void gather_tiled(KParams p, const typename C::T *__restrict__ vol, const float *__restrict__ grid,
-                                                      typename C::T *__restrict__ val, int gx, int gy, int gz, int nty, int ntz, int ntiles, int nbatch, unsigned long long *__restrict__ defer)
+                                                      typename C::T *__restrict__ val, int gx, int gy, int gz, int nty, int ntz, int ntiles, int nbatch, DeferArgs defer)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     Smem &sm = *reinterpret_cast<Smem *>(smem_raw);
@@ -637,7 +637,7 @@ __global__ __launch_bounds__(C::NT) void gather_tiled(KParams p, const typename 
 template <typename C>
 __global__ __launch_bounds__(C::NT) void pull2_tiled(KParams p, const typename C::T *__restrict__ vol, const float *__restrict__ grid,
                                                      typename C::T *__restrict__ val, int gx, int gy, int gz, int nty, int ntz,
-                                                     int ntiles, int nbatch, unsigned long long *__restrict__ defer)
+                                                     int ntiles, int nbatch, DeferArgs defer)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     Smem &sm = *reinterpret_cast<Smem *>(smem_raw);
@@ -801,7 +801,7 @@ __global__ __launch_bounds__(C::NT) void pull2_tiled(KParams p, const typename C
 template <typename C>
 __global__ __launch_bounds__(C::NT) void pull1s_tiled(KParams p, const typename C::T *__restrict__ vol, const float *__restrict__ grid,
                                                      typename C::T *__restrict__ val, int gx, int gy, int gz, int nty, int ntz,
-                                                     int ntiles, int nbatch, unsigned long long *__restrict__ defer)
+                                                     int ntiles, int nbatch, DeferArgs defer)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     Smem &sm = *reinterpret_cast<Smem *>(smem_raw);
@@ -956,7 +956,7 @@ __global__ __launch_bounds__(C::NT) void pull1s_tiled(KParams p, const typename 
 template <typename C>
 __global__ __launch_bounds__(C::NT) void grad1s_tiled(KParams p, const typename C::T *__restrict__ vol, const float *__restrict__ grid,
                                                      typename C::T *__restrict__ val, int gx, int gy, int gz, int nty, int ntz,
-                                                     int ntiles, int nbatch, unsigned long long *__restrict__ defer)
+                                                     int ntiles, int nbatch, DeferArgs defer)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     Smem &sm = *reinterpret_cast<Smem *>(smem_raw);
@@ -1127,7 +1127,7 @@ __global__ __launch_bounds__(C::NT) void grad1s_tiled(KParams p, const typename 
 template <typename C>
 __global__ __launch_bounds__(C::NT) void gradc1s_tiled(KParams p, const typename C::T *__restrict__ gout, const typename C::T *__restrict__ vol,
                                                        const float *__restrict__ grid, float *__restrict__ ggrid,
-                                                       int gx, int gy, int gz, int nty, int ntz, int ntiles, int nbatch, unsigned long long *__restrict__ defer)
+                                                       int gx, int gy, int gz, int nty, int ntz, int ntiles, int nbatch, DeferArgs defer)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     Smem &sm = *reinterpret_cast<Smem *>(smem_raw);
@@ -1712,7 +1712,7 @@ __device__ __forceinline__ bool scatter_pair(const KParams &p, const Lattice &L,
 template <typename C, bool COUNT, bool WC = false>
 __global__ __launch_bounds__(C::NT) void push_tiled(KParams p, const typename C::T *__restrict__ val, const float *__restrict__ grid,
                                                     float *__restrict__ vol, int gx, int gy, int gz, int nty, int ntz,
-                                                    int ntiles, int nbatch, unsigned long long *__restrict__ defer)
+                                                    int ntiles, int nbatch, DeferArgs defer)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     Smem &sm = *reinterpret_cast<Smem *>(smem_raw);
@@ -1787,7 +1787,7 @@ template <typename C>
 __global__ __launch_bounds__(C::NT) void pullbwd_tiled(KParams p, const typename C::T *__restrict__ gout, const typename C::T *__restrict__ vol,
                                                        const float *__restrict__ grid, float *__restrict__ gvol,
                                                        float *__restrict__ ggrid, int64_t gvol_sb, int64_t gvol_sc,
-                                                       int gx, int gy, int gz, int nty, int ntz, int ntiles, int nbatch, unsigned long long *__restrict__ defer)
+                                                       int gx, int gy, int gz, int nty, int ntz, int ntiles, int nbatch, DeferArgs defer)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     Smem &sm = *reinterpret_cast<Smem *>(smem_raw);
@@ -1896,7 +1896,7 @@ template <typename C>
 __global__ __launch_bounds__(C::NT) void pushbwd_tiled(KParams p, const typename C::T *__restrict__ gvol_out,
                                                        const typename C::T *__restrict__ val, const float *__restrict__ grid,
                                                        typename C::T *__restrict__ gval, float *__restrict__ ggrid,
-                                                       int gx, int gy, int gz, int nty, int ntz, int ntiles, int nbatch, unsigned long long *__restrict__ defer)
+                                                       int gx, int gy, int gz, int nty, int ntz, int ntiles, int nbatch, DeferArgs defer)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     Smem &sm = *reinterpret_cast<Smem *>(smem_raw);
@@ -2066,7 +2066,7 @@ static int launch_pull2_impl(const interpol_problem *p, const KParams &k, const 
         const TileCount<C> t(p);
         IP_DEFER(df, t, C);
         hipLaunchKernelGGL((pull2_tiled<C>), t.grid((int)p->batch), dim3(C::NT), smem_bytes<C>(), st,
-                           k, (const T *)vol, (const float *)grid, (T *)val, t.gx, t.gy, t.gz, t.nty, t.ntz, t.ntiles(), (int)p->batch, df.desc);
+                           k, (const T *)vol, (const float *)grid, (T *)val, t.gx, t.gy, t.gz, t.nty, t.ntz, t.ntiles(), (int)p->batch, df.args);
         IP_CHECK_LAUNCH_THEN(df.desc ? DeferOps<T>::pull(k, vol, grid, val, df.tl, st) : 0);
     } else {
         return 0;
@@ -2085,7 +2085,7 @@ static int launch_pull1s_impl(const interpol_problem *p, const KParams &k, const
         const TileCount<C> t(p);
         IP_DEFER(df, t, C);
         hipLaunchKernelGGL((pull1s_tiled<C>), t.grid((int)p->batch), dim3(C::NT), smem_bytes<C>(), st,
-                           k, (const T *)vol, (const float *)grid, (T *)val, t.gx, t.gy, t.gz, t.nty, t.ntz, t.ntiles(), (int)p->batch, df.desc);
+                           k, (const T *)vol, (const float *)grid, (T *)val, t.gx, t.gy, t.gz, t.nty, t.ntz, t.ntiles(), (int)p->batch, df.args);
         IP_CHECK_LAUNCH_THEN(df.desc ? DeferOps<T>::pull(k, vol, grid, val, df.tl, st) : 0);
     } else {
         return 0;
@@ -2103,7 +2103,7 @@ static int launch_grad1s_impl(const interpol_problem *p, const KParams &k, const
         const TileCount<C> t(p);
         IP_DEFER(df, t, C);
         hipLaunchKernelGGL((grad1s_tiled<C>), t.grid((int)p->batch), dim3(C::NT), smem_bytes<C>(), st,
-                           k, (const T *)vol, (const float *)grid, (T *)val, t.gx, t.gy, t.gz, t.nty, t.ntz, t.ntiles(), (int)p->batch, df.desc);
+                           k, (const T *)vol, (const float *)grid, (T *)val, t.gx, t.gy, t.gz, t.nty, t.ntz, t.ntiles(), (int)p->batch, df.args);
         IP_CHECK_LAUNCH_THEN(df.desc ? DeferOps<T>::grad(k, vol, grid, val, df.tl, st) : 0);
     } else {
         return 0;
@@ -2137,7 +2137,7 @@ static int launch_gather_impl(const interpol_problem *p, const KParams &k, const
         IP_DEFER(df1, t1, C);
         hipLaunchKernelGGL((gather_tiled<C, GRAD>), t1.grid((int)p->batch), dim3(C::NT), smem_bytes<C>(), st, k1,
                            (const T *)vol + (p->channels - 1) * k.vol_sc, (const float *)grid, (T *)val + (p->channels - 1) * k.val_sc,
-                           t1.gx, t1.gy, t1.gz, t1.nty, t1.ntz, t1.ntiles(), (int)p->batch, df1.desc);
+                           t1.gx, t1.gy, t1.gz, t1.nty, t1.ntz, t1.ntiles(), (int)p->batch, df1.args);
         IP_CHECK_LAUNCH_THEN(df1.desc ? DeferOps<T>::pull(k1, (const T *)vol + (p->channels - 1) * k.vol_sc, grid, (T *)val + (p->channels - 1) * k.val_sc, df1.tl, st) : 0);
     }
     const int attr = big_lds<C>(gather_tiled<C, GRAD>);
@@ -2145,7 +2145,7 @@ static int launch_gather_impl(const interpol_problem *p, const KParams &k, const
     const TileCount<C> t(p);
     IP_DEFER(df, t, C);
     hipLaunchKernelGGL((gather_tiled<C, GRAD>), t.grid((int)p->batch), dim3(C::NT), smem_bytes<C>(), st,
-                       k, (const T *)vol, (const float *)grid, (T *)val, t.gx, t.gy, t.gz, t.nty, t.ntz, t.ntiles(), (int)p->batch, df.desc);
+                       k, (const T *)vol, (const float *)grid, (T *)val, t.gx, t.gy, t.gz, t.nty, t.ntz, t.ntiles(), (int)p->batch, df.args);
     IP_CHECK_LAUNCH_THEN(!df.desc ? 0 : (GRAD ? DeferOps<T>::grad(k, vol, grid, val, df.tl, st) : DeferOps<T>::pull(k, vol, grid, val, df.tl, st)));
 }
 
@@ -2164,7 +2164,7 @@ static int launch_push_impl(const interpol_problem *p, const KParams &k, const v
             const TileCount<C> t(p);
             IP_DEFER(df, t, C);
             hipLaunchKernelGGL((push_tiled<C, false, true>), t.grid((int)p->batch), dim3(C::NT), smem_bytes<C>(), st,
-                               k, (const T *)val, (const float *)grid, (float *)vol, t.gx, t.gy, t.gz, t.nty, t.ntz, t.ntiles(), (int)p->batch, df.desc);
+                               k, (const T *)val, (const float *)grid, (float *)vol, t.gx, t.gy, t.gz, t.nty, t.ntz, t.ntiles(), (int)p->batch, df.args);
             IP_CHECK_LAUNCH_THEN(df.template push<T>(k, val, grid, vol, st));
         } else {
             return 0;
@@ -2176,10 +2176,10 @@ static int launch_push_impl(const interpol_problem *p, const KParams &k, const v
     IP_DEFER(df, t, C);
     if (val)
         hipLaunchKernelGGL((push_tiled<C, false>), t.grid((int)p->batch), dim3(C::NT), smem_bytes<C>(), st,
-                           k, (const T *)val, (const float *)grid, (float *)vol, t.gx, t.gy, t.gz, t.nty, t.ntz, t.ntiles(), (int)p->batch, df.desc);
+                           k, (const T *)val, (const float *)grid, (float *)vol, t.gx, t.gy, t.gz, t.nty, t.ntz, t.ntiles(), (int)p->batch, df.args);
     else
         hipLaunchKernelGGL((push_tiled<C, true>), t.grid((int)p->batch), dim3(C::NT), smem_bytes<C>(), st,
-                           k, (const T *)nullptr, (const float *)grid, (float *)vol, t.gx, t.gy, t.gz, t.nty, t.ntz, t.ntiles(), (int)p->batch, df.desc);
+                           k, (const T *)nullptr, (const float *)grid, (float *)vol, t.gx, t.gy, t.gz, t.nty, t.ntz, t.ntiles(), (int)p->batch, df.args);
     IP_CHECK_LAUNCH_THEN(df.template push<T>(k, val, grid, vol, st));
 }
 
@@ -2234,7 +2234,7 @@ static int launch_pullbwd(const interpol_problem *p, const KParams &k, const voi
             IP_DEFER(df1, t1, CW);
             hipLaunchKernelGGL((gradc1s_tiled<CW>), t1.grid((int)p->batch), dim3(CW::NT), smem_bytes<CW>(), st,
                                k, (const T *)gout, (const T *)vol, (const float *)grid, (float *)ggrid,
-                               t1.gx, t1.gy, t1.gz, t1.nty, t1.ntz, t1.ntiles(), (int)p->batch, df1.desc);
+                               t1.gx, t1.gy, t1.gz, t1.nty, t1.ntz, t1.ntiles(), (int)p->batch, df1.args);
             IP_CHECK_LAUNCH_THEN(df1.template gradc<T>(k, gout, vol, grid, ggrid, st));
         }
     }
@@ -2244,7 +2244,7 @@ static int launch_pullbwd(const interpol_problem *p, const KParams &k, const voi
     IP_DEFER(df, t, C);
     hipLaunchKernelGGL((pullbwd_tiled<C>), t.grid((int)p->batch), dim3(C::NT), smem_bytes<C>(), st,
                        k, (const T *)gout, (const T *)vol, (const float *)grid, (float *)gvol, (float *)ggrid,
-                       gsb, gsc, t.gx, t.gy, t.gz, t.nty, t.ntz, t.ntiles(), (int)p->batch, df.desc);
+                       gsb, gsc, t.gx, t.gy, t.gz, t.nty, t.ntz, t.ntiles(), (int)p->batch, df.args);
     IP_CHECK_LAUNCH_THEN(df.desc ? DeferOps<T>::pullbwd(k, gout, vol, grid, gvol, ggrid, gsb, gsc, df.tl, st) : 0);
 }
 
@@ -2260,7 +2260,7 @@ static int launch_pushbwd(const interpol_problem *p, const KParams &k, const voi
     IP_DEFER(df, t, C);
     hipLaunchKernelGGL((pushbwd_tiled<C>), t.grid((int)p->batch), dim3(C::NT), smem_bytes<C>(), st,
                        k, (const T *)gvol_out, (const T *)val, (const float *)grid, (T *)gval, (float *)ggrid,
-                       t.gx, t.gy, t.gz, t.nty, t.ntz, t.ntiles(), (int)p->batch, df.desc);
+                       t.gx, t.gy, t.gz, t.nty, t.ntz, t.ntiles(), (int)p->batch, df.args);
     IP_CHECK_LAUNCH_THEN(df.desc ? DeferOps<T>::pushbwd(k, gvol_out, val, grid, gval, ggrid, df.tl, st) : 0);
 }
 

@@ -311,7 +311,7 @@ __device__ __forceinline__ Lattice lattice2d(const KParams &p, int esz, int k0, 
 // ---------------------------------------------------------------------------
 template <typename T, int K0, int K1, int GM>
 __global__ __launch_bounds__(NT, 3) void pull2d(KParams p, const T *__restrict__ vol, const float *__restrict__ grid, T *__restrict__ val,
-                                             int gy, int gz, int ntz, int ntiles, unsigned long long *__restrict__ defer)
+                                             int gy, int gz, int ntz, int ntiles, DeferArgs defer)
 {
     __shared__ Smem sm;
     constexpr int NC = Slot<T>::NC;
@@ -326,11 +326,11 @@ __global__ __launch_bounds__(NT, 3) void pull2d(KParams p, const T *__restrict__
         Tile2<K0, K1, GM>::load(p, grid, b, gy, gz, oy0, oz0, c);
         tl.build(p, L, c, gy, gz, oy0, oz0, sm);
     }
-    if (defer) {                                    // (block-uniform) too rough for the box: the generic kernel takes the tile, defer.hip
+    if (defer.flag) {                                    // (block-uniform) too rough for the box: the generic kernel takes the tile, defer.hip
         bool hand_back = sm.nout > ((NS / 64) << ((p.dbg >> 9) & 7));                  // (a wave pays the per-thread fallback of its slowest lane)
         if (hand_back) hand_back = tiled::tile_smooth(p, grid, b, 2, 0, oy0, oz0, 1, TY, TZ, 1, gy, gz, sm.hi);
-        if (threadIdx.x == 0) defer[blockIdx.x] = hand_back ? tile_desc(b, 0, oy0 / TY, oz0 / TZ) : 0ull;
-        if (hand_back) return;
+        if (hand_back && threadIdx.x == 0) defer_mark(defer, (int)blockIdx.x, tile_desc(b, 0, oy0 / TY, oz0 / TZ));
+        if (hand_back && defer.desc) return;
     }
     prof_mark(0);
     // the box's columns are contiguous runs of the unit-stride dim, sign +1 (dst1: sign 0 at index 0, quirk B-3)
@@ -487,7 +487,7 @@ __global__ __launch_bounds__(NT, 3) void pull2d(KParams p, const T *__restrict__
 // ---------------------------------------------------------------------------
 template <typename T, int K0, int K1, int GM>
 __global__ __launch_bounds__(NT, 3) void gradc2d(KParams p, const T *__restrict__ vol, const T *__restrict__ gout, const float *__restrict__ grid,
-                                              float *__restrict__ ggrid, int gy, int gz, int ntz, int ntiles, unsigned long long *__restrict__ defer)
+                                              float *__restrict__ ggrid, int gy, int gz, int ntz, int ntiles, DeferArgs defer)
 {
     __shared__ Smem sm;
     constexpr int NC = Slot<T>::NC;
@@ -502,11 +502,11 @@ __global__ __launch_bounds__(NT, 3) void gradc2d(KParams p, const T *__restrict_
         Tile2<K0, K1, GM>::load(p, grid, b, gy, gz, oy0, oz0, c);
         tl.build(p, L, c, gy, gz, oy0, oz0, sm);
     }
-    if (defer) {                                    // (block-uniform) too rough for the box: the generic kernel takes the tile, defer.hip
+    if (defer.flag) {                                    // (block-uniform) too rough for the box: the generic kernel takes the tile, defer.hip
         bool hand_back = sm.nout > ((NS / 64) << ((p.dbg >> 9) & 7));                  // (a wave pays the per-thread fallback of its slowest lane)
         if (hand_back) hand_back = tiled::tile_smooth(p, grid, b, 2, 0, oy0, oz0, 1, TY, TZ, 1, gy, gz, sm.hi);
-        if (threadIdx.x == 0) defer[blockIdx.x] = hand_back ? tile_desc(b, 0, oy0 / TY, oz0 / TZ) : 0ull;
-        if (hand_back) return;
+        if (hand_back && threadIdx.x == 0) defer_mark(defer, (int)blockIdx.x, tile_desc(b, 0, oy0 / TY, oz0 / TZ));
+        if (hand_back && defer.desc) return;
     }
     prof_mark(0);
     // the box's columns are contiguous runs of the unit-stride dim, sign +1 (dst1: sign 0 at index 0, quirk B-3)
@@ -685,7 +685,7 @@ __global__ __launch_bounds__(NT, 3) void gradc2d(KParams p, const T *__restrict_
 // ---------------------------------------------------------------------------
 template <typename T, int K0, int K1, int GM, int MODE>
 __global__ __launch_bounds__(NT, 4) void push2d(KParams p, const T *__restrict__ val, const float *__restrict__ grid, float *__restrict__ vol,
-                                             int gy, int gz, int ntz, int ntiles, unsigned long long *__restrict__ defer)
+                                             int gy, int gz, int ntz, int ntiles, DeferArgs defer)
 {
     __shared__ Smem sm;
     const int tid = threadIdx.x;
@@ -719,11 +719,11 @@ __global__ __launch_bounds__(NT, 4) void push2d(KParams p, const T *__restrict__
         Tile2<K0, K1, GM>::load(p, grid, b, gy, gz, oy0, oz0, c);
         tl.build(p, L, c, gy, gz, oy0, oz0, sm);
     }
-    if (defer) {                                    // (block-uniform) too rough for the box: the generic kernel takes the tile, defer.hip
+    if (defer.flag) {                                    // (block-uniform) too rough for the box: the generic kernel takes the tile, defer.hip
         bool hand_back = sm.nout > ((NS / 64) << ((p.dbg >> 9) & 7));                  // (a wave pays the per-thread fallback of its slowest lane)
         if (hand_back) hand_back = tiled::tile_smooth(p, grid, b, 2, 0, oy0, oz0, 1, TY, TZ, 1, gy, gz, sm.hi);
-        if (threadIdx.x == 0) defer[blockIdx.x] = hand_back ? tile_desc(b, 0, oy0 / TY, oz0 / TZ) : 0ull;
-        if (hand_back) return;
+        if (hand_back && threadIdx.x == 0) defer_mark(defer, (int)blockIdx.x, tile_desc(b, 0, oy0 / TY, oz0 / TZ));
+        if (hand_back && defer.desc) return;
     }
     prof_mark(4);
     // density: samples per first-tap cell (16-bit counters in the box, cleared again)
@@ -889,7 +889,7 @@ int IP_SYM(try_tiled2d_pull_, IP_TSFX)(const interpol_problem *p, const KParams 
     int rc;
 #define IP_PULL2D(GM) rc = by_orders<T, GM>(k.order[0], k.order[1], [&](auto k0, auto k1) {                             \
         hipLaunchKernelGGL((pull2d<T, decltype(k0)::value, decltype(k1)::value, GM>), g, dim3(NT), 0, st, k, (const T *)vol, \
-                           (const float *)grid, (T *)val, gy, gz, ntz, ntiles, df.desc); })
+                           (const float *)grid, (T *)val, gy, gz, ntz, ntiles, df.args); })
     if (k.sep == 0) IP_PULL2D(0); else if (k.sep == 1) IP_PULL2D(1); else if (k.sep == 2) IP_PULL2D(2); else IP_PULL2D(3);
 #undef IP_PULL2D
     if (!rc) return 0;
@@ -912,7 +912,7 @@ int IP_SYM(try_tiled2d_gradc_, IP_TSFX)(const interpol_problem *p, const KParams
     int rc;
 #define IP_GRADC2D(GM) rc = by_orders<T, GM>(k.order[0], k.order[1], [&](auto k0, auto k1) {                             \
         hipLaunchKernelGGL((gradc2d<T, decltype(k0)::value, decltype(k1)::value, GM>), g, dim3(NT), 0, st, k, (const T *)vol, \
-                           (const T *)gout, (const float *)grid, (float *)ggrid, gy, gz, ntz, ntiles, df.desc); })
+                           (const T *)gout, (const float *)grid, (float *)ggrid, gy, gz, ntz, ntiles, df.args); })
     if (k.sep == 0) IP_GRADC2D(0); else IP_GRADC2D(2);
 #undef IP_GRADC2D
     if (!rc) return 0;
@@ -935,7 +935,7 @@ int IP_SYM(try_tiled2d_push_, IP_TSFX)(const interpol_problem *p, const KParams 
     int rc;
 #define IP_PUSH2D(GM, MODE) rc = by_orders<T, GM>(k.order[0], k.order[1], [&](auto k0, auto k1) {                       \
         hipLaunchKernelGGL((push2d<T, decltype(k0)::value, decltype(k1)::value, GM, MODE>), g, dim3(NT), 0, st, k, (const T *)val, \
-                           (const float *)grid, (float *)vol, gy, gz, ntz, ntiles, df.desc); })
+                           (const float *)grid, (float *)vol, gy, gz, ntz, ntiles, df.args); })
 #define IP_PUSH2D_GM(MODE) { if (k.sep == 0) IP_PUSH2D(0, MODE); else if (k.sep == 1) IP_PUSH2D(1, MODE); else if (k.sep == 2) IP_PUSH2D(2, MODE); else IP_PUSH2D(3, MODE); }
     if (mode == 0) IP_PUSH2D_GM(0) else if (mode == 1) IP_PUSH2D_GM(1) else IP_PUSH2D_GM(2)
 #undef IP_PUSH2D_GM

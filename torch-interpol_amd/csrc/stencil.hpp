@@ -61,13 +61,23 @@ struct KParams {
     double mask_hi[3];      // n-1+threshold
 };
 
-// Tiles that an LDS-tiled kernel hands back to the generic kernels (defer.hip): one 64-bit descriptor per (tile, batch
-// item) work item -- bit 63: handed back; batch item (20 bits), tile coordinates x, y, z (14 bits each) -- and the
-// tile extents.  desc == NULL: every sample (the plain generic launch).
-struct TileList { const unsigned long long *desc; int nwork; int e[3]; };
+// Tiles that an LDS-tiled kernel hands back to the generic kernels (defer.hip): per (tile, batch item) work item of the
+// launch a 64-bit descriptor -- batch item (20 bits), tile coordinates x, y, z (14 bits each) -- and the number of the
+// launch that wrote it: an entry counts only if its stamp is the current launch's, so the tile kernels write nothing
+// for the tiles they serve and nothing is ever reset.  desc == NULL: every sample (the plain generic launch).
+struct TileList { const unsigned long long *desc; const unsigned *gen; unsigned cur; int nwork; int e[3]; };
+// (flag: where a tile kernel reports -- by storing the launch number -- that it met a tile worth handing back, whether or not
+//  this launch hands back: desc == NULL while the stream's recent launches met none, see defer.hip)
+struct DeferArgs { unsigned long long *desc; unsigned *gen; unsigned *flag; unsigned cur; };
 __host__ __device__ inline unsigned long long tile_desc(int64_t b, int cx, int cy, int cz)
 {
-    return (1ull << 63) | ((unsigned long long)b << 42) | ((unsigned long long)cx << 28) | ((unsigned long long)cy << 14) | (unsigned long long)cz;
+    return ((unsigned long long)b << 42) | ((unsigned long long)cx << 28) | ((unsigned long long)cy << 14) | (unsigned long long)cz;
+}
+// one thread of the block, for a tile worth handing back; true: handed back (skip it), false: this launch serves everything itself
+__device__ inline void defer_mark(const DeferArgs &d, int work, unsigned long long desc)
+{
+    *d.flag = d.cur;
+    if (d.desc) { d.desc[work] = desc; d.gen[work] = d.cur; }
 }
 
 enum { MODE_ND = 0, MODE_ISO1 = 1, MODE_ISO0 = 2 };
