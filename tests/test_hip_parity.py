@@ -531,6 +531,43 @@ def test_stretched_tiles_are_handed_back_to_the_generic_kernels(dim, order, dtyp
                 _same(_hip.push_backward(gvo[:, :1].contiguous(), None, grid, b, o, ex, False, True, flags=fl)[1], ref, tol, ("count bwd", dim, order, dtype, bound, ex, fl))
 
 
+def test_graph_capture_replays_correctly():
+    """hipGraph capture of the operators (launch-bound inner loops, the system prompt's HIP graphs): everything is enqueued
+    on the capturing stream, nothing synchronises, and the tile hand-back -- whose descriptors carry a per-launch number that
+    a replay would repeat -- stays out of captured launches.  Replays with new inputs must match eager calls."""
+    from interpol import _hip
+    gen = torch.Generator().manual_seed(77)
+    ishape, oshape = (60, 50, 70), (40, 36, 48)
+    vol = torch.randn([2, 2, *ishape], generator=gen).to(DEV)
+    src = torch.randn([2, 2, *oshape], generator=gen).to(DEV)
+    base = interpol.identity_grid(oshape)[None].expand(2, *oshape, 3)
+    grid = (base * 2.4 + 0.05 * torch.randn(base.shape, generator=gen)).contiguous().to(DEV)       # stretched: hand-back territory
+    b, o = [3] * 3, [3] * 3
+    for _ in range(3):          # eager first: the stream may be in the hand-back mode when the capture starts
+        _hip.gather("pull", vol, grid, b, o, 1)
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        _hip.gather("pull", vol, grid, b, o, 1); _hip.scatter("push", src, grid, list(ishape), b, o, 1)      # warm-up on the side stream
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        out_pull = _hip.gather("pull", vol, grid, b, o, 1)
+        out_push = _hip.scatter("push", src, grid, list(ishape), b, o, 1)
+        out_bwd = _hip.pull_backward(src, vol, grid, b, o, 1, True, True)
+    for it in range(3):
+        vol.copy_(torch.randn(vol.shape, generator=gen)); src.copy_(torch.randn(src.shape, generator=gen))
+        grid.copy_((base * (1.0 + 0.8 * it) + 0.05 * torch.randn(base.shape, generator=gen)))
+        g.replay()
+        torch.cuda.synchronize()
+        _same(out_pull, _hip.gather("pull", vol, grid, b, o, 1, flags=_hip.FLAG_NO_FASTPATH), 1e-5, ("graph pull", it))
+        _same(out_push, _hip.scatter("push", src, grid, list(ishape), b, o, 1, flags=_hip.FLAG_NO_FASTPATH), 1e-5, ("graph push", it))
+        ref = _hip.pull_backward(src, vol, grid, b, o, 1, True, True, flags=_hip.FLAG_NO_FASTPATH)
+        _same(out_bwd[0], ref[0], 1e-5, ("graph bwd vol", it)); _same(out_bwd[1], ref[1], 2e-5, ("graph bwd grid", it))
+
+
 def test_tiled_scatter_nonfinite_sources_keep_ieee_semantics():
     from interpol import _hip
     vol, grid, tshape, sshape = _tiled_problem(3, 1.0, seed=5)

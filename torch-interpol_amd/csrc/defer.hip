@@ -45,6 +45,10 @@ DeferArgs defer_buffer(hipStream_t st, int64_t nwork, int64_t batch, int ntx, in
     if (nwork <= 0 || nwork > DEFER_CAP || batch > (1 << 20) || ntx > (1 << 14) || nty > (1 << 14) || ntz > (1 << 14)) return none;
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= DEFER_DEVICES) return none;
+    // a launch that is being captured into a graph would replay with the SAME launch number: no hand-back there
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(st, &cap) != hipSuccess) { (void)hipGetLastError(); return none; }
+    if (cap != hipStreamCaptureStatusNone) return none;
     struct Slot { hipStream_t owner; unsigned launches, seen; int mode, quiet; };
     struct Device { unsigned long long *desc; unsigned *gen; volatile unsigned *hflag; unsigned *dflag; bool failed; int nused; Slot slot[DEFER_SLOTS]; };
     static std::mutex mu;
