@@ -72,7 +72,7 @@ if os.path.exists(raw_path):
               "#  * WRITE_SIZE: exact -- __amd_rocclr_copyBuffer of the same run writes 524288 KB and reports 524288.0 KB: factor 1.\n"
               "#  * FETCH_SIZE: the SAME kernel at the identity deformation (sigma = 0), where every input byte is fetched once and the\n"
               "#    reads are grid + source = 1342 MB: factor = 1342 MB / counter(sigma = 0).  pull_sorted mixes 16-byte staging loads\n"
-              "#    (counted 1/2) with 4-byte coordinate loads: factor 1.41; push_tiled reads with 4-byte loads only: factor 1.01.\n"
+              "#    (counted 1/2) with 4-byte coordinate loads: factor ~1.4 (this run: the table); push_tiled reads with 4-byte loads only: factor 1.00.\n"
               "# The push target is never read: its float atomics are executed memory-side and counted as writes (write-through of the\n"
               "# tile halos: 1.40 GB at the identity, 2.78 GB at sigma = 2 for a 0.54 GB target).\n" % tag)
     out = {"_comment": "HBM-side bytes per launch at BASELINE config 2 (sigma = 2) from rocprofv3 PMC passes (profiles/%s_pmc_hbm_traffic.txt): "
