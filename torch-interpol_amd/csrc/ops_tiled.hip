@@ -165,10 +165,12 @@ struct TileGeom {
 // of the operator (defer.hip) instead of crawling through the per-thread fallback.  Block-uniform.  Call after Box::build.
 template <typename C>
 __device__ __forceinline__ bool hand_back(const DeferArgs &defer, int work, int64_t b, const TileGeom &g, int nslow, const KParams &p,
-                                          const float *__restrict__ grid, Smem &sm)
+                                          const float *__restrict__ grid, Smem &sm, bool scatter = false)
 {
     if (!defer.flag) return false;
-    bool hb = nslow > ((C::NS / 8) << ((p.dbg >> 9) & 7));      // measured: tools/handback_sweep.py, profiles/r02_handback.txt
+    // gathers: 1/8 of the samples outside the box; scatters: 1/4 -- the generic scatter pays 64 global atomics per sample where
+    // the tile pays ~4, so it only takes tiles that are mostly outside (measured: tools/handback_sweep.py, profiles/r02_handback.txt)
+    bool hb = nslow > ((C::NS / (scatter ? 4 : 8)) << ((p.dbg >> 9) & 7));
     if (hb) hb = tile_smooth(p, grid, b, C::D, g.ox0, g.oy0, g.oz0, C::TX, C::TY, C::TZ, g.gx, g.gy, g.gz, sm.hi);
     if (hb && threadIdx.x == 0) defer_mark(defer, work, tile_desc(b, g.ox0 / C::TX, g.oy0 / C::TY, g.oz0 / C::TZ));
     hb = hb && defer.desc != nullptr;
@@ -1731,7 +1733,7 @@ __global__ __launch_bounds__(C::NT) void push_tiled(KParams p, const typename C:
         const int nslow = sm.nslow, dmax = sm.dmax;
         prof_mark(0);
         clean = true;                                  // Box::build leaves the box zeroed
-        if (hand_back<C>(defer, work, b, g, nslow, p, grid, sm)) continue;
+        if (hand_back<C>(defer, work, b, g, nslow, p, grid, sm, true)) continue;
         const int nch = p.C + (WC ? 1 : 0);
         for (int c = 0; c < nch; ++c) {
             float *vc = vol + b * p.vol_sb + c * p.vol_sc;
@@ -1802,7 +1804,7 @@ __global__ __launch_bounds__(C::NT) void pullbwd_tiled(KParams p, const typename
     Box<C> box;
     const unsigned fastmask = box.template build<true>(p, L, grid, b, g, sm);
     const int nslow = sm.nslow, dmax = sm.dmax;
-    if (hand_back<C>(defer, work, b, g, nslow, p, grid, sm)) continue;
+    if (hand_back<C>(defer, work, b, g, nslow, p, grid, sm, gvol != nullptr)) continue;
 
     float gg[C::VPT][3];
 #pragma unroll
