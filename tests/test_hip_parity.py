@@ -531,6 +531,31 @@ def test_stretched_tiles_are_handed_back_to_the_generic_kernels(dim, order, dtyp
                 _same(_hip.push_backward(gvo[:, :1].contiguous(), None, grid, b, o, ex, False, True, flags=fl)[1], ref, tol, ("count bwd", dim, order, dtype, bound, ex, fl))
 
 
+@pytest.mark.parametrize("dim,order", [(3, 3), (3, 2), (3, 1), (3, 5), (2, 3), (2, 1)])
+def test_batch_broadcast_grid_gradients(dim, order):
+    """One grid (batch 1) for a batch of images (nd.py:95, `batch = max(...)`): outputs and BOTH gradients must equal those of the
+    expanded grid -- the grid gradient summed over the batch.  (The class-sorted / 2-D grid-gradient kernels once indexed their
+    dense (B, *out, D) output with the grid's batch stride, 0 here.)  Plain and zoomed lattices: tile kernels, hand-back."""
+    gen = torch.Generator().manual_seed(31 * dim + order)
+    shp = (40, 36, 50)[3 - dim:] if dim == 3 else (120, 90)
+    for zoom in (1.0, 2.4):
+        x0 = torch.randn([3, 2, *shp], generator=gen).to(DEV)
+        g1 = (interpol.identity_grid(shp) * zoom + 0.1 * torch.randn([1, *shp, dim], generator=gen)).to(DEV)
+        res = []
+        for expand in (False, True):
+            g = (g1.expand(3, *shp, dim).contiguous() if expand else g1.clone()).requires_grad_(True)
+            x = x0.clone().requires_grad_(True)
+            for _ in range(2):                       # (the second pass may run in the stream's hand-back mode)
+                x.grad = None; g.grad = None
+                y = interpol.grid_pull(x, g, interpolation=order, bound="dct2", extrapolate=True)
+                z = interpol.grid_push(x, g, interpolation=order, bound="dct2", extrapolate=True)
+                (y.square().sum() + z.square().sum()).backward()
+            gg = g.grad.sum(0, keepdim=True) if expand else g.grad
+            res.append((y.detach(), z.detach(), x.grad.clone(), gg.clone()))
+        for name, a, b in zip(("pull", "push", "grad_input", "grad_grid"), res[0], res[1]):
+            _same(a, b, 1e-5, (name, dim, order, zoom))
+
+
 def test_graph_capture_replays_correctly():
     """hipGraph capture of the operators (launch-bound inner loops, the system prompt's HIP graphs): everything is enqueued
     on the capturing stream, nothing synchronises, and the tile hand-back -- whose descriptors carry a per-launch number that

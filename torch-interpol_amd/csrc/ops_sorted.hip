@@ -785,7 +785,7 @@ __global__ __launch_bounds__(NT, 4) void gradc_sorted(KParams p, const T *__rest
                 }
             }
             __syncthreads();
-            float *gb = ggrid + b * p.grid_sb;
+            float *gb = ggrid + b * p.N * 3;                         // dense (B, *out, 3), whatever the batch stride of the grid (0: broadcast)
             if (g.ox0 + TS <= g.gx && g.oy0 + TS <= g.gy && g.oz0 + TS <= g.gz) {
                 // whole tile: four z-neighbours = 12 contiguous floats, three 16-byte stores
 #pragma unroll

@@ -663,7 +663,7 @@ __global__ __launch_bounds__(NT, 3) void gradc2d(KParams p, const T *__restrict_
                 gg[v][0] = a0; gg[v][1] = a1;
             }
         }
-        float *ob = ggrid + b * p.grid_sb + ((int64_t)oy * gz + oz) * 2;
+        float *ob = ggrid + b * p.N * 2 + ((int64_t)oy * gz + oz) * 2;      // dense (B, *out, 2), whatever the batch stride of the grid (0: broadcast)
         float m[VPT];
 #pragma unroll
         for (int v = 0; v < VPT; ++v) m[v] = (float)((tl.inb >> v) & 1);
