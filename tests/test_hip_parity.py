@@ -556,6 +556,39 @@ def test_batch_broadcast_grid_gradients(dim, order):
             _same(a, b, 1e-5, (name, dim, order, zoom))
 
 
+def test_hand_back_on_concurrent_streams():
+    """Each stream owns a slot of the hand-back descriptor lists (csrc/defer.hip): stretched workloads enqueued on several
+    streams at once must not see each other's descriptors."""
+    from interpol import _hip
+    gen = torch.Generator().manual_seed(5)
+    ishape, oshape = (70, 60, 80), (48, 40, 52)
+    streams = [torch.cuda.Stream() for _ in range(4)]
+    base = interpol.identity_grid(oshape)[None].expand(2, *oshape, 3)
+    work = []
+    for i, st in enumerate(streams):
+        vol = torch.randn([2, 2, *ishape], generator=gen).to(DEV)
+        src = torch.randn([2, 2, *oshape], generator=gen).to(DEV)
+        grid = (base * (1.8 + 0.4 * i) + 0.05 * torch.randn(base.shape, generator=gen)).contiguous().to(DEV)
+        work.append((vol, src, grid))
+    torch.cuda.synchronize()
+    b, o = [3] * 3, [3] * 3
+    outs = [[] for _ in streams]
+    for rep in range(6):                              # interleaved launches; from the second round on the streams hand tiles back
+        for i, st in enumerate(streams):
+            vol, src, grid = work[i]
+            with torch.cuda.stream(st):
+                outs[i] = [_hip.gather("pull", vol, grid, b, o, 1), _hip.gather("grad", vol, grid, b, o, 1),
+                           _hip.scatter("push", src, grid, list(ishape), b, o, 1), _hip.pull_backward(src, vol, grid, b, o, 1, False, True)[1]]
+    torch.cuda.synchronize()
+    for i in range(len(streams)):
+        vol, src, grid = work[i]
+        ref = [_hip.gather("pull", vol, grid, b, o, 1, flags=_hip.FLAG_NO_FASTPATH), _hip.gather("grad", vol, grid, b, o, 1, flags=_hip.FLAG_NO_FASTPATH),
+               _hip.scatter("push", src, grid, list(ishape), b, o, 1, flags=_hip.FLAG_NO_FASTPATH),
+               _hip.pull_backward(src, vol, grid, b, o, 1, False, True, flags=_hip.FLAG_NO_FASTPATH)[1]]
+        for name, a, r in zip(("pull", "grad", "push", "grid gradient"), outs[i], ref):
+            _same(a, r, 2e-5, (name, "stream", i))
+
+
 def test_graph_capture_replays_correctly():
     """hipGraph capture of the operators (launch-bound inner loops, the system prompt's HIP graphs): everything is enqueued
     on the capturing stream, nothing synchronises, and the tile hand-back -- whose descriptors carry a per-launch number that
