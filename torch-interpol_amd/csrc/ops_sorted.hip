@@ -868,7 +868,7 @@ __global__ __launch_bounds__(NT, 4) void push_sorted(KParams p, const T *__restr
         tl.build(p, L, g, sm, tid, cnext);
         const int nslow = sm.nslow < SLOWCAP ? sm.nslow : SLOWCAP;
         if (defer.flag) {                                                 // (block-uniform) too rough for the box: the generic kernel takes the tile, defer.hip
-            bool hand_back = sm.nslow > ((2 * HANDBACK) << ((p.dbg >> 9) & 7));   // scatter: twice the gathers' threshold, see tiled::hand_back
+            bool hand_back = sm.nslow > ((3 * HANDBACK / 2) << ((p.dbg >> 9) & 7));   // scatter: 3/16 of the samples, see tiled::hand_back
             if (hand_back) hand_back = tiled::tile_smooth(p, grid, b, 3, g.ox0, g.oy0, g.oz0, TS, TS, TS, g.gx, g.gy, g.gz, sm.hi);
             if (hand_back && tid == 0) defer_mark(defer, work, tile_desc(b, g.ox0 / TS, g.oy0 / TS, g.oz0 / TS));
             if (hand_back && defer.desc) { __syncthreads(); continue; }

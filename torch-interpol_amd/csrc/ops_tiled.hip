@@ -168,9 +168,9 @@ __device__ __forceinline__ bool hand_back(const DeferArgs &defer, int work, int6
                                           const float *__restrict__ grid, Smem &sm, bool scatter = false)
 {
     if (!defer.flag) return false;
-    // gathers: 1/8 of the samples outside the box; scatters: 1/4 -- the generic scatter pays 64 global atomics per sample where
-    // the tile pays ~4, so it only takes tiles that are mostly outside (measured: tools/handback_sweep.py, profiles/r02_handback.txt)
-    bool hb = nslow > ((C::NS / (scatter ? 4 : 8)) << ((p.dbg >> 9) & 7));
+    // gathers: 1/8 of the samples outside the box; scatters: 3/16 -- the generic scatter pays 64 global atomics per sample where
+    // the tile pays ~4; a stride of 2 (23 % outside) is still worth handing back (measured: tools/handback_sweep.py, profiles/r02_handback.txt)
+    bool hb = nslow > (((scatter ? 3 * C::NS : 2 * C::NS) / 16) << ((p.dbg >> 9) & 7));
     if (hb) hb = tile_smooth(p, grid, b, C::D, g.ox0, g.oy0, g.oz0, C::TX, C::TY, C::TZ, g.gx, g.gy, g.gz, sm.hi);
     if (hb && threadIdx.x == 0) defer_mark(defer, work, tile_desc(b, g.ox0 / C::TX, g.oy0 / C::TY, g.oz0 / C::TZ));
     hb = hb && defer.desc != nullptr;
