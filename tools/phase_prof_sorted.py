@@ -9,14 +9,15 @@ from interpol import _hip
 import bench
 
 NAMES = {"pull": ["build:read sorted", "stage", "taps", "unsort+store+slow", "build:coords", "build:split+minmax", "build:tables+classify", "build:scan+holes", "build:records"],
-         "push": ["load records", "hist+cells", "scan+density", "exchange+read", "sources+scale", "taps", "flush"],
+         "push": ["bin:load", "bin:brick+rank", "bin:scan+desc", "bin:direct+pos", "bin:exchange", "bin:store", "6", "7",
+                  "acc:desc", "acc:pass1", "acc:density", "acc:taps", "acc:flush"],
          "pushs": ["build+density", "taps (4 passes)", "flush (4 passes)", "slow + tail", "sources+scale", "build:coords", "build:split+minmax", "build:tables+classify", "build:scan+holes", "build:records"]}
 dev = torch.device("cuda", 0)
 sigma = float(sys.argv[1]) if len(sys.argv) > 1 else 2.0
 inp, grid = bench.make_inputs(4, 2, 256, sigma, dev, 1234)
 L = _hip.lib()
-# pull: pull_sorted; push: the binned push (rough_deformations); pushs: push_sorted (dbg switch 128)
-fn = L.interpol_debug_prof_binned_f32 if (sys.argv[2:] and sys.argv[2] == "push") else L.interpol_debug_prof_sorted_f32
+# pull: pull_sorted; push: the owner-computes push (FLAG_BINNED_SCATTER); pushs: push_sorted (dbg switch 128)
+fn = L.interpol_debug_prof_owner if (sys.argv[2:] and sys.argv[2] == "push") else L.interpol_debug_prof_sorted_f32
 fn.argtypes = [ctypes.c_void_p, ctypes.c_int]
 buf = (ctypes.c_ulonglong * 16)()
 def run(op):

@@ -32,7 +32,18 @@ def from_db(path, out):
         out.write("\n(no counter tables: %s)\n" % e)
 
 
+def dispatches(path, pattern, out):
+    c = sqlite3.connect(path)
+    q = """select s.kernel_name, d.start, d.end from rocpd_kernel_dispatch d join rocpd_info_kernel_symbol s on d.kernel_id=s.id
+           where s.kernel_name like ? order by d.start"""
+    out.write("# dispatches of *%s* in launch order (us)\n" % pattern)
+    out.write(" ".join("%.0f" % ((r[2] - r[1]) / 1e3) for r in c.execute(q, ("%" + pattern + "%",))) + "\n")
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 3 and sys.argv[1] == "--dispatches":
+        dispatches(sys.argv[3], sys.argv[2], sys.stdout)
+        sys.exit(0)
     out = sys.stdout
     for path in sys.argv[1:]:
         out.write("# %s\n" % path)

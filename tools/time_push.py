@@ -1,0 +1,35 @@
+#!/usr/bin/env python
+"""Config-2 grid_push timings: routed kernel vs the owner-computes organisation (FLAG_BINNED_SCATTER), per sigma."""
+import os, sys, json
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "torch-interpol_amd")); sys.path.insert(0, ROOT)
+import torch, interpol, bench
+from interpol import _hip
+dev = torch.device("cuda", 0)
+def timeit(fn, reps=7):
+    fn(); torch.cuda.synchronize()
+    ts = []
+    for _ in range(reps):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record(); fn(); b.record(); torch.cuda.synchronize()
+        ts.append(a.elapsed_time(b))
+    ts.sort(); return ts[len(ts) // 2]
+sig = [float(s) for s in sys.argv[1:]] or [2.0, 0.0]
+for sigma in sig:
+    inp, grid = bench.make_inputs(4, 2, 256, sigma, dev, 1234)
+    res = {}
+    res["push_routed"] = timeit(lambda: _hip.scatter("push", inp, grid, None, [3] * 3, [3] * 3, 1))
+    res["push_owner"] = timeit(lambda: _hip.scatter("push", inp, grid, None, [3] * 3, [3] * 3, 1, flags=_hip.FLAG_BINNED_SCATTER))
+    res["owner_no_taps"] = timeit(lambda: _hip.scatter("push", inp, grid, None, [3] * 3, [3] * 3, 1, flags=_hip.FLAG_BINNED_SCATTER | (2 << 8)))
+    res["owner_valu_only"] = timeit(lambda: _hip.scatter("push", inp, grid, None, [3] * 3, [3] * 3, 1, flags=_hip.FLAG_BINNED_SCATTER | (4 << 8)))
+    res["owner_lds_only"] = timeit(lambda: _hip.scatter("push", inp, grid, None, [3] * 3, [3] * 3, 1, flags=_hip.FLAG_BINNED_SCATTER | (16 << 8)))
+    res["owner_lds_only_synth_cf"] = timeit(lambda: _hip.scatter("push", inp, grid, None, [3] * 3, [3] * 3, 1, flags=_hip.FLAG_BINNED_SCATTER | (48 << 8)))
+    res["owner_lds_only_synth_2way"] = timeit(lambda: _hip.scatter("push", inp, grid, None, [3] * 3, [3] * 3, 1, flags=_hip.FLAG_BINNED_SCATTER | (80 << 8)))
+    res["owner_no_flush"] = timeit(lambda: _hip.scatter("push", inp, grid, None, [3] * 3, [3] * 3, 1, flags=_hip.FLAG_BINNED_SCATTER | (1 << 8)))
+    a = _hip.scatter("push", inp, grid, None, [3] * 3, [3] * 3, 1)
+    b = _hip.scatter("push", inp, grid, None, [3] * 3, [3] * 3, 1, flags=_hip.FLAG_BINNED_SCATTER)
+    res["max_abs_diff"] = float((a - b).abs().max()); res["max_abs"] = float(a.abs().max())
+    b2 = _hip.scatter("push", inp, grid, None, [3] * 3, [3] * 3, 1, flags=_hip.FLAG_BINNED_SCATTER)
+    res["bit_reproducible"] = bool(torch.equal(b, b2)); res["n_diff"] = int((b != b2).sum()); res["max_diff_rerun"] = float((b - b2).abs().max())
+    res["n_diff_routed"] = int((a != b).sum())
+    print("sigma", sigma, json.dumps({k: (round(v, 4) if isinstance(v, float) else v) for k, v in res.items()}), flush=True)

@@ -54,12 +54,9 @@ int launch_resample1d(int dtype, int lin_f64, int order, const KParams &p, int a
 IP_DECL_TILED(f32) IP_DECL_TILED(bf16) IP_DECL_TILED(f16)
 #undef IP_DECL_TILED
 
-// binned (target-stationary) scatter for same-resolution deformations (push_binned.hip)
-#define IP_DECL_BINNED(sfx)                                                                                            \
-    int try_binned_push_##sfx(const interpol_problem *, const KParams &, const void *, const void *, void *, void *, int64_t, hipStream_t); \
-    int64_t binned_workspace_bytes_##sfx(const interpol_problem *, const KParams &, bool);
-IP_DECL_BINNED(f32) IP_DECL_BINNED(bf16) IP_DECL_BINNED(f16)
-#undef IP_DECL_BINNED
+// owner-computes (target-stationary) scatter for same-resolution deformations (push_owner.hip)
+int try_owner_push(const interpol_problem *, const KParams &, const void *, const void *, void *, void *, int64_t, hipStream_t);
+int64_t owner_workspace_bytes(const interpol_problem *, const KParams &, bool);
 
 #define IP_TILED_BY_DTYPE(NAME, ...)                                                     \
     switch (p->dtype) {                                                                  \
@@ -79,10 +76,6 @@ static int try_fast_pullbwd(const interpol_problem *p, const KParams &k, const v
 static int try_fast_pushbwd(const interpol_problem *p, const KParams &k, const void *gvol_out, const void *val, const void *grid,
                             void *gval, void *ggrid, hipStream_t st)
 { IP_TILED_BY_DTYPE(try_fast_pushbwd, p, k, gvol_out, val, grid, gval, ggrid, st) }
-
-static int try_binned_push(const interpol_problem *p, const KParams &k, const void *val, const void *grid, void *vol,
-                           void *ws, int64_t ws_bytes, hipStream_t st)
-{ IP_TILED_BY_DTYPE(try_binned_push, p, k, val, grid, vol, ws, ws_bytes, st) }
 
 static size_t esize(int dtype) { return dtype == INTERPOL_F64 ? 8 : (dtype == INTERPOL_F32 ? 4 : 2); }
 static size_t acc_esize(int dtype) { return dtype == INTERPOL_F64 ? 8 : 4; }
@@ -342,7 +335,7 @@ int interpol_push(const interpol_problem *p, const void *val, const void *grid, 
         KParams k = k0;
         k.cc = with_count ? 1 : 0;
         if (!(p->flags & INTERPOL_FLAG_NO_FASTPATH)) {
-            int rc = try_binned_push(p, k, val, grid, acc, ws, ws_bytes, st);     // needs its workspace: interpol_scatter_workspace
+            int rc = try_owner_push(p, k, val, grid, acc, ws, ws_bytes, st);     // needs its workspace: interpol_scatter_workspace
             if (rc != 0) return rc == 1 ? 0 : rc;
             rc = try_fast_push(p, k, val, grid, acc, st);           // the tiled kernel splats values and count in one pass
             if (rc != 0) return rc == 1 ? 0 : rc;
@@ -409,13 +402,8 @@ int64_t interpol_scatter_workspace(const interpol_problem *p, int32_t count_only
     if (!p || (p->flags & INTERPOL_FLAG_NO_FASTPATH)) return 0;
     if (make_params(p, SCATTER, 1, &k, &B, !count_only)) return 0;
     k.cc = (!count_only && (p->flags & INTERPOL_FLAG_WITH_COUNT)) ? 1 : 0;
-    int64_t ws = 0;
-    switch (p->dtype) {
-    case INTERPOL_F32: ws = binned_workspace_bytes_f32(p, k, count_only != 0); break;
-    case INTERPOL_BF16: ws = binned_workspace_bytes_bf16(p, k, count_only != 0); break;
-    case INTERPOL_F16: ws = binned_workspace_bytes_f16(p, k, count_only != 0); break;
-    default: return 0;
-    }
+    if (p->dtype != INTERPOL_F32 && p->dtype != INTERPOL_BF16 && p->dtype != INTERPOL_F16) return 0;
+    const int64_t ws = owner_workspace_bytes(p, k, count_only != 0);
     if (ws <= 0) return 0;
     const bool lowp = (p->dtype == INTERPOL_BF16 || p->dtype == INTERPOL_F16);
     return ws + (lowp ? ((vol_numel(p) * 4 + 255) & ~(int64_t)255) : 0);
@@ -429,7 +417,7 @@ int interpol_count(const interpol_problem *p, const void *grid, void *vol,
     hipStream_t st = (hipStream_t)stream;
     return scatter_driver(p, 1, false, nullptr, grid, vol, scratch, scratch_bytes, st, [&](const KParams &k, int B, void *acc, void *ws, int64_t ws_bytes) {
         if (!(p->flags & INTERPOL_FLAG_NO_FASTPATH)) {
-            int rc = try_binned_push(p, k, nullptr, grid, acc, ws, ws_bytes, st);
+            int rc = try_owner_push(p, k, nullptr, grid, acc, ws, ws_bytes, st);
             if (rc != 0) return rc == 1 ? 0 : rc;
             rc = try_fast_push(p, k, nullptr, grid, acc, st);
             if (rc != 0) return rc == 1 ? 0 : rc;

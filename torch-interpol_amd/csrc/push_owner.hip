@@ -1,0 +1,812 @@
+// ===========================================================================
+// push_owner.hip -- grid_push / grid_count, OWNER-COMPUTES: every brick of the target lattice is
+// accumulated by exactly one workgroup and written with plain loads / stores -- no global atomics on
+// the main path.  3-D, one spline order 2..3, f32 / bf16 / f16 sources, every boundary / extrapolation
+// mode, every coordinate source (dense grid, separable lattice, displacement field, affine lattice).
+// Reference semantics: interpol/nd.py:146-213 (push), pushpull.py:106-142 (count).
+//
+// Why.  Measured on this chip (tools/microbench/global_atomics.hip, profiles/r03_micro_global_atomics.txt):
+// the memory side retires 0.31 G float lane-atomics per ms however they are coalesced, scoped (the
+// compiler emits the SAME instruction for wavefront / workgroup / agent scope) or packed (u64 pairs:
+// 0.18 G/ms, +15 % payload), while plain coalesced read-modify-write runs at 0.5-0.85 G floats per ms and
+// plain stores at 1.3-1.5 G.  A sample-stationary tile under sigma = 2 voxel noise flushes 9 lattice
+// points per sample: 1.6 of the 3.5 ms of push_tiled / push_sorted are those atomics.  Here:
+//
+//   own_bin        : one workgroup per tile of 16^3 SAMPLE points: coordinates -> brick of the first tap
+//                    (16^3 first-tap cells), counting sort of the tile's samples by brick in LDS, the
+//                    sorted records (coordinates + masked source values as floats) leave as coalesced
+//                    16-byte stores into the tile's own segment of the workspace; one descriptor
+//                    (first record, count) per non-empty (tile, brick) pair is appended to the brick's
+//                    descriptor list (one returning atomic per pair: ~30 per tile).  No count pass, no
+//                    scan: ONE pass over the inputs.
+//   own_accumulate : one workgroup per TARGET brick walks the runs its descriptors name: density of the
+//                    first-tap cells and max |source| (-> fixed-point scale, tile_common.hpp headroom32),
+//                    then every record adds its (K+1)^3 taps into the brick's LDS box (16 + K lattice
+//                    points per dim) with packed 32-bit fixed-point ds_add_u64 (two channels per atomic),
+//                    and the box is ADDED to the target with plain loads and stores.  Boxes of bricks two
+//                    apart are disjoint, so the bricks are launched in 8 colours (parity of the brick
+//                    coordinates): within a launch no two workgroups touch the same lattice point, and
+//                    the launches are ordered by the stream.  Bricks whose box leaves the lattice (the
+//                    boundary condition folds it back: aliasing) go last, with global atomics -- a thin
+//                    shell of the volume.  A target shared by the batch items (batch stride 0) is flushed
+//                    with atomics throughout.
+// Samples whose first tap lies outside [-32, n + 32), tiles spread over more than 6 bricks per dim and
+// runs beyond a brick's 64 descriptors are scattered directly with float atomics by own_bin (always
+// correct; the target is zeroed before own_bin and the brick launches come after it on the stream).
+//
+// Sums inside a brick are integer (exact, order-free); the float additions of up to 8 boxes per lattice
+// point happen in the fixed order of the colours: for a given problem the result is bit-reproducible.
+//
+// Workspace (caller's, interpol_scatter_workspace()): 16 B per sample + 4 B per sample and further
+// channel, 4 + 512 B per brick.
+// ===========================================================================
+#include "sorted_util.hpp"
+
+namespace ip {
+namespace owner {
+
+using namespace sorted;          // helpers of sorted_util.hpp
+
+constexpr int BR = 16;                          // brick edge, in first-tap cells
+constexpr int OFF = 32;                         // first taps in [-OFF, nb * BR - OFF) are binned; beyond: scattered directly
+constexpr int BOX = BR + 3;                     // lattice points a brick's stencils touch per dim (K <= 3)
+constexpr int PZ = BOX;                         // row pitch of the LDS box (8-byte slots): rows back to back
+constexpr int PLANE = BOX * PZ;                 // 361
+constexpr int BOXSLOTS = BOX * PLANE;           // 6859 slots = 54 872 B
+constexpr int NCELL = BR * BR * BR;
+constexpr int CAPD = 256;                       // descriptors (runs) per brick
+constexpr int NT = 512;                         // accumulate: threads per workgroup (two workgroups per CU)
+constexpr int NS = TS * TS * TS;                // samples per tile (own_bin)
+constexpr int NT1 = 512, VPT1 = NS / NT1;       // own_bin: threads, samples per thread
+constexpr int LB = 6, NBIN = LB * LB * LB;      // bricks around a tile that are sorted locally
+constexpr int HALF = NS / 2;                    // records per exchange round
+
+struct BrickGrid {
+    int nb[3];                                  // bricks per dim
+    int per_item;                               // nb[0] * nb[1] * nb[2]
+};
+static BrickGrid brick_grid(const KParams &k)
+{
+    BrickGrid g;
+    for (int d = 0; d < 3; ++d) g.nb[d] = (k.vol_n[d] + 2 * OFF + BR - 1) / BR;
+    g.per_item = g.nb[0] * g.nb[1] * g.nb[2];
+    return g;
+}
+
+// ---------------------------------------------------------------------------
+// own_bin
+// ---------------------------------------------------------------------------
+struct BinSmem {
+    int lo[3], total;
+    int cnt[NBIN];             // samples of the tile per local brick; after the scan: -1 marks an orphan run
+    int base[NBIN];            // first sorted position of the local brick
+    float4 xch[HALF];          // sorted records of one round: x, y, z, value of channel 0
+    float  xv[HALF];           // value of one further channel
+};
+
+// value of target channel ch for a sample: masked source (nd.py:201-203), or the mask itself for the count channel
+template <typename T>
+__device__ __forceinline__ float src_value(const KParams &p, const T *__restrict__ val, int64_t b, int64_t o, int ch, float m)
+{
+    if (val == nullptr || ch >= p.C) return m;
+    return m * Cvt<float, T>::ld(val[b * p.val_sb + ch * p.val_sc + o]);
+}
+
+// Direct scatter of a thread's unbinned samples (bit v of `mask`: sample tid + NT1 v of the tile): float atomics, one tap at a time.
+template <typename T, int K, int GM>
+__device__ __forceinline__ void scatter_direct(const KParams &p, const T *__restrict__ val, const float *__restrict__ grid, float *__restrict__ vol,
+                                            int64_t b, TileGeom g, int tid, unsigned mask, int nch)
+{
+    Lattice L;
+#pragma unroll
+    for (int d = 0; d < 3; ++d) { L.bound[d] = p.bound[d]; L.n[d] = p.vol_n[d]; L.ss[d] = p.vol_ss[d] / 4; L.k[d] = K; }
+    L.lin = 0;
+#pragma unroll 1
+    for (int v = 0; v < VPT1; ++v) {
+        if (!((mask >> v) & 1)) continue;
+        int ox, oy, oz; float x[3];
+        sample_pos(g, tid + NT1 * v, ox, oy, oz);
+        load_xyz<GM>(p, grid, b, g, ox, oy, oz, x);
+        const int64_t o = ((int64_t)ox * g.gy + oy) * g.gz + oz;
+        const float m = inb_mask(p, x);
+        int ii[3]; float tt[3];
+#pragma unroll
+        for (int d = 0; d < 3; ++d) split(K, x[d], ii[d], tt[d]);
+#pragma unroll 1
+        for (int ch = 0; ch < nch; ++ch)
+            tiled::scatter_one_thread(L, vol + b * p.vol_sb + ch * p.vol_sc, src_value<T>(p, val, b, o, ch, m), ii[0], ii[1], ii[2], tt[0], tt[1], tt[2]);
+    }
+}
+
+template <typename T, int K, int GM>
+__global__ __launch_bounds__(NT1, 4) void own_bin(KParams p, BrickGrid bg, const T *__restrict__ val, const float *__restrict__ grid,
+                                               float *__restrict__ vol, int *__restrict__ ndesc, uint2 *__restrict__ desc,
+                                               float4 *__restrict__ rec, float *__restrict__ vals, int64_t nrec,
+                                               int gx, int gy, int gz, int nty, int ntz, int ntiles)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    BinSmem &sm = *reinterpret_cast<BinSmem *>(smem_raw);
+    const int tid = threadIdx.x;
+    const int64_t b = blockIdx.x / ntiles;
+    const TileGeom g = tile_geom(blockIdx.x % ntiles, gx, gy, gz, nty, ntz);
+    const int nch = val == nullptr ? 1 : p.C + p.cc;
+    for (int i = tid; i < NBIN; i += NT1) sm.cnt[i] = 0;
+    if (tid < 3) sm.lo[tid] = 0x7fffffff;
+    float c[VPT1][3], v0[VPT1], v1[VPT1];
+    unsigned valid = 0;
+    prof_mark(-1);
+#pragma unroll
+    for (int v = 0; v < VPT1; ++v) {
+        int ox, oy, oz;
+        sample_pos(g, tid + NT1 * v, ox, oy, oz);
+        if (ox < gx && oy < gy && oz < gz) valid |= 1u << v;
+        ox = ox < gx ? ox : gx - 1; oy = oy < gy ? oy : gy - 1; oz = oz < gz ? oz : gz - 1;
+        load_xyz<GM>(p, grid, b, g, ox, oy, oz, c[v]);
+        const int64_t o = ((int64_t)ox * gy + oy) * gz + oz;
+        v0[v] = (val == nullptr || p.C == 0) ? 1.f : Cvt<float, T>::ld(val[b * p.val_sb + o]);
+        v1[v] = (val == nullptr || p.C < 2) ? 1.f : Cvt<float, T>::ld(val[b * p.val_sb + p.val_sc + o]);
+    }
+    // ---- brick of the first tap (nd.py:45: i0 = floor(x - (K-1)/2)), block minimum of the brick coordinates
+    int bx[VPT1][3];
+    unsigned ok = 0;
+    int mn[3] = { 0x7fffffff, 0x7fffffff, 0x7fffffff };
+#pragma unroll
+    for (int v = 0; v < VPT1; ++v) {
+        bool in = (valid >> v) & 1;
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            const float fl = floorf(c[v][d] - 0.5f * (float)(K - 1));
+            in = in && fl >= (float)(-OFF) && fl < (float)(bg.nb[d] * BR - OFF);       // (false for NaN)
+            bx[v][d] = in ? (__float2int_rz(fl) + OFF) >> 4 : 0;
+        }
+        if (in) {
+            ok |= 1u << v;
+#pragma unroll
+            for (int d = 0; d < 3; ++d) mn[d] = bx[v][d] < mn[d] ? bx[v][d] : mn[d];
+        }
+    }
+    __syncthreads();                                                 // counters zero
+    prof_mark(0);
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        const int a = wave_min(mn[d]);
+        if ((tid & 63) == 0) atomicMin(&sm.lo[d], a);
+    }
+    __syncthreads();
+    const int lo[3] = { sm.lo[0], sm.lo[1], sm.lo[2] };
+    int lbin[VPT1], rank[VPT1];
+    unsigned local = 0;
+#pragma unroll
+    for (int v = 0; v < VPT1; ++v) {
+        const int r0 = bx[v][0] - lo[0], r1 = bx[v][1] - lo[1], r2 = bx[v][2] - lo[2];
+        const bool l = ((ok >> v) & 1) && (unsigned)r0 < (unsigned)LB && (unsigned)r1 < (unsigned)LB && (unsigned)r2 < (unsigned)LB;
+        lbin[v] = l ? (r0 * LB + r1) * LB + r2 : 0;
+        rank[v] = 0;
+        if (l) { local |= 1u << v; rank[v] = atomicAdd(&sm.cnt[lbin[v]], 1); }
+    }
+    __syncthreads();
+    prof_mark(1);
+    // ---- exclusive scan of the local brick counts (one wave), one descriptor per non-empty local brick
+    const int64_t tilebase = (int64_t)blockIdx.x * NS;
+    if (tid < 64) {
+        constexpr int PER = (NBIN + 63) / 64;                        // 4
+        int cn[PER], s = 0;
+#pragma unroll
+        for (int i = 0; i < PER; ++i) { const int e = tid * PER + i; cn[i] = e < NBIN ? sm.cnt[e] : 0; s += cn[i]; }
+        int incl = s;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o); if (tid >= o) incl += t; }
+        int run = incl - s;
+        if (tid == 63) sm.total = incl;
+#pragma unroll
+        for (int i = 0; i < PER; ++i) {
+            const int e = tid * PER + i;
+            if (e < NBIN) {
+                sm.base[e] = run;
+                if (cn[i] > 0) {
+                    const int r0 = e / (LB * LB), r1 = (e / LB) % LB, r2 = e % LB;
+                    const int bk = (int)b * bg.per_item + ((lo[0] + r0) * bg.nb[1] + (lo[1] + r1)) * bg.nb[2] + (lo[2] + r2);
+                    const int slot = atomicAdd(&ndesc[bk], 1);
+                    if (slot < CAPD) desc[(int64_t)bk * CAPD + slot] = make_uint2((unsigned)(tilebase + run), (unsigned)cn[i]);
+                    else sm.cnt[e] = -1;                             // the brick's list is full: this run is scattered directly, below
+                }
+                run += cn[i];
+            }
+        }
+    }
+    __syncthreads();
+    prof_mark(2);
+    const int total = sm.total;
+    // ---- samples that are not binned (first tap far outside the lattice, tile spread over more than LB bricks, orphan
+    // runs) are scattered directly at the END of the kernel, from re-read coordinates: the out-of-line scatter would
+    // otherwise force every live register of the hot path through scratch around its call
+    unsigned direct = valid & ~local;
+#pragma unroll
+    for (int v = 0; v < VPT1; ++v)
+        if (((local >> v) & 1) && sm.cnt[lbin[v]] < 0) direct |= 1u << v;
+    // ---- sorted records leave through LDS, two rounds of HALF records: coalesced 16-byte stores
+    int pos[VPT1];
+#pragma unroll
+    for (int v = 0; v < VPT1; ++v) pos[v] = ((local >> v) & 1) && sm.cnt[lbin[v]] >= 0 ? sm.base[lbin[v]] + rank[v] : -1;
+    const bool two = nch > 1;
+    prof_mark(3);
+    for (int r = 0; r < 2; ++r) {
+        if (r * HALF >= total) break;                                // (block-uniform)
+#pragma unroll
+        for (int v = 0; v < VPT1; ++v) {
+            const int q = pos[v] - r * HALF;
+            if (pos[v] >= 0 && (unsigned)q < (unsigned)HALF) {
+                const float m = inb_mask(p, c[v]);
+                sm.xch[q] = make_float4(c[v][0], c[v][1], c[v][2], (val == nullptr || p.C == 0) ? m : v0[v] * m);
+                if (two) sm.xv[q] = (val == nullptr || p.C < 2) ? m : v1[v] * m;
+            }
+        }
+        __syncthreads();
+        prof_mark(4);
+#pragma unroll
+        for (int j = 0; j < HALF / NT1; ++j) {
+            const int i = tid + NT1 * j;
+            if (r * HALF + i < total) {
+                rec[tilebase + r * HALF + i] = sm.xch[i];
+                if (two) vals[tilebase + r * HALF + i] = sm.xv[i];
+            }
+        }
+        __syncthreads();
+        prof_mark(5);
+        for (int ch = 2; ch < nch; ++ch) {                           // further channels: one more exchange each
+#pragma unroll
+            for (int v = 0; v < VPT1; ++v) {
+                const int q = pos[v] - r * HALF;
+                if (pos[v] >= 0 && (unsigned)q < (unsigned)HALF) {
+                    int ox, oy, oz;
+                    sample_pos(g, tid + NT1 * v, ox, oy, oz);
+                    sm.xv[q] = src_value<T>(p, val, b, ((int64_t)ox * gy + oy) * gz + oz, ch, inb_mask(p, c[v]));
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < HALF / NT1; ++j) {
+                const int i = tid + NT1 * j;
+                if (r * HALF + i < total) vals[(int64_t)(ch - 1) * nrec + tilebase + r * HALF + i] = sm.xv[i];
+            }
+            __syncthreads();
+        }
+    }
+    if (direct) scatter_direct<T, K, GM>(p, val, grid, vol, b, g, tid, direct, nch);
+}
+
+// ---------------------------------------------------------------------------
+// own_accumulate
+// ---------------------------------------------------------------------------
+constexpr int BATCH = 6144;                     // records per class-sorted batch (a brick holds 4096 on average)
+constexpr int VPT = BATCH / NT;                 // records per thread and batch
+constexpr int NCLS = 32;                        // classes = 8-byte bank pairs of the LDS
+constexpr int NHW = NT / 32;                    // half waves per workgroup
+
+struct AccSmem {
+    int   taboff[3][BOX + 1];
+    float tabsgn[3][BOX + 1];
+    int   pref[CAPD];                          // exclusive prefix of the run lengths; entries beyond the last run: INT_MAX
+    unsigned start[CAPD];                      // first record of each run
+    int   cmax[2];
+    int   dmax, n;
+    int   qcnt[NCLS], qoff[NCLS + 1], qmax;    // records per class of the batch, their exclusive prefix, the largest count
+    unsigned cells[NCELL / 2];                 // density: 16-bit counters per first-tap cell
+    unsigned short queue[BATCH];               // records of the batch (index inside the batch), sorted by class
+    unsigned long long box[BOXSLOTS];
+};
+static_assert(sizeof(AccSmem) <= 80 * 1024, "two workgroups per CU");
+
+// the 4 LDS adds of one row of the stencil, at immediate offsets (i, jy compile-time)
+template <int I, int J>
+__device__ __forceinline__ void row_adds(unsigned addr, unsigned long long v0, unsigned long long v1, unsigned long long v2, unsigned long long v3)
+{
+    constexpr int o = (I * PLANE + J * PZ) * 8;
+    asm volatile("ds_add_u64 %0, %1 offset:%5\n\tds_add_u64 %0, %2 offset:%6\n\tds_add_u64 %0, %3 offset:%7\n\tds_add_u64 %0, %4 offset:%8"
+                 :: "v"(addr), "v"(v0), "v"(v1), "v"(v2), "v"(v3), "n"(o), "n"(o + 8), "n"(o + 16), "n"(o + 24) : "memory");
+}
+template <int I, int J>
+__device__ __forceinline__ void scatter_row(unsigned addr, f2 sx, const f2 *w, int dbg)
+{
+    const f2 sy = sx * f2{ w[J].x, w[J].x };
+    unsigned long long v[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const f2 pr = sy * f2{ w[k].y, w[k].y };
+        const int q0 = tiled::cvt_rpi(pr.x), q1 = tiled::cvt_rpi(pr.y);
+        // (q1 << 32) + sext(q0): low word q0, high word q1 + (q0 < 0 ? -1 : 0)
+        v[k] = ((unsigned long long)(unsigned)(q1 + (q0 >> 31)) << 32) | (unsigned)q0;
+    }
+#ifdef IP_ABLATE
+    if (dbg & 4) { asm volatile("" :: "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3])); return; }     // (ablation: the arithmetic without the LDS adds)
+#endif
+    row_adds<I, J>(addr, v[0], v[1], v[2], v[3]);
+}
+template <int K, int I>
+__device__ __forceinline__ void scatter_plane(unsigned addr, f2 s, float wxi, const f2 *w, int dbg)
+{
+#ifdef IP_ABLATE
+    if (dbg & 16) {                                                  // (ablation: the LDS adds without the arithmetic)
+        const unsigned long long c = 0x100000001ull;
+        row_adds<I, 0>(addr, c, c, c, c); row_adds<I, 1>(addr, c, c, c, c); row_adds<I, 2>(addr, c, c, c, c);
+        if (K == 3) row_adds<I, 3>(addr, c, c, c, c);
+        return;
+    }
+#endif
+    const f2 sx = s * f2{ wxi, wxi };
+    scatter_row<I, 0>(addr, sx, w, dbg); scatter_row<I, 1>(addr, sx, w, dbg); scatter_row<I, 2>(addr, sx, w, dbg);
+    if (K == 3) scatter_row<I, 3>(addr, sx, w, dbg);
+}
+
+// record g of the brick's concatenated runs -> record index in the workspace
+__device__ __forceinline__ unsigned record_of(const AccSmem &sm, int g)
+{
+    int j = 0;
+#pragma unroll
+    for (int s = CAPD / 2; s > 0; s >>= 1) j += sm.pref[j + s] <= g ? s : 0;
+    return sm.start[j] + (unsigned)(g - sm.pref[j]);
+}
+
+// first-tap cell and stencil coordinates of a record (same arithmetic as own_bin: nd.py:45-46)
+template <int K>
+__device__ __forceinline__ void record_cell(const float4 &r, const int *b0, int &x0, int &y0, int &z0, float &tx, float &ty, float &tz)
+{
+    const float fx = floorf(r.x - 0.5f * (float)(K - 1)), fy = floorf(r.y - 0.5f * (float)(K - 1)), fz = floorf(r.z - 0.5f * (float)(K - 1));
+    tx = r.x - fx; ty = r.y - fy; tz = r.z - fz;
+    x0 = (__float2int_rz(fx) - b0[0]) & (BR - 1); y0 = (__float2int_rz(fy) - b0[1]) & (BR - 1); z0 = (__float2int_rz(fz) - b0[2]) & (BR - 1);
+}
+
+// COLOR 0..7: the interior bricks of that parity, flushed with plain loads / stores; COLOR 8: the bricks whose box
+// leaves the lattice, flushed with atomics through the boundary tables; COLOR 9: every brick, with atomics (shared target)
+//
+// The taps.  The LDS box is 19^3 slots of 8 bytes, row-major.  A ds_add_u64 of a wave is served per 32-lane half; it is
+// conflict-free when the 32 lanes hit 32 different 8-byte bank pairs, i.e. different (slot mod 32) -- and all taps of a
+// stencil add the same offset in every lane (tools/microbench/lds_gather.hip: 6.3 clk against 12.6 for random lanes;
+// measured here, unsorted: 21 clk).  So the records of a batch are counting-sorted by the CLASS (first slot mod 32) into
+// an index queue in LDS, and lane q of every half wave walks class q: half wave h takes entries h, h + 16, ... of its class.
+template <int K>
+__global__ __launch_bounds__(NT, 4) void own_accumulate(KParams p, BrickGrid bg, const int *__restrict__ ndesc, const uint2 *__restrict__ desc,
+                                                        const float4 *__restrict__ rec, const float *__restrict__ vals, int64_t nrec,
+                                                        float *__restrict__ vol, int nch, int color, int nbatch)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    AccSmem &sm = *reinterpret_cast<AccSmem *>(smem_raw);
+    Lattice L;
+#pragma unroll
+    for (int d = 0; d < 3; ++d) { L.bound[d] = p.bound[d]; L.n[d] = p.vol_n[d]; L.ss[d] = p.vol_ss[d] / 4; L.k[d] = K; }
+    L.lin = 0;
+    // bricks of this launch: every second brick per dim for a colour, all of them otherwise
+    const int step = color < 8 ? 2 : 1;
+    const int c0[3] = { color < 8 ? (color >> 2) & 1 : 0, color < 8 ? (color >> 1) & 1 : 0, color < 8 ? color & 1 : 0 };
+    const int m0 = (bg.nb[0] - c0[0] + step - 1) / step, m1 = (bg.nb[1] - c0[1] + step - 1) / step, m2 = (bg.nb[2] - c0[2] + step - 1) / step;
+    const int nwork = m0 * m1 * m2 * nbatch;
+    for (int e = threadIdx.x; e < BOXSLOTS; e += NT) sm.box[e] = 0ull;
+    for (int work = blockIdx.x; work < nwork; work += gridDim.x) {
+        const int tid = opaque((int)threadIdx.x);
+        int r = work;
+        const int iz = r % m2; r /= m2;
+        const int iy = r % m1; r /= m1;
+        const int ix = r % m0;
+        const int64_t b = r / m0;
+        const int bxyz[3] = { ix * step + c0[0], iy * step + c0[1], iz * step + c0[2] };
+        const int b0[3] = { bxyz[0] * BR - OFF, bxyz[1] * BR - OFF, bxyz[2] * BR - OFF };     // lattice index of box slot 0
+        bool interior = true;
+#pragma unroll
+        for (int d = 0; d < 3; ++d) interior = interior && b0[d] >= (L.bound[d] == B_DST1 ? 1 : 0) && b0[d] + BOX <= L.n[d];
+        if (color < 8 ? !interior : (color == 8 && interior)) continue;       // (block-uniform)
+        const bool atomic = color >= 8;
+        const int brick = (int)b * bg.per_item + (bxyz[0] * bg.nb[1] + bxyz[1]) * bg.nb[2] + bxyz[2];
+        int nd = ndesc[brick];
+        if (nd == 0) continue;                                       // (block-uniform)
+        nd = nd < CAPD ? nd : CAPD;
+        __syncthreads();                                             // the previous brick's flush is done with the tables / the box
+        prof_mark(-1);
+        if (tid < 64) {
+            constexpr int PER = CAPD / 64;
+            int cn[PER], s = 0; unsigned st_[PER];
+#pragma unroll
+            for (int i = 0; i < PER; ++i) {
+                const int e = tid * PER + i;
+                const uint2 dsc = e < nd ? desc[(int64_t)brick * CAPD + e] : make_uint2(0u, 0u);
+                cn[i] = (int)dsc.y; st_[i] = dsc.x; s += cn[i];
+            }
+            int incl = s;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o); if (tid >= o) incl += t; }
+            int run = incl - s;
+#pragma unroll
+            for (int i = 0; i < PER; ++i) {
+                const int e = tid * PER + i;
+                sm.pref[e] = e < nd ? run : 0x7fffffff;
+                sm.start[e] = st_[i];
+                run += cn[i];
+            }
+            if (tid == 63) { sm.n = incl; sm.dmax = 0; sm.cmax[0] = 0; sm.cmax[1] = 0; }
+        } else if (atomic && tid < 64 + 3 * 32) {
+            const int d = (tid - 64) >> 5, slot = tid & 31;
+            if (slot < BOX) {
+                const long long pk = wrap_outofline(L.bound[d], b0[d] + slot, L.n[d]);
+                sm.taboff[d][slot] = (int)(pk & 0xffffffffll) * L.ss[d];
+                sm.tabsgn[d][slot] = (float)(int)(pk >> 32);
+            }
+        }
+        for (int e = tid; e < NCELL / 2; e += NT) sm.cells[e] = 0u;
+        if (tid < NCLS) sm.qcnt[tid] = 0;
+        __syncthreads();
+        const int n = sm.n;
+        prof_mark(8);
+        // ---- pass 1 over all records: density of the first-tap cells, max |source| of the first channel pair; the records
+        // of the first batch are also counted into their classes (rank kept in registers: qr = class | rank << 5)
+        int qr[VPT];
+        {
+            float am0 = 0.f, am1 = 0.f;
+#pragma unroll
+            for (int k0 = 0; k0 < VPT; k0 += 4) {
+                float4 rc[4]; float v1[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int g = tid + (k0 + u) * NT;
+                    const unsigned ri = record_of(sm, g < n ? g : 0);
+                    rc[u] = rec[ri]; v1[u] = nch > 1 ? vals[ri] : 0.f;
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int g = tid + (k0 + u) * NT;
+                    qr[k0 + u] = -1;
+                    if (g < n) {
+                        int x0, y0, z0; float tx, ty, tz;
+                        record_cell<K>(rc[u], b0, x0, y0, z0, tx, ty, tz);
+                        const int cell = (x0 * BR + y0) * BR + z0;
+                        atomicAdd(&sm.cells[cell >> 1], 1u << (16 * (cell & 1)));
+                        const int q = (x0 * PLANE + y0 * PZ + z0) & (NCLS - 1);
+                        qr[k0 + u] = q | (atomicAdd(&sm.qcnt[q], 1) << 5);
+                        const float a0 = __builtin_fabsf(rc[u].w), a1 = __builtin_fabsf(v1[u]);
+                        am0 = (a0 > am0 || a0 != a0) ? a0 : am0;     // NaN sticks
+                        am1 = (a1 > am1 || a1 != a1) ? a1 : am1;
+                    }
+                }
+            }
+            for (int g = tid + BATCH; g < n; g += NT) {              // (bricks beyond one batch: strongly contracting deformations)
+                const unsigned ri = record_of(sm, g);
+                const float4 rc = rec[ri];
+                int x0, y0, z0; float tx, ty, tz;
+                record_cell<K>(rc, b0, x0, y0, z0, tx, ty, tz);
+                const int cell = (x0 * BR + y0) * BR + z0;
+                atomicAdd(&sm.cells[cell >> 1], 1u << (16 * (cell & 1)));
+                const float a0 = __builtin_fabsf(rc.w), a1 = nch > 1 ? __builtin_fabsf(vals[ri]) : 0.f;
+                am0 = (a0 > am0 || a0 != a0) ? a0 : am0;
+                am1 = (a1 > am1 || a1 != a1) ? a1 : am1;
+            }
+            const int w0 = wave_max(__float_as_int(am0)), w1 = wave_max(__float_as_int(am1));   // non-negative floats (and NaN) order like ints
+            if ((tid & 63) == 0) { if (w0) atomicMax(&sm.cmax[0], w0); if (w1) atomicMax(&sm.cmax[1], w1); }
+        }
+        __syncthreads();
+        prof_mark(9);
+        {
+            int dm = 0;
+            for (int e = tid; e < NCELL / 2; e += NT) {
+                const unsigned w2 = sm.cells[e];
+                const int a = (int)(w2 & 0xffffu), c2 = (int)(w2 >> 16);
+                dm = a > dm ? a : dm; dm = c2 > dm ? c2 : dm;
+            }
+            dm = wave_max(dm);
+            if ((tid & 63) == 0 && dm > 0) atomicMax(&sm.dmax, dm);
+        }
+        __syncthreads();
+        prof_mark(10);
+        const int hb = n < 60000 ? tiled::headroom32(L, sm.dmax) : -1;    // (16-bit density counters)
+        for (int c = 0; c < nch; c += 2) {
+            const bool two = c + 1 < nch;
+            float *vc0 = vol + b * p.vol_sb + c * p.vol_sc;
+            float *vc1 = two ? vc0 + p.vol_sc : vc0;
+            const float *va = c == 0 ? nullptr : vals + (int64_t)(c - 1) * nrec;       // channel c (channel 0 travels in the record)
+            const float *vb = two ? vals + (int64_t)c * nrec : nullptr;                 // channel c + 1
+            if (c > 0) {
+                // max |source| of this channel pair
+                float am0 = 0.f, am1 = 0.f;
+                for (int g = tid; g < n; g += NT) {
+                    const unsigned ri = record_of(sm, g);
+                    const float a0 = __builtin_fabsf(va[ri]), a1 = two ? __builtin_fabsf(vb[ri]) : 0.f;
+                    am0 = (a0 > am0 || a0 != a0) ? a0 : am0;
+                    am1 = (a1 > am1 || a1 != a1) ? a1 : am1;
+                }
+                const int w0 = wave_max(__float_as_int(am0)), w1 = wave_max(__float_as_int(am1));
+                if ((tid & 63) == 0) { if (w0) atomicMax(&sm.cmax[0], w0); if (w1) atomicMax(&sm.cmax[1], w1); }
+                __syncthreads();
+            }
+            const int mb0 = sm.cmax[0], mb1 = sm.cmax[1];
+            const bool fin = (mb0 & 0x7f800000) != 0x7f800000 && (mb1 & 0x7f800000) != 0x7f800000;
+            const bool fixedpt = hb >= 0 && fin && !(p.dbg & 8);
+            int ex0 = ((mb0 >> 23) & 0xff) - 127, ex1 = ((mb1 >> 23) & 0xff) - 127;
+            ex0 = ex0 < -90 ? -90 : ex0; ex1 = ex1 < -90 ? -90 : ex1;
+            const int hbc = hb < 0 ? 0 : hb;
+            const f2 scale = { mb0 ? __int_as_float((127 + 29 - ex0 - hbc) << 23) : 0.f, mb1 ? __int_as_float((127 + 29 - ex1 - hbc) << 23) : 0.f };
+            const float inv0 = __int_as_float((127 - 29 + ex0 + hbc) << 23), inv1 = __int_as_float((127 - 29 + ex1 + hbc) << 23);
+            const unsigned boxaddr = (unsigned)(size_t)(__attribute__((address_space(3))) void *)(sm.box);
+            for (int g0 = 0; g0 < n; g0 += BATCH) {
+                const int tid = opaque((int)threadIdx.x);
+                const int m = n - g0 < BATCH ? n - g0 : BATCH;       // records of this batch
+                if (g0 > 0 || c > 0) {
+                    // classes of a later batch / of the same records for a later channel pair: count again
+                    __syncthreads();
+                    if (tid < NCLS) sm.qcnt[tid] = 0;
+                    __syncthreads();
+#pragma unroll
+                    for (int k = 0; k < VPT; ++k) {
+                        const int li = tid + k * NT;
+                        qr[k] = -1;
+                        if (li < m) {
+                            const float4 rc = rec[record_of(sm, g0 + li)];
+                            int x0, y0, z0; float tx, ty, tz;
+                            record_cell<K>(rc, b0, x0, y0, z0, tx, ty, tz);
+                            const int q = (x0 * PLANE + y0 * PZ + z0) & (NCLS - 1);
+                            qr[k] = q | (atomicAdd(&sm.qcnt[q], 1) << 5);
+                        }
+                    }
+                    __syncthreads();
+                }
+                // exclusive prefix of the class counts (one half wave), then every record's batch index goes to its queue slot
+                if (tid < 32) {
+                    const int cq = sm.qcnt[tid];
+                    int tot;
+                    const int off = half_excl_scan(cq, tot);
+                    sm.qoff[tid] = off;
+                    if (tid == 31) sm.qoff[NCLS] = tot;
+                    int mx = cq;
+#pragma unroll
+                    for (int o = 16; o > 0; o >>= 1) { const int t = __shfl_xor(mx, o, 32); mx = t > mx ? t : mx; }
+                    if (tid == 0) sm.qmax = mx;
+                }
+                __syncthreads();
+#pragma unroll
+                for (int k = 0; k < VPT; ++k)
+                    if (qr[k] >= 0) sm.queue[sm.qoff[qr[k] & 31] + (qr[k] >> 5)] = (unsigned short)(tid + k * NT);
+                __syncthreads();
+                // ---- the taps: lane q of half wave hw walks class q
+                const int q = tid & 31, hw = tid >> 5;
+                const int ebeg = sm.qoff[q] + hw, eend = sm.qoff[q + 1];
+                const int nit = (sm.qmax + NHW - 1) / NHW;           // (block-uniform)
+                float4 rc = make_float4(0.f, 0.f, 0.f, 0.f); float s0 = 0.f, s1 = 0.f;
+                if (ebeg < eend) {
+                    const unsigned ri = record_of(sm, g0 + (int)sm.queue[ebeg]);
+                    rc = rec[ri]; s0 = va ? va[ri] : rc.w; s1 = vb ? vb[ri] : 0.f;
+                }
+#pragma unroll 1
+                for (int it = 0; it < nit; ++it) {
+                    const int e = ebeg + it * NHW;
+                    const float4 cur = rc; const float cs0 = s0, cs1 = s1;
+                    if (e + NHW < eend) {
+                        const unsigned ri = record_of(sm, g0 + (int)sm.queue[e + NHW]);
+                        rc = rec[ri]; s0 = va ? va[ri] : rc.w; s1 = vb ? vb[ri] : 0.f;
+                    }
+                    if (e >= eend) continue;
+                    int x0, y0, z0; float tx, ty, tz;
+                    record_cell<K>(cur, b0, x0, y0, z0, tx, ty, tz);
+                    if (fixedpt) {
+#ifdef IP_ABLATE
+                        if (p.dbg & 2) continue;                     // (ablation: no taps)
+#endif
+                        unsigned addr = boxaddr + 8u * (unsigned)(x0 * PLANE + y0 * PZ + z0);
+#ifdef IP_ABLATE
+                        if (p.dbg & 32) addr = boxaddr + 8u * (unsigned)((tid & 31) + 32 * (it & 63));     // (ablation: conflict-free by construction)
+                        if (p.dbg & 64) addr = boxaddr + 8u * (unsigned)((tid & 15) + 32 * (it & 63));     // (ablation: two-way conflicts by construction)
+#endif
+                        f2 w[4];
+                        weights_yz<K>(f2{ ty, tz }, w);
+                        const f2 ss = f2{ cs0, cs1 } * scale;
+                        scatter_plane<K, 0>(addr, ss, weight_x<K>(tx, 0), w, p.dbg);
+                        scatter_plane<K, 1>(addr, ss, weight_x<K>(tx, 1), w, p.dbg);
+                        scatter_plane<K, 2>(addr, ss, weight_x<K>(tx, 2), w, p.dbg);
+                        if (K == 3) scatter_plane<K, 3>(addr, ss, weight_x<K>(tx, 3), w, p.dbg);
+                    } else {
+                        // no fixed point for this brick (density beyond the precision rule, non-finite sources): float atomics,
+                        // straight to global memory.  Safe inside a colour: the taps stay inside this brick's own box.
+                        tiled::scatter_one_thread(L, vc0, cs0, b0[0] + x0, b0[1] + y0, b0[2] + z0, tx, ty, tz);
+                        if (two) tiled::scatter_one_thread(L, vc1, cs1, b0[0] + x0, b0[1] + y0, b0[2] + z0, tx, ty, tz);
+                    }
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __syncthreads();
+            prof_mark(11);
+            // ---- flush: fixed point -> float; the box is re-zeroed on the way
+            if (fixedpt && !(p.dbg & 1)) {
+                constexpr int UF = 4;
+                for (int e0 = tid; e0 < BOXSLOTS; e0 += UF * NT) {
+                    long long a[UF]; int off[UF]; float sg[UF];
+#pragma unroll
+                    for (int u = 0; u < UF; ++u) {
+                        const int e = e0 + u * NT;
+                        a[u] = 0; off[u] = 0; sg[u] = 1.f;
+                        if (e < BOXSLOTS) {
+                            const int xr = e / PLANE, rem = e - xr * PLANE, yr = rem / PZ, zr = rem - yr * PZ;
+                            a[u] = (long long)sm.box[e];
+                            sm.box[e] = 0ull;
+                            if (atomic) {
+                                off[u] = sm.taboff[0][xr] + sm.taboff[1][yr] + sm.taboff[2][zr];
+                                sg[u] = sm.tabsgn[0][xr] * sm.tabsgn[1][yr] * sm.tabsgn[2][zr];
+                            } else {
+                                off[u] = (b0[0] + xr) * L.ss[0] + (b0[1] + yr) * L.ss[1] + (b0[2] + zr) * L.ss[2];
+                            }
+                        }
+                    }
+                    if (atomic) {
+#pragma unroll
+                        for (int u = 0; u < UF; ++u) {
+                            if (a[u] == 0) continue;
+                            const int lo_ = (int)(a[u] & 0xffffffffll);
+                            const int hi_ = (int)((a[u] - (long long)lo_) >> 32);
+                            if (lo_ != 0) __hip_atomic_fetch_add(vc0 + off[u], (float)lo_ * (inv0 * sg[u]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            if (hi_ != 0 && two) __hip_atomic_fetch_add(vc1 + off[u], (float)hi_ * (inv1 * sg[u]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        }
+                    } else {
+                        float t0[UF], t1[UF];
+#pragma unroll
+                        for (int u = 0; u < UF; ++u) {
+                            t0[u] = a[u] != 0 ? vc0[off[u]] : 0.f;
+                            t1[u] = (a[u] != 0 && two) ? vc1[off[u]] : 0.f;
+                        }
+#pragma unroll
+                        for (int u = 0; u < UF; ++u) {
+                            if (a[u] == 0) continue;
+                            const int lo_ = (int)(a[u] & 0xffffffffll);
+                            const int hi_ = (int)((a[u] - (long long)lo_) >> 32);
+                            vc0[off[u]] = t0[u] + (float)lo_ * inv0;
+                            if (two) vc1[off[u]] = t1[u] + (float)hi_ * inv1;
+                        }
+                    }
+                }
+            }
+            __syncthreads();
+            prof_mark(12);
+            if (tid == 0) { sm.cmax[0] = 0; sm.cmax[1] = 0; }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Host side
+// ---------------------------------------------------------------------------
+struct Workspace {
+    int *ndesc; uint2 *desc; float4 *rec; float *vals;
+    int64_t nrec; int nbricks;
+};
+static int64_t align256(int64_t x) { return (x + 255) & ~(int64_t)255; }
+
+static int64_t layout(const KParams &k, int B, int ntiles, int nch, void *base, Workspace *w)
+{
+    const BrickGrid bg = brick_grid(k);
+    const int64_t nbricks = (int64_t)bg.per_item * B;
+    const int64_t nrec = (int64_t)ntiles * NS * B;
+    int64_t o = 0;
+    unsigned char *p = (unsigned char *)base;
+    const int64_t o_nd = o; o += align256(nbricks * 4);
+    const int64_t o_desc = o; o += align256(nbricks * CAPD * 8);
+    const int64_t o_rec = o; o += align256(nrec * 16);
+    const int64_t o_val = o; o += align256(nrec * 4 * (nch > 1 ? nch - 1 : 0));
+    if (w) {
+        w->ndesc = (int *)(p + o_nd); w->desc = (uint2 *)(p + o_desc);
+        w->rec = (float4 *)(p + o_rec); w->vals = (float *)(p + o_val);
+        w->nrec = nrec; w->nbricks = (int)nbricks;
+    }
+    return o;
+}
+
+static int tile_count(const interpol_problem *p)
+{
+    int64_t n = 1;
+    for (int d = 0; d < 3; ++d) n *= (p->grid_shape[d] + TS - 1) / TS;
+    return n > 0x7fffffff ? 0 : (int)n;
+}
+
+} // namespace owner
+
+// Eligible: 3-D, one order 2..3, sample grid about as dense as the target (else the tiled / brick
+// scatters are the better organisation), sizes within 32-bit record counts.
+static bool owner_eligible(const interpol_problem *p, const KParams &k)
+{
+    if (p->dim != 3 || p->batch > 4096) return false;
+    if (!(p->flags & INTERPOL_FLAG_BINNED_SCATTER)) return false;   // opt-in: see interpol_hip.h
+    if (k.order[0] != k.order[1] || k.order[0] != k.order[2] || k.order[0] < 2 || k.order[0] > 3) return false;
+    int64_t n = 1, nv = 1, nb = p->batch;
+    for (int d = 0; d < 3; ++d) {
+        n *= p->grid_shape[d]; nv *= p->vol_shape[d];
+        nb *= (p->vol_shape[d] + 2 * owner::OFF + owner::BR - 1) / owner::BR;
+        if (p->grid_shape[d] > 0x7fffffff / 4) return false;
+    }
+    const int64_t nt = owner::tile_count(p);
+    if (n < 4096 || nt == 0 || nt * owner::NS * p->batch > 0x7fffffffll || nb > 0x7fffffffll / owner::CAPD) return false;
+    if ((uint64_t)n * 12ull > 0xffffffffull) return false;
+    return 4 * n >= nv;                                              // at least a quarter of a sample per target voxel
+}
+
+// bytes of workspace the owner-computes organisation needs for this problem (0: not applicable)
+int64_t owner_workspace_bytes(const interpol_problem *p, const KParams &k, bool count_only)
+{
+    if (!owner_eligible(p, k)) return 0;
+    const int nch = count_only ? 1 : k.C + (k.cc ? 1 : 0);
+    return owner::layout(k, (int)p->batch, owner::tile_count(p), nch, nullptr, nullptr);
+}
+
+namespace owner {
+template <typename T>
+static int launch_bin(const interpol_problem *p, const KParams &k, const BrickGrid &bg, const Workspace &w, const void *val, const void *grid,
+                      void *vol, hipStream_t st)
+{
+    const int gx = (int)p->grid_shape[0], gy = (int)p->grid_shape[1], gz = (int)p->grid_shape[2];
+    const int nty = (gy + TS - 1) / TS, ntz = (gz + TS - 1) / TS;
+    const int ntiles = tile_count(p);
+    const dim3 tgrid((unsigned)(ntiles * (int)p->batch));
+#define IP_OWN_BIN(KK, GM)                                                                                              \
+    {                                                                                                                   \
+        const int attr = big_lds<own_bin<T, KK, GM>>(sizeof(BinSmem));                                                    \
+        if (attr) return attr;                                                                                          \
+        hipLaunchKernelGGL((own_bin<T, KK, GM>), tgrid, dim3(NT1), sizeof(BinSmem), st, k, bg, (const T *)val, (const float *)grid, \
+                           (float *)vol, w.ndesc, w.desc, w.rec, w.vals, w.nrec, gx, gy, gz, nty, ntz, ntiles);            \
+    }
+#define IP_OWN_BY_GM(KK)                                                                                                \
+    { if (k.sep == 0) IP_OWN_BIN(KK, 0) else if (k.sep == 1) IP_OWN_BIN(KK, 1) else if (k.sep == 2) IP_OWN_BIN(KK, 2) else IP_OWN_BIN(KK, 3) }
+    if (k.order[0] == 3) IP_OWN_BY_GM(3) else IP_OWN_BY_GM(2)
+#undef IP_OWN_BY_GM
+#undef IP_OWN_BIN
+    return 0;
+}
+} // namespace owner
+
+// returns 1 when it took the problem, 0 to decline (workspace missing / not eligible), else an error
+int try_owner_push(const interpol_problem *p, const KParams &k, const void *val, const void *grid, void *vol,
+                   void *workspace, int64_t workspace_bytes, hipStream_t st)
+{
+    using namespace owner;
+    if (!workspace || !owner_eligible(p, k)) return 0;
+    const bool count_only = val == nullptr;
+    const int nch = count_only ? 1 : k.C + (k.cc ? 1 : 0);
+    Workspace w;
+    if (layout(k, (int)p->batch, tile_count(p), nch, workspace, &w) > workspace_bytes) return 0;
+    const BrickGrid bg = brick_grid(k);
+    hipError_t e = hipMemsetAsync(w.ndesc, 0, (size_t)w.nbricks * 4, st);
+    if (e != hipSuccess) return (int)e;
+    int rc;
+    switch (count_only ? INTERPOL_F32 : p->dtype) {
+    case INTERPOL_F32: rc = launch_bin<float>(p, k, bg, w, val, grid, vol, st); break;
+    case INTERPOL_BF16: rc = launch_bin<bf16_t>(p, k, bg, w, val, grid, vol, st); break;
+    case INTERPOL_F16: rc = launch_bin<f16_t>(p, k, bg, w, val, grid, vol, st); break;
+    default: return 0;
+    }
+    if (rc) return rc;
+    const bool shared = p->vol_stride[0] == 0 && p->batch > 1;
+    const long long want = 2ll * cu_count();
+    const int B = (int)p->batch;
+    for (int color = shared ? 9 : 0; color < (shared ? 10 : 9); ++color) {
+        long long nwork = B;
+        for (int d = 0; d < 3; ++d) {
+            const int c0 = color < 8 ? (color >> (2 - d)) & 1 : 0, step = color < 8 ? 2 : 1;
+            nwork *= (bg.nb[d] - c0 + step - 1) / step;
+        }
+        if (nwork <= 0) continue;
+        const dim3 agrid((unsigned)(nwork < want ? nwork : want));
+#define IP_OWN_ACC(KK)                                                                                                  \
+        {                                                                                                               \
+            const int attr = big_lds<own_accumulate<KK>>(sizeof(AccSmem));                                              \
+            if (attr) return attr;                                                                                      \
+            hipLaunchKernelGGL((own_accumulate<KK>), agrid, dim3(NT), sizeof(AccSmem), st, k, bg, (const int *)w.ndesc,  \
+                               (const uint2 *)w.desc, (const float4 *)w.rec, (const float *)w.vals, w.nrec, (float *)vol, nch, color, B); \
+        }
+        if (k.order[0] == 3) IP_OWN_ACC(3) else IP_OWN_ACC(2)
+#undef IP_OWN_ACC
+    }
+    e = hipGetLastError();
+    return e == hipSuccess ? 1 : (int)e;
+}
+
+} // namespace ip
+
+#ifdef IP_PROF
+extern "C" __attribute__((visibility("default"))) int interpol_debug_prof_owner(unsigned long long *out, int reset)
+{
+    unsigned long long z[16] = { 0 };
+    if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(ip::sorted::g_prof), sizeof z) != hipSuccess) return -1;
+    if (reset && hipMemcpyToSymbol(HIP_SYMBOL(ip::sorted::g_prof), z, sizeof z) != hipSuccess) return -1;
+    return 0;
+}
+#endif
