@@ -24,7 +24,8 @@ for sigma in sig:
     res["owner_valu_only"] = timeit(lambda: _hip.scatter("push", inp, grid, None, [3] * 3, [3] * 3, 1, flags=_hip.FLAG_BINNED_SCATTER | (4 << 8)))
     res["owner_lds_only"] = timeit(lambda: _hip.scatter("push", inp, grid, None, [3] * 3, [3] * 3, 1, flags=_hip.FLAG_BINNED_SCATTER | (16 << 8)))
     res["owner_lds_only_synth_cf"] = timeit(lambda: _hip.scatter("push", inp, grid, None, [3] * 3, [3] * 3, 1, flags=_hip.FLAG_BINNED_SCATTER | (48 << 8)))
-    res["owner_lds_only_synth_2way"] = timeit(lambda: _hip.scatter("push", inp, grid, None, [3] * 3, [3] * 3, 1, flags=_hip.FLAG_BINNED_SCATTER | (80 << 8)))
+    res["owner_lds_only_realclass_synthrow"] = timeit(lambda: _hip.scatter("push", inp, grid, None, [3] * 3, [3] * 3, 1, flags=_hip.FLAG_BINNED_SCATTER | (80 << 8)))
+    res["owner_lds_only_synth_randrow"] = timeit(lambda: _hip.scatter("push", inp, grid, None, [3] * 3, [3] * 3, 1, flags=_hip.FLAG_BINNED_SCATTER | (144 << 8)))
     res["owner_no_flush"] = timeit(lambda: _hip.scatter("push", inp, grid, None, [3] * 3, [3] * 3, 1, flags=_hip.FLAG_BINNED_SCATTER | (1 << 8)))
     a = _hip.scatter("push", inp, grid, None, [3] * 3, [3] * 3, 1)
     b = _hip.scatter("push", inp, grid, None, [3] * 3, [3] * 3, 1, flags=_hip.FLAG_BINNED_SCATTER)

@@ -61,16 +61,36 @@ constexpr int NT1 = 512, VPT1 = NS / NT1;       // own_bin: threads, samples per
 constexpr int LB = 6, NBIN = LB * LB * LB;      // bricks around a tile that are sorted locally
 constexpr int HALF = NS / 2;                    // records per exchange round
 
+// Bricks of first-tap cells, per dim: [-OFF, 0) in NLO bricks (stencils that leave the lattice at the low end), then the
+// cells [0, M) whose whole stencil lies inside the lattice (M = n - K) in nin bricks of BR cells -- the last one holds the
+// remainder, so that the BOX of every one of them fits the lattice --, then [max(M, 0), ...) in NHI bricks (stencils that
+// leave at the high end).  Only the shell bricks need the boundary condition (and global atomics: their boxes alias).
+constexpr int NLO = OFF / BR, NHI = (OFF + 3 + BR - 1) / BR;
 struct BrickGrid {
     int nb[3];                                  // bricks per dim
+    int m[3], nin[3];                           // fully-inside first-tap cells, bricks that hold them
     int per_item;                               // nb[0] * nb[1] * nb[2]
 };
 static BrickGrid brick_grid(const KParams &k)
 {
     BrickGrid g;
-    for (int d = 0; d < 3; ++d) g.nb[d] = (k.vol_n[d] + 2 * OFF + BR - 1) / BR;
+    for (int d = 0; d < 3; ++d) {
+        const int m = k.vol_n[d] - k.order[d];
+        g.m[d] = m > 0 ? m : 0;
+        g.nin[d] = (g.m[d] + BR - 1) / BR;
+        g.nb[d] = NLO + g.nin[d] + NHI;
+    }
     g.per_item = g.nb[0] * g.nb[1] * g.nb[2];
     return g;
+}
+// brick of a first-tap cell (inside [-OFF, m + NHI * BR)) and first cell of a brick
+__host__ __device__ __forceinline__ int brick_of_cell(int ft, int m, int nin)
+{
+    return ft < 0 ? (ft + OFF) >> 4 : (ft < m ? NLO + (ft >> 4) : NLO + nin + ((ft - m) >> 4));
+}
+__host__ __device__ __forceinline__ int brick_origin(int bk, int m, int nin)
+{
+    return bk < NLO ? bk * BR - OFF : (bk < NLO + nin ? (bk - NLO) * BR : m + (bk - NLO - nin) * BR);
 }
 
 // ---------------------------------------------------------------------------
@@ -156,8 +176,8 @@ __global__ __launch_bounds__(NT1, 4) void own_bin(KParams p, BrickGrid bg, const
 #pragma unroll
         for (int d = 0; d < 3; ++d) {
             const float fl = floorf(c[v][d] - 0.5f * (float)(K - 1));
-            in = in && fl >= (float)(-OFF) && fl < (float)(bg.nb[d] * BR - OFF);       // (false for NaN)
-            bx[v][d] = in ? (__float2int_rz(fl) + OFF) >> 4 : 0;
+            in = in && fl >= (float)(-OFF) && fl < (float)(bg.m[d] + NHI * BR);        // (false for NaN)
+            bx[v][d] = in ? brick_of_cell(__float2int_rz(fl), bg.m[d], bg.nin[d]) : 0;
         }
         if (in) {
             ok |= 1u << v;
@@ -389,10 +409,12 @@ __global__ __launch_bounds__(NT, 4) void own_accumulate(KParams p, BrickGrid bg,
         const int ix = r % m0;
         const int64_t b = r / m0;
         const int bxyz[3] = { ix * step + c0[0], iy * step + c0[1], iz * step + c0[2] };
-        const int b0[3] = { bxyz[0] * BR - OFF, bxyz[1] * BR - OFF, bxyz[2] * BR - OFF };     // lattice index of box slot 0
+        const int b0[3] = { brick_origin(bxyz[0], bg.m[0], bg.nin[0]), brick_origin(bxyz[1], bg.m[1], bg.nin[1]),
+                            brick_origin(bxyz[2], bg.m[2], bg.nin[2]) };                       // lattice index of box slot 0
+        // interior: every stencil of the brick lies inside the lattice (dst1: index 0 carries the sign 0, bounds.py:62-89 -- tables)
         bool interior = true;
 #pragma unroll
-        for (int d = 0; d < 3; ++d) interior = interior && b0[d] >= (L.bound[d] == B_DST1 ? 1 : 0) && b0[d] + BOX <= L.n[d];
+        for (int d = 0; d < 3; ++d) interior = interior && bxyz[d] >= NLO + (L.bound[d] == B_DST1 ? 1 : 0) && bxyz[d] < NLO + bg.nin[d];
         if (color < 8 ? !interior : (color == 8 && interior)) continue;       // (block-uniform)
         const bool atomic = color >= 8;
         const int brick = (int)b * bg.per_item + (bxyz[0] * bg.nb[1] + bxyz[1]) * bg.nb[2] + bxyz[2];
@@ -589,7 +611,8 @@ __global__ __launch_bounds__(NT, 4) void own_accumulate(KParams p, BrickGrid bg,
                         unsigned addr = boxaddr + 8u * (unsigned)(x0 * PLANE + y0 * PZ + z0);
 #ifdef IP_ABLATE
                         if (p.dbg & 32) addr = boxaddr + 8u * (unsigned)((tid & 31) + 32 * (it & 63));     // (ablation: conflict-free by construction)
-                        if (p.dbg & 64) addr = boxaddr + 8u * (unsigned)((tid & 15) + 32 * (it & 63));     // (ablation: two-way conflicts by construction)
+                        if (p.dbg & 64) addr = boxaddr + 8u * (unsigned)(((x0 * PLANE + y0 * PZ + z0) & 31) + 32 * (it & 63));     // (ablation: the record's class, a synthetic row)
+                        if (p.dbg & 128) addr = boxaddr + 8u * (unsigned)((tid & 31) + 32 * ((tid * 2654435761u + it * 40503u) >> 25));   // (ablation: the lane's class, a random row)
 #endif
                         f2 w[4];
                         weights_yz<K>(f2{ ty, tz }, w);
@@ -711,7 +734,7 @@ static bool owner_eligible(const interpol_problem *p, const KParams &k)
     int64_t n = 1, nv = 1, nb = p->batch;
     for (int d = 0; d < 3; ++d) {
         n *= p->grid_shape[d]; nv *= p->vol_shape[d];
-        nb *= (p->vol_shape[d] + 2 * owner::OFF + owner::BR - 1) / owner::BR;
+        nb *= owner::NLO + owner::NHI + (p->vol_shape[d] + owner::BR - 1) / owner::BR;
         if (p->grid_shape[d] > 0x7fffffff / 4) return false;
     }
     const int64_t nt = owner::tile_count(p);
