@@ -117,14 +117,22 @@ typedef struct interpol_problem {
  * pass over the grid -- push followed by count on the same grid is the usual pairing (normalised
  * splatting; SURVEY config 4).  vol_stride describe the (B, C+1, *shape) target. */
 #define INTERPOL_FLAG_WITH_COUNT    32
-/* interpol_push / interpol_count: organise the scatter TARGET-STATIONARY (push_binned.hip): the samples
- * are first binned by the lattice brick of their first tap, then every brick is accumulated by one
- * workgroup.  Its cost does not depend on the deformation (6 - 7 ms at 4x2x256^3 cubic for i.i.d.
- * displacements of sigma = 0.5 ... 6 voxels), whereas the sample-stationary tiles (the default: 2.8 /
- * 3.5 / 5.0 / 8.6 / 126 ms at sigma = 0.5 / 2 / 3 / 4 / 6) need the stencils of a 16^3 tile of samples
- * to fit a 32^3 LDS box: set it for very rough deformations.  Needs the workspace announced by
- * interpol_scatter_workspace(); ignored (tiles / generic kernels) when it does not apply. */
+/* interpol_push / interpol_count: organise the scatter OWNER-COMPUTES (push_owner.hip): the samples are
+ * first sorted by the 16^3 brick of target lattice points their first tap falls into (one pass over the
+ * inputs), then every brick is accumulated in LDS by one workgroup and added to the target with plain
+ * loads and stores -- no global atomics but for the thin shell of stencils that leave the lattice.  The
+ * cost does not depend on the deformation (4x2x256^3 cubic: 3.9 - 4.4 ms from the identity to i.i.d.
+ * noise of sigma = 6 voxels), where the default sample-stationary tiles need the stencils of a 16^3 tile
+ * of samples to fit a 33 x 33 x 32 LDS box (2.2 ms at the identity, 3.5 at sigma = 2, 126 at sigma = 6).
+ * 3-D, one order 2..3, float32 coordinates.  Needs the workspace announced by
+ * interpol_scatter_workspace(); ignored (tiles / generic kernels) when it does not apply.
+ *   INTERPOL_FLAG_BINNED_SCATTER: always;
+ *   INTERPOL_FLAG_AUTO_SCATTER:   a probe kernel of the same call examines 256 tiles of the sample grid
+ *     and writes a device-side gate; both organisations are enqueued, each kernel reads the gate on
+ *     entry and one of the two returns at once (about 50 us of empty launches).  Stateless: the choice
+ *     depends on the coordinates of this call alone; safe under hipGraph capture. */
 #define INTERPOL_FLAG_BINNED_SCATTER 64
+#define INTERPOL_FLAG_AUTO_SCATTER  (1 << 24)
 /* The sample coordinates are an AFFINE function of the sample index, x = A o + t -- the fused form of
  * affine_grid (api.py:534-572) followed by the operator: `grid` points to ONE D x (D+1) matrix [A | t]
  * (grid_dtype, row-major), evaluated in registers as ((A_d0 o_0) + A_d1 o_1 ...) + t_d with fused
@@ -152,8 +160,9 @@ typedef struct interpol_problem {
  * float accumulation buffer `scratch` of batch*channels*prod(vol_shape) floats
  * (scratch_bytes = that * 4); pass NULL/0 for F32/F64.
  *
- * Workspace of the scatters: with INTERPOL_FLAG_BINNED_SCATTER, interpol_push / interpol_count first
- * bin the samples by target brick (push_binned.hip), which needs room for the sorted records:
+ * Workspace of the scatters: with INTERPOL_FLAG_BINNED_SCATTER / INTERPOL_FLAG_AUTO_SCATTER, interpol_push /
+ * interpol_count first sort the samples by target brick (push_owner.hip), which needs room for the sorted
+ * records (16 B per sample + 4 B per sample and further channel, 2 KiB per brick):
  * interpol_scatter_workspace(p, count_only) returns the number of bytes `scratch` must then have
  * (it INCLUDES the fp32 accumulator of a BF16 / F16 target, which comes first), or 0 when the
  * organisation does not apply.  With a smaller (or no) scratch the operators fall back to the

@@ -172,7 +172,7 @@ if "r" in which:    # config 2 vs the roughness of the deformation: identity + s
         try:
             rec(res, "cfg2_push_binned_sigma_%g" % sigma, timeit(lambda: interpol.grid_push(inp, grid, **kw), 3), vox, nb)
         finally:
-            backend.rough_deformations = False
+            backend.rough_deformations = None
         del inp, grid
 
 if "r" in which:    # SURVEY 8(d)'s smooth variant: 12^3 control points, sigma = 2 / 8 voxels, cubic-upsampled displacement (a registration field)

@@ -18,7 +18,7 @@ for _ in range(4):
         elif op in ("push_binned", "push_owner"):
             backend.rough_deformations = True
             interpol.grid_push(inp, grid, **kw)
-            backend.rough_deformations = False
+            backend.rough_deformations = None
         elif op == "push_sorted":
             _hip.scatter("push", inp, grid, None, [3] * 3, [3] * 3, 1, flags=128 << 8)
         elif op == "count": interpol.grid_count(grid, **kw)

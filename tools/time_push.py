@@ -18,15 +18,13 @@ sig = [float(s) for s in sys.argv[1:]] or [2.0, 0.0]
 for sigma in sig:
     inp, grid = bench.make_inputs(4, 2, 256, sigma, dev, 1234)
     res = {}
+    from interpol import backend
+    backend.rough_deformations = False
+    res["push_tiles"] = timeit(lambda: _hip.scatter("push", inp, grid, None, [3] * 3, [3] * 3, 1))
+    backend.rough_deformations = None
     res["push_routed"] = timeit(lambda: _hip.scatter("push", inp, grid, None, [3] * 3, [3] * 3, 1))
+    res["count_routed"] = timeit(lambda: _hip.scatter("count", None, grid, None, [3] * 3, [3] * 3, 1))
     res["push_owner"] = timeit(lambda: _hip.scatter("push", inp, grid, None, [3] * 3, [3] * 3, 1, flags=_hip.FLAG_BINNED_SCATTER))
-    res["owner_no_taps"] = timeit(lambda: _hip.scatter("push", inp, grid, None, [3] * 3, [3] * 3, 1, flags=_hip.FLAG_BINNED_SCATTER | (2 << 8)))
-    res["owner_valu_only"] = timeit(lambda: _hip.scatter("push", inp, grid, None, [3] * 3, [3] * 3, 1, flags=_hip.FLAG_BINNED_SCATTER | (4 << 8)))
-    res["owner_lds_only"] = timeit(lambda: _hip.scatter("push", inp, grid, None, [3] * 3, [3] * 3, 1, flags=_hip.FLAG_BINNED_SCATTER | (16 << 8)))
-    res["owner_lds_only_synth_cf"] = timeit(lambda: _hip.scatter("push", inp, grid, None, [3] * 3, [3] * 3, 1, flags=_hip.FLAG_BINNED_SCATTER | (48 << 8)))
-    res["owner_lds_only_realclass_synthrow"] = timeit(lambda: _hip.scatter("push", inp, grid, None, [3] * 3, [3] * 3, 1, flags=_hip.FLAG_BINNED_SCATTER | (80 << 8)))
-    res["owner_lds_only_synth_randrow"] = timeit(lambda: _hip.scatter("push", inp, grid, None, [3] * 3, [3] * 3, 1, flags=_hip.FLAG_BINNED_SCATTER | (144 << 8)))
-    res["owner_no_flush"] = timeit(lambda: _hip.scatter("push", inp, grid, None, [3] * 3, [3] * 3, 1, flags=_hip.FLAG_BINNED_SCATTER | (1 << 8)))
     a = _hip.scatter("push", inp, grid, None, [3] * 3, [3] * 3, 1)
     b = _hip.scatter("push", inp, grid, None, [3] * 3, [3] * 3, 1, flags=_hip.FLAG_BINNED_SCATTER)
     res["max_abs_diff"] = float((a - b).abs().max()); res["max_abs"] = float(a.abs().max())

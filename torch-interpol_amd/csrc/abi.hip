@@ -55,7 +55,7 @@ IP_DECL_TILED(f32) IP_DECL_TILED(bf16) IP_DECL_TILED(f16)
 #undef IP_DECL_TILED
 
 // owner-computes (target-stationary) scatter for same-resolution deformations (push_owner.hip)
-int try_owner_push(const interpol_problem *, const KParams &, const void *, const void *, void *, void *, int64_t, hipStream_t);
+int try_owner_push(const interpol_problem *, const KParams &, const void *, const void *, void *, void *, int64_t, hipStream_t, const int **);
 int64_t owner_workspace_bytes(const interpol_problem *, const KParams &, bool);
 
 #define IP_TILED_BY_DTYPE(NAME, ...)                                                     \
@@ -335,8 +335,8 @@ int interpol_push(const interpol_problem *p, const void *val, const void *grid, 
         KParams k = k0;
         k.cc = with_count ? 1 : 0;
         if (!(p->flags & INTERPOL_FLAG_NO_FASTPATH)) {
-            int rc = try_owner_push(p, k, val, grid, acc, ws, ws_bytes, st);     // needs its workspace: interpol_scatter_workspace
-            if (rc != 0) return rc == 1 ? 0 : rc;
+            int rc = try_owner_push(p, k, val, grid, acc, ws, ws_bytes, st, &k.gate);     // needs its workspace: interpol_scatter_workspace
+            if (rc != 0 && rc != 2) return rc == 1 ? 0 : rc;       // (2: launched behind the probe's gate; the kernels below read the same gate)
             rc = try_fast_push(p, k, val, grid, acc, st);           // the tiled kernel splats values and count in one pass
             if (rc != 0) return rc == 1 ? 0 : rc;
         }
@@ -415,10 +415,11 @@ int interpol_count(const interpol_problem *p, const void *grid, void *vol,
     if (p && p->channels != 1) return INTERPOL_E_SHAPE;
     if (p && (p->flags & INTERPOL_FLAG_WITH_COUNT)) return INTERPOL_E_STRIDE;      // interpol_push only
     hipStream_t st = (hipStream_t)stream;
-    return scatter_driver(p, 1, false, nullptr, grid, vol, scratch, scratch_bytes, st, [&](const KParams &k, int B, void *acc, void *ws, int64_t ws_bytes) {
+    return scatter_driver(p, 1, false, nullptr, grid, vol, scratch, scratch_bytes, st, [&](const KParams &k0, int B, void *acc, void *ws, int64_t ws_bytes) {
+        KParams k = k0;
         if (!(p->flags & INTERPOL_FLAG_NO_FASTPATH)) {
-            int rc = try_owner_push(p, k, nullptr, grid, acc, ws, ws_bytes, st);
-            if (rc != 0) return rc == 1 ? 0 : rc;
+            int rc = try_owner_push(p, k, nullptr, grid, acc, ws, ws_bytes, st, &k.gate);
+            if (rc != 0 && rc != 2) return rc == 1 ? 0 : rc;
             rc = try_fast_push(p, k, nullptr, grid, acc, st);
             if (rc != 0) return rc == 1 ? 0 : rc;
         }

@@ -264,6 +264,7 @@ template <typename T, typename G, typename R, typename AccT, int D, int KMAX, bo
 __global__ __launch_bounds__(BLOCK) void push_generic(KParams p, const T *__restrict__ val,
                                                       const G *__restrict__ grid, AccT *__restrict__ vol, int B, TileList tl)
 {
+    if (p.gate && *p.gate) return;                     // the owner-computes organisation took this call (push_owner.hip: own_probe)
     IP_FOR_SAMPLES {
         const int64_t b = it_.b, o = it_.o;
         R x[D];

@@ -849,6 +849,7 @@ __global__ __launch_bounds__(NT, 4) void push_sorted(KParams p, const T *__restr
                                                      float *__restrict__ vol, int gx, int gy, int gz, int nty, int ntz, int ntiles, int nbatch,
                                                      DeferArgs defer)
 {
+    if (p.gate && *p.gate) return;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     Smem &sm = *reinterpret_cast<Smem *>(smem_raw);
     Lattice L;

@@ -1716,6 +1716,7 @@ __global__ __launch_bounds__(C::NT) void push_tiled(KParams p, const typename C:
                                                     float *__restrict__ vol, int gx, int gy, int gz, int nty, int ntz,
                                                     int ntiles, int nbatch, DeferArgs defer)
 {
+    if (p.gate && *p.gate) return;                     // the owner-computes organisation took this call (push_owner.hip: own_probe)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     Smem &sm = *reinterpret_cast<Smem *>(smem_raw);
     using T = typename C::T;

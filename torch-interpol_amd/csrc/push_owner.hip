@@ -142,8 +142,9 @@ template <typename T, int K, int GM>
 __global__ __launch_bounds__(NT1, 4) void own_bin(KParams p, BrickGrid bg, const T *__restrict__ val, const float *__restrict__ grid,
                                                float *__restrict__ vol, int *__restrict__ ndesc, uint2 *__restrict__ desc,
                                                float4 *__restrict__ rec, float *__restrict__ vals, int64_t nrec,
-                                               int gx, int gy, int gz, int nty, int ntz, int ntiles)
+                                               int gx, int gy, int gz, int nty, int ntz, int ntiles, const int *__restrict__ gate)
 {
+    if (gate && *gate != 1) return;                                  // INTERPOL_FLAG_AUTO_SCATTER: the probe chose the tiles
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     BinSmem &sm = *reinterpret_cast<BinSmem *>(smem_raw);
     const int tid = threadIdx.x;
@@ -292,7 +293,9 @@ __global__ __launch_bounds__(NT1, 4) void own_bin(KParams p, BrickGrid bg, const
             __syncthreads();
         }
     }
+#ifndef IP_ABLATE
     if (direct) scatter_direct<T, K, GM>(p, val, grid, vol, b, g, tid, direct, nch);
+#endif
 }
 
 // ---------------------------------------------------------------------------
@@ -387,8 +390,9 @@ __device__ __forceinline__ void record_cell(const float4 &r, const int *b0, int 
 template <int K>
 __global__ __launch_bounds__(NT, 4) void own_accumulate(KParams p, BrickGrid bg, const int *__restrict__ ndesc, const uint2 *__restrict__ desc,
                                                         const float4 *__restrict__ rec, const float *__restrict__ vals, int64_t nrec,
-                                                        float *__restrict__ vol, int nch, int color, int nbatch)
+                                                        float *__restrict__ vol, int nch, int color, int nbatch, const int *__restrict__ gate)
 {
+    if (gate && *gate != 1) return;                                  // INTERPOL_FLAG_AUTO_SCATTER: the probe chose the tiles
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     AccSmem &sm = *reinterpret_cast<AccSmem *>(smem_raw);
     Lattice L;
@@ -688,10 +692,111 @@ __global__ __launch_bounds__(NT, 4) void own_accumulate(KParams p, BrickGrid bg,
 }
 
 // ---------------------------------------------------------------------------
+// own_probe (INTERPOL_FLAG_AUTO_SCATTER): which organisation serves this call?
+// The sample-stationary tiles (ops_tiled.hip) accumulate a tile of 16^3 samples in an LDS box of at most 33 x 33 x 32
+// lattice points centred on the tile's stencils; samples outside it take a slow path, and beyond a few per cent of them the
+// kernel degrades by one to two orders of magnitude (config 2, i.i.d. noise: 3.6 / 5.0 / 8.6 / 126 ms at sigma 2 / 3 / 4 / 6,
+// where this file needs 4.1 - 4.4 ms throughout).  NPROBE tiles spread over the sample grid are examined exactly as
+// Box::build does it: the workgroup that finishes last writes gate = 1 (owner-computes) when more than 0.4 % of the
+// probed samples fall outside their tile's box -- and hardly any outside the binned range, where this file would fall
+// back to per-sample atomics -- else 0 (tiles).  Every scatter kernel of the call reads the word on entry: one of the two
+// organisations returns at once.  Stateless and deterministic: the choice depends on the coordinates of this call alone.
+// ---------------------------------------------------------------------------
+__global__ void own_zero(int *__restrict__ p, int n)
+{
+    const int i = blockIdx.x * 1024 + threadIdx.x;
+    if (i < n) p[i] = 0;
+}
+
+constexpr int NPROBE = 256;
+struct ProbeHdr { int gate, done, nslow, nfar, nvalid, pad[3]; };
+
+template <int K, int GM>
+__global__ __launch_bounds__(NT1) void own_probe(KParams p, BrickGrid bg, const float *__restrict__ grid, ProbeHdr *__restrict__ hdr,
+                                                 int gx, int gy, int gz, int nty, int ntz, int ntiles, int nbatch)
+{
+    __shared__ int lo[3], hi[3], cnt[3];
+    const int tid = threadIdx.x;
+    const int64_t total = (int64_t)ntiles * nbatch;
+    const int64_t work = (int64_t)blockIdx.x * total / gridDim.x;
+    const int64_t b = work / ntiles;
+    const TileGeom g = tile_geom((int)(work % ntiles), gx, gy, gz, nty, ntz);
+    if (tid < 3) { lo[tid] = 0x7fffffff; hi[tid] = -0x7fffffff; cnt[tid] = 0; }
+    float fl[VPT1][3];
+    unsigned valid = 0;
+    int far = 0;
+#pragma unroll
+    for (int v = 0; v < VPT1; ++v) {
+        int ox, oy, oz; float c[3];
+        sample_pos(g, tid + NT1 * v, ox, oy, oz);
+        if (ox < gx && oy < gy && oz < gz) valid |= 1u << v;
+        ox = ox < gx ? ox : gx - 1; oy = oy < gy ? oy : gy - 1; oz = oz < gz ? oz : gz - 1;
+        load_xyz<GM>(p, grid, b, g, ox, oy, oz, c);
+        bool in = true;
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            fl[v][d] = floorf(c[d] - 0.5f * (float)(K - 1));
+            in = in && fl[v][d] >= (float)(-OFF) && fl[v][d] < (float)(bg.m[d] + NHI * BR);
+            fl[v][d] = __builtin_fmaxf(__builtin_fminf(fl[v][d], 1073741824.f), -1073741824.f);
+        }
+        if (((valid >> v) & 1) && !in) ++far;
+    }
+    __syncthreads();
+    int mn[3] = { 0x7fffffff, 0x7fffffff, 0x7fffffff }, mx[3] = { -0x7fffffff, -0x7fffffff, -0x7fffffff };
+#pragma unroll
+    for (int v = 0; v < VPT1; ++v) {
+        if (!((valid >> v) & 1)) continue;
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            const int i = fl[v][d] == fl[v][d] ? __float2int_rz(fl[v][d]) : 0;
+            mn[d] = i < mn[d] ? i : mn[d]; mx[d] = i > mx[d] ? i : mx[d];
+        }
+    }
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        const int a = wave_min(mn[d]), e = wave_max(mx[d]);
+        if ((tid & 63) == 0) { atomicMin(&lo[d], a); atomicMax(&hi[d], e); }
+    }
+    __syncthreads();
+    // the tile's box as the tiles cut it (ops_tiled.hip: Box::build): centred, at most 33 x 33 x 32 lattice points
+    const int cap[3] = { 33, 33, 32 };
+    int l[3], h[3];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        int a = lo[d], sz = hi[d] + K - a + 1;
+        if (sz > cap[d]) { a += (sz - cap[d]) / 2; sz = cap[d]; }
+        l[d] = a; h[d] = a + sz - K - 1;
+    }
+    int slow = 0, nv = 0;
+#pragma unroll
+    for (int v = 0; v < VPT1; ++v) {
+        if (!((valid >> v) & 1)) continue;
+        ++nv;
+        bool in = true;
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            const int i = fl[v][d] == fl[v][d] ? __float2int_rz(fl[v][d]) : 0x7fffffff;
+            in = in && i >= l[d] && i <= h[d];
+        }
+        if (!in) ++slow;
+    }
+    atomicAdd(&cnt[0], slow); atomicAdd(&cnt[1], far); atomicAdd(&cnt[2], nv);
+    __syncthreads();
+    if (tid == 0) {
+        atomicAdd(&hdr->nslow, cnt[0]); atomicAdd(&hdr->nfar, cnt[1]); atomicAdd(&hdr->nvalid, cnt[2]);
+        __threadfence();
+        if (atomicAdd(&hdr->done, 1) == (int)gridDim.x - 1) {
+            const int ns = atomicAdd(&hdr->nslow, 0), nf = atomicAdd(&hdr->nfar, 0), nn = atomicAdd(&hdr->nvalid, 0);
+            hdr->gate = ((int64_t)ns * 250 > nn && (int64_t)nf * 64 <= nn) ? 1 : 0;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
 // Host side
 // ---------------------------------------------------------------------------
 struct Workspace {
-    int *ndesc; uint2 *desc; float4 *rec; float *vals;
+    ProbeHdr *hdr; int *ndesc; uint2 *desc; float4 *rec; float *vals;
     int64_t nrec; int nbricks;
 };
 static int64_t align256(int64_t x) { return (x + 255) & ~(int64_t)255; }
@@ -703,12 +808,13 @@ static int64_t layout(const KParams &k, int B, int ntiles, int nch, void *base, 
     const int64_t nrec = (int64_t)ntiles * NS * B;
     int64_t o = 0;
     unsigned char *p = (unsigned char *)base;
+    const int64_t o_hdr = o; o += 256;                               // header and brick counters are zeroed by ONE memset
     const int64_t o_nd = o; o += align256(nbricks * 4);
     const int64_t o_desc = o; o += align256(nbricks * CAPD * 8);
     const int64_t o_rec = o; o += align256(nrec * 16);
     const int64_t o_val = o; o += align256(nrec * 4 * (nch > 1 ? nch - 1 : 0));
     if (w) {
-        w->ndesc = (int *)(p + o_nd); w->desc = (uint2 *)(p + o_desc);
+        w->hdr = (ProbeHdr *)(p + o_hdr); w->ndesc = (int *)(p + o_nd); w->desc = (uint2 *)(p + o_desc);
         w->rec = (float4 *)(p + o_rec); w->vals = (float *)(p + o_val);
         w->nrec = nrec; w->nbricks = (int)nbricks;
     }
@@ -729,7 +835,7 @@ static int tile_count(const interpol_problem *p)
 static bool owner_eligible(const interpol_problem *p, const KParams &k)
 {
     if (p->dim != 3 || p->batch > 4096) return false;
-    if (!(p->flags & INTERPOL_FLAG_BINNED_SCATTER)) return false;   // opt-in: see interpol_hip.h
+    if (!(p->flags & (INTERPOL_FLAG_BINNED_SCATTER | INTERPOL_FLAG_AUTO_SCATTER))) return false;   // see interpol_hip.h
     if (k.order[0] != k.order[1] || k.order[0] != k.order[2] || k.order[0] < 2 || k.order[0] > 3) return false;
     int64_t n = 1, nv = 1, nb = p->batch;
     for (int d = 0; d < 3; ++d) {
@@ -754,7 +860,7 @@ int64_t owner_workspace_bytes(const interpol_problem *p, const KParams &k, bool 
 namespace owner {
 template <typename T>
 static int launch_bin(const interpol_problem *p, const KParams &k, const BrickGrid &bg, const Workspace &w, const void *val, const void *grid,
-                      void *vol, hipStream_t st)
+                      void *vol, const int *gate, hipStream_t st)
 {
     const int gx = (int)p->grid_shape[0], gy = (int)p->grid_shape[1], gz = (int)p->grid_shape[2];
     const int nty = (gy + TS - 1) / TS, ntz = (gz + TS - 1) / TS;
@@ -765,7 +871,7 @@ static int launch_bin(const interpol_problem *p, const KParams &k, const BrickGr
         const int attr = big_lds<own_bin<T, KK, GM>>(sizeof(BinSmem));                                                    \
         if (attr) return attr;                                                                                          \
         hipLaunchKernelGGL((own_bin<T, KK, GM>), tgrid, dim3(NT1), sizeof(BinSmem), st, k, bg, (const T *)val, (const float *)grid, \
-                           (float *)vol, w.ndesc, w.desc, w.rec, w.vals, w.nrec, gx, gy, gz, nty, ntz, ntiles);            \
+                           (float *)vol, w.ndesc, w.desc, w.rec, w.vals, w.nrec, gx, gy, gz, nty, ntz, ntiles, gate);      \
     }
 #define IP_OWN_BY_GM(KK)                                                                                                \
     { if (k.sep == 0) IP_OWN_BIN(KK, 0) else if (k.sep == 1) IP_OWN_BIN(KK, 1) else if (k.sep == 2) IP_OWN_BIN(KK, 2) else IP_OWN_BIN(KK, 3) }
@@ -776,9 +882,11 @@ static int launch_bin(const interpol_problem *p, const KParams &k, const BrickGr
 }
 } // namespace owner
 
-// returns 1 when it took the problem, 0 to decline (workspace missing / not eligible), else an error
+// returns 1 when it took the problem, 2 when it launched itself GATED behind the roughness probe (INTERPOL_FLAG_AUTO_SCATTER:
+// the caller launches the tiled / generic scatter as well, with KParams::gate = *gate_out), 0 to decline (workspace missing /
+// not eligible), else an error
 int try_owner_push(const interpol_problem *p, const KParams &k, const void *val, const void *grid, void *vol,
-                   void *workspace, int64_t workspace_bytes, hipStream_t st)
+                   void *workspace, int64_t workspace_bytes, hipStream_t st, const int **gate_out)
 {
     using namespace owner;
     if (!workspace || !owner_eligible(p, k)) return 0;
@@ -787,20 +895,37 @@ int try_owner_push(const interpol_problem *p, const KParams &k, const void *val,
     Workspace w;
     if (layout(k, (int)p->batch, tile_count(p), nch, workspace, &w) > workspace_bytes) return 0;
     const BrickGrid bg = brick_grid(k);
-    hipError_t e = hipMemsetAsync(w.ndesc, 0, (size_t)w.nbricks * 4, st);
+    const bool gated = !(p->flags & INTERPOL_FLAG_BINNED_SCATTER);
+    // (a kernel, not hipMemsetAsync: under hipGraph capture the memset node of ROCm 7.2 was observed not to re-run on replays)
+    hipLaunchKernelGGL(own_zero, dim3((unsigned)((64 + w.nbricks + 1023) / 1024)), dim3(1024), 0, st, (int *)w.hdr, 64 + w.nbricks);
+    hipError_t e = hipGetLastError();
     if (e != hipSuccess) return (int)e;
+    const int *gate = nullptr;
+    const int B = (int)p->batch;
+    if (gated) {
+        const int gx = (int)p->grid_shape[0], gy = (int)p->grid_shape[1], gz = (int)p->grid_shape[2];
+        const int nty = (gy + TS - 1) / TS, ntz = (gz + TS - 1) / TS, ntiles = tile_count(p);
+        const long long total = (long long)ntiles * B;
+        const dim3 pgrid((unsigned)(total < NPROBE ? total : NPROBE));
+#define IP_OWN_PROBE(KK, GM) hipLaunchKernelGGL((own_probe<KK, GM>), pgrid, dim3(NT1), 0, st, k, bg, (const float *)grid, w.hdr, gx, gy, gz, nty, ntz, ntiles, B);
+#define IP_OWN_PROBE_GM(KK) { if (k.sep == 0) IP_OWN_PROBE(KK, 0) else if (k.sep == 1) IP_OWN_PROBE(KK, 1) else if (k.sep == 2) IP_OWN_PROBE(KK, 2) else IP_OWN_PROBE(KK, 3) }
+        if (k.order[0] == 3) IP_OWN_PROBE_GM(3) else IP_OWN_PROBE_GM(2)
+#undef IP_OWN_PROBE_GM
+#undef IP_OWN_PROBE
+        gate = &w.hdr->gate;
+    }
     int rc;
     switch (count_only ? INTERPOL_F32 : p->dtype) {
-    case INTERPOL_F32: rc = launch_bin<float>(p, k, bg, w, val, grid, vol, st); break;
-    case INTERPOL_BF16: rc = launch_bin<bf16_t>(p, k, bg, w, val, grid, vol, st); break;
-    case INTERPOL_F16: rc = launch_bin<f16_t>(p, k, bg, w, val, grid, vol, st); break;
+    case INTERPOL_F32: rc = launch_bin<float>(p, k, bg, w, val, grid, vol, gate, st); break;
+    case INTERPOL_BF16: rc = launch_bin<bf16_t>(p, k, bg, w, val, grid, vol, gate, st); break;
+    case INTERPOL_F16: rc = launch_bin<f16_t>(p, k, bg, w, val, grid, vol, gate, st); break;
     default: return 0;
     }
     if (rc) return rc;
     const bool shared = p->vol_stride[0] == 0 && p->batch > 1;
     const long long want = 2ll * cu_count();
-    const int B = (int)p->batch;
     for (int color = shared ? 9 : 0; color < (shared ? 10 : 9); ++color) {
+        if ((k.dbg & 1024) && color != ((k.dbg >> 11) & 15)) continue;        // (debugging: one colour only)
         long long nwork = B;
         for (int d = 0; d < 3; ++d) {
             const int c0 = color < 8 ? (color >> (2 - d)) & 1 : 0, step = color < 8 ? 2 : 1;
@@ -813,13 +938,15 @@ int try_owner_push(const interpol_problem *p, const KParams &k, const void *val,
             const int attr = big_lds<own_accumulate<KK>>(sizeof(AccSmem));                                              \
             if (attr) return attr;                                                                                      \
             hipLaunchKernelGGL((own_accumulate<KK>), agrid, dim3(NT), sizeof(AccSmem), st, k, bg, (const int *)w.ndesc,  \
-                               (const uint2 *)w.desc, (const float4 *)w.rec, (const float *)w.vals, w.nrec, (float *)vol, nch, color, B); \
+                               (const uint2 *)w.desc, (const float4 *)w.rec, (const float *)w.vals, w.nrec, (float *)vol, nch, color, B, gate); \
         }
         if (k.order[0] == 3) IP_OWN_ACC(3) else IP_OWN_ACC(2)
 #undef IP_OWN_ACC
     }
     e = hipGetLastError();
-    return e == hipSuccess ? 1 : (int)e;
+    if (e != hipSuccess) return (int)e;
+    if (gate_out) *gate_out = gate;
+    return gated ? 2 : 1;
 }
 
 } // namespace ip

@@ -25,6 +25,8 @@ FLAG_SEPARABLE_GRID = 8
 FLAG_DISPLACEMENT = 16
 FLAG_WITH_COUNT = 32
 FLAG_BINNED_SCATTER = 64
+FLAG_AUTO_SCATTER = 1 << 24
+_POISON_SCRATCH = os.environ.get("INTERPOL_POISON_SCRATCH", "0") not in ("", "0")
 FLAG_AFFINE_GRID = 128
 
 _DTYPE_CODE = {torch.float32: F32, torch.float64: F64, torch.bfloat16: BF16, torch.float16: F16}
@@ -307,8 +309,11 @@ def scatter(op, val, grid, shape, bound, order, extrapolate, flags=0, out=None, 
     from . import backend
     if backend.want_exact_scatter():
         flags |= FLAG_NO_FASTPATH                       # float atomics, like the reference's scatter_add_
-    elif backend.rough_deformations and op in ("push", "count"):
-        flags |= FLAG_BINNED_SCATTER                    # target-stationary organisation (csrc/push_binned.hip)
+    elif op in ("push", "count") and not (flags & (FLAG_NO_FASTPATH | FLAG_FORCE_TILED | FLAG_BINNED_SCATTER)) and (flags >> 8) == 0:
+        if backend.rough_deformations is None:
+            flags |= FLAG_AUTO_SCATTER                  # a probe of this call picks tiles or owner-computes (csrc/push_owner.hip)
+        elif backend.rough_deformations:
+            flags |= FLAG_BINNED_SCATTER                # owner-computes organisation, always
     dt, gdt = common_dtypes(val, grid)
     out_dt = dt
     if op == "pushgrad" and dt in (torch.bfloat16, torch.float16):
@@ -361,6 +366,8 @@ def scatter(op, val, grid, shape, bound, order, extrapolate, flags=0, out=None, 
         sbytes = max(sbytes, vol.numel() * 4)
     if sbytes > 0:
         scratch = torch.empty(sbytes, dtype=torch.uint8, device=dev)
+        if _POISON_SCRATCH:
+            scratch.fill_(0xff)                          # (debugging aid: INTERPOL_POISON_SCRATCH=1 -- the kernels must not depend on stale workspace contents)
     with torch.cuda.device(dev):
         if op == "count":
             rc = L.interpol_count(ctypes.byref(p), _ptr(grid), _ptr(vol), _ptr(scratch), sbytes, _stream(dev))

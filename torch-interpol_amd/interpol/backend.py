@@ -13,13 +13,17 @@ jitfields = False
 # reference's scatter_add_ -- two orders of magnitude slower at BASELINE config 2.
 exact_scatter = False
 
-# grid_push / grid_count of VERY rough deformations (displacements that differ by more than ~8 voxels
-# between neighbouring samples): the default scatter works on 16^3 tiles of samples whose stencils must
-# fit a 32^3 box in LDS, and slows down sharply beyond that (4x2x256^3 cubic, i.i.d. displacements of
-# sigma = 2 / 3 / 4 / 6 voxels: 3.5 / 5.0 / 8.6 / 126 ms).  `rough_deformations = True` selects the
-# target-stationary organisation (csrc/push_binned.hip) whose cost does not depend on the deformation
-# (6 - 7 ms in all those cases); it takes 24 bytes of workspace per sample point.
-rough_deformations = False
+# grid_push / grid_count: two organisations of the same scatter (same results within float32 rounding).
+#   * sample-stationary tiles (csrc/ops_tiled.hip): 16^3 tiles of samples accumulate in an LDS box that their
+#     stencils must fit (33 x 33 x 32 lattice points); fastest for smooth deformations (4x2x256^3 cubic: 2.2 ms at
+#     the identity, 3.5 ms under i.i.d. displacements of sigma = 2 voxels) and sharply slower beyond that
+#     (sigma = 3 / 4 / 6: 5.0 / 8.6 / 126 ms);
+#   * owner-computes bricks (csrc/push_owner.hip): the samples are first sorted by target brick; cost independent of
+#     the deformation (3.9 - 4.4 ms in all those cases), 16 - 20 bytes of workspace per sample point.
+# `rough_deformations = None` (default): a probe kernel inside every call examines 256 tiles of the sample grid and
+# gates the two organisations on the device (no host synchronisation, stateless, hipGraph-safe; ~50 us).
+# True: always the bricks.  False: always the tiles (no workspace is allocated).
+rough_deformations = None
 
 
 def want_exact_scatter():
