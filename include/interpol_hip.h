@@ -127,7 +127,7 @@ typedef struct interpol_problem {
  * 3-D, one order 2..3, float32 coordinates.  Needs the workspace announced by
  * interpol_scatter_workspace(); ignored (tiles / generic kernels) when it does not apply.
  *   INTERPOL_FLAG_BINNED_SCATTER: always;
- *   INTERPOL_FLAG_AUTO_SCATTER:   a probe kernel of the same call examines 256 tiles of the sample grid
+ *   INTERPOL_FLAG_AUTO_SCATTER:   a probe kernel of the same call examines 128 tiles of the sample grid
  *     and writes a device-side gate; both organisations are enqueued, each kernel reads the gate on
  *     entry and one of the two returns at once (about 50 us of empty launches).  Stateless: the choice
  *     depends on the coordinates of this call alone; safe under hipGraph capture. */

@@ -293,9 +293,7 @@ __global__ __launch_bounds__(NT1, 4) void own_bin(KParams p, BrickGrid bg, const
             __syncthreads();
         }
     }
-#ifndef IP_ABLATE
     if (direct) scatter_direct<T, K, GM>(p, val, grid, vol, b, g, tid, direct, nch);
-#endif
 }
 
 // ---------------------------------------------------------------------------
@@ -696,7 +694,7 @@ __global__ __launch_bounds__(NT, 4) void own_accumulate(KParams p, BrickGrid bg,
 // The sample-stationary tiles (ops_tiled.hip) accumulate a tile of 16^3 samples in an LDS box of at most 33 x 33 x 32
 // lattice points centred on the tile's stencils; samples outside it take a slow path, and beyond a few per cent of them the
 // kernel degrades by one to two orders of magnitude (config 2, i.i.d. noise: 3.6 / 5.0 / 8.6 / 126 ms at sigma 2 / 3 / 4 / 6,
-// where this file needs 4.1 - 4.4 ms throughout).  NPROBE tiles spread over the sample grid are examined exactly as
+// where this file needs 4.1 - 4.4 ms throughout).  128 tiles spread over the sample grid are examined exactly as
 // Box::build does it: the workgroup that finishes last writes gate = 1 (owner-computes) when more than 0.4 % of the
 // probed samples fall outside their tile's box -- and hardly any outside the binned range, where this file would fall
 // back to per-sample atomics -- else 0 (tiles).  Every scatter kernel of the call reads the word on entry: one of the two
@@ -708,7 +706,7 @@ __global__ void own_zero(int *__restrict__ p, int n)
     if (i < n) p[i] = 0;
 }
 
-constexpr int NPROBE = 256;
+constexpr int NPROBE = 128;
 struct ProbeHdr { int gate, done, nslow, nfar, nvalid, pad[3]; };
 
 template <int K, int GM>
@@ -925,7 +923,6 @@ int try_owner_push(const interpol_problem *p, const KParams &k, const void *val,
     const bool shared = p->vol_stride[0] == 0 && p->batch > 1;
     const long long want = 2ll * cu_count();
     for (int color = shared ? 9 : 0; color < (shared ? 10 : 9); ++color) {
-        if ((k.dbg & 1024) && color != ((k.dbg >> 11) & 15)) continue;        // (debugging: one colour only)
         long long nwork = B;
         for (int d = 0; d < 3; ++d) {
             const int c0 = color < 8 ? (color >> (2 - d)) & 1 : 0, step = color < 8 ? 2 : 1;

@@ -20,7 +20,7 @@ exact_scatter = False
 #     (sigma = 3 / 4 / 6: 5.0 / 8.6 / 126 ms);
 #   * owner-computes bricks (csrc/push_owner.hip): the samples are first sorted by target brick; cost independent of
 #     the deformation (3.9 - 4.4 ms in all those cases), 16 - 20 bytes of workspace per sample point.
-# `rough_deformations = None` (default): a probe kernel inside every call examines 256 tiles of the sample grid and
+# `rough_deformations = None` (default): a probe kernel inside every call examines 128 tiles of the sample grid and
 # gates the two organisations on the device (no host synchronisation, stateless, hipGraph-safe; ~50 us).
 # True: always the bricks.  False: always the tiles (no workspace is allocated).
 rough_deformations = None
