@@ -11,7 +11,12 @@
  * Conventions
  *   - plain C types only: device pointers, sizes, element strides, int codes;
  *   - the caller owns every buffer (inputs, outputs, scratch); the library
- *     never allocates, frees or retains a pointer, and keeps no global state;
+ *     never retains a pointer to them.  State: the ONLY state of the library is
+ *     the tile hand-back of csrc/defer.hip (see interpol_set_handback below):
+ *     1 KiB of pinned host memory per device on first use, and up to 16 slots
+ *     of 3 MiB of device memory per device, one per stream whose launches met
+ *     stretched tiles -- recycled least-recently-used, released by
+ *     interpol_release_stream(), freed when the library is unloaded;
  *   - kernels are enqueued asynchronously on `stream` (a hipStream_t passed as
  *     void*; NULL = the default stream); no internal synchronisation;
  *   - return value: 0 = ok, < 0 = INTERPOL_E_* (invalid argument, nothing
@@ -221,8 +226,9 @@ int interpol_push_bricks(const interpol_problem *p, const void *val, const void 
  * dtype = INTERPOL_F32, i.e. 4-byte elements; grid_dtype = INTERPOL_F32); for every sample the
  * label with the largest interpolated indicator value (> 0) under the stencil is returned, the
  * smallest such label on ties, 0 if none -- what the reference's loop over unique() computes,
- * in one pass.  Covered: all dims share one order and (order+1)^dim <= 27; otherwise
- * INTERPOL_E_ORDER (the caller keeps the loop).  Dense / separable / displacement grids. */
+ * in one pass.  Covered: all dims share one order <= 3 (stencils of up to 64 taps: beyond 27 taps a
+ * second kernel visits the distinct labels under the stencil one by one); otherwise INTERPOL_E_ORDER
+ * (the caller keeps the loop).  Dense / separable / displacement grids. */
 int interpol_pull_labels(const interpol_problem *p, const void *vol, const void *grid, void *val, void *stream);
 
 /* --- separable resampling ------------------------------------------------------
@@ -267,6 +273,27 @@ int32_t interpol_host_bound_index(int32_t bound, int32_t i, int32_t n);
 int32_t interpol_host_bound_sign(int32_t bound, int32_t i, int32_t n);
 double  interpol_host_weight(int32_t order, double x, int32_t which);
 float   interpol_host_weight_f32(int32_t order, float x, int32_t which);
+
+/* --- the tile hand-back (csrc/defer.hip): the library's only state -----------------
+ * The LDS-tiled kernels hand tiles whose stencils do not fit their LDS box back to the generic kernel of the same
+ * operator, launched right behind them on the same stream.  The two kernel families sum in different orders, so
+ * WHETHER a launch hands back shows in the last bits of the result:
+ *   INTERPOL_HANDBACK_ADAPTIVE (default): a stream hands back only after one of its recent launches met such a
+ *       tile (a flag the kernels store into pinned host memory, read without synchronisation at the next launch):
+ *       smooth workloads never pay the second kernel, but a result can depend on the history of the stream;
+ *   INTERPOL_HANDBACK_ALWAYS / _NEVER: every launch / no launch hands back: each operator is then a deterministic
+ *       function of its inputs, as the reference's gather is (nd.py:118-136).
+ * interpol_set_handback(mode) returns the previous mode (process-wide; the environment variable
+ * INTERPOL_HANDBACK = adaptive | always | never sets the initial one).
+ * interpol_release_stream(stream): the hand-back slot (3 MiB of device memory) of `stream` on the current device goes
+ * back to the pool; call it before destroying a stream that ran stretched workloads (optional: slots are recycled
+ * least-recently-used).  Returns 1 when the stream held a slot.  Thread-safe, like every entry point: launches of
+ * several host threads on one stream are serialised per stream. */
+#define INTERPOL_HANDBACK_ADAPTIVE 0
+#define INTERPOL_HANDBACK_ALWAYS   1
+#define INTERPOL_HANDBACK_NEVER    2
+int32_t interpol_set_handback(int32_t mode);
+int32_t interpol_release_stream(void *stream);
 
 int32_t     interpol_abi_version(void);
 const char *interpol_error_string(int code);

@@ -589,6 +589,90 @@ def test_hand_back_on_concurrent_streams():
             _same(a, r, 2e-5, (name, "stream", i))
 
 
+def _stretched_problem(seed, scale=2.4):
+    gen = torch.Generator().manual_seed(seed)
+    ishape, oshape = (70, 60, 80), (48, 40, 52)
+    vol = torch.randn([2, 2, *ishape], generator=gen).to(DEV)
+    base = interpol.identity_grid(oshape)[None].expand(2, *oshape, 3)
+    grid = (base * scale + 0.05 * torch.randn(base.shape, generator=gen)).contiguous().to(DEV)
+    return vol, grid
+
+
+def test_hand_back_slots_are_recycled_over_many_streams():
+    """csrc/defer.hip keeps 16 slots per device; the 17th stream takes the least recently used one.  40 streams run a stretched pull
+    one after the other in the ALWAYS mode: the 40th must still hand back -- its result is bit-identical to the first stream's
+    (tiles + generic kernel) and differs, in the last bits, from the NEVER mode (tiles alone)."""
+    from interpol import _hip
+    vol, grid = _stretched_problem(11)
+    b, o = [3] * 3, [3] * 3
+    prev = _hip.set_handback("never")
+    try:
+        plain = _hip.gather("pull", vol, grid, b, o, 1)
+        _hip.set_handback("always")
+        outs = []
+        streams = [torch.cuda.Stream() for _ in range(40)]
+        torch.cuda.synchronize()
+        for st in streams:
+            with torch.cuda.stream(st):
+                outs.append(_hip.gather("pull", vol, grid, b, o, 1))
+        torch.cuda.synchronize()
+        ref = _hip.gather("pull", vol, grid, b, o, 1, flags=_hip.FLAG_NO_FASTPATH)
+        for i, out in enumerate(outs):
+            _same(out, ref, 1e-5, ("stream", i))
+            assert torch.equal(out, outs[0]), ("stream %d does not hand back like stream 0" % i)
+        assert not torch.equal(outs[0], plain), "the stretched problem was expected to hand tiles back"
+        assert _hip.release_stream(streams[-1]) and not _hip.release_stream(streams[-1])
+    finally:
+        _hip.set_handback(prev)
+
+
+@pytest.mark.parametrize("mode", ["always", "never"])
+def test_pinned_hand_back_mode_is_history_independent(mode):
+    """In the ALWAYS / NEVER modes every operator is a deterministic function of its inputs (the reference's gather is:
+    nd.py:118-136): the same stretched pull before and after a run of smooth launches on the same stream is torch.equal."""
+    from interpol import _hip
+    vol, grid = _stretched_problem(12)
+    smooth = _stretched_problem(13, scale=1.0)[1]
+    b, o = [3] * 3, [3] * 3
+    prev = _hip.set_handback(mode)
+    try:
+        first = _hip.gather("pull", vol, grid, b, o, 1)
+        for _ in range(12):
+            _hip.gather("pull", vol, smooth, b, o, 1)
+        again = _hip.gather("pull", vol, grid, b, o, 1)
+        assert torch.equal(first, again)
+    finally:
+        _hip.set_handback(prev)
+
+
+def test_hand_back_two_host_threads_on_one_stream():
+    """Two host threads launch stretched workloads on the SAME stream: the slot's lease keeps each tile kernel and its deferred
+    generic kernel together (interleaved, the second launch's descriptors would hide the first's: tiles silently skipped)."""
+    import threading
+    from interpol import _hip
+    probs = [_stretched_problem(21 + i, scale=2.0 + 0.3 * i) for i in range(2)]
+    b, o = [3] * 3, [3] * 3
+    refs = [_hip.gather("pull", v, g, b, o, 1, flags=_hip.FLAG_NO_FASTPATH) for v, g in probs]
+    prev = _hip.set_handback("always")
+    stream = torch.cuda.Stream()
+    errs = []
+    def worker(i):
+        try:
+            with torch.cuda.stream(stream):
+                for _ in range(25):
+                    out = _hip.gather("pull", probs[i][0], probs[i][1], b, o, 1)
+                stream.synchronize()
+                _same(out, refs[i], 1e-5, ("thread", i))
+        except Exception as e:          # noqa: BLE001
+            errs.append(e)
+    try:
+        ts = [threading.Thread(target=worker, args=(i,)) for i in range(2)]
+        [t.start() for t in ts]; [t.join() for t in ts]
+        assert not errs, errs
+    finally:
+        _hip.set_handback(prev)
+
+
 def test_graph_capture_replays_correctly():
     """hipGraph capture of the operators (launch-bound inner loops, the system prompt's HIP graphs): everything is enqueued
     on the capturing stream, nothing synchronises, and the tile hand-back -- whose descriptors carry a per-launch number that

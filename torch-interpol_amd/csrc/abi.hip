@@ -11,6 +11,7 @@
 #include "../../include/interpol_hip.h"
 #include "stencil.hpp"
 #include "filter_params.hpp"
+#include "defer.hpp"
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <string.h>
@@ -669,6 +670,9 @@ float interpol_host_weight_f32(int32_t order, float x, int32_t which)
 {
     return which == 0 ? bspline_w<float>(order, x) : (which == 1 ? bspline_g<float>(order, x) : bspline_h<float>(order, x));
 }
+
+int32_t interpol_set_handback(int32_t mode) { return defer_set_mode(mode); }
+int32_t interpol_release_stream(void *stream) { return defer_release_stream((hipStream_t)stream); }
 
 const char *interpol_kernel_name(const interpol_problem *p, const char *op)
 {

@@ -3,13 +3,20 @@
 // generic kernels restricted to the handed-back tiles (ops_instantiate.inc, IP_DEFER).
 // ===========================================================================
 #pragma once
+#include "../../include/interpol_hip.h"
 #include "stencil.hpp"
 #include <hip/hip_runtime.h>
 
 namespace ip {
 
-// the descriptor list of this stream for a launch of `nwork` work items (desc == NULL: no hand-back), stamped with a fresh launch number
-DeferArgs defer_buffer(hipStream_t st, int64_t nwork, int64_t batch, int ntx, int nty, int ntz);
+// The descriptor list of this stream for a launch of `nwork` work items (args.desc == NULL: no hand-back), stamped with a
+// fresh launch number, and the LEASE of the stream's slot (slot >= 0): nobody else launches through the slot until
+// defer_release() -- call it once the deferred kernel is enqueued (struct Defer below does, in its destructor).
+struct DeferLease { DeferArgs args; int dev, slot; };
+DeferLease defer_acquire(hipStream_t st, int64_t nwork, int64_t batch, int ntx, int nty, int ntz);
+void defer_release(const DeferLease &lease, hipStream_t st);
+int defer_set_mode(int mode);                  // INTERPOL_HANDBACK_*; returns the previous mode
+int defer_release_stream(hipStream_t st);      // 1: the stream held a slot and gave it back
 
 #define IP_DEFER_DECL(sfx) \
 int launch_pull_deferred_##sfx(const KParams &p, const void *vol, const void *grid, void *val, const TileList &tl, hipStream_t st); \
@@ -41,13 +48,19 @@ struct Defer {
     unsigned long long *desc;
     DeferArgs args;
     TileList tl;
+    DeferLease lease;
+    hipStream_t stream;
     // nwork = ntiles * batch work items of tiles ex x ey x ez (kernel dims x, y, z: the LAST dims of the problem)
-    Defer(const KParams &k, hipStream_t st, int64_t ntiles, int64_t batch, int ntx, int nty, int ntz, int ex, int ey, int ez)
+    Defer(const KParams &k, hipStream_t st, int64_t ntiles, int64_t batch, int ntx, int nty, int ntz, int ex, int ey, int ez) : stream(st)
     {
-        args = (k.dbg & 256) ? DeferArgs{ nullptr, nullptr, nullptr, 0u } : defer_buffer(st, ntiles * batch, batch, ntx, nty, ntz);     // dbg 256: A/B switch, no hand-back
+        lease = (k.dbg & 256) ? DeferLease{ { nullptr, nullptr, nullptr, 0u }, -1, -1 } : defer_acquire(st, ntiles * batch, batch, ntx, nty, ntz);     // dbg 256: A/B switch, no hand-back
+        args = lease.args;
         desc = args.desc;
         tl.desc = desc; tl.gen = args.gen; tl.cur = args.cur; tl.nwork = (int)(ntiles * batch); tl.e[0] = ex; tl.e[1] = ey; tl.e[2] = ez;
     }
+    ~Defer() { defer_release(lease, stream); }
+    Defer(const Defer &) = delete;
+    Defer &operator=(const Defer &) = delete;
     // push / count / push + count (k.cc) of the handed-back tiles into the float accumulator `acc`; val == NULL: count
     template <typename T> int push(const KParams &k, const void *val, const void *grid, void *acc, hipStream_t st) const
     {

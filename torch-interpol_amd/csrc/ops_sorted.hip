@@ -223,16 +223,19 @@ struct Tile {
             if (in) fastmask |= 1u << v;
             rk[v] = atomicAdd(&sm.cnt[in ? (yz & (NCLS - 1)) : NCLS], 1);
         }
-        if ((validmask & ~fastmask) != 0) {                          // (rare) out-of-box samples: slow list
+        const unsigned oob = validmask & ~fastmask;
+        if (oob != 0) {                                              // (rare) out-of-box samples: slow list
 #pragma unroll
             for (int v = 0; v < VPT; ++v) {
-                if (!(((validmask & ~fastmask) >> v) & 1)) continue;
+                if (!((oob >> v) & 1)) continue;
                 const int slot = atomicAdd(&sm.nslow, 1);
                 if (slot < SLOWCAP) sm.slow[slot] = (unsigned short)(tid + NT * v);
-                else selfmask |= 1u << v;
             }
         }
         __syncthreads();
+        // a slow list that overflows is not used at all: every out-of-box sample is then left to its thread -- WHICH samples
+        // made it into the list would depend on the order of the atomics, and the two paths sum in different orders
+        if (sm.nslow > SLOWCAP) selfmask |= oob;
         prof_mark(6);
         // holes and surplus: class q offers max(0, NSLOT - cnt) holes and has max(0, cnt - NSLOT) surplus samples
         const int q_l = tid & 31;
@@ -325,7 +328,7 @@ __global__ __launch_bounds__(NT, 4) void pull_sorted(KParams p, const T *__restr
         float cnext[VPT][3];
         Tile<K, GM>::load(p, grid, b, g, tid, cnext);
         tl.build(p, L, g, sm, tid, cnext);
-        const int nslow = sm.nslow < SLOWCAP ? sm.nslow : SLOWCAP;
+        const int nslow = sm.nslow <= SLOWCAP ? sm.nslow : 0;       // (an overflowing list is not used: Tile::build)
         if (defer.flag) {                                                 // (block-uniform) too rough for the box: the generic kernel takes the tile, defer.hip
             bool hand_back = sm.nslow > (HANDBACK << ((p.dbg >> 9) & 7));
             if (hand_back) hand_back = tiled::tile_smooth(p, grid, b, 3, g.ox0, g.oy0, g.oz0, TS, TS, TS, g.gx, g.gy, g.gz, sm.hi);
@@ -560,7 +563,7 @@ __global__ __launch_bounds__(NT, 4) void gradc_sorted(KParams p, const T *__rest
         float cnext[VPT][3];
         Tile<K, GM>::load(p, grid, b, g, tid, cnext);
         tl.build(p, L, g, sm, tid, cnext);
-        const int nslow = sm.nslow < SLOWCAP ? sm.nslow : SLOWCAP;
+        const int nslow = sm.nslow <= SLOWCAP ? sm.nslow : 0;       // (an overflowing list is not used: Tile::build)
         if (defer.flag) {                                                 // (block-uniform) too rough for the box: the generic kernel takes the tile, defer.hip
             bool hand_back = sm.nslow > (HANDBACK << ((p.dbg >> 9) & 7));
             if (hand_back) hand_back = tiled::tile_smooth(p, grid, b, 3, g.ox0, g.oy0, g.oz0, TS, TS, TS, g.gx, g.gy, g.gz, sm.hi);
@@ -867,7 +870,7 @@ __global__ __launch_bounds__(NT, 4) void push_sorted(KParams p, const T *__restr
         Tile<K, GM> tl;
         Tile<K, GM>::load(p, grid, b, g, tid, cnext);
         tl.build(p, L, g, sm, tid, cnext);
-        const int nslow = sm.nslow < SLOWCAP ? sm.nslow : SLOWCAP;
+        const int nslow = sm.nslow <= SLOWCAP ? sm.nslow : 0;       // (an overflowing list is not used: Tile::build)
         if (defer.flag) {                                                 // (block-uniform) too rough for the box: the generic kernel takes the tile, defer.hip
             bool hand_back = sm.nslow > ((3 * HANDBACK / 2) << ((p.dbg >> 9) & 7));   // scatter: 3/16 of the samples, see tiled::hand_back
             if (hand_back) hand_back = tiled::tile_smooth(p, grid, b, 3, g.ox0, g.oy0, g.oz0, TS, TS, TS, g.gx, g.gy, g.gz, sm.hi);

@@ -39,6 +39,7 @@ SYMBOLS = (
     "interpol_push_bricks", "interpol_push_bricks_workspace", "interpol_host_bound_index", "interpol_host_bound_sign",
     "interpol_host_weight", "interpol_host_weight_f32", "interpol_abi_version",
     "interpol_error_string", "interpol_kernel_name", "interpol_scatter_workspace",
+    "interpol_set_handback", "interpol_release_stream",
 )
 
 
@@ -101,6 +102,10 @@ def lib():
     L.interpol_push_bricks_workspace.restype = i64
     L.interpol_scatter_workspace.argtypes = [pp, i32]
     L.interpol_scatter_workspace.restype = i64
+    L.interpol_set_handback.argtypes = [i32]
+    L.interpol_set_handback.restype = i32
+    L.interpol_release_stream.argtypes = [ctypes.c_void_p]
+    L.interpol_release_stream.restype = i32
     L.interpol_resample_1d.argtypes = [i32, i32, i32, i32, i32, i32, i32, i64, i64, i64, i64, vp, vp, vp, vp]
     for name in ("interpol_pull", "interpol_grad", "interpol_hess", "interpol_push", "interpol_pushgrad",
                  "interpol_count", "interpol_pull_backward", "interpol_push_backward",
@@ -617,3 +622,22 @@ def push_bricks(val, grid, shape, bound, order, extrapolate, flags=0, out=None, 
         rc = L.interpol_push_bricks(ctypes.byref(p), _ptr(val), _ptr(grid), _ptr(vol), _ptr(work), int(nbytes), _stream(dev))
     _check(rc, "interpol_push_bricks")
     return vol
+
+
+HANDBACK_MODES = {"adaptive": 0, "always": 1, "never": 2}
+
+
+def set_handback(mode):
+    """Tile hand-back policy of the library (include/interpol_hip.h, interpol_set_handback): 'adaptive' (default: per
+    stream, from the flags of its recent launches -- results may differ in the last bits with the stream's history),
+    'always' or 'never' (every operator is then a deterministic function of its inputs).  Returns the previous mode."""
+    code = HANDBACK_MODES[mode] if isinstance(mode, str) else int(mode)
+    prev = int(lib().interpol_set_handback(code))
+    return {v: k for k, v in HANDBACK_MODES.items()}.get(prev, prev)
+
+
+def release_stream(stream=None):
+    """Give the hand-back slot of `stream` (a torch.cuda.Stream; default: the current one) back to the library."""
+    st = torch.cuda.current_stream() if stream is None else stream
+    with torch.cuda.device(st.device):
+        return bool(lib().interpol_release_stream(ctypes.c_void_p(st.cuda_stream)))
