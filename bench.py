@@ -35,11 +35,12 @@ HBM_PEAK_GBS = 8000.0            # MI355X HBM3E spec peak (MI355X_MICROARCH.md);
 
 
 def make_inputs(B, C, n, sigma, device, seed):
-    """SURVEY 8d generator: inp = randn, grid = identity + sigma * randn (voxels)."""
+    """SURVEY 8d generator: `torch.manual_seed(seed)` on the CPU, inp = randn, grid = identity + sigma * randn (voxels),
+    then moved to the device -- the inputs the CPU baseline of the reference was timed on."""
     import interpol
-    g = torch.Generator(device=device).manual_seed(seed)
-    inp = torch.randn([B, C, n, n, n], generator=g, device=device, dtype=torch.float32)
-    grid = torch.randn([B, n, n, n, 3], generator=g, device=device, dtype=torch.float32).mul_(sigma)
+    g = torch.Generator().manual_seed(seed)
+    inp = torch.randn([B, C, n, n, n], generator=g, dtype=torch.float32).to(device)
+    grid = torch.randn([B, n, n, n, 3], generator=g, dtype=torch.float32).mul_(sigma).to(device)
     grid += interpol.identity_grid([n, n, n], dtype=torch.float32, device=device)
     return inp, grid
 

@@ -45,11 +45,23 @@ def _worker(rank, world, port, tmp):
         a, b_ = slab_range(one_grid, rank, world)
         local = grid_pull_slabs(one_inp, one_grid, gather=False, interpolation=3, bound="dct2", extrapolate=True)
         assert local.shape[2] == b_ - a
+        # slabs of unequal length (5 rows over 2 ranks): padded all_gather
+        odd_grid = grid[:1, :5] * 0.4
+        odd = grid_pull_slabs(one_inp, odd_grid, interpolation=3, bound="dct2", extrapolate=True)
+        # grid_push of ONE volume over slabs of the source lattice (+ the count image), summed over the ranks;
+        # the same with the reduce-scatter switch set (gloo keeps the all_reduce: control flow only)
+        from interpol.distributed import grid_push_slabs
+        pslab, cslab = grid_push_slabs(inp[:1, :, :5], grid[:1, :5], [m, m, m], interpolation=3, bound="replicate",
+                                       extrapolate=True, with_count=True)
+        os.environ["INTERPOL_REDUCE"] = "reduce_scatter"
+        pslab2 = grid_push_slabs(inp[0, :, :5], grid[0, :5], [m, m, m], interpolation=3, bound="replicate", extrapolate=True)
+        del os.environ["INTERPOL_REDUCE"]
     gathered = [None] * world
     dist.all_gather_object(gathered, pulled.numpy())
     if rank == 0:
         np.savez(tmp, push=push.numpy(), count=count.numpy(), pulled=np.concatenate(gathered, 0),
-                 inp=inp.numpy(), grid=grid.numpy(), slab=slab.numpy(), one_grid=one_grid.numpy())
+                 inp=inp.numpy(), grid=grid.numpy(), slab=slab.numpy(), one_grid=one_grid.numpy(),
+                 odd=odd.numpy(), odd_grid=odd_grid.numpy(), pslab=pslab.numpy(), cslab=cslab.numpy(), pslab2=pslab2.numpy())
     if rank == 1:
         np.savez(tmp + ".dst", push=p2.numpy(), count=c2.numpy())
     dist.barrier()
@@ -100,6 +112,13 @@ def test_push_count_shared_gloo_world2(tmp_path):
     assert np.array_equal(r["pulled"], want_pull)          # batch sharding == full-batch result
     want_slab = np.asarray(oracle.grid_pull(r["inp"][:1], r["one_grid"], [3], [3], 1))
     assert np.array_equal(r["slab"], want_slab)            # output-grid slabs == unsharded result, bit for bit
+    want_odd = np.asarray(oracle.grid_pull(r["inp"][:1], r["odd_grid"], [3], [3], 1))
+    assert np.array_equal(r["odd"], want_odd)              # unequal slabs (3 + 2 rows)
+    want_ps = np.asarray(oracle.grid_push(r["inp"][:1, :, :5], r["grid"][:1, :5], [m, m, m], [1], [3], 1))[0]
+    want_cs = np.asarray(oracle.grid_count(r["grid"][:1, :5], [m, m, m], [1], [3], 1))[0]
+    assert np.abs(r["pslab"] - want_ps).max() < 1e-12 * np.abs(want_ps).max()      # source-lattice slabs of one volume
+    assert np.abs(r["cslab"] - want_cs).max() < 1e-12 * np.abs(want_cs).max()
+    assert np.abs(r["pslab2"] - want_ps).max() < 1e-12 * np.abs(want_ps).max()
     d = np.load(tmp + ".dst.npz")
     assert np.abs(d["push"] - want_push).max() < 1e-12 * np.abs(want_push).max()
     assert np.abs(d["count"] - want_count).max() < 1e-12 * np.abs(want_count).max()

@@ -87,16 +87,22 @@ def test_alias_tables():
         bound_to_nitorch(7)
 
 
-def test_cpu_tensors_are_refused_loudly():
+def test_hip_layer_refuses_cpu_tensors_loudly():
+    """The C-ABI layer has no CPU path and says so; the public API serves CPU tensors through the product's own PyTorch
+    restatement instead (interpol/torch_kernels.py, tests/test_torch_kernels.py) -- never through a silent fallback of the
+    GPU path: CUDA tensors of 1-3 spatial dims always go to libinterpol_hip.so (ops.kernels)."""
     x, g = torch.randn(1, 1, 4, 4), torch.rand(1, 4, 4, 2)
     with pytest.raises(RuntimeError, match="no CPU path"):
-        interpol.grid_pull(x, g)
+        _hip.gather("pull", x, g, [1, 1], [1, 1], 1)
     with pytest.raises(RuntimeError, match="no CPU path"):
-        interpol.grid_push(x, g)
+        _hip.scatter("push", x, g, None, [1, 1], [1, 1], 1)
     with pytest.raises(RuntimeError, match="no CPU path"):
-        interpol.grid_count(g)
+        _hip.scatter("count", None, g, None, [1, 1], [1, 1], 1)
     with pytest.raises(RuntimeError, match="no CPU path"):
-        interpol.spline_coeff_nd(x, 3)
+        _hip.spline_filter_(x.clone(), 3, 3, -1)
+    from interpol.torch_kernels import TorchKernels
+    assert ops.kernels(x, g, dim=2) is TorchKernels
+    assert ops.kernels(dim=2) is ops._HipKernels and ops.kernels(dim=4) is TorchKernels
 
 
 def test_api_shape_conventions():

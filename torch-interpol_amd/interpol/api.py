@@ -92,7 +92,7 @@ def grid_pull(input, grid, interpolation='linear', bound='zero', extrapolate=Fal
 
     if not input.dtype.is_floating_point:
         codes = [order_to_code(o) for o in (interpolation if isinstance(interpolation, (list, tuple)) else [interpolation])]
-        fused = (grid.dtype == torch.float32 and ops.labels_covered(dim, codes)
+        fused = (grid.dtype == torch.float32 and ops.labels_covered(dim, codes, input, grid)
                  and (not prefilter or max(pad_codes(codes, dim)) <= 1)          # order <= 1: the prefilter is the identity
                  and (input.dtype in (torch.bool, torch.uint8, torch.int8, torch.int16, torch.int32)
                       or (input.dtype == torch.int64 and (input.numel() == 0 or int(input.abs().max()) < 2 ** 31))))

@@ -20,12 +20,12 @@ def _spline_coeff(inp, bound, order, dim=-1, inplace=False):
     if inp.dim() == 0:
         return inp if inplace else inp.clone()
     if inplace and inp.is_contiguous():
-        out = ops.kernels().spline_filter_(inp, bound, order, dim)
+        out = ops.kernels(inp).spline_filter_(inp, bound, order, dim)
     elif inp.is_contiguous():
         # out of place: the kernel reads `inp` and writes the result (no copy first)
-        out = ops.kernels().spline_filter_(inp.new_empty(inp.shape), bound, order, dim, src=inp)
+        out = ops.kernels(inp).spline_filter_(inp.new_empty(inp.shape), bound, order, dim, src=inp)
     else:
-        out = ops.kernels().spline_filter_(inp.contiguous(), bound, order, dim)
+        out = ops.kernels(inp).spline_filter_(inp.contiguous(), bound, order, dim)
     if inplace and out is not inp:
         inp.copy_(out)
         return inp
@@ -53,7 +53,7 @@ def _spline_coeff_nd(inp, bound, order, dim=None, inplace=False):
     else:
         out, src = (inp.contiguous() if not inp.is_contiguous() else inp.clone()), None
     for d, b, o in todo:
-        ops.kernels().spline_filter_(out, b, o, -dim + d, src=src)
+        ops.kernels(out).spline_filter_(out, b, o, -dim + d, src=src)
         src = None
     if inplace and out is not inp:
         inp.copy_(out)

@@ -53,14 +53,86 @@ def grid_pull_slabs(input, grid, rank=None, world_size=None, group=None, gather=
     if not gather or world_size == 1:
         return local
     od = local.dim() - grid.shape[-1]                    # the same axis in the output
-    sizes = [shard_range(grid.shape[sd], r, world_size) for r in range(world_size)]
-    parts = [local.new_empty(list(local.shape[:od]) + [b - a] + list(local.shape[od + 1:])) for a, b in sizes]
-    dist.all_gather(parts, local.contiguous(), group=group)
-    return torch.cat(parts, od)
+    return _gather_slabs(local, od, grid.shape[sd], world_size, group)
+
+
+def _gather_slabs(local, axis, n, world_size, group):
+    """all_gather of slabs that may differ in length by one row (n not divisible by the world size): gloo, and older
+    RCCL builds, need equal sizes, so every slab travels padded to ceil(n / world) rows and is trimmed on arrival."""
+    dist = torch.distributed
+    rows = -(-n // world_size)
+    shape = list(local.shape)
+    mine = shape[axis]
+    if mine < rows:
+        shape[axis] = rows - mine
+        local = torch.cat([local, local.new_zeros(shape)], axis)
+    local = local.contiguous()
+    parts = [torch.empty_like(local) for _ in range(world_size)]
+    dist.all_gather(parts, local, group=group)
+    sizes = [shard_range(n, r, world_size) for r in range(world_size)]
+    return torch.cat([p.narrow(axis, 0, b - a) for p, (a, b) in zip(parts, sizes)], axis)
+
+
+def grid_push_slabs(input, grid, shape=None, rank=None, world_size=None, group=None, reduce='all', dst=0,
+                    with_count=False, **kw):
+    """grid_push (and, `with_count=True`, grid_count) of ONE volume (B = 1) sharded over axis 0 of the SOURCE lattice:
+    each rank splats its slab of `input` / `grid` into a private full-size target and the targets are summed over the
+    ranks (`reduce` as in `push_count_shared`).  Every source point is independent (reference interpol/nd.py:146-213),
+    so the sum equals the unsharded `grid_push(input, grid, shape)` up to the order of the float additions.
+    input : (1, C, *inshape) or (C, *inshape)     grid : (1, *inshape, D) or (*inshape, D)
+    Returns push (C, *shape), or (push, count) with `with_count=True`."""
+    dist = torch.distributed
+    if rank is None:
+        rank = dist.get_rank(group) if dist.is_initialized() else 0
+    if world_size is None:
+        world_size = dist.get_world_size(group) if dist.is_initialized() else 1
+    dim = grid.shape[-1]
+    if grid.dim() == dim + 1:
+        grid = grid[None]
+    if input.dim() == dim + 1:
+        input = input[None]
+    if grid.shape[0] != 1 or input.shape[0] != 1:
+        raise ValueError('grid_push_slabs shards ONE volume; batches shard over the batch axis (shard_range)')
+    if shape is None:
+        shape = list(grid.shape[1:-1])
+    lo, hi = shard_range(grid.shape[1], rank, world_size)
+    push, count = push_count_shared(input[:, :, lo:hi], grid[:, lo:hi], shape, group=group, reduce=reduce, dst=dst,
+                                    with_count=with_count, **kw)
+    return (push, count) if with_count else push
 
 
 def _as_list(x):
     return list(x) if isinstance(x, (list, tuple)) else [x]
+
+
+def _reduce_scatter_wanted():
+    """INTERPOL_REDUCE=reduce_scatter: the shared-target sum as ONE reduce-scatter + ONE all-gather instead of the
+    library's all_reduce (on the xGMI full mesh of an MI355X node every rank then exchanges 1/world of the
+    1 GB buffer with every peer directly -- 7 links busy -- where a ring is bound by one link).  A switch, so that both
+    can be timed on an 8-GPU node (`bench.py --config 4`)."""
+    import os
+    return os.environ.get('INTERPOL_REDUCE', 'all_reduce').lower() in ('reduce_scatter', 'rs')
+
+
+def _all_reduce_by_reduce_scatter(buf, group):
+    dist = torch.distributed
+    if dist.get_backend(group) == 'gloo':                   # (gloo has no reduce_scatter: the CPU dry runs keep the all_reduce)
+        dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group)
+        return
+    world = dist.get_world_size(group)
+    flat = buf.view(-1)
+    n = flat.numel()
+    per = -(-n // world)
+    if per * world != n:                                    # equal chunks: pad the tail
+        work = flat.new_zeros(per * world)
+        work[:n] = flat
+    else:
+        work = flat
+    mine = torch.empty(per, dtype=flat.dtype, device=flat.device)
+    dist.reduce_scatter_tensor(mine, work, op=dist.ReduceOp.SUM, group=group)
+    dist.all_gather_into_tensor(work, mine, group=group)
+    if work is not flat:
+        flat.copy_(work[:n])
 
 
 def push_count_shared(input, grid, shape, interpolation='linear', bound='zero', extrapolate=False,
@@ -95,7 +167,7 @@ def push_count_shared(input, grid, shape, interpolation='linear', bound='zero', 
         raise ValueError('push_count_shared accumulates in the target: use a float32 / float64 image (low-precision targets cannot accumulate)')
     # push and count share one buffer -> one collective message
     buf = torch.zeros([1, nch] + shape, dtype=dtype, device=grid.device)
-    k = ops.kernels()
+    k = ops.kernels(input, grid, dim=dim)
     if grid.shape[0] > 0:
         if input is not None and with_count:
             k.push_shared_(buf, input, grid, b, o, ex, with_count=True)    # values and count in one pass over the grid
@@ -104,7 +176,9 @@ def push_count_shared(input, grid, shape, interpolation='linear', bound='zero', 
         else:
             k.push_shared_(buf[:, C:], None, grid, b, o, ex)
     if reduce != 'none' and torch.distributed.is_available() and torch.distributed.is_initialized():
-        if reduce == 'all':
+        if reduce == 'all' and _reduce_scatter_wanted():
+            _all_reduce_by_reduce_scatter(buf, group)
+        elif reduce == 'all':
             torch.distributed.all_reduce(buf, op=torch.distributed.ReduceOp.SUM, group=group)
         elif reduce == 'dst':
             torch.distributed.reduce(buf, dst=dst, op=torch.distributed.ReduceOp.SUM, group=group)

@@ -136,8 +136,22 @@ def use_kernels(table):
         _kernels = old
 
 
-def kernels():
-    return _kernels
+def kernels(*tensors, dim=None):
+    """The kernel table that serves these tensors: the HIP library for CUDA tensors of 1-3 spatial dims (it raises when
+    libinterpol_hip.so is missing: there is no silent fallback on the GPU), the device-generic PyTorch restatement
+    (interpol/torch_kernels.py) for what the library does not cover -- CPU tensors and D > 3, which the reference's nd
+    path accepts (pushpull.py:49-66).  A table installed with `use_kernels` (tests) always wins."""
+    if _kernels is not _HipKernels:
+        return _kernels
+    on_gpu = True
+    for t in tensors:
+        dev = getattr(t, 'device', None)
+        if dev is not None and torch.device(dev).type != 'cuda':
+            on_gpu = False
+    if on_gpu and (dim is None or dim <= 3):
+        return _HipKernels
+    from .torch_kernels import TorchKernels
+    return TorchKernels
 
 
 def _codes(grid, bound, interpolation):
@@ -156,7 +170,7 @@ def _check_push_shapes(inp, grid, trailing=0):
 def grid_pull(inp, grid, bound, interpolation, extrapolate, displacement=False):
     """(B,C,*in), (B,*out,D) -> (B,C,*out).   Reference pushpull.py:35-66."""
     bound, interpolation = _codes(grid, bound, interpolation)
-    return _kernels.pull(inp, grid, bound, interpolation, int(extrapolate), **_kw(displacement))
+    return kernels(inp, grid, dim=grid.shape[-1]).pull(inp, grid, bound, interpolation, int(extrapolate), **_kw(displacement))
 
 
 def grid_push(inp, grid, shape, bound, interpolation, extrapolate, displacement=False):
@@ -164,20 +178,20 @@ def grid_push(inp, grid, shape, bound, interpolation, extrapolate, displacement=
     bound, interpolation = _codes(grid, bound, interpolation)
     _check_push_shapes(inp, grid)
     shape = None if shape is None else list(shape)
-    return _kernels.push(inp, grid, shape, bound, interpolation, int(extrapolate), **_kw(displacement))
+    return kernels(inp, grid, dim=grid.shape[-1]).push(inp, grid, shape, bound, interpolation, int(extrapolate), **_kw(displacement))
 
 
 def grid_count(grid, shape, bound, interpolation, extrapolate, displacement=False):
     """(B,*in,D) -> (B,1,*shape).   Reference pushpull.py:106-142."""
     bound, interpolation = _codes(grid, bound, interpolation)
     shape = None if shape is None else list(shape)
-    return _kernels.count(grid, shape, bound, interpolation, int(extrapolate), **_kw(displacement))
+    return kernels(grid, dim=grid.shape[-1]).count(grid, shape, bound, interpolation, int(extrapolate), **_kw(displacement))
 
 
 def grid_grad(inp, grid, bound, interpolation, extrapolate, displacement=False):
     """(B,C,*in), (B,*out,D) -> (B,C,*out,D).   Reference pushpull.py:146-172."""
     bound, interpolation = _codes(grid, bound, interpolation)
-    return _kernels.grad(inp, grid, bound, interpolation, int(extrapolate), **_kw(displacement))
+    return kernels(inp, grid, dim=grid.shape[-1]).grad(inp, grid, bound, interpolation, int(extrapolate), **_kw(displacement))
 
 
 def grid_pushgrad(inp, grid, shape, bound, interpolation, extrapolate, displacement=False):
@@ -185,13 +199,13 @@ def grid_pushgrad(inp, grid, shape, bound, interpolation, extrapolate, displacem
     bound, interpolation = _codes(grid, bound, interpolation)
     _check_push_shapes(inp, grid, trailing=1)
     shape = None if shape is None else list(shape)
-    return _kernels.pushgrad(inp, grid, shape, bound, interpolation, int(extrapolate), **_kw(displacement))
+    return kernels(inp, grid, dim=grid.shape[-1]).pushgrad(inp, grid, shape, bound, interpolation, int(extrapolate), **_kw(displacement))
 
 
 def grid_hess(inp, grid, bound, interpolation, extrapolate, displacement=False):
     """(B,C,*in), (B,*out,D) -> (B,C,*out,D,D).   Reference pushpull.py:207-233."""
     bound, interpolation = _codes(grid, bound, interpolation)
-    return _kernels.hess(inp, grid, bound, interpolation, int(extrapolate), **_kw(displacement))
+    return kernels(inp, grid, dim=grid.shape[-1]).hess(inp, grid, bound, interpolation, int(extrapolate), **_kw(displacement))
 
 
 def grid_pull_backward(grad, inp, grid, bound, interpolation, extrapolate,
@@ -204,7 +218,7 @@ def grid_pull_backward(grad, inp, grid, bound, interpolation, extrapolate,
     need_grid = grid.requires_grad if need_grid is None else need_grid
     if not (need_inp or need_grid):
         return None, None
-    return _kernels.pull_backward(grad, inp, grid, bound, interpolation, int(extrapolate), need_inp, need_grid,
+    return kernels(grad, inp, grid, dim=grid.shape[-1]).pull_backward(grad, inp, grid, bound, interpolation, int(extrapolate), need_inp, need_grid,
                                   **_kw(displacement))
 
 
@@ -217,7 +231,7 @@ def grid_push_backward(grad, inp, grid, bound, interpolation, extrapolate,
     need_grid = grid.requires_grad if need_grid is None else need_grid
     if not (need_inp or need_grid):
         return None, None
-    return _kernels.push_backward(grad, inp, grid, bound, interpolation, int(extrapolate), need_inp, need_grid,
+    return kernels(grad, inp, grid, dim=grid.shape[-1]).push_backward(grad, inp, grid, bound, interpolation, int(extrapolate), need_inp, need_grid,
                                   **_kw(displacement))
 
 
@@ -227,7 +241,7 @@ def grid_count_backward(grad, grid, bound, interpolation, extrapolate, need_grid
     need_grid = grid.requires_grad if need_grid is None else need_grid
     if not need_grid:
         return None
-    return _kernels.count_backward(grad, grid, bound, interpolation, int(extrapolate), **_kw(displacement))
+    return kernels(grad, grid, dim=grid.shape[-1]).count_backward(grad, grid, bound, interpolation, int(extrapolate), **_kw(displacement))
 
 
 def grid_grad_backward(grad, inp, grid, bound, interpolation, extrapolate,
@@ -249,11 +263,13 @@ def grid_grad_backward(grad, inp, grid, bound, interpolation, extrapolate,
 def resample1d(src, lin, dim, order, bound, extrapolate, mode, adjoint=False, n_lattice=None):
     """One 1-D pass of a tensor-product resampling along `dim` (see `separable.py`):
     forward = pull along that dim at coordinates `lin`, adjoint = the matching push."""
-    return _kernels.resample1d(src, lin, dim, int(order), int(bound), int(extrapolate), int(mode), bool(adjoint), n_lattice)
+    return kernels(src, lin).resample1d(src, lin, dim, int(order), int(bound), int(extrapolate), int(mode), bool(adjoint), n_lattice)
 
 
-def labels_covered(dim, interpolation):
+def labels_covered(dim, interpolation, *tensors):
     """Can `grid_pull_labels` serve this stencil (else the caller loops over the labels)?"""
+    if dim > 3 or kernels(*tensors, dim=dim) is not _HipKernels:
+        return False
     return _hip.labels_covered(dim, pad_codes(interpolation, dim))
 
 
@@ -262,7 +278,7 @@ def grid_pull_labels(inp, grid, bound, interpolation, extrapolate, displacement=
     interpolated indicator image is largest (> 0), smallest label on ties, else 0 -- the result of
     the reference's loop over `input.unique()` (api.py:194-205, prefilter=False) in one pass."""
     bound, interpolation = _codes(grid, bound, interpolation)
-    return _kernels.pull_labels(inp, grid, bound, interpolation, int(extrapolate), **_kw(displacement))
+    return kernels(inp, grid, dim=grid.shape[-1]).pull_labels(inp, grid, bound, interpolation, int(extrapolate), **_kw(displacement))
 
 
 def grid_push_count(inp, grid, shape, bound, interpolation, extrapolate, displacement=False):
@@ -271,4 +287,4 @@ def grid_push_count(inp, grid, shape, bound, interpolation, extrapolate, displac
     bound, interpolation = _codes(grid, bound, interpolation)
     _check_push_shapes(inp, grid)
     shape = None if shape is None else list(shape)
-    return _kernels.push_count(inp, grid, shape, bound, interpolation, int(extrapolate), **_kw(displacement))
+    return kernels(inp, grid, dim=grid.shape[-1]).push_count(inp, grid, shape, bound, interpolation, int(extrapolate), **_kw(displacement))
