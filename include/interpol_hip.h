@@ -16,7 +16,7 @@
  *     1 KiB of pinned host memory per device on first use, and up to 16 slots
  *     of 3 MiB of device memory per device, one per stream whose launches met
  *     stretched tiles -- recycled least-recently-used, released by
- *     interpol_release_stream(), freed when the library is unloaded;
+ *     interpol_release_stream(), freed at process exit;
  *   - kernels are enqueued asynchronously on `stream` (a hipStream_t passed as
  *     void*; NULL = the default stream); no internal synchronisation;
  *   - return value: 0 = ok, < 0 = INTERPOL_E_* (invalid argument, nothing

@@ -18,7 +18,7 @@
 //     (2^18 descriptors + stamps), allocated with hipMalloc when the slot first hands back, plus one event.
 //     A 17th stream takes the least recently used slot (its first launch waits, on the device, for the
 //     previous owner's last hand-back launch); interpol_release_stream() gives a slot back explicitly;
-//     everything is freed when the library is unloaded.
+//     everything is freed at process exit (atexit).
 //   * a slot is LEASED to one launch at a time: the lease (a mutex) is held from the moment the launch
 //     number is drawn until the deferred kernel is enqueued, so two host threads that launch on the same
 //     stream cannot interleave "tile kernel A, tile kernel B, deferred A, deferred B" (B's descriptors
@@ -68,6 +68,8 @@ std::mutex g_mu;                                   // guards the tables below (n
 Device g_dev[DEFER_DEVICES];
 std::atomic<int> g_mode{ -1 };                     // -1: not read from the environment yet
 
+void defer_shutdown_fwd();
+
 int current_mode()
 {
     int m = g_mode.load(std::memory_order_relaxed);
@@ -90,6 +92,8 @@ bool device_ready(Device &D)
     if (hipHostGetDevicePointer(&d, h, 0) != hipSuccess || !d) { (void)hipGetLastError(); (void)hipHostFree(h); D.failed = true; return false; }
     for (int i = 0; i < 16 * DEFER_SLOTS; ++i) ((unsigned *)h)[i] = 0u;
     D.hflag = (volatile unsigned *)h; D.dflag = (unsigned *)d;
+    static bool registered = false;
+    if (!registered) { registered = true; std::atexit(defer_shutdown_fwd); }
     return true;
 }
 
@@ -228,8 +232,11 @@ int defer_release_stream(hipStream_t st)
     }
 }
 
-// library unload: give everything back (errors ignored: the runtime may be shutting down)
-__attribute__((destructor)) static void defer_shutdown()
+// process exit: give everything back.  Registered with atexit() on first use -- i.e. AFTER the HIP runtime registered its own
+// teardown, so this runs BEFORE it (a library destructor would run after: HIP calls from there crash).
+static void defer_shutdown();
+namespace { void defer_shutdown_fwd() { defer_shutdown(); } }
+static void defer_shutdown()
 {
     for (int d = 0; d < DEFER_DEVICES; ++d) {
         Device &D = g_dev[d];
