@@ -299,21 +299,25 @@ __global__ __launch_bounds__(NT1, 4) void own_bin(KParams p, BrickGrid bg, const
 // ---------------------------------------------------------------------------
 // own_accumulate
 // ---------------------------------------------------------------------------
-constexpr int BATCH = 6144;                     // records per class-sorted batch (a brick holds 4096 on average)
-constexpr int VPT = BATCH / NT;                 // records per thread and batch
+constexpr int VPT = 12;                         // pieces per wave and batch
+constexpr int NPIECE = VPT * (NT / 64);         // pieces (<= 64 consecutive records of one run) per batch: 96
+constexpr int BATCH = NPIECE * 64;              // records per class-sorted batch, at most (a brick holds 4096 on average)
 constexpr int NCLS = 32;                        // classes = 8-byte bank pairs of the LDS
 constexpr int NHW = NT / 32;                    // half waves per workgroup
+static_assert(NPIECE <= 128, "a queue entry is piece << 6 | lane in 16 bits");
 
 struct AccSmem {
     int   taboff[3][BOX + 1];
     float tabsgn[3][BOX + 1];
-    int   pref[CAPD];                          // exclusive prefix of the run lengths; entries beyond the last run: INT_MAX
+    int   ppref[CAPD];                         // exclusive prefix of the runs' piece counts; entries beyond the last run: INT_MAX
     unsigned start[CAPD];                      // first record of each run
+    int   rcnt[CAPD];                          // records of each run
+    uint2 piece[NPIECE];                       // pieces of the current batch: first record, records (0: none)
     int   cmax[2];
-    int   dmax, n;
+    int   dmax, n, npieces;
     int   qcnt[NCLS], qoff[NCLS + 1], qmax;    // records per class of the batch, their exclusive prefix, the largest count
     unsigned cells[NCELL / 2];                 // density: 16-bit counters per first-tap cell
-    unsigned short queue[BATCH];               // records of the batch (index inside the batch), sorted by class
+    unsigned short queue[BATCH];               // records of the batch (piece << 6 | lane), sorted by class
     unsigned long long box[BOXSLOTS];
 };
 static_assert(sizeof(AccSmem) <= 80 * 1024, "two workgroups per CU");
@@ -357,15 +361,6 @@ __device__ __forceinline__ void scatter_plane(unsigned addr, f2 s, float wxi, co
     const f2 sx = s * f2{ wxi, wxi };
     scatter_row<I, 0>(addr, sx, w, dbg); scatter_row<I, 1>(addr, sx, w, dbg); scatter_row<I, 2>(addr, sx, w, dbg);
     if (K == 3) scatter_row<I, 3>(addr, sx, w, dbg);
-}
-
-// record g of the brick's concatenated runs -> record index in the workspace
-__device__ __forceinline__ unsigned record_of(const AccSmem &sm, int g)
-{
-    int j = 0;
-#pragma unroll
-    for (int s = CAPD / 2; s > 0; s >>= 1) j += sm.pref[j + s] <= g ? s : 0;
-    return sm.start[j] + (unsigned)(g - sm.pref[j]);
 }
 
 // first-tap cell and stencil coordinates of a record (same arithmetic as own_bin: nd.py:45-46)
@@ -426,26 +421,31 @@ __global__ __launch_bounds__(NT, 4) void own_accumulate(KParams p, BrickGrid bg,
         __syncthreads();                                             // the previous brick's flush is done with the tables / the box
         prof_mark(-1);
         if (tid < 64) {
+            // runs of the brick: records, pieces (<= 64 consecutive records) and the exclusive prefix of the piece counts
             constexpr int PER = CAPD / 64;
-            int cn[PER], s = 0; unsigned st_[PER];
+            int cn[PER], np[PER], s = 0, sp = 0; unsigned st_[PER];
 #pragma unroll
             for (int i = 0; i < PER; ++i) {
                 const int e = tid * PER + i;
                 const uint2 dsc = e < nd ? desc[(int64_t)brick * CAPD + e] : make_uint2(0u, 0u);
-                cn[i] = (int)dsc.y; st_[i] = dsc.x; s += cn[i];
+                cn[i] = (int)dsc.y; st_[i] = dsc.x; np[i] = (cn[i] + 63) >> 6; s += cn[i]; sp += np[i];
             }
-            int incl = s;
+            int incl = s, inclp = sp;
 #pragma unroll
-            for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o); if (tid >= o) incl += t; }
-            int run = incl - s;
+            for (int o = 1; o < 64; o <<= 1) {
+                const int t = __shfl_up(incl, o), tp = __shfl_up(inclp, o);
+                if (tid >= o) { incl += t; inclp += tp; }
+            }
+            int runp = inclp - sp;
 #pragma unroll
             for (int i = 0; i < PER; ++i) {
                 const int e = tid * PER + i;
-                sm.pref[e] = e < nd ? run : 0x7fffffff;
+                sm.ppref[e] = e < nd ? runp : 0x7fffffff;
                 sm.start[e] = st_[i];
-                run += cn[i];
+                sm.rcnt[e] = cn[i];
+                runp += np[i];
             }
-            if (tid == 63) { sm.n = incl; sm.dmax = 0; sm.cmax[0] = 0; sm.cmax[1] = 0; }
+            if (tid == 63) { sm.n = incl; sm.npieces = inclp; sm.dmax = 0; sm.cmax[0] = 0; sm.cmax[1] = 0; }
         } else if (atomic && tid < 64 + 3 * 32) {
             const int d = (tid - 64) >> 5, slot = tid & 31;
             if (slot < BOX) {
@@ -457,52 +457,65 @@ __global__ __launch_bounds__(NT, 4) void own_accumulate(KParams p, BrickGrid bg,
         for (int e = tid; e < NCELL / 2; e += NT) sm.cells[e] = 0u;
         if (tid < NCLS) sm.qcnt[tid] = 0;
         __syncthreads();
-        const int n = sm.n;
+        const int n = sm.n, npieces = sm.npieces;
+        const int wave = tid >> 6, lane = tid & 63;
+        // piece table of batch `pb0 / NPIECE`: piece g -> run (search over <= 256 runs, once per 64 records), first record, length
+        auto build_pieces = [&](int pb0) {
+            if (tid < NPIECE) {
+                const int g = pb0 + tid;
+                uint2 pc = make_uint2(0u, 0u);
+                if (g < npieces) {
+                    int j = 0;
+#pragma unroll
+                    for (int st = CAPD / 2; st > 0; st >>= 1) j += sm.ppref[j + st] <= g ? st : 0;
+                    const int q = g - sm.ppref[j], left = sm.rcnt[j] - 64 * q;
+                    pc = make_uint2(sm.start[j] + 64u * (unsigned)q, (unsigned)(left < 64 ? left : 64));
+                }
+                sm.piece[tid] = pc;
+            }
+            __syncthreads();
+        };
         prof_mark(8);
         // ---- pass 1 over all records: density of the first-tap cells, max |source| of the first channel pair; the records
         // of the first batch are also counted into their classes (rank kept in registers: qr = class | rank << 5)
         int qr[VPT];
         {
             float am0 = 0.f, am1 = 0.f;
+            for (int pb0 = 0; pb0 < npieces; pb0 += NPIECE) {
+                if (pb0 > 0) __syncthreads();                        // (every wave is done with the previous piece table)
+                build_pieces(pb0);
 #pragma unroll
-            for (int k0 = 0; k0 < VPT; k0 += 4) {
-                float4 rc[4]; float v1[4];
+                for (int k0 = 0; k0 < VPT; k0 += 4) {
+                    float4 rc[4]; float v1[4]; bool on[4];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int g = tid + (k0 + u) * NT;
-                    const unsigned ri = record_of(sm, g < n ? g : 0);
-                    rc[u] = rec[ri]; v1[u] = nch > 1 ? vals[ri] : 0.f;
-                }
+                    for (int u = 0; u < 4; ++u) {
+                        const uint2 pc = sm.piece[wave + (k0 + u) * (NT / 64)];
+                        on[u] = lane < (int)pc.y;
+                        const unsigned ri = pc.x + (on[u] ? (unsigned)lane : 0u);
+                        rc[u] = on[u] || pc.y ? rec[ri] : make_float4(0.f, 0.f, 0.f, 0.f);
+                        v1[u] = (nch > 1 && (on[u] || pc.y)) ? vals[ri] : 0.f;
+                    }
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int g = tid + (k0 + u) * NT;
-                    qr[k0 + u] = -1;
-                    if (g < n) {
-                        int x0, y0, z0; float tx, ty, tz;
-                        record_cell<K>(rc[u], b0, x0, y0, z0, tx, ty, tz);
-                        const int cell = (x0 * BR + y0) * BR + z0;
-                        atomicAdd(&sm.cells[cell >> 1], 1u << (16 * (cell & 1)));
-                        const int q = (x0 * PLANE + y0 * PZ + z0) & (NCLS - 1);
-                        qr[k0 + u] = q | (atomicAdd(&sm.qcnt[q], 1) << 5);
-                        const float a0 = __builtin_fabsf(rc[u].w), a1 = __builtin_fabsf(v1[u]);
-                        am0 = (a0 > am0 || a0 != a0) ? a0 : am0;     // NaN sticks
-                        am1 = (a1 > am1 || a1 != a1) ? a1 : am1;
+                    for (int u = 0; u < 4; ++u) {
+                        if (pb0 == 0) qr[k0 + u] = -1;
+                        if (on[u]) {
+                            int x0, y0, z0; float tx, ty, tz;
+                            record_cell<K>(rc[u], b0, x0, y0, z0, tx, ty, tz);
+                            const int cell = (x0 * BR + y0) * BR + z0;
+                            atomicAdd(&sm.cells[cell >> 1], 1u << (16 * (cell & 1)));
+                            if (pb0 == 0) {
+                                const int q = (x0 * PLANE + y0 * PZ + z0) & (NCLS - 1);
+                                qr[k0 + u] = q | (atomicAdd(&sm.qcnt[q], 1) << 5);
+                            }
+                            const float a0 = __builtin_fabsf(rc[u].w), a1 = __builtin_fabsf(v1[u]);
+                            am0 = (a0 > am0 || a0 != a0) ? a0 : am0;     // NaN sticks
+                            am1 = (a1 > am1 || a1 != a1) ? a1 : am1;
+                        }
                     }
                 }
             }
-            for (int g = tid + BATCH; g < n; g += NT) {              // (bricks beyond one batch: strongly contracting deformations)
-                const unsigned ri = record_of(sm, g);
-                const float4 rc = rec[ri];
-                int x0, y0, z0; float tx, ty, tz;
-                record_cell<K>(rc, b0, x0, y0, z0, tx, ty, tz);
-                const int cell = (x0 * BR + y0) * BR + z0;
-                atomicAdd(&sm.cells[cell >> 1], 1u << (16 * (cell & 1)));
-                const float a0 = __builtin_fabsf(rc.w), a1 = nch > 1 ? __builtin_fabsf(vals[ri]) : 0.f;
-                am0 = (a0 > am0 || a0 != a0) ? a0 : am0;
-                am1 = (a1 > am1 || a1 != a1) ? a1 : am1;
-            }
             const int w0 = wave_max(__float_as_int(am0)), w1 = wave_max(__float_as_int(am1));   // non-negative floats (and NaN) order like ints
-            if ((tid & 63) == 0) { if (w0) atomicMax(&sm.cmax[0], w0); if (w1) atomicMax(&sm.cmax[1], w1); }
+            if (lane == 0) { if (w0) atomicMax(&sm.cmax[0], w0); if (w1) atomicMax(&sm.cmax[1], w1); }
         }
         __syncthreads();
         prof_mark(9);
@@ -514,11 +527,12 @@ __global__ __launch_bounds__(NT, 4) void own_accumulate(KParams p, BrickGrid bg,
                 dm = a > dm ? a : dm; dm = c2 > dm ? c2 : dm;
             }
             dm = wave_max(dm);
-            if ((tid & 63) == 0 && dm > 0) atomicMax(&sm.dmax, dm);
+            if (lane == 0 && dm > 0) atomicMax(&sm.dmax, dm);
         }
         __syncthreads();
         prof_mark(10);
         const int hb = n < 60000 ? tiled::headroom32(L, sm.dmax) : -1;    // (16-bit density counters)
+        const bool one_batch = npieces <= NPIECE;
         for (int c = 0; c < nch; c += 2) {
             const bool two = c + 1 < nch;
             float *vc0 = vol + b * p.vol_sb + c * p.vol_sc;
@@ -528,14 +542,19 @@ __global__ __launch_bounds__(NT, 4) void own_accumulate(KParams p, BrickGrid bg,
             if (c > 0) {
                 // max |source| of this channel pair
                 float am0 = 0.f, am1 = 0.f;
-                for (int g = tid; g < n; g += NT) {
-                    const unsigned ri = record_of(sm, g);
-                    const float a0 = __builtin_fabsf(va[ri]), a1 = two ? __builtin_fabsf(vb[ri]) : 0.f;
-                    am0 = (a0 > am0 || a0 != a0) ? a0 : am0;
-                    am1 = (a1 > am1 || a1 != a1) ? a1 : am1;
+                for (int pb0 = 0; pb0 < npieces; pb0 += NPIECE) {
+                    if (!one_batch) { __syncthreads(); build_pieces(pb0); }
+                    for (int k = 0; k < VPT; ++k) {
+                        const uint2 pc = sm.piece[wave + k * (NT / 64)];
+                        if (lane >= (int)pc.y) continue;
+                        const unsigned ri = pc.x + (unsigned)lane;
+                        const float a0 = __builtin_fabsf(va[ri]), a1 = two ? __builtin_fabsf(vb[ri]) : 0.f;
+                        am0 = (a0 > am0 || a0 != a0) ? a0 : am0;
+                        am1 = (a1 > am1 || a1 != a1) ? a1 : am1;
+                    }
                 }
                 const int w0 = wave_max(__float_as_int(am0)), w1 = wave_max(__float_as_int(am1));
-                if ((tid & 63) == 0) { if (w0) atomicMax(&sm.cmax[0], w0); if (w1) atomicMax(&sm.cmax[1], w1); }
+                if (lane == 0) { if (w0) atomicMax(&sm.cmax[0], w0); if (w1) atomicMax(&sm.cmax[1], w1); }
                 __syncthreads();
             }
             const int mb0 = sm.cmax[0], mb1 = sm.cmax[1];
@@ -547,20 +566,20 @@ __global__ __launch_bounds__(NT, 4) void own_accumulate(KParams p, BrickGrid bg,
             const f2 scale = { mb0 ? __int_as_float((127 + 29 - ex0 - hbc) << 23) : 0.f, mb1 ? __int_as_float((127 + 29 - ex1 - hbc) << 23) : 0.f };
             const float inv0 = __int_as_float((127 - 29 + ex0 + hbc) << 23), inv1 = __int_as_float((127 - 29 + ex1 + hbc) << 23);
             const unsigned boxaddr = (unsigned)(size_t)(__attribute__((address_space(3))) void *)(sm.box);
-            for (int g0 = 0; g0 < n; g0 += BATCH) {
+            for (int pb0 = 0; pb0 < npieces; pb0 += NPIECE) {
                 const int tid = opaque((int)threadIdx.x);
-                const int m = n - g0 < BATCH ? n - g0 : BATCH;       // records of this batch
-                if (g0 > 0 || c > 0) {
+                const int wave = tid >> 6, lane = tid & 63;
+                if (pb0 > 0 || c > 0) {
                     // classes of a later batch / of the same records for a later channel pair: count again
                     __syncthreads();
                     if (tid < NCLS) sm.qcnt[tid] = 0;
-                    __syncthreads();
+                    if (!one_batch) build_pieces(pb0); else __syncthreads();
 #pragma unroll
                     for (int k = 0; k < VPT; ++k) {
-                        const int li = tid + k * NT;
+                        const uint2 pc = sm.piece[wave + k * (NT / 64)];
                         qr[k] = -1;
-                        if (li < m) {
-                            const float4 rc = rec[record_of(sm, g0 + li)];
+                        if (lane < (int)pc.y) {
+                            const float4 rc = rec[pc.x + (unsigned)lane];
                             int x0, y0, z0; float tx, ty, tz;
                             record_cell<K>(rc, b0, x0, y0, z0, tx, ty, tz);
                             const int q = (x0 * PLANE + y0 * PZ + z0) & (NCLS - 1);
@@ -568,8 +587,11 @@ __global__ __launch_bounds__(NT, 4) void own_accumulate(KParams p, BrickGrid bg,
                         }
                     }
                     __syncthreads();
+                } else if (!one_batch) {
+                    __syncthreads();
+                    build_pieces(0);                                 // (pass 1 left the table of the LAST batch)
                 }
-                // exclusive prefix of the class counts (one half wave), then every record's batch index goes to its queue slot
+                // exclusive prefix of the class counts (one half wave), then every record (piece << 6 | lane) goes to its queue slot
                 if (tid < 32) {
                     const int cq = sm.qcnt[tid];
                     int tot;
@@ -584,25 +606,24 @@ __global__ __launch_bounds__(NT, 4) void own_accumulate(KParams p, BrickGrid bg,
                 __syncthreads();
 #pragma unroll
                 for (int k = 0; k < VPT; ++k)
-                    if (qr[k] >= 0) sm.queue[sm.qoff[qr[k] & 31] + (qr[k] >> 5)] = (unsigned short)(tid + k * NT);
+                    if (qr[k] >= 0) sm.queue[sm.qoff[qr[k] & 31] + (qr[k] >> 5)] = (unsigned short)(((wave + k * (NT / 64)) << 6) | lane);
                 __syncthreads();
                 // ---- the taps: lane q of half wave hw walks class q
                 const int q = tid & 31, hw = tid >> 5;
                 const int ebeg = sm.qoff[q] + hw, eend = sm.qoff[q + 1];
                 const int nit = (sm.qmax + NHW - 1) / NHW;           // (block-uniform)
-                float4 rc = make_float4(0.f, 0.f, 0.f, 0.f); float s0 = 0.f, s1 = 0.f;
-                if (ebeg < eend) {
-                    const unsigned ri = record_of(sm, g0 + (int)sm.queue[ebeg]);
+                auto fetch = [&](int e, float4 &rc, float &s0, float &s1) {
+                    const unsigned qe = sm.queue[e];
+                    const unsigned ri = sm.piece[qe >> 6].x + (qe & 63u);
                     rc = rec[ri]; s0 = va ? va[ri] : rc.w; s1 = vb ? vb[ri] : 0.f;
-                }
+                };
+                float4 rc = make_float4(0.f, 0.f, 0.f, 0.f); float s0 = 0.f, s1 = 0.f;
+                if (ebeg < eend) fetch(ebeg, rc, s0, s1);
 #pragma unroll 1
                 for (int it = 0; it < nit; ++it) {
                     const int e = ebeg + it * NHW;
                     const float4 cur = rc; const float cs0 = s0, cs1 = s1;
-                    if (e + NHW < eend) {
-                        const unsigned ri = record_of(sm, g0 + (int)sm.queue[e + NHW]);
-                        rc = rec[ri]; s0 = va ? va[ri] : rc.w; s1 = vb ? vb[ri] : 0.f;
-                    }
+                    if (e + NHW < eend) fetch(e + NHW, rc, s0, s1);
                     if (e >= eend) continue;
                     int x0, y0, z0; float tx, ty, tz;
                     record_cell<K>(cur, b0, x0, y0, z0, tx, ty, tz);
@@ -611,11 +632,6 @@ __global__ __launch_bounds__(NT, 4) void own_accumulate(KParams p, BrickGrid bg,
                         if (p.dbg & 2) continue;                     // (ablation: no taps)
 #endif
                         unsigned addr = boxaddr + 8u * (unsigned)(x0 * PLANE + y0 * PZ + z0);
-#ifdef IP_ABLATE
-                        if (p.dbg & 32) addr = boxaddr + 8u * (unsigned)((tid & 31) + 32 * (it & 63));     // (ablation: conflict-free by construction)
-                        if (p.dbg & 64) addr = boxaddr + 8u * (unsigned)(((x0 * PLANE + y0 * PZ + z0) & 31) + 32 * (it & 63));     // (ablation: the record's class, a synthetic row)
-                        if (p.dbg & 128) addr = boxaddr + 8u * (unsigned)((tid & 31) + 32 * ((tid * 2654435761u + it * 40503u) >> 25));   // (ablation: the lane's class, a random row)
-#endif
                         f2 w[4];
                         weights_yz<K>(f2{ ty, tz }, w);
                         const f2 ss = f2{ cs0, cs1 } * scale;
