@@ -92,7 +92,7 @@ __global__ __launch_bounds__(256) void pull_labels_kernel(KParams p, const int *
 // very sum the per-label pull forms -- and strike those taps off.  Weights are re-formed on the fly as
 // (wx wy) wz, the node-major product of the reference.
 template <typename G, typename R, int D, int K>
-__global__ __launch_bounds__(256) void pull_labels_wide_kernel(KParams p, const int *__restrict__ vol, const G *__restrict__ grid,
+__global__ __launch_bounds__(256, 4) void pull_labels_wide_kernel(KParams p, const int *__restrict__ vol, const G *__restrict__ grid,
                                                                int *__restrict__ val, int B)
 {
     const int64_t o = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -130,29 +130,43 @@ __global__ __launch_bounds__(256) void pull_labels_wide_kernel(KParams p, const 
             for (int j = 0; j < T1; ++j) wxy[i * T1 + j] = wd[0][i] * wd[1][j];
         for (int c = 0; c < p.C; ++c) {
             const char *v0 = reinterpret_cast<const char *>(vol + b * p.vol_sb + c * p.vol_sc);
-            int lab[NT];
-#pragma unroll
-            for (int i = 0; i < T0; ++i)
-#pragma unroll
-                for (int j = 0; j < T1; ++j)
-#pragma unroll
-                    for (int k = 0; k < T2; ++k)
-                        lab[(i * T1 + j) * T2 + k] = *reinterpret_cast<const int *>(v0 + (s.off[0][i] + s.off[1][j] + s.off[2][k]));
+            // One pass over the stencil per DISTINCT label under it (one or two for most stencils of a label map).  The 64 labels are
+            // re-read from the L1 / L2 in every pass instead of being held in registers: held, they took the kernel to 256 VGPRs -- one
+            // wave per SIMD, nothing to hide the latency of the gathers behind (6.4 ms for 192^3 samples; now bound by the gathers).
             unsigned long long todo = NT == 64 ? ~0ull : ((1ull << (NT & 63)) - 1ull);
             int best_l = 0x7fffffff;
             R best_w = R(0);
             while (todo) {
-                const int t = __ffsll((long long)todo) - 1;          // first tap not accounted for
-                int l = lab[0];
+                const int t = __ffsll((long long)todo) - 1;          // first tap not accounted for: its label
+                const int ti = t / (T1 * T2), tj = (t / T2) % T1, tk = t % T2;
+                unsigned offt = 0;
 #pragma unroll
-                for (int u = 1; u < NT; ++u) l = (t == u) ? lab[u] : l;
+                for (int u = 0; u <= K; ++u) {
+                    offt += (ti == u ? s.off[0][u] : 0u);
+                    if (D > 1) offt += (tj == u ? s.off[1][u] : 0u);
+                    if (D > 2) offt += (tk == u ? s.off[2][u] : 0u);
+                }
+                const int l = *reinterpret_cast<const int *>(v0 + offt);
                 R sum = R(0);
                 unsigned lo_hit = 0u, hi_hit = 0u;
 #pragma unroll
-                for (int u = 0; u < NT; ++u) {
-                    const bool m = lab[u] == l;
-                    sum += m ? wxy[u / T2] * wd[2][u % T2] : R(0);   // tap order, as the per-label pull sums
-                    if (u < 32) lo_hit |= m ? (1u << u) : 0u; else hi_hit |= m ? (1u << (u - 32)) : 0u;
+                for (int i = 0; i < T0; ++i) {
+                    unsigned oi = s.off[0][i];
+                    asm volatile("" : "+v"(oi));                     // (the 64 tap addresses are loop-invariant: hoisted, they spill)
+#pragma unroll
+                    for (int j = 0; j < T1; ++j) {
+                        int lab[T2];
+#pragma unroll
+                        for (int k = 0; k < T2; ++k) lab[k] = *reinterpret_cast<const int *>(v0 + (oi + s.off[1][j] + s.off[2][k]));
+#pragma unroll
+                        for (int k = 0; k < T2; ++k) {
+                            const int u = (i * T1 + j) * T2 + k;
+                            const bool m = lab[k] == l;
+                            sum += m ? wxy[i * T1 + j] * wd[2][k] : R(0);     // tap order, as the per-label pull sums
+                            if (u < 32) lo_hit |= m ? (1u << u) : 0u; else hi_hit |= m ? (1u << (u - 32)) : 0u;
+                        }
+                    }
+                    asm volatile("" ::: "memory");                   // one x-plane of gathers in flight at a time: 16 results, not 64
                 }
                 todo &= ~(((unsigned long long)hi_hit << 32) | lo_hit);
                 sum *= s.mask;
