@@ -64,9 +64,11 @@ if all(dbs("pmc_%s_s%s" % (c, sg)) for c in ("FETCH_SIZE", "WRITE_SIZE") for sg 
     json.dump(raw, open(raw_path, "w"), indent=1)
 if os.path.exists(raw_path):
     raw = json.load(open(raw_path))
+    # the raw counters travel with the table built from them: <round>_pmc_hbm_traffic.txt is reproducible from <round>_pmc_raw.json
+    json.dump(raw, open(os.path.join(dst, rnd + "_pmc_raw.json"), "w"), indent=1)
     buf = io.StringIO()
     buf.write("# rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE (separate passes) -- python tools/pmc_workload.py <sigma>\n"
-              "# per-dispatch values summed over the counter's instances, KB (tools/profile_round.sh %s pmc; raw values: pmc_raw.json).\n"
+              "# per-dispatch values summed over the counter's instances, KB (tools/profile_round.sh %s pmc; raw values: profiles/%s_pmc_raw.json).\n"
               "# Corrections (MI355X_MICROARCH.md sec. HBM: FETCH_SIZE reports 1/2 of wide coalesced reads on gfx950, other widths and\n"
               "# WRITE_SIZE are to be calibrated on a known byte count in one's own access pattern):\n"
               "#  * WRITE_SIZE: exact -- __amd_rocclr_copyBuffer of the same run writes 524288 KB and reports 524288.0 KB: factor 1.\n"
@@ -74,7 +76,7 @@ if os.path.exists(raw_path):
               "#    reads are grid + source = 1342 MB: factor = 1342 MB / counter(sigma = 0).  pull_sorted mixes 16-byte staging loads\n"
               "#    (counted 1/2) with 4-byte coordinate loads: factor ~1.4 (this run: the table); push_tiled reads with 4-byte loads only: factor 1.00.\n"
               "# The push target is never read: its float atomics are executed memory-side and counted as writes (write-through of the\n"
-              "# tile halos: 1.40 GB at the identity, 2.78 GB at sigma = 2 for a 0.54 GB target).\n" % tag)
+              "# tile halos: 1.40 GB at the identity, 2.78 GB at sigma = 2 for a 0.54 GB target).\n" % (tag, rnd))
     out = {"_comment": "HBM-side bytes per launch at BASELINE config 2 (sigma = 2) from rocprofv3 PMC passes (profiles/%s_pmc_hbm_traffic.txt): "
                        "FETCH_SIZE KB x 1024 x the factor calibrated on the same kernel at the identity deformation + WRITE_SIZE KB x 1024 (exact per "
                        "the copy calibration of the same run)" % rnd}

@@ -9,14 +9,17 @@
 #   tools/profile_round.sh <tag> micro   LDS microbenchmarks (tools/microbench)
 # Outputs under gpurun_out/<tag>/; tools/make_profiles.py condenses them into profiles/.
 set -u
-TAG=${1:-r02}; WHAT=${2:-bench}
+TAG=${1:-r03}; WHAT=${2:-bench}
 R=${GRAFT_REPO_ROOT:-$(pwd)}; O=$R/gpurun_out/$TAG; mkdir -p $O
 cd /tmp; export TMPDIR=/tmp
 case $WHAT in
 pmc)
   for s in 2.0 0.0; do for c in FETCH_SIZE WRITE_SIZE; do
     timeout 600 rocprofv3 --kernel-trace --pmc $c -d $O/pmc_${c}_s$s -- python $R/tools/pmc_workload.py $s > $O/pmc_${c}_s$s.log 2>&1
-  done; done ;;
+  done; done
+  # raw per-dispatch counters of THESE passes -> $O/pmc_raw.json (the databases stay on the box; make_profiles.py builds the tables from it)
+  python $R/tools/make_profiles.py $TAG ${ROUND:-r03} > /dev/null 2>&1
+  rm -rf $O/pmc_*_s*/ ;;
 sq)
   PMC_OPS=pull,push timeout 1500 python $R/tools/pmc_sq.py $TAG/sq_cfg2 2.0 > $O/sq_cfg2.log 2>&1
   PMC_OPS=pull2d,push2d PMC_GROUPS=0,1,2,3,6,7,10,11,12,13 timeout 1500 python $R/tools/pmc_sq.py $TAG/sq_cfg5 2.0 > $O/sq_cfg5.log 2>&1 ;;

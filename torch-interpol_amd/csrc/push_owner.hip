@@ -30,8 +30,8 @@
 //                    boundary condition folds it back: aliasing) go last, with global atomics -- a thin
 //                    shell of the volume.  A target shared by the batch items (batch stride 0) is flushed
 //                    with atomics throughout.
-// Samples whose first tap lies outside [-32, n + 32), tiles spread over more than 6 bricks per dim and
-// runs beyond a brick's 64 descriptors are scattered directly with float atomics by own_bin (always
+// Samples whose first tap lies outside [-160, n + 160), tiles spread over more than 6 bricks per dim and
+// runs beyond a brick's 128 descriptors are scattered directly with float atomics by own_bin (always
 // correct; the target is zeroed before own_bin and the brick launches come after it on the stream).
 //
 // Sums inside a brick are integer (exact, order-free); the float additions of up to 8 boxes per lattice
@@ -48,13 +48,14 @@ namespace owner {
 using namespace sorted;          // helpers of sorted_util.hpp
 
 constexpr int BR = 16;                          // brick edge, in first-tap cells
-constexpr int OFF = 32;                         // first taps in [-OFF, nb * BR - OFF) are binned; beyond: scattered directly
+constexpr int OFF = 160;                        // first taps in [-OFF, n + OFF) are binned (a zoom by 2 about the centre of a 256^3 lattice reaches 128 voxels
+                                                // beyond it); beyond: scattered directly
 constexpr int BOX = BR + 3;                     // lattice points a brick's stencils touch per dim (K <= 3)
 constexpr int PZ = BOX;                         // row pitch of the LDS box (8-byte slots): rows back to back
 constexpr int PLANE = BOX * PZ;                 // 361
 constexpr int BOXSLOTS = BOX * PLANE;           // 6859 slots = 54 872 B
 constexpr int NCELL = BR * BR * BR;
-constexpr int CAPD = 256;                       // descriptors (runs) per brick
+constexpr int CAPD = 128;                       // descriptors (runs) per brick
 constexpr int NT = 512;                         // accumulate: threads per workgroup (two workgroups per CU)
 constexpr int NS = TS * TS * TS;                // samples per tile (own_bin)
 constexpr int NT1 = 512, VPT1 = NS / NT1;       // own_bin: threads, samples per thread
@@ -330,7 +331,7 @@ __device__ __forceinline__ void row_adds(unsigned addr, unsigned long long v0, u
     asm volatile("ds_add_u64 %0, %1 offset:%5\n\tds_add_u64 %0, %2 offset:%6\n\tds_add_u64 %0, %3 offset:%7\n\tds_add_u64 %0, %4 offset:%8"
                  :: "v"(addr), "v"(v0), "v"(v1), "v"(v2), "v"(v3), "n"(o), "n"(o + 8), "n"(o + 16), "n"(o + 24) : "memory");
 }
-template <int I, int J>
+template <int I, int J, bool WIDE>
 __device__ __forceinline__ void scatter_row(unsigned addr, f2 sx, const f2 *w, int dbg)
 {
     const f2 sy = sx * f2{ w[J].x, w[J].x };
@@ -339,15 +340,16 @@ __device__ __forceinline__ void scatter_row(unsigned addr, f2 sx, const f2 *w, i
     for (int k = 0; k < 4; ++k) {
         const f2 pr = sy * f2{ w[k].y, w[k].y };
         const int q0 = tiled::cvt_rpi(pr.x), q1 = tiled::cvt_rpi(pr.y);
+        if (WIDE) v[k] = (unsigned long long)(long long)q0;          // one channel, 64-bit sum of 31-bit terms: cannot overflow
         // (q1 << 32) + sext(q0): low word q0, high word q1 + (q0 < 0 ? -1 : 0)
-        v[k] = ((unsigned long long)(unsigned)(q1 + (q0 >> 31)) << 32) | (unsigned)q0;
+        else v[k] = ((unsigned long long)(unsigned)(q1 + (q0 >> 31)) << 32) | (unsigned)q0;
     }
 #ifdef IP_ABLATE
     if (dbg & 4) { asm volatile("" :: "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3])); return; }     // (ablation: the arithmetic without the LDS adds)
 #endif
     row_adds<I, J>(addr, v[0], v[1], v[2], v[3]);
 }
-template <int K, int I>
+template <int K, int I, bool WIDE>
 __device__ __forceinline__ void scatter_plane(unsigned addr, f2 s, float wxi, const f2 *w, int dbg)
 {
 #ifdef IP_ABLATE
@@ -359,8 +361,8 @@ __device__ __forceinline__ void scatter_plane(unsigned addr, f2 s, float wxi, co
     }
 #endif
     const f2 sx = s * f2{ wxi, wxi };
-    scatter_row<I, 0>(addr, sx, w, dbg); scatter_row<I, 1>(addr, sx, w, dbg); scatter_row<I, 2>(addr, sx, w, dbg);
-    if (K == 3) scatter_row<I, 3>(addr, sx, w, dbg);
+    scatter_row<I, 0, WIDE>(addr, sx, w, dbg); scatter_row<I, 1, WIDE>(addr, sx, w, dbg); scatter_row<I, 2, WIDE>(addr, sx, w, dbg);
+    if (K == 3) scatter_row<I, 3, WIDE>(addr, sx, w, dbg);
 }
 
 // first-tap cell and stencil coordinates of a record (same arithmetic as own_bin: nd.py:45-46)
@@ -370,6 +372,20 @@ __device__ __forceinline__ void record_cell(const float4 &r, const int *b0, int 
     const float fx = floorf(r.x - 0.5f * (float)(K - 1)), fy = floorf(r.y - 0.5f * (float)(K - 1)), fz = floorf(r.z - 0.5f * (float)(K - 1));
     tx = r.x - fx; ty = r.y - fy; tz = r.z - fz;
     x0 = (__float2int_rz(fx) - b0[0]) & (BR - 1); y0 = (__float2int_rz(fy) - b0[1]) & (BR - 1); z0 = (__float2int_rz(fz) - b0[2]) & (BR - 1);
+}
+
+// first brick index and number of bricks a launch enumerates along dim d (host and device)
+__host__ __device__ __forceinline__ int color_first(int color, int d)
+{
+    if (color >= 8) return 0;
+    const int par = (color >> (2 - d)) & 1;
+    return NLO + ((par - NLO) & 1);                                  // first interior brick index of that parity
+}
+__host__ __device__ __forceinline__ int color_count(int color, int d, const BrickGrid &bg)
+{
+    if (color >= 8) return bg.nb[d];
+    const int j0 = color_first(color, d) - NLO;
+    return bg.nin[d] > j0 ? (bg.nin[d] - j0 + 1) >> 1 : 0;
 }
 
 // COLOR 0..7: the interior bricks of that parity, flushed with plain loads / stores; COLOR 8: the bricks whose box
@@ -392,13 +408,39 @@ __global__ __launch_bounds__(NT, 4) void own_accumulate(KParams p, BrickGrid bg,
 #pragma unroll
     for (int d = 0; d < 3; ++d) { L.bound[d] = p.bound[d]; L.n[d] = p.vol_n[d]; L.ss[d] = p.vol_ss[d] / 4; L.k[d] = K; }
     L.lin = 0;
-    // bricks of this launch: every second brick per dim for a colour, all of them otherwise
+    // bricks of this launch: a colour enumerates the INTERIOR bricks of its parity only (every work item then carries a
+    // brick's worth of samples: the workgroups stay balanced); the other launches enumerate all bricks
     const int step = color < 8 ? 2 : 1;
-    const int c0[3] = { color < 8 ? (color >> 2) & 1 : 0, color < 8 ? (color >> 1) & 1 : 0, color < 8 ? color & 1 : 0 };
-    const int m0 = (bg.nb[0] - c0[0] + step - 1) / step, m1 = (bg.nb[1] - c0[1] + step - 1) / step, m2 = (bg.nb[2] - c0[2] + step - 1) / step;
+    const int c0[3] = { color_first(color, 0), color_first(color, 1), color_first(color, 2) };
+    const int m0 = color_count(color, 0, bg), m1 = color_count(color, 1, bg), m2 = color_count(color, 2, bg);
     const int nwork = m0 * m1 * m2 * nbatch;
     for (int e = threadIdx.x; e < BOXSLOTS; e += NT) sm.box[e] = 0ull;
-    for (int work = blockIdx.x; work < nwork; work += gridDim.x) {
+    // A workgroup's work items are blockIdx.x + k * gridDim.x.  Most bricks of a launch hold nothing (the margin of virtual
+    // bricks around the lattice, the other colours' share of the shell): 64 candidates are examined at once, one per lane,
+    // and only the bricks of this launch that hold records are visited.
+    for (int chunk = blockIdx.x; chunk < nwork; chunk += 64 * (int)gridDim.x) {
+    unsigned long long pending;
+    {
+        const int w = chunk + (int)(threadIdx.x & 63) * (int)gridDim.x;
+        bool take = false;
+        if (w < nwork) {
+            int r = w;
+            const int iz = r % m2; r /= m2;
+            const int iy = r % m1; r /= m1;
+            const int ix = r % m0;
+            const int bb = r / m0;
+            const int bx_[3] = { ix * step + c0[0], iy * step + c0[1], iz * step + c0[2] };
+            bool interior = true;
+#pragma unroll
+            for (int d = 0; d < 3; ++d) interior = interior && bx_[d] >= NLO + (L.bound[d] == B_DST1 ? 1 : 0) && bx_[d] < NLO + bg.nin[d];
+            if (color < 8 ? interior : (color == 9 || !interior))
+                take = ndesc[bb * bg.per_item + (bx_[0] * bg.nb[1] + bx_[1]) * bg.nb[2] + bx_[2]] != 0;
+        }
+        pending = __ballot(take);
+    }
+    while (pending) {
+        const int work = chunk + (__ffsll((long long)pending) - 1) * (int)gridDim.x;
+        pending &= pending - 1;
         const int tid = opaque((int)threadIdx.x);
         int r = work;
         const int iz = r % m2; r /= m2;
@@ -559,18 +601,24 @@ __global__ __launch_bounds__(NT, 4) void own_accumulate(KParams p, BrickGrid bg,
             }
             const int mb0 = sm.cmax[0], mb1 = sm.cmax[1];
             const bool fin = (mb0 & 0x7f800000) != 0x7f800000 && (mb1 & 0x7f800000) != 0x7f800000;
-            const bool fixedpt = hb >= 0 && fin && !(p.dbg & 8);
+            // 32-bit channel pairs when the density allows; else WIDE: one channel per pass, 64-bit sums of 31-bit terms
+            // (strongly contracting deformations: folds, strides); float atomics only for non-finite sources
+            const bool wide = hb < 0 && fin;
+            const bool fixedpt = fin && !(p.dbg & 8);
             int ex0 = ((mb0 >> 23) & 0xff) - 127, ex1 = ((mb1 >> 23) & 0xff) - 127;
             ex0 = ex0 < -90 ? -90 : ex0; ex1 = ex1 < -90 ? -90 : ex1;
             const int hbc = hb < 0 ? 0 : hb;
             const f2 scale = { mb0 ? __int_as_float((127 + 29 - ex0 - hbc) << 23) : 0.f, mb1 ? __int_as_float((127 + 29 - ex1 - hbc) << 23) : 0.f };
             const float inv0 = __int_as_float((127 - 29 + ex0 + hbc) << 23), inv1 = __int_as_float((127 - 29 + ex1 + hbc) << 23);
+            const f2 scalew = { mb0 ? __int_as_float((127 + 30 - ex0) << 23) : 0.f, mb1 ? __int_as_float((127 + 30 - ex1) << 23) : 0.f };
+            const float invw0 = __int_as_float((127 - 30 + ex0) << 23), invw1 = __int_as_float((127 - 30 + ex1) << 23);
             const unsigned boxaddr = (unsigned)(size_t)(__attribute__((address_space(3))) void *)(sm.box);
+            for (int sub = 0; sub < (wide && two ? 2 : 1); ++sub) {
             for (int pb0 = 0; pb0 < npieces; pb0 += NPIECE) {
                 const int tid = opaque((int)threadIdx.x);
                 const int wave = tid >> 6, lane = tid & 63;
-                if (pb0 > 0 || c > 0) {
-                    // classes of a later batch / of the same records for a later channel pair: count again
+                if (pb0 > 0 || c > 0 || sub > 0) {
+                    // classes of a later batch / of the same records for a later channel (pair): count again
                     __syncthreads();
                     if (tid < NCLS) sm.qcnt[tid] = 0;
                     if (!one_batch) build_pieces(pb0); else __syncthreads();
@@ -634,11 +682,19 @@ __global__ __launch_bounds__(NT, 4) void own_accumulate(KParams p, BrickGrid bg,
                         unsigned addr = boxaddr + 8u * (unsigned)(x0 * PLANE + y0 * PZ + z0);
                         f2 w[4];
                         weights_yz<K>(f2{ ty, tz }, w);
-                        const f2 ss = f2{ cs0, cs1 } * scale;
-                        scatter_plane<K, 0>(addr, ss, weight_x<K>(tx, 0), w, p.dbg);
-                        scatter_plane<K, 1>(addr, ss, weight_x<K>(tx, 1), w, p.dbg);
-                        scatter_plane<K, 2>(addr, ss, weight_x<K>(tx, 2), w, p.dbg);
-                        if (K == 3) scatter_plane<K, 3>(addr, ss, weight_x<K>(tx, 3), w, p.dbg);
+                        if (wide) {
+                            const f2 ss = sub ? f2{ cs1 * scalew.y, 0.f } : f2{ cs0 * scalew.x, 0.f };
+                            scatter_plane<K, 0, true>(addr, ss, weight_x<K>(tx, 0), w, p.dbg);
+                            scatter_plane<K, 1, true>(addr, ss, weight_x<K>(tx, 1), w, p.dbg);
+                            scatter_plane<K, 2, true>(addr, ss, weight_x<K>(tx, 2), w, p.dbg);
+                            if (K == 3) scatter_plane<K, 3, true>(addr, ss, weight_x<K>(tx, 3), w, p.dbg);
+                        } else {
+                            const f2 ss = f2{ cs0, cs1 } * scale;
+                            scatter_plane<K, 0, false>(addr, ss, weight_x<K>(tx, 0), w, p.dbg);
+                            scatter_plane<K, 1, false>(addr, ss, weight_x<K>(tx, 1), w, p.dbg);
+                            scatter_plane<K, 2, false>(addr, ss, weight_x<K>(tx, 2), w, p.dbg);
+                            if (K == 3) scatter_plane<K, 3, false>(addr, ss, weight_x<K>(tx, 3), w, p.dbg);
+                        }
                     } else {
                         // no fixed point for this brick (density beyond the precision rule, non-finite sources): float atomics,
                         // straight to global memory.  Safe inside a colour: the taps stay inside this brick's own box.
@@ -671,7 +727,18 @@ __global__ __launch_bounds__(NT, 4) void own_accumulate(KParams p, BrickGrid bg,
                             }
                         }
                     }
-                    if (atomic) {
+                    if (wide) {
+                        // one channel: the slot is a 64-bit sum
+                        float *vcs = sub ? vc1 : vc0;
+                        const float invs = sub ? invw1 : invw0;
+#pragma unroll
+                        for (int u = 0; u < UF; ++u) {
+                            if (a[u] == 0) continue;
+                            const float val = (float)((double)a[u] * (double)(invs * sg[u]));
+                            if (atomic) __hip_atomic_fetch_add(vcs + off[u], val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            else vcs[off[u]] += val;
+                        }
+                    } else if (atomic) {
 #pragma unroll
                         for (int u = 0; u < UF; ++u) {
                             if (a[u] == 0) continue;
@@ -699,9 +766,11 @@ __global__ __launch_bounds__(NT, 4) void own_accumulate(KParams p, BrickGrid bg,
                 }
             }
             __syncthreads();
+            }                                                        // sub
             prof_mark(12);
             if (tid == 0) { sm.cmax[0] = 0; sm.cmax[1] = 0; }
         }
+    }
     }
 }
 
@@ -940,10 +1009,7 @@ int try_owner_push(const interpol_problem *p, const KParams &k, const void *val,
     const long long want = 2ll * cu_count();
     for (int color = shared ? 9 : 0; color < (shared ? 10 : 9); ++color) {
         long long nwork = B;
-        for (int d = 0; d < 3; ++d) {
-            const int c0 = color < 8 ? (color >> (2 - d)) & 1 : 0, step = color < 8 ? 2 : 1;
-            nwork *= (bg.nb[d] - c0 + step - 1) / step;
-        }
+        for (int d = 0; d < 3; ++d) nwork *= color_count(color, d, bg);
         if (nwork <= 0) continue;
         const dim3 agrid((unsigned)(nwork < want ? nwork : want));
 #define IP_OWN_ACC(KK)                                                                                                  \
