@@ -399,7 +399,8 @@ __host__ __device__ __forceinline__ int color_count(int color, int d, const Bric
 template <int K>
 __global__ __launch_bounds__(NT, 4) void own_accumulate(KParams p, BrickGrid bg, const int *__restrict__ ndesc, const uint2 *__restrict__ desc,
                                                         const float4 *__restrict__ rec, const float *__restrict__ vals, int64_t nrec,
-                                                        float *__restrict__ vol, int nch, int color, int nbatch, const int *__restrict__ gate)
+                                                        float *__restrict__ vol, int nch, int color, int nbatch, const int *__restrict__ gate,
+                                                        int *__restrict__ ctr)
 {
     if (gate && *gate != 1) return;                                  // INTERPOL_FLAG_AUTO_SCATTER: the probe chose the tiles
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -415,13 +416,27 @@ __global__ __launch_bounds__(NT, 4) void own_accumulate(KParams p, BrickGrid bg,
     const int m0 = color_count(color, 0, bg), m1 = color_count(color, 1, bg), m2 = color_count(color, 2, bg);
     const int nwork = m0 * m1 * m2 * nbatch;
     for (int e = threadIdx.x; e < BOXSLOTS; e += NT) sm.box[e] = 0ull;
-    // A workgroup's work items are blockIdx.x + k * gridDim.x.  Most bricks of a launch hold nothing (the margin of virtual
-    // bricks around the lattice, the other colours' share of the shell): 64 candidates are examined at once, one per lane,
-    // and only the bricks of this launch that hold records are visited.
-    for (int chunk = blockIdx.x; chunk < nwork; chunk += 64 * (int)gridDim.x) {
+    // Colour launches: every candidate is an interior brick; they are drawn one at a time from a counter of the launch
+    // (balanced whatever the brick count).  Other launches: most candidates hold nothing; a workgroup examines 64 at once (one per
+    // lane: candidates blockIdx + (64 k + lane) gridDim, interleaved over the workgroups -- the bricks that hold records cluster
+    // along the faces of the lattice) and visits the ones that hold records.
+    const bool dynamic = color < 8;
+    __shared__ int next_chunk;
+    for (int round = 0; ; ++round) {
+    int chunk, stride;
+    if (dynamic) {
+        __syncthreads();
+        if (threadIdx.x == 0) next_chunk = atomicAdd(ctr, 1);
+        __syncthreads();
+        chunk = next_chunk; stride = nwork;                          // (one candidate: lane 0)
+    } else {
+        chunk = (int)blockIdx.x + round * 64 * (int)gridDim.x; stride = (int)gridDim.x;
+    }
+    if (chunk >= nwork) break;
     unsigned long long pending;
     {
-        const int w = chunk + (int)(threadIdx.x & 63) * (int)gridDim.x;
+        const long long wl = (long long)chunk + (long long)(threadIdx.x & 63) * stride;
+        const int w = wl < nwork ? (int)wl : nwork;
         bool take = false;
         if (w < nwork) {
             int r = w;
@@ -439,7 +454,7 @@ __global__ __launch_bounds__(NT, 4) void own_accumulate(KParams p, BrickGrid bg,
         pending = __ballot(take);
     }
     while (pending) {
-        const int work = chunk + (__ffsll((long long)pending) - 1) * (int)gridDim.x;
+        const int work = chunk + (__ffsll((long long)pending) - 1) * stride;
         pending &= pending - 1;
         const int tid = opaque((int)threadIdx.x);
         int r = work;
@@ -1017,7 +1032,8 @@ int try_owner_push(const interpol_problem *p, const KParams &k, const void *val,
             const int attr = big_lds<own_accumulate<KK>>(sizeof(AccSmem));                                              \
             if (attr) return attr;                                                                                      \
             hipLaunchKernelGGL((own_accumulate<KK>), agrid, dim3(NT), sizeof(AccSmem), st, k, bg, (const int *)w.ndesc,  \
-                               (const uint2 *)w.desc, (const float4 *)w.rec, (const float *)w.vals, w.nrec, (float *)vol, nch, color, B, gate); \
+                               (const uint2 *)w.desc, (const float4 *)w.rec, (const float *)w.vals, w.nrec, (float *)vol, nch, color, B, gate, \
+                               (int *)w.hdr + 16 + color);                                                              \
         }
         if (k.order[0] == 3) IP_OWN_ACC(3) else IP_OWN_ACC(2)
 #undef IP_OWN_ACC
