@@ -25,8 +25,6 @@ for sigma in sig:
     res["push_routed"] = timeit(lambda: _hip.scatter("push", inp, grid, None, [3] * 3, [3] * 3, 1))
     res["count_routed"] = timeit(lambda: _hip.scatter("count", None, grid, None, [3] * 3, [3] * 3, 1))
     res["push_owner"] = timeit(lambda: _hip.scatter("push", inp, grid, None, [3] * 3, [3] * 3, 1, flags=_hip.FLAG_BINNED_SCATTER))
-    for d in (2048, 1 << 12, 2 << 12, 4 << 12, 8 << 12, 12 << 12):
-        res["owner_dbg_%d" % d] = timeit(lambda: _hip.scatter("push", inp, grid, None, [3] * 3, [3] * 3, 1, flags=_hip.FLAG_BINNED_SCATTER | (d << 8)))
     a = _hip.scatter("push", inp, grid, None, [3] * 3, [3] * 3, 1)
     b = _hip.scatter("push", inp, grid, None, [3] * 3, [3] * 3, 1, flags=_hip.FLAG_BINNED_SCATTER)
     res["max_abs_diff"] = float((a - b).abs().max()); res["max_abs"] = float(a.abs().max())
