@@ -11,13 +11,20 @@ dev = torch.device("cuda", 0)
 PEAK = 8000e9
 
 
-def timeit(fn, reps=5):
-    fn(); torch.cuda.synchronize()
+def timeit(fn, reps=5, inner=4):
+    """median over `reps` of the time per call of `inner` back-to-back calls (a single call after a synchronisation runs
+    at idle clocks: +15-20 % on this chip)"""
+    for _ in range(2):
+        fn()
+    torch.cuda.synchronize()
     ts = []
     for _ in range(reps):
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        a.record(); fn(); b.record(); torch.cuda.synchronize()
-        ts.append(a.elapsed_time(b))
+        a.record()
+        for _ in range(inner):
+            fn()
+        b.record(); torch.cuda.synchronize()
+        ts.append(a.elapsed_time(b) / inner)
     ts.sort()
     return ts[len(ts) // 2]
 

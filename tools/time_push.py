@@ -6,14 +6,22 @@ sys.path.insert(0, os.path.join(ROOT, "torch-interpol_amd")); sys.path.insert(0,
 import torch, interpol, bench
 from interpol import _hip
 dev = torch.device("cuda", 0)
-def timeit(fn, reps=7):
-    fn(); torch.cuda.synchronize()
+def timeit(fn, reps=7, inner=4):
+    """median over `reps` of the time per call of `inner` back-to-back calls (a single call after a synchronisation runs
+    at idle clocks: +15-20 % on this chip)"""
+    for _ in range(2):
+        fn()
+    torch.cuda.synchronize()
     ts = []
     for _ in range(reps):
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        a.record(); fn(); b.record(); torch.cuda.synchronize()
-        ts.append(a.elapsed_time(b))
-    ts.sort(); return ts[len(ts) // 2]
+        a.record()
+        for _ in range(inner):
+            fn()
+        b.record(); torch.cuda.synchronize()
+        ts.append(a.elapsed_time(b) / inner)
+    ts.sort()
+    return ts[len(ts) // 2]
 sig = [float(s) for s in sys.argv[1:]] or [2.0, 0.0]
 for sigma in sig:
     inp, grid = bench.make_inputs(4, 2, 256, sigma, dev, 1234)

@@ -62,6 +62,7 @@ struct Smem {
     float tabsgn[3][40];       // boundary sign of the same
     int   lo[3], hi[3];        // block reductions of the first-tap indices
     int   nslow, pad[1];
+    int   oobc[VPT][NT / 64];  // out-of-box samples per (sample slot, wave): count, then exclusive prefix -- their rank in the slow list
     int   cmax[8];             // scatter kernels: float bits of max |source| of the tile, per channel of the pair
     int   cnt[NCLS + 4];       // samples per class; [NCLS] collects the samples outside the box
     int   ooff[NCLS];          // surplus samples of the classes before this one
@@ -134,7 +135,6 @@ struct Tile {
     __device__ __forceinline__ void build(const KParams &p, const Lattice &L, const TileGeom &g, Smem &sm, const int tid, float (&c)[VPT][3])
     {
         if (tid < 3) { sm.lo[tid] = 0x7fffffff; sm.hi[tid] = -0x7fffffff; }
-        if (tid == 0) sm.nslow = 0;
         if (tid <= NCLS) sm.cnt[tid] = 0;
         // (Everything here runs once per sample and is counted in VALU instructions: the kernels are
         // bound by their issue rate, 4 cycles per wave instruction.)
@@ -223,19 +223,24 @@ struct Tile {
             if (in) fastmask |= 1u << v;
             rk[v] = atomicAdd(&sm.cnt[in ? (yz & (NCLS - 1)) : NCLS], 1);
         }
+        // (rare) out-of-box samples: the first SLOWCAP of them -- in the order (sample slot, wave, lane), NOT in the order of
+        // arrival: the slow list (a wave per sample) and the per-thread path sum in different orders, and which sample takes
+        // which must not depend on the timing of atomics -- go to the slow list, the rest is left to its thread
         const unsigned oob = validmask & ~fastmask;
-        if (oob != 0) {                                              // (rare) out-of-box samples: slow list
 #pragma unroll
-            for (int v = 0; v < VPT; ++v) {
-                if (!((oob >> v) & 1)) continue;
-                const int slot = atomicAdd(&sm.nslow, 1);
-                if (slot < SLOWCAP) sm.slow[slot] = (unsigned short)(tid + NT * v);
-            }
+        for (int v = 0; v < VPT; ++v) {
+            const unsigned long long bal = __ballot((oob >> v) & 1);
+            if ((tid & 63) == 0) sm.oobc[v][tid >> 6] = __popcll(bal);
         }
         __syncthreads();
-        // a slow list that overflows is not used at all: every out-of-box sample is then left to its thread -- WHICH samples
-        // made it into the list would depend on the order of the atomics, and the two paths sum in different orders
-        if (sm.nslow > SLOWCAP) selfmask |= oob;
+        if (tid < 64) {
+            const int c = sm.oobc[tid >> 3][tid & 7];                // (VPT x NT / 64 = 64 counters, slot-major)
+            int incl = c;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o); if (tid >= o) incl += t; }
+            sm.oobc[tid >> 3][tid & 7] = incl - c;
+            if (tid == 63) sm.nslow = incl;
+        }
         prof_mark(6);
         // holes and surplus: class q offers max(0, NSLOT - cnt) holes and has max(0, cnt - NSLOT) surplus samples
         const int q_l = tid & 31;
@@ -257,6 +262,16 @@ struct Tile {
         const int cnteff = (cq < NSLOT ? cq : NSLOT) + filled;       // occupied half-wave slots of lane q_l
         __syncthreads();
         prof_mark(7);
+        // slow list: rank = prefix of the (slot, wave) counters + position among the wave's lanes
+#pragma unroll
+        for (int v = 0; v < VPT; ++v) {
+            const unsigned long long bal = __ballot((oob >> v) & 1);
+            if ((oob >> v) & 1) {
+                const int rank = sm.oobc[v][tid >> 6] + __popcll(bal & ((1ull << (tid & 63)) - 1ull));
+                if (rank < SLOWCAP) sm.slow[rank] = (unsigned short)(tid + NT * v);
+                else selfmask |= 1u << v;
+            }
+        }
         float4 *rec = reinterpret_cast<float4 *>(sm.box);
 #pragma unroll
         for (int v = 0; v < VPT; ++v) {
@@ -328,7 +343,7 @@ __global__ __launch_bounds__(NT, 4) void pull_sorted(KParams p, const T *__restr
         float cnext[VPT][3];
         Tile<K, GM>::load(p, grid, b, g, tid, cnext);
         tl.build(p, L, g, sm, tid, cnext);
-        const int nslow = sm.nslow <= SLOWCAP ? sm.nslow : 0;       // (an overflowing list is not used: Tile::build)
+        const int nslow = sm.nslow < SLOWCAP ? sm.nslow : SLOWCAP;
         if (defer.flag) {                                                 // (block-uniform) too rough for the box: the generic kernel takes the tile, defer.hip
             bool hand_back = sm.nslow > (HANDBACK << ((p.dbg >> 9) & 7));
             if (hand_back) hand_back = tiled::tile_smooth(p, grid, b, 3, g.ox0, g.oy0, g.oz0, TS, TS, TS, g.gx, g.gy, g.gz, sm.hi);
@@ -563,7 +578,7 @@ __global__ __launch_bounds__(NT, 4) void gradc_sorted(KParams p, const T *__rest
         float cnext[VPT][3];
         Tile<K, GM>::load(p, grid, b, g, tid, cnext);
         tl.build(p, L, g, sm, tid, cnext);
-        const int nslow = sm.nslow <= SLOWCAP ? sm.nslow : 0;       // (an overflowing list is not used: Tile::build)
+        const int nslow = sm.nslow < SLOWCAP ? sm.nslow : SLOWCAP;
         if (defer.flag) {                                                 // (block-uniform) too rough for the box: the generic kernel takes the tile, defer.hip
             bool hand_back = sm.nslow > (HANDBACK << ((p.dbg >> 9) & 7));
             if (hand_back) hand_back = tiled::tile_smooth(p, grid, b, 3, g.ox0, g.oy0, g.oz0, TS, TS, TS, g.gx, g.gy, g.gz, sm.hi);
@@ -870,7 +885,7 @@ __global__ __launch_bounds__(NT, 4) void push_sorted(KParams p, const T *__restr
         Tile<K, GM> tl;
         Tile<K, GM>::load(p, grid, b, g, tid, cnext);
         tl.build(p, L, g, sm, tid, cnext);
-        const int nslow = sm.nslow <= SLOWCAP ? sm.nslow : 0;       // (an overflowing list is not used: Tile::build)
+        const int nslow = sm.nslow < SLOWCAP ? sm.nslow : SLOWCAP;
         if (defer.flag) {                                                 // (block-uniform) too rough for the box: the generic kernel takes the tile, defer.hip
             bool hand_back = sm.nslow > ((3 * HANDBACK / 2) << ((p.dbg >> 9) & 7));   // scatter: 3/16 of the samples, see tiled::hand_back
             if (hand_back) hand_back = tiled::tile_smooth(p, grid, b, 3, g.ox0, g.oy0, g.oz0, TS, TS, TS, g.gx, g.gy, g.gz, sm.hi);
