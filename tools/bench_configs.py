@@ -137,6 +137,12 @@ if "f" in which:    # row f4: label map (50 labels), trilinear, 1x1x192^3, one-p
     rec(res, "f4_labels_50_linear_192_per_label_loop", timeit(loop, 3), vox, vox * (12 + 8 + 8))
 
     rec(res, "f4_labels_50_cubic_192_one_pass_64_taps", timeit(lambda: interpol.grid_pull(lab, gr, interpolation=3, bound="dct2", extrapolate=True), 3), vox, vox * (12 + 8 + 8))
+    # the same with a piecewise-constant label map (8^3 blocks: what segmentations look like -- one or two labels under most stencils;
+    # the i.i.d. map above is the adversarial case: ~36 distinct labels under every stencil)
+    coarse = torch.randint(0, 50, [1, 1, n // 8, n // 8, n // 8], generator=g, device=dev)
+    blocky = coarse.repeat_interleave(8, 2).repeat_interleave(8, 3).repeat_interleave(8, 4).contiguous()
+    rec(res, "f4_labels_50_blocks_cubic_192_one_pass_64_taps", timeit(lambda: interpol.grid_pull(blocky, gr, interpolation=3, bound="dct2", extrapolate=True), 3), vox, vox * (12 + 8 + 8))
+    rec(res, "f4_labels_50_blocks_linear_192_one_pass", timeit(lambda: interpol.grid_pull(blocky, gr, interpolation=1, bound="dct2", extrapolate=True), 3), vox, vox * (12 + 8 + 8))
 
 if "f" in which:    # row f3: affine lattice evaluated in the kernel vs a dense affine grid tensor (4x2x256^3 cubic)
     B, C, n = 4, 2, 256

@@ -91,11 +91,14 @@ __global__ __launch_bounds__(256) void pull_labels_kernel(KParams p, const int *
 // weights of all taps that carry its label -- in tap order, adding exact zeros for the others, i.e. the
 // very sum the per-label pull forms -- and strike those taps off.  Weights are re-formed on the fly as
 // (wx wy) wz, the node-major product of the reference.
+constexpr int WIDE_NT = 128;                 // 32 KiB of staged labels per workgroup: five workgroups per CU
 template <typename G, typename R, int D, int K>
-__global__ __launch_bounds__(256, 4) void pull_labels_wide_kernel(KParams p, const int *__restrict__ vol, const G *__restrict__ grid,
+__global__ __launch_bounds__(WIDE_NT, 3) void pull_labels_wide_kernel(KParams p, const int *__restrict__ vol, const G *__restrict__ grid,
                                                                int *__restrict__ val, int B)
 {
-    const int64_t o = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    // the labels under a thread's stencil, staged once: column threadIdx.x of labs[tap][thread] (conflict-free: a wave reads a row)
+    __shared__ int labs[64][WIDE_NT];
+    const int64_t o = (int64_t)blockIdx.x * WIDE_NT + threadIdx.x;
     if (o >= p.N) return;
     constexpr int T0 = K + 1, T1 = D > 1 ? K + 1 : 1, T2 = D > 2 ? K + 1 : 1, NT = T0 * T1 * T2;
     static_assert(NT <= 64, "one bit per tap");
@@ -130,43 +133,42 @@ __global__ __launch_bounds__(256, 4) void pull_labels_wide_kernel(KParams p, con
             for (int j = 0; j < T1; ++j) wxy[i * T1 + j] = wd[0][i] * wd[1][j];
         for (int c = 0; c < p.C; ++c) {
             const char *v0 = reinterpret_cast<const char *>(vol + b * p.vol_sb + c * p.vol_sc);
-            // One pass over the stencil per DISTINCT label under it (one or two for most stencils of a label map).  The 64 labels are
-            // re-read from the L1 / L2 in every pass instead of being held in registers: held, they took the kernel to 256 VGPRs -- one
-            // wave per SIMD, nothing to hide the latency of the gathers behind (6.4 ms for 192^3 samples; now bound by the gathers).
+            // The NT labels under the stencil are gathered ONCE, into LDS (held in registers they took the kernel to 256 VGPRs: one
+            // wave per SIMD and nothing to hide the gathers behind, 6.4 ms for 192^3 samples); then one pass over them per DISTINCT
+            // label -- one or two for most stencils of a label map, up to NT for noise.
+#pragma unroll
+            for (int i = 0; i < T0; ++i) {
+                // one x-plane (T1 * T2 gathers) in flight at a time; its addresses are formed here, not kept across planes
+                unsigned oi = s.off[0][i];
+                asm volatile("" : "+v"(oi));
+                int tmp[T1 * T2];
+#pragma unroll
+                for (int j = 0; j < T1; ++j)
+#pragma unroll
+                    for (int k = 0; k < T2; ++k) tmp[j * T2 + k] = *reinterpret_cast<const int *>(v0 + (oi + s.off[1][j] + s.off[2][k]));
+#pragma unroll
+                for (int jk = 0; jk < T1 * T2; ++jk) labs[i * T1 * T2 + jk][threadIdx.x] = tmp[jk];
+                asm volatile("" ::: "memory");
+            }
             unsigned long long todo = NT == 64 ? ~0ull : ((1ull << (NT & 63)) - 1ull);
             int best_l = 0x7fffffff;
             R best_w = R(0);
+            // (volatile: the reads are loop-invariant to the compiler, which would hoist all NT of them into registers again)
+            const volatile int *col = &labs[0][threadIdx.x];
             while (todo) {
                 const int t = __ffsll((long long)todo) - 1;          // first tap not accounted for: its label
-                const int ti = t / (T1 * T2), tj = (t / T2) % T1, tk = t % T2;
-                unsigned offt = 0;
-#pragma unroll
-                for (int u = 0; u <= K; ++u) {
-                    offt += (ti == u ? s.off[0][u] : 0u);
-                    if (D > 1) offt += (tj == u ? s.off[1][u] : 0u);
-                    if (D > 2) offt += (tk == u ? s.off[2][u] : 0u);
-                }
-                const int l = *reinterpret_cast<const int *>(v0 + offt);
+                const int l = col[t * WIDE_NT];
                 R sum = R(0);
                 unsigned lo_hit = 0u, hi_hit = 0u;
+                R wz[T2];                                            // (laundered per pass: the NT products wxy * wz are invariant of this loop
+#pragma unroll                                                       //  and would be hoisted into NT more registers)
+                for (int k = 0; k < T2; ++k) { wz[k] = wd[2][k]; asm volatile("" : "+v"(wz[k])); }
 #pragma unroll
-                for (int i = 0; i < T0; ++i) {
-                    unsigned oi = s.off[0][i];
-                    asm volatile("" : "+v"(oi));                     // (the 64 tap addresses are loop-invariant: hoisted, they spill)
-#pragma unroll
-                    for (int j = 0; j < T1; ++j) {
-                        int lab[T2];
-#pragma unroll
-                        for (int k = 0; k < T2; ++k) lab[k] = *reinterpret_cast<const int *>(v0 + (oi + s.off[1][j] + s.off[2][k]));
-#pragma unroll
-                        for (int k = 0; k < T2; ++k) {
-                            const int u = (i * T1 + j) * T2 + k;
-                            const bool m = lab[k] == l;
-                            sum += m ? wxy[i * T1 + j] * wd[2][k] : R(0);     // tap order, as the per-label pull sums
-                            if (u < 32) lo_hit |= m ? (1u << u) : 0u; else hi_hit |= m ? (1u << (u - 32)) : 0u;
-                        }
-                    }
-                    asm volatile("" ::: "memory");                   // one x-plane of gathers in flight at a time: 16 results, not 64
+                for (int u = 0; u < NT; ++u) {
+                    const bool m = col[u * WIDE_NT] == l;
+                    sum += m ? wxy[u / T2] * wz[u % T2] : R(0);      // tap order, as the per-label pull sums
+                    if (u < 32) lo_hit |= m ? (1u << u) : 0u; else hi_hit |= m ? (1u << (u - 32)) : 0u;
+                    if ((u & 7) == 7) asm volatile("" : "+v"(sum), "+v"(lo_hit), "+v"(hi_hit) :: "memory");   // (eight reads in flight, not NT)
                 }
                 todo &= ~(((unsigned long long)hi_hit << 32) | lo_hit);
                 sum *= s.mask;
@@ -187,7 +189,8 @@ int launch_g(const KParams &p, const void *vol, const void *grid, void *val, int
     IP_L(1, 0) IP_L(1, 1) IP_L(1, 2) IP_L(1, 3) IP_L(2, 0) IP_L(2, 1) IP_L(2, 2) IP_L(2, 3) IP_L(3, 0) IP_L(3, 1) IP_L(3, 2)
 #undef IP_L
     if (p.dim == 3 && K == 3) {
-        hipLaunchKernelGGL((pull_labels_wide_kernel<G, R, 3, 3>), sample_grid(p, B), dim3(256), 0, st, p, (const int *)vol, (const G *)grid, (int *)val, B);
+        const dim3 wgrid((unsigned)((p.N + WIDE_NT - 1) / WIDE_NT), (unsigned)(B < 65535 ? B : 65535), 1);
+        hipLaunchKernelGGL((pull_labels_wide_kernel<G, R, 3, 3>), wgrid, dim3(WIDE_NT), 0, st, p, (const int *)vol, (const G *)grid, (int *)val, B);
         goto done;
     }
     return INTERPOL_E_ORDER;
