@@ -50,4 +50,14 @@ for name, grid in cases.items():
     a, r = f(), f(_hip.FLAG_NO_FASTPATH)
     res["rel_err_vs_generic"] = "%.1e" % float((a - r).abs().max() / r.abs().max())
     del a, r
+    if name in ("smooth_amp_8", "iid_sigma_6"):
+        gout = torch.randn_like(inp)
+        res["pull_backward_both"] = round(timeit(lambda: _hip.pull_backward(gout, inp, grid, [3] * 3, [3] * 3, 1, True, True)), 2)
+        backend.rough_deformations = False
+        res["pull_backward_both_tiles"] = round(timeit(lambda: _hip.pull_backward(gout, inp, grid, [3] * 3, [3] * 3, 1, True, True)), 2)
+        backend.rough_deformations = None
+        ga = _hip.pull_backward(gout, inp, grid, [3] * 3, [3] * 3, 1, True, True)
+        gr_ = _hip.pull_backward(gout, inp, grid, [3] * 3, [3] * 3, 1, True, True, flags=_hip.FLAG_NO_FASTPATH)
+        res["bwd_rel_err"] = "%.1e" % max(float((x - y).abs().max() / y.abs().max()) for x, y in zip(ga, gr_))
+        del gout, ga, gr_
     print(name, json.dumps(res), flush=True)
