@@ -353,6 +353,9 @@ __global__ __launch_bounds__(NT, 4) void pull_sorted(KParams p, const T *__restr
         // rows of the box are contiguous runs of the lattice's unit-stride dim, sign +1 throughout
         // (dst1 has sign 0 at index 0 -- quirk B-3 -- so its run must start at 1)
         const bool zlin = L.ss[2] == 1 && tl.lo[2] >= (L.bound[2] == B_DST1 ? 1 : 0) && tl.lo[2] + tl.S[2] <= L.n[2];
+        // the boundary conditions of x and y never change the sign (replicate, dct1, dct2, dft: bounds.py:30-89)
+        const bool plus = L.bound[0] != B_ZERO && L.bound[0] != B_DST1 && L.bound[0] != B_DST2
+                       && L.bound[1] != B_ZERO && L.bound[1] != B_DST1 && L.bound[1] != B_DST2;
         prof_mark(0);
 
         for (int c = 0; ; c += 2) {
@@ -381,31 +384,40 @@ __global__ __launch_bounds__(NT, 4) void pull_sorted(KParams p, const T *__restr
                     // alone cost as much as all the quads.)  ALL loads of the pass are issued before the
                     // first store: one exposed round trip.
                     const int nq = (tl.S[2] + 3) >> 2;               // quads per row; the last one is shifted to END at S_z
-                    constexpr int QPR = PZ / 4, NU = (NPL * CAPY * QPR + NT - 1) / NT;
+                    // thread = (row of the sweep, quad): 56 rows of 9 quads per sweep, 5 sweeps over the 256 resident rows -- the
+                    // quad, its z offset and the row's slot are fixed per thread and pass (no division per quad)
+                    constexpr int QPR = PZ / 4, RPS = NT / QPR, NU = (NPL * CAPY + RPS - 1) / RPS;
+                    const int r0 = tid / QPR, qd = tid - r0 * QPR;
+                    const bool qon = qd < nq && r0 < RPS;
+                    const int zs = 4 * qd + 4 <= tl.S[2] ? 4 * qd : tl.S[2] - 4;
+                    const int zoff = tl.lo[2] + zs;
                     float4 a0[NU], a1[NU]; float sg[NU];
 #pragma unroll
                     for (int u = 0; u < NU; ++u) {
-                        const int e = tid + NT * u, r = e / QPR, qd = e - r * QPR;
-                        const bool on = qd < nq && r < nrow && (r & 31) < tl.S[1];
+                        const int r = r0 + RPS * u;
+                        const bool on = qon && r < nrow && (r & 31) < tl.S[1];
                         const int xr = on ? 4 * (r >> 5) + ps : 0, yr = on ? r & 31 : 0;
-                        const int zs = 4 * qd + 4 <= tl.S[2] ? 4 * qd : tl.S[2] - 4;
-                        const int off = (on ? sm.taboff[0][xr] + sm.taboff[1][yr] + tl.lo[2] + zs : 0) & omask;
-                        sg[u] = sm.tabsgn[0][xr] * sm.tabsgn[1][yr];
+                        const int off = (on ? sm.taboff[0][xr] + sm.taboff[1][yr] + zoff : 0) & omask;
+                        sg[u] = plus ? 1.f : sm.tabsgn[0][xr] * sm.tabsgn[1][yr];
                         a0[u] = ld4<T>(vc0 + off);
                         a1[u] = ld4<T>(vc1 + off);
                     }
+                    float2 *dst0 = sm.box + r0 * PZ + zs;
 #pragma unroll
                     for (int u = 0; u < NU; ++u) {
-                        const int e = tid + NT * u, r = e / QPR, qd = e - r * QPR;
-                        if (qd < nq && r < nrow && (r & 31) < tl.S[1]) {
-                            const int zs = 4 * qd + 4 <= tl.S[2] ? 4 * qd : tl.S[2] - 4;
-                            float2 *dst = sm.box + r * PZ + zs;
+                        const int r = r0 + RPS * u;
+                        if (qon && r < nrow && (r & 31) < tl.S[1]) {
+                            float2 *dst = dst0 + u * (RPS * PZ);
+                            if (!plus) {
+                                a0[u].x *= sg[u]; a0[u].y *= sg[u]; a0[u].z *= sg[u]; a0[u].w *= sg[u];
+                                a1[u].x *= sg[u]; a1[u].y *= sg[u]; a1[u].z *= sg[u]; a1[u].w *= sg[u];
+                            }
                             if (!(zs & 1)) {
-                                reinterpret_cast<float4 *>(dst)[0] = make_float4(a0[u].x * sg[u], a1[u].x * sg[u], a0[u].y * sg[u], a1[u].y * sg[u]);
-                                reinterpret_cast<float4 *>(dst)[1] = make_float4(a0[u].z * sg[u], a1[u].z * sg[u], a0[u].w * sg[u], a1[u].w * sg[u]);
+                                reinterpret_cast<float4 *>(dst)[0] = make_float4(a0[u].x, a1[u].x, a0[u].y, a1[u].y);
+                                reinterpret_cast<float4 *>(dst)[1] = make_float4(a0[u].z, a1[u].z, a0[u].w, a1[u].w);
                             } else {                                 // shifted last quad of an odd extent: 8-byte stores
-                                dst[0] = make_float2(a0[u].x * sg[u], a1[u].x * sg[u]); dst[1] = make_float2(a0[u].y * sg[u], a1[u].y * sg[u]);
-                                dst[2] = make_float2(a0[u].z * sg[u], a1[u].z * sg[u]); dst[3] = make_float2(a0[u].w * sg[u], a1[u].w * sg[u]);
+                                dst[0] = make_float2(a0[u].x, a1[u].x); dst[1] = make_float2(a0[u].y, a1[u].y);
+                                dst[2] = make_float2(a0[u].z, a1[u].z); dst[3] = make_float2(a0[u].w, a1[u].w);
                             }
                         }
                     }
