@@ -101,8 +101,11 @@ struct BinSmem {
     int lo[3], total;
     int cnt[NBIN];             // samples of the tile per local brick; after the scan: -1 marks an orphan run
     int base[NBIN];            // first sorted position of the local brick
+    int bmx[2];                // max |masked source| over the tile's binned samples, first two channels (float bits)
+    int gbk[NBIN];             // global brick of the local brick when its run was published, else -1
     float4 xch[HALF];          // sorted records of one round: x, y, z, value of channel 0
     float  xv[HALF];           // value of one further channel
+    unsigned short xm[HALF];   // first-tap cell of the record inside its brick: x0 << 8 | y0 << 4 | z0
 };
 
 // value of target channel ch for a sample: masked source (nd.py:201-203), or the mask itself for the count channel
@@ -142,7 +145,8 @@ __device__ __forceinline__ void scatter_direct(const KParams &p, const T *__rest
 template <typename T, int K, int GM>
 __global__ __launch_bounds__(NT1, 4) void own_bin(KParams p, BrickGrid bg, const T *__restrict__ val, const float *__restrict__ grid,
                                                float *__restrict__ vol, int *__restrict__ ndesc, uint2 *__restrict__ desc,
-                                               float4 *__restrict__ rec, float *__restrict__ vals, int64_t nrec,
+                                               float4 *__restrict__ rec, float *__restrict__ vals, unsigned short *__restrict__ meta,
+                                               int *__restrict__ bmax, int64_t nrec,
                                                int gx, int gy, int gz, int nty, int ntz, int ntiles, const int *__restrict__ gate)
 {
     if (gate && *gate != 1) return;                                  // INTERPOL_FLAG_AUTO_SCATTER: the probe chose the tiles
@@ -152,11 +156,17 @@ __global__ __launch_bounds__(NT1, 4) void own_bin(KParams p, BrickGrid bg, const
     const int64_t b = blockIdx.x / ntiles;
     const TileGeom g = tile_geom(blockIdx.x % ntiles, gx, gy, gz, nty, ntz);
     const int nch = val == nullptr ? 1 : p.C + p.cc;
-    for (int i = tid; i < NBIN; i += NT1) sm.cnt[i] = 0;
+    for (int i = tid; i < NBIN; i += NT1) { sm.cnt[i] = 0; sm.gbk[i] = -1; }
+    if (tid < 2) sm.bmx[tid] = 0;
     if (tid < 3) sm.lo[tid] = 0x7fffffff;
     float c[VPT1][3], v0[VPT1], v1[VPT1];
     unsigned valid = 0;
     prof_mark(-1);
+    // sources of the first two channels: loaded unconditionally (a branch per load would serialise the round trips), from the
+    // coordinates themselves where there is no such channel (count: the mask is the source)
+    const bool has0 = val != nullptr && p.C > 0, has1 = val != nullptr && p.C > 1;
+    const T *vp0 = has0 ? val + b * p.val_sb : reinterpret_cast<const T *>(grid);
+    const T *vp1 = has1 ? val + b * p.val_sb + p.val_sc : reinterpret_cast<const T *>(grid);
 #pragma unroll
     for (int v = 0; v < VPT1; ++v) {
         int ox, oy, oz;
@@ -165,8 +175,13 @@ __global__ __launch_bounds__(NT1, 4) void own_bin(KParams p, BrickGrid bg, const
         ox = ox < gx ? ox : gx - 1; oy = oy < gy ? oy : gy - 1; oz = oz < gz ? oz : gz - 1;
         load_xyz<GM>(p, grid, b, g, ox, oy, oz, c[v]);
         const int64_t o = ((int64_t)ox * gy + oy) * gz + oz;
-        v0[v] = (val == nullptr || p.C == 0) ? 1.f : Cvt<float, T>::ld(val[b * p.val_sb + o]);
-        v1[v] = (val == nullptr || p.C < 2) ? 1.f : Cvt<float, T>::ld(val[b * p.val_sb + p.val_sc + o]);
+        v0[v] = Cvt<float, T>::ld(vp0[has0 ? o : 0]);
+        v1[v] = Cvt<float, T>::ld(vp1[has1 ? o : 0]);
+    }
+#pragma unroll
+    for (int v = 0; v < VPT1; ++v) {                                  // masked sources (nd.py:201-203); count: the mask itself
+        const float m = inb_mask(p, c[v]);
+        v0[v] = has0 ? v0[v] * m : m; v1[v] = has1 ? v1[v] * m : m;
     }
     // ---- brick of the first tap (nd.py:45: i0 = floor(x - (K-1)/2)), block minimum of the brick coordinates
     int bx[VPT1][3];
@@ -179,12 +194,14 @@ __global__ __launch_bounds__(NT1, 4) void own_bin(KParams p, BrickGrid bg, const
         for (int d = 0; d < 3; ++d) {
             const float fl = floorf(c[v][d] - 0.5f * (float)(K - 1));
             in = in && fl >= (float)(-OFF) && fl < (float)(bg.m[d] + NHI * BR);        // (false for NaN)
-            bx[v][d] = in ? brick_of_cell(__float2int_rz(fl), bg.m[d], bg.nin[d]) : 0;
+            const int ft = __float2int_rz(fl);
+            // brick, and above it the cell inside the brick (OFF is a multiple of BR: only the high shell is not aligned to 0)
+            bx[v][d] = in ? brick_of_cell(ft, bg.m[d], bg.nin[d]) | (((ft >= bg.m[d] && ft >= 0 ? ft - bg.m[d] : ft) & (BR - 1)) << 16) : 0;
         }
         if (in) {
             ok |= 1u << v;
 #pragma unroll
-            for (int d = 0; d < 3; ++d) mn[d] = bx[v][d] < mn[d] ? bx[v][d] : mn[d];
+            for (int d = 0; d < 3; ++d) mn[d] = (bx[v][d] & 0xffff) < mn[d] ? (bx[v][d] & 0xffff) : mn[d];
         }
     }
     __syncthreads();                                                 // counters zero
@@ -196,15 +213,15 @@ __global__ __launch_bounds__(NT1, 4) void own_bin(KParams p, BrickGrid bg, const
     }
     __syncthreads();
     const int lo[3] = { sm.lo[0], sm.lo[1], sm.lo[2] };
-    int lbin[VPT1], rank[VPT1];
+    int lbin[VPT1];                     // local brick (8 bits), cell inside the brick (12), rank inside the local brick (12)
     unsigned local = 0;
 #pragma unroll
     for (int v = 0; v < VPT1; ++v) {
-        const int r0 = bx[v][0] - lo[0], r1 = bx[v][1] - lo[1], r2 = bx[v][2] - lo[2];
+        const int r0 = (bx[v][0] & 0xffff) - lo[0], r1 = (bx[v][1] & 0xffff) - lo[1], r2 = (bx[v][2] & 0xffff) - lo[2];
         const bool l = ((ok >> v) & 1) && (unsigned)r0 < (unsigned)LB && (unsigned)r1 < (unsigned)LB && (unsigned)r2 < (unsigned)LB;
-        lbin[v] = l ? (r0 * LB + r1) * LB + r2 : 0;
-        rank[v] = 0;
-        if (l) { local |= 1u << v; rank[v] = atomicAdd(&sm.cnt[lbin[v]], 1); }
+        // local brick, and above it the first-tap cell inside the brick: x0 << 8 | y0 << 4 | z0
+        lbin[v] = l ? ((r0 * LB + r1) * LB + r2) | ((bx[v][0] >> 16) << 16 | (bx[v][1] >> 16) << 12 | (bx[v][2] >> 16) << 8) : 0;
+        if (l) { local |= 1u << v; lbin[v] |= atomicAdd(&sm.cnt[lbin[v] & 255], 1) << 20; }
     }
     __syncthreads();
     prof_mark(1);
@@ -229,7 +246,7 @@ __global__ __launch_bounds__(NT1, 4) void own_bin(KParams p, BrickGrid bg, const
                     const int r0 = e / (LB * LB), r1 = (e / LB) % LB, r2 = e % LB;
                     const int bk = (int)b * bg.per_item + ((lo[0] + r0) * bg.nb[1] + (lo[1] + r1)) * bg.nb[2] + (lo[2] + r2);
                     const int slot = atomicAdd(&ndesc[bk], 1);
-                    if (slot < CAPD) desc[(int64_t)bk * CAPD + slot] = make_uint2((unsigned)(tilebase + run), (unsigned)cn[i]);
+                    if (slot < CAPD) { desc[(int64_t)bk * CAPD + slot] = make_uint2((unsigned)(tilebase + run), (unsigned)cn[i]); sm.gbk[e] = bk; }
                     else sm.cnt[e] = -1;                             // the brick's list is full: this run is scattered directly, below
                 }
                 run += cn[i];
@@ -245,22 +262,24 @@ __global__ __launch_bounds__(NT1, 4) void own_bin(KParams p, BrickGrid bg, const
     unsigned direct = valid & ~local;
 #pragma unroll
     for (int v = 0; v < VPT1; ++v)
-        if (((local >> v) & 1) && sm.cnt[lbin[v]] < 0) direct |= 1u << v;
+        if (((local >> v) & 1) && sm.cnt[lbin[v] & 255] < 0) direct |= 1u << v;
     // ---- sorted records leave through LDS, two rounds of HALF records: coalesced 16-byte stores
     int pos[VPT1];
 #pragma unroll
-    for (int v = 0; v < VPT1; ++v) pos[v] = ((local >> v) & 1) && sm.cnt[lbin[v]] >= 0 ? sm.base[lbin[v]] + rank[v] : -1;
+    for (int v = 0; v < VPT1; ++v)      // sorted position, and above it the cell
+        pos[v] = ((local >> v) & 1) && sm.cnt[lbin[v] & 255] >= 0 ? (sm.base[lbin[v] & 255] + (int)((unsigned)lbin[v] >> 20)) | (((lbin[v] >> 8) & 0xfff) << 16) : -1;
     const bool two = nch > 1;
+    int amx0 = 0, amx1 = 0;             // max |source| of what this thread stores (non-negative floats, and NaN, order like ints)
     prof_mark(3);
     for (int r = 0; r < 2; ++r) {
         if (r * HALF >= total) break;                                // (block-uniform)
 #pragma unroll
         for (int v = 0; v < VPT1; ++v) {
-            const int q = pos[v] - r * HALF;
+            const int q = (pos[v] & 0xffff) - r * HALF;
             if (pos[v] >= 0 && (unsigned)q < (unsigned)HALF) {
-                const float m = inb_mask(p, c[v]);
-                sm.xch[q] = make_float4(c[v][0], c[v][1], c[v][2], (val == nullptr || p.C == 0) ? m : v0[v] * m);
-                if (two) sm.xv[q] = (val == nullptr || p.C < 2) ? m : v1[v] * m;
+                sm.xch[q] = make_float4(c[v][0], c[v][1], c[v][2], v0[v]);
+                sm.xm[q] = (unsigned short)(pos[v] >> 16);
+                if (two) sm.xv[q] = v1[v];
             }
         }
         __syncthreads();
@@ -269,8 +288,17 @@ __global__ __launch_bounds__(NT1, 4) void own_bin(KParams p, BrickGrid bg, const
         for (int j = 0; j < HALF / NT1; ++j) {
             const int i = tid + NT1 * j;
             if (r * HALF + i < total) {
-                rec[tilebase + r * HALF + i] = sm.xch[i];
-                if (two) vals[tilebase + r * HALF + i] = sm.xv[i];
+                const float4 rc = sm.xch[i];
+                rec[tilebase + r * HALF + i] = rc;
+                meta[tilebase + r * HALF + i] = sm.xm[i];
+                const int a0 = __float_as_int(__builtin_fabsf(rc.w));
+                amx0 = a0 > amx0 ? a0 : amx0;
+                if (two) {
+                    const float s1 = sm.xv[i];
+                    vals[tilebase + r * HALF + i] = s1;
+                    const int a1 = __float_as_int(__builtin_fabsf(s1));
+                    amx1 = a1 > amx1 ? a1 : amx1;
+                }
             }
         }
         __syncthreads();
@@ -278,7 +306,7 @@ __global__ __launch_bounds__(NT1, 4) void own_bin(KParams p, BrickGrid bg, const
         for (int ch = 2; ch < nch; ++ch) {                           // further channels: one more exchange each
 #pragma unroll
             for (int v = 0; v < VPT1; ++v) {
-                const int q = pos[v] - r * HALF;
+                const int q = (pos[v] & 0xffff) - r * HALF;
                 if (pos[v] >= 0 && (unsigned)q < (unsigned)HALF) {
                     int ox, oy, oz;
                     sample_pos(g, tid + NT1 * v, ox, oy, oz);
@@ -293,6 +321,17 @@ __global__ __launch_bounds__(NT1, 4) void own_bin(KParams p, BrickGrid bg, const
             }
             __syncthreads();
         }
+    }
+    // max |source| of the first channel pair, per brick: the tile's maximum goes to every brick it published a run for (the
+    // fixed-point scale of own_accumulate is as local as the tiled scatter's)
+    amx0 = wave_max(amx0); amx1 = wave_max(amx1);
+    if ((tid & 63) == 0) { if (amx0) atomicMax(&sm.bmx[0], amx0); if (amx1) atomicMax(&sm.bmx[1], amx1); }
+    __syncthreads();
+    for (int e = tid; e < NBIN; e += NT1) {
+        const int bk = sm.gbk[e];
+        if (bk < 0) continue;
+        if (sm.bmx[0]) atomicMax(&bmax[2 * (int64_t)bk], sm.bmx[0]);
+        if (sm.bmx[1]) atomicMax(&bmax[2 * (int64_t)bk + 1], sm.bmx[1]);
     }
     if (direct) scatter_direct<T, K, GM>(p, val, grid, vol, b, g, tid, direct, nch);
 }
@@ -398,7 +437,8 @@ __host__ __device__ __forceinline__ int color_count(int color, int d, const Bric
 // an index queue in LDS, and lane q of every half wave walks class q: half wave h takes entries h, h + 16, ... of its class.
 template <int K>
 __global__ __launch_bounds__(NT, 4) void own_accumulate(KParams p, BrickGrid bg, const int *__restrict__ ndesc, const uint2 *__restrict__ desc,
-                                                        const float4 *__restrict__ rec, const float *__restrict__ vals, int64_t nrec,
+                                                        const float4 *__restrict__ rec, const float *__restrict__ vals,
+                                                        const unsigned short *__restrict__ meta, const int *__restrict__ bmax, int64_t nrec,
                                                         float *__restrict__ vol, int nch, int color, int nbatch, const int *__restrict__ gate,
                                                         int *__restrict__ ctr)
 {
@@ -533,46 +573,33 @@ __global__ __launch_bounds__(NT, 4) void own_accumulate(KParams p, BrickGrid bg,
             __syncthreads();
         };
         prof_mark(8);
-        // ---- pass 1 over all records: density of the first-tap cells, max |source| of the first channel pair; the records
-        // of the first batch are also counted into their classes (rank kept in registers: qr = class | rank << 5)
+        // ---- pass 1 over all records: density of the first-tap cells (own_bin left every record's cell in `meta`, 2 bytes, and the
+        // brick's max |source| of the first channel pair in `bmax`); the records of the first batch are also counted into their
+        // classes (rank kept in registers: qr = class | rank << 5)
         int qr[VPT];
-        {
-            float am0 = 0.f, am1 = 0.f;
-            for (int pb0 = 0; pb0 < npieces; pb0 += NPIECE) {
-                if (pb0 > 0) __syncthreads();                        // (every wave is done with the previous piece table)
-                build_pieces(pb0);
+        if (tid == 0) { sm.cmax[0] = bmax[2 * (int64_t)brick]; sm.cmax[1] = nch > 1 ? bmax[2 * (int64_t)brick + 1] : 0; }
+        for (int pb0 = 0; pb0 < npieces; pb0 += NPIECE) {
+            if (pb0 > 0) __syncthreads();                            // (every wave is done with the previous piece table)
+            build_pieces(pb0);
+            unsigned mk[VPT];
 #pragma unroll
-                for (int k0 = 0; k0 < VPT; k0 += 4) {
-                    float4 rc[4]; float v1[4]; bool on[4];
+            for (int k = 0; k < VPT; ++k) {
+                const uint2 pc = sm.piece[wave + k * (NT / 64)];
+                mk[k] = lane < (int)pc.y ? (unsigned)meta[pc.x + (unsigned)lane] : 0xffffffffu;
+            }
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        const uint2 pc = sm.piece[wave + (k0 + u) * (NT / 64)];
-                        on[u] = lane < (int)pc.y;
-                        const unsigned ri = pc.x + (on[u] ? (unsigned)lane : 0u);
-                        rc[u] = on[u] || pc.y ? rec[ri] : make_float4(0.f, 0.f, 0.f, 0.f);
-                        v1[u] = (nch > 1 && (on[u] || pc.y)) ? vals[ri] : 0.f;
-                    }
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        if (pb0 == 0) qr[k0 + u] = -1;
-                        if (on[u]) {
-                            int x0, y0, z0; float tx, ty, tz;
-                            record_cell<K>(rc[u], b0, x0, y0, z0, tx, ty, tz);
-                            const int cell = (x0 * BR + y0) * BR + z0;
-                            atomicAdd(&sm.cells[cell >> 1], 1u << (16 * (cell & 1)));
-                            if (pb0 == 0) {
-                                const int q = (x0 * PLANE + y0 * PZ + z0) & (NCLS - 1);
-                                qr[k0 + u] = q | (atomicAdd(&sm.qcnt[q], 1) << 5);
-                            }
-                            const float a0 = __builtin_fabsf(rc[u].w), a1 = __builtin_fabsf(v1[u]);
-                            am0 = (a0 > am0 || a0 != a0) ? a0 : am0;     // NaN sticks
-                            am1 = (a1 > am1 || a1 != a1) ? a1 : am1;
-                        }
+            for (int k = 0; k < VPT; ++k) {
+                if (pb0 == 0) qr[k] = -1;
+                if (mk[k] != 0xffffffffu) {
+                    const int x0 = (mk[k] >> 8) & 15, y0 = (mk[k] >> 4) & 15, z0 = mk[k] & 15;
+                    const int cell = (int)(mk[k] & 4095u);
+                    atomicAdd(&sm.cells[cell >> 1], 1u << (16 * (cell & 1)));
+                    if (pb0 == 0) {
+                        const int q = (x0 * PLANE + y0 * PZ + z0) & (NCLS - 1);
+                        qr[k] = q | (atomicAdd(&sm.qcnt[q], 1) << 5);
                     }
                 }
             }
-            const int w0 = wave_max(__float_as_int(am0)), w1 = wave_max(__float_as_int(am1));   // non-negative floats (and NaN) order like ints
-            if (lane == 0) { if (w0) atomicMax(&sm.cmax[0], w0); if (w1) atomicMax(&sm.cmax[1], w1); }
         }
         __syncthreads();
         prof_mark(9);
@@ -642,9 +669,8 @@ __global__ __launch_bounds__(NT, 4) void own_accumulate(KParams p, BrickGrid bg,
                         const uint2 pc = sm.piece[wave + k * (NT / 64)];
                         qr[k] = -1;
                         if (lane < (int)pc.y) {
-                            const float4 rc = rec[pc.x + (unsigned)lane];
-                            int x0, y0, z0; float tx, ty, tz;
-                            record_cell<K>(rc, b0, x0, y0, z0, tx, ty, tz);
+                            const unsigned mk = meta[pc.x + (unsigned)lane];
+                            const int x0 = (mk >> 8) & 15, y0 = (mk >> 4) & 15, z0 = mk & 15;
                             const int q = (x0 * PLANE + y0 * PZ + z0) & (NCLS - 1);
                             qr[k] = q | (atomicAdd(&sm.qcnt[q], 1) << 5);
                         }
@@ -894,7 +920,7 @@ __global__ __launch_bounds__(NT1) void own_probe(KParams p, BrickGrid bg, const 
 // Host side
 // ---------------------------------------------------------------------------
 struct Workspace {
-    ProbeHdr *hdr; int *ndesc; uint2 *desc; float4 *rec; float *vals;
+    ProbeHdr *hdr; int *ndesc; int *bmax; uint2 *desc; float4 *rec; float *vals; unsigned short *meta;
     int64_t nrec; int nbricks;
 };
 static int64_t align256(int64_t x) { return (x + 255) & ~(int64_t)255; }
@@ -907,13 +933,16 @@ static int64_t layout(const KParams &k, int B, int ntiles, int nch, void *base, 
     int64_t o = 0;
     unsigned char *p = (unsigned char *)base;
     const int64_t o_hdr = o; o += 256;                               // header and brick counters are zeroed by ONE memset
-    const int64_t o_nd = o; o += align256(nbricks * 4);
+    const int64_t o_nd = o; o += nbricks * 4;                        // (header, brick counters and brick maxima: ONE zero-fill)
+    const int64_t o_bm = o; o += align256(nbricks * 8);
     const int64_t o_desc = o; o += align256(nbricks * CAPD * 8);
     const int64_t o_rec = o; o += align256(nrec * 16);
     const int64_t o_val = o; o += align256(nrec * 4 * (nch > 1 ? nch - 1 : 0));
+    const int64_t o_meta = o; o += align256(nrec * 2);
     if (w) {
         w->hdr = (ProbeHdr *)(p + o_hdr); w->ndesc = (int *)(p + o_nd); w->desc = (uint2 *)(p + o_desc);
-        w->rec = (float4 *)(p + o_rec); w->vals = (float *)(p + o_val);
+        w->rec = (float4 *)(p + o_rec); w->vals = (float *)(p + o_val); w->meta = (unsigned short *)(p + o_meta);
+        w->bmax = (int *)(p + o_bm);
         w->nrec = nrec; w->nbricks = (int)nbricks;
     }
     return o;
@@ -969,7 +998,7 @@ static int launch_bin(const interpol_problem *p, const KParams &k, const BrickGr
         const int attr = big_lds<own_bin<T, KK, GM>>(sizeof(BinSmem));                                                    \
         if (attr) return attr;                                                                                          \
         hipLaunchKernelGGL((own_bin<T, KK, GM>), tgrid, dim3(NT1), sizeof(BinSmem), st, k, bg, (const T *)val, (const float *)grid, \
-                           (float *)vol, w.ndesc, w.desc, w.rec, w.vals, w.nrec, gx, gy, gz, nty, ntz, ntiles, gate);      \
+                           (float *)vol, w.ndesc, w.desc, w.rec, w.vals, w.meta, w.bmax, w.nrec, gx, gy, gz, nty, ntz, ntiles, gate); \
     }
 #define IP_OWN_BY_GM(KK)                                                                                                \
     { if (k.sep == 0) IP_OWN_BIN(KK, 0) else if (k.sep == 1) IP_OWN_BIN(KK, 1) else if (k.sep == 2) IP_OWN_BIN(KK, 2) else IP_OWN_BIN(KK, 3) }
@@ -995,7 +1024,7 @@ int try_owner_push(const interpol_problem *p, const KParams &k, const void *val,
     const BrickGrid bg = brick_grid(k);
     const bool gated = !(p->flags & INTERPOL_FLAG_BINNED_SCATTER);
     // (a kernel, not hipMemsetAsync: under hipGraph capture the memset node of ROCm 7.2 was observed not to re-run on replays)
-    hipLaunchKernelGGL(own_zero, dim3((unsigned)((64 + w.nbricks + 1023) / 1024)), dim3(1024), 0, st, (int *)w.hdr, 64 + w.nbricks);
+    hipLaunchKernelGGL(own_zero, dim3((unsigned)((64 + 3ll * w.nbricks + 1023) / 1024)), dim3(1024), 0, st, (int *)w.hdr, 64 + 3 * w.nbricks);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return (int)e;
     const int *gate = nullptr;
@@ -1032,7 +1061,8 @@ int try_owner_push(const interpol_problem *p, const KParams &k, const void *val,
             const int attr = big_lds<own_accumulate<KK>>(sizeof(AccSmem));                                              \
             if (attr) return attr;                                                                                      \
             hipLaunchKernelGGL((own_accumulate<KK>), agrid, dim3(NT), sizeof(AccSmem), st, k, bg, (const int *)w.ndesc,  \
-                               (const uint2 *)w.desc, (const float4 *)w.rec, (const float *)w.vals, w.nrec, (float *)vol, nch, color, B, gate, \
+                               (const uint2 *)w.desc, (const float4 *)w.rec, (const float *)w.vals, (const unsigned short *)w.meta,  \
+                               (const int *)w.bmax, w.nrec, (float *)vol, nch, color, B, gate, \
                                (int *)w.hdr + 16 + color);                                                              \
         }
         if (k.order[0] == 3) IP_OWN_ACC(3) else IP_OWN_ACC(2)
