@@ -32,6 +32,10 @@ for sigma in sig:
     backend.rough_deformations = None
     res["push_routed"] = timeit(lambda: _hip.scatter("push", inp, grid, None, [3] * 3, [3] * 3, 1))
     res["count_routed"] = timeit(lambda: _hip.scatter("count", None, grid, None, [3] * 3, [3] * 3, 1))
+    backend.rough_deformations = False
+    res["count_tiles"] = timeit(lambda: _hip.scatter("count", None, grid, None, [3] * 3, [3] * 3, 1))
+    backend.rough_deformations = None
+    res["count_owner"] = timeit(lambda: _hip.scatter("count", None, grid, None, [3] * 3, [3] * 3, 1, flags=_hip.FLAG_BINNED_SCATTER))
     res["push_owner"] = timeit(lambda: _hip.scatter("push", inp, grid, None, [3] * 3, [3] * 3, 1, flags=_hip.FLAG_BINNED_SCATTER))
     a = _hip.scatter("push", inp, grid, None, [3] * 3, [3] * 3, 1)
     b = _hip.scatter("push", inp, grid, None, [3] * 3, [3] * 3, 1, flags=_hip.FLAG_BINNED_SCATTER)

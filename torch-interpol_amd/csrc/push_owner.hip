@@ -833,11 +833,12 @@ __global__ void own_zero(int *__restrict__ p, int n)
 }
 
 constexpr int NPROBE = 128;
-struct ProbeHdr { int gate, done, nslow, nfar, nvalid, pad[3]; };
+constexpr int BOXVOL = 24500;
+struct ProbeHdr { int gate, done, nslow, nfar, nvalid, nbox, nfull, pad[1]; };
 
 template <int K, int GM>
 __global__ __launch_bounds__(NT1) void own_probe(KParams p, BrickGrid bg, const float *__restrict__ grid, ProbeHdr *__restrict__ hdr,
-                                                 int gx, int gy, int gz, int nty, int ntz, int ntiles, int nbatch)
+                                                 int gx, int gy, int gz, int nty, int ntz, int ntiles, int nbatch, int nch)
 {
     __shared__ int lo[3], hi[3], cnt[3];
     const int tid = threadIdx.x;
@@ -884,12 +885,13 @@ __global__ __launch_bounds__(NT1) void own_probe(KParams p, BrickGrid bg, const 
     __syncthreads();
     // the tile's box as the tiles cut it (ops_tiled.hip: Box::build): centred, at most 33 x 33 x 32 lattice points
     const int cap[3] = { 33, 33, 32 };
-    int l[3], h[3];
+    int l[3], h[3], boxvol = 1;
 #pragma unroll
     for (int d = 0; d < 3; ++d) {
         int a = lo[d], sz = hi[d] + K - a + 1;
         if (sz > cap[d]) { a += (sz - cap[d]) / 2; sz = cap[d]; }
         l[d] = a; h[d] = a + sz - K - 1;
+        boxvol *= sz > 0 ? sz : 0;
     }
     int slow = 0, nv = 0;
 #pragma unroll
@@ -908,10 +910,16 @@ __global__ __launch_bounds__(NT1) void own_probe(KParams p, BrickGrid bg, const 
     __syncthreads();
     if (tid == 0) {
         atomicAdd(&hdr->nslow, cnt[0]); atomicAdd(&hdr->nfar, cnt[1]); atomicAdd(&hdr->nvalid, cnt[2]);
+        if (cnt[2] == NS) { atomicAdd(&hdr->nbox, boxvol); atomicAdd(&hdr->nfull, 1); }      // (whole tiles: their boxes are comparable)
         __threadfence();
         if (atomicAdd(&hdr->done, 1) == (int)gridDim.x - 1) {
             const int ns = atomicAdd(&hdr->nslow, 0), nf = atomicAdd(&hdr->nfar, 0), nn = atomicAdd(&hdr->nvalid, 0);
-            hdr->gate = ((int64_t)ns * 250 > nn && (int64_t)nf * 64 <= nn) ? 1 : 0;
+            const int nb = atomicAdd(&hdr->nbox, 0), nt = atomicAdd(&hdr->nfull, 0);
+            // owner-computes when the tiles would leave samples outside their boxes, or -- two channels and more -- when the boxes
+            // they flush with global atomics are large (mean above BOXVOL lattice points: i.i.d. noise of sigma ~ 1.7 voxels on a
+            // 16^3 tile; the tiles then need 3.4 ms and more at config 2, this file 3.0 - 3.4; a single channel flushes half as
+            // much and stays with the tiles: count 2.1 against 2.8 ms) -- unless samples lie outside the binned range
+            hdr->gate = (((int64_t)ns * 250 > nn || (nch > 1 && (int64_t)nb > (int64_t)BOXVOL * nt)) && (int64_t)nf * 64 <= nn) ? 1 : 0;
         }
     }
 }
@@ -1034,7 +1042,7 @@ int try_owner_push(const interpol_problem *p, const KParams &k, const void *val,
         const int nty = (gy + TS - 1) / TS, ntz = (gz + TS - 1) / TS, ntiles = tile_count(p);
         const long long total = (long long)ntiles * B;
         const dim3 pgrid((unsigned)(total < NPROBE ? total : NPROBE));
-#define IP_OWN_PROBE(KK, GM) hipLaunchKernelGGL((own_probe<KK, GM>), pgrid, dim3(NT1), 0, st, k, bg, (const float *)grid, w.hdr, gx, gy, gz, nty, ntz, ntiles, B);
+#define IP_OWN_PROBE(KK, GM) hipLaunchKernelGGL((own_probe<KK, GM>), pgrid, dim3(NT1), 0, st, k, bg, (const float *)grid, w.hdr, gx, gy, gz, nty, ntz, ntiles, B, nch);
 #define IP_OWN_PROBE_GM(KK) { if (k.sep == 0) IP_OWN_PROBE(KK, 0) else if (k.sep == 1) IP_OWN_PROBE(KK, 1) else if (k.sep == 2) IP_OWN_PROBE(KK, 2) else IP_OWN_PROBE(KK, 3) }
         if (k.order[0] == 3) IP_OWN_PROBE_GM(3) else IP_OWN_PROBE_GM(2)
 #undef IP_OWN_PROBE_GM
