@@ -317,7 +317,9 @@ def main():
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "traffic_source": traffic_source,
-                         "algorithmic_bytes_per_launch": dom_bytes, "avg_launch_ms": round(dom_ms, 4)},
+                         "algorithmic_bytes_per_launch": dom_bytes, "avg_launch_ms": round(dom_ms, 4),
+                         "launch": "one interpol_push call = the kernels its probe routes to (rough fields: own_bin + 9 own_accumulate "
+                                   "of csrc/push_owner.hip; smooth: push_tiled) + zero-fill; per-kernel times: profiles/*_kernel_stats.txt"},
         }
         if world == 1 and args.grid == "random" and not args.no_extras:
             # same workload under the other deformation models of SURVEY 8d (not the headline)

@@ -237,16 +237,23 @@ __global__ __launch_bounds__(NT1, 4) void own_bin(KParams p, BrickGrid bg, const
         for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o); if (tid >= o) incl += t; }
         int run = incl - s;
         if (tid == 63) sm.total = incl;
+        // (all of the lane's descriptor slots are drawn before the first one is used: one round trip to the L2, not PER)
+        int bk[PER], slot[PER];
+#pragma unroll
+        for (int i = 0; i < PER; ++i) {
+            const int e = tid * PER + i;
+            const int r0 = e / (LB * LB), r1 = (e / LB) % LB, r2 = e % LB;
+            bk[i] = (int)b * bg.per_item + ((lo[0] + r0) * bg.nb[1] + (lo[1] + r1)) * bg.nb[2] + (lo[2] + r2);
+            slot[i] = 0;
+            if (e < NBIN && cn[i] > 0) slot[i] = atomicAdd(&ndesc[bk[i]], 1);
+        }
 #pragma unroll
         for (int i = 0; i < PER; ++i) {
             const int e = tid * PER + i;
             if (e < NBIN) {
                 sm.base[e] = run;
                 if (cn[i] > 0) {
-                    const int r0 = e / (LB * LB), r1 = (e / LB) % LB, r2 = e % LB;
-                    const int bk = (int)b * bg.per_item + ((lo[0] + r0) * bg.nb[1] + (lo[1] + r1)) * bg.nb[2] + (lo[2] + r2);
-                    const int slot = atomicAdd(&ndesc[bk], 1);
-                    if (slot < CAPD) { desc[(int64_t)bk * CAPD + slot] = make_uint2((unsigned)(tilebase + run), (unsigned)cn[i]); sm.gbk[e] = bk; }
+                    if (slot[i] < CAPD) { desc[(int64_t)bk[i] * CAPD + slot[i]] = make_uint2((unsigned)(tilebase + run), (unsigned)cn[i]); sm.gbk[e] = bk[i]; }
                     else sm.cnt[e] = -1;                             // the brick's list is full: this run is scattered directly, below
                 }
                 run += cn[i];
