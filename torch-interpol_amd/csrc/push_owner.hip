@@ -362,7 +362,9 @@ struct AccSmem {
     uint2 piece[NPIECE];                       // pieces of the current batch: first record, records (0: none)
     int   cmax[2];
     int   dmax, n, npieces;
-    int   qcnt[NCLS], qoff[NCLS + 1], qmax;    // records per class of the batch, their exclusive prefix, the largest count
+    int   qcnt[NCLS];                          // records per class of the batch
+    int   qsur[NCLS + 1], qhol[NCLS + 1];      // exclusive prefixes of the classes' surplus records / free queue slots
+    int   qeff[NCLS], qcap;                    // occupied slots per class once the holes are filled; slots per class
     unsigned cells[NCELL / 2];                 // density: 16-bit counters per first-tap cell
     unsigned short queue[BATCH];               // records of the batch (piece << 6 | lane), sorted by class
     unsigned long long box[BOXSLOTS];
@@ -687,27 +689,43 @@ __global__ __launch_bounds__(NT, 4) void own_accumulate(KParams p, BrickGrid bg,
                     __syncthreads();
                     build_pieces(0);                                 // (pass 1 left the table of the LAST batch)
                 }
-                // exclusive prefix of the class counts (one half wave), then every record (piece << 6 | lane) goes to its queue slot
+                // Every class owns qcap = ceil(records / 32) slots of the queue (rounded to the NHW half waves that walk it): the
+                // records a class holds beyond that fill the free slots of the others (those lanes may collide on a bank pair),
+                // so that every lane walks the same number of entries -- the classes of an i.i.d. field are Poisson-filled, the
+                // fullest of 32 holds 20 % more than the mean.
                 if (tid < 32) {
                     const int cq = sm.qcnt[tid];
-                    int tot;
-                    const int off = half_excl_scan(cq, tot);
-                    sm.qoff[tid] = off;
-                    if (tid == 31) sm.qoff[NCLS] = tot;
-                    int mx = cq;
-#pragma unroll
-                    for (int o = 16; o > 0; o >>= 1) { const int t = __shfl_xor(mx, o, 32); mx = t > mx ? t : mx; }
-                    if (tid == 0) sm.qmax = mx;
+                    int tot, nsur, nhol;
+                    half_excl_scan(cq, tot);
+                    const int cap = (((tot + NCLS - 1) / NCLS) + NHW - 1) / NHW * NHW;
+                    const int sur = cq > cap ? cq - cap : 0, hol = cq < cap ? cap - cq : 0;
+                    const int so = half_excl_scan(sur, nsur), ho = half_excl_scan(hol, nhol);
+                    sm.qsur[tid] = so; sm.qhol[tid] = ho;
+                    if (tid == 31) { sm.qsur[NCLS] = nsur; sm.qhol[NCLS] = nhol; sm.qcap = cap; }
+                    const int fill = nsur - ho < 0 ? 0 : (nsur - ho > hol ? hol : nsur - ho);
+                    sm.qeff[tid] = (cq < cap ? cq : cap) + fill;
                 }
                 __syncthreads();
+                const int qcap = sm.qcap;
 #pragma unroll
-                for (int k = 0; k < VPT; ++k)
-                    if (qr[k] >= 0) sm.queue[sm.qoff[qr[k] & 31] + (qr[k] >> 5)] = (unsigned short)(((wave + k * (NT / 64)) << 6) | lane);
+                for (int k = 0; k < VPT; ++k) {
+                    if (qr[k] < 0) continue;
+                    const int qq = qr[k] & 31, r = qr[k] >> 5;
+                    int slot = qq * qcap + r;
+                    if (r >= qcap) {                                 // surplus record o of the batch: into the o-th free slot
+                        const int o = sm.qsur[qq] + r - qcap;
+                        int c2 = 0;
+#pragma unroll
+                        for (int st = 16; st > 0; st >>= 1) if (sm.qhol[c2 + st] <= o) c2 += st;      // last class with qhol <= o
+                        slot = c2 * qcap + sm.qcnt[c2] + (o - sm.qhol[c2]);
+                    }
+                    sm.queue[slot] = (unsigned short)(((wave + k * (NT / 64)) << 6) | lane);
+                }
                 __syncthreads();
-                // ---- the taps: lane q of half wave hw walks class q
+                // ---- the taps: lane q of half wave hw walks the slots of class q
                 const int q = tid & 31, hw = tid >> 5;
-                const int ebeg = sm.qoff[q] + hw, eend = sm.qoff[q + 1];
-                const int nit = (sm.qmax + NHW - 1) / NHW;           // (block-uniform)
+                const int ebeg = q * qcap + hw, eend = q * qcap + sm.qeff[q];
+                const int nit = qcap / NHW;                          // (block-uniform)
                 auto fetch = [&](int e, float4 &rc, float &s0, float &s1) {
                     const unsigned qe = sm.queue[e];
                     const unsigned ri = sm.piece[qe >> 6].x + (qe & 63u);
