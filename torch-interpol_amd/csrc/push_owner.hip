@@ -362,6 +362,7 @@ struct AccSmem {
     uint2 piece[NPIECE];                       // pieces of the current batch: first record, records (0: none)
     int   cmax[2];
     int   dmax, n, npieces;
+    int   rlo[3], rhi[3];                      // launches that flush with atomics: occupied first-tap cells of the brick, per dim
     int   qcnt[NCLS];                          // records per class of the batch
     int   qsur[NCLS + 1], qhol[NCLS + 1];      // exclusive prefixes of the classes' surplus records / free queue slots
     int   qeff[NCLS], qcap;                    // occupied slots per class once the holes are filled; slots per class
@@ -552,6 +553,7 @@ __global__ __launch_bounds__(NT, 4) void own_accumulate(KParams p, BrickGrid bg,
                 runp += np[i];
             }
             if (tid == 63) { sm.n = incl; sm.npieces = inclp; sm.dmax = 0; sm.cmax[0] = 0; sm.cmax[1] = 0; }
+            if (tid < 3) { sm.rlo[tid] = BR; sm.rhi[tid] = -1; }
         } else if (atomic && tid < 64 + 3 * 32) {
             const int d = (tid - 64) >> 5, slot = tid & 31;
             if (slot < BOX) {
@@ -614,13 +616,28 @@ __global__ __launch_bounds__(NT, 4) void own_accumulate(KParams p, BrickGrid bg,
         prof_mark(9);
         {
             int dm = 0;
+            int mn[3] = { BR, BR, BR }, mx[3] = { -1, -1, -1 };
             for (int e = tid; e < NCELL / 2; e += NT) {
                 const unsigned w2 = sm.cells[e];
                 const int a = (int)(w2 & 0xffffu), c2 = (int)(w2 >> 16);
                 dm = a > dm ? a : dm; dm = c2 > dm ? c2 : dm;
+                if (atomic && w2) {                                  // cells 2e, 2e + 1 = (x0 * BR + y0) * BR + z0
+                    const int x0 = e >> 7, y0 = (e >> 3) & 15, z0 = (2 * e) & 15;
+                    mn[0] = x0 < mn[0] ? x0 : mn[0]; mx[0] = x0 > mx[0] ? x0 : mx[0];
+                    mn[1] = y0 < mn[1] ? y0 : mn[1]; mx[1] = y0 > mx[1] ? y0 : mx[1];
+                    mn[2] = z0 < mn[2] ? z0 : mn[2]; mx[2] = z0 + 1 > mx[2] ? z0 + 1 : mx[2];
+                }
             }
             dm = wave_max(dm);
             if (lane == 0 && dm > 0) atomicMax(&sm.dmax, dm);
+            if (atomic) {
+                // a brick of the shell holds a few layers of samples: only the part of the box they reach is flushed
+#pragma unroll
+                for (int d = 0; d < 3; ++d) {
+                    const int a = wave_min(mn[d]), c2 = wave_max(mx[d]);
+                    if (lane == 0) { atomicMin(&sm.rlo[d], a); atomicMax(&sm.rhi[d], c2); }
+                }
+            }
         }
         __syncthreads();
         prof_mark(10);
@@ -775,14 +792,29 @@ __global__ __launch_bounds__(NT, 4) void own_accumulate(KParams p, BrickGrid bg,
             // ---- flush: fixed point -> float; the box is re-zeroed on the way
             if (fixedpt && !(p.dbg & 1)) {
                 constexpr int UF = 4;
-                for (int e0 = tid; e0 < BOXSLOTS; e0 += UF * NT) {
+                // (atomic launches: the slots [rlo, rhi + K] per dim, enumerated with a float reciprocal -- exact: the quotients
+                // stay half a unit away from the integers)
+                const int fl0 = atomic ? sm.rlo[0] : 0, fl1 = atomic ? sm.rlo[1] : 0, fl2 = atomic ? sm.rlo[2] : 0;
+                const int fe1 = atomic ? sm.rhi[1] + K - fl1 + 1 : BOX, fe2 = atomic ? sm.rhi[2] + K - fl2 + 1 : BOX;
+                const int nflush = atomic ? (sm.rhi[0] + K - fl0 + 1) * fe1 * fe2 : BOXSLOTS;
+                const float r2 = 1.f / (float)fe2, r1 = 1.f / (float)fe1;
+                for (int e0 = tid; e0 < nflush; e0 += UF * NT) {
                     long long a[UF]; int off[UF]; float sg[UF];
 #pragma unroll
                     for (int u = 0; u < UF; ++u) {
-                        const int e = e0 + u * NT;
+                        int e = e0 + u * NT;
                         a[u] = 0; off[u] = 0; sg[u] = 1.f;
-                        if (e < BOXSLOTS) {
-                            const int xr = e / PLANE, rem = e - xr * PLANE, yr = rem / PZ, zr = rem - yr * PZ;
+                        if (e < nflush) {
+                            int xr, yr, zr;
+                            if (atomic) {
+                                const int t = (int)(((float)e + 0.5f) * r2);
+                                zr = e - t * fe2 + fl2;
+                                xr = (int)(((float)t + 0.5f) * r1);
+                                yr = t - xr * fe1 + fl1; xr += fl0;
+                                e = xr * PLANE + yr * PZ + zr;
+                            } else {
+                                xr = e / PLANE; const int rem = e - xr * PLANE; yr = rem / PZ; zr = rem - yr * PZ;
+                            }
                             a[u] = (long long)sm.box[e];
                             sm.box[e] = 0ull;
                             if (atomic) {
