@@ -62,36 +62,60 @@ constexpr int NT1 = 512, VPT1 = NS / NT1;       // own_bin: threads, samples per
 constexpr int LB = 6, NBIN = LB * LB * LB;      // bricks around a tile that are sorted locally
 constexpr int HALF = NS / 2;                    // records per exchange round
 
-// Bricks of first-tap cells, per dim: [-OFF, 0) in NLO bricks (stencils that leave the lattice at the low end), then the
-// cells [0, M) whose whole stencil lies inside the lattice (M = n - K) in nin bricks of BR cells -- the last one holds the
-// remainder, so that the BOX of every one of them fits the lattice --, then [max(M, 0), ...) in NHI bricks (stencils that
-// leave at the high end).  Only the shell bricks need the boundary condition (and global atomics: their boxes alias).
+// Bricks of first-tap cells, per dim.  INTERIOR cells [lo, top) lie in nin bricks of BR cells: the bricks up to index
+// `split` are aligned to lo, the ones above it to top (brick `split` is the short one in between).  Two cases:
+//   * the boundary condition of the dim is a single reflection or a clamp without a change of sign (replicate, dct1, dct2) and
+//     the lattice is not tiny: lo = -9, top = n + 6 -- the boxes of the bricks at the two ends leave the lattice by at most 9
+//     points: their contents are FOLDED back inside the box in LDS before the flush, and that far out the target of every fold
+//     still lies in the same box (low end: box [-9, 10), point -9 -> 8; high end: box [n - 10, n + 9), point n + 8 -> n - 9);
+//   * else: lo = 0, top = n - K -- the stencils that lie inside the lattice (split = nin - 1: the last brick holds the remainder).
+// [lo - OFF, lo) lies in NLO bricks, [top, top + NHI * BR) in NHI bricks: the SHELL (stencils far outside the lattice, wrapping and
+// sign-changing boundary conditions), whose bricks flush through the boundary tables with global atomics -- their boxes alias.
 constexpr int NLO = OFF / BR, NHI = (OFF + 3 + BR - 1) / BR;
 struct BrickGrid {
     int nb[3];                                  // bricks per dim
-    int m[3], nin[3];                           // fully-inside first-tap cells, bricks that hold them
+    int lo[3], top[3], nin[3], split[3];        // interior first-tap cells [lo, top), bricks that hold them, the short brick
     int per_item;                               // nb[0] * nb[1] * nb[2]
 };
+__host__ __device__ __forceinline__ bool folds(int bound, int n) { return (bound == B_REPLICATE || bound == B_DCT1 || bound == B_DCT2) && n >= 2 * BR; }
 static BrickGrid brick_grid(const KParams &k)
 {
     BrickGrid g;
     for (int d = 0; d < 3; ++d) {
-        const int m = k.vol_n[d] - k.order[d];
-        g.m[d] = m > 0 ? m : 0;
-        g.nin[d] = (g.m[d] + BR - 1) / BR;
+        const int K = k.order[d], n = k.vol_n[d];
+        const bool f = folds(k.bound[d], n);
+        // folding dims: as far out as the mirror image of every point of the end bricks' boxes stays inside the box
+        g.lo[d] = f ? -(BOX - 1) / 2 : 0;
+        g.top[d] = f ? n - (BOX + 1) / 2 + BR : (n - K > 0 ? n - K : 0);
+        g.nin[d] = (g.top[d] - g.lo[d] + BR - 1) / BR;
+        if (f) {
+            // no short brick of less than K cells: the box of the brick below it (K points beyond its own cells) must not
+            // reach the brick above it, which has the same colour
+            const int c = g.top[d] - g.lo[d] - BR * (g.nin[d] - 1);
+            if (c < K) { g.top[d] -= c; g.nin[d] -= 1; }
+        }
+        g.split[d] = f ? g.nin[d] / 2 : (g.nin[d] > 0 ? g.nin[d] - 1 : 0);
         g.nb[d] = NLO + g.nin[d] + NHI;
     }
     g.per_item = g.nb[0] * g.nb[1] * g.nb[2];
     return g;
 }
-// brick of a first-tap cell (inside [-OFF, m + NHI * BR)) and first cell of a brick
-__host__ __device__ __forceinline__ int brick_of_cell(int ft, int m, int nin)
+// brick of a first-tap cell (inside [lo - OFF, top + NHI * BR)) and the cell's index inside its brick (<< 16)
+__host__ __device__ __forceinline__ int brick_and_cell(int ft, int lo, int top, int nin, int split)
 {
-    return ft < 0 ? (ft + OFF) >> 4 : (ft < m ? NLO + (ft >> 4) : NLO + nin + ((ft - m) >> 4));
+    if (ft < lo) return ((ft - lo + OFF) >> 4) | (((ft - lo + OFF) & (BR - 1)) << 16);
+    if (ft >= top) return (NLO + nin + ((ft - top) >> 4)) | (((ft - top) & (BR - 1)) << 16);
+    const int u = ft - lo, v = top - 1 - ft;
+    const bool hi = u >= BR * split && (v >> 4) < nin - 1 - split;
+    return hi ? (NLO + nin - 1 - (v >> 4)) | ((BR - 1 - (v & (BR - 1))) << 16) : (NLO + (u >> 4)) | ((u & (BR - 1)) << 16);
 }
-__host__ __device__ __forceinline__ int brick_origin(int bk, int m, int nin)
+// first cell of a brick
+__host__ __device__ __forceinline__ int brick_origin(int bk, int lo, int top, int nin, int split)
 {
-    return bk < NLO ? bk * BR - OFF : (bk < NLO + nin ? (bk - NLO) * BR : m + (bk - NLO - nin) * BR);
+    if (bk < NLO) return lo + bk * BR - OFF;
+    if (bk >= NLO + nin) return top + (bk - NLO - nin) * BR;
+    const int j = bk - NLO;
+    return j <= split ? lo + j * BR : top - (nin - j) * BR;
 }
 
 // ---------------------------------------------------------------------------
@@ -193,10 +217,9 @@ __global__ __launch_bounds__(NT1, 4) void own_bin(KParams p, BrickGrid bg, const
 #pragma unroll
         for (int d = 0; d < 3; ++d) {
             const float fl = floorf(c[v][d] - 0.5f * (float)(K - 1));
-            in = in && fl >= (float)(-OFF) && fl < (float)(bg.m[d] + NHI * BR);        // (false for NaN)
-            const int ft = __float2int_rz(fl);
-            // brick, and above it the cell inside the brick (OFF is a multiple of BR: only the high shell is not aligned to 0)
-            bx[v][d] = in ? brick_of_cell(ft, bg.m[d], bg.nin[d]) | (((ft >= bg.m[d] && ft >= 0 ? ft - bg.m[d] : ft) & (BR - 1)) << 16) : 0;
+            in = in && fl >= (float)(bg.lo[d] - OFF) && fl < (float)(bg.top[d] + NHI * BR);        // (false for NaN)
+            // brick, and above it the cell inside the brick
+            bx[v][d] = in ? brick_and_cell(__float2int_rz(fl), bg.lo[d], bg.top[d], bg.nin[d], bg.split[d]) : 0;
         }
         if (in) {
             ok |= 1u << v;
@@ -513,14 +536,19 @@ __global__ __launch_bounds__(NT, 4) void own_accumulate(KParams p, BrickGrid bg,
         const int ix = r % m0;
         const int64_t b = r / m0;
         const int bxyz[3] = { ix * step + c0[0], iy * step + c0[1], iz * step + c0[2] };
-        const int b0[3] = { brick_origin(bxyz[0], bg.m[0], bg.nin[0]), brick_origin(bxyz[1], bg.m[1], bg.nin[1]),
-                            brick_origin(bxyz[2], bg.m[2], bg.nin[2]) };                       // lattice index of box slot 0
+        const int b0[3] = { brick_origin(bxyz[0], bg.lo[0], bg.top[0], bg.nin[0], bg.split[0]), brick_origin(bxyz[1], bg.lo[1], bg.top[1], bg.nin[1], bg.split[1]),
+                            brick_origin(bxyz[2], bg.lo[2], bg.top[2], bg.nin[2], bg.split[2]) };                       // lattice index of box slot 0
         // interior: every stencil of the brick lies inside the lattice (dst1: index 0 carries the sign 0, bounds.py:62-89 -- tables)
         bool interior = true;
 #pragma unroll
         for (int d = 0; d < 3; ++d) interior = interior && bxyz[d] >= NLO + (L.bound[d] == B_DST1 ? 1 : 0) && bxyz[d] < NLO + bg.nin[d];
         if (color < 8 ? !interior : (color == 8 && interior)) continue;       // (block-uniform)
         const bool atomic = color >= 8;
+        // bricks at the ends of a folding dim (BrickGrid): part of the box lies outside the lattice
+        bool edge = false;
+#pragma unroll
+        for (int d = 0; d < 3; ++d) edge = edge || b0[d] < 0 || b0[d] + BOX > L.n[d];
+        edge = edge && !atomic;
         const int brick = (int)b * bg.per_item + (bxyz[0] * bg.nb[1] + bxyz[1]) * bg.nb[2] + bxyz[2];
         int nd = ndesc[brick];
         if (nd == 0) continue;                                       // (block-uniform)
@@ -789,6 +817,30 @@ __global__ __launch_bounds__(NT, 4) void own_accumulate(KParams p, BrickGrid bg,
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __syncthreads();
             prof_mark(11);
+            // ---- bricks at the ends of a folding dim: the planes / rows / slices of the box that lie outside the lattice are added
+            // onto their mirror images (replicate: the end point; dct1 / dct2: bounds.py:30-61) -- inside the same box, dim after dim
+            if (edge && fixedpt) {
+#pragma unroll
+                for (int d = 0; d < 3; ++d) {
+                    const int nlo = b0[d] < 0 ? -b0[d] : 0, nhi = b0[d] + BOX > L.n[d] ? b0[d] + BOX - L.n[d] : 0;     // (block-uniform)
+                    if (nlo + nhi == 0) continue;
+                    for (int i = tid; i < (nlo + nhi) * (BOX * BOX); i += NT) {
+                        const int o = i / (BOX * BOX), rest = i - o * (BOX * BOX), r1 = rest / BOX, r2 = rest - r1 * BOX;
+                        const int rd = o < nlo ? o : BOX - nhi + (o - nlo);
+                        const int idx = b0[d] + rd;
+                        int j;
+                        if (L.bound[d] == B_REPLICATE) j = idx < 0 ? 0 : L.n[d] - 1;
+                        else if (L.bound[d] == B_DCT1) j = idx < 0 ? -idx : 2 * L.n[d] - 2 - idx;
+                        else j = idx < 0 ? -1 - idx : 2 * L.n[d] - 1 - idx;
+                        const int rt = j - b0[d];
+                        const int es = d == 0 ? rd * PLANE + r1 * PZ + r2 : d == 1 ? r1 * PLANE + rd * PZ + r2 : r1 * PLANE + r2 * PZ + rd;
+                        const int et = d == 0 ? rt * PLANE + r1 * PZ + r2 : d == 1 ? r1 * PLANE + rt * PZ + r2 : r1 * PLANE + r2 * PZ + rt;
+                        const unsigned long long v = sm.box[es];
+                        if (v) { sm.box[es] = 0ull; atomicAdd(&sm.box[et], v); }
+                    }
+                    __syncthreads();
+                }
+            }
             // ---- flush: fixed point -> float; the box is re-zeroed on the way
             if (fixedpt && !(p.dbg & 1)) {
                 constexpr int UF = 4;
@@ -918,7 +970,7 @@ __global__ __launch_bounds__(NT1) void own_probe(KParams p, BrickGrid bg, const 
 #pragma unroll
         for (int d = 0; d < 3; ++d) {
             fl[v][d] = floorf(c[d] - 0.5f * (float)(K - 1));
-            in = in && fl[v][d] >= (float)(-OFF) && fl[v][d] < (float)(bg.m[d] + NHI * BR);
+            in = in && fl[v][d] >= (float)(bg.lo[d] - OFF) && fl[v][d] < (float)(bg.top[d] + NHI * BR);
             fl[v][d] = __builtin_fmaxf(__builtin_fminf(fl[v][d], 1073741824.f), -1073741824.f);
         }
         if (((valid >> v) & 1) && !in) ++far;
@@ -1032,7 +1084,7 @@ static bool owner_eligible(const interpol_problem *p, const KParams &k)
     int64_t n = 1, nv = 1, nb = p->batch;
     for (int d = 0; d < 3; ++d) {
         n *= p->grid_shape[d]; nv *= p->vol_shape[d];
-        nb *= owner::NLO + owner::NHI + (p->vol_shape[d] + owner::BR - 1) / owner::BR;
+        nb *= owner::NLO + owner::NHI + (p->vol_shape[d] + 11 + owner::BR - 1) / owner::BR;   // (an upper bound of BrickGrid::nb)
         if (p->grid_shape[d] > 0x7fffffff / 4) return false;
     }
     const int64_t nt = owner::tile_count(p);
