@@ -942,7 +942,7 @@ __global__ void own_zero(int *__restrict__ p, int n)
 }
 
 constexpr int NPROBE = 128;
-constexpr int BOXVOL = 24500;
+constexpr int BOXVOL = 14500;
 struct ProbeHdr { int gate, done, nslow, nfar, nvalid, nbox, nfull, pad[1]; };
 
 template <int K, int GM>
@@ -1025,9 +1025,9 @@ __global__ __launch_bounds__(NT1) void own_probe(KParams p, BrickGrid bg, const 
             const int ns = atomicAdd(&hdr->nslow, 0), nf = atomicAdd(&hdr->nfar, 0), nn = atomicAdd(&hdr->nvalid, 0);
             const int nb = atomicAdd(&hdr->nbox, 0), nt = atomicAdd(&hdr->nfull, 0);
             // owner-computes when the tiles would leave samples outside their boxes, or -- two channels and more -- when the boxes
-            // they flush with global atomics are large (mean above BOXVOL lattice points: i.i.d. noise of sigma ~ 1.7 voxels on a
-            // 16^3 tile; the tiles then need 3.4 ms and more at config 2, this file 3.0 - 3.4; a single channel flushes half as
-            // much and stays with the tiles: count 2.1 against 2.8 ms) -- unless samples lie outside the binned range
+            // they flush with global atomics are large (mean above BOXVOL lattice points: i.i.d. noise of sigma ~ 0.9 voxels on a
+            // 16^3 tile; the tiles then need 2.9 ms and more at config 2, this file 2.9 - 3.0; a single channel flushes half as
+            // much and stays with the tiles: count 2.1 against 2.5 ms) -- unless samples lie outside the binned range
             hdr->gate = (((int64_t)ns * 250 > nn || (nch > 1 && (int64_t)nb > (int64_t)BOXVOL * nt)) && (int64_t)nf * 64 <= nn) ? 1 : 0;
         }
     }
