@@ -943,27 +943,29 @@ __global__ void own_zero(int *__restrict__ p, int n)
 
 constexpr int NPROBE = 128;
 constexpr int BOXVOL = 14500;
-struct ProbeHdr { int gate, done, nslow, nfar, nvalid, nbox, nfull, pad[1]; };
+struct ProbeHdr { int gate, done, nslow, nfar, nvalid, nbox, nfull, ncorner; };
 
 template <int K, int GM>
 __global__ __launch_bounds__(NT1) void own_probe(KParams p, BrickGrid bg, const float *__restrict__ grid, ProbeHdr *__restrict__ hdr,
                                                  int gx, int gy, int gz, int nty, int ntz, int ntiles, int nbatch, int nch)
 {
-    __shared__ int lo[3], hi[3], cnt[3];
+    __shared__ int lo[3], hi[3], cnt[3], clo[3], chi[3];
     const int tid = threadIdx.x;
     const int64_t total = (int64_t)ntiles * nbatch;
     const int64_t work = (int64_t)blockIdx.x * total / gridDim.x;
     const int64_t b = work / ntiles;
     const TileGeom g = tile_geom((int)(work % ntiles), gx, gy, gz, nty, ntz);
-    if (tid < 3) { lo[tid] = 0x7fffffff; hi[tid] = -0x7fffffff; cnt[tid] = 0; }
+    if (tid < 3) { lo[tid] = 0x7fffffff; hi[tid] = -0x7fffffff; cnt[tid] = 0; clo[tid] = 0x7fffffff; chi[tid] = -0x7fffffff; }
     float fl[VPT1][3];
-    unsigned valid = 0;
+    unsigned valid = 0, corner = 0;
     int far = 0;
 #pragma unroll
     for (int v = 0; v < VPT1; ++v) {
         int ox, oy, oz; float c[3];
         sample_pos(g, tid + NT1 * v, ox, oy, oz);
         if (ox < gx && oy < gy && oz < gz) valid |= 1u << v;
+        // the eight corner samples of the tile: their bounding box is what a smooth deformation makes of the tile
+        if (((ox - g.ox0) % (TS - 1)) == 0 && ((oy - g.oy0) % (TS - 1)) == 0 && ((oz - g.oz0) % (TS - 1)) == 0) corner |= 1u << v;
         ox = ox < gx ? ox : gx - 1; oy = oy < gy ? oy : gy - 1; oz = oz < gz ? oz : gz - 1;
         load_xyz<GM>(p, grid, b, g, ox, oy, oz, c);
         bool in = true;
@@ -984,6 +986,7 @@ __global__ __launch_bounds__(NT1) void own_probe(KParams p, BrickGrid bg, const 
         for (int d = 0; d < 3; ++d) {
             const int i = fl[v][d] == fl[v][d] ? __float2int_rz(fl[v][d]) : 0;
             mn[d] = i < mn[d] ? i : mn[d]; mx[d] = i > mx[d] ? i : mx[d];
+            if ((corner >> v) & 1) { atomicMin(&clo[d], i); atomicMax(&chi[d], i); }
         }
     }
 #pragma unroll
@@ -994,13 +997,15 @@ __global__ __launch_bounds__(NT1) void own_probe(KParams p, BrickGrid bg, const 
     __syncthreads();
     // the tile's box as the tiles cut it (ops_tiled.hip: Box::build): centred, at most 33 x 33 x 32 lattice points
     const int cap[3] = { 33, 33, 32 };
-    int l[3], h[3], boxvol = 1;
+    int l[3], h[3], boxvol = 1, cornervol = 1;
 #pragma unroll
     for (int d = 0; d < 3; ++d) {
         int a = lo[d], sz = hi[d] + K - a + 1;
         if (sz > cap[d]) { a += (sz - cap[d]) / 2; sz = cap[d]; }
         l[d] = a; h[d] = a + sz - K - 1;
         boxvol *= sz > 0 ? sz : 0;
+        const int cs = chi[d] + K - clo[d] + 1;
+        cornervol *= cs > 0 ? (cs < cap[d] ? cs : cap[d]) : 0;
     }
     int slow = 0, nv = 0;
 #pragma unroll
@@ -1019,16 +1024,20 @@ __global__ __launch_bounds__(NT1) void own_probe(KParams p, BrickGrid bg, const 
     __syncthreads();
     if (tid == 0) {
         atomicAdd(&hdr->nslow, cnt[0]); atomicAdd(&hdr->nfar, cnt[1]); atomicAdd(&hdr->nvalid, cnt[2]);
-        if (cnt[2] == NS) { atomicAdd(&hdr->nbox, boxvol); atomicAdd(&hdr->nfull, 1); }      // (whole tiles: their boxes are comparable)
+        if (cnt[2] == NS) { atomicAdd(&hdr->nbox, boxvol); atomicAdd(&hdr->nfull, 1); atomicAdd(&hdr->ncorner, cornervol); }   // (whole tiles: their boxes are comparable)
         __threadfence();
         if (atomicAdd(&hdr->done, 1) == (int)gridDim.x - 1) {
             const int ns = atomicAdd(&hdr->nslow, 0), nf = atomicAdd(&hdr->nfar, 0), nn = atomicAdd(&hdr->nvalid, 0);
-            const int nb = atomicAdd(&hdr->nbox, 0), nt = atomicAdd(&hdr->nfull, 0);
+            const int nb = atomicAdd(&hdr->nbox, 0), nt = atomicAdd(&hdr->nfull, 0), nc = atomicAdd(&hdr->ncorner, 0);
             // owner-computes when the tiles would leave samples outside their boxes, or -- two channels and more -- when the boxes
             // they flush with global atomics are large (mean above BOXVOL lattice points: i.i.d. noise of sigma ~ 0.9 voxels on a
             // 16^3 tile; the tiles then need 2.9 ms and more at config 2, this file 2.9 - 3.0; a single channel flushes half as
-            // much and stays with the tiles: count 2.1 against 2.5 ms) -- unless samples lie outside the binned range
-            hdr->gate = (((int64_t)ns * 250 > nn || (nch > 1 && (int64_t)nb > (int64_t)BOXVOL * nt)) && (int64_t)nf * 64 <= nn) ? 1 : 0;
+            // much and stays with the tiles: count 2.1 against 2.5 ms) AND it is roughness that makes them large -- they hold 1.6
+            // times the boxes of the tiles' eight corner samples and more; an expanding smooth field has large boxes that hardly
+            // overlap, the tiles flush little more than the target then (zoom 1.5: tiles 4.0, this file 5.5 ms) -- unless samples
+            // lie outside the binned range
+            const bool rough = nch > 1 && (int64_t)nb > (int64_t)BOXVOL * nt && (int64_t)nb * 10 > (int64_t)nc * 16;
+            hdr->gate = (((int64_t)ns * 250 > nn || rough) && (int64_t)nf * 64 <= nn) ? 1 : 0;
         }
     }
 }
