@@ -125,15 +125,18 @@ typedef struct interpol_problem {
 /* interpol_push / interpol_count: organise the scatter OWNER-COMPUTES (push_owner.hip): the samples are
  * first sorted by the 16^3 brick of target lattice points their first tap falls into (one pass over the
  * inputs), then every brick is accumulated in LDS by one workgroup and added to the target with plain
- * loads and stores -- no global atomics but for the thin shell of stencils that leave the lattice.  The
- * cost does not depend on the deformation (4x2x256^3 cubic: 3.9 - 4.4 ms from the identity to i.i.d.
- * noise of sigma = 6 voxels), where the default sample-stationary tiles need the stencils of a 16^3 tile
- * of samples to fit a 33 x 33 x 32 LDS box (2.2 ms at the identity, 3.5 at sigma = 2, 126 at sigma = 6).
+ * loads and stores -- no global atomics: under replicate / dct1 / dct2 the stencils that leave the lattice
+ * are folded back inside the LDS box of the brick at the end of the dim; what lies further out than 9
+ * points, and the other boundary conditions, flush a thin shell of bricks with atomics.  The cost hardly
+ * depends on the deformation (4x2x256^3 cubic: 2.8 - 3.6 ms from the identity to i.i.d. noise of sigma = 6
+ * voxels), where the sample-stationary tiles need the stencils of a 16^3 tile of samples to fit a
+ * 33 x 33 x 32 LDS box (2.2 ms at the identity, 3.5 at sigma = 2, 126 at sigma = 6).
  * 3-D, one order 2..3, float32 coordinates.  Needs the workspace announced by
  * interpol_scatter_workspace(); ignored (tiles / generic kernels) when it does not apply.
  *   INTERPOL_FLAG_BINNED_SCATTER: always;
  *   INTERPOL_FLAG_AUTO_SCATTER:   a probe kernel of the same call examines 128 tiles of the sample grid
- *     and writes a device-side gate; both organisations are enqueued, each kernel reads the gate on
+ *     (owner-computes when samples fall outside the tiles' boxes, or -- two channels and more -- when
+ *     roughness makes those boxes large) and writes a device-side gate; both organisations are enqueued, each kernel reads the gate on
  *     entry and one of the two returns at once (about 50 us of empty launches).  Stateless: the choice
  *     depends on the coordinates of this call alone; safe under hipGraph capture. */
 #define INTERPOL_FLAG_BINNED_SCATTER 64
