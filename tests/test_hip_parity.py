@@ -1227,6 +1227,37 @@ def test_push_bricks_and_binned_push_against_oracle(bound):
         oracle.set_threads(1)
 
 
+@pytest.mark.parametrize("shape", [(32, 34, 35), (33, 49, 50), (51, 36, 47)])
+def test_owner_push_folds_the_end_bricks(shape):
+    """Owner-computes push (csrc/push_owner.hip) on lattices whose end bricks fold: replicate / dct1 / dct2 (mixed with
+    bounds that do not fold), lattice lengths that leave every length of short brick (and none), samples up to 14 voxels
+    outside the lattice on both sides (beyond 9: the shell bricks), both orders, the count channel; against the oracle,
+    and twice -- no atomics are left in the folded dims: the result is the same to the bit."""
+    from interpol import _hip
+    oracle.set_threads(8)
+    try:
+        g = torch.Generator().manual_seed(sum(shape))
+        gshp = (30, 28, 30)                     # (a quarter of a sample per lattice point and more: csrc/push_owner.hip owner_eligible)
+        src = torch.randn([2, 2, *gshp], generator=g)
+        scale = torch.tensor([(n + 27.0) / (m - 1) for n, m in zip(shape, gshp)])
+        grid = (interpol.identity_grid(gshp) * scale - 14.0)[None] + 2.0 * torch.randn([2, *gshp, 3], generator=g)
+        for bounds in ([1, 2, 3], [3, 3, 3], [2, 6, 1], [3, 5, 2], [0, 3, 4]):
+            for order, ex in ((3, 1), (2, 1), (3, 0)):
+                o = [order] * 3
+                got = _hip.scatter("push", src.to(DEV), grid.to(DEV), list(shape), bounds, o, ex, flags=_hip.FLAG_BINNED_SCATTER, with_count=True)
+                wp = oracle.grid_push(src.numpy(), grid.numpy(), list(shape), bounds, o, ex)
+                wc = oracle.grid_count(grid.numpy(), list(shape), bounds, o, ex)
+                G.assert_close(got[:, :2].cpu().numpy(), wp, rtol=1e-5, atol_rel=1e-5, what=("folded push", shape, bounds, order, ex))
+                G.assert_close(got[:, 2:].cpu().numpy(), wc, rtol=1e-5, atol_rel=1e-5, what=("folded count", shape, bounds, order, ex))
+        inner = (interpol.identity_grid(gshp) * torch.tensor([(n - 1.0) / (m - 1) for n, m in zip(shape, gshp)]))[None] \
+            + torch.randn([2, *gshp, 3], generator=g).clamp_(-4, 4)      # stencils leave the lattice by 6 points at most
+        a = _hip.scatter("push", src.to(DEV), inner.to(DEV), list(shape), [3] * 3, [3] * 3, 1, flags=_hip.FLAG_BINNED_SCATTER)
+        b = _hip.scatter("push", src.to(DEV), inner.to(DEV), list(shape), [3] * 3, [3] * 3, 1, flags=_hip.FLAG_BINNED_SCATTER)
+        assert torch.equal(a, b)
+    finally:
+        oracle.set_threads(1)
+
+
 def test_expanding_push_goes_through_bricks_at_api_level():
     """grid_push into a target >= 8x larger than the sample lattice takes the target-stationary
     kernels; the result is that of the scatter kernels (and gradients flow as usual)."""
