@@ -842,7 +842,42 @@ __global__ __launch_bounds__(NT, 4) void own_accumulate(KParams p, BrickGrid bg,
                 }
             }
             // ---- flush: fixed point -> float; the box is re-zeroed on the way
-            if (fixedpt && !(p.dbg & 1)) {
+            if (fixedpt && !atomic && !wide && !(p.dbg & 1)) {
+                // colour launches, channel pairs (the common case): the loads of seven of the thread's lattice points are in flight
+                // at once -- two exposed round trips to the target instead of four; the sums stay in LDS meanwhile
+                constexpr int UF2 = 7;
+#pragma unroll 1
+                for (int e0 = tid; e0 < BOXSLOTS; e0 += UF2 * NT) {
+                    int off[UF2]; float t0[UF2], t1[UF2];
+                    unsigned nz = 0;
+#pragma unroll
+                    for (int u = 0; u < UF2; ++u) {
+                        const int e = e0 + u * NT;
+                        off[u] = 0;
+                        if (e < BOXSLOTS) {
+                            const int xr = e / PLANE, rem = e - xr * PLANE, yr = rem / PZ, zr = rem - yr * PZ;
+                            off[u] = (b0[0] + xr) * L.ss[0] + (b0[1] + yr) * L.ss[1] + (b0[2] + zr) * L.ss[2];
+                            if (sm.box[e] != 0ull) nz |= 1u << u;
+                        }
+                    }
+#pragma unroll
+                    for (int u = 0; u < UF2; ++u) {
+                        t0[u] = ((nz >> u) & 1) ? vc0[off[u]] : 0.f;
+                        t1[u] = (((nz >> u) & 1) && two) ? vc1[off[u]] : 0.f;
+                    }
+#pragma unroll
+                    for (int u = 0; u < UF2; ++u) {
+                        if (!((nz >> u) & 1)) continue;
+                        const int e = e0 + u * NT;
+                        const long long a = (long long)sm.box[e];
+                        sm.box[e] = 0ull;
+                        const int lo_ = (int)(a & 0xffffffffll);
+                        const int hi_ = (int)((a - (long long)lo_) >> 32);
+                        vc0[off[u]] = t0[u] + (float)lo_ * inv0;
+                        if (two) vc1[off[u]] = t1[u] + (float)hi_ * inv1;
+                    }
+                }
+            } else if (fixedpt && !(p.dbg & 1)) {
                 constexpr int UF = 4;
                 // (atomic launches: the slots [rlo, rhi + K] per dim, enumerated with a float reciprocal -- exact: the quotients
                 // stay half a unit away from the integers)
