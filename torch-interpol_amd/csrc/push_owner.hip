@@ -1128,7 +1128,7 @@ static bool owner_eligible(const interpol_problem *p, const KParams &k)
     int64_t n = 1, nv = 1, nb = p->batch;
     for (int d = 0; d < 3; ++d) {
         n *= p->grid_shape[d]; nv *= p->vol_shape[d];
-        nb *= owner::NLO + owner::NHI + (p->vol_shape[d] + 11 + owner::BR - 1) / owner::BR;   // (an upper bound of BrickGrid::nb)
+        nb *= owner::NLO + owner::NHI + (p->vol_shape[d] + 15 + owner::BR - 1) / owner::BR;   // (an upper bound of BrickGrid::nb)
         if (p->grid_shape[d] > 0x7fffffff / 4) return false;
     }
     const int64_t nt = owner::tile_count(p);
