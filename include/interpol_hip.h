@@ -170,7 +170,7 @@ typedef struct interpol_problem {
  *
  * Workspace of the scatters: with INTERPOL_FLAG_BINNED_SCATTER / INTERPOL_FLAG_AUTO_SCATTER, interpol_push /
  * interpol_count first sort the samples by target brick (push_owner.hip), which needs room for the sorted
- * records (16 B per sample + 4 B per sample and further channel, 2 KiB per brick):
+ * records (18 B per sample + 4 B per sample and further channel, 2 KiB per brick):
  * interpol_scatter_workspace(p, count_only) returns the number of bytes `scratch` must then have
  * (it INCLUDES the fp32 accumulator of a BF16 / F16 target, which comes first), or 0 when the
  * organisation does not apply.  With a smaller (or no) scratch the operators fall back to the
