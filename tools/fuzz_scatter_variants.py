@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """Differential fuzz of the target-stationary scatters against the generic kernels: interpol_push_bricks (expanding fields,
-csrc/push_bricks.hip) and INTERPOL_FLAG_BINNED_SCATTER (rough fields, csrc/push_binned.hip) -- random shapes, orders 0-3,
+csrc/push_bricks.hip) and INTERPOL_FLAG_BINNED_SCATTER (owner-computes, csrc/push_owner.hip) -- random shapes, orders 0-3,
 every bound, extrapolation modes, 1-3 channels, count channel, shared targets, expansions 1-5x, noise up to 8 voxels.
 usage: tools/fuzz_scatter_variants.py [n_cases] [seed]"""
 import sys, os, random
@@ -18,7 +18,7 @@ bad = 0
 for case in range(n_cases):
     variant = rnd.choice(["bricks", "binned"])
     B, C = rnd.choice([1, 2, 4]), rnd.choice([1, 2, 3])
-    sshape = [rnd.randint(9, 40) for _ in range(3)]
+    sshape = [rnd.randint(9, 40) for _ in range(3)] if variant == "bricks" else [rnd.randint(12, 56) for _ in range(3)]    # (>= 32: the end bricks fold)
     expand = rnd.choice([1.0, 2.0, 3.3, 5.0]) if variant == "bricks" else rnd.choice([1.0, 1.3])
     tshape = [max(4, int(s * expand) + rnd.randint(-2, 3)) for s in sshape]
     order = [rnd.choice([0, 1, 2, 3, 3])] * 3; bound = [rnd.randrange(7)] * 3 if rnd.random() < 0.6 else [rnd.randrange(7) for _ in range(3)]
