@@ -15,30 +15,34 @@
 //   own_bin        : one workgroup per tile of 16^3 SAMPLE points: coordinates -> brick of the first tap
 //                    (16^3 first-tap cells), counting sort of the tile's samples by brick in LDS, the
 //                    sorted records (coordinates + masked source values as floats) leave as coalesced
-//                    16-byte stores into the tile's own segment of the workspace; one descriptor
-//                    (first record, count) per non-empty (tile, brick) pair is appended to the brick's
-//                    descriptor list (one returning atomic per pair: ~30 per tile).  No count pass, no
-//                    scan: ONE pass over the inputs.
+//                    16-byte stores into the tile's own segment of the workspace, each with the cell of its
+//                    first tap inside the brick (2 bytes); one descriptor (first record, count) per non-empty
+//                    (tile, brick) pair is appended to the brick's descriptor list (one returning atomic per
+//                    pair: ~30 per tile) and the tile's max |source| is folded into the brick's.  No count
+//                    pass, no scan: ONE pass over the inputs.
 //   own_accumulate : one workgroup per TARGET brick walks the runs its descriptors name: density of the
-//                    first-tap cells and max |source| (-> fixed-point scale, tile_common.hpp headroom32),
-//                    then every record adds its (K+1)^3 taps into the brick's LDS box (16 + K lattice
-//                    points per dim) with packed 32-bit fixed-point ds_add_u64 (two channels per atomic),
-//                    and the box is ADDED to the target with plain loads and stores.  Boxes of bricks two
-//                    apart are disjoint, so the bricks are launched in 8 colours (parity of the brick
+//                    first-tap cells (with the brick's max |source| -> fixed-point scale, tile_common.hpp
+//                    headroom32), then every record adds its (K+1)^3 taps into the brick's LDS box (16 + K
+//                    lattice points per dim) with packed 32-bit fixed-point ds_add_u64 (two channels per
+//                    atomic), and the box is ADDED to the target with plain loads and stores.  Boxes of bricks
+//                    two apart are disjoint, so the bricks are launched in 8 colours (parity of the brick
 //                    coordinates): within a launch no two workgroups touch the same lattice point, and
-//                    the launches are ordered by the stream.  Bricks whose box leaves the lattice (the
-//                    boundary condition folds it back: aliasing) go last, with global atomics -- a thin
-//                    shell of the volume.  A target shared by the batch items (batch stride 0) is flushed
-//                    with atomics throughout.
+//                    the launches are ordered by the stream.  Stencils that leave the lattice: under
+//                    replicate / dct1 / dct2 the bricks at the ends of the dim hold them (up to 9 points out)
+//                    and fold that part of the box back inside it in LDS before the flush (BrickGrid below);
+//                    what lies further out, and the other boundary conditions, go last, in a launch of shell
+//                    bricks that flush through the boundary tables with global atomics.  A target shared by
+//                    the batch items (batch stride 0) is flushed with atomics throughout.
 // Samples whose first tap lies outside [-160, n + 160), tiles spread over more than 6 bricks per dim and
 // runs beyond a brick's 128 descriptors are scattered directly with float atomics by own_bin (always
 // correct; the target is zeroed before own_bin and the brick launches come after it on the stream).
 //
 // Sums inside a brick are integer (exact, order-free); the float additions of up to 8 boxes per lattice
-// point happen in the fixed order of the colours: for a given problem the result is bit-reproducible.
+// point happen in the fixed order of the colours: where no atomics are involved (folding dims, samples
+// within 9 points of the lattice) the result is bit-reproducible.
 //
-// Workspace (caller's, interpol_scatter_workspace()): 16 B per sample + 4 B per sample and further
-// channel, 4 + 512 B per brick.
+// Workspace (caller's, interpol_scatter_workspace()): 18 B per sample + 4 B per sample and further
+// channel, 12 + 1024 B per brick.
 // ===========================================================================
 #include "sorted_util.hpp"
 
