@@ -1249,6 +1249,20 @@ def test_owner_push_folds_the_end_bricks(shape):
                 wc = oracle.grid_count(grid.numpy(), list(shape), bounds, o, ex)
                 G.assert_close(got[:, :2].cpu().numpy(), wp, rtol=1e-5, atol_rel=1e-5, what=("folded push", shape, bounds, order, ex))
                 G.assert_close(got[:, 2:].cpu().numpy(), wc, rtol=1e-5, atol_rel=1e-5, what=("folded count", shape, bounds, order, ex))
+        # a stride of 2.2: two thirds of the samples lie beyond the lattice and clamp (replicate) / fold onto its faces, edges and
+        # corner -- the folded sums of the end bricks need the headroom (or the 64-bit sums) of all the points they collect.
+        # (Tolerance 1e-3 of the maximum: the corner collects ~10^5 float additions from the shell bricks, as it does in the
+        # reference's scatter_add_; an overflowing 32-bit sum is off by 3 %.)
+        far = (interpol.identity_grid(gshp) * 2.2 - 0.4)[None].expand(2, *gshp, 3).contiguous()
+        for bounds in ([1, 1, 1], [3, 1, 2]):
+            for order in (2, 3):
+                got = _hip.scatter("push", src.to(DEV), far.to(DEV), list(shape), bounds, [order] * 3, 1, flags=_hip.FLAG_BINNED_SCATTER, with_count=True)
+                wp = oracle.grid_push(src.numpy(), far.numpy(), list(shape), bounds, [order] * 3, 1)
+                wc = oracle.grid_count(far.numpy(), list(shape), bounds, [order] * 3, 1)
+                G.assert_close(got[:, :2].cpu().numpy(), wp, rtol=1e-3, atol_rel=1e-3, what=("clamped push", shape, bounds, order))
+                G.assert_close(got[:, 2:].cpu().numpy(), wc, rtol=1e-3, atol_rel=1e-3, what=("clamped count", shape, bounds, order))
+                got = _hip.scatter("count", None, far.to(DEV), list(shape), bounds, [order] * 3, 1, flags=_hip.FLAG_BINNED_SCATTER)
+                G.assert_close(got.cpu().numpy(), wc, rtol=1e-3, atol_rel=1e-3, what=("clamped count alone", shape, bounds, order))
         inner = (interpol.identity_grid(gshp) * torch.tensor([(n - 1.0) / (m - 1) for n, m in zip(shape, gshp)]))[None] \
             + torch.randn([2, *gshp, 3], generator=g).clamp_(-4, 4)      # stencils leave the lattice by 6 points at most
         a = _hip.scatter("push", src.to(DEV), inner.to(DEV), list(shape), [3] * 3, [3] * 3, 1, flags=_hip.FLAG_BINNED_SCATTER)

@@ -19,12 +19,13 @@ for case in range(n_cases):
     variant = rnd.choice(["bricks", "binned"])
     B, C = rnd.choice([1, 2, 4]), rnd.choice([1, 2, 3])
     sshape = [rnd.randint(9, 40) for _ in range(3)] if variant == "bricks" else [rnd.randint(12, 56) for _ in range(3)]    # (>= 32: the end bricks fold)
-    expand = rnd.choice([1.0, 2.0, 3.3, 5.0]) if variant == "bricks" else rnd.choice([1.0, 1.3])
+    expand = rnd.choice([1.0, 2.0, 3.3, 5.0]) if variant == "bricks" else rnd.choice([1.0, 1.3, 0.45])     # 0.45: half of the samples beyond the lattice
     tshape = [max(4, int(s * expand) + rnd.randint(-2, 3)) for s in sshape]
     order = [rnd.choice([0, 1, 2, 3, 3])] * 3; bound = [rnd.randrange(7)] * 3 if rnd.random() < 0.6 else [rnd.randrange(7) for _ in range(3)]
     ex = rnd.choice([0, 1, 1, 2]); wc = rnd.random() < 0.4 and C < 3; shared = rnd.random() < 0.4
     sigma = rnd.choice([0.0, 0.5, 2.0]) if variant == "bricks" else rnd.choice([0.5, 3.0, 8.0])
     scale = (torch.tensor(tshape, dtype=torch.float32) - 1) / (torch.tensor(sshape, dtype=torch.float32) - 1)
+    if expand < 1: scale = torch.ones(3)                             # (the sample grid keeps its pitch: it overhangs the lattice)
     grid = (interpol.identity_grid(sshape) * scale)[None] + sigma * torch.randn([B, *sshape, 3], generator=gen)
     grid = grid.contiguous().to(dev); src = torch.randn([B, C, *sshape], generator=gen).to(dev)
     try:

@@ -553,6 +553,16 @@ __global__ __launch_bounds__(NT, 4) void own_accumulate(KParams p, BrickGrid bg,
 #pragma unroll
         for (int d = 0; d < 3; ++d) edge = edge || b0[d] < 0 || b0[d] + BOX > L.n[d];
         edge = edge && !atomic;
+        // ... and a lattice point of the box then collects the sums of `foldmul` points: its mirror image per dim (dct1, dct2), all
+        // the points beyond the end (replicate) -- the fixed-point headroom counts them in (many: the 64-bit sums)
+        int foldmul = 1;
+        if (edge) {
+#pragma unroll
+            for (int d = 0; d < 3; ++d) {
+                const int nout = b0[d] < 0 ? -b0[d] : (b0[d] + BOX > L.n[d] ? b0[d] + BOX - L.n[d] : 0);
+                foldmul *= nout == 0 ? 1 : (L.bound[d] == B_REPLICATE ? nout + 1 : 2);
+            }
+        }
         const int brick = (int)b * bg.per_item + (bxyz[0] * bg.nb[1] + bxyz[1]) * bg.nb[2] + bxyz[2];
         int nd = ndesc[brick];
         if (nd == 0) continue;                                       // (block-uniform)
@@ -673,7 +683,7 @@ __global__ __launch_bounds__(NT, 4) void own_accumulate(KParams p, BrickGrid bg,
         }
         __syncthreads();
         prof_mark(10);
-        const int hb = n < 60000 ? tiled::headroom32(L, sm.dmax) : -1;    // (16-bit density counters)
+        const int hb = n < 60000 ? tiled::headroom32(L, sm.dmax * foldmul) : -1;    // (16-bit density counters)
         const bool one_batch = npieces <= NPIECE;
         for (int c = 0; c < nch; c += 2) {
             const bool two = c + 1 < nch;
