@@ -40,7 +40,13 @@ for case in range(n_cases):
                            _hip.scatter("count", None, grid, tshape, bound, order, ex, flags=GEN, shared=shared)))
     except Exception as ex_:
         print("EXCEPTION", case, variant, B, C, sshape, tshape, order, bound, ex, wc, shared, sigma, repr(ex_)); bad += 1; continue
-    if not e <= 2e-4:
+    tol = 2e-4
+    if expand < 1 and not e <= tol:
+        # overhanging sample grids pile thousands of float additions onto the faces of the lattice (replicate: onto single points):
+        # the fp32 generic kernel is itself noisy there -- both are judged against the fp64 generic kernel
+        ref64 = _hip.scatter("push", src.double(), grid.double(), tshape, bound, order, ex, flags=GEN, shared=shared, with_count=wc)
+        e, tol = rel(got.double(), ref64), max(tol, 3.0 * rel(ref.double(), ref64))
+    if not e <= tol:
         bad += 1; print("MISMATCH", case, variant, "B", B, "C", C, sshape, "->", tshape, "order", order, "bound", bound, "ex", ex, "count", wc, "shared", shared, "sigma", sigma, "err %.1e" % e)
 print("fuzz scatter variants: %d cases, %d bad (seed %d)" % (n_cases, bad, seed))
 sys.exit(1 if bad else 0)
