@@ -947,7 +947,9 @@ def test_separable_grid_matches_dense_grid(dim, order):
         _same(a, d, 2e-6, ("count", dim, order, flags))
         ga = _hip.pull_backward(src, vol, sep, b, o, 1, True, False, flags=flags)[0]
         gd = _hip.pull_backward(src, vol, dense, b, o, 1, True, False, flags=flags)[0]
-        _same(ga, gd, 2e-6, ("pull_backward", dim, order, flags))
+        # (dense grid, default flags: the image gradient is a routed push -- the owner-computes kernels sum in 32-bit fixed point
+        # with the headroom of the folding end bricks: 2^-21 of the largest source per term)
+        _same(ga, gd, 6e-6, ("pull_backward", dim, order, flags))
         gva = _hip.push_backward(vol, src, sep, b, o, 1, True, False, flags=flags)[0]
         gvd = _hip.push_backward(vol, src, dense, b, o, 1, True, False, flags=flags)[0]
         _same(gva, gvd, 2e-6, ("push_backward", dim, order, flags))      # sep: generic kernel, dense: tiled
@@ -1001,7 +1003,7 @@ def test_displacement_flag_matches_identity_plus_displacement(dim):
                   _hip.scatter("push", vol, grid, list(shape), b, o, 1, flags=flags), 2e-6, ("push", dim, flags))
             ga = _hip.pull_backward(vol, vol, disp, b, o, 1, True, True, flags=fd)
             gb = _hip.pull_backward(vol, vol, grid, b, o, 1, True, True, flags=flags)
-            _same(ga[0], gb[0], 2e-6, ("pull_backward vol", dim, flags))
+            _same(ga[0], gb[0], 6e-6, ("pull_backward vol", dim, flags))      # (default flags: a routed push in fixed point, see above)
             _same(ga[1], gb[1], 1e-6, ("pull_backward grid", dim, flags))
     # ... and against the ORACLE on identity + displacement (the kernels above could agree and both be wrong)
     vol = torch.randn([2, 2, *shape], generator=g)
