@@ -19,6 +19,16 @@ gathers, target of the scatters -- must span less than 4 GiB of byte offsets (10
 over, 812^3 fp64 too), spatial strides must stay below 2 GiB, D <= 3, CUDA (HIP) tensors only.
 Larger problems raise `ValueError: ... bad or too large extent` from the C-ABI; split them along a
 spatial axis (e.g. `interpol.distributed.grid_pull_slabs` for the sample grid) before calling.
+(The statement about D and CUDA tensors holds for the HIP kernels: CPU tensors and D > 3 run the
+package's PyTorch restatement, `torch_kernels.py`.)
+
+Autograd.  First-order gradients run the fused HIP kernels.  Under `create_graph=True` (double
+backward: gradient penalties, Hessian-vector products) the backward is composed from the
+differentiable Functions of `autograd.py` instead, as the reference composes its backward from torch
+ops (pushpull.py:237-325): the gradient with respect to the grid then materialises `grid_grad`'s
+(B, C, *out, D) tensor -- C x D times the memory of the grid, and a second pass -- and third-order
+derivatives through the grid (a backward of that double backward) raise instead of being dropped
+(`GridGrad.backward` is once-differentiable; the reference, being plain torch, differentiates on).
 """
 import torch
 
