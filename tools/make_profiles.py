@@ -13,7 +13,8 @@ dst = os.path.join(ROOT, "profiles")
 
 
 def dbs(sub):
-    return sorted(glob.glob(os.path.join(src, sub, "**", "*.db"), recursive=True))
+    """databases under gpurun_out/<tag>/<sub>, the most recent first (gpurun merges every run's files into the same directory)"""
+    return sorted(glob.glob(os.path.join(src, sub, "**", "*.db"), recursive=True), key=os.path.getmtime, reverse=True)
 
 
 def counter(db, name, kernel_sub):
