@@ -1391,7 +1391,7 @@ def test_scatter_dynamic_range_and_exact_switch():
 
 
 def test_binned_scatter_rough_deformation_and_modes():
-    """interpol_push / interpol_count with INTERPOL_FLAG_BINNED_SCATTER (target-stationary, push_binned.hip)
+    """interpol_push / interpol_count with INTERPOL_FLAG_BINNED_SCATTER (owner-computes, csrc/push_owner.hip)
     against the oracle: a deformation far too rough for the tiles (sigma = 7 voxels), every bound, samples far
     outside the field of view, the count channel, a shared target, bf16 storage, the backend switch."""
     from interpol import _hip, backend

@@ -183,7 +183,7 @@ if "r" in which:    # config 2 vs the roughness of the deformation: identity + s
         rec(res, "cfg2_push_sigma_%g" % sigma, timeit(lambda: interpol.grid_push(inp, grid, **kw), 3), vox, nb)
         backend.rough_deformations = True
         try:
-            rec(res, "cfg2_push_binned_sigma_%g" % sigma, timeit(lambda: interpol.grid_push(inp, grid, **kw), 3), vox, nb)
+            rec(res, "cfg2_push_owner_sigma_%g" % sigma, timeit(lambda: interpol.grid_push(inp, grid, **kw), 3), vox, nb)
         finally:
             backend.rough_deformations = None
         del inp, grid

@@ -1,6 +1,6 @@
 // ===========================================================================
 // sorted_util.hpp -- helpers shared by the class-sorted tile kernels (ops_sorted.hip) and the
-// binned scatter (push_binned.hip): optimisation fences, packed float pairs, 32-lane scans,
+// owner-computes scatter (push_owner.hip): optimisation fences, packed float pairs, 32-lane scans,
 // tile geometry of the sample grid, coordinate loads, 16-byte loads / stores, the extrapolation
 // mask, the weights of a stencil in packed form, phase profiling, launch helpers.
 // ===========================================================================
