@@ -39,6 +39,15 @@ def mid():
     return _CACHE["mid"]
 
 
+def fold():
+    """Scatter cases on lattices of 33 - 40 points (the end bricks of the owner-computes push fold), sample grids that
+    overhang the lattice, tests/golden/make_golden_fold.py.  Same conventions as mid()."""
+    if "fold" not in _CACHE:
+        with open(os.path.join(HERE, "golden_fold.json")) as f:
+            _CACHE["fold"] = (json.load(f), np.load(os.path.join(HERE, "golden_fold.npz")))
+    return _CACHE["fold"]
+
+
 def arr(name, dtype=np.float64):
     return np.asarray(arrays()[name], dtype=dtype)
 

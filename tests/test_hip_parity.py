@@ -1329,6 +1329,18 @@ def test_golden_mid_fp32(variant, flags):
     assert n >= 80
 
 
+@pytest.mark.parametrize("variant,flags", [("default", 0), ("owner_computes", 64), ("force_tiled", 4), ("generic", 1)])
+def test_golden_fold_fp32(variant, flags):
+    """Reference vectors on lattices of 33 - 40 points with sample grids that overhang them (tests/golden/make_golden_fold.py):
+    the folding end bricks of the owner-computes push (and the shell bricks beyond the folding range) against the reference
+    itself, next to the other organisations."""
+    man, npz = G.fold()
+    for c in man["cases"]:
+        got = _run_mid(c, npz, flags, torch.float32)
+        G.assert_close(got.cpu().numpy(), npz[c["output"]], rtol=1e-5, atol_rel=1e-5, what=(variant, c["tag"], c["op"], c["order"], c["bound"], c["extrapolate"]))
+    assert len(man["cases"]) >= 15
+
+
 @pytest.mark.parametrize("flags", [0, 4])
 def test_golden_mid_bf16_storage(flags):
     """config 5 in miniature: bf16 images (the stored values are bf16-representable), fp32 grid and

@@ -116,6 +116,18 @@ def test_mid_size_cases():
         G.assert_close(got, npz[c["output"]], rtol=2e-7, atol_rel=2e-7, what=str(c))
 
 
+def test_fold_cases():
+    """The oracle against the reference vectors on lattices of 33 - 40 points with overhanging sample grids (the cases
+    that meet the folding end bricks of the owner-computes push on the GPU)."""
+    man, npz = G.fold()
+    assert len(man["cases"]) >= 15
+    for c in man["cases"]:
+        ins = {k: np.asarray(npz[v], dtype=np.float64) for k, v in c["inputs"].items()}
+        b, o, e = c["bound"], c["order"], c["extrapolate"]
+        got = oracle.grid_push(ins["inp"], ins["grid"], c["shape"], b, o, e) if c["op"] == "push" else oracle.grid_count(ins["grid"], c["shape"], b, o, e)
+        G.assert_close(got, npz[c["output"]], rtol=2e-7, atol_rel=2e-7, what=str(c))
+
+
 def test_mid_size_backward():
     from interpol_codes import to_int_lists
     man, npz = G.mid()
