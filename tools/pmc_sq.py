@@ -42,7 +42,7 @@ for i, g in enumerate(GROUPS):
     for db in glob.glob(os.path.join(d, "**", "*.db"), recursive=True):
         try:
             for k, name, v, n in sqlite3.connect(db).execute(Q):
-                if any(s in k for s in ("sorted", "tiled", "t2d", "binned", "bricks", "generic", "copyBuffer", "prefilter", "filter", "owner")):
+                if any(s in k for s in ("sorted", "window", "tiled", "t2d", "binned", "bricks", "generic", "copyBuffer", "prefilter", "filter", "owner")):
                     short = k.split("(")[0].replace("void ip::", "")[:70]
                     res.setdefault(short, {})[name] = v
         except sqlite3.Error as e:

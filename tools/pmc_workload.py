@@ -26,6 +26,9 @@ ops = os.environ.get("PMC_OPS", "pull,push").split(",")
 for _ in range(3):
     if "pull" in ops:
         a = interpol.grid_pull(inp, grid, interpolation=3, bound="dct2", extrapolate=True)
+    if "pull4" in ops:                   # the four-pass tiles (pull_sorted), debug bit 4096
+        from interpol import _hip
+        a = _hip.gather("pull", inp, grid, [3] * 3, [3] * 3, 1, flags=4096 << 8)
     if "push" in ops:
         b = interpol.grid_push(inp, grid, interpolation=3, bound="dct2", extrapolate=True)
 torch.cuda.synchronize()

@@ -300,22 +300,6 @@ struct Tile {
     }
 };
 
-// One out-of-box sample gathered tap-parallel by a wave: lane = tap; returns this lane's products
-// for the two channels (to be summed over the wave) and the sample's extrapolation mask.
-template <typename T, int K, int GM>
-__device__ __forceinline__ void slow_taps(const KParams &p, const Lattice &L, const float *__restrict__ grid, int64_t b, const TileGeom &g,
-                                          int id, int lane, const T *__restrict__ vc0, const T *__restrict__ vc1, float &a0, float &a1, float &m)
-{
-    int ox, oy, oz; float x[3];
-    sample_pos(g, id, ox, oy, oz);
-    load_xyz<GM>(p, grid, b, g, ox, oy, oz, x);
-    int off;
-    const float w = tiled::tap_weight_t<K, K>(L, x[0], x[1], x[2], lane, &off, nullptr);
-    a0 = 0.f; a1 = 0.f;
-    if (lane < (K + 1) * (K + 1) * (K + 1)) { a0 = w * Cvt<float, T>::ld(vc0[off]); a1 = w * Cvt<float, T>::ld(vc1[off]); }
-    m = inb_mask(p, x);
-}
-
 // ---------------------------------------------------------------------------
 // pull: val[b,c,o] = mask * sum_taps w vol        (nd.py:80-143)
 // ---------------------------------------------------------------------------
@@ -1262,11 +1246,18 @@ static int sorted_order(const interpol_problem *p, const KParams &k)
 #define IP_SYM2(a, b) a##b
 #define IP_SYM(a, b) IP_SYM2(a, b)
 
+// the windowed gather (pull_window.hip): every sample visited once
+int IP_SYM(try_window_pull_, IP_TSFX)(const interpol_problem *p, const KParams &k, int K, const void *vol, const void *grid, void *val, hipStream_t st);
+
 // returns 1 when it took the problem, 0 to decline, anything else: error
 int IP_SYM(try_sorted_pull_, IP_TSFX)(const interpol_problem *p, const KParams &k, const void *vol, const void *grid, void *val, hipStream_t st)
 {
     const int K = sorted_order(p, k);
     if (K < 0) return 0;
+    if (!(k.dbg & 4096)) {                                         // A/B switch: the four-pass tiles below
+        const int rc = IP_SYM(try_window_pull_, IP_TSFX)(p, k, K, vol, grid, val, st);
+        if (rc != 0) return rc;
+    }
     using T = IP_TT;
     if (k.sep) {
         if constexpr (std::is_same<T, float>::value) {

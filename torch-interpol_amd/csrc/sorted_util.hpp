@@ -216,6 +216,22 @@ __device__ __forceinline__ float wgrad_x(float t, int i)
     }
 }
 
+// One out-of-box sample gathered tap-parallel by a wave: lane = tap; returns this lane's products
+// for the two channels (to be summed over the wave) and the sample's extrapolation mask.
+template <typename T, int K, int GM>
+__device__ __forceinline__ void slow_taps(const KParams &p, const Lattice &L, const float *__restrict__ grid, int64_t b, const TileGeom &g,
+                                          int id, int lane, const T *__restrict__ vc0, const T *__restrict__ vc1, float &a0, float &a1, float &m)
+{
+    int ox, oy, oz; float x[3];
+    sample_pos(g, id, ox, oy, oz);
+    load_xyz<GM>(p, grid, b, g, ox, oy, oz, x);
+    int off;
+    const float w = tiled::tap_weight_t<K, K>(L, x[0], x[1], x[2], lane, &off, nullptr);
+    a0 = 0.f; a1 = 0.f;
+    if (lane < (K + 1) * (K + 1) * (K + 1)) { a0 = w * Cvt<float, T>::ld(vc0[off]); a1 = w * Cvt<float, T>::ld(vc1[off]); }
+    m = inb_mask(p, x);
+}
+
 // ---------------------------------------------------------------------------
 // Launch helpers
 // ---------------------------------------------------------------------------
