@@ -1,6 +1,7 @@
 #!/usr/bin/env python
-"""A/B of the windowed gather (csrc/pull_window.hip, the default) against the four-pass tiles (debug bit 4096) and the
-generic kernels on a spread of problems, then config-2 timings of both.  usage: tools/ab_window.py [quick]"""
+"""A/B of the pull organisations: the default (four-pass class-sorted tiles + compact tiles chosen per tile), the same
+without compact tiles (debug bit 8192), the windowed gather (csrc/pull_window.hip, debug bit 4096) -- against the generic
+kernels on a spread of problems, then config-2 timings.  usage: tools/ab_window.py [quick]"""
 import os, sys, json, itertools
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "torch-interpol_amd")); sys.path.insert(0, ROOT)
@@ -8,7 +9,8 @@ import torch, interpol
 from interpol import _hip
 import bench
 dev = torch.device("cuda", 0)
-OLD = 4096 << 8
+OLD = 8192 << 8          # no compact tiles
+WIN = 4096 << 8          # the windowed gather
 BOUNDS = {"zero": 0, "replicate": 1, "dct1": 2, "dct2": 3, "dst1": 4, "dst2": 5, "dft": 6}
 
 
@@ -70,16 +72,17 @@ def main():
             ts.append(a.elapsed_time(b) / batch)
         ts.sort(); return ts[len(ts) // 2]
     res = {}
-    for sigma in [2.0, 0.0, 1.0, 4.0]:
+    for sigma in [2.0, 0.0, 0.5, 1.0]:
         inp, grid = bench.make_inputs(4, 2, 256, sigma, dev, 1234)
         for _ in range(10): _hip.gather("pull", inp, grid, [3] * 3, [3] * 3, 1)
         res["sigma%g" % sigma] = {
-            "window": round(timeit(lambda: _hip.gather("pull", inp, grid, [3] * 3, [3] * 3, 1)), 3),
-            "four_pass": round(timeit(lambda: _hip.gather("pull", inp, grid, [3] * 3, [3] * 3, 1, flags=OLD)), 3),
-            "window_quadratic": round(timeit(lambda: _hip.gather("pull", inp, grid, [3] * 3, [2] * 3, 1)), 3),
-            "window_nostage": round(timeit(lambda: _hip.gather("pull", inp, grid, [3] * 3, [3] * 3, 1, flags=1 << 8)), 3),
-            "window_notaps": round(timeit(lambda: _hip.gather("pull", inp, grid, [3] * 3, [3] * 3, 1, flags=2 << 8)), 3),
-            "window_neither": round(timeit(lambda: _hip.gather("pull", inp, grid, [3] * 3, [3] * 3, 1, flags=3 << 8)), 3),
+            "default": round(timeit(lambda: _hip.gather("pull", inp, grid, [3] * 3, [3] * 3, 1)), 3),
+            "no_compact": round(timeit(lambda: _hip.gather("pull", inp, grid, [3] * 3, [3] * 3, 1, flags=OLD)), 3),
+            "window": round(timeit(lambda: _hip.gather("pull", inp, grid, [3] * 3, [3] * 3, 1, flags=WIN)), 3),
+            "default_quadratic": round(timeit(lambda: _hip.gather("pull", inp, grid, [3] * 3, [2] * 3, 1)), 3),
+            "default_nostage": round(timeit(lambda: _hip.gather("pull", inp, grid, [3] * 3, [3] * 3, 1, flags=1 << 8)), 3),
+            "default_notaps": round(timeit(lambda: _hip.gather("pull", inp, grid, [3] * 3, [3] * 3, 1, flags=2 << 8)), 3),
+            "default_neither": round(timeit(lambda: _hip.gather("pull", inp, grid, [3] * 3, [3] * 3, 1, flags=3 << 8)), 3),
         }
         a = _hip.gather("pull", inp, grid, [3] * 3, [3] * 3, 1)
         b_ = _hip.gather("pull", inp, grid, [3] * 3, [3] * 3, 1, flags=OLD)
@@ -87,8 +90,8 @@ def main():
         del inp, grid, a, b_
     grid = bench.smooth_grid(4, 256, 2.0, dev, 7)
     inp = torch.randn([4, 2, 256, 256, 256], device=dev)
-    res["smooth"] = {"window": round(timeit(lambda: _hip.gather("pull", inp, grid, [3] * 3, [3] * 3, 1)), 3),
-                     "four_pass": round(timeit(lambda: _hip.gather("pull", inp, grid, [3] * 3, [3] * 3, 1, flags=OLD)), 3)}
+    res["smooth"] = {"default": round(timeit(lambda: _hip.gather("pull", inp, grid, [3] * 3, [3] * 3, 1)), 3),
+                     "no_compact": round(timeit(lambda: _hip.gather("pull", inp, grid, [3] * 3, [3] * 3, 1, flags=OLD)), 3)}
     print(json.dumps(res, indent=1))
 
 

@@ -1254,7 +1254,7 @@ int IP_SYM(try_sorted_pull_, IP_TSFX)(const interpol_problem *p, const KParams &
 {
     const int K = sorted_order(p, k);
     if (K < 0) return 0;
-    if (!(k.dbg & 4096)) {                                         // A/B switch: the four-pass tiles below
+    if (k.dbg & 4096) {                                            // opt-in: the windowed gather (experimental: 1.75 ms against 1.35 ms at config 2)
         const int rc = IP_SYM(try_window_pull_, IP_TSFX)(p, k, K, vol, grid, val, st);
         if (rc != 0) return rc;
     }
