@@ -1168,6 +1168,15 @@ struct TileCount {
         const long long total = (long long)ntiles() * B, want = 2ll * cu_count();
         return dim3((unsigned)(total < want ? total : want), 1u);
     }
+    // one workgroup per tile: 8 * ceil(total / 8) workgroups, of which WorkRange (tile_common.hpp) gives each exactly one tile
+    // of its XCD's eighth -- the dispatcher, not a stride, balances tiles of unequal cost; `mult` tiles per workgroup otherwise
+    dim3 grid_each(int B, int mult) const
+    {
+        const long long total = (long long)ntiles() * B;
+        if (total < 8) return dim3((unsigned)total, 1u);
+        const long long per = (total + 7) >> 3, wg = (per + mult - 1) / mult;
+        return dim3((unsigned)(8 * wg), 1u);
+    }
 };
 
 template <typename T, int K, int GM>
@@ -1177,7 +1186,10 @@ static int launch_pull(const interpol_problem *p, const KParams &k, const void *
     if (attr) return attr;
     const TileCount t(p);
     const Defer df(k, st, t.ntiles(), p->batch, t.ntx, t.nty, t.ntz, TS, TS, TS);
-    hipLaunchKernelGGL((pull_sorted<T, K, GM>), t.grid((int)p->batch), dim3(NT), sizeof(Smem), st,
+    // two tiles per workgroup, dealt by the dispatcher as workgroups retire: 1.36 -> 1.28 ms at config 2 against two persistent
+    // workgroups per CU walking equal shares (tiles differ in cost: slow lists, box sizes); debug bits 13-15: 7 = persistent, 1-4 = tiles
+    const int mopt = (k.dbg >> 13) & 7, mult = mopt == 0 ? 2 : mopt;
+    hipLaunchKernelGGL((pull_sorted<T, K, GM>), mopt == 7 ? t.grid((int)p->batch) : t.grid_each((int)p->batch, mult), dim3(NT), sizeof(Smem), st,
                        k, (const T *)vol, (const float *)grid, (T *)val, t.gx, t.gy, t.gz, t.nty, t.ntz, t.ntiles(), (int)p->batch, df.args);
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) return (int)e;
@@ -1192,7 +1204,8 @@ static int launch_gradc(const interpol_problem *p, const KParams &k, const void 
     if (attr) return attr;
     const TileCount t(p);
     const Defer df(k, st, t.ntiles(), p->batch, t.ntx, t.nty, t.ntz, TS, TS, TS);
-    hipLaunchKernelGGL((gradc_sorted<T, K, GM>), t.grid((int)p->batch), dim3(NT), sizeof(Smem), st,
+    const int mopt = (k.dbg >> 13) & 7, mult = mopt == 0 ? 2 : mopt;   // (as launch_pull)
+    hipLaunchKernelGGL((gradc_sorted<T, K, GM>), mopt == 7 ? t.grid((int)p->batch) : t.grid_each((int)p->batch, mult), dim3(NT), sizeof(Smem), st,
                        k, (const T *)vol, (const T *)gout, (const float *)grid, (float *)ggrid, t.gx, t.gy, t.gz, t.nty, t.ntz, t.ntiles(), (int)p->batch, df.args);
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) return (int)e;
