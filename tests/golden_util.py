@@ -97,18 +97,23 @@ def run_case(ops, case, dtype):
     raise ValueError(op)
 
 
-def fp32_tol(case_or_order):
-    """Stated fp32 parity tolerance (rtol, atol relative to max|ref|).
+def fp32_tol(case_or_order=None):
+    """Stated fp32 parity tolerance (rtol, atol relative to max|ref|): north_star's rtol = 1e-5 with atol = 1e-5 max|ref|
+    (SURVEY A.8), for EVERY spline order.  The goldens are the reference's float64 outputs; the kernels evaluate the
+    middle pieces of the order 4-7 splines about their outer breakpoints (csrc/spline_math.hpp), which keeps the fp32
+    weights within 1e-7 of the exact ones where the reference's own fp32 Horner forms (splines.py:56-79) lose five
+    digits.  Measured worst errors, in units of this tolerance: tests/tolerance_report.py -> profiles/r04_tolerance.txt."""
+    return (1e-5, 1e-5)
 
-    SURVEY A.8 calibrated rtol=1e-5, atol=1e-5*max|ref| on the reference's own
-    fp32-vs-fp64 discrepancy for orders <= 5.  For orders 6 and 7 the reference's
-    fp32 Horner polynomials (splines.py:56-79) cancel near the knots and its own
-    fp32 result deviates from its fp64 result by up to 1.3e-5*max|ref| (measured
-    on these vectors), so the bound is 5e-5 there."""
+
+def reference_fp32_tol(case_or_order):
+    """What the REFERENCE's own fp32 arithmetic achieves against its fp64 outputs (the oracle's fp32 mode restates it,
+    tests/test_oracle_golden.py): rtol 1e-5 with atol 1e-5 max|ref| up to order 5; for orders 6 and 7 its Horner polynomials
+    (splines.py:56-79) cancel near the knots and it deviates by up to 1.3e-5 max|ref| on these vectors: 5e-5 there.  The HIP
+    kernels are held to fp32_tol() for every order."""
     order = case_or_order["order"] if isinstance(case_or_order, dict) else case_or_order
     order = order if isinstance(order, (list, tuple)) else [order]
-    hi = max(order) >= 6
-    return (1e-5, 5e-5) if hi else (1e-5, 1e-5)
+    return (1e-5, 5e-5) if max(order) >= 6 else (1e-5, 1e-5)
 
 
 def resize_cases():

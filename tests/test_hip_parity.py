@@ -5,7 +5,7 @@ at larger sizes (adjointness, partition of unity, linearity, count == push(1),
 bit-exact nearest neighbour).
 
 Stated tolerances: fp64 1e-11*max|ref|; fp32 rtol 1e-5 + atol 1e-5*max|ref|
-(5e-5 for spline orders 6-7, see golden_util.fp32_tol); bf16/f16 1e-2; order-0
+(all spline orders, see golden_util.fp32_tol); bf16/f16 1e-2; order-0
 pull bit-exact."""
 import numpy as np
 import pytest
@@ -118,7 +118,7 @@ def test_low_precision_storage(dtype, tol):
 
 def test_prefilter_golden():
     for c in G.manifest()["prefilter"]:
-        for dtype, tol in ((torch.float64, 1e-10), (torch.float32, 2e-5)):
+        for dtype, tol in ((torch.float64, 1e-10), (torch.float32, 1e-5)):
             x = torch.from_numpy(G.arr(c["inp"])).to(DEV, dtype)
             if c["fn"] == "spline_coeff":
                 got = interpol.spline_coeff(x, interpolation=c["order"], bound=c["bound"], dim=c["dim"])
@@ -130,7 +130,7 @@ def test_prefilter_golden():
 def test_backward_golden():
     """API-level autograd (fused backward kernels) vs the reference's autograd."""
     for c in G.manifest()["backward"]:
-        for dtype, tol in ((torch.float64, 1e-11), (torch.float32, 3e-5)):
+        for dtype, tol in ((torch.float64, 1e-11), (torch.float32, 1e-5)):
             kw = dict(interpolation=c["interpolation"], bound=c["bound"], extrapolate=c["extrapolate"])
             grid = torch.from_numpy(G.arr(c["grid"])).to(DEV, dtype).requires_grad_(True)
             gout = torch.from_numpy(G.arr(c["gout"])).to(DEV, dtype)
@@ -408,11 +408,11 @@ def test_tiled_gather_matches_generic(dim, order, sigma):
             for op in ("pull", "grad"):
                 fast = _hip.gather(op, inp, grid, b, o, ex, flags=_hip.FLAG_FORCE_TILED)
                 slow = _hip.gather(op, inp, grid, b, o, ex, flags=_hip.FLAG_NO_FASTPATH)
-                _same(fast, slow, 4e-6 if order < 6 else 2e-5, (op, dim, bound, ex, order, sigma))
+                _same(fast, slow, 4e-6 if order < 6 else 6e-6, (op, dim, bound, ex, order, sigma))
     mixed = [4, 2, 6][:dim]
     fast = _hip.gather("pull", inp, grid, mixed, [order] * dim, 1)
     slow = _hip.gather("pull", inp, grid, mixed, [order] * dim, 1, flags=_hip.FLAG_NO_FASTPATH)
-    _same(fast, slow, 4e-6 if order < 6 else 2e-5, "mixed bounds")
+    _same(fast, slow, 4e-6 if order < 6 else 6e-6, "mixed bounds")
 
 
 @pytest.mark.parametrize("dim", [3, 2])
@@ -440,7 +440,7 @@ def test_tiled_scatter_matches_generic(dim, order, sigma):
         gg = _hip.gather("grad", vol, grid, b, o, ex, flags=_hip.FLAG_NO_FASTPATH)
         want_ggrid = (gg * src.unsqueeze(-1)).sum(1)
         _same(gvol, want_gvol, 1e-5, ("bwd gvol", dim, bound, ex, order, sigma))
-        _same(ggrid, want_ggrid, 2e-5 if order < 6 else 1e-4, ("bwd ggrid", dim, bound, ex, order, sigma))
+        _same(ggrid, want_ggrid, 2e-5, ("bwd ggrid", dim, bound, ex, order, sigma))
         only_grid = _hip.pull_backward(src, vol, grid, b, o, ex, False, True)
         assert only_grid[0] is None
         # (not bit for bit: in tiles whose slow list overflows -- the far-outside samples of this problem blow the box up --
@@ -751,7 +751,7 @@ def test_tiled_mixed_orders_match_generic(dim, orders, sigma):
     from interpol import _hip
     inp, grid, ishape, oshape = _tiled_problem(dim, sigma, seed=int(sum(orders) * 10 + sigma) + dim)
     src = torch.randn([2, 3, *oshape], generator=torch.Generator().manual_seed(12)).to(DEV)
-    tol = 2e-5 if max(orders) >= 6 else 4e-6
+    tol = 6e-6 if max(orders) >= 6 else 4e-6
     for bounds in ([2, 5, 0][:dim], [6, 1, 3][:dim], [4, 4, 4][:dim]):
         for ex in (1, 0):
             for op in ("pull", "grad"):
@@ -765,7 +765,7 @@ def test_tiled_mixed_orders_match_generic(dim, orders, sigma):
         want_gvol = _hip.scatter("push", src, grid, list(ishape), bounds, orders, 1, flags=_hip.FLAG_NO_FASTPATH)
         gg = _hip.gather("grad", inp, grid, bounds, orders, 1, flags=_hip.FLAG_NO_FASTPATH)
         _same(gvol, want_gvol, 1e-5, "bwd gvol")
-        _same(ggrid, (gg * src.unsqueeze(-1)).sum(1), 1e-4 if max(orders) >= 6 else 2e-5, "bwd ggrid")
+        _same(ggrid, (gg * src.unsqueeze(-1)).sum(1), 2e-5, "bwd ggrid")
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
@@ -793,7 +793,7 @@ def test_tiled_low_precision_storage_matches_generic(dtype, dim, orders):
     _same(gvol.float(), slow.float(), 2 * eps, ("bwd gvol", dtype, dim))
 
 
-@pytest.mark.parametrize("dtype,tol", [(torch.float64, 1e-10), (torch.float32, 3e-5)])
+@pytest.mark.parametrize("dtype,tol", [(torch.float64, 1e-10), (torch.float32, 1e-5)])
 @pytest.mark.parametrize("inner", [1, 16, 33, 3])
 def test_prefilter_kernels_against_oracle(dtype, tol, inner):
     """All three prefilter kernels (wave-per-line scan for contiguous lines, chunked
@@ -842,7 +842,7 @@ def test_tiled_pull_channel_pairs_match_generic(order, sigma):
             b, o = [bound] * 3, [order] * 3
             fast = _hip.gather("pull", inp, grid, b, o, ex)
             slow = _hip.gather("pull", inp, grid, b, o, ex, flags=_hip.FLAG_NO_FASTPATH)
-            _same(fast, slow, 4e-6 if order < 6 else 2e-5, ("pull2", bound, ex, order, sigma))
+            _same(fast, slow, 4e-6 if order < 6 else 6e-6, ("pull2", bound, ex, order, sigma))
     fast = _hip.gather("pull", inp.to(torch.bfloat16), grid, [3] * 3, [order] * 3, 1)
     slow = _hip.gather("pull", inp.to(torch.bfloat16), grid, [3] * 3, [order] * 3, 1, flags=_hip.FLAG_NO_FASTPATH)
     _same(fast.float(), slow.float(), 2 ** -6, "pull2 bf16")

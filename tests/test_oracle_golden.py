@@ -24,7 +24,7 @@ def test_ops_fp32(op):
     for c in _cases(op):
         got = G.run_case(oracle, c, np.float32)
         assert got.dtype == np.float32
-        rtol, atol_rel = G.fp32_tol(c)
+        rtol, atol_rel = G.reference_fp32_tol(c)           # (the oracle's fp32 mode IS the reference's fp32 arithmetic)
         G.assert_close(got, G.arr(c["output"]), rtol=rtol, atol_rel=atol_rel, what=str(c))
 
 

@@ -46,7 +46,8 @@ IP_HD R bspline_w(int order, R t, int piece = -1)
     case 4: {
         R x2 = x * x;
         R lo = x2 * (x2 * R(0.25) - R(0.625)) + R(115. / 192.);
-        R mid = x * (x * (x * (R(5) - x) * R(1. / 6.) - R(1.25)) + R(5. / 24.)) + R(55. / 96.);
+        R v = R(1.5) - x;                                             // (the middle piece about its outer breakpoint, see order 6)
+        R mid = (((R(-1. / 6.) * v + R(1. / 6.)) * v + R(0.25)) * v + R(1. / 6.)) * v + R(1. / 24.);
         R u = x - R(2.5); u = u * u;
         R up = (u * u) * R(1. / 24.);
         return piece < 0 ? (x < R(0.5) ? lo : (x < R(1.5) ? mid : up)) : (piece == 0 ? lo : (piece == 1 ? mid : up));
@@ -54,7 +55,8 @@ IP_HD R bspline_w(int order, R t, int piece = -1)
     case 5: {
         R x2 = x * x;
         R lo = x2 * (x2 * (R(0.25) - x * R(1. / 12.)) - R(0.5)) + R(0.55);
-        R mid = x * (x * (x * (x * (x * R(1. / 24.) - R(0.375)) + R(1.25)) - R(1.75)) + R(0.625)) + R(0.425);
+        R v = R(2) - x;                                               // (the middle piece about its outer breakpoint, see order 6)
+        R mid = ((((R(-1. / 24.) * v + R(1. / 24.)) * v + R(1. / 12.)) * v + R(1. / 12.)) * v + R(1. / 24.)) * v + R(1. / 120.);
         R u = R(3) - x; R u2 = u * u;
         R up = (u * u2 * u2) * R(1. / 120.);
         return piece < 0 ? (x < R(1) ? lo : (x < R(2) ? mid : up)) : (piece == 0 ? lo : (piece == 1 ? mid : up));
@@ -62,8 +64,12 @@ IP_HD R bspline_w(int order, R t, int piece = -1)
     case 6: {
         R x2 = x * x;
         R lo = x2 * (x2 * (R(7. / 48.) - x2 * R(1. / 36.)) - R(77. / 192.)) + R(5887. / 11520.);
-        R ml = x * (x * (x * (x * (x * (x * R(1. / 48.) - R(7. / 48.)) + R(0.328125)) - R(35. / 288.)) - R(91. / 256.)) - R(7. / 768.)) + R(7861. / 15360.);
-        R mu = x * (x * (x * (x * (x * (R(7. / 60.) - x * R(1. / 120.)) - R(0.65625)) + R(133. / 72.)) - R(2.5703125)) + R(1267. / 960.)) + R(1379. / 7680.);
+        // (the middle pieces are expanded about their OUTER breakpoint, v = 1.5 - x and 2.5 - x in (0, 1]: the same polynomials as
+        //  splines.py:60-66, but Horner in x sums terms of order 1 to a value of order 1e-3 and loses five digits in fp32)
+        R v = R(1.5) - x;
+        R ml = (((((R(1. / 48.) * v - R(1. / 24.)) * v - R(1. / 16.)) * v + R(1. / 36.)) * v + R(3. / 16.)) * v + R(5. / 24.)) * v + R(19. / 240.);
+        v = R(2.5) - x;
+        R mu = (((((R(-1. / 120.) * v + R(1. / 120.)) * v + R(1. / 48.)) * v + R(1. / 36.)) * v + R(1. / 48.)) * v + R(1. / 120.)) * v + R(1. / 720.);
         R u = x - R(3.5); R u3 = u * u * u;
         R up = (u3 * u3) * R(1. / 720.);
         return piece < 0 ? (x < R(0.5) ? lo : (x < R(1.5) ? ml : (x < R(2.5) ? mu : up))) : (piece == 0 ? lo : (piece == 1 ? ml : (piece == 2 ? mu : up)));
@@ -71,8 +77,11 @@ IP_HD R bspline_w(int order, R t, int piece = -1)
     case 7: {
         R x2 = x * x;
         R lo = x2 * (x2 * (x2 * (x * R(1. / 144.) - R(1. / 36.)) + R(1. / 9.)) - R(1. / 3.)) + R(151. / 315.);
-        R ml = x * (x * (x * (x * (x * (x * (R(0.05) - x * R(1. / 240.)) - R(7. / 30.)) + R(0.5)) - R(7. / 18.)) - R(0.1)) - R(7. / 90.)) + R(103. / 210.);
-        R mu = x * (x * (x * (x * (x * (x * (x * R(1. / 720.) - R(1. / 36.)) + R(7. / 30.)) - R(19. / 18.)) + R(49. / 18.)) - R(23. / 6.)) + R(217. / 90.)) - R(139. / 630.);
+        // (middle pieces about their outer breakpoint, v = 2 - x and 3 - x in (0, 1]: splines.py:70-76 re-expanded, see order 6)
+        R v = R(2) - x;
+        R ml = ((((((R(1. / 240.) * v - R(1. / 120.)) * v - R(1. / 60.)) * v) * v + R(1. / 18.)) * v + R(1. / 10.)) * v + R(7. / 90.)) * v + R(1. / 42.);
+        v = R(3) - x;
+        R mu = ((((((R(-1. / 720.) * v + R(1. / 720.)) * v + R(1. / 240.)) * v + R(1. / 144.)) * v + R(1. / 144.)) * v + R(1. / 240.)) * v + R(1. / 720.)) * v + R(1. / 5040.);
         R u = R(4) - x; R u3 = u * u * u;
         R up = (u3 * u3 * u) * R(1. / 5040.);
         return piece < 0 ? (x < R(1) ? lo : (x < R(2) ? ml : (x < R(3) ? mu : up))) : (piece == 0 ? lo : (piece == 1 ? ml : (piece == 2 ? mu : up)));
@@ -104,7 +113,8 @@ IP_HD R bspline_g(int order, R t, int piece = -1)
     case 4: {
         R u = R(2) * x - R(5);
         R lo = x * (x * x - R(1.25));
-        R mid = x * (x * (x * R(-2. / 3.) + R(2.5)) - R(2.5)) + R(5. / 24.);
+        R v = R(1.5) - x;
+        R mid = ((R(2. / 3.) * v - R(0.5)) * v - R(0.5)) * v - R(1. / 6.);
         R up = (u * u * u) * R(1. / 48.);
         r = piece < 0 ? (x < R(0.5) ? lo : (x < R(1.5) ? mid : up)) : (piece == 0 ? lo : (piece == 1 ? mid : up));
         break;
@@ -112,7 +122,8 @@ IP_HD R bspline_g(int order, R t, int piece = -1)
     case 5: {
         R u = x - R(3); u = u * u;
         R lo = x * (x * (x * (x * R(-5. / 12.) + R(1))) - R(1));
-        R mid = x * (x * (x * (x * R(5. / 24.) - R(1.5)) + R(3.75)) - R(3.5)) + R(0.625);
+        R v = R(2) - x;
+        R mid = (((R(5. / 24.) * v - R(1. / 6.)) * v - R(0.25)) * v - R(1. / 6.)) * v - R(1. / 24.);
         R up = (u * u) * R(-1. / 24.);
         r = piece < 0 ? (x < R(1) ? lo : (x < R(2) ? mid : up)) : (piece == 0 ? lo : (piece == 1 ? mid : up));
         break;
@@ -121,8 +132,10 @@ IP_HD R bspline_g(int order, R t, int piece = -1)
         R x2 = x * x;
         R u = R(2) * x - R(7); R u2 = u * u;
         R lo = x * (x2 * R(7. / 12.) - (x2 * x2) * R(1. / 6.) - R(77. / 96.));
-        R ml = x * (x * (x * (x * (x * R(0.125) - R(35. / 48.)) + R(1.3125)) - R(35. / 96.)) - R(0.7109375)) - R(7. / 768.);
-        R mu = x * (x * (x * (x * (x * R(-1. / 20.) + R(7. / 12.)) - R(2.625)) + R(133. / 24.)) - R(5.140625)) + R(1267. / 960.);
+        R v = R(1.5) - x;                                             // (about the outer breakpoint, see bspline_w)
+        R ml = ((((R(-1. / 8.) * v + R(5. / 24.)) * v + R(1. / 4.)) * v - R(1. / 12.)) * v - R(3. / 8.)) * v - R(5. / 24.);
+        v = R(2.5) - x;
+        R mu = ((((R(1. / 20.) * v - R(1. / 24.)) * v - R(1. / 12.)) * v - R(1. / 12.)) * v - R(1. / 24.)) * v - R(1. / 120.);
         R up = (u * u2 * u2) * R(1. / 3840.);
         r = piece < 0 ? (x < R(0.5) ? lo : (x < R(1.5) ? ml : (x < R(2.5) ? mu : up))) : (piece == 0 ? lo : (piece == 1 ? ml : (piece == 2 ? mu : up)));
         break;
@@ -131,8 +144,10 @@ IP_HD R bspline_g(int order, R t, int piece = -1)
         R x2 = x * x;
         R u = x - R(4); R u3 = u * u * u;
         R lo = x * (x2 * (x2 * (x * R(7. / 144.) - R(1. / 6.)) + R(4. / 9.)) - R(2. / 3.));
-        R ml = x * (x * (x * (x * (x * (x * R(-7. / 240.) + R(3. / 10.)) - R(7. / 6.)) + R(2)) - R(7. / 6.)) - R(1. / 5.)) - R(7. / 90.);
-        R mu = x * (x * (x * (x * (x * (x * R(7. / 720.) - R(1. / 6.)) + R(7. / 6.)) - R(38. / 9.)) + R(49. / 6.)) - R(23. / 3.)) + R(217. / 90.);
+        R v = R(2) - x;                                               // (about the outer breakpoint, see bspline_w)
+        R ml = (((((R(-7. / 240.) * v + R(1. / 20.)) * v + R(1. / 12.)) * v) * v - R(1. / 6.)) * v - R(1. / 5.)) * v - R(7. / 90.);
+        v = R(3) - x;
+        R mu = (((((R(7. / 720.) * v - R(1. / 120.)) * v - R(1. / 48.)) * v - R(1. / 36.)) * v - R(1. / 48.)) * v - R(1. / 120.)) * v - R(1. / 720.);
         R up = (u3 * u3) * R(-1. / 720.);
         r = piece < 0 ? (x < R(1) ? lo : (x < R(2) ? ml : (x < R(3) ? mu : up))) : (piece == 0 ? lo : (piece == 1 ? ml : (piece == 2 ? mu : up)));
         break;
@@ -155,28 +170,36 @@ IP_HD R bspline_h(int order, R t)
     case 4: {
         R u = R(2) * x - R(5);
         return x < R(0.5) ? R(3) * (x * x) - R(1.25)
-             : (x < R(1.5) ? x * (R(-2) * x + R(5)) - R(2.5) : (u * u) * R(0.125));
+             : (x < R(1.5) ? (R(-2) * (R(1.5) - x) + R(1)) * (R(1.5) - x) + R(0.5) : (u * u) * R(0.125));
     }
     case 5: {
         R lo = -(x * x) * (x * R(5. / 3.) - R(3)) - R(1);
-        R mid = x * (x * (x * R(5. / 6.) - R(4.5)) + R(7.5)) - R(3.5);
-        R up = R(4.5) - x * (x * (x * R(1. / 6.) - R(1.5)) + R(4.5));
+        R v = R(2) - x;
+        R mid = ((R(-5. / 6.) * v + R(0.5)) * v + R(0.5)) * v + R(1. / 6.);
+        R u = R(3) - x;
+        R up = (u * u * u) * R(1. / 6.);                              // (= 4.5 - x (x (x / 6 - 1.5) + 4.5), splines.py:173, without the cancellation)
         return x < R(1) ? lo : (x < R(2) ? mid : up);
     }
     case 6: {
         R x2 = x * x;
         R lo = -x2 * (x2 * R(5. / 6.) - R(1.75)) - R(77. / 96.);
-        R ml = x * (x * (x * (x * R(0.625) - R(35. / 12.)) + R(63. / 16.)) - R(35. / 48.)) - R(91. / 128.);
-        R mu = -(x * (x * (x * (x * R(0.25) - R(7. / 3.)) + R(63. / 8.)) - R(133. / 12.)) + R(329. / 64.));
-        R up = x * (x * (x * (x * R(1. / 24.) - R(7. / 12.)) + R(49. / 16.)) - R(343. / 48.)) + R(2401. / 384.);
+        R v = R(1.5) - x;                                             // (about the outer breakpoint, see bspline_w)
+        R ml = (((R(5. / 8.) * v - R(5. / 6.)) * v - R(3. / 4.)) * v + R(1. / 6.)) * v + R(3. / 8.);
+        v = R(2.5) - x;
+        R mu = (((R(-1. / 4.) * v + R(1. / 6.)) * v + R(1. / 4.)) * v + R(1. / 6.)) * v + R(1. / 24.);
+        R u = x - R(3.5); u = u * u;
+        R up = (u * u) * R(1. / 24.);                                 // (the outer piece as a power of the distance to the end of the support)
         return x < R(0.5) ? lo : (x < R(1.5) ? ml : (x < R(2.5) ? mu : up));
     }
     case 7: {
         R x2 = x * x;
         R lo = x2 * (x2 * (x * R(7. / 24.) - R(5. / 6.)) + R(4. / 3.)) - R(2. / 3.);
-        R ml = -(x * (x * (x * (x * (x * R(7. / 40.) - R(1.5)) + R(14. / 3.)) - R(6)) + R(7. / 3.)) + R(0.2));
-        R mu = x * (x * (x * (x * (x * R(7. / 120.) - R(5. / 6.)) + R(14. / 3.)) - R(38. / 3.)) + R(49. / 3.)) - R(23. / 3.);
-        R up = -(x * (x * (x * (x * (x * R(1. / 120.) - R(1. / 6.)) + R(4. / 3.)) - R(16. / 3.)) + R(32. / 3.)) - R(128. / 15.));
+        R v = R(2) - x;                                               // (about the outer breakpoint, see bspline_w)
+        R ml = ((((R(7. / 40.) * v - R(1. / 4.)) * v - R(1. / 3.)) * v) * v + R(1. / 3.)) * v + R(1. / 5.);
+        v = R(3) - x;
+        R mu = ((((R(-7. / 120.) * v + R(1. / 24.)) * v + R(1. / 12.)) * v + R(1. / 12.)) * v + R(1. / 24.)) * v + R(1. / 120.);
+        R u = R(4) - x; R u2 = u * u;
+        R up = (u * u2 * u2) * R(1. / 120.);
         return x < R(1) ? lo : (x < R(2) ? ml : (x < R(3) ? mu : up));
     }
     default: return R(0);
