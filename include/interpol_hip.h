@@ -173,8 +173,8 @@ typedef struct interpol_problem {
  * records (18 B per sample + 4 B per sample and further channel, 2 KiB per brick):
  * interpol_scatter_workspace(p, count_only) returns the number of bytes `scratch` must then have
  * (it INCLUDES the fp32 accumulator of a BF16 / F16 target, which comes first), or 0 when the
- * organisation does not apply.  With a smaller (or no) scratch the operators fall back to the
- * tiled / generic scatters: same results.
+ * organisation does not apply.  With a smaller (or no) scratch -- or one that is not aligned to 256 bytes (the
+ * workspace holds 8- and 16-byte records) -- the operators fall back to the tiled / generic scatters: same results.
  * --------------------------------------------------------------------------- */
 int64_t interpol_scatter_workspace(const interpol_problem *p, int32_t count_only);
 int interpol_pull(const interpol_problem *p, const void *vol, const void *grid, void *val, void *stream);

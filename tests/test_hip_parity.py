@@ -1440,6 +1440,29 @@ def test_binned_scatter_rough_deformation_and_modes():
     G.assert_close(a.cpu().numpy(), oracle.grid_push(src.numpy(), grid.numpy(), list(shp), [3], [3], 1), rtol=1e-5, atol_rel=1e-5, what="backend switch")
 
 
+def test_owner_push_more_tiles_per_brick_than_descriptors():
+    """A strongly contracting field (96^3 samples into 16^3 cells of the lattice): more than the 128 (tile, brick) runs a
+    brick's descriptor list holds -- the orphan runs are scattered directly, and their places in the sorted order must not
+    leak stale LDS into the bricks' fixed-point scales (own_bin).  Small sources next to LDS that earlier launches left
+    full of large values: a wrong scale would quantise the result to zero."""
+    from interpol import _hip
+    g = torch.Generator().manual_seed(77)
+    gshp, shp = (96, 96, 96), (40, 40, 40)
+    big = torch.full([1, 2, 64, 64, 64], 3e30)                           # (leaves large floats in the workgroups' LDS)
+    idg = interpol.identity_grid((64, 64, 64))[None]
+    _hip.scatter("push", big.to(DEV), idg.to(DEV), [64] * 3, [3] * 3, [3] * 3, 1, flags=_hip.FLAG_BINNED_SCATTER)
+    src = 1e-3 * torch.randn([1, 2, *gshp], generator=g)
+    grid = (interpol.identity_grid(gshp) / 6.0 + 12.0)[None] + 0.3 * torch.randn([1, *gshp, 3], generator=g)
+    oracle.set_threads(8)
+    try:
+        for bound, order in ((3, 3), (6, 2)):
+            got = _hip.scatter("push", src.to(DEV), grid.to(DEV), list(shp), [bound] * 3, [order] * 3, 1, flags=_hip.FLAG_BINNED_SCATTER)
+            want = oracle.grid_push(src.double().numpy(), grid.double().numpy(), list(shp), [bound], [order], 1)
+            G.assert_close(got.cpu().numpy(), want, rtol=1e-5, atol_rel=1e-5, what=("contracting owner push", bound, order))
+    finally:
+        oracle.set_threads(1)
+
+
 # ---------------------------------------------------------------------------
 # SURVEY 8 row f3, second half: affine lattices evaluated in the kernels (INTERPOL_FLAG_AFFINE_GRID)
 # ---------------------------------------------------------------------------

@@ -143,7 +143,9 @@ DeferLease defer_acquire(hipStream_t st, int64_t nwork, int64_t batch, int ntx, 
             if (slot < 0) {
                 // a free slot, else the least recently used one that no launch holds right now
                 unsigned long long best = ~0ull;
-                for (int i = 0; i < DEFER_SLOTS; ++i) if (!D.slot[i].used) { slot = i; break; }
+                // (a free slot's lease can still be held by a launch that raced with interpol_release_stream: try_lock, never
+                //  wait for a lease while holding g_mu -- the other paths take the lease first, g_mu second)
+                for (int i = 0; i < DEFER_SLOTS; ++i) if (!D.slot[i].used && D.slot[i].lease.try_lock()) { slot = i; break; }
                 if (slot < 0) {
                     for (int i = 0; i < DEFER_SLOTS; ++i) {
                         if (D.slot[i].tick < best && D.slot[i].lease.try_lock()) {
@@ -152,8 +154,6 @@ DeferLease defer_acquire(hipStream_t st, int64_t nwork, int64_t batch, int ntx, 
                         }
                     }
                     if (slot < 0) return none;                    // every slot is in the middle of a launch
-                } else {
-                    D.slot[slot].lease.lock();                    // (free: nobody holds it)
                 }
                 Slot &S = D.slot[slot];
                 // the new owner's launches come behind the previous owner's last hand-back launch on the device

@@ -298,10 +298,16 @@ __global__ __launch_bounds__(NT1, 4) void own_bin(KParams p, BrickGrid bg, const
     for (int v = 0; v < VPT1; ++v)
         if (((local >> v) & 1) && sm.cnt[lbin[v] & 255] < 0) direct |= 1u << v;
     // ---- sorted records leave through LDS, two rounds of HALF records: coalesced 16-byte stores
+    // (the samples of an ORPHAN run -- its brick's descriptor list was full -- keep their places in the sorted order, which
+    //  nobody will read: they go there with zero sources, so that every slot the store loop reads has been written this round
+    //  and the maxima below see no stale LDS)
     int pos[VPT1];
+    unsigned orphan = 0;
 #pragma unroll
-    for (int v = 0; v < VPT1; ++v)      // sorted position, and above it the cell
-        pos[v] = ((local >> v) & 1) && sm.cnt[lbin[v] & 255] >= 0 ? (sm.base[lbin[v] & 255] + (int)((unsigned)lbin[v] >> 20)) | (((lbin[v] >> 8) & 0xfff) << 16) : -1;
+    for (int v = 0; v < VPT1; ++v) {    // sorted position, and above it the cell
+        pos[v] = ((local >> v) & 1) ? (sm.base[lbin[v] & 255] + (int)((unsigned)lbin[v] >> 20)) | (((lbin[v] >> 8) & 0xfff) << 16) : -1;
+        if (((local >> v) & 1) && sm.cnt[lbin[v] & 255] < 0) orphan |= 1u << v;
+    }
     const bool two = nch > 1;
     int amx0 = 0, amx1 = 0;             // max |source| of what this thread stores (non-negative floats, and NaN, order like ints)
     prof_mark(3);
@@ -311,9 +317,10 @@ __global__ __launch_bounds__(NT1, 4) void own_bin(KParams p, BrickGrid bg, const
         for (int v = 0; v < VPT1; ++v) {
             const int q = (pos[v] & 0xffff) - r * HALF;
             if (pos[v] >= 0 && (unsigned)q < (unsigned)HALF) {
-                sm.xch[q] = make_float4(c[v][0], c[v][1], c[v][2], v0[v]);
+                const bool orph = (orphan >> v) & 1;
+                sm.xch[q] = make_float4(c[v][0], c[v][1], c[v][2], orph ? 0.f : v0[v]);
                 sm.xm[q] = (unsigned short)(pos[v] >> 16);
-                if (two) sm.xv[q] = v1[v];
+                if (two) sm.xv[q] = orph ? 0.f : v1[v];
             }
         }
         __syncthreads();
@@ -1109,7 +1116,7 @@ static int64_t layout(const KParams &k, int B, int ntiles, int nch, void *base, 
     unsigned char *p = (unsigned char *)base;
     const int64_t o_hdr = o; o += 256;                               // header and brick counters are zeroed by ONE memset
     const int64_t o_nd = o; o += nbricks * 4;                        // (header, brick counters and brick maxima: ONE zero-fill)
-    const int64_t o_bm = o; o += align256(nbricks * 8);
+    const int64_t o_bm = o; o += nbricks * 8; o = align256(o);        // (what follows holds 8- and 16-byte elements: aligned)
     const int64_t o_desc = o; o += align256(nbricks * CAPD * 8);
     const int64_t o_rec = o; o += align256(nrec * 16);
     const int64_t o_val = o; o += align256(nrec * 4 * (nch > 1 ? nch - 1 : 0));
@@ -1195,6 +1202,7 @@ int try_owner_push(const interpol_problem *p, const KParams &k, const void *val,
     const bool count_only = val == nullptr;
     const int nch = count_only ? 1 : k.C + (k.cc ? 1 : 0);
     Workspace w;
+    if (((uintptr_t)workspace & 255u) != 0) return 0;                // (interpol_hip.h: 256-byte aligned, or the other scatters run)
     if (layout(k, (int)p->batch, tile_count(p), nch, workspace, &w) > workspace_bytes) return 0;
     const BrickGrid bg = brick_grid(k);
     const bool gated = !(p->flags & INTERPOL_FLAG_BINNED_SCATTER);

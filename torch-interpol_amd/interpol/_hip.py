@@ -370,8 +370,22 @@ def scatter(op, val, grid, shape, bound, order, extrapolate, flags=0, out=None, 
     if dt in (torch.bfloat16, torch.float16):
         sbytes = max(sbytes, vol.numel() * 4)
     if sbytes > 0:
-        scratch = torch.empty(sbytes, dtype=torch.uint8, device=dev)
-        if _POISON_SCRATCH:
+        try:
+            scratch = torch.empty(sbytes, dtype=torch.uint8, device=dev)
+        except torch.cuda.OutOfMemoryError:
+            # The probe-routed default asks for the owner-computes workspace (~22 B per sample + 1 KiB per brick, api.py)
+            # whether or not the probe will pick that organisation; when it does not fit, the call falls back to the tiles,
+            # which need none -- a push that fitted without the router still fits.
+            if not (flags & FLAG_AUTO_SCATTER):
+                raise
+            flags &= ~FLAG_AUTO_SCATTER
+            p = make_problem(dim, dt, gdt, bound, order, extrapolate, B, C, shape, gshape,
+                             vstr, _grid_strides(grid, B, dim), valstr, flags)
+            sbytes = int(L.interpol_scatter_workspace(ctypes.byref(p), 1 if op == "count" else 0))
+            if dt in (torch.bfloat16, torch.float16):
+                sbytes = max(sbytes, vol.numel() * 4)
+            scratch = torch.empty(sbytes, dtype=torch.uint8, device=dev) if sbytes > 0 else None
+        if scratch is not None and _POISON_SCRATCH:
             scratch.fill_(0xff)                          # (debugging aid: INTERPOL_POISON_SCRATCH=1 -- the kernels must not depend on stale workspace contents)
     with torch.cuda.device(dev):
         if op == "count":

@@ -22,6 +22,10 @@ exact_scatter = False
 #     the deformation (3.9 - 4.4 ms in all those cases), 16 - 20 bytes of workspace per sample point.
 # `rough_deformations = None` (default): a probe kernel inside every call examines 128 tiles of the sample grid and
 # gates the two organisations on the device (no host synchronisation, stateless, hipGraph-safe; ~50 us).
+# Memory: under the default (and under True) every 3-D quadratic / cubic grid_push / grid_count -- and the image gradient of
+# grid_pull's backward, which is such a push -- allocates the bricks' workspace for the duration of the call: about 22 bytes per
+# sample point plus 1 KiB per 16^3 brick of the target (1.7 GB at 4x2x256^3), whichever organisation the probe then picks.  When
+# that allocation fails the call falls back to the tiles, which need none (interpol/_hip.py: scatter).
 # True: always the bricks.  False: always the tiles (no workspace is allocated).
 rough_deformations = None
 
