@@ -14,8 +14,8 @@ by a barrier + synchronize and the MAX over ranks is reported.
 
 Prints ONE JSON line (rank 0): metric/value = aggregate Mvox/s, where a voxel is
 one sample location (B * prod(spatial)) and each op of the step processes all of
-them; `roofline` is for the slower of the two kernels, measured with HIP events
-inside the timed region; `cpu_baseline` times the CPU oracle (a port of the
+them; `roofline` is for the slower of the two operators (median of the HIP-event times
+inside the timed region), `roofline_per_op` for both; `cpu_baseline` times the CPU oracle (a port of the
 reference algorithm, all host cores) on a bounded sample of the same workload.
 """
 import argparse
@@ -264,10 +264,21 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    local_elapsed = elapsed
     if dist is not None:
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t)
+
+    # per-rank step times (a SCALE run describes itself: every rank's clock, and the number of ranks RCCL really spans)
+    rank_ms = [1e3 * elapsed / args.steps]
+    rccl_world = 1
+    if dist is not None:
+        rccl_world = dist.get_world_size()
+        tl = torch.tensor([local_elapsed], device=device, dtype=torch.float64)
+        allt = [torch.zeros_like(tl) for _ in range(rccl_world)]
+        dist.all_gather(allt, tl)
+        rank_ms = [1e3 * float(x) / args.steps for x in allt]
 
     pull_ms = sorted(e[0].elapsed_time(e[1]) for e in events)
     push_ms = sorted(e[1].elapsed_time(e[2]) for e in events)
@@ -282,8 +293,34 @@ def main():
     # algorithmic bytes per launch: every input read once, every output written once
     bytes_pull = vox_rank * (3 * 4 + C * 4) + B * C * n ** 3 * 4
     bytes_push = vox_rank * (3 * 4 + C * 4) + B * C * n ** 3 * 4
-    dom = "grid_push" if push_avg >= pull_avg else "grid_pull"
-    dom_ms = max(push_avg, pull_avg)
+    # SURVEY 8d protocol next to the API-level numbers: outputs allocated BEFORE the timed region, medians.  (pull writes
+    # into `out=`; push accumulates into a target that was zeroed outside the events -- its zero-fill, 0.06 ms, is then
+    # not in the number, which the API-level push_ms includes.)
+    pre = {}
+    if world == 1:
+        bc, oc = [bound_to_code(args.bound)] * 3, [args.order] * 3
+        pflags = _hip.FLAG_NO_FASTPATH if args.no_fastpath else 0
+        o_pull = torch.empty_like(inp)
+        o_push = torch.zeros_like(inp)
+        ev2 = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(args.steps)]
+        for k in range(-2, args.steps):
+            e = ev2[max(k, 0)]
+            e[0].record(); _hip.gather("pull", inp, grid, bc, oc, 1, flags=pflags, out=o_pull)
+            e[1].record(); _hip.scatter("push", inp, grid, [n] * 3, bc, oc, 1, flags=pflags | _hip.FLAG_ACCUMULATE, out=o_push)
+            e[2].record()
+        torch.cuda.synchronize()
+        a = sorted(e[0].elapsed_time(e[1]) for e in ev2); b_ = sorted(e[1].elapsed_time(e[2]) for e in ev2)
+        pre = {"pull_ms_median": round(a[len(a) // 2], 4), "push_ms_median": round(b_[len(b_) // 2], 4),
+               "note": "outputs allocated before the timed region (C-ABI level: interpol_pull into `out`, interpol_push with "
+                       "INTERPOL_FLAG_ACCUMULATE into a target zeroed outside the events), medians of %d" % args.steps}
+        del o_pull, o_push
+    ops_roof = {}
+    for name, nbytes, med_ms, avg_ms in (("grid_pull", bytes_pull, pull_med, pull_avg), ("grid_push", bytes_push, push_med, push_avg)):
+        ops_roof[name] = {"bound": "hbm", "achieved": round(nbytes / (med_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                          "frac": round(nbytes / (med_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "algorithmic_bytes_per_launch": nbytes,
+                          "median_launch_ms": round(med_ms, 4), "avg_launch_ms": round(avg_ms, 4)}
+    dom = "grid_push" if push_med >= pull_med else "grid_pull"
+    dom_ms = max(push_med, pull_med)
     dom_bytes = bytes_push if dom == "grid_push" else bytes_pull
     achieved = dom_bytes / (dom_ms * 1e-3) / 1e9
     # HBM-side bytes of the same launch: NOT measured in this run -- read from the committed PMC summary
@@ -292,7 +329,10 @@ def main():
     pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if os.path.exists(pmc):
         try:
-            traffic = json.load(open(pmc)).get(dom)
+            pj = json.load(open(pmc))
+            traffic = pj.get(dom)
+            for name in ops_roof:
+                ops_roof[name]["traffic"] = pj.get(name)
             traffic_source = "profiles/pmc_traffic.json (separate rocprofv3 --pmc passes, not this run)"
         except Exception:
             traffic = None
@@ -307,6 +347,7 @@ def main():
                                    "bound %s, extrapolate=True, grid = identity + N(0,%g^2) (%s)"
                                    % (B, C, n, args.order, args.bound, args.sigma, args.grid),
                        "batch_per_gpu": B, "channels": C, "shape": [n, n, n], "parallelism": "batch-sharded x%d" % world},
+            "rccl_world_size": rccl_world, "rank_ms_per_step": [round(x, 4) for x in rank_ms],
             "pull_ms": round(pull_avg, 4), "push_ms": round(push_avg, 4),
             "pull_ms_median": round(pull_med, 4), "push_ms_median": round(push_med, 4),
             "timing_note": "HIP events on the launch stream around each op inside the timed region; the op allocates its "
@@ -317,10 +358,13 @@ def main():
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "traffic_source": traffic_source,
-                         "algorithmic_bytes_per_launch": dom_bytes, "avg_launch_ms": round(dom_ms, 4),
+                         "algorithmic_bytes_per_launch": dom_bytes, "avg_launch_ms": round(dom_ms, 4), "timing": "median of %d launches" % args.steps,
                          "launch": "one interpol_push call = the kernels its probe routes to (rough fields: own_bin + 9 own_accumulate "
                                    "of csrc/push_owner.hip; smooth: push_tiled) + zero-fill; per-kernel times: profiles/*_kernel_stats.txt"},
         }
+        line["roofline_per_op"] = ops_roof
+        if pre:
+            line["preallocated_outputs"] = pre
         if world == 1 and args.grid == "random" and not args.no_extras:
             # same workload under the other deformation models of SURVEY 8d (not the headline)
             extras = {}

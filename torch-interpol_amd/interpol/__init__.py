@@ -6,7 +6,8 @@ fused hand-written HIP kernels for gfx950 behind the reference's Python API.
     import interpol
     warped = interpol.grid_pull(image, grid, interpolation=3, bound='dct2', extrapolate=True)
 
-Tensors must live on a ROCm GPU; there is no CPU path in this build.
+CUDA (ROCm) tensors of 1-3 spatial dims run the HIP kernels (libinterpol_hip.so must be built: there is no silent
+fallback for them); CPU tensors and D > 3 are served by the device-generic PyTorch kernel table of interpol/torch_kernels.py.
 """
 from .api import (pull, push, count, grid_pull, grid_push, grid_count, grid_grad,       # noqa: F401
                   spline_coeff, spline_coeff_nd)

@@ -269,8 +269,9 @@ def _prep_grid(grid, gdt):
     return grid, 0
 
 
-def gather(op, vol, grid, bound, order, extrapolate, flags=0):
-    """pull / grad / hess: vol (B,C,*in), grid (B,*out,D) -> val (B,C,*out[,D[,D]])."""
+def gather(op, vol, grid, bound, order, extrapolate, flags=0, out=None):
+    """pull / grad / hess: vol (B,C,*in), grid (B,*out,D) -> val (B,C,*out[,D[,D]]).
+    `out`: a dense tensor of that shape and dtype to write into instead of allocating one."""
     dev = _require_gpu(vol, grid)
     dim = grid.shape[-1]
     if dim not in (1, 2, 3):
@@ -286,7 +287,13 @@ def gather(op, vol, grid, bound, order, extrapolate, flags=0):
     C = vol.shape[1]
     oshape = list(grid.shape[1:-1])
     trailing = {"pull": [], "grad": [dim], "hess": [dim, dim]}[op]
-    val = torch.empty([B, C] + oshape + trailing, dtype=dt, device=dev)
+    if out is None:
+        val = torch.empty([B, C] + oshape + trailing, dtype=dt, device=dev)
+    else:
+        val = out
+        if not (val.is_contiguous() and val.dtype == dt and list(val.shape) == [B, C] + oshape + trailing):
+            raise ValueError("gather output: expected a contiguous %s tensor of shape %s, got %s %s"
+                             % (dt, [B, C] + oshape + trailing, val.dtype, list(val.shape)))
     if val.numel() == 0:
         return val.to(out_dt)
     vstr = [_bstride(vol, B), vol.stride(1)] + _pad_to([vol.stride(2 + d) for d in range(dim)], 3)

@@ -57,14 +57,16 @@ def affine_grid(mat, shape):
     """Dense grid from (..., D[+1], D+1) affine matrices.  reference interpol/api.py:534-572"""
     mat = torch.as_tensor(mat)
     shape = list(shape)
-    nb_dim = mat.shape[-1] - 1
-    if nb_dim != len(shape):
-        raise ValueError('Dimension of the affine matrix ({}) and shape ({}) '
-                         'are not the same.'.format(nb_dim, len(shape)))
-    if mat.shape[-2] not in (nb_dim, nb_dim + 1):
-        raise ValueError('First argument should be matrces of shape '
-                         '(..., {0}, {1}) or (..., {1], {1}) but got {2}.'
-                         .format(nb_dim, nb_dim + 1, mat.shape))
+    D = len(shape)
+    rows, cols = mat.shape[-2], mat.shape[-1]
+    # same two refusals as the reference (ValueError both): the matrix maps D-dimensional homogeneous coordinates, and it
+    # is either the full (D+1) x (D+1) matrix or its first D rows
+    if cols != D + 1:
+        raise ValueError("affine_grid: a %d-D lattice needs matrices with %d columns, got shape %s" % (D, D + 1, tuple(mat.shape)))
+    if rows != D and rows != D + 1:
+        raise ValueError("affine_grid: expected matrices of shape (..., %d, %d) or (..., %d, %d), got %s"
+                         % (D, D + 1, D + 1, D + 1, tuple(mat.shape)))
+    nb_dim = D
     grid = identity_grid(shape, mat.dtype, mat.device)
     lin = mat[..., :nb_dim, :nb_dim]
     off = mat[..., :nb_dim, -1]
