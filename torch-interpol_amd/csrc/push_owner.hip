@@ -130,6 +130,7 @@ struct BinSmem {
     int cnt[NBIN];             // samples of the tile per local brick; after the scan: -1 marks an orphan run
     int base[NBIN];            // first sorted position of the local brick
     int bmx[2];                // max |masked source| over the tile's binned samples, first two channels (float bits)
+    int orph, pad_;            // the tile has orphan runs (a brick's descriptor list was full)
     int gbk[NBIN];             // global brick of the local brick when its run was published, else -1
     float4 xch[HALF];          // sorted records of one round: x, y, z, value of channel 0
     float  xv[HALF];           // value of one further channel
@@ -186,6 +187,7 @@ __global__ __launch_bounds__(NT1, 4) void own_bin(KParams p, BrickGrid bg, const
     const int nch = val == nullptr ? 1 : p.C + p.cc;
     for (int i = tid; i < NBIN; i += NT1) { sm.cnt[i] = 0; sm.gbk[i] = -1; }
     if (tid < 2) sm.bmx[tid] = 0;
+    if (tid == 2) sm.orph = 0;
     if (tid < 3) sm.lo[tid] = 0x7fffffff;
     float c[VPT1][3], v0[VPT1], v1[VPT1];
     unsigned valid = 0;
@@ -281,7 +283,7 @@ __global__ __launch_bounds__(NT1, 4) void own_bin(KParams p, BrickGrid bg, const
                 sm.base[e] = run;
                 if (cn[i] > 0) {
                     if (slot[i] < CAPD) { desc[(int64_t)bk[i] * CAPD + slot[i]] = make_uint2((unsigned)(tilebase + run), (unsigned)cn[i]); sm.gbk[e] = bk[i]; }
-                    else sm.cnt[e] = -1;                             // the brick's list is full: this run is scattered directly, below
+                    else { sm.cnt[e] = -1; sm.orph = 1; }            // the brick's list is full: this run is scattered directly, below
                 }
                 run += cn[i];
             }
@@ -298,29 +300,31 @@ __global__ __launch_bounds__(NT1, 4) void own_bin(KParams p, BrickGrid bg, const
     for (int v = 0; v < VPT1; ++v)
         if (((local >> v) & 1) && sm.cnt[lbin[v] & 255] < 0) direct |= 1u << v;
     // ---- sorted records leave through LDS, two rounds of HALF records: coalesced 16-byte stores
-    // (the samples of an ORPHAN run -- its brick's descriptor list was full -- keep their places in the sorted order, which
-    //  nobody will read: they go there with zero sources, so that every slot the store loop reads has been written this round
-    //  and the maxima below see no stale LDS)
     int pos[VPT1];
-    unsigned orphan = 0;
 #pragma unroll
-    for (int v = 0; v < VPT1; ++v) {    // sorted position, and above it the cell
-        pos[v] = ((local >> v) & 1) ? (sm.base[lbin[v] & 255] + (int)((unsigned)lbin[v] >> 20)) | (((lbin[v] >> 8) & 0xfff) << 16) : -1;
-        if (((local >> v) & 1) && sm.cnt[lbin[v] & 255] < 0) orphan |= 1u << v;
-    }
+    for (int v = 0; v < VPT1; ++v)      // sorted position, and above it the cell
+        pos[v] = ((local >> v) & 1) && sm.cnt[lbin[v] & 255] >= 0 ? (sm.base[lbin[v] & 255] + (int)((unsigned)lbin[v] >> 20)) | (((lbin[v] >> 8) & 0xfff) << 16) : -1;
+    // (the samples of an ORPHAN run -- its brick's descriptor list was full -- are scattered directly and leave their places in
+    //  the sorted order unwritten; nobody reads those records, but the store loop below does pass over the slots: a tile that
+    //  has orphans (rare: more than 128 tiles feed one brick) clears the exchange buffer first, so that the maxima see zeros,
+    //  not stale LDS.  A flag, not a per-sample select: this kernel sits at its register limit)
+    const bool has_orphans = sm.orph != 0;                           // (block-uniform)
     const bool two = nch > 1;
     int amx0 = 0, amx1 = 0;             // max |source| of what this thread stores (non-negative floats, and NaN, order like ints)
     prof_mark(3);
     for (int r = 0; r < 2; ++r) {
         if (r * HALF >= total) break;                                // (block-uniform)
+        if (has_orphans) {
+            for (int i = tid; i < HALF; i += NT1) { sm.xch[i] = make_float4(0.f, 0.f, 0.f, 0.f); sm.xv[i] = 0.f; }
+            __syncthreads();
+        }
 #pragma unroll
         for (int v = 0; v < VPT1; ++v) {
             const int q = (pos[v] & 0xffff) - r * HALF;
             if (pos[v] >= 0 && (unsigned)q < (unsigned)HALF) {
-                const bool orph = (orphan >> v) & 1;
-                sm.xch[q] = make_float4(c[v][0], c[v][1], c[v][2], orph ? 0.f : v0[v]);
+                sm.xch[q] = make_float4(c[v][0], c[v][1], c[v][2], v0[v]);
                 sm.xm[q] = (unsigned short)(pos[v] >> 16);
-                if (two) sm.xv[q] = orph ? 0.f : v1[v];
+                if (two) sm.xv[q] = v1[v];
             }
         }
         __syncthreads();
