@@ -1440,6 +1440,43 @@ def test_binned_scatter_rough_deformation_and_modes():
     G.assert_close(a.cpu().numpy(), oracle.grid_push(src.numpy(), grid.numpy(), list(shp), [3], [3], 1), rtol=1e-5, atol_rel=1e-5, what="backend switch")
 
 
+@pytest.mark.parametrize("sigma", [0.0, 2.5, 7.0])
+def test_float64_push_tiles_against_oracle_and_generic(sigma):
+    """grid_push / grid_count in float64 on LDS tiles (csrc/push_f64.hip: 3-D, orders 0..3 per dim, >= 4096 samples) against the
+    oracle at the float64 tolerance 1e-11 and against the generic kernels, every bound, mixed orders, the three extrapolation
+    modes, the count channel; sigma = 7 pushes most stencils out of the tiles' boxes (the tap-by-tap path)."""
+    from interpol import _hip
+    g = torch.Generator().manual_seed(int(10 * sigma) + 3)
+    ishape, oshape = (29, 34, 31), (36, 30, 40)
+    oracle.set_threads(8)
+    try:
+        for bound in range(7):
+            orders = ([3, 3, 3], [2, 2, 2], [1, 1, 1], [3, 1, 2], [0, 2, 3], [2, 3, 0], [1, 3, 3])[bound]
+            ex = bound % 3
+            C = 1 + bound % 2
+            src = torch.randn([2, C, *oshape], generator=g, dtype=torch.float64)
+            lin = [torch.linspace(0, n - 1, m, dtype=torch.float64) for n, m in zip(ishape, oshape)]
+            grid = torch.stack(torch.meshgrid(*lin, indexing="ij"), -1)[None] + sigma * torch.randn([2, *oshape, 3], generator=g, dtype=torch.float64)
+            b = [bound, (bound + 2) % 7, (bound + 5) % 7]
+            got = _hip.scatter("push", src.to(DEV), grid.to(DEV), list(ishape), b, orders, ex, with_count=True)
+            slow = _hip.scatter("push", src.to(DEV), grid.to(DEV), list(ishape), b, orders, ex, with_count=True, flags=_hip.FLAG_NO_FASTPATH)
+            assert G.rel_err(got.cpu().numpy(), slow.cpu().numpy()) < 1e-12, ("tiles vs generic", bound, orders, ex)
+            wp = oracle.grid_push(src.numpy(), grid.numpy(), list(ishape), b, orders, ex)
+            wc = oracle.grid_count(grid.numpy(), list(ishape), b, orders, ex)
+            assert G.rel_err(got[:, :C].cpu().numpy(), wp) < 1e-11, ("push", bound, orders, ex)
+            assert G.rel_err(got[:, C:].cpu().numpy(), wc) < 1e-11, ("count channel", bound, orders, ex)
+            cnt = _hip.scatter("count", None, grid.to(DEV), list(ishape), b, orders, ex)
+            assert G.rel_err(cnt.cpu().numpy(), wc) < 1e-11, ("count", bound, orders, ex)
+        # autograd: the image gradient of grid_pull takes the same tiles
+        inp = torch.randn([2, 2, *ishape], generator=g, dtype=torch.float64)
+        gout = torch.randn([2, 2, *oshape], generator=g, dtype=torch.float64)
+        want_i, want_g = oracle.grid_pull_backward(gout, inp, grid, [3], [3], 1)
+        gi, gg = ops.grid_pull_backward(gout.to(DEV), inp.to(DEV), grid.to(DEV), [3], [3], 1, need_inp=True, need_grid=True)
+        assert G.rel_err(gi.cpu().numpy(), want_i) < 1e-11 and G.rel_err(gg.cpu().numpy(), want_g) < 1e-11
+    finally:
+        oracle.set_threads(1)
+
+
 def test_owner_push_more_tiles_per_brick_than_descriptors():
     """A strongly contracting field (96^3 samples into 16^3 cells of the lattice): more than the 128 (tile, brick) runs a
     brick's descriptor list holds -- the orphan runs are scattered directly, and their places in the sorted order must not

@@ -57,6 +57,7 @@ IP_DECL_TILED(f32) IP_DECL_TILED(bf16) IP_DECL_TILED(f16)
 
 // owner-computes (target-stationary) scatter for same-resolution deformations (push_owner.hip)
 int try_owner_push(const interpol_problem *, const KParams &, const void *, const void *, void *, void *, int64_t, hipStream_t, const int **);
+int try_push_f64_tiles(const interpol_problem *, const KParams &, const void *, const void *, void *, hipStream_t);
 int64_t owner_workspace_bytes(const interpol_problem *, const KParams &, bool);
 
 #define IP_TILED_BY_DTYPE(NAME, ...)                                                     \
@@ -342,6 +343,20 @@ int interpol_push(const interpol_problem *p, const void *val, const void *grid, 
             if (rc != 0) return rc == 1 ? 0 : rc;
         }
         k.cc = 0;
+        if (!(p->flags & INTERPOL_FLAG_NO_FASTPATH) && p->dtype == INTERPOL_F64) {
+            // float64 on LDS tiles (push_f64.hip); the count channel is a second launch into channel C of the accumulator
+            int rc = try_push_f64_tiles(p, k, val, grid, acc, st);
+            if (rc != 0 && rc != 1) return rc;
+            if (rc == 1) {
+                if (!with_count) return 0;
+                KParams kc = k;
+                kc.C = 1;
+                char *accc = (char *)acc + (size_t)k.C * (size_t)k.vol_sc * acc_esize(p->dtype);
+                rc = try_push_f64_tiles(p, kc, nullptr, grid, accc, st);
+                if (rc == 1) return 0;
+                return rc ? rc : launch_push_f64(kc, nullptr, grid, accc, B, st);
+            }
+        }
         int rc = by_dtype(p->dtype,
             [&] { return launch_push_f32(k, val, grid, acc, B, st); },
             [&] { return launch_push_f64(k, val, grid, acc, B, st); },
@@ -422,6 +437,10 @@ int interpol_count(const interpol_problem *p, const void *grid, void *vol,
             int rc = try_owner_push(p, k, nullptr, grid, acc, ws, ws_bytes, st, &k.gate);
             if (rc != 0 && rc != 2) return rc == 1 ? 0 : rc;
             rc = try_fast_push(p, k, nullptr, grid, acc, st);
+            if (rc != 0) return rc == 1 ? 0 : rc;
+        }
+        if (!(p->flags & INTERPOL_FLAG_NO_FASTPATH) && p->dtype == INTERPOL_F64) {
+            const int rc = try_push_f64_tiles(p, k, nullptr, grid, acc, st);          // float64 on LDS tiles (push_f64.hip)
             if (rc != 0) return rc == 1 ? 0 : rc;
         }
         return by_dtype(p->dtype,
