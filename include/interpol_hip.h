@@ -178,6 +178,17 @@ typedef struct interpol_problem {
  * --------------------------------------------------------------------------- */
 int64_t interpol_scatter_workspace(const interpol_problem *p, int32_t count_only);
 int interpol_pull(const interpol_problem *p, const void *vol, const void *grid, void *val, void *stream);
+/* interpol_pull with a workspace (the same seam, interpol/pushpull.py:69-104 -> nd.pull): deformation-independent cost for
+ * 3-D quadratic / cubic F32 pulls.  With INTERPOL_FLAG_AUTO_SCATTER the sample tiles (ops_sorted.hip) run first and leave the
+ * tiles whose LDS box cannot hold their stencils (more than 512 samples outside it: i.i.d. displacements beyond ~3.5 voxels,
+ * folding fields) to a second organisation, which sorts those tiles' samples by the 16^3 brick of the image they read and gathers
+ * brick by brick (push_owner.hip: own_bin in index mode + own_gather; 4x2x256^3 cubic, sigma = 6: 9.8 -> 3 ms) -- decided per
+ * tile, on the device, no host synchronisation, hipGraph-safe.  INTERPOL_FLAG_BINNED_SCATTER: the bricks for every tile.
+ * interpol_pull_workspace(p) returns the bytes `workspace` must have (18 B per sample + 2 KiB per brick + 4 B per tile; 0: the
+ * organisation does not apply); with a smaller, missing or not 256-byte aligned workspace the call is interpol_pull.  The
+ * workspace need not be cleared.  Same results within float32 rounding (sums in a different order). */
+int64_t interpol_pull_workspace(const interpol_problem *p);
+int interpol_pull_ws(const interpol_problem *p, const void *vol, const void *grid, void *val, void *workspace, int64_t workspace_bytes, void *stream);
 int interpol_push(const interpol_problem *p, const void *val, const void *grid, void *vol,
                   void *scratch, int64_t scratch_bytes, void *stream);
 int interpol_count(const interpol_problem *p, const void *grid, void *vol,

@@ -1477,6 +1477,34 @@ def test_float64_push_tiles_against_oracle_and_generic(sigma):
         oracle.set_threads(1)
 
 
+@pytest.mark.parametrize("sigma", [0.0, 2.0, 7.0])
+def test_routed_pull_bricks_of_the_image_against_oracle(sigma):
+    """interpol_pull_ws (3-D quadratic / cubic, float32): the sample tiles leave the tiles whose box cannot hold their stencils
+    to bricks of the image (csrc/push_owner.hip: own_bin in index mode + own_gather).  The routed default and the bricks alone
+    (INTERPOL_FLAG_BINNED_SCATTER) against the oracle and the generic kernels: every bound (mixed per dim), the three
+    extrapolation modes, 1 - 3 channels, sample grids that overhang the lattice; sigma = 7 flags every tile."""
+    from interpol import _hip
+    g = torch.Generator().manual_seed(int(sigma) + 40)
+    oracle.set_threads(8)
+    try:
+        for (ishape, oshape) in (((40, 33, 50), (37, 45, 29)), ((48, 48, 48), (48, 48, 48))):
+            for bound in range(7):
+                order = 3 - (bound % 2)
+                ex, C = (bound + order) % 3, 1 + (bound + order) % 3
+                inp = torch.randn([2, C, *ishape], generator=g)
+                lin = [torch.linspace(-2, n + 1, m) for n, m in zip(ishape, oshape)]
+                grid = torch.stack(torch.meshgrid(*lin, indexing="ij"), -1)[None] + sigma * torch.randn([2, *oshape, 3], generator=g)
+                b = [bound, (bound + 3) % 7, (bound + 5) % 7]
+                want = oracle.grid_pull(inp.double().numpy(), grid.double().numpy(), b, [order], ex)
+                slow = _hip.gather("pull", inp.to(DEV), grid.to(DEV), b, [order] * 3, ex, flags=_hip.FLAG_NO_FASTPATH)
+                for name, fl in (("routed", 0), ("bricks", _hip.FLAG_BINNED_SCATTER)):
+                    got = _hip.gather("pull", inp.to(DEV), grid.to(DEV), b, [order] * 3, ex, flags=fl)
+                    G.assert_close(got.cpu().numpy(), want, rtol=1e-5, atol_rel=1e-5, what=(name, sigma, b, order, ex))
+                    assert G.rel_err(got.cpu().numpy(), slow.cpu().numpy()) < 4e-6, (name, "vs generic", sigma, b, order, ex)
+    finally:
+        oracle.set_threads(1)
+
+
 def test_owner_push_more_tiles_per_brick_than_descriptors():
     """A strongly contracting field (96^3 samples into 16^3 cells of the lattice): more than the 128 (tile, brick) runs a
     brick's descriptor list holds -- the orphan runs are scattered directly, and their places in the sorted order must not

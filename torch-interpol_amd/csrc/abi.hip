@@ -58,6 +58,9 @@ IP_DECL_TILED(f32) IP_DECL_TILED(bf16) IP_DECL_TILED(f16)
 // owner-computes (target-stationary) scatter for same-resolution deformations (push_owner.hip)
 int try_owner_push(const interpol_problem *, const KParams &, const void *, const void *, void *, void *, int64_t, hipStream_t, const int **);
 int try_push_f64_tiles(const interpol_problem *, const KParams &, const void *, const void *, void *, hipStream_t);
+int owner_pull_prepare(const interpol_problem *, const KParams &, void *, int64_t, hipStream_t, int **, int *);
+int owner_pull_finish(const interpol_problem *, const KParams &, const void *, const void *, void *, void *, int64_t, bool, hipStream_t);
+int64_t owner_pull_workspace_bytes(const interpol_problem *, const KParams &);
 int64_t owner_workspace_bytes(const interpol_problem *, const KParams &, bool);
 
 #define IP_TILED_BY_DTYPE(NAME, ...)                                                     \
@@ -127,6 +130,7 @@ static int make_params(const interpol_problem *p, Role role, int trailing, KPara
     k->mode = all1 ? MODE_ISO1 : (all0 ? MODE_ISO0 : MODE_ND);
     k->C = (int)p->channels;
     k->dbg = (p->flags >> 8) & 0xffff;
+    k->gate_n = 0;
     k->N = N;
     k->vol_sb = p->vol_stride[0];
     k->vol_sc = p->vol_stride[1];
@@ -278,6 +282,50 @@ int interpol_pull(const interpol_problem *p, const void *vol, const void *grid, 
     if (!(p->flags & INTERPOL_FLAG_NO_FASTPATH)) {
         rc = try_fast_pull(p, k, vol, grid, val, st);
         if (rc != 0) return rc == 1 ? 0 : rc;
+    }
+    return by_dtype(p->dtype,
+        [&] { return launch_pull_f32(k, vol, grid, val, B, st); },
+        [&] { return launch_pull_f64(k, vol, grid, val, B, st); },
+        [&] { return launch_pull_bf16(k, vol, grid, val, B, st); },
+        [&] { return launch_pull_f16(k, vol, grid, val, B, st); });
+}
+
+/* grid_pull with a workspace: the deformation-independent organisation (bricks of the image, push_owner.hip: own_gather) for
+ * fields too rough for the sample tiles, chosen by a probe of the call (INTERPOL_FLAG_AUTO_SCATTER) or always
+ * (INTERPOL_FLAG_BINNED_SCATTER); without a (large enough, 256-byte aligned) workspace: interpol_pull. */
+int64_t interpol_pull_workspace(const interpol_problem *p)
+{
+    KParams k; int B;
+    if (make_params(p, GATHER, 1, &k, &B)) return 0;
+    if (p->flags & INTERPOL_FLAG_NO_FASTPATH) return 0;
+    return owner_pull_workspace_bytes(p, k);
+}
+
+int interpol_pull_ws(const interpol_problem *p, const void *vol, const void *grid, void *val, void *workspace, int64_t workspace_bytes, void *stream)
+{
+    KParams k; int B;
+    int rc = make_params(p, GATHER, 1, &k, &B);
+    if (rc) return rc;
+    if (!vol || !grid || !val) return INTERPOL_E_NULL;
+    hipStream_t st = (hipStream_t)stream;
+    if (!(p->flags & INTERPOL_FLAG_NO_FASTPATH)) {
+        int *flags = nullptr;
+        int nzero = 0;
+        rc = owner_pull_prepare(p, k, workspace, workspace_bytes, st, &flags, &nzero);
+        if (rc != 0 && rc != 1) return rc;
+        if (rc == 1) {
+            if (p->flags & INTERPOL_FLAG_BINNED_SCATTER) return owner_pull_finish(p, k, vol, grid, val, workspace, workspace_bytes, true, st);
+            // the sample tiles first: pull_sorted flags the tiles it leaves to the bricks (too many samples outside its LDS box)
+            k.gate = flags; k.gate_n = nzero;
+            rc = try_fast_pull(p, k, vol, grid, val, st);
+            if (rc == 1 && (k.dbg & 32768)) return 0;              // (ablation: the tiles with their flags, no brick kernels behind them)
+            if (rc == 1) return owner_pull_finish(p, k, vol, grid, val, workspace, workspace_bytes, false, st);
+            if (rc != 0) return rc;
+            k.gate = nullptr; k.gate_n = 0;
+        } else {
+            rc = try_fast_pull(p, k, vol, grid, val, st);
+            if (rc != 0) return rc == 1 ? 0 : rc;
+        }
     }
     return by_dtype(p->dtype,
         [&] { return launch_pull_f32(k, vol, grid, val, B, st); },

@@ -51,6 +51,8 @@ constexpr int BOXSLOTS = NPL * PLANE;           // 9216 slots = 73728 B
 constexpr int NCLS = 32;                        // classes = 8-byte bank pairs
 constexpr int NSLOT = NS / NCLS;                // half-wave slots per class
 constexpr int SLOWCAP = 512;
+constexpr int ROUGH = 512;                      // out-of-box samples beyond which a tile is left to the bricks of interpol_pull_ws: the slow list (a wave per sample,
+                                                // ~0.035 us each) is full and the rest would be gathered one THREAD per sample
 constexpr int HANDBACK = NS / 8;                // out-of-box samples beyond which the generic kernel takes a (smooth) tile, defer.hip;
                                                 // measured: tools/handback_sweep.py, profiles/r02_handback.txt
 constexpr int TABCAP = (BOXSLOTS * 8 - NS * 16) / 2;   // surplus samples the hole table can place (2048)
@@ -314,7 +316,18 @@ __global__ __launch_bounds__(NT, 4) void pull_sorted(KParams p, const T *__restr
 #pragma unroll
     for (int d = 0; d < 3; ++d) { L.bound[d] = p.bound[d]; L.n[d] = p.vol_n[d]; L.ss[d] = p.vol_ss[d] / (int)sizeof(T); L.k[d] = K; }
     L.lin = 0;
+    if (p.gate && p.gate_n > 0) {
+        // interpol_pull_ws: the header, brick counters and brick list of the bricks' workspace lie in front of the tile flags; the
+        // sample tiles clear them on their way (own_bin, launched behind this kernel, counts in them): no launch of its own
+        int *z = const_cast<int *>(p.gate) - p.gate_n;
+        for (int i = (int)blockIdx.x * NT + (int)threadIdx.x; i < p.gate_n; i += (int)gridDim.x * NT) z[i] = 0;
+    }
     const WorkRange wr(ntiles * nbatch);
+    if (p.gate) {
+        // (the workspace arrives dirty: the workgroup clears the flags of ITS tiles before it starts -- one round trip, under the
+        //  first coordinate loads; a store per tile inside the loop is waited for at the tile's next barrier: 4 % of the kernel)
+        for (int w_ = wr.first + (int)threadIdx.x * wr.step; w_ < wr.end; w_ += NT * wr.step) const_cast<int *>(p.gate)[w_] = 0;
+    }
     for (int work = wr.first; work < wr.end; work += wr.step) {
         // the thread index is made opaque per tile: everything derived from it would otherwise be
         // hoisted out of the persistent loop and held (spilled) across all phases
@@ -333,6 +346,13 @@ __global__ __launch_bounds__(NT, 4) void pull_sorted(KParams p, const T *__restr
             if (hand_back) hand_back = tiled::tile_smooth(p, grid, b, 3, g.ox0, g.oy0, g.oz0, TS, TS, TS, g.gx, g.gy, g.gz, sm.hi);
             if (hand_back && tid == 0) defer_mark(defer, work, tile_desc(b, g.ox0 / TS, g.oy0 / TS, g.oz0 / TS));
             if (hand_back && defer.desc) { __syncthreads(); continue; }
+        }
+        // interpol_pull_ws: a tile with many samples outside the box -- each costs a wave -- is left to the bricks of the image
+        // (push_owner.hip: own_gather), whose cost does not depend on the deformation: flagged, skipped (block-uniform)
+        if (p.gate && sm.nslow > ROUGH) {
+            if (tid == 0) const_cast<int *>(p.gate)[work] = 1;
+            __syncthreads();
+            continue;
         }
         // rows of the box are contiguous runs of the lattice's unit-stride dim, sign +1 throughout
         // (dst1 has sign 0 at index 0 -- quirk B-3 -- so its run must start at 1)

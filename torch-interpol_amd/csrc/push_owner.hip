@@ -171,20 +171,50 @@ __device__ __forceinline__ void scatter_direct(const KParams &p, const T *__rest
     }
 }
 
+// Direct gather of a thread's unbinned samples (own_bin in index mode, the owner-computes PULL): one thread per sample, taps from
+// global memory.  `img`: the image, `out`: the output (p: the gather's parameters -- vol_* the image, val_* the output).
 template <typename T, int K, int GM>
+__device__ __forceinline__ void gather_direct(const KParams &p, const T *__restrict__ img, const float *__restrict__ grid, T *__restrict__ out,
+                                              int64_t b, TileGeom g, int tid, unsigned mask)
+{
+    Lattice L;
+#pragma unroll
+    for (int d = 0; d < 3; ++d) { L.bound[d] = p.bound[d]; L.n[d] = p.vol_n[d]; L.ss[d] = p.vol_ss[d] / (int)sizeof(T); L.k[d] = K; }
+    L.lin = 0;
+#pragma unroll 1
+    for (int v = 0; v < VPT1; ++v) {
+        if (!((mask >> v) & 1)) continue;
+        int ox, oy, oz; float x[3];
+        sample_pos(g, tid + NT1 * v, ox, oy, oz);
+        load_xyz<GM>(p, grid, b, g, ox, oy, oz, x);
+        const int64_t o = ((int64_t)ox * g.gy + oy) * g.gz + oz;
+        const float m = inb_mask(p, x);
+        int ii[3]; float tt[3];
+#pragma unroll
+        for (int d = 0; d < 3; ++d) split(K, x[d], ii[d], tt[d]);
+#pragma unroll 1
+        for (int ch = 0; ch < p.C; ++ch)
+            out[b * p.val_sb + ch * p.val_sc + o] = Cvt<float, T>::st(m * tiled::gather_one_thread<T>(L, img + b * p.vol_sb + ch * p.vol_sc, ii[0], ii[1], ii[2], tt[0], tt[1], tt[2], -1));
+    }
+}
+
+// IDX (the owner-computes pull, own_gather below): the records carry the sample's linear index instead of a source value; `val` is
+// then the IMAGE and `vol` the OUTPUT of the gather (for the samples gathered directly), `bmax` the list of non-empty bricks
+// (entry 0: their number).
+template <typename T, int K, int GM, bool IDX = false>
 __global__ __launch_bounds__(NT1, 4) void own_bin(KParams p, BrickGrid bg, const T *__restrict__ val, const float *__restrict__ grid,
                                                float *__restrict__ vol, int *__restrict__ ndesc, uint2 *__restrict__ desc,
                                                float4 *__restrict__ rec, float *__restrict__ vals, unsigned short *__restrict__ meta,
                                                int *__restrict__ bmax, int64_t nrec,
                                                int gx, int gy, int gz, int nty, int ntz, int ntiles, const int *__restrict__ gate)
 {
-    if (gate && *gate != 1) return;                                  // INTERPOL_FLAG_AUTO_SCATTER: the probe chose the tiles
+    if (IDX ? (gate && gate[blockIdx.x] == 0) : (gate && *gate != 1)) return;      // AUTO: the probe chose the tiles / (pull) the sample tiles served this tile
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     BinSmem &sm = *reinterpret_cast<BinSmem *>(smem_raw);
     const int tid = threadIdx.x;
     const int64_t b = blockIdx.x / ntiles;
     const TileGeom g = tile_geom(blockIdx.x % ntiles, gx, gy, gz, nty, ntz);
-    const int nch = val == nullptr ? 1 : p.C + p.cc;
+    const int nch = (IDX || val == nullptr) ? 1 : p.C + p.cc;
     for (int i = tid; i < NBIN; i += NT1) { sm.cnt[i] = 0; sm.gbk[i] = -1; }
     if (tid < 2) sm.bmx[tid] = 0;
     if (tid == 2) sm.orph = 0;
@@ -194,7 +224,7 @@ __global__ __launch_bounds__(NT1, 4) void own_bin(KParams p, BrickGrid bg, const
     prof_mark(-1);
     // sources of the first two channels: loaded unconditionally (a branch per load would serialise the round trips), from the
     // coordinates themselves where there is no such channel (count: the mask is the source)
-    const bool has0 = val != nullptr && p.C > 0, has1 = val != nullptr && p.C > 1;
+    const bool has0 = !IDX && val != nullptr && p.C > 0, has1 = !IDX && val != nullptr && p.C > 1;
     const T *vp0 = has0 ? val + b * p.val_sb : reinterpret_cast<const T *>(grid);
     const T *vp1 = has1 ? val + b * p.val_sb + p.val_sc : reinterpret_cast<const T *>(grid);
 #pragma unroll
@@ -205,11 +235,12 @@ __global__ __launch_bounds__(NT1, 4) void own_bin(KParams p, BrickGrid bg, const
         ox = ox < gx ? ox : gx - 1; oy = oy < gy ? oy : gy - 1; oz = oz < gz ? oz : gz - 1;
         load_xyz<GM>(p, grid, b, g, ox, oy, oz, c[v]);
         const int64_t o = ((int64_t)ox * gy + oy) * gz + oz;
+        if (IDX) { v0[v] = __int_as_float((int)o); v1[v] = 0.f; continue; }
         v0[v] = Cvt<float, T>::ld(vp0[has0 ? o : 0]);
         v1[v] = Cvt<float, T>::ld(vp1[has1 ? o : 0]);
     }
 #pragma unroll
-    for (int v = 0; v < VPT1; ++v) {                                  // masked sources (nd.py:201-203); count: the mask itself
+    for (int v = 0; v < VPT1 && !IDX; ++v) {                          // masked sources (nd.py:201-203); count: the mask itself
         const float m = inb_mask(p, c[v]);
         v0[v] = has0 ? v0[v] * m : m; v1[v] = has1 ? v1[v] * m : m;
     }
@@ -275,6 +306,7 @@ __global__ __launch_bounds__(NT1, 4) void own_bin(KParams p, BrickGrid bg, const
             bk[i] = (int)b * bg.per_item + ((lo[0] + r0) * bg.nb[1] + (lo[1] + r1)) * bg.nb[2] + (lo[2] + r2);
             slot[i] = 0;
             if (e < NBIN && cn[i] > 0) slot[i] = atomicAdd(&ndesc[bk[i]], 1);
+            if (IDX && e < NBIN && cn[i] > 0 && slot[i] == 0) bmax[1 + atomicAdd(&bmax[0], 1)] = bk[i];     // first run of the brick: onto the list
         }
 #pragma unroll
         for (int i = 0; i < PER; ++i) {
@@ -372,12 +404,13 @@ __global__ __launch_bounds__(NT1, 4) void own_bin(KParams p, BrickGrid bg, const
     amx0 = wave_max(amx0); amx1 = wave_max(amx1);
     if ((tid & 63) == 0) { if (amx0) atomicMax(&sm.bmx[0], amx0); if (amx1) atomicMax(&sm.bmx[1], amx1); }
     __syncthreads();
-    for (int e = tid; e < NBIN; e += NT1) {
+    for (int e = tid; e < NBIN && !IDX; e += NT1) {                  // (index mode: `bmax` is the brick list)
         const int bk = sm.gbk[e];
         if (bk < 0) continue;
         if (sm.bmx[0]) atomicMax(&bmax[2 * (int64_t)bk], sm.bmx[0]);
         if (sm.bmx[1]) atomicMax(&bmax[2 * (int64_t)bk + 1], sm.bmx[1]);
     }
+    if (IDX) { if (direct) gather_direct<T, K, GM>(p, val, grid, reinterpret_cast<T *>(vol), b, g, tid, direct); return; }
     if (direct) scatter_direct<T, K, GM>(p, val, grid, vol, b, g, tid, direct, nch);
 }
 
@@ -1001,6 +1034,135 @@ __global__ void own_zero(int *__restrict__ p, int n)
     if (i < n) p[i] = 0;
 }
 
+
+// ---------------------------------------------------------------------------
+// own_gather -- the owner-computes PULL (grid_pull, reference interpol/nd.py:80-143) for deformations too rough for the sample
+// tiles of ops_sorted.hip, whose LDS box (32 x 32 x 36 lattice points around 16^3 samples) holds the stencils of i.i.d.
+// displacements up to sigma ~ 3 voxels only (sigma = 6: 11 ms at config 2, as slow as the generic kernel).  own_bin (index
+// mode) sorts the samples by the brick of their first tap; here a workgroup draws a non-empty brick from the list, stages
+// the brick's 19^3 lattice points ONCE per channel pair (1.7 lattice points per sample, whatever the deformation) and gathers
+// the brick's records from it: weights once, 64 LDS reads at immediate offsets, 84 packed FMAs, two scattered 4-byte stores.
+// Cost independent of the deformation.  Every boundary condition: a box slot is a lattice point through the tables.
+// ---------------------------------------------------------------------------
+constexpr int GPZ = 20;                         // row pitch of the gather's box (8-byte slots)
+constexpr int GPLANE = BOX * GPZ;
+struct GatSmem {
+    int   taboff[3][BOX + 1];
+    float tabsgn[3][BOX + 1];
+    unsigned start[CAPD];
+    int   rcnt[CAPD];
+    int   brick, pad;
+    float2 box[BOX * GPLANE];                  // 57 760 B
+};
+#define IP_RD(o, off) "ds_read_b64 %" #o ", %16 offset:" #off "\n\t"
+__device__ __forceinline__ void gather_reads(unsigned addr, f2 (&v)[16])
+{
+    static_assert(GPZ * 8 == 160, "the immediate offsets are (row * GPZ + k) * 8");
+    asm volatile(IP_RD(0, 0) IP_RD(1, 8) IP_RD(2, 16) IP_RD(3, 24)
+                 IP_RD(4, 160) IP_RD(5, 168) IP_RD(6, 176) IP_RD(7, 184)
+                 IP_RD(8, 320) IP_RD(9, 328) IP_RD(10, 336) IP_RD(11, 344)
+                 IP_RD(12, 480) IP_RD(13, 488) IP_RD(14, 496) IP_RD(15, 504)
+                 "s_waitcnt lgkmcnt(0)"
+                 : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]), "=&v"(v[4]), "=&v"(v[5]), "=&v"(v[6]), "=&v"(v[7]),
+                   "=&v"(v[8]), "=&v"(v[9]), "=&v"(v[10]), "=&v"(v[11]), "=&v"(v[12]), "=&v"(v[13]), "=&v"(v[14]), "=&v"(v[15])
+                 : "v"(addr) : "memory");
+}
+#undef IP_RD
+
+template <int K>
+__global__ __launch_bounds__(NT, 4) void own_gather(KParams p, BrickGrid bg, const int *__restrict__ ndesc, const uint2 *__restrict__ desc,
+                                                    const float4 *__restrict__ rec, const int *__restrict__ list, int *__restrict__ draw,
+                                                    const float *__restrict__ img, float *__restrict__ out, const int *__restrict__ gate)
+{
+    if (gate && *gate != 1) return;                                  // the probe chose the sample tiles
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    GatSmem &sm = *reinterpret_cast<GatSmem *>(smem_raw);
+    const int nlist = list[0];
+    for (;;) {
+        const int tid = opaque((int)threadIdx.x);
+        __syncthreads();                                             // the previous brick's readers are done
+        if (tid == 0) { const int i = atomicAdd(draw, 1); sm.brick = i < nlist ? list[1 + i] : -1; }
+        __syncthreads();
+        const int bk = sm.brick;
+        if (bk < 0) break;
+        const int64_t b = bk / bg.per_item;
+        int r = bk - (int)b * bg.per_item;
+        const int bz = r % bg.nb[2]; r /= bg.nb[2];
+        const int by = r % bg.nb[1], bx = r / bg.nb[1];
+        const int b0[3] = { brick_origin(bx, bg.lo[0], bg.top[0], bg.nin[0], bg.split[0]), brick_origin(by, bg.lo[1], bg.top[1], bg.nin[1], bg.split[1]),
+                            brick_origin(bz, bg.lo[2], bg.top[2], bg.nin[2], bg.split[2]) };      // lattice index of box slot 0
+        const int nd = min(ndesc[bk], CAPD);
+        if (tid < nd) { const uint2 d = desc[(int64_t)bk * CAPD + tid]; sm.start[tid] = d.x; sm.rcnt[tid] = (int)d.y; }
+        if (tid < 3 * 64) {                                          // box slot -> wrapped lattice offset and sign (bounds.py:30-89)
+            const int d = tid >> 6, slot = tid & 63;
+            if (slot < BOX) {
+                const long long pk = wrap_outofline(p.bound[d], (d == 0 ? b0[0] : d == 1 ? b0[1] : b0[2]) + slot, p.vol_n[d]);
+                sm.taboff[d][slot] = (int)(pk & 0xffffffffll) * (p.vol_ss[d] / 4);
+                sm.tabsgn[d][slot] = (float)(int)(pk >> 32);
+            }
+        }
+        for (int c = 0; c < p.C; c += 2) {
+            const bool two = c + 1 < p.C;
+            const float *vc0 = img + b * p.vol_sb + (int64_t)c * p.vol_sc;
+            const float *vc1 = two ? vc0 + p.vol_sc : vc0;
+            float *oc0 = out + b * p.val_sb + (int64_t)c * p.val_sc;
+            __syncthreads();                                         // tables written / the previous pair's readers are done
+            for (int e = tid; e < BOX * BOX * BOX && !(p.dbg & 1); e += NT) {       // ((ablation bit 1: no staging)
+                const int x = e / (BOX * BOX), y = (e / BOX) % BOX, z = e % BOX;
+                const int off = sm.taboff[0][x] + sm.taboff[1][y] + sm.taboff[2][z];
+                const float sg = sm.tabsgn[0][x] * sm.tabsgn[1][y] * sm.tabsgn[2][z];
+                sm.box[(x * BOX + y) * GPZ + z] = make_float2(vc0[off] * sg, vc1[off] * sg);
+            }
+            __syncthreads();
+            const unsigned boxaddr = (unsigned)(size_t)(__attribute__((address_space(3))) void *)(sm.box);
+            const int wave = tid >> 6, lane = tid & 63;
+            for (int run = wave; run < nd; run += NT / 64) {
+                const int n = sm.rcnt[run];
+                const unsigned first = sm.start[run];
+                for (int i = lane; i < n; i += 64) {
+                    const float4 rc = rec[first + i];
+                    const float fx = floorf(rc.x - 0.5f * (float)(K - 1)), fy = floorf(rc.y - 0.5f * (float)(K - 1)), fz = floorf(rc.z - 0.5f * (float)(K - 1));
+                    const float tx = rc.x - fx; const f2 tyz = f2{ rc.y - fy, rc.z - fz };
+                    // first-tap cell inside the brick: 0 .. 15 by construction of the bins (own_bin); clamped, should a coordinate be off
+                    int cx = __float2int_rz(fx) - b0[0], cy = __float2int_rz(fy) - b0[1], cz = __float2int_rz(fz) - b0[2];
+                    cx = max(0, min(cx, BR - 1)); cy = max(0, min(cy, BR - 1)); cz = max(0, min(cz, BR - 1));
+                    const unsigned addr = boxaddr + (unsigned)((cx * BOX + cy) * GPZ + cz) * 8u;
+                    float wx[4];
+                    { // the K + 1 weights of the x-stencil (scalar form of weights_yz; splines.py:30-80)
+                        if (K == 3) { const float u = tx - 1.f, v = 2.f - tx, u2 = u * u, v2 = v * v;
+                                      wx[0] = (v2 * v) * (1.f / 6.f); wx[3] = (u2 * u) * (1.f / 6.f); wx[1] = u2 * (u * 0.5f - 1.f) + 2.f / 3.f; wx[2] = v2 * (v * 0.5f - 1.f) + 2.f / 3.f; }
+                        else { const float a = 1.5f - tx, cc = tx - 0.5f, m = tx - 1.f; wx[0] = (a * a) * 0.5f; wx[1] = 0.75f - m * m; wx[2] = (cc * cc) * 0.5f; wx[3] = 0.f; }
+                    }
+                    f2 w[4];
+                    weights_yz<K>(tyz, w);
+                    f2 a = { 0.f, 0.f };
+#pragma unroll
+                    for (int ii = 0; ii <= K; ++ii) {
+                        if (p.dbg & 2) { a = f2{ w[0].x + wx[ii], w[1].y }; break; }      // (ablation: no taps)
+                        f2 t2[16];
+                        gather_reads(addr + (unsigned)(ii * GPLANE * 8), t2);
+                        f2 pp = { 0.f, 0.f };
+#pragma unroll
+                        for (int jy = 0; jy <= K; ++jy) {
+                            f2 q = { 0.f, 0.f };
+#pragma unroll
+                            for (int k = 0; k <= K; ++k) q = f2{ w[k].y, w[k].y } * t2[4 * jy + k] + q;
+                            pp = f2{ w[jy].x, w[jy].x } * q + pp;
+                        }
+                        a = f2{ wx[ii], wx[ii] } * pp + a;
+                    }
+                    const float xyz[3] = { rc.x, rc.y, rc.z };
+                    const float m = inb_mask(p, xyz);                // nd.py:139-140
+                    const int64_t o = (int64_t)__float_as_int(rc.w);
+                    if ((p.dbg & 4) && a.x != 12345.f) continue;     // (ablation: no stores)
+                    oc0[o] = a.x * m;
+                    if (two) oc0[p.val_sc + o] = a.y * m;
+                }
+            }
+        }
+    }
+}
+
 constexpr int NPROBE = 128;
 constexpr int BOXVOL = 14500;
 struct ProbeHdr { int gate, done, nslow, nfar, nvalid, nbox, nfull, ncorner; };
@@ -1106,12 +1268,13 @@ __global__ __launch_bounds__(NT1) void own_probe(KParams p, BrickGrid bg, const 
 // Host side
 // ---------------------------------------------------------------------------
 struct Workspace {
+    int *flags;
     ProbeHdr *hdr; int *ndesc; int *bmax; uint2 *desc; float4 *rec; float *vals; unsigned short *meta;
     int64_t nrec; int nbricks;
 };
 static int64_t align256(int64_t x) { return (x + 255) & ~(int64_t)255; }
 
-static int64_t layout(const KParams &k, int B, int ntiles, int nch, void *base, Workspace *w)
+static int64_t layout(const KParams &k, int B, int ntiles, int nch, void *base, Workspace *w, int64_t nflags = 0)
 {
     const BrickGrid bg = brick_grid(k);
     const int64_t nbricks = (int64_t)bg.per_item * B;
@@ -1120,7 +1283,8 @@ static int64_t layout(const KParams &k, int B, int ntiles, int nch, void *base, 
     unsigned char *p = (unsigned char *)base;
     const int64_t o_hdr = o; o += 256;                               // header and brick counters are zeroed by ONE memset
     const int64_t o_nd = o; o += nbricks * 4;                        // (header, brick counters and brick maxima: ONE zero-fill)
-    const int64_t o_bm = o; o += nbricks * 8; o = align256(o);        // (what follows holds 8- and 16-byte elements: aligned)
+    const int64_t o_bm = o; o += nbricks * 8;
+    const int64_t o_fl = o; o += nflags * 4; o = align256(o);        // (pull: one flag per sample tile; what follows holds 8- and 16-byte elements: aligned)
     const int64_t o_desc = o; o += align256(nbricks * CAPD * 8);
     const int64_t o_rec = o; o += align256(nrec * 16);
     const int64_t o_val = o; o += align256(nrec * 4 * (nch > 1 ? nch - 1 : 0));
@@ -1128,7 +1292,7 @@ static int64_t layout(const KParams &k, int B, int ntiles, int nch, void *base, 
     if (w) {
         w->hdr = (ProbeHdr *)(p + o_hdr); w->ndesc = (int *)(p + o_nd); w->desc = (uint2 *)(p + o_desc);
         w->rec = (float4 *)(p + o_rec); w->vals = (float *)(p + o_val); w->meta = (unsigned short *)(p + o_meta);
-        w->bmax = (int *)(p + o_bm);
+        w->bmax = (int *)(p + o_bm); w->flags = (int *)(p + o_fl);
         w->nrec = nrec; w->nbricks = (int)nbricks;
     }
     return o;
@@ -1171,7 +1335,7 @@ int64_t owner_workspace_bytes(const interpol_problem *p, const KParams &k, bool 
 }
 
 namespace owner {
-template <typename T>
+template <typename T, bool IDX = false>
 static int launch_bin(const interpol_problem *p, const KParams &k, const BrickGrid &bg, const Workspace &w, const void *val, const void *grid,
                       void *vol, const int *gate, hipStream_t st)
 {
@@ -1181,9 +1345,9 @@ static int launch_bin(const interpol_problem *p, const KParams &k, const BrickGr
     const dim3 tgrid((unsigned)(ntiles * (int)p->batch));
 #define IP_OWN_BIN(KK, GM)                                                                                              \
     {                                                                                                                   \
-        const int attr = big_lds<own_bin<T, KK, GM>>(sizeof(BinSmem));                                                    \
+        const int attr = big_lds<own_bin<T, KK, GM, IDX>>(sizeof(BinSmem));                                               \
         if (attr) return attr;                                                                                          \
-        hipLaunchKernelGGL((own_bin<T, KK, GM>), tgrid, dim3(NT1), sizeof(BinSmem), st, k, bg, (const T *)val, (const float *)grid, \
+        hipLaunchKernelGGL((own_bin<T, KK, GM, IDX>), tgrid, dim3(NT1), sizeof(BinSmem), st, k, bg, (const T *)val, (const float *)grid, \
                            (float *)vol, w.ndesc, w.desc, w.rec, w.vals, w.meta, w.bmax, w.nrec, gx, gy, gz, nty, ntz, ntiles, gate); \
     }
 #define IP_OWN_BY_GM(KK)                                                                                                \
@@ -1259,6 +1423,75 @@ int try_owner_push(const interpol_problem *p, const KParams &k, const void *val,
     if (e != hipSuccess) return (int)e;
     if (gate_out) *gate_out = gate;
     return gated ? 2 : 1;
+}
+
+// ---------------------------------------------------------------------------
+// The owner-computes PULL: interpol_pull_ws (abi.hip).  Same workspace layout as the push with one channel; returns 1 when it
+// took the problem, 2 when it launched itself GATED behind the roughness probe (INTERPOL_FLAG_AUTO_SCATTER: the caller launches the
+// sample tiles as well, with KParams::gate = *gate_out), 0 to decline.
+// ---------------------------------------------------------------------------
+static bool owner_pull_eligible(const interpol_problem *p, const KParams &k)
+{
+    if (p->dtype != INTERPOL_F32 || p->grid_dtype != INTERPOL_F32) return false;
+    if (p->val_stride[0] < 0) return false;
+    return owner_eligible(p, k);
+}
+int64_t owner_pull_workspace_bytes(const interpol_problem *p, const KParams &k)
+{
+    if (!owner_pull_eligible(p, k)) return 0;
+    const int nt = owner::tile_count(p);
+    return owner::layout(k, (int)p->batch, nt, 1, nullptr, nullptr, (int64_t)nt * p->batch);
+}
+// Step 1 (before the sample tiles): zero the header, the brick counters and the tile flags.  Returns 1 and the flag array (one int
+// per (batch item, tile) in pull_sorted's order: the tiles it leaves to the bricks), 0 to decline.
+int owner_pull_prepare(const interpol_problem *p, const KParams &k, void *workspace, int64_t workspace_bytes, hipStream_t st, int **flags_out, int *nzero_out)
+{
+    using namespace owner;
+    if (!workspace || !owner_pull_eligible(p, k)) return 0;
+    if (((uintptr_t)workspace & 255u) != 0) return 0;
+    const int nt = tile_count(p);
+    const int64_t nflags = (int64_t)nt * p->batch;
+    Workspace w;
+    if (layout(k, (int)p->batch, nt, 1, workspace, &w, nflags) > workspace_bytes) return 0;
+    const int64_t nz = 64 + 3ll * w.nbricks;                         // header, brick counters, brick list: contiguous, right in front of the flags
+    if (nz + nflags > 0x7fffffffll || (int *)w.hdr + nz != w.flags) return 0;
+    if (p->flags & INTERPOL_FLAG_BINNED_SCATTER) {
+        // the bricks alone: no tile kernel in front that could clear the counters on its way
+        hipLaunchKernelGGL(own_zero, dim3((unsigned)((nz + 1023) / 1024)), dim3(1024), 0, st, (int *)w.hdr, (int)nz);
+        const hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return (int)e;
+    }
+    *flags_out = w.flags;
+    *nzero_out = (int)nz;
+    return 1;
+}
+// Step 2 (behind the sample tiles, or alone: all == true, INTERPOL_FLAG_BINNED_SCATTER): the flagged tiles' samples sorted by the
+// brick of the image they read (own_bin, index mode; unbinned samples are gathered on the spot), then the bricks (own_gather).
+int owner_pull_finish(const interpol_problem *p, const KParams &k, const void *vol, const void *grid, void *val,
+                      void *workspace, int64_t workspace_bytes, bool all, hipStream_t st)
+{
+    using namespace owner;
+    const int nt = tile_count(p);
+    Workspace w;
+    if (layout(k, (int)p->batch, nt, 1, workspace, &w, (int64_t)nt * p->batch) > workspace_bytes) return INTERPOL_E_SCRATCH;
+    const BrickGrid bg = brick_grid(k);
+    KParams kk = k;
+    kk.gate = nullptr;
+    int rc = launch_bin<float, true>(p, kk, bg, w, vol, grid, val, all ? nullptr : w.flags, st);
+    if (rc) return rc;
+    const long long want = 2ll * cu_count();
+    const dim3 ggrid((unsigned)(w.nbricks < want ? w.nbricks : want));
+#define IP_OWN_GAT(KK)                                                                                                  \
+    {                                                                                                                   \
+        const int attr = big_lds<own_gather<KK>>(sizeof(GatSmem));                                                      \
+        if (attr) return attr;                                                                                          \
+        hipLaunchKernelGGL((own_gather<KK>), ggrid, dim3(NT), sizeof(GatSmem), st, kk, bg, (const int *)w.ndesc, (const uint2 *)w.desc, \
+                           (const float4 *)w.rec, (const int *)w.bmax, (int *)w.hdr + 40, (const float *)vol, (float *)val, (const int *)nullptr); \
+    }
+    if (k.order[0] == 3) IP_OWN_GAT(3) else IP_OWN_GAT(2)
+#undef IP_OWN_GAT
+    const hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : (int)e;
 }
 
 } // namespace ip

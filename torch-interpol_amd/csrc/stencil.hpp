@@ -59,6 +59,7 @@ struct KParams {
     int64_t val_sb, val_sc; // val : spatial (+ trailing d,e) dims contiguous
     double mask_lo;         // -threshold
     double mask_hi[3];      // n-1+threshold
+    int gate_n;             // interpol_pull_ws: ints in front of `gate` (header, brick counters, brick list) that pull_sorted zeroes for own_bin
     const int *gate;        // scatters under INTERPOL_FLAG_AUTO_SCATTER: a device word written by the roughness probe of this call
                             // (push_owner.hip); the tiled / generic scatter kernels return at once when it is non-zero
 };

@@ -39,7 +39,7 @@ SYMBOLS = (
     "interpol_push_bricks", "interpol_push_bricks_workspace", "interpol_host_bound_index", "interpol_host_bound_sign",
     "interpol_host_weight", "interpol_host_weight_f32", "interpol_abi_version",
     "interpol_error_string", "interpol_kernel_name", "interpol_scatter_workspace",
-    "interpol_set_handback", "interpol_release_stream",
+    "interpol_set_handback", "interpol_release_stream", "interpol_pull_workspace", "interpol_pull_ws",
 )
 
 
@@ -102,6 +102,10 @@ def lib():
     L.interpol_push_bricks_workspace.restype = i64
     L.interpol_scatter_workspace.argtypes = [pp, i32]
     L.interpol_scatter_workspace.restype = i64
+    L.interpol_pull_workspace.argtypes = [pp]
+    L.interpol_pull_workspace.restype = i64
+    L.interpol_pull_ws.argtypes = [pp, vp, vp, vp, vp, i64, vp]
+    L.interpol_pull_ws.restype = ctypes.c_int
     L.interpol_set_handback.argtypes = [i32]
     L.interpol_set_handback.restype = i32
     L.interpol_release_stream.argtypes = [ctypes.c_void_p]
@@ -283,6 +287,16 @@ def gather(op, vol, grid, bound, order, extrapolate, flags=0, out=None):
     vol = vol.to(dt)
     grid, gflag = _prep_grid(grid, gdt)
     flags |= gflag
+    routed = False
+    if op == "pull" and dim == 3 and dt == torch.float32 and not (flags & (FLAG_NO_FASTPATH | FLAG_FORCE_TILED | FLAG_BINNED_SCATTER)) and (flags >> 8) == 0:
+        # the router of the pull (csrc/push_owner.hip: own_gather): like the push's, see interpol/backend.py
+        from . import backend
+        if backend.rough_deformations is None:
+            flags |= FLAG_AUTO_SCATTER
+        elif backend.rough_deformations:
+            flags |= FLAG_BINNED_SCATTER
+    if op == "pull" and (flags & (FLAG_AUTO_SCATTER | FLAG_BINNED_SCATTER)):
+        routed = True
     B = max(vol.shape[0], grid.shape[0])
     C = vol.shape[1]
     oshape = list(grid.shape[1:-1])
@@ -300,7 +314,23 @@ def gather(op, vol, grid, bound, order, extrapolate, flags=0, out=None):
     valstr = [val.stride(0), val.stride(1)] + _pad_to([val.stride(2 + d) for d in range(dim)], 3) + [0, 0]
     p = make_problem(dim, dt, gdt, bound, order, extrapolate, B, C, vol.shape[2:], oshape,
                      vstr, _grid_strides(grid, B, dim), valstr, flags)
-    fn = getattr(lib(), "interpol_" + op)
+    L = lib()
+    if routed:
+        # workspace of the routed pull (18 B per sample + 2 KiB per brick of the image; 0: the organisation does not apply).  When
+        # it cannot be allocated the call is the plain interpol_pull: the sample tiles need none.
+        ws, wbytes = None, int(L.interpol_pull_workspace(ctypes.byref(p)))
+        if wbytes > 0:
+            try:
+                ws = torch.empty(wbytes, dtype=torch.uint8, device=dev)
+            except torch.cuda.OutOfMemoryError:
+                ws, wbytes = None, 0
+        if ws is not None:
+            with torch.cuda.device(dev):
+                rc = L.interpol_pull_ws(ctypes.byref(p), _ptr(vol), _ptr(grid), _ptr(val), _ptr(ws), wbytes, _stream(dev))
+            _check(rc, "interpol_pull_ws")
+            return val.to(out_dt)
+        p.flags &= ~(FLAG_AUTO_SCATTER | FLAG_BINNED_SCATTER)
+    fn = getattr(L, "interpol_" + op)
     with torch.cuda.device(dev):
         rc = fn(ctypes.byref(p), _ptr(vol), _ptr(grid), _ptr(val), _stream(dev))
     _check(rc, "interpol_" + op)

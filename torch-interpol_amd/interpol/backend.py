@@ -26,6 +26,9 @@ exact_scatter = False
 # grid_pull's backward, which is such a push -- allocates the bricks' workspace for the duration of the call: about 22 bytes per
 # sample point plus 1 KiB per 16^3 brick of the target (1.7 GB at 4x2x256^3), whichever organisation the probe then picks.  When
 # that allocation fails the call falls back to the tiles, which need none (interpol/_hip.py: scatter).
+# grid_pull (3-D quadratic / cubic, float32) is routed too, per TILE: the sample tiles of csrc/ops_sorted.hip leave the tiles whose
+# LDS box cannot hold their stencils to bricks of the IMAGE (csrc/push_owner.hip: own_gather; 18 bytes of workspace per sample,
+# allocated per call like the push's): 4x2x256^3 cubic under i.i.d. noise of sigma = 6 voxels 9.8 -> 3 ms; ~3 % on smooth fields.
 # True: always the bricks.  False: always the tiles (no workspace is allocated).
 rough_deformations = None
 
