@@ -305,6 +305,111 @@ __device__ __forceinline__ void stage_slots(Smem &sm, const T *__restrict__ vc0,
 }
 
 // ---------------------------------------------------------------------------
+// COMPACT tiles.  Under a smooth deformation the box of a tile is small (the identity: 19^3 lattice points): laid out with
+// a row pitch of 24 slots it fits the 72 KiB of LDS WHOLE, and the natural order of the samples -- lanes along z, the
+// two rows of a half wave two rows of the tile apart: 24 slots = 48 banks, twice that = 32 banks mod 64 -- is already
+// free of bank conflicts.  Such a tile needs no sort, no record exchange, no passes: one staging round, then every thread
+// gathers its own 8 samples (weights once, 64 reads at immediate offsets, 84 packed FMAs each).  Chosen per tile.
+// ---------------------------------------------------------------------------
+constexpr int CZ = 24;                          // row pitch of the compact layout (8-byte slots)
+constexpr int CQ = CZ / 4, CRPS = NT / CQ;      // quads per row, rows per staging sweep of the workgroup
+#define IP_RD(o, off) "ds_read_b64 %" #o ", %16 offset:" #off "\n\t"
+__device__ __forceinline__ void compact_reads(unsigned addr, f2 (&v)[16])
+{
+    asm volatile(IP_RD(0, 0) IP_RD(1, 8) IP_RD(2, 16) IP_RD(3, 24)
+                 IP_RD(4, 192) IP_RD(5, 200) IP_RD(6, 208) IP_RD(7, 216)
+                 IP_RD(8, 384) IP_RD(9, 392) IP_RD(10, 400) IP_RD(11, 408)
+                 IP_RD(12, 576) IP_RD(13, 584) IP_RD(14, 592) IP_RD(15, 600)
+                 "s_waitcnt lgkmcnt(0)"
+                 : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]), "=&v"(v[4]), "=&v"(v[5]), "=&v"(v[6]), "=&v"(v[7]),
+                   "=&v"(v[8]), "=&v"(v[9]), "=&v"(v[10]), "=&v"(v[11]), "=&v"(v[12]), "=&v"(v[13]), "=&v"(v[14]), "=&v"(v[15])
+                 : "v"(addr) : "memory");
+}
+#undef IP_RD
+#define IP_RD(o, off) "ds_read_b64 %" #o ", %9 offset:" #off "\n\t"
+__device__ __forceinline__ void compact_reads(unsigned addr, f2 (&v)[9])
+{
+    asm volatile(IP_RD(0, 0) IP_RD(1, 8) IP_RD(2, 16)
+                 IP_RD(3, 192) IP_RD(4, 200) IP_RD(5, 208)
+                 IP_RD(6, 384) IP_RD(7, 392) IP_RD(8, 400)
+                 "s_waitcnt lgkmcnt(0)"
+                 : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]), "=&v"(v[4]), "=&v"(v[5]), "=&v"(v[6]), "=&v"(v[7]), "=&v"(v[8])
+                 : "v"(addr) : "memory");
+}
+#undef IP_RD
+static_assert(CZ * 8 == 192, "the immediate offsets above are (row * CZ + k) * 8");
+
+// all taps of one sample from the compact box; pp8: plane pitch in bytes
+template <int K>
+__device__ __forceinline__ f2 compact_sample(unsigned addr, unsigned pp8, float tx, f2 tyz)
+{
+    float wx[4];
+    weights_x<K>(tx, wx);
+    f2 w[4];
+    weights_yz<K>(tyz, w);
+    f2 a = { 0.f, 0.f };
+#pragma unroll
+    for (int i = 0; i <= K; ++i) {
+        f2 t2[(K + 1) * (K + 1)];
+        compact_reads(addr + (unsigned)i * pp8, t2);
+        f2 pp = { 0.f, 0.f };
+#pragma unroll
+        for (int jy = 0; jy <= K; ++jy) {
+            f2 q = { 0.f, 0.f };
+#pragma unroll
+            for (int k = 0; k <= K; ++k) q = f2{ w[k].y, w[k].y } * t2[(K + 1) * jy + k] + q;
+            pp = f2{ w[jy].x, w[jy].x } * q + pp;
+        }
+        a = f2{ wx[i], wx[i] } * pp + a;
+    }
+    return a;
+}
+
+// Staging of the whole box in the compact layout: slot (x * S1 + y) * CZ + z = (sign * c0, sign * c1) of the wrapped
+// lattice point (bounds.py:30-89 through the tables); the rows are contiguous runs of the lattice's unit-stride dim (zlin).
+// Thread = (row of the sweep, quad): 85 rows of 6 quads per sweep, three sweeps per round trip.
+template <typename T>
+__device__ __forceinline__ void compact_stage(Smem &sm, const T *__restrict__ vc0, const T *__restrict__ vc1, int tid, int S0, int S1, int S2, int loz, bool plus)
+{
+    const int r0 = tid / CQ, qd = tid - r0 * CQ;
+    const int nq = (S2 + 3) >> 2, nrow = S0 * S1;
+    const bool qon = qd < nq && r0 < CRPS;
+    const int zs = qon ? (4 * qd + 4 <= S2 ? 4 * qd : S2 - 4) : 0;   // the last quad is shifted to END at S_z
+    const unsigned boff = (unsigned)((loz + zs) * (int)sizeof(T));
+    const float rS1 = 1.f / (float)S1;
+    for (int u0 = 0; u0 * CRPS < nrow; u0 += 3) {
+        float4 a0[3], a1[3]; float sg[3];
+#pragma unroll
+        for (int u = 0; u < 3; ++u) {
+            int r = r0 + CRPS * (u0 + u);
+            r = r < nrow - 1 ? r : nrow - 1;                         // (rows that do not exist read the last one; dropped below)
+            const int x = (int)(((float)r + 0.5f) * rS1), y = r - x * S1;
+            const unsigned off = (unsigned)((sm.taboff[0][x] + sm.taboff[1][y]) * (int)sizeof(T)) + boff;
+            sg[u] = plus ? 1.f : sm.tabsgn[0][x] * sm.tabsgn[1][y];
+            a0[u] = ld4<T>(reinterpret_cast<const T *>(reinterpret_cast<const char *>(vc0) + off));
+            a1[u] = ld4<T>(reinterpret_cast<const T *>(reinterpret_cast<const char *>(vc1) + off));
+        }
+#pragma unroll
+        for (int u = 0; u < 3; ++u) {
+            const int r = r0 + CRPS * (u0 + u);
+            if (!(qon && r < nrow)) continue;
+            float2 *dst = sm.box + r * CZ + zs;
+            if (!plus) {
+                a0[u].x *= sg[u]; a0[u].y *= sg[u]; a0[u].z *= sg[u]; a0[u].w *= sg[u];
+                a1[u].x *= sg[u]; a1[u].y *= sg[u]; a1[u].z *= sg[u]; a1[u].w *= sg[u];
+            }
+            if (!(zs & 1)) {
+                reinterpret_cast<float4 *>(dst)[0] = make_float4(a0[u].x, a1[u].x, a0[u].y, a1[u].y);
+                reinterpret_cast<float4 *>(dst)[1] = make_float4(a0[u].z, a1[u].z, a0[u].w, a1[u].w);
+            } else {                                                 // shifted last quad of an odd extent: 8-byte stores
+                dst[0] = make_float2(a0[u].x, a1[u].x); dst[1] = make_float2(a0[u].y, a1[u].y);
+                dst[2] = make_float2(a0[u].z, a1[u].z); dst[3] = make_float2(a0[u].w, a1[u].w);
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
 // pull: val[b,c,o] = mask * sum_taps w vol        (nd.py:80-143)
 // ---------------------------------------------------------------------------
 // LEAN: every tile is whole and no sample is masked (extrapolate = 1) -- the launcher knows --: the validity and mask
@@ -347,13 +452,16 @@ __global__ __launch_bounds__(NT, 4) void pull_window(KParams p, const T *__restr
         TileGeom g = tile_geom(tile, gx, gy, gz, nty, ntz);
         g.ox0 = __builtin_amdgcn_readfirstlane(g.ox0); g.oy0 = __builtin_amdgcn_readfirstlane(g.oy0); g.oz0 = __builtin_amdgcn_readfirstlane(g.oz0);
         prof_mark(-1);
+        // the thread's samples: natural ids nid + 512 v, nid = the thread index with bits 4 and 5 swapped -- the two rows of a half
+        // wave lie two rows of the tile apart (what the compact tiles want; the sorted ones do not care)
+        const int nid = (tid & ~0x30) | ((tid & 0x10) << 1) | ((tid & 0x20) >> 1);
         const bool full = LEAN || (g.ox0 + TS <= g.gx && g.oy0 + TS <= g.gy && g.oz0 + TS <= g.gz);     // block-uniform
 
         // ---- coordinates of the thread's 8 samples (natural order: sample tid + 512 v) ----------------------
         float c[VPT][3];
         if (GM == 0 && full) {
             // one address per thread; its samples lie two x-planes apart
-            const float *gp = grid + b * p.grid_sb + (((int64_t)(g.ox0 + (tid >> 8)) * g.gy + (g.oy0 + ((tid >> 4) & 15))) * g.gz + (g.oz0 + (tid & 15))) * 3;
+            const float *gp = grid + b * p.grid_sb + (((int64_t)(g.ox0 + (nid >> 8)) * g.gy + (g.oy0 + ((nid >> 4) & 15))) * g.gz + (g.oz0 + (nid & 15))) * 3;
             const int64_t step = (int64_t)g.gy * g.gz * 6;
 #pragma unroll
             for (int v = 0; v < VPT; ++v) { c[v][0] = gp[v * step]; c[v][1] = gp[v * step + 1]; c[v][2] = gp[v * step + 2]; }
@@ -361,7 +469,7 @@ __global__ __launch_bounds__(NT, 4) void pull_window(KParams p, const T *__restr
 #pragma unroll
             for (int v = 0; v < VPT; ++v) {
                 int ox, oy, oz;
-                sample_pos(g, tid + NT * v, ox, oy, oz);
+                sample_pos(g, nid + NT * v, ox, oy, oz);
                 // unconditional loads from a clamped position: the compiler batches them (one exposed round trip)
                 ox = ox < g.gx ? ox : g.gx - 1; oy = oy < g.gy ? oy : g.gy - 1; oz = oz < g.gz ? oz : g.gz - 1;
                 load_xyz<GM>(p, grid, b, g, ox, oy, oz, c[v]);
@@ -375,7 +483,7 @@ __global__ __launch_bounds__(NT, 4) void pull_window(KParams p, const T *__restr
 #pragma unroll
             for (int v = 0; v < VPT; ++v) {
                 int ox, oy, oz;
-                sample_pos(g, tid + NT * v, ox, oy, oz);
+                sample_pos(g, nid + NT * v, ox, oy, oz);
                 if (ox < g.gx && oy < g.gy && oz < g.gz) validmask |= 1u << v;
             }
         }
@@ -416,6 +524,7 @@ __global__ __launch_bounds__(NT, 4) void pull_window(KParams p, const T *__restr
         prof_mark(4);
         int lo[3], S[3];
         bool whole = LEAN;                                           // the box holds the stencils of all the tile's (finite) samples
+        bool unclamped = true;
         {
             const int cap[3] = { CAPX, CAPY, CAPZ };
 #pragma unroll
@@ -423,7 +532,7 @@ __global__ __launch_bounds__(NT, 4) void pull_window(KParams p, const T *__restr
                 int l = sm.lo[d], h = sm.hi[d] + K;           // supports span [l, h]
                 if (h < l) { l = 0; h = 0; }                   // tile without valid samples
                 int sz_ = h - l + 1;
-                if (sz_ > cap[d]) { l += (sz_ - cap[d]) / 2; sz_ = cap[d]; whole = false; }   // keep the centre; the rest goes to the slow list
+                if (sz_ > cap[d]) { l += (sz_ - cap[d]) / 2; sz_ = cap[d]; whole = false; unclamped = false; }   // keep the centre; the rest goes to the slow list
                 lo[d] = l; S[d] = sz_;
             }
         }
@@ -441,6 +550,61 @@ __global__ __launch_bounds__(NT, 4) void pull_window(KParams p, const T *__restr
                 sm.tabsgn[d][slot] = (float)(int)(pk >> 32);
             }
         }
+        // ---- COMPACT tile (block-uniform): whole tile, every stencil in the unclamped box, the box fits LDS with a row pitch of CZ
+        // slots, contiguous rows: no sort, no windows -- staged once, every thread gathers its own samples
+        {
+            const bool zl = L.ss[2] == 1 && S[2] >= 4 && lo[2] >= (L.bound[2] == B_DST1 ? 1 : 0) && lo[2] + S[2] <= L.n[2];
+            const bool compact = unclamped && validmask == (1u << VPT) - 1u && zl && S[2] <= CZ && S[0] * S[1] * CZ <= BOXSLOTS && (p.dbg & 8192);
+            if (compact) {
+                const bool pl = L.bound[0] != B_ZERO && L.bound[0] != B_DST1 && L.bound[0] != B_DST2
+                             && L.bound[1] != B_ZERO && L.bound[1] != B_DST1 && L.bound[1] != B_DST2;
+                unsigned cadr[VPT];
+#pragma unroll
+                for (int v = 0; v < VPT; ++v) {
+                    int x0 = __float2int_rz(fl[v][0]) - lo[0], y0 = __float2int_rz(fl[v][1]) - lo[1], z0 = __float2int_rz(fl[v][2]) - lo[2];
+                    x0 = max(0, min(x0, S[0] - K - 1)); y0 = max(0, min(y0, S[1] - K - 1)); z0 = max(0, min(z0, S[2] - K - 1));
+                    cadr[v] = (unsigned)(((x0 * S[1] + y0) * CZ + z0) * 8);
+                }
+                const unsigned boxaddr = (unsigned)(size_t)(__attribute__((address_space(3))) void *)(sm.box);
+                const unsigned pp8 = (unsigned)(S[1] * CZ * 8);
+                for (int cch = 0; cch < p.C; cch += 2) {
+                    const bool two = cch + 1 < p.C;
+                    const T *vc0 = vol + b * p.vol_sb + cch * p.vol_sc;
+                    const T *vc1 = two ? vc0 + p.vol_sc : vc0;
+                    T *oc0 = val + b * p.val_sb + cch * p.val_sc;
+                    T *oc1 = oc0 + p.val_sc;
+                    __syncthreads();                                 // tables written / the previous pair's stores have read the box
+                    compact_stage<T>(sm, vc0, vc1, tid, S[0], S[1], S[2], lo[2], pl);
+                    __syncthreads();
+                    f2 res[VPT];
+#pragma unroll
+                    for (int v = 0; v < VPT; ++v) {
+                        float tx = c[v][0]; f2 tyz = f2{ c[v][1], c[v][2] };
+                        asm volatile("" : "+v"(tx), "+v"(tyz));
+                        res[v] = compact_sample<K>(boxaddr + opaque((int)cadr[v]), pp8, tx, tyz);
+                        asm volatile("" : "+v"(res[v]));
+                    }
+                    __syncthreads();
+                    float2 *outb = sm.box;
+#pragma unroll
+                    for (int v = 0; v < VPT; ++v) {
+                        const float m = (float)((inbmask >> v) & 1);
+                        outb[nid + NT * v] = make_float2(res[v].x * m, res[v].y * m);
+                    }
+                    __syncthreads();
+#pragma unroll
+                    for (int u = 0; u < NS / 4 / NT; ++u) {
+                        const int qi = tid + NT * u;                 // quad: x = qi >> 6, y = (qi >> 2) & 15, z = 4 (qi & 3)
+                        const float4 *src = reinterpret_cast<const float4 *>(outb + 4 * qi);
+                        const float4 lo_ = src[0], hi_ = src[1];
+                        const int64_t o = ((int64_t)(g.ox0 + (qi >> 6)) * g.gy + (g.oy0 + ((qi >> 2) & 15))) * g.gz + (g.oz0 + 4 * (qi & 3));
+                        st4<T>(oc0 + o, make_float4(lo_.x, lo_.z, hi_.x, hi_.z));
+                        if (two) st4<T>(oc1 + o, make_float4(lo_.y, lo_.w, hi_.y, hi_.w));
+                    }
+                }
+                return;
+            }
+        }
         // ---- classification + histogram.  In the box <=> lo <= i0 <= lo + S - K - 1 in every dim.  Every sample does
         // ONE returning LDS add, unconditionally (the ranks of the 8 samples come back together): on the counter of its
         // (first-tap plane, class), or on the spare counter when it is not in the box.
@@ -456,7 +620,7 @@ __global__ __launch_bounds__(NT, 4) void pull_window(KParams p, const T *__restr
                 const int yz = y0 * PZ + z0;                         // slot inside a plane; yz mod 32 = class
                 unsigned bin = (unsigned)((x0 << 5) | (yz & (NCLS - 1)));
                 bin = bin < (unsigned)(NXB * NCLS - 1) ? bin : (unsigned)(NXB * NCLS - 1);
-                kq[v] = (int)(bin >> 5) | ((yz & 2047) << 5) | ((tid + NT * v) << 16) | (3 << 28);
+                kq[v] = (int)(bin >> 5) | ((yz & 2047) << 5) | ((nid + NT * v) << 16) | (3 << 28);
                 rk[v] = atomicAdd(&(&sm.hist[0][0])[bin], 1);
             }
             if (tid == 0) sm.nslow = 0;
@@ -469,7 +633,7 @@ __global__ __launch_bounds__(NT, 4) void pull_window(KParams p, const T *__restr
                               & (fl[v][2] >= flo[2]) & (fl[v][2] <= fhi[2]) & (bool)((validmask >> v) & 1);
                 const int x0 = __float2int_rz(fl[v][0]) - lo[0], y0 = __float2int_rz(fl[v][1]) - lo[1], z0 = __float2int_rz(fl[v][2]) - lo[2];
                 const int yz = y0 * PZ + z0;                         // slot inside a plane; yz mod 32 = class
-                kq[v] = (x0 & 31) | ((yz & 2047) << 5) | ((tid + NT * v) << 16) | (int)(((inbmask >> v) & 1) << 28) | (1 << 29);
+                kq[v] = (x0 & 31) | ((yz & 2047) << 5) | ((nid + NT * v) << 16) | (int)(((inbmask >> v) & 1) << 28) | (1 << 29);
                 if (in) fastmask |= 1u << v;
                 rk[v] = atomicAdd(in ? &sm.hist[x0][yz & (NCLS - 1)] : &sm.oob, 1);
             }
@@ -549,7 +713,7 @@ __global__ __launch_bounds__(NT, 4) void pull_window(KParams p, const T *__restr
             const unsigned long long bal = __ballot((oob >> v) & 1);
             if ((oob >> v) & 1) {
                 const int rank = sm.oobc[v][tid >> 6] + __popcll(bal & ((1ull << (tid & 63)) - 1ull));
-                if (rank < SLOWCAP) sm.slow[rank] = (unsigned short)(tid + NT * v);
+                if (rank < SLOWCAP) sm.slow[rank] = (unsigned short)(nid + NT * v);
                 else selfmask |= 1u << v;
             }
         }
@@ -718,13 +882,13 @@ __global__ __launch_bounds__(NT, 4) void pull_window(KParams p, const T *__restr
                 for (int v = 0; v < VPT; ++v) {
                     if (!((selfmask >> v) & 1)) continue;
                     int ox, oy, oz; float x[3];
-                    sample_pos(g, tid + NT * v, ox, oy, oz);
+                    sample_pos(g, nid + NT * v, ox, oy, oz);
                     load_xyz<GM>(p, grid, b, g, ox, oy, oz, x);
                     int ii[3]; float tt[3];
 #pragma unroll
                     for (int d = 0; d < 3; ++d) split(K, x[d], ii[d], tt[d]);
                     const float m = inb_mask(p, x);
-                    outb[tid + NT * v] = make_float2(m * tiled::gather_one_thread<T>(L, vc0, ii[0], ii[1], ii[2], tt[0], tt[1], tt[2], -1),
+                    outb[nid + NT * v] = make_float2(m * tiled::gather_one_thread<T>(L, vc0, ii[0], ii[1], ii[2], tt[0], tt[1], tt[2], -1),
                                                      m * tiled::gather_one_thread<T>(L, vc1, ii[0], ii[1], ii[2], tt[0], tt[1], tt[2], -1));
                 }
             }
