@@ -478,9 +478,20 @@ def test_tiled2d_grid_gradient_matches_generic(dtype):
                     _same(fast[0].float(), slow[0].float(), 1e-2 if dtype != torch.float32 else 1e-5, ("push bwd 2d val", dtype, C, sigma, o, b, ex))
 
 
+@pytest.fixture
+def sample_tiles_only():
+    """The hand-back tests exercise csrc/defer.hip: the sample tiles leave stretched tiles to the generic kernel.  With the router
+    of the pull (interpol_pull_ws, a workspace) those tiles go to the bricks of the image instead, so it is switched off here."""
+    from interpol import backend
+    prev = backend.rough_deformations
+    backend.rough_deformations = False
+    yield
+    backend.rough_deformations = prev
+
+
 @pytest.mark.parametrize("dim,order,dtype", [(3, 3, torch.float32), (3, 2, torch.bfloat16), (3, 1, torch.float32), (3, 5, torch.float32),
                                              (3, 7, torch.float32), (2, 3, torch.float32), (2, 2, torch.bfloat16), (2, 1, torch.float16)])
-def test_stretched_tiles_are_handed_back_to_the_generic_kernels(dim, order, dtype):
+def test_stretched_tiles_are_handed_back_to_the_generic_kernels(dim, order, dtype, sample_tiles_only):
     """Zoomed lattices (stride 2.2 / 3.1 plus a little noise: a 16^3 sample tile spans more lattice points than its LDS box
     holds): the tile kernels hand such tiles back to the generic kernel of the operator (csrc/defer.hip).  Every operator,
     with the hand-back (default), without it (debug switch 256: the in-kernel fallbacks) and the generic kernels alone must
@@ -556,7 +567,7 @@ def test_batch_broadcast_grid_gradients(dim, order):
             _same(a, b, 1e-5, (name, dim, order, zoom))
 
 
-def test_hand_back_on_concurrent_streams():
+def test_hand_back_on_concurrent_streams(sample_tiles_only):
     """Each stream owns a slot of the hand-back descriptor lists (csrc/defer.hip): stretched workloads enqueued on several
     streams at once must not see each other's descriptors."""
     from interpol import _hip
@@ -598,7 +609,7 @@ def _stretched_problem(seed, scale=2.4):
     return vol, grid
 
 
-def test_hand_back_slots_are_recycled_over_many_streams():
+def test_hand_back_slots_are_recycled_over_many_streams(sample_tiles_only):
     """csrc/defer.hip keeps 16 slots per device; the 17th stream takes the least recently used one.  40 streams run a stretched pull
     one after the other in the ALWAYS mode: the 40th must still hand back -- its result is bit-identical to the first stream's
     (tiles + generic kernel) and differs, in the last bits, from the NEVER mode (tiles alone)."""
@@ -627,7 +638,7 @@ def test_hand_back_slots_are_recycled_over_many_streams():
 
 
 @pytest.mark.parametrize("mode", ["always", "never"])
-def test_pinned_hand_back_mode_is_history_independent(mode):
+def test_pinned_hand_back_mode_is_history_independent(mode, sample_tiles_only):
     """In the ALWAYS / NEVER modes every operator is a deterministic function of its inputs (the reference's gather is:
     nd.py:118-136): the same stretched pull before and after a run of smooth launches on the same stream is torch.equal."""
     from interpol import _hip
@@ -645,7 +656,7 @@ def test_pinned_hand_back_mode_is_history_independent(mode):
         _hip.set_handback(prev)
 
 
-def test_hand_back_two_host_threads_on_one_stream():
+def test_hand_back_two_host_threads_on_one_stream(sample_tiles_only):
     """Two host threads launch stretched workloads on the SAME stream: the slot's lease keeps each tile kernel and its deferred
     generic kernel together (interleaved, the second launch's descriptors would hide the first's: tiles silently skipped)."""
     import threading
@@ -1501,6 +1512,35 @@ def test_routed_pull_bricks_of_the_image_against_oracle(sigma):
                     got = _hip.gather("pull", inp.to(DEV), grid.to(DEV), b, [order] * 3, ex, flags=fl)
                     G.assert_close(got.cpu().numpy(), want, rtol=1e-5, atol_rel=1e-5, what=(name, sigma, b, order, ex))
                     assert G.rel_err(got.cpu().numpy(), slow.cpu().numpy()) < 4e-6, (name, "vs generic", sigma, b, order, ex)
+    finally:
+        oracle.set_threads(1)
+
+
+@pytest.mark.parametrize("sigma", [0.0, 2.0, 7.0])
+def test_routed_grid_gradient_bricks_of_the_image_against_oracle(sigma):
+    """interpol_pull_backward with a bricks workspace in `scratch` (3-D quadratic / cubic, float32, grid gradient alone,
+    pushpull.py:256-257): the sample tiles of the grid gradient leave rough tiles to bricks of the image (own_bin in index mode 2 +
+    own_gather<K, true>).  Routed default and bricks alone against the oracle and the generic kernel: every bound (mixed per
+    dim), the three extrapolation modes, 1 - 3 channels (3: the second pair accumulates), overhanging sample grids."""
+    from interpol import _hip
+    g = torch.Generator().manual_seed(int(sigma) + 60)
+    oracle.set_threads(8)
+    try:
+        for (ishape, oshape) in (((40, 33, 50), (37, 45, 29)), ((48, 48, 48), (48, 48, 48))):
+            for bound in range(7):
+                order = 3 - (bound % 2)
+                ex, C = (bound + order) % 3, 1 + (bound + order) % 3
+                inp = torch.randn([2, C, *ishape], generator=g)
+                gout = torch.randn([2, C, *oshape], generator=g)
+                lin = [torch.linspace(-2, n + 1, m) for n, m in zip(ishape, oshape)]
+                grid = torch.stack(torch.meshgrid(*lin, indexing="ij"), -1)[None] + sigma * torch.randn([2, *oshape, 3], generator=g)
+                b = [bound, (bound + 3) % 7, (bound + 5) % 7]
+                _, want = oracle.grid_pull_backward(gout.double().numpy(), inp.double().numpy(), grid.double().numpy(), b, [order], ex)
+                slow = _hip.pull_backward(gout.to(DEV), inp.to(DEV), grid.to(DEV), b, [order] * 3, ex, False, True, flags=_hip.FLAG_NO_FASTPATH)[1]
+                for name, fl in (("routed", 0), ("bricks", _hip.FLAG_BINNED_SCATTER)):
+                    got = _hip.pull_backward(gout.to(DEV), inp.to(DEV), grid.to(DEV), b, [order] * 3, ex, False, True, flags=fl)[1]
+                    G.assert_close(got.cpu().numpy(), want, rtol=1e-5, atol_rel=1e-5, what=(name, sigma, b, order, ex))
+                    assert G.rel_err(got.cpu().numpy(), slow.cpu().numpy()) < 6e-6, (name, "vs generic", sigma, b, order, ex)
     finally:
         oracle.set_threads(1)
 

@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""Default-flag scatter on the deformations that used to be cliffs: i.i.d. noise, a folding smooth field, strides, zooms.
+"""Default-flag scatter (and, since round 4, gather) on the deformations that used to be cliffs: i.i.d. noise, a folding smooth field, strides, zooms.
 Prints ms per call: default routing (probe: tiles or owner-computes), tiles only, owner-computes only, and the largest difference of the
 default result to the generic kernels."""
 import os, sys, json
@@ -50,6 +50,17 @@ for name, grid in cases.items():
     a, r = f(), f(_hip.FLAG_NO_FASTPATH)
     res["rel_err_vs_generic"] = "%.1e" % float((a - r).abs().max() / r.abs().max())
     del a, r
+    # the grid gradient of the pull (backward w.r.t. the grid): routed / sample tiles only / bricks only, error against the generic kernel
+    gout = torch.randn_like(inp)
+    gf = lambda fl=0: _hip.pull_backward(gout, inp, grid, [3] * 3, [3] * 3, 1, False, True, flags=fl)[1]
+    res["gradgrid_default"] = round(timeit(gf), 2)
+    backend.rough_deformations = False
+    res["gradgrid_tiles"] = round(timeit(gf), 2)
+    backend.rough_deformations = None
+    res["gradgrid_bricks"] = round(timeit(lambda: gf(_hip.FLAG_BINNED_SCATTER)), 2)
+    a, a2, r = gf(), gf(_hip.FLAG_BINNED_SCATTER), gf(_hip.FLAG_NO_FASTPATH)
+    res["gradgrid_rel_err_vs_generic"] = "%.1e / bricks %.1e" % (float((a - r).abs().max() / r.abs().max()), float((a2 - r).abs().max() / r.abs().max()))
+    del a, a2, r, gout
     if name in ("smooth_amp_8", "iid_sigma_6"):
         gout = torch.randn_like(inp)
         res["pull_backward_both"] = round(timeit(lambda: _hip.pull_backward(gout, inp, grid, [3] * 3, [3] * 3, 1, True, True)), 2)
@@ -60,4 +71,12 @@ for name, grid in cases.items():
         gr_ = _hip.pull_backward(gout, inp, grid, [3] * 3, [3] * 3, 1, True, True, flags=_hip.FLAG_NO_FASTPATH)
         res["bwd_rel_err"] = "%.1e" % max(float((x - y).abs().max() / y.abs().max()) for x, y in zip(ga, gr_))
         del gout, ga, gr_
+    # the pull of the same field: routed (the tiles leave the rough tiles to bricks of the image), tiles only, bricks only
+    pf = lambda fl=0: _hip.gather("pull", inp, grid, [3] * 3, [3] * 3, 1, flags=fl)
+    res["pull_default"] = round(timeit(pf), 2)
+    res["pull_tiles"] = round(timeit(lambda: pf(_hip.FLAG_FORCE_TILED)), 2)
+    res["pull_bricks"] = round(timeit(lambda: pf(_hip.FLAG_BINNED_SCATTER)), 2)
+    a, r = pf(), pf(_hip.FLAG_NO_FASTPATH)
+    res["pull_rel_err_vs_generic"] = "%.1e" % float((a - r).abs().max() / r.abs().max())
+    del a, r
     print(name, json.dumps(res), flush=True)

@@ -59,7 +59,10 @@ IP_DECL_TILED(f32) IP_DECL_TILED(bf16) IP_DECL_TILED(f16)
 int try_owner_push(const interpol_problem *, const KParams &, const void *, const void *, void *, void *, int64_t, hipStream_t, const int **);
 int try_push_f64_tiles(const interpol_problem *, const KParams &, const void *, const void *, void *, hipStream_t);
 int owner_pull_prepare(const interpol_problem *, const KParams &, void *, int64_t, hipStream_t, int **, int *);
-int owner_pull_finish(const interpol_problem *, const KParams &, const void *, const void *, void *, void *, int64_t, bool, hipStream_t);
+int owner_pull_finish(const interpol_problem *, const KParams &, const void *, const void *, void *, void *, int64_t, bool, hipStream_t,
+                      bool grad = false, const void *gout = nullptr, bool probed = false);
+int owner_grad_probe(const interpol_problem *, const KParams &, const void *, void *, int64_t, hipStream_t);
+int try_sorted_gradc_f32(const interpol_problem *, const KParams &, const void *, const void *, const void *, void *, hipStream_t);
 int64_t owner_pull_workspace_bytes(const interpol_problem *, const KParams &);
 int64_t owner_workspace_bytes(const interpol_problem *, const KParams &, bool);
 
@@ -566,6 +569,34 @@ int interpol_pull_backward(const interpol_problem *p, const void *grad_out, cons
             if (rc < 0 || rc > 1) return rc;
             vol_done = rc == 1;
             rc = (vol_done && !grad_grid) ? 1 : 0;
+        }
+        if (rc == 0 && grad_grid && (vol_done || !grad_vol) && p->dtype == INTERPOL_F32 && scratch) {
+            // float32 with a bricks workspace (interpol_pull_workspace(p) bytes, as interpol_pull_ws): the sample tiles of the grid
+            // gradient flag the tiles whose samples leave their LDS box; those samples go to the bricks of the image
+            // (own_gather<K, true>, push_owner.hip) -- 4 x 2 x 256^3 cubic, sigma = 6: 20 -> x ms
+            int *flags = nullptr;
+            int nzero = 0;
+            const int r = owner_pull_prepare(p, k, scratch, scratch_bytes, st, &flags, &nzero);
+            if (r != 0 && r != 1) return r;
+            if (r == 1 && (p->flags & INTERPOL_FLAG_BINNED_SCATTER)) {
+                rc = owner_pull_finish(p, k, vol, grid, grad_grid, scratch, scratch_bytes, true, st, true, grad_out);
+                if (rc) return rc;
+                rc = 1;
+            } else if (r == 1) {
+                // a probe of the call first: dense samplings go to the bricks altogether (the tile kernel returns at once: gate_n < 0,
+                // the probe's header lies -gate_n ints in front of the flags), else the tiles run and flag what they leave
+                rc = owner_grad_probe(p, k, grid, scratch, scratch_bytes, st);
+                if (rc) return rc;
+                KParams kg = k;
+                kg.gate = flags; kg.gate_n = -nzero;
+                rc = try_sorted_gradc_f32(p, kg, grad_out, vol, grid, grad_grid, st);
+                if (rc != 0 && rc != 1) return rc;
+                if (rc == 1 && !(k.dbg & 32768)) {
+                    rc = owner_pull_finish(p, k, vol, grid, grad_grid, scratch, scratch_bytes, false, st, true, grad_out, true);
+                    if (rc) return rc;
+                    rc = 1;
+                }
+            }
         }
         if (rc == 0) {
             rc = try_fast_pullbwd(p, k, grad_out, vol, grid, vol_done ? nullptr : acc, grad_grid, gsb, gsc, st);   // 1 = done, 0 = declined

@@ -341,18 +341,19 @@ __global__ __launch_bounds__(NT, 4) void pull_sorted(KParams p, const T *__restr
         Tile<K, GM>::load(p, grid, b, g, tid, cnext);
         tl.build(p, L, g, sm, tid, cnext);
         const int nslow = sm.nslow < SLOWCAP ? sm.nslow : SLOWCAP;
+        // interpol_pull_ws: a tile with many samples outside the box -- each costs a wave -- is left to the bricks of the image
+        // (push_owner.hip: own_gather), whose cost does not depend on the deformation: flagged, skipped (block-uniform).  Rough
+        // AND smooth-but-stretched tiles (folding fields, zooms: 4.7 -> 2.3 ms where the generic kernel used to take them)
+        if (p.gate && sm.nslow > ROUGH) {
+            if (tid == 0) const_cast<int *>(p.gate)[work] = 1;
+            __syncthreads();
+            continue;
+        }
         if (defer.flag) {                                                 // (block-uniform) too rough for the box: the generic kernel takes the tile, defer.hip
             bool hand_back = sm.nslow > (HANDBACK << ((p.dbg >> 9) & 7));
             if (hand_back) hand_back = tiled::tile_smooth(p, grid, b, 3, g.ox0, g.oy0, g.oz0, TS, TS, TS, g.gx, g.gy, g.gz, sm.hi);
             if (hand_back && tid == 0) defer_mark(defer, work, tile_desc(b, g.ox0 / TS, g.oy0 / TS, g.oz0 / TS));
             if (hand_back && defer.desc) { __syncthreads(); continue; }
-        }
-        // interpol_pull_ws: a tile with many samples outside the box -- each costs a wave -- is left to the bricks of the image
-        // (push_owner.hip: own_gather), whose cost does not depend on the deformation: flagged, skipped (block-uniform)
-        if (p.gate && sm.nslow > ROUGH) {
-            if (tid == 0) const_cast<int *>(p.gate)[work] = 1;
-            __syncthreads();
-            continue;
         }
         // rows of the box are contiguous runs of the lattice's unit-stride dim, sign +1 throughout
         // (dst1 has sign 0 at index 0 -- quirk B-3 -- so its run must start at 1)
@@ -581,7 +582,12 @@ __global__ __launch_bounds__(NT, 4) void gradc_sorted(KParams p, const T *__rest
 #pragma unroll
     for (int d = 0; d < 3; ++d) { L.bound[d] = p.bound[d]; L.n[d] = p.vol_n[d]; L.ss[d] = p.vol_ss[d] / (int)sizeof(T); L.k[d] = K; }
     L.lin = 0;
+    // interpol_pull_backward with a bricks workspace: the probe's verdict lies -gate_n ints in front of the tile flags; 1 = every
+    // tile goes to the bricks of the image (push_owner.hip: own_probe, nch < 0)
+    if (p.gate && p.gate_n < 0 && p.gate[p.gate_n] == 1) return;
     const WorkRange wr(ntiles * nbatch);
+    if (p.gate)
+        for (int w_ = wr.first + (int)threadIdx.x * wr.step; w_ < wr.end; w_ += NT * wr.step) const_cast<int *>(p.gate)[w_] = 0;
     for (int work = wr.first; work < wr.end; work += wr.step) {
         // the thread index is made opaque per tile: everything derived from it would otherwise be
         // hoisted out of the persistent loop and held (spilled) across all phases
@@ -595,6 +601,12 @@ __global__ __launch_bounds__(NT, 4) void gradc_sorted(KParams p, const T *__rest
         Tile<K, GM>::load(p, grid, b, g, tid, cnext);
         tl.build(p, L, g, sm, tid, cnext);
         const int nslow = sm.nslow < SLOWCAP ? sm.nslow : SLOWCAP;
+        // interpol_pull_backward with a bricks workspace: the tile is left to the bricks of the image (as pull_sorted)
+        if (p.gate && sm.nslow > ROUGH) {
+            if (tid == 0) const_cast<int *>(p.gate)[work] = 1;
+            __syncthreads();
+            continue;
+        }
         if (defer.flag) {                                                 // (block-uniform) too rough for the box: the generic kernel takes the tile, defer.hip
             bool hand_back = sm.nslow > (HANDBACK << ((p.dbg >> 9) & 7));
             if (hand_back) hand_back = tiled::tile_smooth(p, grid, b, 3, g.ox0, g.oy0, g.oz0, TS, TS, TS, g.gx, g.gy, g.gz, sm.hi);

@@ -198,17 +198,53 @@ __device__ __forceinline__ void gather_direct(const KParams &p, const T *__restr
     }
 }
 
+// The same for the grid gradient of the pull (pushpull.py:256-257): ggrid[b,o,:] = mask * sum_c gout[b,c,o] * grad pull(img[b,c])(x_o);
+// p: val_* describe grad_out, the grid gradient is dense (B, *out, 3).
+template <typename T, int K, int GM>
+__device__ __forceinline__ void gradc_direct(const KParams &p, const T *__restrict__ img, const T *__restrict__ gout, const float *__restrict__ grid,
+                                             float *__restrict__ ggrid, int64_t b, TileGeom g, int tid, unsigned mask)
+{
+    Lattice L;
+#pragma unroll
+    for (int d = 0; d < 3; ++d) { L.bound[d] = p.bound[d]; L.n[d] = p.vol_n[d]; L.ss[d] = p.vol_ss[d] / (int)sizeof(T); L.k[d] = K; }
+    L.lin = 0;
+#pragma unroll 1
+    for (int v = 0; v < VPT1; ++v) {
+        if (!((mask >> v) & 1)) continue;
+        int ox, oy, oz; float x[3];
+        sample_pos(g, tid + NT1 * v, ox, oy, oz);
+        load_xyz<GM>(p, grid, b, g, ox, oy, oz, x);
+        const int64_t o = ((int64_t)ox * g.gy + oy) * g.gz + oz;
+        const float m = inb_mask(p, x);
+        int ii[3]; float tt[3];
+#pragma unroll
+        for (int d = 0; d < 3; ++d) split(K, x[d], ii[d], tt[d]);
+        float a[3] = { 0.f, 0.f, 0.f };
+#pragma unroll 1
+        for (int ch = 0; ch < p.C; ++ch) {
+            const float gv = gout ? Cvt<float, T>::ld(gout[b * p.val_sb + ch * p.val_sc + o]) : 1.f;
+#pragma unroll 1
+            for (int d = 0; d < 3; ++d)
+                a[d] = __builtin_fmaf(gv, tiled::gather_one_thread<T>(L, img + b * p.vol_sb + ch * p.vol_sc, ii[0], ii[1], ii[2], tt[0], tt[1], tt[2], d), a[d]);
+        }
+        float *dst = ggrid + (b * p.N + o) * 3;
+        dst[0] = a[0] * m; dst[1] = a[1] * m; dst[2] = a[2] * m;
+    }
+}
+
 // IDX (the owner-computes pull, own_gather below): the records carry the sample's linear index instead of a source value; `val` is
 // then the IMAGE and `vol` the OUTPUT of the gather (for the samples gathered directly), `bmax` the list of non-empty bricks
-// (entry 0: their number).
-template <typename T, int K, int GM, bool IDX = false>
+// (entry 0: their number).  IDX == 2: the grid gradient of the pull (own_gather<K, true>): `aux` is grad_out, `vol` the grid gradient.
+template <typename T, int K, int GM, int IDX = 0>
 __global__ __launch_bounds__(NT1, 4) void own_bin(KParams p, BrickGrid bg, const T *__restrict__ val, const float *__restrict__ grid,
                                                float *__restrict__ vol, int *__restrict__ ndesc, uint2 *__restrict__ desc,
                                                float4 *__restrict__ rec, float *__restrict__ vals, unsigned short *__restrict__ meta,
                                                int *__restrict__ bmax, int64_t nrec,
-                                               int gx, int gy, int gz, int nty, int ntz, int ntiles, const int *__restrict__ gate)
+                                               int gx, int gy, int gz, int nty, int ntz, int ntiles, const int *__restrict__ gate,
+                                               const T *__restrict__ aux, const int *__restrict__ all)
 {
-    if (IDX ? (gate && gate[blockIdx.x] == 0) : (gate && *gate != 1)) return;      // AUTO: the probe chose the tiles / (pull) the sample tiles served this tile
+    // AUTO: the probe chose the tiles / (pull, grid gradient) the sample tiles served this tile -- unless the probe gave every tile to the bricks (*all == 1)
+    if (IDX ? (gate && gate[blockIdx.x] == 0 && !(all && *all == 1)) : (gate && *gate != 1)) return;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     BinSmem &sm = *reinterpret_cast<BinSmem *>(smem_raw);
     const int tid = threadIdx.x;
@@ -410,6 +446,7 @@ __global__ __launch_bounds__(NT1, 4) void own_bin(KParams p, BrickGrid bg, const
         if (sm.bmx[0]) atomicMax(&bmax[2 * (int64_t)bk], sm.bmx[0]);
         if (sm.bmx[1]) atomicMax(&bmax[2 * (int64_t)bk + 1], sm.bmx[1]);
     }
+    if (IDX == 2) { if (direct) gradc_direct<T, K, GM>(p, val, aux, grid, vol, b, g, tid, direct); return; }
     if (IDX) { if (direct) gather_direct<T, K, GM>(p, val, grid, reinterpret_cast<T *>(vol), b, g, tid, direct); return; }
     if (direct) scatter_direct<T, K, GM>(p, val, grid, vol, b, g, tid, direct, nch);
 }
@@ -1069,10 +1106,14 @@ __device__ __forceinline__ void gather_reads(unsigned addr, f2 (&v)[16])
 }
 #undef IP_RD
 
-template <int K>
+// GRAD: the grid gradient of the pull instead (pushpull.py:256-257) -- per tap the channel pair contracted with grad_out (`gout`, two
+// scattered 4-byte loads per sample and pair), three derivative sums, `out` = the dense (B, *out, 3) grid gradient: written by the
+// first pair, accumulated by the following ones (the same thread owns the sample in every pair).
+template <int K, bool GRAD = false>
 __global__ __launch_bounds__(NT, 4) void own_gather(KParams p, BrickGrid bg, const int *__restrict__ ndesc, const uint2 *__restrict__ desc,
                                                     const float4 *__restrict__ rec, const int *__restrict__ list, int *__restrict__ draw,
-                                                    const float *__restrict__ img, float *__restrict__ out, const int *__restrict__ gate)
+                                                    const float *__restrict__ img, float *__restrict__ out, const int *__restrict__ gate,
+                                                    const float *__restrict__ gout)
 {
     if (gate && *gate != 1) return;                                  // the probe chose the sample tiles
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -1159,6 +1200,44 @@ __global__ __launch_bounds__(NT, 4) void own_gather(KParams p, BrickGrid bg, con
                     }
                     f2 w[4];
                     weights_yz<K>(tyz, w);
+                    if (GRAD) {
+                        const int64_t o = (int64_t)__float_as_int(rc.w);
+                        const float *gc0 = gout ? gout + b * p.val_sb + (int64_t)c * p.val_sc : nullptr;
+                        const float go0 = gc0 ? gc0[o] : 1.f, go1 = two ? (gc0 ? gc0[p.val_sc + o] : 1.f) : 0.f;   // (no grad_out: ones -- the backward of count)
+                        f2 dq[4];
+                        wgrads_yz<K>(tyz, dq);
+                        float ag0 = 0.f, ag1 = 0.f, ag2 = 0.f;
+#pragma unroll
+                        for (int ii = 0; ii <= K; ++ii) {
+                            f2 t2[16];
+                            gather_reads(addr + (unsigned)(ii * GPLANE * 8), t2);
+                            float pp = 0.f, ppy = 0.f, ppz = 0.f;
+#pragma unroll
+                            for (int jy = 0; jy <= K; ++jy) {
+                                float q = 0.f, qz = 0.f;
+#pragma unroll
+                                for (int k = 0; k <= K; ++k) {
+                                    const float sgl = __builtin_fmaf(go1, t2[4 * jy + k].y, go0 * t2[4 * jy + k].x);
+                                    q = __builtin_fmaf(w[k].y, sgl, q);
+                                    qz = __builtin_fmaf(dq[k].y, sgl, qz);
+                                }
+                                pp = __builtin_fmaf(w[jy].x, q, pp);
+                                ppy = __builtin_fmaf(dq[jy].x, q, ppy);
+                                ppz = __builtin_fmaf(w[jy].x, qz, ppz);
+                            }
+                            const float wxi = weight_x<K>(tx, ii);
+                            ag0 = __builtin_fmaf(wgrad_x<K>(tx, ii), pp, ag0);
+                            ag1 = __builtin_fmaf(wxi, ppy, ag1);
+                            ag2 = __builtin_fmaf(wxi, ppz, ag2);
+                            asm volatile("" : "+v"(ag0), "+v"(ag1), "+v"(ag2));      // (one x-plane at a time: the planes' 16 reads each interleaved spill)
+                        }
+                        const float xyz[3] = { rc.x, rc.y, rc.z };
+                        const float m = inb_mask(p, xyz);            // nd.py:139-140
+                        float *dst = out + (b * p.N + o) * 3;
+                        if (c == 0) { dst[0] = ag0 * m; dst[1] = ag1 * m; dst[2] = ag2 * m; }
+                        else { dst[0] += ag0 * m; dst[1] += ag1 * m; dst[2] += ag2 * m; }
+                        continue;
+                    }
                     f2 a = { 0.f, 0.f };
 #pragma unroll
                     for (int ii = 0; ii <= K; ++ii) {
@@ -1189,6 +1268,7 @@ __global__ __launch_bounds__(NT, 4) void own_gather(KParams p, BrickGrid bg, con
 
 constexpr int NPROBE = 128;
 constexpr int BOXVOL = 14500;
+constexpr int DENSEVOL = 13000;
 struct ProbeHdr { int gate, done, nslow, nfar, nvalid, nbox, nfull, ncorner; };
 
 template <int K, int GM>
@@ -1283,7 +1363,14 @@ __global__ __launch_bounds__(NT1) void own_probe(KParams p, BrickGrid bg, const 
             // overlap, the tiles flush little more than the target then (zoom 1.5: tiles 4.0, this file 5.5 ms) -- unless samples
             // lie outside the binned range
             const bool rough = nch > 1 && (int64_t)nb > (int64_t)BOXVOL * nt && (int64_t)nb * 10 > (int64_t)nc * 16;
-            hdr->gate = (((int64_t)ns * 250 > nn || rough) && (int64_t)nf * 64 <= nn) ? 1 : 0;
+            // nch < 0, the grid gradient of the pull (own_gather<K, true>): the bricks of the image beat the sample tiles on DENSE
+            // samplings whatever their roughness (config 2: identity 1.9 against 2.2 ms, sigma = 2 2.06 / 2.47, sigma = 6 2.8 / 20) and
+            // lose on expanding ones, whose samples spread over more bricks (zoom 1.5: 4.1 / 2.3 ms) -- dense: the eight corner samples
+            // of a tile span at most DENSEVOL lattice points on average (19^3 at the identity, 27^3 at zoom 1.5), or the tiles leave
+            // samples outside their boxes
+            const bool dense = (int64_t)nc <= (int64_t)DENSEVOL * nt;
+            if (nch < 0) hdr->gate = (((int64_t)ns * 250 > nn || dense) && (int64_t)nf * 64 <= nn) ? 1 : 0;
+            else hdr->gate = (((int64_t)ns * 250 > nn || rough) && (int64_t)nf * 64 <= nn) ? 1 : 0;
         }
     }
 }
@@ -1359,9 +1446,9 @@ int64_t owner_workspace_bytes(const interpol_problem *p, const KParams &k, bool 
 }
 
 namespace owner {
-template <typename T, bool IDX = false>
+template <typename T, int IDX = 0>
 static int launch_bin(const interpol_problem *p, const KParams &k, const BrickGrid &bg, const Workspace &w, const void *val, const void *grid,
-                      void *vol, const int *gate, hipStream_t st)
+                      void *vol, const int *gate, hipStream_t st, const void *aux = nullptr, const int *all = nullptr)
 {
     const int gx = (int)p->grid_shape[0], gy = (int)p->grid_shape[1], gz = (int)p->grid_shape[2];
     const int nty = (gy + TS - 1) / TS, ntz = (gz + TS - 1) / TS;
@@ -1372,7 +1459,7 @@ static int launch_bin(const interpol_problem *p, const KParams &k, const BrickGr
         const int attr = big_lds<own_bin<T, KK, GM, IDX>>(sizeof(BinSmem));                                               \
         if (attr) return attr;                                                                                          \
         hipLaunchKernelGGL((own_bin<T, KK, GM, IDX>), tgrid, dim3(NT1), sizeof(BinSmem), st, k, bg, (const T *)val, (const float *)grid, \
-                           (float *)vol, w.ndesc, w.desc, w.rec, w.vals, w.meta, w.bmax, w.nrec, gx, gy, gz, nty, ntz, ntiles, gate); \
+                           (float *)vol, w.ndesc, w.desc, w.rec, w.vals, w.meta, w.bmax, w.nrec, gx, gy, gz, nty, ntz, ntiles, gate, (const T *)aux, all); \
     }
 #define IP_OWN_BY_GM(KK)                                                                                                \
     { if (k.sep == 0) IP_OWN_BIN(KK, 0) else if (k.sep == 1) IP_OWN_BIN(KK, 1) else if (k.sep == 2) IP_OWN_BIN(KK, 2) else IP_OWN_BIN(KK, 3) }
@@ -1489,10 +1576,35 @@ int owner_pull_prepare(const interpol_problem *p, const KParams &k, void *worksp
     *nzero_out = (int)nz;
     return 1;
 }
+// Step 1b (grid gradient, INTERPOL_FLAG_AUTO_SCATTER): clear the counters and let the probe decide whether EVERY tile goes to the
+// bricks (hdr->gate = 1: gradc_sorted returns at once, own_bin takes every tile) or the sample tiles run and flag what they leave
+int owner_grad_probe(const interpol_problem *p, const KParams &k, const void *grid, void *workspace, int64_t workspace_bytes, hipStream_t st)
+{
+    using namespace owner;
+    const int ntiles = tile_count(p);
+    Workspace w;
+    if (layout(k, (int)p->batch, ntiles, 1, workspace, &w, (int64_t)ntiles * p->batch) > workspace_bytes) return INTERPOL_E_SCRATCH;
+    const BrickGrid bg = brick_grid(k);
+    const int64_t nz = 64 + 3ll * w.nbricks;
+    hipLaunchKernelGGL(own_zero, dim3((unsigned)((nz + 1023) / 1024)), dim3(1024), 0, st, (int *)w.hdr, (int)nz);
+    const int B = (int)p->batch;
+    const int gx = (int)p->grid_shape[0], gy = (int)p->grid_shape[1], gz = (int)p->grid_shape[2];
+    const int nty = (gy + TS - 1) / TS, ntz = (gz + TS - 1) / TS;
+    const long long total = (long long)ntiles * B;
+    const dim3 pgrid((unsigned)(total < NPROBE ? total : NPROBE));
+#define IP_OWN_PROBE(KK, GM) hipLaunchKernelGGL((own_probe<KK, GM>), pgrid, dim3(NT1), 0, st, k, bg, (const float *)grid, w.hdr, gx, gy, gz, nty, ntz, ntiles, B, -1);
+#define IP_OWN_PROBE_GM(KK) { if (k.sep == 0) IP_OWN_PROBE(KK, 0) else if (k.sep == 1) IP_OWN_PROBE(KK, 1) else if (k.sep == 2) IP_OWN_PROBE(KK, 2) else IP_OWN_PROBE(KK, 3) }
+    if (k.order[0] == 3) IP_OWN_PROBE_GM(3) else IP_OWN_PROBE_GM(2)
+#undef IP_OWN_PROBE_GM
+#undef IP_OWN_PROBE
+    const hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : (int)e;
+}
 // Step 2 (behind the sample tiles, or alone: all == true, INTERPOL_FLAG_BINNED_SCATTER): the flagged tiles' samples sorted by the
 // brick of the image they read (own_bin, index mode; unbinned samples are gathered on the spot), then the bricks (own_gather).
+// grad == true: the grid gradient of the pull (val := the dense grid gradient, gout := grad_out or NULL for ones).
 int owner_pull_finish(const interpol_problem *p, const KParams &k, const void *vol, const void *grid, void *val,
-                      void *workspace, int64_t workspace_bytes, bool all, hipStream_t st)
+                      void *workspace, int64_t workspace_bytes, bool all, hipStream_t st, bool grad, const void *gout, bool probed)
 {
     using namespace owner;
     const int nt = tile_count(p);
@@ -1501,18 +1613,21 @@ int owner_pull_finish(const interpol_problem *p, const KParams &k, const void *v
     const BrickGrid bg = brick_grid(k);
     KParams kk = k;
     kk.gate = nullptr;
-    int rc = launch_bin<float, true>(p, kk, bg, w, vol, grid, val, all ? nullptr : w.flags, st);
+    int rc = grad ? launch_bin<float, 2>(p, kk, bg, w, vol, grid, val, all ? nullptr : w.flags, st, gout, probed ? &w.hdr->gate : nullptr)
+                  : launch_bin<float, 1>(p, kk, bg, w, vol, grid, val, all ? nullptr : w.flags, st);
     if (rc) return rc;
     const long long want = 2ll * cu_count();
     const dim3 ggrid((unsigned)(w.nbricks < want ? w.nbricks : want));
-#define IP_OWN_GAT(KK)                                                                                                  \
+#define IP_OWN_GAT(KK, GR)                                                                                              \
     {                                                                                                                   \
-        const int attr = big_lds<own_gather<KK>>(sizeof(GatSmem));                                                      \
+        const int attr = big_lds<own_gather<KK, GR>>(sizeof(GatSmem));                                                  \
         if (attr) return attr;                                                                                          \
-        hipLaunchKernelGGL((own_gather<KK>), ggrid, dim3(NT), sizeof(GatSmem), st, kk, bg, (const int *)w.ndesc, (const uint2 *)w.desc, \
-                           (const float4 *)w.rec, (const int *)w.bmax, (int *)w.hdr + 40, (const float *)vol, (float *)val, (const int *)nullptr); \
+        hipLaunchKernelGGL((own_gather<KK, GR>), ggrid, dim3(NT), sizeof(GatSmem), st, kk, bg, (const int *)w.ndesc, (const uint2 *)w.desc, \
+                           (const float4 *)w.rec, (const int *)w.bmax, (int *)w.hdr + 40, (const float *)vol, (float *)val, (const int *)nullptr, \
+                           (const float *)gout);                                                                        \
     }
-    if (k.order[0] == 3) IP_OWN_GAT(3) else IP_OWN_GAT(2)
+    if (grad) { if (k.order[0] == 3) IP_OWN_GAT(3, true) else IP_OWN_GAT(2, true) }
+    else { if (k.order[0] == 3) IP_OWN_GAT(3, false) else IP_OWN_GAT(2, false) }
 #undef IP_OWN_GAT
     const hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : (int)e;
