@@ -141,6 +141,10 @@ typedef struct interpol_problem {
  *     depends on the coordinates of this call alone; safe under hipGraph capture. */
 #define INTERPOL_FLAG_BINNED_SCATTER 64
 #define INTERPOL_FLAG_AUTO_SCATTER  (1 << 24)
+/* (experimental, opt-in) interpol_pull_ws with the single-pass small-box tiles for smooth deformations in front of the class-sorted
+ * tiles (pull_direct.hip): measured slower than the class-sorted tiles alone at config 2 (identity 1.16 against 1.05 ms, mixed
+ * fields up to +26 %: profiles/r04_pull_steps.txt), so it is not the default. */
+#define INTERPOL_FLAG_SMALL_TILES (1 << 25)
 /* The sample coordinates are an AFFINE function of the sample index, x = A o + t -- the fused form of
  * affine_grid (api.py:534-572) followed by the operator: `grid` points to ONE D x (D+1) matrix [A | t]
  * (grid_dtype, row-major), evaluated in registers as ((A_d0 o_0) + A_d1 o_1 ...) + t_d with fused

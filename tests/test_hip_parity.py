@@ -1545,6 +1545,46 @@ def test_routed_grid_gradient_bricks_of_the_image_against_oracle(sigma):
         oracle.set_threads(1)
 
 
+@pytest.mark.parametrize("sigma", [0.0, 0.3, 2.0])
+def test_small_box_tiles_opt_in_against_oracle(sigma):
+    """csrc/pull_direct.hip (opt-in, INTERPOL_FLAG_SMALL_TILES: measured slower than the class-sorted tiles, kept parity-tested): the
+    single-pass small-box tiles serve the smooth tiles, flag the rest for pull_sorted / the bricks.  Every bound (mixed per dim),
+    the three extrapolation modes, 1 - 3 channels, orders 2 and 3, ragged sample grids that overhang the lattice; sigma = 2: every
+    tile is left to pull_sorted."""
+    from interpol import _hip
+    g = torch.Generator().manual_seed(int(10 * sigma) + 282)
+    fl = _hip.FLAG_AUTO_SCATTER | _hip.FLAG_SMALL_TILES
+    oracle.set_threads(8)
+    try:
+        for (ishape, oshape) in (((40, 33, 50), (44, 36, 47)), ((48, 48, 48), (48, 48, 48))):
+            for bound in range(7):
+                order = 3 - (bound % 2)
+                ex, C = (bound + order) % 3, 1 + (bound + order) % 3
+                inp = torch.randn([2, C, *ishape], generator=g)
+                lin = [torch.linspace(-2, n + 1, m) for n, m in zip(ishape, oshape)]
+                grid = torch.stack(torch.meshgrid(*lin, indexing="ij"), -1)[None] + sigma * torch.randn([2, *oshape, 3], generator=g)
+                b = [bound, (bound + 3) % 7, (bound + 5) % 7]
+                want = oracle.grid_pull(inp.double().numpy(), grid.double().numpy(), b, [order], ex)
+                got = _hip.gather("pull", inp.to(DEV), grid.to(DEV), b, [order] * 3, ex, flags=fl)
+                slow = _hip.gather("pull", inp.to(DEV), grid.to(DEV), b, [order] * 3, ex, flags=_hip.FLAG_NO_FASTPATH)
+                assert G.rel_err(got.cpu().numpy(), slow.cpu().numpy()) < 4e-6, ("small tiles vs generic", sigma, b, order, ex)
+                # (a float32 coordinate that EQUALS the float32 extrapolation threshold is masked in float32 -- by the reference too --
+                #  and not by the float64 oracle: about one sample per run of this test; those few must be the generic kernel's as well)
+                err = np.abs(got.cpu().numpy() - want)
+                bad = err > 1e-5 * np.abs(want) + 1e-5 * np.abs(want).max()
+                assert bad.sum() <= 3 and not got.cpu().numpy()[bad].any(), \
+                    ("small tiles", sigma, b, order, ex, int(bad.sum()))
+        # the identity lattice as a displacement field of zeros and as a separable lattice (coordinate sources 2 and 1)
+        inp = torch.randn([1, 2, 40, 40, 40], generator=g).to(DEV)
+        ident = interpol.identity_grid((40, 40, 40))[None].to(DEV)
+        ref = _hip.gather("pull", inp, ident, [3] * 3, [3] * 3, 1, flags=_hip.FLAG_NO_FASTPATH)
+        for gridlike, extra in ((torch.zeros_like(ident), _hip.FLAG_DISPLACEMENT),):
+            got = _hip.gather("pull", inp, gridlike, [3] * 3, [3] * 3, 1, flags=fl | extra)
+            _same(got, ref, 1e-5, "displacement field through the small tiles")
+    finally:
+        oracle.set_threads(1)
+
+
 def test_owner_push_more_tiles_per_brick_than_descriptors():
     """A strongly contracting field (96^3 samples into 16^3 cells of the lattice): more than the 128 (tile, brick) runs a
     brick's descriptor list holds -- the orphan runs are scattered directly, and their places in the sorted order must not

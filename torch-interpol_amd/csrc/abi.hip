@@ -62,6 +62,8 @@ int owner_pull_prepare(const interpol_problem *, const KParams &, void *, int64_
 int owner_pull_finish(const interpol_problem *, const KParams &, const void *, const void *, void *, void *, int64_t, bool, hipStream_t,
                       bool grad = false, const void *gout = nullptr, bool probed = false);
 int owner_grad_probe(const interpol_problem *, const KParams &, const void *, void *, int64_t, hipStream_t);
+int try_pull_direct(const interpol_problem *, const KParams &, const void *, const void *, void *, int *, int, hipStream_t);
+int try_sorted_pull_f32(const interpol_problem *, const KParams &, const void *, const void *, void *, hipStream_t);
 int try_sorted_gradc_f32(const interpol_problem *, const KParams &, const void *, const void *, const void *, void *, hipStream_t);
 int64_t owner_pull_workspace_bytes(const interpol_problem *, const KParams &);
 int64_t owner_workspace_bytes(const interpol_problem *, const KParams &, bool);
@@ -320,6 +322,20 @@ int interpol_pull_ws(const interpol_problem *p, const void *vol, const void *gri
             if (p->flags & INTERPOL_FLAG_BINNED_SCATTER) return owner_pull_finish(p, k, vol, grid, val, workspace, workspace_bytes, true, st);
             // the sample tiles first: pull_sorted flags the tiles it leaves to the bricks (too many samples outside its LDS box)
             k.gate = flags; k.gate_n = nzero;
+            if (p->dtype == INTERPOL_F32 && !(k.dbg & (4096 | 32)) && (p->flags & INTERPOL_FLAG_SMALL_TILES)) {
+                // (opt-in experiment) the single-pass small-box tiles first (pull_direct.hip: smooth deformations); they write every flag
+                // -- 0: served, 2: left to pull_sorted, which then runs on the flagged tiles only (gate_n < 0).  Declined (0): as before.
+                rc = try_pull_direct(p, k, vol, grid, val, flags, nzero, st);
+                if (rc != 0 && rc != 1) return rc;
+                if (rc == 1) {
+                    k.gate_n = -nzero;
+                    rc = try_sorted_pull_f32(p, k, vol, grid, val, st);
+                    if (rc != 0 && rc != 1) return rc;
+                    if (rc == 1) return owner_pull_finish(p, k, vol, grid, val, workspace, workspace_bytes, false, st);
+                    k.gate = nullptr; k.gate_n = 0;                  // (pull_sorted declined: the generic kernel serves every sample again)
+                    return launch_pull_f32(k, vol, grid, val, B, st);
+                }
+            }
             rc = try_fast_pull(p, k, vol, grid, val, st);
             if (rc == 1 && (k.dbg & 32768)) return 0;              // (ablation: the tiles with their flags, no brick kernels behind them)
             if (rc == 1) return owner_pull_finish(p, k, vol, grid, val, workspace, workspace_bytes, false, st);

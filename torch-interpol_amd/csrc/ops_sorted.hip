@@ -323,15 +323,18 @@ __global__ __launch_bounds__(NT, 4) void pull_sorted(KParams p, const T *__restr
         for (int i = (int)blockIdx.x * NT + (int)threadIdx.x; i < p.gate_n; i += (int)gridDim.x * NT) z[i] = 0;
     }
     const WorkRange wr(ntiles * nbatch);
-    if (p.gate) {
+    if (p.gate && p.gate_n >= 0) {
         // (the workspace arrives dirty: the workgroup clears the flags of ITS tiles before it starts -- one round trip, under the
         //  first coordinate loads; a store per tile inside the loop is waited for at the tile's next barrier: 4 % of the kernel)
         for (int w_ = wr.first + (int)threadIdx.x * wr.step; w_ < wr.end; w_ += NT * wr.step) const_cast<int *>(p.gate)[w_] = 0;
     }
+    // gate_n < 0: the small-box tiles of pull_direct.hip ran in front of this kernel and wrote every flag -- 0: served there
+    const bool after_direct = p.gate && p.gate_n < 0;
     for (int work = wr.first; work < wr.end; work += wr.step) {
         // the thread index is made opaque per tile: everything derived from it would otherwise be
         // hoisted out of the persistent loop and held (spilled) across all phases
         const int tid = opaque((int)threadIdx.x);
+        if (after_direct && p.gate[work] == 0) continue;              // (block-uniform)
         const int64_t b = work / ntiles;
         int tile = work % ntiles;
         const TileGeom g = tile_geom(tile, gx, gy, gz, nty, ntz);
@@ -349,6 +352,8 @@ __global__ __launch_bounds__(NT, 4) void pull_sorted(KParams p, const T *__restr
             __syncthreads();
             continue;
         }
+        // (after pull_direct: the flag said "left to pull_sorted"; served here -- every thread read it before the barriers of build)
+        if (after_direct && tid == 0) const_cast<int *>(p.gate)[work] = 0;
         if (defer.flag) {                                                 // (block-uniform) too rough for the box: the generic kernel takes the tile, defer.hip
             bool hand_back = sm.nslow > (HANDBACK << ((p.dbg >> 9) & 7));
             if (hand_back) hand_back = tiled::tile_smooth(p, grid, b, 3, g.ox0, g.oy0, g.oz0, TS, TS, TS, g.gx, g.gy, g.gz, sm.hi);

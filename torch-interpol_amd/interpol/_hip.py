@@ -26,6 +26,7 @@ FLAG_DISPLACEMENT = 16
 FLAG_WITH_COUNT = 32
 FLAG_BINNED_SCATTER = 64
 FLAG_AUTO_SCATTER = 1 << 24
+FLAG_SMALL_TILES = 1 << 25           # (experimental, opt-in: csrc/pull_direct.hip)
 _POISON_SCRATCH = os.environ.get("INTERPOL_POISON_SCRATCH", "0") not in ("", "0")
 FLAG_AFFINE_GRID = 128
 
