@@ -64,7 +64,6 @@ constexpr int NT = 512;                         // accumulate: threads per workg
 constexpr int NS = TS * TS * TS;                // samples per tile (own_bin)
 constexpr int NT1 = 512, VPT1 = NS / NT1;       // own_bin: threads, samples per thread
 constexpr int LB = 6, NBIN = LB * LB * LB;      // bricks around a tile that are sorted locally
-constexpr int HALF = NS / 2;                    // records per exchange round
 
 // Bricks of first-tap cells, per dim.  INTERIOR cells [lo, top) lie in nin bricks of BR cells: the bricks up to index
 // `split` are aligned to lo, the ones above it to top (brick `split` is the short one in between).  Two cases:
@@ -132,9 +131,6 @@ struct BinSmem {
     int bmx[2];                // max |masked source| over the tile's binned samples, first two channels (float bits)
     int orph, pad_;            // the tile has orphan runs (a brick's descriptor list was full)
     int gbk[NBIN];             // global brick of the local brick when its run was published, else -1
-    float4 xch[HALF];          // sorted records of one round: x, y, z, value of channel 0
-    float  xv[HALF];           // value of one further channel
-    unsigned short xm[HALF];   // first-tap cell of the record inside its brick: x0 << 8 | y0 << 4 | z0
 };
 
 // value of target channel ch for a sample: masked source (nd.py:201-203), or the mask itself for the count channel
@@ -359,7 +355,6 @@ __global__ __launch_bounds__(NT1, 4) void own_bin(KParams p, BrickGrid bg, const
     }
     __syncthreads();
     prof_mark(2);
-    const int total = sm.total;
     // ---- samples that are not binned (first tap far outside the lattice, tile spread over more than LB bricks, orphan
     // runs) are scattered directly at the END of the kernel, from re-read coordinates: the out-of-line scatter would
     // otherwise force every live register of the hot path through scratch around its call
@@ -367,72 +362,48 @@ __global__ __launch_bounds__(NT1, 4) void own_bin(KParams p, BrickGrid bg, const
 #pragma unroll
     for (int v = 0; v < VPT1; ++v)
         if (((local >> v) & 1) && sm.cnt[lbin[v] & 255] < 0) direct |= 1u << v;
-    // ---- sorted records leave through LDS, two rounds of HALF records: coalesced 16-byte stores
+    // ---- sorted position of every binned sample
     int pos[VPT1];
 #pragma unroll
     for (int v = 0; v < VPT1; ++v)      // sorted position, and above it the cell
         pos[v] = ((local >> v) & 1) && sm.cnt[lbin[v] & 255] >= 0 ? (sm.base[lbin[v] & 255] + (int)((unsigned)lbin[v] >> 20)) | (((lbin[v] >> 8) & 0xfff) << 16) : -1;
-    // (the samples of an ORPHAN run -- its brick's descriptor list was full -- are scattered directly and leave their places in
-    //  the sorted order unwritten; nobody reads those records, but the store loop below does pass over the slots: a tile that
-    //  has orphans (rare: more than 128 tiles feed one brick) clears the exchange buffer first, so that the maxima see zeros,
-    //  not stale LDS.  A flag, not a per-sample select: this kernel sits at its register limit)
-    const bool has_orphans = sm.orph != 0;                           // (block-uniform)
+    if (IDX) {
+        // index mode: the record (x, y, z, sample index) is all the gather needs -- stored straight to its sorted place, 16 bytes
+        // per lane (the four records of a 64-byte line come from this workgroup within microseconds: the L2 merges them); no
+        // exchange through LDS, no cell table
+#pragma unroll
+        for (int v = 0; v < VPT1; ++v)
+            if (pos[v] >= 0) rec[tilebase + (pos[v] & 0xffff)] = make_float4(c[v][0], c[v][1], c[v][2], v0[v]);
+        if (IDX == 2) { if (direct) gradc_direct<T, K, GM>(p, val, aux, grid, vol, b, g, tid, direct); return; }
+        if (direct) gather_direct<T, K, GM>(p, val, grid, reinterpret_cast<T *>(vol), b, g, tid, direct);
+        return;
+    }
+    // ---- the sorted records are stored straight to their places (16 + 2 + 4 bytes per lane: the lines are completed by this
+    // workgroup within microseconds and merge in the L2); the samples of an ORPHAN run (its brick's descriptor list was full) are
+    // scattered directly below and leave their places unwritten -- nobody reads those
     const bool two = nch > 1;
     int amx0 = 0, amx1 = 0;             // max |source| of what this thread stores (non-negative floats, and NaN, order like ints)
-    prof_mark(3);
-    for (int r = 0; r < 2; ++r) {
-        if (r * HALF >= total) break;                                // (block-uniform)
-        if (has_orphans) {
-            for (int i = tid; i < HALF; i += NT1) { sm.xch[i] = make_float4(0.f, 0.f, 0.f, 0.f); sm.xv[i] = 0.f; }
-            __syncthreads();
+#pragma unroll
+    for (int v = 0; v < VPT1; ++v) {
+        if (pos[v] < 0) continue;
+        const int64_t at = tilebase + (pos[v] & 0xffff);
+        rec[at] = make_float4(c[v][0], c[v][1], c[v][2], v0[v]);
+        meta[at] = (unsigned short)(pos[v] >> 16);
+        const int a0 = __float_as_int(__builtin_fabsf(v0[v]));
+        amx0 = a0 > amx0 ? a0 : amx0;
+        if (two) {
+            vals[at] = v1[v];
+            const int a1 = __float_as_int(__builtin_fabsf(v1[v]));
+            amx1 = a1 > amx1 ? a1 : amx1;
         }
+    }
+    for (int ch = 2; ch < nch; ++ch) {                               // further channels
 #pragma unroll
         for (int v = 0; v < VPT1; ++v) {
-            const int q = (pos[v] & 0xffff) - r * HALF;
-            if (pos[v] >= 0 && (unsigned)q < (unsigned)HALF) {
-                sm.xch[q] = make_float4(c[v][0], c[v][1], c[v][2], v0[v]);
-                sm.xm[q] = (unsigned short)(pos[v] >> 16);
-                if (two) sm.xv[q] = v1[v];
-            }
-        }
-        __syncthreads();
-        prof_mark(4);
-#pragma unroll
-        for (int j = 0; j < HALF / NT1; ++j) {
-            const int i = tid + NT1 * j;
-            if (r * HALF + i < total) {
-                const float4 rc = sm.xch[i];
-                rec[tilebase + r * HALF + i] = rc;
-                meta[tilebase + r * HALF + i] = sm.xm[i];
-                const int a0 = __float_as_int(__builtin_fabsf(rc.w));
-                amx0 = a0 > amx0 ? a0 : amx0;
-                if (two) {
-                    const float s1 = sm.xv[i];
-                    vals[tilebase + r * HALF + i] = s1;
-                    const int a1 = __float_as_int(__builtin_fabsf(s1));
-                    amx1 = a1 > amx1 ? a1 : amx1;
-                }
-            }
-        }
-        __syncthreads();
-        prof_mark(5);
-        for (int ch = 2; ch < nch; ++ch) {                           // further channels: one more exchange each
-#pragma unroll
-            for (int v = 0; v < VPT1; ++v) {
-                const int q = (pos[v] & 0xffff) - r * HALF;
-                if (pos[v] >= 0 && (unsigned)q < (unsigned)HALF) {
-                    int ox, oy, oz;
-                    sample_pos(g, tid + NT1 * v, ox, oy, oz);
-                    sm.xv[q] = src_value<T>(p, val, b, ((int64_t)ox * gy + oy) * gz + oz, ch, inb_mask(p, c[v]));
-                }
-            }
-            __syncthreads();
-#pragma unroll
-            for (int j = 0; j < HALF / NT1; ++j) {
-                const int i = tid + NT1 * j;
-                if (r * HALF + i < total) vals[(int64_t)(ch - 1) * nrec + tilebase + r * HALF + i] = sm.xv[i];
-            }
-            __syncthreads();
+            if (pos[v] < 0) continue;
+            int ox, oy, oz;
+            sample_pos(g, tid + NT1 * v, ox, oy, oz);
+            vals[(int64_t)(ch - 1) * nrec + tilebase + (pos[v] & 0xffff)] = src_value<T>(p, val, b, ((int64_t)ox * gy + oy) * gz + oz, ch, inb_mask(p, c[v]));
         }
     }
     // max |source| of the first channel pair, per brick: the tile's maximum goes to every brick it published a run for (the
