@@ -231,6 +231,13 @@ int interpol_push_backward(const interpol_problem *p, const void *grad_vol_out, 
                            void *grad_val, void *grad_grid, void *stream);
 int interpol_count_backward(const interpol_problem *p, const void *grad_vol_out, const void *grid,
                             void *grad_grid, void *stream);
+/* interpol_push_backward (val != NULL) / interpol_count_backward (val == NULL, grad_val == NULL) with the bricks workspace of the two
+ * gathers they consist of -- interpol_pull_workspace(p) bytes, 256-byte aligned, contents undefined on entry; float32, 3-D quadratic /
+ * cubic, INTERPOL_FLAG_AUTO_SCATTER or INTERPOL_FLAG_BINNED_SCATTER: grad_val is the routed pull of grad_vol_out (interpol_pull_ws),
+ * grad_grid the routed grid gradient (as interpol_pull_backward's, the roles of the two images swapped: pushpull.py:276-281).
+ * Otherwise, or without a workspace: exactly the two calls above. */
+int interpol_push_backward_ws(const interpol_problem *p, const void *grad_vol_out, const void *val, const void *grid,
+                              void *grad_val, void *grad_grid, void *workspace, int64_t workspace_bytes, void *stream);
 
 /* --- target-stationary splatting -------------------------------------------------
  * interpol_push_bricks: the same operator as interpol_push (pushpull.py:70-102; with

@@ -1545,6 +1545,51 @@ def test_routed_grid_gradient_bricks_of_the_image_against_oracle(sigma):
         oracle.set_threads(1)
 
 
+@pytest.mark.parametrize("sigma", [0.0, 7.0])
+def test_routed_push_and_count_backward_against_oracle(sigma):
+    """interpol_push_backward_ws: both gradients of grid_push (pushpull.py:262-282) and the grid gradient of grid_count (286-299)
+    through the router of the gathers they consist of -- default flags and the bricks alone against the oracle and the generic
+    fused kernel; every bound (mixed per dim), the three extrapolation modes, 1 - 3 channels; sigma = 7 flags every tile.
+    (Samples whose float32 coordinate equals a float32 extrapolation threshold differ from the float64 oracle: compared with
+    the generic kernel, at most three per case.)"""
+    from interpol import _hip
+    g = torch.Generator().manual_seed(int(sigma) + 70)
+    oracle.set_threads(8)
+
+    def check(got, want, slow, what):
+        got, slow = got.cpu().numpy(), slow.cpu().numpy()
+        scale = max(float(np.abs(want).max()), 1e-30)
+        assert float(np.abs(got - slow).max()) <= 6e-6 * max(float(np.abs(slow).max()), 1e-30), (what, "vs generic")
+        bad = np.abs(got - want) > 1e-5 * np.abs(want) + 1e-5 * scale
+        assert bad.sum() <= 3 * got.shape[-1], (what, int(bad.sum()))
+
+    try:
+        for (ishape, oshape) in (((40, 33, 50), (37, 45, 29)), ((48, 48, 48), (48, 48, 48))):
+            for bound in range(7):
+                order = 3 - (bound % 2)
+                ex, C = (bound + order) % 3, 1 + (bound + order) % 3
+                gvol = torch.randn([2, C, *ishape], generator=g)
+                val = torch.randn([2, C, *oshape], generator=g)
+                lin = [torch.linspace(-2, n + 1, m) for n, m in zip(ishape, oshape)]
+                grid = torch.stack(torch.meshgrid(*lin, indexing="ij"), -1)[None] + sigma * torch.randn([2, *oshape, 3], generator=g)
+                b = [bound, (bound + 3) % 7, (bound + 5) % 7]
+                want_v, want_g = oracle.grid_push_backward(gvol.double().numpy(), val.double().numpy(), grid.double().numpy(), b, [order], ex)
+                slow = _hip.push_backward(gvol.to(DEV), val.to(DEV), grid.to(DEV), b, [order] * 3, ex, True, True, flags=_hip.FLAG_NO_FASTPATH)
+                for name, fl in (("routed", 0), ("bricks", _hip.FLAG_BINNED_SCATTER)):
+                    gv, gg = _hip.push_backward(gvol.to(DEV), val.to(DEV), grid.to(DEV), b, [order] * 3, ex, True, True, flags=fl)
+                    check(gv, want_v, slow[0], (name, "grad_val", sigma, b, order, ex))
+                    check(gg, want_g, slow[1], (name, "grad_grid", sigma, b, order, ex))
+                if bound % 3 == 0:                                  # the backward of count: grad_out of ones, one channel
+                    g1 = gvol[:, :1].contiguous()
+                    want_c = oracle.grid_count_backward(g1.double().numpy(), grid.double().numpy(), b, [order], ex)
+                    slow_c = _hip.push_backward(g1.to(DEV), None, grid.to(DEV), b, [order] * 3, ex, False, True, flags=_hip.FLAG_NO_FASTPATH)[1]
+                    for name, fl in (("routed", 0), ("bricks", _hip.FLAG_BINNED_SCATTER)):
+                        gc = _hip.push_backward(g1.to(DEV), None, grid.to(DEV), b, [order] * 3, ex, False, True, flags=fl)[1]
+                        check(gc, want_c, slow_c, (name, "count grad_grid", sigma, b, order, ex))
+    finally:
+        oracle.set_threads(1)
+
+
 @pytest.mark.parametrize("sigma", [0.0, 0.3, 2.0])
 def test_small_box_tiles_opt_in_against_oracle(sigma):
     """csrc/pull_direct.hip (opt-in, INTERPOL_FLAG_SMALL_TILES: measured slower than the class-sorted tiles, kept parity-tested): the

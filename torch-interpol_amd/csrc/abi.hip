@@ -306,6 +306,39 @@ int64_t interpol_pull_workspace(const interpol_problem *p)
     return owner_pull_workspace_bytes(p, k);
 }
 
+// The routed pull.  1: done, 0: declined (nothing launched that the caller's fallback would not overwrite), else an error.
+static int routed_pull(const interpol_problem *p, KParams k, int B, const void *vol, const void *grid, void *val, void *workspace, int64_t workspace_bytes,
+                       hipStream_t st)
+{
+    int *flags = nullptr;
+    int nzero = 0;
+    int rc = owner_pull_prepare(p, k, workspace, workspace_bytes, st, &flags, &nzero);
+    if (rc != 1) return rc;
+    if (p->flags & INTERPOL_FLAG_BINNED_SCATTER) { rc = owner_pull_finish(p, k, vol, grid, val, workspace, workspace_bytes, true, st); return rc ? rc : 1; }
+    // the sample tiles first: pull_sorted flags the tiles it leaves to the bricks (too many samples outside its LDS box)
+    k.gate = flags; k.gate_n = nzero;
+    if (p->dtype == INTERPOL_F32 && !(k.dbg & (4096 | 32)) && (p->flags & INTERPOL_FLAG_SMALL_TILES)) {
+        // (opt-in experiment) the single-pass small-box tiles first (pull_direct.hip: smooth deformations); they write every flag
+        // -- 0: served, 2: left to pull_sorted, which then runs on the flagged tiles only (gate_n < 0).  Declined (0): as before.
+        rc = try_pull_direct(p, k, vol, grid, val, flags, nzero, st);
+        if (rc != 0 && rc != 1) return rc;
+        if (rc == 1) {
+            k.gate_n = -nzero;
+            rc = try_sorted_pull_f32(p, k, vol, grid, val, st);
+            if (rc != 0 && rc != 1) return rc;
+            if (rc == 1) { rc = owner_pull_finish(p, k, vol, grid, val, workspace, workspace_bytes, false, st); return rc ? rc : 1; }
+            k.gate = nullptr; k.gate_n = 0;                          // (pull_sorted declined: the generic kernel serves every sample again)
+            rc = launch_pull_f32(k, vol, grid, val, B, st);
+            return rc ? rc : 1;
+        }
+    }
+    rc = try_fast_pull(p, k, vol, grid, val, st);
+    if (rc != 1) return rc;
+    if (k.dbg & 32768) return 1;                                     // (ablation: the tiles with their flags, no brick kernels behind them)
+    rc = owner_pull_finish(p, k, vol, grid, val, workspace, workspace_bytes, false, st);
+    return rc ? rc : 1;
+}
+
 int interpol_pull_ws(const interpol_problem *p, const void *vol, const void *grid, void *val, void *workspace, int64_t workspace_bytes, void *stream)
 {
     KParams k; int B;
@@ -314,37 +347,10 @@ int interpol_pull_ws(const interpol_problem *p, const void *vol, const void *gri
     if (!vol || !grid || !val) return INTERPOL_E_NULL;
     hipStream_t st = (hipStream_t)stream;
     if (!(p->flags & INTERPOL_FLAG_NO_FASTPATH)) {
-        int *flags = nullptr;
-        int nzero = 0;
-        rc = owner_pull_prepare(p, k, workspace, workspace_bytes, st, &flags, &nzero);
-        if (rc != 0 && rc != 1) return rc;
-        if (rc == 1) {
-            if (p->flags & INTERPOL_FLAG_BINNED_SCATTER) return owner_pull_finish(p, k, vol, grid, val, workspace, workspace_bytes, true, st);
-            // the sample tiles first: pull_sorted flags the tiles it leaves to the bricks (too many samples outside its LDS box)
-            k.gate = flags; k.gate_n = nzero;
-            if (p->dtype == INTERPOL_F32 && !(k.dbg & (4096 | 32)) && (p->flags & INTERPOL_FLAG_SMALL_TILES)) {
-                // (opt-in experiment) the single-pass small-box tiles first (pull_direct.hip: smooth deformations); they write every flag
-                // -- 0: served, 2: left to pull_sorted, which then runs on the flagged tiles only (gate_n < 0).  Declined (0): as before.
-                rc = try_pull_direct(p, k, vol, grid, val, flags, nzero, st);
-                if (rc != 0 && rc != 1) return rc;
-                if (rc == 1) {
-                    k.gate_n = -nzero;
-                    rc = try_sorted_pull_f32(p, k, vol, grid, val, st);
-                    if (rc != 0 && rc != 1) return rc;
-                    if (rc == 1) return owner_pull_finish(p, k, vol, grid, val, workspace, workspace_bytes, false, st);
-                    k.gate = nullptr; k.gate_n = 0;                  // (pull_sorted declined: the generic kernel serves every sample again)
-                    return launch_pull_f32(k, vol, grid, val, B, st);
-                }
-            }
-            rc = try_fast_pull(p, k, vol, grid, val, st);
-            if (rc == 1 && (k.dbg & 32768)) return 0;              // (ablation: the tiles with their flags, no brick kernels behind them)
-            if (rc == 1) return owner_pull_finish(p, k, vol, grid, val, workspace, workspace_bytes, false, st);
-            if (rc != 0) return rc;
-            k.gate = nullptr; k.gate_n = 0;
-        } else {
-            rc = try_fast_pull(p, k, vol, grid, val, st);
-            if (rc != 0) return rc == 1 ? 0 : rc;
-        }
+        rc = routed_pull(p, k, B, vol, grid, val, workspace, workspace_bytes, st);
+        if (rc != 0) return rc == 1 ? 0 : rc;
+        rc = try_fast_pull(p, k, vol, grid, val, st);
+        if (rc != 0) return rc == 1 ? 0 : rc;
     }
     return by_dtype(p->dtype,
         [&] { return launch_pull_f32(k, vol, grid, val, B, st); },
@@ -530,6 +536,35 @@ int interpol_pushgrad(const interpol_problem *p, const void *val, const void *gr
     });
 }
 
+// The grid gradient of a gather through the router (float32, 3-D quadratic / cubic, a bricks workspace of interpol_pull_workspace(p)
+// bytes): ggrid[b,o,:] = mask * sum_c gout[b,c,o] * grad pull(vol[b,c])(x_o) (pushpull.py:256-257; gout == NULL: ones).
+// The sample tiles flag the tiles whose samples leave their LDS box; those samples go to the bricks of the image
+// (own_gather<K, true>, push_owner.hip) -- 4 x 2 x 256^3 cubic, sigma = 6: 20 -> 2.9 ms.  1: done, 0: declined, else an error.
+static int routed_gradc(const interpol_problem *p, const KParams &k, const void *gout, const void *vol, const void *grid, void *ggrid,
+                        void *scratch, int64_t scratch_bytes, hipStream_t st)
+{
+    int *flags = nullptr;
+    int nzero = 0;
+    const int r = owner_pull_prepare(p, k, scratch, scratch_bytes, st, &flags, &nzero);
+    if (r != 1) return r;
+    int rc;
+    if (p->flags & INTERPOL_FLAG_BINNED_SCATTER) {
+        rc = owner_pull_finish(p, k, vol, grid, ggrid, scratch, scratch_bytes, true, st, true, gout);
+        return rc ? rc : 1;
+    }
+    // a probe of the call first: dense samplings go to the bricks altogether (the tile kernel returns at once: gate_n < 0,
+    // the probe's header lies -gate_n ints in front of the flags), else the tiles run and flag what they leave
+    rc = owner_grad_probe(p, k, grid, scratch, scratch_bytes, st);
+    if (rc) return rc;
+    KParams kg = k;
+    kg.gate = flags; kg.gate_n = -nzero;
+    rc = try_sorted_gradc_f32(p, kg, gout, vol, grid, ggrid, st);
+    if (rc != 1) return rc;
+    if (k.dbg & 32768) return 1;                                     // (ablation: the tiles with their flags, no brick kernels behind them)
+    rc = owner_pull_finish(p, k, vol, grid, ggrid, scratch, scratch_bytes, false, st, true, gout, true);
+    return rc ? rc : 1;
+}
+
 int interpol_pull_backward(const interpol_problem *p, const void *grad_out, const void *vol, const void *grid,
                            void *grad_vol, void *grad_grid, void *scratch, int64_t scratch_bytes, void *stream)
 {
@@ -587,32 +622,8 @@ int interpol_pull_backward(const interpol_problem *p, const void *grad_out, cons
             rc = (vol_done && !grad_grid) ? 1 : 0;
         }
         if (rc == 0 && grad_grid && (vol_done || !grad_vol) && p->dtype == INTERPOL_F32 && scratch) {
-            // float32 with a bricks workspace (interpol_pull_workspace(p) bytes, as interpol_pull_ws): the sample tiles of the grid
-            // gradient flag the tiles whose samples leave their LDS box; those samples go to the bricks of the image
-            // (own_gather<K, true>, push_owner.hip) -- 4 x 2 x 256^3 cubic, sigma = 6: 20 -> x ms
-            int *flags = nullptr;
-            int nzero = 0;
-            const int r = owner_pull_prepare(p, k, scratch, scratch_bytes, st, &flags, &nzero);
-            if (r != 0 && r != 1) return r;
-            if (r == 1 && (p->flags & INTERPOL_FLAG_BINNED_SCATTER)) {
-                rc = owner_pull_finish(p, k, vol, grid, grad_grid, scratch, scratch_bytes, true, st, true, grad_out);
-                if (rc) return rc;
-                rc = 1;
-            } else if (r == 1) {
-                // a probe of the call first: dense samplings go to the bricks altogether (the tile kernel returns at once: gate_n < 0,
-                // the probe's header lies -gate_n ints in front of the flags), else the tiles run and flag what they leave
-                rc = owner_grad_probe(p, k, grid, scratch, scratch_bytes, st);
-                if (rc) return rc;
-                KParams kg = k;
-                kg.gate = flags; kg.gate_n = -nzero;
-                rc = try_sorted_gradc_f32(p, kg, grad_out, vol, grid, grad_grid, st);
-                if (rc != 0 && rc != 1) return rc;
-                if (rc == 1 && !(k.dbg & 32768)) {
-                    rc = owner_pull_finish(p, k, vol, grid, grad_grid, scratch, scratch_bytes, false, st, true, grad_out, true);
-                    if (rc) return rc;
-                    rc = 1;
-                }
-            }
+            rc = routed_gradc(p, k, grad_out, vol, grid, grad_grid, scratch, scratch_bytes, st);
+            if (rc != 0 && rc != 1) return rc;
         }
         if (rc == 0) {
             rc = try_fast_pullbwd(p, k, grad_out, vol, grid, vol_done ? nullptr : acc, grad_grid, gsb, gsc, st);   // 1 = done, 0 = declined
@@ -665,6 +676,37 @@ int interpol_push_backward(const interpol_problem *p, const void *grad_vol_out, 
         [&] { return launch_pushbwd_f64(k, grad_vol_out, val, grid, grad_val, grad_grid, B, st); },
         [&] { return launch_pushbwd_bf16(k, grad_vol_out, val, grid, grad_val, grad_grid, B, st); },
         [&] { return launch_pushbwd_f16(k, grad_vol_out, val, grid, grad_val, grad_grid, B, st); });
+}
+
+// interpol_push_backward (val != NULL) / interpol_count_backward (val == NULL, grad_val == NULL) with the bricks workspace of the gathers
+// they are made of (interpol_pull_workspace(p) bytes): the value gradient is the routed pull of grad_vol_out, the grid gradient
+// the routed grid gradient with the two images' roles swapped (pushpull.py:276-281, 296-298).
+int interpol_push_backward_ws(const interpol_problem *p, const void *grad_vol_out, const void *val, const void *grid,
+                              void *grad_val, void *grad_grid, void *workspace, int64_t workspace_bytes, void *stream)
+{
+    if (!val && grad_val) return INTERPOL_E_NULL;
+    KParams k; int B;
+    int rc = make_params(p, GATHER, 1, &k, &B, val != nullptr);
+    if (rc) return rc;
+    if (!grad_vol_out || !grid) return INTERPOL_E_NULL;
+    if (!grad_val && !grad_grid) return 0;
+    if (grad_grid && (p->flags & (INTERPOL_FLAG_SEPARABLE_GRID | INTERPOL_FLAG_AFFINE_GRID))) return INTERPOL_E_STRIDE;
+    hipStream_t st = (hipStream_t)stream;
+    if (!(p->flags & INTERPOL_FLAG_NO_FASTPATH) && p->dtype == INTERPOL_F32 && workspace) {
+        if (grad_grid) {
+            rc = routed_gradc(p, k, val, grad_vol_out, grid, grad_grid, workspace, workspace_bytes, st);
+            if (rc != 0 && rc != 1) return rc;
+            if (rc == 1) grad_grid = nullptr;
+        }
+        if (grad_val && !grad_grid) {                                // (the workspace is free again: the same stream)
+            rc = routed_pull(p, k, B, grad_vol_out, grid, grad_val, workspace, workspace_bytes, st);
+            if (rc != 0 && rc != 1) return rc;
+            if (rc == 1) grad_val = nullptr;
+        }
+        if (!grad_val && !grad_grid) return 0;
+    }
+    return val ? interpol_push_backward(p, grad_vol_out, val, grid, grad_val, grad_grid, stream)
+               : interpol_count_backward(p, grad_vol_out, grid, grad_grid, stream);
 }
 
 int interpol_count_backward(const interpol_problem *p, const void *grad_vol_out, const void *grid,

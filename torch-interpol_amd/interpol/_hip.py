@@ -40,7 +40,7 @@ SYMBOLS = (
     "interpol_push_bricks", "interpol_push_bricks_workspace", "interpol_host_bound_index", "interpol_host_bound_sign",
     "interpol_host_weight", "interpol_host_weight_f32", "interpol_abi_version",
     "interpol_error_string", "interpol_kernel_name", "interpol_scatter_workspace",
-    "interpol_set_handback", "interpol_release_stream", "interpol_pull_workspace", "interpol_pull_ws",
+    "interpol_set_handback", "interpol_release_stream", "interpol_pull_workspace", "interpol_pull_ws", "interpol_push_backward_ws",
 )
 
 
@@ -107,6 +107,8 @@ def lib():
     L.interpol_pull_workspace.restype = i64
     L.interpol_pull_ws.argtypes = [pp, vp, vp, vp, vp, i64, vp]
     L.interpol_pull_ws.restype = ctypes.c_int
+    L.interpol_push_backward_ws.argtypes = [pp, vp, vp, vp, vp, vp, vp, i64, vp]
+    L.interpol_push_backward_ws.restype = ctypes.c_int
     L.interpol_set_handback.argtypes = [i32]
     L.interpol_set_handback.restype = i32
     L.interpol_release_stream.argtypes = [ctypes.c_void_p]
@@ -543,6 +545,29 @@ def push_backward(gvol_out, val, grid, bound, order, extrapolate, need_val, need
     p = make_problem(dim, dt, gdt, bound, order, extrapolate, B, C, gvol_out.shape[2:], gshape,
                      vstr, _grid_strides(grid_c, B, dim), valstr, flags)
     L = lib()
+    from . import backend
+    routed = 0
+    if (dim == 3 and dt == torch.float32 and gdt == torch.float32 and (flags >> 8) == 0
+            and not (flags & (FLAG_NO_FASTPATH | FLAG_FORCE_TILED | FLAG_BINNED_SCATTER))):
+        # both gradients are gathers: they take the router of the pull (bricks of the image, csrc/push_owner.hip: own_gather)
+        routed = FLAG_AUTO_SCATTER if backend.rough_deformations is None else (FLAG_BINNED_SCATTER if backend.rough_deformations else 0)
+    elif flags & FLAG_BINNED_SCATTER:
+        routed = FLAG_BINNED_SCATTER
+    if routed:
+        p.flags |= routed
+        ws, wbytes = None, int(L.interpol_pull_workspace(ctypes.byref(p)))
+        if wbytes > 0:
+            try:
+                ws = torch.empty(wbytes, dtype=torch.uint8, device=dev)
+            except torch.cuda.OutOfMemoryError:
+                ws = None
+        if ws is not None:
+            with torch.cuda.device(dev):
+                rc = L.interpol_push_backward_ws(ctypes.byref(p), _ptr(gvol_out), _ptr(None if count else val), _ptr(grid_c),
+                                                 _ptr(gval), _ptr(ggrid), _ptr(ws), wbytes, _stream(dev))
+            _check(rc, "interpol_push_backward_ws")
+            return gval, ggrid
+        p.flags &= ~(FLAG_AUTO_SCATTER | FLAG_BINNED_SCATTER)
     with torch.cuda.device(dev):
         if count:
             rc = L.interpol_count_backward(ctypes.byref(p), _ptr(gvol_out), _ptr(grid_c), _ptr(ggrid), _stream(dev))
