@@ -54,7 +54,8 @@ for name in ("bench.json", "other_configs.json"):
 ALG_READ = 4 * 256 ** 3 * 12 + 4 * 2 * 256 ** 3 * 4     # algorithmic HBM read bytes per launch at BASELINE config 2: grid + source
 # kernels of one grid_pull / grid_push launch (substrings of the kernel names); the first one counts the launches
 KERNELS = {"grid_pull": ["pull_sorted"],
-           "grid_push": ["own_bin", "own_accumulate", "own_probe", "own_zero", "push_tiled", "fillBuffer"]}
+           "grid_push": ["own_probe", "own_bin", "own_accumulate", "own_zero", "push_tiled", "fillBuffer"]}   # (own_bin also runs,
+           # nearly empty, in index mode behind every routed pull since round 4: the probe counts the push launches)
 raw_path = os.path.join(src, "pmc_raw.json")
 if all(dbs("pmc_%s_s%s" % (c, sg)) for c in ("FETCH_SIZE", "WRITE_SIZE") for sg in ("2.0", "0.0")):
     raw = {}
