@@ -1545,6 +1545,42 @@ def test_routed_grid_gradient_bricks_of_the_image_against_oracle(sigma):
         oracle.set_threads(1)
 
 
+@pytest.mark.parametrize("sigma", [0.0, 2.0, 7.0])
+def test_routed_grid_grad_bricks_of_the_image_against_oracle(sigma):
+    """interpol_grad_ws (grid_grad, nd.py:216-288; 3-D quadratic / cubic, float32): the bricks of the image (own_gather<K, 2>) --
+    default flags (a probe of the call chooses bricks or tiles) and the bricks alone against the oracle and the generic kernel;
+    every bound (mixed per dim), the three extrapolation modes, 1 - 3 channels, overhanging sample grids.  (A float32 coordinate
+    equal to a float32 extrapolation threshold: at most three samples per case may differ from the float64 oracle.)"""
+    from interpol import _hip
+    g = torch.Generator().manual_seed(int(sigma) + 90)
+    oracle.set_threads(8)
+    try:
+        for (ishape, oshape) in (((40, 33, 50), (37, 45, 29)), ((48, 48, 48), (48, 48, 48))):
+            for bound in range(7):
+                order = 3 - (bound % 2)
+                ex, C = (bound + order) % 3, 1 + (bound + order) % 3
+                inp = torch.randn([2, C, *ishape], generator=g)
+                lin = [torch.linspace(-2, n + 1, m) for n, m in zip(ishape, oshape)]
+                grid = torch.stack(torch.meshgrid(*lin, indexing="ij"), -1)[None] + sigma * torch.randn([2, *oshape, 3], generator=g)
+                b = [bound, (bound + 3) % 7, (bound + 5) % 7]
+                want = oracle.grid_grad(inp.double().numpy(), grid.double().numpy(), b, [order], ex)
+                slow = _hip.gather("grad", inp.to(DEV), grid.to(DEV), b, [order] * 3, ex, flags=_hip.FLAG_NO_FASTPATH).cpu().numpy()
+                for name, fl in (("routed", 0), ("bricks", _hip.FLAG_BINNED_SCATTER)):
+                    got = _hip.gather("grad", inp.to(DEV), grid.to(DEV), b, [order] * 3, ex, flags=fl).cpu().numpy()
+                    assert float(np.abs(got - slow).max()) <= 6e-6 * float(np.abs(slow).max()), (name, "vs generic", sigma, b, order, ex)
+                    bad = np.abs(got - want) > 1e-5 * np.abs(want) + 2e-5 * float(np.abs(want).max())
+                    assert bad.sum() <= 9 * C, (name, sigma, b, order, ex, int(bad.sum()))
+        # a ninefold zoom: a tile's samples spread over more bricks than own_bin sorts locally -- gathered directly (grad_direct)
+        inp = torch.randn([2, 3, 25, 47, 58], generator=g).to(DEV)
+        grid = ((interpol.identity_grid((43, 25, 19)) - 10.0) * 9.0)[None].expand(2, 43, 25, 19, 3).contiguous().to(DEV)
+        for b in ([6, 5, 6], [3, 1, 2]):
+            slow = _hip.gather("grad", inp, grid, b, [3] * 3, 0, flags=_hip.FLAG_NO_FASTPATH)
+            for fl in (0, _hip.FLAG_BINNED_SCATTER):
+                _same(_hip.gather("grad", inp, grid, b, [3] * 3, 0, flags=fl), slow, 1e-5, ("zoomed grid_grad through the bricks", b, fl))
+    finally:
+        oracle.set_threads(1)
+
+
 @pytest.mark.parametrize("sigma", [0.0, 7.0])
 def test_routed_push_and_count_backward_against_oracle(sigma):
     """interpol_push_backward_ws: both gradients of grid_push (pushpull.py:262-282) and the grid gradient of grid_count (286-299)

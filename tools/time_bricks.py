@@ -33,10 +33,13 @@ for s in [float(a) for a in sys.argv[1:]] or (2.0, 0.0, 6.0):
     pf = lambda fl=0: _hip.gather("pull", inp, grid, [3] * 3, [3] * 3, 1, flags=fl)
     gf = lambda fl=0: _hip.pull_backward(gout, inp, grid, [3] * 3, [3] * 3, 1, False, True, flags=fl)[1]
     pb = lambda: _hip.push_backward(gout, inp, grid, [3] * 3, [3] * 3, 1, True, True)
+    sg = lambda fl=0: _hip.gather("grad", inp, grid, [3] * 3, [3] * 3, 1, flags=fl)
     ref_p, ref_g = pf(_hip.FLAG_NO_FASTPATH), gf(_hip.FLAG_NO_FASTPATH)
     res = {"push_owner": timeit(lambda: f(B)), "push_default": timeit(f),
            "pull_bricks": timeit(lambda: pf(B)), "pull_default": timeit(pf),
            "gradgrid_bricks": timeit(lambda: gf(B)), "gradgrid_default": timeit(gf),
-           "push_backward_both": timeit(pb)}
+           "push_backward_both": timeit(pb), "grad_bricks": timeit(lambda: sg(B)), "grad_default": timeit(sg), "grad_tiles": timeit(lambda: sg(_hip.FLAG_FORCE_TILED))}
+    ref_s = sg(_hip.FLAG_NO_FASTPATH)
+    gerr = float((sg(B) - ref_s).abs().max() / ref_s.abs().max())
     print("sigma", s, {k: round(v, 3) for k, v in res.items()},
-          "err pull %.1e grad %.1e" % (float((pf(B) - ref_p).abs().max() / ref_p.abs().max()), float((gf(B) - ref_g).abs().max() / ref_g.abs().max())), flush=True)
+          "err pull %.1e gradgrid %.1e grad %.1e" % (float((pf(B) - ref_p).abs().max() / ref_p.abs().max()), float((gf(B) - ref_g).abs().max() / ref_g.abs().max()), gerr), flush=True)

@@ -60,7 +60,7 @@ int try_owner_push(const interpol_problem *, const KParams &, const void *, cons
 int try_push_f64_tiles(const interpol_problem *, const KParams &, const void *, const void *, void *, hipStream_t);
 int owner_pull_prepare(const interpol_problem *, const KParams &, void *, int64_t, hipStream_t, int **, int *);
 int owner_pull_finish(const interpol_problem *, const KParams &, const void *, const void *, void *, void *, int64_t, bool, hipStream_t,
-                      bool grad = false, const void *gout = nullptr, bool probed = false);
+                      bool grad = false, const void *gout = nullptr, bool probed = false, bool spatial = false);
 int owner_grad_probe(const interpol_problem *, const KParams &, const void *, void *, int64_t, hipStream_t);
 int try_pull_direct(const interpol_problem *, const KParams &, const void *, const void *, void *, int *, int, hipStream_t);
 int try_sorted_pull_f32(const interpol_problem *, const KParams &, const void *, const void *, void *, hipStream_t);
@@ -301,7 +301,7 @@ int interpol_pull(const interpol_problem *p, const void *vol, const void *grid, 
 int64_t interpol_pull_workspace(const interpol_problem *p)
 {
     KParams k; int B;
-    if (make_params(p, GATHER, 1, &k, &B)) return 0;
+    if (make_params(p, GATHER, 1, &k, &B, false)) return 0;          // (the layout of `val` -- pull, grad, a gradient -- plays no part)
     if (p->flags & INTERPOL_FLAG_NO_FASTPATH) return 0;
     return owner_pull_workspace_bytes(p, k);
 }
@@ -385,6 +385,34 @@ int interpol_grad(const interpol_problem *p, const void *vol, const void *grid, 
         [&] { return launch_grad_f64(k, vol, grid, val, B, st); },
         [&] { return launch_grad_bf16(k, vol, grid, val, B, st); },
         [&] { return launch_grad_f16(k, vol, grid, val, B, st); });
+}
+
+// grid_grad with the bricks workspace of interpol_pull_workspace(p) (float32, 3-D quadratic / cubic): the bricks of the
+// image always (INTERPOL_FLAG_BINNED_SCATTER) or when the probe of the call finds a dense or rough sampling
+// (INTERPOL_FLAG_AUTO_SCATTER: the tile / generic kernels are enqueued as well and return at once behind the probe's gate).
+int interpol_grad_ws(const interpol_problem *p, const void *vol, const void *grid, void *val, void *workspace, int64_t workspace_bytes, void *stream)
+{
+    KParams k; int B;
+    int rc = make_params(p, GATHER, p ? p->dim : 1, &k, &B);
+    if (rc) return rc;
+    if (!vol || !grid || !val) return INTERPOL_E_NULL;
+    hipStream_t st = (hipStream_t)stream;
+    int *flags = nullptr;
+    int nzero = 0;
+    if ((p->flags & INTERPOL_FLAG_NO_FASTPATH) || p->dtype != INTERPOL_F32 || owner_pull_prepare(p, k, workspace, workspace_bytes, st, &flags, &nzero) != 1)
+        return interpol_grad(p, vol, grid, val, stream);
+    if (p->flags & INTERPOL_FLAG_BINNED_SCATTER) return owner_pull_finish(p, k, vol, grid, val, workspace, workspace_bytes, true, st, false, nullptr, false, true);
+    rc = owner_grad_probe(p, k, grid, workspace, workspace_bytes, st);
+    if (rc) return rc;
+    KParams kt = k;
+    kt.gate = flags - nzero;                                         // the probe's verdict (ProbeHdr::gate, the first word of the header): 1 = the bricks
+    rc = try_fast_grad(p, kt, vol, grid, val, st);
+    if (rc != 0 && rc != 1) return rc;
+    if (rc == 0) {
+        rc = launch_grad_f32(kt, vol, grid, val, B, st);
+        if (rc) return rc;
+    }
+    return owner_pull_finish(p, k, vol, grid, val, workspace, workspace_bytes, true, st, false, nullptr, true, true);
 }
 
 int interpol_hess(const interpol_problem *p, const void *vol, const void *grid, void *val, void *stream)

@@ -159,6 +159,7 @@ template <typename T, typename G, typename R, int D, int KMAX, bool ISO, bool DE
 __global__ __launch_bounds__(BLOCK) void grad_generic(KParams p, const T *__restrict__ vol,
                                                       const G *__restrict__ grid, T *__restrict__ val, int B, TileList tl)
 {
+    if (p.gate && *p.gate == 1) return;                // interpol_grad_ws: the bricks of the image took the call (push_owner.hip)
     IP_FOR_SAMPLES {
         const int64_t b = it_.b, o = it_.o;
         R x[D];

@@ -228,6 +228,35 @@ __device__ __forceinline__ void gradc_direct(const KParams &p, const T *__restri
     }
 }
 
+// ... and for grid_grad (nd.py:216-288): out[b,c,o,:] = mask * the three derivative sums (own_bin index mode 3)
+template <typename T, int K, int GM>
+__device__ __forceinline__ void grad_direct(const KParams &p, const T *__restrict__ img, const float *__restrict__ grid, T *__restrict__ out,
+                                            int64_t b, TileGeom g, int tid, unsigned mask)
+{
+    Lattice L;
+#pragma unroll
+    for (int d = 0; d < 3; ++d) { L.bound[d] = p.bound[d]; L.n[d] = p.vol_n[d]; L.ss[d] = p.vol_ss[d] / (int)sizeof(T); L.k[d] = K; }
+    L.lin = 0;
+#pragma unroll 1
+    for (int v = 0; v < VPT1; ++v) {
+        if (!((mask >> v) & 1)) continue;
+        int ox, oy, oz; float x[3];
+        sample_pos(g, tid + NT1 * v, ox, oy, oz);
+        load_xyz<GM>(p, grid, b, g, ox, oy, oz, x);
+        const int64_t o = ((int64_t)ox * g.gy + oy) * g.gz + oz;
+        const float m = inb_mask(p, x);
+        int ii[3]; float tt[3];
+#pragma unroll
+        for (int d = 0; d < 3; ++d) split(K, x[d], ii[d], tt[d]);
+#pragma unroll 1
+        for (int ch = 0; ch < p.C; ++ch)
+#pragma unroll 1
+            for (int d = 0; d < 3; ++d)
+                out[b * p.val_sb + ch * p.val_sc + 3 * o + d] =
+                    Cvt<float, T>::st(m * tiled::gather_one_thread<T>(L, img + b * p.vol_sb + ch * p.vol_sc, ii[0], ii[1], ii[2], tt[0], tt[1], tt[2], d));
+    }
+}
+
 // IDX (the owner-computes pull, own_gather below): the records carry the sample's linear index instead of a source value; `val` is
 // then the IMAGE and `vol` the OUTPUT of the gather (for the samples gathered directly), `bmax` the list of non-empty bricks
 // (entry 0: their number).  IDX == 2: the grid gradient of the pull (own_gather<K, true>): `aux` is grad_out, `vol` the grid gradient.
@@ -240,7 +269,9 @@ __global__ __launch_bounds__(NT1, 4) void own_bin(KParams p, BrickGrid bg, const
                                                const T *__restrict__ aux, const int *__restrict__ all)
 {
     // AUTO: the probe chose the tiles / (pull, grid gradient) the sample tiles served this tile -- unless the probe gave every tile to the bricks (*all == 1)
-    if (IDX ? (gate && gate[blockIdx.x] == 0 && !(all && *all == 1)) : (gate && *gate != 1)) return;
+    // (index mode without tile flags: `all` alone decides -- every tile or none)
+    if (IDX) { const bool every = all && *all == 1; if (gate ? (gate[blockIdx.x] == 0 && !every) : (all && !every)) return; }
+    else if (gate && *gate != 1) return;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     BinSmem &sm = *reinterpret_cast<BinSmem *>(smem_raw);
     const int tid = threadIdx.x;
@@ -375,6 +406,7 @@ __global__ __launch_bounds__(NT1, 4) void own_bin(KParams p, BrickGrid bg, const
         for (int v = 0; v < VPT1; ++v)
             if (pos[v] >= 0) rec[tilebase + (pos[v] & 0xffff)] = make_float4(c[v][0], c[v][1], c[v][2], v0[v]);
         if (IDX == 2) { if (direct) gradc_direct<T, K, GM>(p, val, aux, grid, vol, b, g, tid, direct); return; }
+        if (IDX == 3) { if (direct) grad_direct<T, K, GM>(p, val, grid, reinterpret_cast<T *>(vol), b, g, tid, direct); return; }
         if (direct) gather_direct<T, K, GM>(p, val, grid, reinterpret_cast<T *>(vol), b, g, tid, direct);
         return;
     }
@@ -1080,7 +1112,8 @@ __device__ __forceinline__ void gather_reads(unsigned addr, f2 (&v)[16])
 // GRAD: the grid gradient of the pull instead (pushpull.py:256-257) -- per tap the channel pair contracted with grad_out (`gout`, two
 // scattered 4-byte loads per sample and pair), three derivative sums, `out` = the dense (B, *out, 3) grid gradient: written by the
 // first pair, accumulated by the following ones (the same thread owns the sample in every pair).
-template <int K, bool GRAD = false>
+// GRAD == 2: grid_grad (nd.py:216-288) -- val[b,c,o,:] = mask * the three derivative sums of each channel, the pair packed.
+template <int K, int GRAD = 0>
 __global__ __launch_bounds__(NT, 4) void own_gather(KParams p, BrickGrid bg, const int *__restrict__ ndesc, const uint2 *__restrict__ desc,
                                                     const float4 *__restrict__ rec, const int *__restrict__ list, int *__restrict__ draw,
                                                     const float *__restrict__ img, float *__restrict__ out, const int *__restrict__ gate,
@@ -1171,7 +1204,41 @@ __global__ __launch_bounds__(NT, 4) void own_gather(KParams p, BrickGrid bg, con
                     }
                     f2 w[4];
                     weights_yz<K>(tyz, w);
-                    if (GRAD) {
+                    if (GRAD == 2) {
+                        f2 dq[4];
+                        wgrads_yz<K>(tyz, dq);
+                        f2 g0 = { 0.f, 0.f }, g1 = { 0.f, 0.f }, g2 = { 0.f, 0.f };
+#pragma unroll
+                        for (int ii = 0; ii <= K; ++ii) {
+                            f2 t2[16];
+                            gather_reads(addr + (unsigned)(ii * GPLANE * 8), t2);
+                            f2 pp = { 0.f, 0.f }, ppy = { 0.f, 0.f }, ppz = { 0.f, 0.f };
+#pragma unroll
+                            for (int jy = 0; jy <= K; ++jy) {
+                                f2 q = { 0.f, 0.f }, qz = { 0.f, 0.f };
+#pragma unroll
+                                for (int k = 0; k <= K; ++k) {
+                                    q = f2{ w[k].y, w[k].y } * t2[4 * jy + k] + q;
+                                    qz = f2{ dq[k].y, dq[k].y } * t2[4 * jy + k] + qz;
+                                }
+                                pp = f2{ w[jy].x, w[jy].x } * q + pp;
+                                ppy = f2{ dq[jy].x, dq[jy].x } * q + ppy;
+                                ppz = f2{ w[jy].x, w[jy].x } * qz + ppz;
+                            }
+                            const float wxi = weight_x<K>(tx, ii), gxi = wgrad_x<K>(tx, ii);
+                            g0 = f2{ gxi, gxi } * pp + g0;
+                            g1 = f2{ wxi, wxi } * ppy + g1;
+                            g2 = f2{ wxi, wxi } * ppz + g2;
+                            asm volatile("" : "+v"(g0), "+v"(g1), "+v"(g2));      // (one x-plane at a time)
+                        }
+                        const float xyz[3] = { rc.x, rc.y, rc.z };
+                        const float m = inb_mask(p, xyz);            // nd.py:286-287
+                        float *dst = oc0 + 3 * (int64_t)__float_as_int(rc.w);
+                        dst[0] = g0.x * m; dst[1] = g1.x * m; dst[2] = g2.x * m;
+                        if (two) { dst[p.val_sc] = g0.y * m; dst[p.val_sc + 1] = g1.y * m; dst[p.val_sc + 2] = g2.y * m; }
+                        continue;
+                    }
+                    if (GRAD == 1) {
                         const int64_t o = (int64_t)__float_as_int(rc.w);
                         const float *gc0 = gout ? gout + b * p.val_sb + (int64_t)c * p.val_sc : nullptr;
                         const float go0 = gc0 ? gc0[o] : 1.f, go1 = two ? (gc0 ? gc0[p.val_sc + o] : 1.f) : 0.f;   // (no grad_out: ones -- the backward of count)
@@ -1575,7 +1642,7 @@ int owner_grad_probe(const interpol_problem *p, const KParams &k, const void *gr
 // brick of the image they read (own_bin, index mode; unbinned samples are gathered on the spot), then the bricks (own_gather).
 // grad == true: the grid gradient of the pull (val := the dense grid gradient, gout := grad_out or NULL for ones).
 int owner_pull_finish(const interpol_problem *p, const KParams &k, const void *vol, const void *grid, void *val,
-                      void *workspace, int64_t workspace_bytes, bool all, hipStream_t st, bool grad, const void *gout, bool probed)
+                      void *workspace, int64_t workspace_bytes, bool all, hipStream_t st, bool grad, const void *gout, bool probed, bool spatial)
 {
     using namespace owner;
     const int nt = tile_count(p);
@@ -1584,7 +1651,9 @@ int owner_pull_finish(const interpol_problem *p, const KParams &k, const void *v
     const BrickGrid bg = brick_grid(k);
     KParams kk = k;
     kk.gate = nullptr;
+    // (spatial: grid_grad through the bricks -- the records of the pull; with the probe every tile or none, own_gather is gated)
     int rc = grad ? launch_bin<float, 2>(p, kk, bg, w, vol, grid, val, all ? nullptr : w.flags, st, gout, probed ? &w.hdr->gate : nullptr)
+           : spatial ? launch_bin<float, 3>(p, kk, bg, w, vol, grid, val, nullptr, st, nullptr, probed ? &w.hdr->gate : nullptr)
                   : launch_bin<float, 1>(p, kk, bg, w, vol, grid, val, all ? nullptr : w.flags, st);
     if (rc) return rc;
     const long long want = 2ll * cu_count();
@@ -1594,11 +1663,12 @@ int owner_pull_finish(const interpol_problem *p, const KParams &k, const void *v
         const int attr = big_lds<own_gather<KK, GR>>(sizeof(GatSmem));                                                  \
         if (attr) return attr;                                                                                          \
         hipLaunchKernelGGL((own_gather<KK, GR>), ggrid, dim3(NT), sizeof(GatSmem), st, kk, bg, (const int *)w.ndesc, (const uint2 *)w.desc, \
-                           (const float4 *)w.rec, (const int *)w.bmax, (int *)w.hdr + 40, (const float *)vol, (float *)val, (const int *)nullptr, \
-                           (const float *)gout);                                                                        \
+                           (const float4 *)w.rec, (const int *)w.bmax, (int *)w.hdr + 40, (const float *)vol, (float *)val,            \
+                           (spatial && probed) ? (const int *)&w.hdr->gate : (const int *)nullptr, (const float *)gout);  \
     }
-    if (grad) { if (k.order[0] == 3) IP_OWN_GAT(3, true) else IP_OWN_GAT(2, true) }
-    else { if (k.order[0] == 3) IP_OWN_GAT(3, false) else IP_OWN_GAT(2, false) }
+    if (grad) { if (k.order[0] == 3) IP_OWN_GAT(3, 1) else IP_OWN_GAT(2, 1) }
+    else if (spatial) { if (k.order[0] == 3) IP_OWN_GAT(3, 2) else IP_OWN_GAT(2, 2) }
+    else { if (k.order[0] == 3) IP_OWN_GAT(3, 0) else IP_OWN_GAT(2, 0) }
 #undef IP_OWN_GAT
     const hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : (int)e;

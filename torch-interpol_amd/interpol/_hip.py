@@ -40,7 +40,7 @@ SYMBOLS = (
     "interpol_push_bricks", "interpol_push_bricks_workspace", "interpol_host_bound_index", "interpol_host_bound_sign",
     "interpol_host_weight", "interpol_host_weight_f32", "interpol_abi_version",
     "interpol_error_string", "interpol_kernel_name", "interpol_scatter_workspace",
-    "interpol_set_handback", "interpol_release_stream", "interpol_pull_workspace", "interpol_pull_ws", "interpol_push_backward_ws",
+    "interpol_set_handback", "interpol_release_stream", "interpol_pull_workspace", "interpol_pull_ws", "interpol_push_backward_ws", "interpol_grad_ws",
 )
 
 
@@ -107,6 +107,8 @@ def lib():
     L.interpol_pull_workspace.restype = i64
     L.interpol_pull_ws.argtypes = [pp, vp, vp, vp, vp, i64, vp]
     L.interpol_pull_ws.restype = ctypes.c_int
+    L.interpol_grad_ws.argtypes = [pp, vp, vp, vp, vp, i64, vp]
+    L.interpol_grad_ws.restype = ctypes.c_int
     L.interpol_push_backward_ws.argtypes = [pp, vp, vp, vp, vp, vp, vp, i64, vp]
     L.interpol_push_backward_ws.restype = ctypes.c_int
     L.interpol_set_handback.argtypes = [i32]
@@ -291,14 +293,14 @@ def gather(op, vol, grid, bound, order, extrapolate, flags=0, out=None):
     grid, gflag = _prep_grid(grid, gdt)
     flags |= gflag
     routed = False
-    if op == "pull" and dim == 3 and dt == torch.float32 and not (flags & (FLAG_NO_FASTPATH | FLAG_FORCE_TILED | FLAG_BINNED_SCATTER)) and (flags >> 8) == 0:
+    if op in ("pull", "grad") and dim == 3 and dt == torch.float32 and not (flags & (FLAG_NO_FASTPATH | FLAG_FORCE_TILED | FLAG_BINNED_SCATTER)) and (flags >> 8) == 0:
         # the router of the pull (csrc/push_owner.hip: own_gather): like the push's, see interpol/backend.py
         from . import backend
         if backend.rough_deformations is None:
             flags |= FLAG_AUTO_SCATTER
         elif backend.rough_deformations:
             flags |= FLAG_BINNED_SCATTER
-    if op == "pull" and (flags & (FLAG_AUTO_SCATTER | FLAG_BINNED_SCATTER)):
+    if op in ("pull", "grad") and (flags & (FLAG_AUTO_SCATTER | FLAG_BINNED_SCATTER)):
         routed = True
     B = max(vol.shape[0], grid.shape[0])
     C = vol.shape[1]
@@ -329,8 +331,8 @@ def gather(op, vol, grid, bound, order, extrapolate, flags=0, out=None):
                 ws, wbytes = None, 0
         if ws is not None:
             with torch.cuda.device(dev):
-                rc = L.interpol_pull_ws(ctypes.byref(p), _ptr(vol), _ptr(grid), _ptr(val), _ptr(ws), wbytes, _stream(dev))
-            _check(rc, "interpol_pull_ws")
+                rc = (L.interpol_pull_ws if op == "pull" else L.interpol_grad_ws)(ctypes.byref(p), _ptr(vol), _ptr(grid), _ptr(val), _ptr(ws), wbytes, _stream(dev))
+            _check(rc, "interpol_%s_ws" % op)
             return val.to(out_dt)
         p.flags &= ~(FLAG_AUTO_SCATTER | FLAG_BINNED_SCATTER)
     fn = getattr(L, "interpol_" + op)
