@@ -29,7 +29,13 @@ exact_scatter = False
 # grid_pull (3-D quadratic / cubic, float32) is routed too, per TILE: the sample tiles of csrc/ops_sorted.hip leave the tiles whose
 # LDS box cannot hold their stencils to bricks of the IMAGE (csrc/push_owner.hip: own_gather; 18 bytes of workspace per sample,
 # allocated per call like the push's): 4x2x256^3 cubic under i.i.d. noise of sigma = 6 voxels 9.8 -> 3 ms; ~3 % on smooth fields.
+# grid_grad, the grid gradient of grid_pull's backward and both gradients of grid_push's / grid_count's backward (float32, 3-D
+# quadratic / cubic) take the same bricks: dense samplings altogether (a probe of the call), expanding ones stay with the tiles.
 # True: always the bricks.  False: always the tiles (no workspace is allocated).
+# Reproducibility: the organisation -- hence the summation order, hence the last bits of a result -- may differ between the
+# settings and, under None, between calls whose probes decide differently; every organisation is held to the same tolerance
+# (1e-5 of max|ref|).  Under None / True the backward of grid_pull is two passes (image gradient = grid_push of grad_out through
+# this router, then the grid gradient), not the fused kernel.
 rough_deformations = None
 
 
