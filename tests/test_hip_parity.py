@@ -703,6 +703,7 @@ def test_graph_capture_replays_correctly():
     side.wait_stream(torch.cuda.current_stream())
     with torch.cuda.stream(side):
         _hip.gather("pull", vol, grid, b, o, 1); _hip.scatter("push", src, grid, list(ishape), b, o, 1)      # warm-up on the side stream
+        _hip.gather("grad", vol, grid, b, o, 1); _hip.push_backward(vol, src, grid, b, o, 1, True, True); _hip.pull_backward(src, vol, grid, b, o, 1, True, True)
     torch.cuda.current_stream().wait_stream(side)
     torch.cuda.synchronize()
     g = torch.cuda.CUDAGraph()
@@ -710,6 +711,8 @@ def test_graph_capture_replays_correctly():
         out_pull = _hip.gather("pull", vol, grid, b, o, 1)
         out_push = _hip.scatter("push", src, grid, list(ishape), b, o, 1)
         out_bwd = _hip.pull_backward(src, vol, grid, b, o, 1, True, True)
+        out_grad = _hip.gather("grad", vol, grid, b, o, 1)
+        out_pbwd = _hip.push_backward(vol, src, grid, b, o, 1, True, True)
     for it in range(3):
         vol.copy_(torch.randn(vol.shape, generator=gen)); src.copy_(torch.randn(src.shape, generator=gen))
         grid.copy_((base * (1.0 + 0.8 * it) + 0.05 * torch.randn(base.shape, generator=gen)))
@@ -719,6 +722,10 @@ def test_graph_capture_replays_correctly():
         _same(out_push, _hip.scatter("push", src, grid, list(ishape), b, o, 1, flags=_hip.FLAG_NO_FASTPATH), 1e-5, ("graph push", it))
         ref = _hip.pull_backward(src, vol, grid, b, o, 1, True, True, flags=_hip.FLAG_NO_FASTPATH)
         _same(out_bwd[0], ref[0], 1e-5, ("graph bwd vol", it)); _same(out_bwd[1], ref[1], 2e-5, ("graph bwd grid", it))
+        # (round 4: the routed grid_grad and push backward -- their probes decide anew at every replay: the zoom changes)
+        _same(out_grad, _hip.gather("grad", vol, grid, b, o, 1, flags=_hip.FLAG_NO_FASTPATH), 2e-5, ("graph grad", it))
+        ref = _hip.push_backward(vol, src, grid, b, o, 1, True, True, flags=_hip.FLAG_NO_FASTPATH)
+        _same(out_pbwd[0], ref[0], 1e-5, ("graph push bwd val", it)); _same(out_pbwd[1], ref[1], 2e-5, ("graph push bwd grid", it))
 
 
 def test_tiled_scatter_nonfinite_sources_keep_ieee_semantics():
