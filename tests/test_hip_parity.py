@@ -1588,6 +1588,42 @@ def test_routed_grid_grad_bricks_of_the_image_against_oracle(sigma):
         oracle.set_threads(1)
 
 
+@pytest.mark.parametrize("sigma", [0.0, 5.0])
+def test_orders_4_and_5_through_bricks_of_the_image_against_oracle(sigma):
+    """csrc/gather5.hip: grid_pull and grid_grad of orders 4 and 5 (3-D, float32) through bricks of the image -- default flags (a probe
+    of the call chooses bricks or tiles; sigma = 5: the bricks) and the bricks alone against the oracle and the generic kernels:
+    every bound (mixed per dim), the three extrapolation modes, 1 - 3 channels, overhanging ragged sample grids; a ninefold zoom
+    (samples gathered directly by bin5).  Samples on a float32 extrapolation threshold may differ from the float64 oracle."""
+    from interpol import _hip
+    g = torch.Generator().manual_seed(int(sigma) + 110)
+    oracle.set_threads(8)
+    try:
+        for (ishape, oshape) in (((40, 33, 50), (37, 45, 29)), ((48, 48, 48), (48, 48, 48))):
+            for bound in range(7):
+                order = 5 - (bound % 2)
+                ex, C = (bound + order) % 3, 1 + (bound + order) % 3
+                inp = torch.randn([2, C, *ishape], generator=g)
+                lin = [torch.linspace(-2, n + 1, m) for n, m in zip(ishape, oshape)]
+                grid = torch.stack(torch.meshgrid(*lin, indexing="ij"), -1)[None] + sigma * torch.randn([2, *oshape, 3], generator=g)
+                b = [bound, (bound + 3) % 7, (bound + 5) % 7]
+                for op, ofun in (("pull", oracle.grid_pull), ("grad", oracle.grid_grad)):
+                    want = ofun(inp.double().numpy(), grid.double().numpy(), b, [order], ex)
+                    slow = _hip.gather(op, inp.to(DEV), grid.to(DEV), b, [order] * 3, ex, flags=_hip.FLAG_NO_FASTPATH).cpu().numpy()
+                    for name, fl in (("routed", 0), ("bricks", _hip.FLAG_BINNED_SCATTER)):
+                        got = _hip.gather(op, inp.to(DEV), grid.to(DEV), b, [order] * 3, ex, flags=fl).cpu().numpy()
+                        assert float(np.abs(got - slow).max()) <= 8e-6 * float(np.abs(slow).max()), (op, name, "vs generic", sigma, b, order, ex)
+                        bad = np.abs(got - want) > 1e-5 * np.abs(want) + 2e-5 * float(np.abs(want).max())
+                        assert bad.sum() <= 9 * C, (op, name, sigma, b, order, ex, int(bad.sum()))
+        inp = torch.randn([2, 3, 25, 47, 58], generator=g).to(DEV)
+        grid = ((interpol.identity_grid((43, 25, 19)) - 10.0) * 9.0)[None].expand(2, 43, 25, 19, 3).contiguous().to(DEV)
+        for order, b in ((5, [6, 5, 6]), (4, [3, 1, 2])):
+            for op in ("pull", "grad"):
+                slow = _hip.gather(op, inp, grid, b, [order] * 3, 0, flags=_hip.FLAG_NO_FASTPATH)
+                _same(_hip.gather(op, inp, grid, b, [order] * 3, 0, flags=_hip.FLAG_BINNED_SCATTER), slow, 1e-5, ("zoomed", op, order, b))
+    finally:
+        oracle.set_threads(1)
+
+
 @pytest.mark.parametrize("sigma", [0.0, 7.0])
 def test_routed_push_and_count_backward_against_oracle(sigma):
     """interpol_push_backward_ws: both gradients of grid_push (pushpull.py:262-282) and the grid gradient of grid_count (286-299)

@@ -62,6 +62,8 @@ int owner_pull_prepare(const interpol_problem *, const KParams &, void *, int64_
 int owner_pull_finish(const interpol_problem *, const KParams &, const void *, const void *, void *, void *, int64_t, bool, hipStream_t,
                       bool grad = false, const void *gout = nullptr, bool probed = false, bool spatial = false);
 int owner_grad_probe(const interpol_problem *, const KParams &, const void *, void *, int64_t, hipStream_t);
+int64_t gather5_workspace_bytes(const interpol_problem *, const KParams &);
+int try_gather5(const interpol_problem *, const KParams &, const void *, const void *, void *, void *, int64_t, bool, hipStream_t, const int **);
 int try_pull_direct(const interpol_problem *, const KParams &, const void *, const void *, void *, int *, int, hipStream_t);
 int try_sorted_pull_f32(const interpol_problem *, const KParams &, const void *, const void *, void *, hipStream_t);
 int try_sorted_gradc_f32(const interpol_problem *, const KParams &, const void *, const void *, const void *, void *, hipStream_t);
@@ -303,7 +305,8 @@ int64_t interpol_pull_workspace(const interpol_problem *p)
     KParams k; int B;
     if (make_params(p, GATHER, 1, &k, &B, false)) return 0;          // (the layout of `val` -- pull, grad, a gradient -- plays no part)
     if (p->flags & INTERPOL_FLAG_NO_FASTPATH) return 0;
-    return owner_pull_workspace_bytes(p, k);
+    const int64_t b5 = gather5_workspace_bytes(p, k);               // orders 4 and 5 (gather5.hip)
+    return b5 ? b5 : owner_pull_workspace_bytes(p, k);
 }
 
 // The routed pull.  1: done, 0: declined (nothing launched that the caller's fallback would not overwrite), else an error.
@@ -312,6 +315,17 @@ static int routed_pull(const interpol_problem *p, KParams k, int B, const void *
 {
     int *flags = nullptr;
     int nzero = 0;
+    if (k.order[0] >= 4) {
+        // orders 4 and 5 (gather5.hip): the bricks always, or behind a probe of the call next to the tiles, which read the same verdict
+        const int *gate = nullptr;
+        int r5 = try_gather5(p, k, vol, grid, val, workspace, workspace_bytes, false, st, &gate);
+        if (r5 != 2) return r5;
+        k.gate = gate; k.gate_n = -1;
+        r5 = try_fast_pull(p, k, vol, grid, val, st);
+        if (r5 != 0) return r5;
+        r5 = launch_pull_f32(k, vol, grid, val, B, st);                // (the tiles declined: the generic kernel, behind the same verdict)
+        return r5 ? r5 : 1;
+    }
     int rc = owner_pull_prepare(p, k, workspace, workspace_bytes, st, &flags, &nzero);
     if (rc != 1) return rc;
     if (p->flags & INTERPOL_FLAG_BINNED_SCATTER) { rc = owner_pull_finish(p, k, vol, grid, val, workspace, workspace_bytes, true, st); return rc ? rc : 1; }
@@ -399,13 +413,26 @@ int interpol_grad_ws(const interpol_problem *p, const void *vol, const void *gri
     hipStream_t st = (hipStream_t)stream;
     int *flags = nullptr;
     int nzero = 0;
+    if (!(p->flags & INTERPOL_FLAG_NO_FASTPATH) && k.order[0] >= 4) {
+        const int *gate = nullptr;
+        rc = try_gather5(p, k, vol, grid, val, workspace, workspace_bytes, true, st, &gate);
+        if (rc == 1) return 0;
+        if (rc != 0 && rc != 2) return rc;
+        if (rc == 2) {
+            KParams kt = k;
+            kt.gate = gate; kt.gate_n = -1;
+            rc = try_fast_grad(p, kt, vol, grid, val, st);
+            if (rc != 0 && rc != 1) return rc;
+            return rc == 1 ? 0 : launch_grad_f32(kt, vol, grid, val, B, st);
+        }
+    }
     if ((p->flags & INTERPOL_FLAG_NO_FASTPATH) || p->dtype != INTERPOL_F32 || owner_pull_prepare(p, k, workspace, workspace_bytes, st, &flags, &nzero) != 1)
         return interpol_grad(p, vol, grid, val, stream);
     if (p->flags & INTERPOL_FLAG_BINNED_SCATTER) return owner_pull_finish(p, k, vol, grid, val, workspace, workspace_bytes, true, st, false, nullptr, false, true);
     rc = owner_grad_probe(p, k, grid, workspace, workspace_bytes, st);
     if (rc) return rc;
     KParams kt = k;
-    kt.gate = flags - nzero;                                         // the probe's verdict (ProbeHdr::gate, the first word of the header): 1 = the bricks
+    kt.gate = flags - nzero; kt.gate_n = -1;                         // the probe's verdict (ProbeHdr::gate, the first word of the header): 1 = the bricks
     rc = try_fast_grad(p, kt, vol, grid, val, st);
     if (rc != 0 && rc != 1) return rc;
     if (rc == 0) {

@@ -1,0 +1,520 @@
+// ===========================================================================
+// gather5.hip -- grid_pull / grid_grad (reference interpol/nd.py:80-143, 216-288) for spline orders 4 and 5 in 3-D, float32,
+// through BRICKS OF THE IMAGE: the organisation of push_owner.hip's own_gather for the 125 / 216-tap stencils of
+// BASELINE config 3 (8 x 1 x 192^3, order 5).
+//
+// The LDS tiles of ops_tiled.hip stage, per 16^3-sample tile, the bounding box of the tile's stencils -- (16 + 5 + 4 sigma)^3
+// lattice points under i.i.d. noise, 147 KiB: ONE workgroup per CU, every phase of a tile exposed.  Here the samples are first
+// sorted by the 16^3 brick of the image their stencil STARTS in (bin5: one pass over the sample grid, tile-local counting sort,
+// runs of records (x, y, z, sample index) published per (tile, brick)); then a workgroup draws a non-empty brick, stages the
+// brick's 21^3 lattice points once per channel (1.7 lattice points per sample whatever the deformation; 69 KiB: two workgroups
+// per CU) and gathers the brick's records from it (gather5).  A box slot holds the PAIR (v[z], v[z + 1]): one ds_read_b64 feeds
+// two z-taps of a single channel at any z -- 108 reads for the 216 taps of a quintic stencil.
+// Samples whose stencil starts more than 160 points outside the lattice, tiles that spread over more than 6 bricks per dim and
+// runs beyond a brick's 128 descriptors are gathered by their own thread from global memory.
+// Every boundary condition (a box slot is a lattice point through the tables), the three extrapolation modes, the four coordinate
+// sources.  Workspace: 16 B per sample + 1 KiB per brick (interpol_pull_workspace).
+// ===========================================================================
+#include "sorted_util.hpp"
+
+namespace ip {
+namespace g5 {
+
+using namespace sorted;
+
+constexpr int BR = 16;                          // brick edge, in first-tap cells
+constexpr int OFFB = 160;                       // first taps in [-OFFB, n + OFFB) are binned
+constexpr int BOX = BR + 5;                     // lattice points a brick's stencils touch per dim (K <= 5)
+constexpr int PZ = BOX - 1;                     // pair slots per row: slot z = (v[z], v[z + 1])
+constexpr int PLANE = BOX * PZ;
+constexpr int NT = 512;                         // gather5: threads (two workgroups per CU)
+constexpr int NS = TS * TS * TS, NT1 = 512, VPT1 = NS / NT1;
+constexpr int LB = 6, NBIN = LB * LB * LB;      // bricks around a tile that are sorted locally
+constexpr int CAPD = 128;                       // runs per brick
+
+struct Grid5 { int nb[3]; int per_item; };
+static Grid5 brick_grid(const KParams &k)
+{
+    Grid5 g;
+    for (int d = 0; d < 3; ++d) g.nb[d] = (k.vol_n[d] + 2 * OFFB + BR - 1) / BR;
+    g.per_item = g.nb[0] * g.nb[1] * g.nb[2];
+    return g;
+}
+
+struct Workspace { int *hdr; int *ndesc; int *list; uint2 *desc; float4 *rec; int64_t nbricks, nrec; };
+static int64_t align256(int64_t x) { return (x + 255) & ~(int64_t)255; }
+static int64_t layout(const Grid5 &bg, int B, int64_t ntiles, void *base, Workspace *w)
+{
+    const int64_t nbricks = (int64_t)bg.per_item * B, nrec = ntiles * NS * B;
+    unsigned char *p = (unsigned char *)base;
+    int64_t o = 0;
+    const int64_t o_hdr = o; o += 256;                               // header (64 ints), brick counters, brick list: ONE zero-fill
+    const int64_t o_nd = o; o += nbricks * 4;
+    const int64_t o_li = o; o += (nbricks + 1) * 4; o = align256(o);
+    const int64_t o_desc = o; o += align256(nbricks * CAPD * 8);
+    const int64_t o_rec = o; o += align256(nrec * 16);
+    if (w) { w->hdr = (int *)(p + o_hdr); w->ndesc = (int *)(p + o_nd); w->list = (int *)(p + o_li); w->desc = (uint2 *)(p + o_desc);
+             w->rec = (float4 *)(p + o_rec); w->nbricks = nbricks; w->nrec = nrec; }
+    return o;
+}
+
+__global__ void zero5(int *p, int n)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = 0;
+}
+
+// MODE 0: pull, val[b,c,o]; MODE 2: grid_grad, val[b,c,o,:]
+template <int K, int GM, int MODE>
+__device__ __forceinline__ void direct5(const KParams &p, const float *__restrict__ img, const float *__restrict__ grid, float *__restrict__ out,
+                                        int64_t b, TileGeom g, int tid, unsigned mask)
+{
+    Lattice L;
+#pragma unroll
+    for (int d = 0; d < 3; ++d) { L.bound[d] = p.bound[d]; L.n[d] = p.vol_n[d]; L.ss[d] = p.vol_ss[d] / 4; L.k[d] = K; }
+    L.lin = 0;
+#pragma unroll 1
+    for (int v = 0; v < VPT1; ++v) {
+        if (!((mask >> v) & 1)) continue;
+        int ox, oy, oz; float x[3];
+        sample_pos(g, tid + NT1 * v, ox, oy, oz);
+        load_xyz<GM>(p, grid, b, g, ox, oy, oz, x);
+        const int64_t o = ((int64_t)ox * g.gy + oy) * g.gz + oz;
+        const float m = inb_mask(p, x);
+        int ii[3]; float tt[3];
+#pragma unroll
+        for (int d = 0; d < 3; ++d) split(K, x[d], ii[d], tt[d]);
+#pragma unroll 1
+        for (int ch = 0; ch < p.C; ++ch) {
+            const float *ic = img + b * p.vol_sb + ch * p.vol_sc;
+            if (MODE == 0) out[b * p.val_sb + ch * p.val_sc + o] = m * tiled::gather_one_thread<float>(L, ic, ii[0], ii[1], ii[2], tt[0], tt[1], tt[2], -1);
+            else {
+#pragma unroll 1
+                for (int d = 0; d < 3; ++d)
+                    out[b * p.val_sb + ch * p.val_sc + 3 * o + d] = m * tiled::gather_one_thread<float>(L, ic, ii[0], ii[1], ii[2], tt[0], tt[1], tt[2], d);
+            }
+        }
+    }
+}
+
+struct BinSmem { int lo[3], pad; int cnt[NBIN], base[NBIN]; };
+
+// One workgroup per 16^3-sample tile: the tile's samples sorted by the brick of their first tap (nd.py:45: i0 = floor(x - (K-1)/2)).
+template <int K, int GM, int MODE>
+__global__ __launch_bounds__(NT1, 4) void bin5(KParams p, Grid5 bg, const float *__restrict__ img, const float *__restrict__ grid, float *__restrict__ out,
+                                               int *__restrict__ ndesc, int *__restrict__ list, uint2 *__restrict__ desc, float4 *__restrict__ rec,
+                                               int gx, int gy, int gz, int nty, int ntz, int ntiles, const int *__restrict__ gate)
+{
+    if (gate && *gate != 1) return;                                  // INTERPOL_FLAG_AUTO_SCATTER: the probe chose the tiles
+    __shared__ BinSmem sm;
+    const int tid = threadIdx.x;
+    const int64_t b = blockIdx.x / ntiles;
+    const TileGeom g = tile_geom(blockIdx.x % ntiles, gx, gy, gz, nty, ntz);
+    for (int i = tid; i < NBIN; i += NT1) sm.cnt[i] = 0;
+    if (tid < 3) sm.lo[tid] = 0x7fffffff;
+    float c[VPT1][3];
+    int idx[VPT1];
+    unsigned valid = 0;
+#pragma unroll
+    for (int v = 0; v < VPT1; ++v) {
+        int ox, oy, oz;
+        sample_pos(g, tid + NT1 * v, ox, oy, oz);
+        if (ox < gx && oy < gy && oz < gz) valid |= 1u << v;
+        ox = ox < gx ? ox : gx - 1; oy = oy < gy ? oy : gy - 1; oz = oz < gz ? oz : gz - 1;
+        load_xyz<GM>(p, grid, b, g, ox, oy, oz, c[v]);
+        idx[v] = (int)(((int64_t)ox * gy + oy) * gz + oz);
+    }
+    int bx[VPT1][3];
+    unsigned ok = 0;
+    int mn[3] = { 0x7fffffff, 0x7fffffff, 0x7fffffff };
+#pragma unroll
+    for (int v = 0; v < VPT1; ++v) {
+        bool in = (valid >> v) & 1;
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            const float fl = floorf(c[v][d] - 0.5f * (float)(K - 1));
+            in = in && fl >= (float)(-OFFB) && fl < (float)(bg.nb[d] * BR - OFFB);     // (false for NaN)
+            bx[v][d] = in ? (__float2int_rz(fl) + OFFB) >> 4 : 0;
+        }
+        if (in) {
+            ok |= 1u << v;
+#pragma unroll
+            for (int d = 0; d < 3; ++d) mn[d] = bx[v][d] < mn[d] ? bx[v][d] : mn[d];
+        }
+    }
+    __syncthreads();                                                 // counters zero
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        const int a = wave_min(mn[d]);
+        if ((tid & 63) == 0) atomicMin(&sm.lo[d], a);
+    }
+    __syncthreads();
+    const int lo[3] = { sm.lo[0], sm.lo[1], sm.lo[2] };
+    int lbin[VPT1];                                                  // local brick (8 bits), rank inside it (above)
+    unsigned local = 0;
+#pragma unroll
+    for (int v = 0; v < VPT1; ++v) {
+        const int r0 = bx[v][0] - lo[0], r1 = bx[v][1] - lo[1], r2 = bx[v][2] - lo[2];
+        const bool l = ((ok >> v) & 1) && (unsigned)r0 < (unsigned)LB && (unsigned)r1 < (unsigned)LB && (unsigned)r2 < (unsigned)LB;
+        lbin[v] = l ? (r0 * LB + r1) * LB + r2 : 0;
+        if (l) { local |= 1u << v; lbin[v] |= atomicAdd(&sm.cnt[lbin[v]], 1) << 8; }
+    }
+    __syncthreads();
+    const int64_t tilebase = (int64_t)blockIdx.x * NS;
+    if (tid < 64) {
+        constexpr int PER = (NBIN + 63) / 64;                        // 4
+        int cn[PER], s = 0;
+#pragma unroll
+        for (int i = 0; i < PER; ++i) { const int e = tid * PER + i; cn[i] = e < NBIN ? sm.cnt[e] : 0; s += cn[i]; }
+        int incl = s;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o); if (tid >= o) incl += t; }
+        int run = incl - s;
+        int bk[PER], slot[PER];
+#pragma unroll
+        for (int i = 0; i < PER; ++i) {                              // (all slots drawn before the first is used: one round trip)
+            const int e = tid * PER + i;
+            const int r0 = e / (LB * LB), r1 = (e / LB) % LB, r2 = e % LB;
+            bk[i] = (int)b * bg.per_item + ((lo[0] + r0) * bg.nb[1] + (lo[1] + r1)) * bg.nb[2] + (lo[2] + r2);
+            slot[i] = 0;
+            if (e < NBIN && cn[i] > 0) slot[i] = atomicAdd(&ndesc[bk[i]], 1);
+            if (e < NBIN && cn[i] > 0 && slot[i] == 0) list[1 + atomicAdd(&list[0], 1)] = bk[i];          // first run of the brick
+        }
+#pragma unroll
+        for (int i = 0; i < PER; ++i) {
+            const int e = tid * PER + i;
+            if (e < NBIN) {
+                sm.base[e] = run;
+                if (cn[i] > 0) {
+                    if (slot[i] < CAPD) desc[(int64_t)bk[i] * CAPD + slot[i]] = make_uint2((unsigned)(tilebase + run), (unsigned)cn[i]);
+                    else sm.cnt[e] = -1;                             // the brick's list is full: gathered directly, below
+                }
+                run += cn[i];
+            }
+        }
+    }
+    __syncthreads();
+    unsigned direct = valid & ~local;
+#pragma unroll
+    for (int v = 0; v < VPT1; ++v) {
+        if (!((local >> v) & 1)) continue;
+        const int e = lbin[v] & 255;
+        if (sm.cnt[e] < 0) { direct |= 1u << v; continue; }
+        rec[tilebase + sm.base[e] + (lbin[v] >> 8)] = make_float4(c[v][0], c[v][1], c[v][2], __int_as_float(idx[v]));
+    }
+    if (direct) direct5<K, GM, MODE>(p, img, grid, out, b, g, tid, direct);
+}
+
+// INTERPOL_FLAG_AUTO_SCATTER: NPROBE tiles of the sample grid are examined the way the LDS tiles of ops_tiled.hip would cut them --
+// the box of a 16^3-sample tile of orders 4 / 5 holds 33 x 33 x 32 lattice points, centred on the tile's stencils; a sample whose
+// stencil leaves it costs a WAVE there (64 times a sample inside).  hdr[0] = 1 (the bricks) when more than 1 / 300 of the probed
+// samples do: i.i.d. noise of sigma ~ 2.3 voxels, where the two organisations cross (config 3's shape: sigma = 2 0.06 % outside,
+// tiles 2.6 ms against 2.8; sigma = 2.5 0.4 %, 3.0 against 2.8; sigma = 3 1.4 %, 4.0 against 2.75).  hdr[1..3]: counters.
+constexpr int NPROBE = 128;
+template <int K, int GM>
+__global__ __launch_bounds__(NT1) void probe5(KParams p, const float *__restrict__ grid, int *__restrict__ hdr, int gx, int gy, int gz, int nty, int ntz,
+                                              int ntiles, int nbatch)
+{
+    __shared__ int lo[3], hi[3], cnt[2];
+    const int tid = threadIdx.x;
+    const int64_t total = (int64_t)ntiles * nbatch;
+    const int64_t work = (int64_t)blockIdx.x * total / gridDim.x;
+    const int64_t b = work / ntiles;
+    const TileGeom g = tile_geom((int)(work % ntiles), gx, gy, gz, nty, ntz);
+    if (tid < 3) { lo[tid] = 0x7fffffff; hi[tid] = -0x7fffffff; }
+    if (tid < 2) cnt[tid] = 0;
+    float fl[VPT1][3];
+    unsigned valid = 0;
+#pragma unroll
+    for (int v = 0; v < VPT1; ++v) {
+        int ox, oy, oz; float c[3];
+        sample_pos(g, tid + NT1 * v, ox, oy, oz);
+        if (ox < gx && oy < gy && oz < gz) valid |= 1u << v;
+        load_xyz<GM>(p, grid, b, g, ox < gx ? ox : gx - 1, oy < gy ? oy : gy - 1, oz < gz ? oz : gz - 1, c);
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            const float f = floorf(c[d] - 0.5f * (float)(K - 1));
+            fl[v][d] = f == f ? __builtin_fmaxf(__builtin_fminf(f, 1073741824.f), -1073741824.f) : 0.f;
+        }
+    }
+    __syncthreads();
+    int mn[3] = { 0x7fffffff, 0x7fffffff, 0x7fffffff }, mx[3] = { -0x7fffffff, -0x7fffffff, -0x7fffffff };
+#pragma unroll
+    for (int v = 0; v < VPT1; ++v) {
+        if (!((valid >> v) & 1)) continue;
+#pragma unroll
+        for (int d = 0; d < 3; ++d) { const int i = __float2int_rz(fl[v][d]); mn[d] = i < mn[d] ? i : mn[d]; mx[d] = i > mx[d] ? i : mx[d]; }
+    }
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        const int a = wave_min(mn[d]), e = wave_max(mx[d]);
+        if ((tid & 63) == 0) { atomicMin(&lo[d], a); atomicMax(&hi[d], e); }
+    }
+    __syncthreads();
+    const int cap[3] = { 33, 33, 32 };
+    int l[3], h[3];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        int a = lo[d], sz = hi[d] + K - a + 1;
+        if (sz > cap[d]) { a += (sz - cap[d]) / 2; sz = cap[d]; }
+        l[d] = a; h[d] = a + sz - K - 1;
+    }
+    int slow = 0, nv = 0;
+#pragma unroll
+    for (int v = 0; v < VPT1; ++v) {
+        if (!((valid >> v) & 1)) continue;
+        ++nv;
+        bool in = true;
+#pragma unroll
+        for (int d = 0; d < 3; ++d) { const int i = __float2int_rz(fl[v][d]); in = in && i >= l[d] && i <= h[d]; }
+        if (!in) ++slow;
+    }
+    slow = wave_sum(slow); nv = wave_sum(nv);
+    if ((tid & 63) == 0) { atomicAdd(&cnt[0], slow); atomicAdd(&cnt[1], nv); }
+    __syncthreads();
+    if (tid == 0) {
+        atomicAdd(&hdr[1], cnt[0]); atomicAdd(&hdr[2], cnt[1]);
+        __threadfence();
+        if (atomicAdd(&hdr[3], 1) == (int)gridDim.x - 1) {
+            const int ns = atomicAdd(&hdr[1], 0), nn = atomicAdd(&hdr[2], 0);
+            hdr[0] = (int64_t)ns * 300 > nn ? 1 : 0;
+        }
+    }
+}
+
+struct GatSmem {
+    int   taboff[3][BOX + 3];
+    float tabsgn[3][BOX + 3];
+    unsigned start[CAPD];
+    int   rcnt[CAPD];
+    int   brick, pad[3];
+    float2 box[BOX * PLANE + 64];              // 21 x 21 x 20 pair slots = 70 560 B (+ the quartic stencil's unused sixth row / plane)
+};
+static_assert(sizeof(GatSmem) <= 80 * 1024, "two workgroups per CU");
+
+#define IP_RD(o, off) "ds_read_b64 %" #o ", %18 offset:" #off "\n\t"
+// the 36 taps of one x-plane of a stencil: six rows 160 bytes apart, three pairs per row
+__device__ __forceinline__ void plane_reads(unsigned addr, f2 (&v)[18])
+{
+    static_assert(PZ * 8 == 160, "the immediate offsets are (row * PZ + 2 k) * 8");
+    asm volatile(IP_RD(0, 0) IP_RD(1, 16) IP_RD(2, 32) IP_RD(3, 160) IP_RD(4, 176) IP_RD(5, 192)
+                 IP_RD(6, 320) IP_RD(7, 336) IP_RD(8, 352) IP_RD(9, 480) IP_RD(10, 496) IP_RD(11, 512)
+                 IP_RD(12, 640) IP_RD(13, 656) IP_RD(14, 672) IP_RD(15, 800) IP_RD(16, 816) IP_RD(17, 832)
+                 "s_waitcnt lgkmcnt(0)"
+                 : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]), "=&v"(v[4]), "=&v"(v[5]), "=&v"(v[6]), "=&v"(v[7]), "=&v"(v[8]),
+                   "=&v"(v[9]), "=&v"(v[10]), "=&v"(v[11]), "=&v"(v[12]), "=&v"(v[13]), "=&v"(v[14]), "=&v"(v[15]), "=&v"(v[16]), "=&v"(v[17])
+                 : "v"(addr) : "memory");
+}
+#undef IP_RD
+
+template <int K, int MODE>
+__global__ __launch_bounds__(NT, 4) void gather5(KParams p, Grid5 bg, const int *__restrict__ ndesc, const uint2 *__restrict__ desc,
+                                                 const float4 *__restrict__ rec, const int *__restrict__ list, int *__restrict__ draw,
+                                                 const float *__restrict__ img, float *__restrict__ out, const int *__restrict__ gate)
+{
+    if (gate && *gate != 1) return;                                  // INTERPOL_FLAG_AUTO_SCATTER: the probe chose the tiles
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    GatSmem &sm = *reinterpret_cast<GatSmem *>(smem_raw);
+    const int nlist = list[0];
+    for (;;) {
+        const int tid = opaque((int)threadIdx.x);
+        __syncthreads();                                             // the previous brick's readers are done
+        if (tid == 0) { const int i = atomicAdd(draw, 1); sm.brick = i < nlist ? list[1 + i] : -1; }
+        __syncthreads();
+        const int bk = sm.brick;
+        if (bk < 0) break;
+        const int64_t b = bk / bg.per_item;
+        int r = bk - (int)b * bg.per_item;
+        const int bz = r % bg.nb[2]; r /= bg.nb[2];
+        const int by = r % bg.nb[1], bx = r / bg.nb[1];
+        const int b0[3] = { bx * BR - OFFB, by * BR - OFFB, bz * BR - OFFB };       // lattice index of box slot 0
+        const int nd = min(ndesc[bk], CAPD);
+        if (tid < nd) { const uint2 d = desc[(int64_t)bk * CAPD + tid]; sm.start[tid] = d.x; sm.rcnt[tid] = (int)d.y; }
+        if (tid >= 128 && tid < 128 + 3 * 64) {                      // box slot -> wrapped lattice offset and sign (bounds.py:30-89)
+            const int d = (tid - 128) >> 6, slot = tid & 63;
+            if (slot < BOX) {
+                const long long pk = wrap_outofline(p.bound[d], (d == 0 ? b0[0] : d == 1 ? b0[1] : b0[2]) + slot, p.vol_n[d]);
+                sm.taboff[d][slot] = (int)(pk & 0xffffffffll) * (p.vol_ss[d] / 4);
+                sm.tabsgn[d][slot] = (float)(int)(pk >> 32);
+            }
+        }
+        const unsigned boxaddr = (unsigned)(size_t)(__attribute__((address_space(3))) void *)(sm.box);
+        for (int c = 0; c < p.C; ++c) {
+            const float *vc = img + b * p.vol_sb + (int64_t)c * p.vol_sc;
+            float *oc = out + b * p.val_sb + (int64_t)c * p.val_sc;
+            __syncthreads();                                         // tables written / the previous channel's readers are done
+            // rows that are contiguous runs of the image's unit-stride dim with sign +1: five quads of pair slots per row from a
+            // 16-byte load and the value behind it; else slot by slot through the z table
+            const bool zlin = p.vol_ss[2] == 4 && b0[2] >= (p.bound[2] == B_DST1 ? 1 : 0) && b0[2] + BOX <= p.vol_n[2];
+            if (zlin) {
+                for (int e = tid; e < BOX * BOX * 5; e += NT) {
+                    const int row = e / 5, q = e - row * 5;
+                    const int x = row / BOX, y = row - x * BOX;
+                    const int off = sm.taboff[0][x] + sm.taboff[1][y] + b0[2] + 4 * q;
+                    const float sg = sm.tabsgn[0][x] * sm.tabsgn[1][y];
+                    const float4 a = ld4<float>(vc + off);
+                    const float n = vc[off + 4] * sg;
+                    float4 *dst = reinterpret_cast<float4 *>(sm.box + row * PZ + 4 * q);
+                    dst[0] = make_float4(a.x * sg, a.y * sg, a.y * sg, a.z * sg);
+                    dst[1] = make_float4(a.z * sg, a.w * sg, a.w * sg, n);
+                }
+            } else {
+                for (int e = tid; e < BOX * BOX * PZ; e += NT) {
+                    const int x = e / (BOX * PZ), y = (e / PZ) % BOX, z = e % PZ;
+                    const int o0 = sm.taboff[0][x] + sm.taboff[1][y];
+                    const float sg = sm.tabsgn[0][x] * sm.tabsgn[1][y];
+                    sm.box[e] = make_float2(vc[o0 + sm.taboff[2][z]] * (sg * sm.tabsgn[2][z]), vc[o0 + sm.taboff[2][z + 1]] * (sg * sm.tabsgn[2][z + 1]));
+                }
+            }
+            __syncthreads();
+            const int wave = tid >> 6, lane = tid & 63;
+            for (int run = wave; run < nd; run += NT / 64) {
+                const int n = sm.rcnt[run];
+                const unsigned first = sm.start[run];
+                for (int i = lane; i < n; i += 64) {
+                    const float4 rc = rec[first + i];
+                    const float fx = floorf(rc.x - 0.5f * (float)(K - 1)), fy = floorf(rc.y - 0.5f * (float)(K - 1)), fz = floorf(rc.z - 0.5f * (float)(K - 1));
+                    const float tx = rc.x - fx, ty = rc.y - fy, tz = rc.z - fz;
+                    // first-tap cell inside the brick: 0 .. 15 by construction of the bins; clamped, should a coordinate be off
+                    int cx = __float2int_rz(fx) - b0[0], cy = __float2int_rz(fy) - b0[1], cz = __float2int_rz(fz) - b0[2];
+                    cx = max(0, min(cx, BR - 1)); cy = max(0, min(cy, BR - 1)); cz = max(0, min(cz, BR - 1));
+                    const unsigned addr = boxaddr + (unsigned)((cx * BOX + cy) * PZ + cz) * 8u;
+                    float wy[6], wz[6];
+                    wy[5] = 0.f; wz[5] = 0.f;                        // (K == 4: the sixth weight is 0)
+                    tiled::weights<K>(0, K, ty, wy);
+                    tiled::weights<K>(0, K, tz, wz);
+                    const f2 wzp[3] = { f2{ wz[0], wz[1] }, f2{ wz[2], wz[3] }, f2{ wz[4], wz[5] } };
+                    const float xyz[3] = { rc.x, rc.y, rc.z };
+                    const float m = inb_mask(p, xyz);                // nd.py:139-140
+                    const int64_t o = (int64_t)__float_as_int(rc.w);
+                    if (MODE == 0) {
+                        float acc = 0.f;
+#pragma unroll
+                        for (int ii = 0; ii <= K; ++ii) {
+                            f2 t[18];
+                            plane_reads(addr + (unsigned)(ii * PLANE * 8), t);
+                            float pl = 0.f;
+#pragma unroll
+                            for (int j = 0; j <= K; ++j) {
+                                const f2 s = wzp[0] * t[3 * j] + (wzp[1] * t[3 * j + 1] + wzp[2] * t[3 * j + 2]);
+                                pl = __builtin_fmaf(wy[j], s.x + s.y, pl);
+                            }
+                            acc = __builtin_fmaf(tiled::weight1(0, K, tx, ii, tiled::tap_piece(K, ii)), pl, acc);
+                            asm volatile("" : "+v"(acc));            // (one x-plane at a time)
+                        }
+                        oc[o] = acc * m;
+                    } else {
+                        float gy[6], gzz[6];
+                        gy[5] = 0.f; gzz[5] = 0.f;
+                        tiled::wgrads<K>(0, K, ty, gy);
+                        tiled::wgrads<K>(0, K, tz, gzz);
+                        const f2 gzp[3] = { f2{ gzz[0], gzz[1] }, f2{ gzz[2], gzz[3] }, f2{ gzz[4], gzz[5] } };
+                        float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+#pragma unroll
+                        for (int ii = 0; ii <= K; ++ii) {
+                            f2 t[18];
+                            plane_reads(addr + (unsigned)(ii * PLANE * 8), t);
+                            float pl = 0.f, ply = 0.f, plz = 0.f;
+#pragma unroll
+                            for (int j = 0; j <= K; ++j) {
+                                const f2 s = wzp[0] * t[3 * j] + (wzp[1] * t[3 * j + 1] + wzp[2] * t[3 * j + 2]);
+                                const f2 sz = gzp[0] * t[3 * j] + (gzp[1] * t[3 * j + 1] + gzp[2] * t[3 * j + 2]);
+                                const float rv = s.x + s.y, rz = sz.x + sz.y;
+                                pl = __builtin_fmaf(wy[j], rv, pl);
+                                ply = __builtin_fmaf(gy[j], rv, ply);
+                                plz = __builtin_fmaf(wy[j], rz, plz);
+                            }
+                            const float wxi = tiled::weight1(0, K, tx, ii, tiled::tap_piece(K, ii)), gxi = tiled::wgrad1(0, K, tx, ii, tiled::tap_piece(K, ii));
+                            a0 = __builtin_fmaf(gxi, pl, a0);
+                            a1 = __builtin_fmaf(wxi, ply, a1);
+                            a2 = __builtin_fmaf(wxi, plz, a2);
+                            asm volatile("" : "+v"(a0), "+v"(a1), "+v"(a2));
+                        }
+                        float *dst = oc + 3 * o;
+                        dst[0] = a0 * m; dst[1] = a1 * m; dst[2] = a2 * m;
+                    }
+                }
+            }
+        }
+    }
+}
+
+static bool eligible(const interpol_problem *p, const KParams &k)
+{
+    if (p->dim != 3 || p->dtype != INTERPOL_F32 || p->grid_dtype != INTERPOL_F32 || p->batch > 4096) return false;
+    if (!(p->flags & (INTERPOL_FLAG_BINNED_SCATTER | INTERPOL_FLAG_AUTO_SCATTER))) return false;
+    if (k.order[0] != k.order[1] || k.order[0] != k.order[2] || k.order[0] < 4 || k.order[0] > 5) return false;
+    if (p->val_stride[0] < 0) return false;
+    int64_t n = 1, nt = p->batch, nb = p->batch;
+    for (int d = 0; d < 3; ++d) {
+        if (p->grid_shape[d] > 0x7fffffff / 4) return false;
+        n *= p->grid_shape[d];
+        nt *= (p->grid_shape[d] + TS - 1) / TS;
+        nb *= (p->vol_shape[d] + 2 * OFFB + BR - 1) / BR;
+    }
+    if (n < 4096 || nt * NS > 0x7fffffffll || nb > 0x7fffffffll / CAPD) return false;
+    if ((uint64_t)n * 12ull > 0xffffffffull) return false;
+    return true;
+}
+
+} // namespace g5
+
+int64_t gather5_workspace_bytes(const interpol_problem *p, const KParams &k)
+{
+    if (!g5::eligible(p, k)) return 0;
+    int64_t nt = 1;
+    for (int d = 0; d < 3; ++d) nt *= (p->grid_shape[d] + sorted::TS - 1) / sorted::TS;
+    return g5::layout(g5::brick_grid(k), (int)p->batch, nt, nullptr, nullptr);
+}
+
+// grid_pull (grad == false) / grid_grad through the bricks: 1 = done, 0 = declined, else an error
+// INTERPOL_FLAG_AUTO_SCATTER: 2 = launched behind the probe's verdict -- the caller launches the tile / generic kernels as well, with
+// KParams::gate = *gate_out and gate_n = -1 (they return at once when the verdict is 1).
+int try_gather5(const interpol_problem *p, const KParams &k, const void *vol, const void *grid, void *val, void *workspace, int64_t workspace_bytes,
+                bool grad, hipStream_t st, const int **gate_out)
+{
+    using namespace g5;
+    if (!workspace || ((uintptr_t)workspace & 255u) != 0 || !eligible(p, k)) return 0;
+    const int gx = (int)p->grid_shape[0], gy = (int)p->grid_shape[1], gz = (int)p->grid_shape[2];
+    const int nty = (gy + TS - 1) / TS, ntz = (gz + TS - 1) / TS, ntiles = ((gx + TS - 1) / TS) * nty * ntz;
+    const Grid5 bg = brick_grid(k);
+    Workspace w;
+    if (layout(bg, (int)p->batch, ntiles, workspace, &w) > workspace_bytes) return 0;
+    const int64_t nz = 64 + 2 * w.nbricks + 1;
+    if (nz > 0x7fffffffll) return 0;
+    hipLaunchKernelGGL(zero5, dim3((unsigned)((nz + 1023) / 1024)), dim3(1024), 0, st, w.hdr, (int)nz);
+    const bool gated = !(p->flags & INTERPOL_FLAG_BINNED_SCATTER);
+    const int *gate = gated ? w.hdr : nullptr;
+    if (gated) {
+        const long long total = (long long)ntiles * p->batch;
+        const dim3 pgrid((unsigned)(total < NPROBE ? total : NPROBE));
+#define IP_P5(KK, GM) hipLaunchKernelGGL((probe5<KK, GM>), pgrid, dim3(NT1), 0, st, k, (const float *)grid, w.hdr, gx, gy, gz, nty, ntz, ntiles, (int)p->batch);
+#define IP_P5_GM(KK) { if (k.sep == 0) IP_P5(KK, 0) else if (k.sep == 1) IP_P5(KK, 1) else if (k.sep == 2) IP_P5(KK, 2) else IP_P5(KK, 3) }
+        if (k.order[0] == 5) IP_P5_GM(5) else IP_P5_GM(4)
+#undef IP_P5_GM
+#undef IP_P5
+    }
+    const dim3 tgrid((unsigned)(ntiles * (int)p->batch));
+    const long long want = 2ll * cu_count();
+    const dim3 ggrid((unsigned)(w.nbricks < want ? w.nbricks : want));
+#define IP_G5(KK, GM, MD)                                                                                               \
+    {                                                                                                                   \
+        hipLaunchKernelGGL((bin5<KK, GM, MD>), tgrid, dim3(NT1), 0, st, k, bg, (const float *)vol, (const float *)grid, (float *)val, \
+                           w.ndesc, w.list, w.desc, w.rec, gx, gy, gz, nty, ntz, ntiles, gate);                         \
+        const int attr = big_lds<gather5<KK, MD>>(sizeof(GatSmem));                                                     \
+        if (attr) return attr;                                                                                          \
+        hipLaunchKernelGGL((gather5<KK, MD>), ggrid, dim3(NT), sizeof(GatSmem), st, k, bg, (const int *)w.ndesc, (const uint2 *)w.desc, \
+                           (const float4 *)w.rec, (const int *)w.list, w.hdr + 40, (const float *)vol, (float *)val, gate); \
+    }
+#define IP_G5_GM(KK, MD) { if (k.sep == 0) IP_G5(KK, 0, MD) else if (k.sep == 1) IP_G5(KK, 1, MD) else if (k.sep == 2) IP_G5(KK, 2, MD) else IP_G5(KK, 3, MD) }
+    if (k.order[0] == 5) { if (grad) IP_G5_GM(5, 2) else IP_G5_GM(5, 0) }
+    else { if (grad) IP_G5_GM(4, 2) else IP_G5_GM(4, 0) }
+#undef IP_G5_GM
+#undef IP_G5
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return (int)e;
+    if (gate_out) *gate_out = gate;
+    return gated ? 2 : 1;
+}
+
+} // namespace ip

@@ -123,6 +123,7 @@ template <typename T, typename G, typename R, int D, int KMAX, bool ISO, bool DE
 __global__ __launch_bounds__(BLOCK) void pull_generic(KParams p, const T *__restrict__ vol,
                                                       const G *__restrict__ grid, T *__restrict__ val, int B, TileList tl)
 {
+    if (p.gate_n == -1 && p.gate && *p.gate == 1) return;   // a probe of the call gave it to the bricks of the image (interpol_pull_ws / interpol_grad_ws)
     IP_FOR_SAMPLES {
         const int64_t b = it_.b, o = it_.o;
         R x[D];
@@ -159,7 +160,7 @@ template <typename T, typename G, typename R, int D, int KMAX, bool ISO, bool DE
 __global__ __launch_bounds__(BLOCK) void grad_generic(KParams p, const T *__restrict__ vol,
                                                       const G *__restrict__ grid, T *__restrict__ val, int B, TileList tl)
 {
-    if (p.gate && *p.gate == 1) return;                // interpol_grad_ws: the bricks of the image took the call (push_owner.hip)
+    if (p.gate_n == -1 && p.gate && *p.gate == 1) return;   // a probe of the call gave it to the bricks of the image (interpol_pull_ws / interpol_grad_ws)
     IP_FOR_SAMPLES {
         const int64_t b = it_.b, o = it_.o;
         R x[D];

@@ -549,7 +549,7 @@ template <typename C, bool GRAD>
 __global__ __launch_bounds__(C::NT) void gather_tiled(KParams p, const typename C::T *__restrict__ vol, const float *__restrict__ grid,
                                                       typename C::T *__restrict__ val, int gx, int gy, int gz, int nty, int ntz, int ntiles, int nbatch, DeferArgs defer)
 {
-    if (GRAD && p.gate && *p.gate == 1) return;        // interpol_grad_ws: the probe of the call gave it to the bricks of the image (push_owner.hip)
+    if (p.gate_n == -1 && p.gate && *p.gate == 1) return;   // a probe of the call gave it to the bricks of the image (interpol_pull_ws / interpol_grad_ws)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     Smem &sm = *reinterpret_cast<Smem *>(smem_raw);
     constexpr int D = C::D;
@@ -642,6 +642,7 @@ __global__ __launch_bounds__(C::NT) void pull2_tiled(KParams p, const typename C
                                                      typename C::T *__restrict__ val, int gx, int gy, int gz, int nty, int ntz,
                                                      int ntiles, int nbatch, DeferArgs defer)
 {
+    if (p.gate_n == -1 && p.gate && *p.gate == 1) return;   // a probe of the call gave it to the bricks of the image (interpol_pull_ws / interpol_grad_ws)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     Smem &sm = *reinterpret_cast<Smem *>(smem_raw);
     static_assert(C::D == 3, "pair mode is 3-D only");
@@ -806,6 +807,7 @@ __global__ __launch_bounds__(C::NT) void pull1s_tiled(KParams p, const typename 
                                                      typename C::T *__restrict__ val, int gx, int gy, int gz, int nty, int ntz,
                                                      int ntiles, int nbatch, DeferArgs defer)
 {
+    if (p.gate_n == -1 && p.gate && *p.gate == 1) return;   // a probe of the call gave it to the bricks of the image (interpol_pull_ws / interpol_grad_ws)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     Smem &sm = *reinterpret_cast<Smem *>(smem_raw);
     static_assert(C::D == 3 && C::ISO, "shifted-pair mode: 3-D, one compile-time order");
@@ -961,7 +963,7 @@ __global__ __launch_bounds__(C::NT) void grad1s_tiled(KParams p, const typename 
                                                      typename C::T *__restrict__ val, int gx, int gy, int gz, int nty, int ntz,
                                                      int ntiles, int nbatch, DeferArgs defer)
 {
-    if (p.gate && *p.gate == 1) return;                // interpol_grad_ws: the bricks of the image took the call
+    if (p.gate_n == -1 && p.gate && *p.gate == 1) return;   // a probe of the call gave it to the bricks of the image (interpol_pull_ws / interpol_grad_ws)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     Smem &sm = *reinterpret_cast<Smem *>(smem_raw);
     static_assert(C::D == 3 && C::ISO, "shifted-pair mode: 3-D, one compile-time order");
