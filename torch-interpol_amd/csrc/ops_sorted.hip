@@ -1242,7 +1242,9 @@ static int launch_gradc(const interpol_problem *p, const KParams &k, const void 
     const TileCount t(p);
     const Defer df(k, st, t.ntiles(), p->batch, t.ntx, t.nty, t.ntz, TS, TS, TS);
     const int mopt = (k.dbg >> 13) & 7, mult = mopt == 0 ? 2 : mopt;   // (as launch_pull)
-    hipLaunchKernelGGL((gradc_sorted<T, K, GM>), mopt == 7 ? t.grid((int)p->batch) : t.grid_each((int)p->batch, mult), dim3(NT), sizeof(Smem), st,
+    // (behind the probe of interpol_pull_backward's router -- gate_n < 0 -- the kernel usually returns at once: two workgroups per CU
+    //  instead of 8192 that are dispatched for nothing, 50 us)
+    hipLaunchKernelGGL((gradc_sorted<T, K, GM>), (mopt == 7 || (k.gate && k.gate_n < 0)) ? t.grid((int)p->batch) : t.grid_each((int)p->batch, mult), dim3(NT), sizeof(Smem), st,
                        k, (const T *)vol, (const T *)gout, (const float *)grid, (float *)ggrid, t.gx, t.gy, t.gz, t.nty, t.ntz, t.ntiles(), (int)p->batch, df.args);
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) return (int)e;
