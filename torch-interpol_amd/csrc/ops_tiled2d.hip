@@ -327,8 +327,11 @@ __global__ __launch_bounds__(NT, 3) void pull2d(KParams p, const T *__restrict__
         tl.build(p, L, c, gy, gz, oy0, oz0, sm);
     }
     if (defer.flag) {                                    // (block-uniform) too rough for the box: the generic kernel takes the tile, defer.hip
-        bool hand_back = sm.nout > ((NS / 64) << ((p.dbg >> 9) & 7));                  // (a wave pays the per-thread fallback of its slowest lane)
-        if (hand_back) hand_back = tiled::tile_smooth(p, grid, b, 2, 0, oy0, oz0, 1, TY, TZ, 1, gy, gz, sm.hi);
+        // (a wave pays the per-thread fallback of its slowest lane: a tile with n pixels outside costs about 1 + n / 2 tiles, the generic
+        //  kernel 3.3 -- measured at config 5's shape, sigma = 6 and 8)
+        bool hand_back = sm.nout > ((NS / 256) << ((p.dbg >> 9) & 7));
+        // (smooth or rough: unlike in 3-D the generic gather -- 16 taps per pixel -- beats the tile's per-thread fallbacks whatever the
+        //  field; 16 pixels outside the box hit most of the tile's waves: 32 x 3 x 1024^2 bf16, sigma = 8: 5.1 -> 2.0 ms, 16: 7.0 -> 3.0)
         if (hand_back && threadIdx.x == 0) defer_mark(defer, (int)blockIdx.x, tile_desc(b, 0, oy0 / TY, oz0 / TZ));
         if (hand_back && defer.desc) return;
     }
