@@ -506,8 +506,9 @@ __global__ __launch_bounds__(NT, 3) void gradc2d(KParams p, const T *__restrict_
         tl.build(p, L, c, gy, gz, oy0, oz0, sm);
     }
     if (defer.flag) {                                    // (block-uniform) too rough for the box: the generic kernel takes the tile, defer.hip
-        bool hand_back = sm.nout > ((NS / 64) << ((p.dbg >> 9) & 7));                  // (a wave pays the per-thread fallback of its slowest lane)
-        if (hand_back) hand_back = tiled::tile_smooth(p, grid, b, 2, 0, oy0, oz0, 1, TY, TZ, 1, gy, gz, sm.hi);
+        // (as pull2d: more than four pixels outside the box, smooth or rough -- the generic fused kernel serves such a tile faster than
+        //  the per-thread fallbacks: config 5's shape, sigma = 8: grid gradient 7.6 ms against 2.3 generic)
+        const bool hand_back = sm.nout > ((NS / 256) << ((p.dbg >> 9) & 7));
         if (hand_back && threadIdx.x == 0) defer_mark(defer, (int)blockIdx.x, tile_desc(b, 0, oy0 / TY, oz0 / TZ));
         if (hand_back && defer.desc) return;
     }
