@@ -286,8 +286,8 @@ struct GatSmem {
     int   taboff[3][BOX + 3];
     float tabsgn[3][BOX + 3];
     unsigned start[CAPD];
-    int   rcnt[CAPD];
-    int   brick, pad[3];
+    int   pref[CAPD + 2];                      // records in front of each run of the brick; [nd ...]: all of them
+    int   brick, pad;
     float2 box[BOX * PLANE + 64];              // 21 x 21 x 20 pair slots = 70 560 B (+ the quartic stencil's unused sixth row / plane)
 };
 static_assert(sizeof(GatSmem) <= 80 * 1024, "two workgroups per CU");
@@ -329,7 +329,19 @@ __global__ __launch_bounds__(NT, 4) void gather5(KParams p, Grid5 bg, const int 
         const int by = r % bg.nb[1], bx = r / bg.nb[1];
         const int b0[3] = { bx * BR - OFFB, by * BR - OFFB, bz * BR - OFFB };       // lattice index of box slot 0
         const int nd = min(ndesc[bk], CAPD);
-        if (tid < nd) { const uint2 d = desc[(int64_t)bk * CAPD + tid]; sm.start[tid] = d.x; sm.rcnt[tid] = (int)d.y; }
+        if (tid < 64) {
+            // the runs of the brick and the exclusive prefix of their lengths: the threads walk the brick's records as ONE list
+            static_assert(CAPD == 128, "two runs per lane");
+            const int e0 = 2 * tid, e1 = e0 + 1;
+            const uint2 d0 = e0 < nd ? desc[(int64_t)bk * CAPD + e0] : make_uint2(0u, 0u), d1 = e1 < nd ? desc[(int64_t)bk * CAPD + e1] : make_uint2(0u, 0u);
+            const int sum = (int)d0.y + (int)d1.y;
+            int incl = sum;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o); if (tid >= o) incl += t; }
+            sm.start[e0] = d0.x; sm.start[e1] = d1.x;
+            sm.pref[e0] = incl - sum; sm.pref[e1] = incl - (int)d1.y;
+            if (tid == 63) { sm.pref[CAPD] = incl; sm.pref[CAPD + 1] = 0x7fffffff; }
+        }
         if (tid >= 128 && tid < 128 + 3 * 64) {                      // box slot -> wrapped lattice offset and sign (bounds.py:30-89)
             const int d = (tid - 128) >> 6, slot = tid & 63;
             if (slot < BOX) {
@@ -367,12 +379,12 @@ __global__ __launch_bounds__(NT, 4) void gather5(KParams p, Grid5 bg, const int 
                 }
             }
             __syncthreads();
-            const int wave = tid >> 6, lane = tid & 63;
-            for (int run = wave; run < nd; run += NT / 64) {
-                const int n = sm.rcnt[run];
-                const unsigned first = sm.start[run];
-                for (int i = lane; i < n; i += 64) {
-                    const float4 rc = rec[first + i];
+            const int ntot = sm.pref[CAPD];
+            int rr = 0;
+            for (int j = tid; j < ntot; j += NT) {
+                {
+                    while (j >= sm.pref[rr + 1]) ++rr;               // (runs beyond the last hold nothing: their prefix is the total)
+                    const float4 rc = rec[sm.start[rr] + (unsigned)(j - sm.pref[rr])];
                     const float fx = floorf(rc.x - 0.5f * (float)(K - 1)), fy = floorf(rc.y - 0.5f * (float)(K - 1)), fz = floorf(rc.z - 0.5f * (float)(K - 1));
                     const float tx = rc.x - fx, ty = rc.y - fy, tz = rc.z - fz;
                     // first-tap cell inside the brick: 0 .. 15 by construction of the bins; clamped, should a coordinate be off

@@ -1090,7 +1090,7 @@ struct GatSmem {
     int   taboff[3][BOX + 1];
     float tabsgn[3][BOX + 1];
     unsigned start[CAPD];
-    int   rcnt[CAPD];
+    int   pref[CAPD + 2];                      // records in front of each run of the brick; [nd ...]: all of them
     int   brick, pad;
     float2 box[BOX * GPLANE];                  // 57 760 B
 };
@@ -1137,7 +1137,20 @@ __global__ __launch_bounds__(NT, 4) void own_gather(KParams p, BrickGrid bg, con
         const int b0[3] = { brick_origin(bx, bg.lo[0], bg.top[0], bg.nin[0], bg.split[0]), brick_origin(by, bg.lo[1], bg.top[1], bg.nin[1], bg.split[1]),
                             brick_origin(bz, bg.lo[2], bg.top[2], bg.nin[2], bg.split[2]) };      // lattice index of box slot 0
         const int nd = min(ndesc[bk], CAPD);
-        if (tid < nd) { const uint2 d = desc[(int64_t)bk * CAPD + tid]; sm.start[tid] = d.x; sm.rcnt[tid] = (int)d.y; }
+        if (tid >= 256 && tid < 320) {
+            // the runs of the brick and the exclusive prefix of their lengths: the threads walk the brick's records as ONE list (a run
+            // holds ~150 records at sigma = 2, ~30 at sigma = 6: a wave per run left half of its lanes idle)
+            static_assert(CAPD == 128, "two runs per lane");
+            const int ln = tid - 256, e0 = 2 * ln, e1 = e0 + 1;
+            const uint2 d0 = e0 < nd ? desc[(int64_t)bk * CAPD + e0] : make_uint2(0u, 0u), d1 = e1 < nd ? desc[(int64_t)bk * CAPD + e1] : make_uint2(0u, 0u);
+            const int sum = (int)d0.y + (int)d1.y;
+            int incl = sum;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o); if (ln >= o) incl += t; }
+            sm.start[e0] = d0.x; sm.start[e1] = d1.x;
+            sm.pref[e0] = incl - sum; sm.pref[e1] = incl - (int)d1.y;
+            if (ln == 63) { sm.pref[CAPD] = incl; sm.pref[CAPD + 1] = 0x7fffffff; }
+        }
         if (tid < 3 * 64) {                                          // box slot -> wrapped lattice offset and sign (bounds.py:30-89)
             const int d = tid >> 6, slot = tid & 63;
             if (slot < BOX) {
@@ -1184,12 +1197,12 @@ __global__ __launch_bounds__(NT, 4) void own_gather(KParams p, BrickGrid bg, con
             }
             __syncthreads();
             const unsigned boxaddr = (unsigned)(size_t)(__attribute__((address_space(3))) void *)(sm.box);
-            const int wave = tid >> 6, lane = tid & 63;
-            for (int run = wave; run < nd; run += NT / 64) {
-                const int n = sm.rcnt[run];
-                const unsigned first = sm.start[run];
-                for (int i = lane; i < n; i += 64) {
-                    const float4 rc = rec[first + i];
+            const int ntot = sm.pref[CAPD];
+            int rr = 0;
+            for (int j = tid; j < ntot; j += NT) {
+                {
+                    while (j >= sm.pref[rr + 1]) ++rr;               // (runs beyond the last hold nothing: their prefix is the total)
+                    const float4 rc = rec[sm.start[rr] + (unsigned)(j - sm.pref[rr])];
                     const float fx = floorf(rc.x - 0.5f * (float)(K - 1)), fy = floorf(rc.y - 0.5f * (float)(K - 1)), fz = floorf(rc.z - 0.5f * (float)(K - 1));
                     const float tx = rc.x - fx; const f2 tyz = f2{ rc.y - fy, rc.z - fz };
                     // first-tap cell inside the brick: 0 .. 15 by construction of the bins (own_bin); clamped, should a coordinate be off
