@@ -1614,6 +1614,14 @@ def test_orders_4_and_5_through_bricks_of_the_image_against_oracle(sigma):
                         assert float(np.abs(got - slow).max()) <= 8e-6 * float(np.abs(slow).max()), (op, name, "vs generic", sigma, b, order, ex)
                         bad = np.abs(got - want) > 1e-5 * np.abs(want) + 2e-5 * float(np.abs(want).max())
                         assert bad.sum() <= 9 * C, (op, name, sigma, b, order, ex, int(bad.sum()))
+                # the backward of the pull: grid gradient through the same bricks (gather5 mode 1), alone and next to the image gradient
+                gout = torch.randn([2, C, *oshape], generator=g)
+                slow = _hip.pull_backward(gout.to(DEV), inp.to(DEV), grid.to(DEV), b, [order] * 3, ex, True, True, flags=_hip.FLAG_NO_FASTPATH)
+                for need_vol in (False, True):
+                    got = _hip.pull_backward(gout.to(DEV), inp.to(DEV), grid.to(DEV), b, [order] * 3, ex, need_vol, True)
+                    _same(got[1], slow[1], 1e-5, ("grid gradient of the pull, bricks", sigma, b, order, ex, need_vol))
+                    if need_vol:
+                        _same(got[0], slow[0], 1e-5, ("image gradient next to it", sigma, b, order, ex))
         inp = torch.randn([2, 3, 25, 47, 58], generator=g).to(DEV)
         grid = ((interpol.identity_grid((43, 25, 19)) - 10.0) * 9.0)[None].expand(2, 43, 25, 19, 3).contiguous().to(DEV)
         for order, b in ((5, [6, 5, 6]), (4, [3, 1, 2])):

@@ -63,7 +63,7 @@ int owner_pull_finish(const interpol_problem *, const KParams &, const void *, c
                       bool grad = false, const void *gout = nullptr, bool probed = false, bool spatial = false);
 int owner_grad_probe(const interpol_problem *, const KParams &, const void *, void *, int64_t, hipStream_t);
 int64_t gather5_workspace_bytes(const interpol_problem *, const KParams &);
-int try_gather5(const interpol_problem *, const KParams &, const void *, const void *, void *, void *, int64_t, bool, hipStream_t, const int **);
+int try_gather5(const interpol_problem *, const KParams &, const void *, const void *, void *, void *, int64_t, int, const void *, hipStream_t, const int **);
 int try_pull_direct(const interpol_problem *, const KParams &, const void *, const void *, void *, int *, int, hipStream_t);
 int try_sorted_pull_f32(const interpol_problem *, const KParams &, const void *, const void *, void *, hipStream_t);
 int try_sorted_gradc_f32(const interpol_problem *, const KParams &, const void *, const void *, const void *, void *, hipStream_t);
@@ -318,7 +318,7 @@ static int routed_pull(const interpol_problem *p, KParams k, int B, const void *
     if (k.order[0] >= 4) {
         // orders 4 and 5 (gather5.hip): the bricks always, or behind a probe of the call next to the tiles, which read the same verdict
         const int *gate = nullptr;
-        int r5 = try_gather5(p, k, vol, grid, val, workspace, workspace_bytes, false, st, &gate);
+        int r5 = try_gather5(p, k, vol, grid, val, workspace, workspace_bytes, 0, nullptr, st, &gate);
         if (r5 != 2) return r5;
         k.gate = gate; k.gate_n = -1;
         r5 = try_fast_pull(p, k, vol, grid, val, st);
@@ -415,7 +415,7 @@ int interpol_grad_ws(const interpol_problem *p, const void *vol, const void *gri
     int nzero = 0;
     if (!(p->flags & INTERPOL_FLAG_NO_FASTPATH) && k.order[0] >= 4) {
         const int *gate = nullptr;
-        rc = try_gather5(p, k, vol, grid, val, workspace, workspace_bytes, true, st, &gate);
+        rc = try_gather5(p, k, vol, grid, val, workspace, workspace_bytes, 2, nullptr, st, &gate);
         if (rc == 1) return 0;
         if (rc != 0 && rc != 2) return rc;
         if (rc == 2) {
@@ -600,6 +600,10 @@ static int routed_gradc(const interpol_problem *p, const KParams &k, const void 
 {
     int *flags = nullptr;
     int nzero = 0;
+    if (k.order[0] >= 4) {                                           // orders 4 and 5: gather5.hip, the bricks always (1), or declined (0)
+        const int r5 = try_gather5(p, k, vol, grid, ggrid, scratch, scratch_bytes, 1, gout, st, nullptr);
+        return r5 == 2 ? INTERPOL_E_SHAPE : r5;
+    }
     const int r = owner_pull_prepare(p, k, scratch, scratch_bytes, st, &flags, &nzero);
     if (r != 1) return r;
     int rc;

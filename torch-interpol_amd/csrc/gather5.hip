@@ -64,10 +64,11 @@ __global__ void zero5(int *p, int n)
     if (i < n) p[i] = 0;
 }
 
-// MODE 0: pull, val[b,c,o]; MODE 2: grid_grad, val[b,c,o,:]
+// MODE 0: pull, val[b,c,o]; MODE 2: grid_grad, val[b,c,o,:]; MODE 1: the grid gradient of the pull's backward (pushpull.py:256-257),
+// out[b,o,:] = mask * sum_c gout[b,c,o] * grad pull(img[b,c])(x_o) (gout == NULL: ones; p.val_* describe gout)
 template <int K, int GM, int MODE>
 __device__ __forceinline__ void direct5(const KParams &p, const float *__restrict__ img, const float *__restrict__ grid, float *__restrict__ out,
-                                        int64_t b, TileGeom g, int tid, unsigned mask)
+                                        int64_t b, TileGeom g, int tid, unsigned mask, const float *__restrict__ gout)
 {
     Lattice L;
 #pragma unroll
@@ -84,6 +85,19 @@ __device__ __forceinline__ void direct5(const KParams &p, const float *__restric
         int ii[3]; float tt[3];
 #pragma unroll
         for (int d = 0; d < 3; ++d) split(K, x[d], ii[d], tt[d]);
+        if (MODE == 1) {
+            float a[3] = { 0.f, 0.f, 0.f };
+#pragma unroll 1
+            for (int ch = 0; ch < p.C; ++ch) {
+                const float gv = gout ? gout[b * p.val_sb + ch * p.val_sc + o] : 1.f;
+#pragma unroll 1
+                for (int d = 0; d < 3; ++d)
+                    a[d] = __builtin_fmaf(gv, tiled::gather_one_thread<float>(L, img + b * p.vol_sb + ch * p.vol_sc, ii[0], ii[1], ii[2], tt[0], tt[1], tt[2], d), a[d]);
+            }
+            float *dst = out + (b * p.N + o) * 3;
+            dst[0] = a[0] * m; dst[1] = a[1] * m; dst[2] = a[2] * m;
+            continue;
+        }
 #pragma unroll 1
         for (int ch = 0; ch < p.C; ++ch) {
             const float *ic = img + b * p.vol_sb + ch * p.vol_sc;
@@ -103,7 +117,8 @@ struct BinSmem { int lo[3], pad; int cnt[NBIN], base[NBIN]; };
 template <int K, int GM, int MODE>
 __global__ __launch_bounds__(NT1, 4) void bin5(KParams p, Grid5 bg, const float *__restrict__ img, const float *__restrict__ grid, float *__restrict__ out,
                                                int *__restrict__ ndesc, int *__restrict__ list, uint2 *__restrict__ desc, float4 *__restrict__ rec,
-                                               int gx, int gy, int gz, int nty, int ntz, int ntiles, const int *__restrict__ gate)
+                                               int gx, int gy, int gz, int nty, int ntz, int ntiles, const int *__restrict__ gate,
+                                               const float *__restrict__ gout)
 {
     if (gate && *gate != 1) return;                                  // INTERPOL_FLAG_AUTO_SCATTER: the probe chose the tiles
     __shared__ BinSmem sm;
@@ -202,40 +217,48 @@ __global__ __launch_bounds__(NT1, 4) void bin5(KParams p, Grid5 bg, const float 
         if (sm.cnt[e] < 0) { direct |= 1u << v; continue; }
         rec[tilebase + sm.base[e] + (lbin[v] >> 8)] = make_float4(c[v][0], c[v][1], c[v][2], __int_as_float(idx[v]));
     }
-    if (direct) direct5<K, GM, MODE>(p, img, grid, out, b, g, tid, direct);
+    if (direct) direct5<K, GM, MODE>(p, img, grid, out, b, g, tid, direct, gout);
 }
 
 // INTERPOL_FLAG_AUTO_SCATTER: NPROBE tiles of the sample grid are examined the way the LDS tiles of ops_tiled.hip would cut them --
 // the box of a 16^3-sample tile of orders 4 / 5 holds 33 x 33 x 32 lattice points, centred on the tile's stencils; a sample whose
-// stencil leaves it costs a WAVE there (64 times a sample inside).  hdr[0] = 1 (the bricks) when more than 1 / 300 of the probed
-// samples do: i.i.d. noise of sigma ~ 2.3 voxels, where the two organisations cross (config 3's shape: sigma = 2 0.06 % outside,
-// tiles 2.6 ms against 2.8; sigma = 2.5 0.4 %, 3.0 against 2.8; sigma = 3 1.4 %, 4.0 against 2.75).  hdr[1..3]: counters.
+// stencil leaves it costs a WAVE there (64 times a sample inside).  Used for the order-4 pull only (try_gather5): hdr[0] = 1 (the
+// bricks) when more than 1 / 300 of the probed samples do, or when the field is ROUGH (8 x 1 x 192^3, i.i.d. noise: sigma = 1 1.54
+// against 1.78 ms, sigma = 2 1.61 / 2.02); smooth fields stay with the tiles (identity 1.19 / 1.27, zoom 1.2 1.23 / 1.51).
+// hdr[1..5]: counters.
 constexpr int NPROBE = 128;
 template <int K, int GM>
 __global__ __launch_bounds__(NT1) void probe5(KParams p, const float *__restrict__ grid, int *__restrict__ hdr, int gx, int gy, int gz, int nty, int ntz,
                                               int ntiles, int nbatch)
 {
-    __shared__ int lo[3], hi[3], cnt[2];
+    __shared__ int lo[3], hi[3], cnt[4];
     const int tid = threadIdx.x;
     const int64_t total = (int64_t)ntiles * nbatch;
     const int64_t work = (int64_t)blockIdx.x * total / gridDim.x;
     const int64_t b = work / ntiles;
     const TileGeom g = tile_geom((int)(work % ntiles), gx, gy, gz, nty, ntz);
     if (tid < 3) { lo[tid] = 0x7fffffff; hi[tid] = -0x7fffffff; }
-    if (tid < 2) cnt[tid] = 0;
+    if (tid < 4) cnt[tid] = 0;
     float fl[VPT1][3];
     unsigned valid = 0;
+    float rough = 0.f;                                               // sum over the thread's samples and the dims of |second difference along z|
+    int nrough = 0;
 #pragma unroll
     for (int v = 0; v < VPT1; ++v) {
         int ox, oy, oz; float c[3];
         sample_pos(g, tid + NT1 * v, ox, oy, oz);
         if (ox < gx && oy < gy && oz < gz) valid |= 1u << v;
         load_xyz<GM>(p, grid, b, g, ox < gx ? ox : gx - 1, oy < gy ? oy : gy - 1, oz < gz ? oz : gz - 1, c);
+        // (a row of 16 z-neighbours lies in 16 consecutive lanes: sample id = tid + 512 v)
+        const bool mid = (tid & 15) >= 1 && (tid & 15) <= 14 && oz + 1 < gz && ox < gx && oy < gy;
 #pragma unroll
         for (int d = 0; d < 3; ++d) {
             const float f = floorf(c[d] - 0.5f * (float)(K - 1));
             fl[v][d] = f == f ? __builtin_fmaxf(__builtin_fminf(f, 1073741824.f), -1073741824.f) : 0.f;
+            const float d2 = __shfl_up(c[d], 1) - 2.f * c[d] + __shfl_down(c[d], 1);
+            if (mid && d2 == d2) rough += __builtin_fminf(__builtin_fabsf(d2), 64.f);
         }
+        if (mid) ++nrough;
     }
     __syncthreads();
     int mn[3] = { 0x7fffffff, 0x7fffffff, 0x7fffffff }, mx[3] = { -0x7fffffff, -0x7fffffff, -0x7fffffff };
@@ -270,14 +293,18 @@ __global__ __launch_bounds__(NT1) void probe5(KParams p, const float *__restrict
         if (!in) ++slow;
     }
     slow = wave_sum(slow); nv = wave_sum(nv);
-    if ((tid & 63) == 0) { atomicAdd(&cnt[0], slow); atomicAdd(&cnt[1], nv); }
+    const int r256 = wave_sum((int)(rough * 16.f)), nr = wave_sum(nrough);
+    if ((tid & 63) == 0) { atomicAdd(&cnt[0], slow); atomicAdd(&cnt[1], nv); atomicAdd(&cnt[2], r256); atomicAdd(&cnt[3], nr); }
     __syncthreads();
     if (tid == 0) {
-        atomicAdd(&hdr[1], cnt[0]); atomicAdd(&hdr[2], cnt[1]);
+        atomicAdd(&hdr[1], cnt[0]); atomicAdd(&hdr[2], cnt[1]); atomicAdd(&hdr[4], cnt[2] >> 4); atomicAdd(&hdr[5], cnt[3]);
         __threadfence();
         if (atomicAdd(&hdr[3], 1) == (int)gridDim.x - 1) {
             const int ns = atomicAdd(&hdr[1], 0), nn = atomicAdd(&hdr[2], 0);
-            hdr[0] = (int64_t)ns * 300 > nn ? 1 : 0;
+            // rough: the mean |second difference| of the coordinates along z, summed over the dims, exceeds two voxels (i.i.d. noise of
+            // sigma voxels: ~ 6 sigma -- sigma = 0.25: tiles 1.23 against 1.32 ms, sigma = 1: 1.78 / 1.54; registration fields, zooms, the identity: ~ 0)
+            const int r2 = atomicAdd(&hdr[4], 0), n2 = atomicAdd(&hdr[5], 0);
+            hdr[0] = ((int64_t)ns * 300 > nn || (int64_t)r2 > 2 * (int64_t)n2) ? 1 : 0;
         }
     }
 }
@@ -310,7 +337,8 @@ __device__ __forceinline__ void plane_reads(unsigned addr, f2 (&v)[18])
 template <int K, int MODE>
 __global__ __launch_bounds__(NT, 4) void gather5(KParams p, Grid5 bg, const int *__restrict__ ndesc, const uint2 *__restrict__ desc,
                                                  const float4 *__restrict__ rec, const int *__restrict__ list, int *__restrict__ draw,
-                                                 const float *__restrict__ img, float *__restrict__ out, const int *__restrict__ gate)
+                                                 const float *__restrict__ img, float *__restrict__ out, const int *__restrict__ gate,
+                                                 const float *__restrict__ gout)
 {
     if (gate && *gate != 1) return;                                  // INTERPOL_FLAG_AUTO_SCATTER: the probe chose the tiles
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -442,8 +470,17 @@ __global__ __launch_bounds__(NT, 4) void gather5(KParams p, Grid5 bg, const int 
                             a2 = __builtin_fmaf(wxi, plz, a2);
                             asm volatile("" : "+v"(a0), "+v"(a1), "+v"(a2));
                         }
-                        float *dst = oc + 3 * o;
-                        dst[0] = a0 * m; dst[1] = a1 * m; dst[2] = a2 * m;
+                        if (MODE == 1) {
+                            // contracted with grad_out; written by the first channel, accumulated by the following ones (the same thread
+                            // meets the sample in every channel)
+                            const float gm = (gout ? gout[b * p.val_sb + (int64_t)c * p.val_sc + o] : 1.f) * m;
+                            float *dst = out + (b * p.N + o) * 3;
+                            if (c == 0) { dst[0] = a0 * gm; dst[1] = a1 * gm; dst[2] = a2 * gm; }
+                            else { dst[0] += a0 * gm; dst[1] += a1 * gm; dst[2] += a2 * gm; }
+                        } else {
+                            float *dst = oc + 3 * o;
+                            dst[0] = a0 * m; dst[1] = a1 * m; dst[2] = a2 * m;
+                        }
                     }
                 }
             }
@@ -482,9 +519,11 @@ int64_t gather5_workspace_bytes(const interpol_problem *p, const KParams &k)
 // grid_pull (grad == false) / grid_grad through the bricks: 1 = done, 0 = declined, else an error
 // INTERPOL_FLAG_AUTO_SCATTER: 2 = launched behind the probe's verdict -- the caller launches the tile / generic kernels as well, with
 // KParams::gate = *gate_out and gate_n = -1 (they return at once when the verdict is 1).
+// mode 0: grid_pull, 2: grid_grad, 1: the grid gradient of the pull's backward (val := the dense (B, *out, 3) gradient, gout := grad_out)
 int try_gather5(const interpol_problem *p, const KParams &k, const void *vol, const void *grid, void *val, void *workspace, int64_t workspace_bytes,
-                bool grad, hipStream_t st, const int **gate_out)
+                int mode, const void *gout, hipStream_t st, const int **gate_out)
 {
+    const bool grad = mode != 0;
     using namespace g5;
     if (!workspace || ((uintptr_t)workspace & 255u) != 0 || !eligible(p, k)) return 0;
     const int gx = (int)p->grid_shape[0], gy = (int)p->grid_shape[1], gz = (int)p->grid_shape[2];
@@ -495,7 +534,11 @@ int try_gather5(const interpol_problem *p, const KParams &k, const void *vol, co
     const int64_t nz = 64 + 2 * w.nbricks + 1;
     if (nz > 0x7fffffffll) return 0;
     hipLaunchKernelGGL(zero5, dim3((unsigned)((nz + 1023) / 1024)), dim3(1024), 0, st, w.hdr, (int)nz);
-    const bool gated = !(p->flags & INTERPOL_FLAG_BINNED_SCATTER);
+    // order 5: the bricks beat the LDS tiles on every field measured (8 x 1 x 192^3: identity 1.37 against 1.59 ms, sigma = 2 1.77 / 2.58,
+    // zoom 2 3.5 / 9.3; grad 1.70 / 2.02, 1.95 / 2.89 -- a tie at zoom 1.5): no probe, no tiles.  Order 4: the tiles keep smooth fields
+    // (identity 1.19 against 1.27 ms, zoom 1.2 1.23 / 1.51), the probe gives rough ones to the bricks.
+    // grid_grad of order 4: the bricks as well (identity 1.50 against 1.54, sigma = 2 1.72 / 2.31).
+    const bool gated = !(p->flags & INTERPOL_FLAG_BINNED_SCATTER) && k.order[0] == 4 && !grad;
     const int *gate = gated ? w.hdr : nullptr;
     if (gated) {
         const long long total = (long long)ntiles * p->batch;
@@ -512,15 +555,15 @@ int try_gather5(const interpol_problem *p, const KParams &k, const void *vol, co
 #define IP_G5(KK, GM, MD)                                                                                               \
     {                                                                                                                   \
         hipLaunchKernelGGL((bin5<KK, GM, MD>), tgrid, dim3(NT1), 0, st, k, bg, (const float *)vol, (const float *)grid, (float *)val, \
-                           w.ndesc, w.list, w.desc, w.rec, gx, gy, gz, nty, ntz, ntiles, gate);                         \
+                           w.ndesc, w.list, w.desc, w.rec, gx, gy, gz, nty, ntz, ntiles, gate, (const float *)gout);   \
         const int attr = big_lds<gather5<KK, MD>>(sizeof(GatSmem));                                                     \
         if (attr) return attr;                                                                                          \
         hipLaunchKernelGGL((gather5<KK, MD>), ggrid, dim3(NT), sizeof(GatSmem), st, k, bg, (const int *)w.ndesc, (const uint2 *)w.desc, \
-                           (const float4 *)w.rec, (const int *)w.list, w.hdr + 40, (const float *)vol, (float *)val, gate); \
+                           (const float4 *)w.rec, (const int *)w.list, w.hdr + 40, (const float *)vol, (float *)val, gate, (const float *)gout); \
     }
 #define IP_G5_GM(KK, MD) { if (k.sep == 0) IP_G5(KK, 0, MD) else if (k.sep == 1) IP_G5(KK, 1, MD) else if (k.sep == 2) IP_G5(KK, 2, MD) else IP_G5(KK, 3, MD) }
-    if (k.order[0] == 5) { if (grad) IP_G5_GM(5, 2) else IP_G5_GM(5, 0) }
-    else { if (grad) IP_G5_GM(4, 2) else IP_G5_GM(4, 0) }
+    if (k.order[0] == 5) { if (mode == 2) IP_G5_GM(5, 2) else if (mode == 1) IP_G5_GM(5, 1) else IP_G5_GM(5, 0) }
+    else { if (mode == 2) IP_G5_GM(4, 2) else if (mode == 1) IP_G5_GM(4, 1) else IP_G5_GM(4, 0) }
 #undef IP_G5_GM
 #undef IP_G5
     const hipError_t e = hipGetLastError();
