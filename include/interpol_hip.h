@@ -191,9 +191,10 @@ int interpol_pull(const interpol_problem *p, const void *vol, const void *grid, 
  * interpol_pull_workspace(p) returns the bytes `workspace` must have (18 B per sample + 2 KiB per brick + 4 B per tile; 0: the
  * organisation does not apply); with a smaller, missing or not 256-byte aligned workspace the call is interpol_pull.  The
  * workspace need not be cleared.  Same results within float32 rounding (sums in a different order). */
-/* Orders 4 and 5 (3-D, float32; round 4, gather5.hip): the same two entry points and interpol_grad_ws serve them through bricks of
- * the image of their own (16 B per sample + 1 KiB per brick of workspace); AUTO: a probe of the call chooses between them and the
- * LDS tiles (8 x 1 x 192^3 order 5: sigma = 6 43 -> 2.5 ms, grad 124 -> 3.1 ms; smooth fields stay with the tiles, +1 %). */
+/* Orders 4 and 5 (3-D, float32; round 4, gather5.hip): the same two entry points, interpol_grad_ws and the grid gradient of
+ * interpol_pull_backward serve them through bricks of the image of their own (16 B per sample + 1 KiB per brick of workspace).
+ * AUTO: order 5 always (8 x 1 x 192^3, sigma = 2: pull 2.57 -> 1.77 ms, grad 2.89 -> 1.96; sigma = 6: 43 -> 1.9 ms), order 4 for
+ * grid_grad and the grid gradient, its pull behind a probe of the call (smooth fields stay with the LDS tiles). */
 int64_t interpol_pull_workspace(const interpol_problem *p);
 int interpol_pull_ws(const interpol_problem *p, const void *vol, const void *grid, void *val, void *workspace, int64_t workspace_bytes, void *stream);
 /* grid_grad (interpol_grad) with the same workspace (interpol_pull_workspace(p) bytes; for the grad problem the same number as for
