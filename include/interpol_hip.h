@@ -338,6 +338,9 @@ int32_t interpol_set_handback(int32_t mode);
 int32_t interpol_release_stream(void *stream);
 
 int32_t     interpol_abi_version(void);
+/* 1 for a library built with the measured-slower experimental organisations (torch-interpol_amd/experiments/, `make
+ * experiments`: INTERPOL_FLAG_SMALL_TILES and debug bit 4096 select them); 0 for the product library, which ignores both. */
+int32_t     interpol_has_experiments(void);
 const char *interpol_error_string(int code);
 /* name of the kernel family the dispatcher would pick for `p` and op
  * ("pull","push","count","grad","pushgrad","hess"); for tests and profiling. */

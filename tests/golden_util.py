@@ -76,6 +76,28 @@ def assert_close(got, want, rtol, atol_rel, what=""):
         what, int(bad.sum()), bad.size, float(np.abs(got - want).max()), float(np.abs(want).max()))
 
 
+
+def f32_masked_samples(grid, shape, extrapolate):
+    """Samples that the reference masks when it runs in float32 and a float64 evaluation of the SAME float32 coordinates does
+    not (nd.py:10-27): the Python scalar threshold (-thr, n - 1 + thr; thr = 0.05 / 0.55) is cast to the tensor's
+    dtype for the comparison, so a float32 coordinate EQUAL to the float32-rounded threshold is outside in float32 and -- where
+    the rounding went towards the inside -- still inside in float64.  Returns a bool array (B, *out): expected outputs of
+    gathers at those samples are zeros (the mask multiplies the result).  The opposite disagreement cannot occur (no float32
+    lies strictly between a double and its nearest float32); asserted."""
+    g32 = np.asarray(grid, dtype=np.float32)
+    out = np.zeros(g32.shape[:-1], dtype=bool)
+    if extrapolate == 1:
+        return out
+    thr = 0.05 if extrapolate == 0 else 0.55
+    m32 = np.ones(g32.shape[:-1], dtype=bool)
+    m64 = np.ones(g32.shape[:-1], dtype=bool)
+    for d, n in enumerate(shape):
+        x32, x64 = g32[..., d], g32[..., d].astype(np.float64)
+        m32 &= (x32 > np.float32(-thr)) & (x32 < np.float32(n - 1 + thr))
+        m64 &= (x64 > -thr) & (x64 < n - 1 + thr)
+    assert not (m32 & ~m64).any()
+    return m64 & ~m32
+
 def run_case(ops, case, dtype):
     """Run one manifest case through an operator table `ops` exposing the
     pushpull-style functions grid_pull/grid_push/... on numpy arrays."""

@@ -86,7 +86,7 @@ def test_cfg3_full_size_grad_and_backward():
     kw = dict(interpolation=5, bound="dft", extrapolate=True)
     # the gradient of a constant image vanishes (derivative weights sum to zero)
     gc = interpol.grid_grad(torch.full_like(inp, 3.0), grid, **kw)
-    assert float(gc.abs().max()) < 5e-5
+    assert float(gc.abs().max()) < 1e-5 * 3.0                                # (1e-5 of the image's amplitude)
     # backward of pull w.r.t. the image is its adjoint; w.r.t. the grid it is sum_c gout * grid_grad
     x = inp.clone().requires_grad_(True)
     gr = grid.clone().requires_grad_(True)
@@ -97,7 +97,7 @@ def test_cfg3_full_size_grad_and_backward():
     assert abs(lhs - rhs) <= 1e-5 * float(out.detach().double().norm()) * float(gout.double().norm())
     gg = interpol.grid_grad(inp, grid, **kw)                                   # (B, C, *out, 3)
     want = (gg * gout.unsqueeze(-1)).sum(1)
-    assert _rel(gr.grad, want) < 2e-5
+    assert _rel(gr.grad, want) < 1e-5
 
 
 def test_cfg4_full_size_shared_target_mass():

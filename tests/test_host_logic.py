@@ -235,7 +235,7 @@ def test_resize_restrict_golden_host_logic():
             assert G.rel_err(got64.numpy(), c["out64"]) < 1e-10, (c["fn"], c["kwargs"])
             got32 = fn(torch.from_numpy(c["inp"]), **c["kwargs"])
             assert got32.dtype == torch.float32
-            G.assert_close(got32.numpy(), c["out32"], rtol=2e-5, atol_rel=2e-5, what=str((c["fn"], c["kwargs"])))
+            G.assert_close(got32.numpy(), c["out32"], rtol=1e-5, atol_rel=1e-5, what=str((c["fn"], c["kwargs"])))
 
 
 def test_separable_grid_equals_dense_grid_host_logic():

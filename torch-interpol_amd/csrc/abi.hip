@@ -64,7 +64,9 @@ int owner_pull_finish(const interpol_problem *, const KParams &, const void *, c
 int owner_grad_probe(const interpol_problem *, const KParams &, const void *, void *, int64_t, hipStream_t);
 int64_t gather5_workspace_bytes(const interpol_problem *, const KParams &);
 int try_gather5(const interpol_problem *, const KParams &, const void *, const void *, void *, void *, int64_t, int, const void *, hipStream_t, const int **);
+#ifdef IP_EXPERIMENTS
 int try_pull_direct(const interpol_problem *, const KParams &, const void *, const void *, void *, int *, int, hipStream_t);
+#endif
 int try_sorted_pull_f32(const interpol_problem *, const KParams &, const void *, const void *, void *, hipStream_t);
 int try_sorted_gradc_f32(const interpol_problem *, const KParams &, const void *, const void *, const void *, void *, hipStream_t);
 int64_t owner_pull_workspace_bytes(const interpol_problem *, const KParams &);
@@ -331,6 +333,7 @@ static int routed_pull(const interpol_problem *p, KParams k, int B, const void *
     if (p->flags & INTERPOL_FLAG_BINNED_SCATTER) { rc = owner_pull_finish(p, k, vol, grid, val, workspace, workspace_bytes, true, st); return rc ? rc : 1; }
     // the sample tiles first: pull_sorted flags the tiles it leaves to the bricks (too many samples outside its LDS box)
     k.gate = flags; k.gate_n = nzero;
+#ifdef IP_EXPERIMENTS
     if (p->dtype == INTERPOL_F32 && !(k.dbg & (4096 | 32)) && (p->flags & INTERPOL_FLAG_SMALL_TILES)) {
         // (opt-in experiment) the single-pass small-box tiles first (pull_direct.hip: smooth deformations); they write every flag
         // -- 0: served, 2: left to pull_sorted, which then runs on the flagged tiles only (gate_n < 0).  Declined (0): as before.
@@ -346,7 +349,11 @@ static int routed_pull(const interpol_problem *p, KParams k, int B, const void *
             return rc ? rc : 1;
         }
     }
-    rc = try_fast_pull(p, k, vol, grid, val, st);
+#endif
+    // (the class-sorted tiles themselves, not try_fast_pull: they alone clear the header and the brick counters on their way and
+    //  write every tile's flag -- a kernel that ignored `gate_n` would leave own_bin / own_gather with a dirty workspace)
+    if (p->dtype != INTERPOL_F32 || (k.dbg & 32)) return 0;
+    rc = try_sorted_pull_f32(p, k, vol, grid, val, st);
     if (rc != 1) return rc;
     if (k.dbg & 32768) return 1;                                     // (ablation: the tiles with their flags, no brick kernels behind them)
     rc = owner_pull_finish(p, k, vol, grid, val, workspace, workspace_bytes, false, st);
@@ -888,6 +895,14 @@ float interpol_host_weight_f32(int32_t order, float x, int32_t which)
 
 int32_t interpol_set_handback(int32_t mode) { return defer_set_mode(mode); }
 int32_t interpol_release_stream(void *stream) { return defer_release_stream((hipStream_t)stream); }
+int32_t interpol_has_experiments(void)
+{
+#ifdef IP_EXPERIMENTS
+    return 1;
+#else
+    return 0;
+#endif
+}
 
 const char *interpol_kernel_name(const interpol_problem *p, const char *op)
 {

@@ -1298,18 +1298,22 @@ static int sorted_order(const interpol_problem *p, const KParams &k)
 #define IP_SYM2(a, b) a##b
 #define IP_SYM(a, b) IP_SYM2(a, b)
 
-// the windowed gather (pull_window.hip): every sample visited once
+#ifdef IP_EXPERIMENTS
+// the windowed gather (experiments/pull_window.hip, `make experiments`): every sample visited once -- measured slower, not in the product
 int IP_SYM(try_window_pull_, IP_TSFX)(const interpol_problem *p, const KParams &k, int K, const void *vol, const void *grid, void *val, hipStream_t st);
+#endif
 
 // returns 1 when it took the problem, 0 to decline, anything else: error
 int IP_SYM(try_sorted_pull_, IP_TSFX)(const interpol_problem *p, const KParams &k, const void *vol, const void *grid, void *val, hipStream_t st)
 {
     const int K = sorted_order(p, k);
     if (K < 0) return 0;
+#ifdef IP_EXPERIMENTS
     if (k.dbg & 4096) {                                            // opt-in: the windowed gather (experimental: 1.75 ms against 1.35 ms at config 2)
         const int rc = IP_SYM(try_window_pull_, IP_TSFX)(p, k, K, vol, grid, val, st);
         if (rc != 0) return rc;
     }
+#endif
     using T = IP_TT;
     if (k.sep) {
         if constexpr (std::is_same<T, float>::value) {

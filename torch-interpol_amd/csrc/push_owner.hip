@@ -348,10 +348,13 @@ __global__ __launch_bounds__(NT1, 4) void own_bin(KParams p, BrickGrid bg, const
     }
     __syncthreads();
     prof_mark(1);
-    // ---- exclusive scan of the local brick counts (one wave), one descriptor per non-empty local brick
+    // ---- exclusive scan of the local brick counts (one wave); one descriptor per non-empty local brick -- its slot in the
+    // brick's list is DRAWN here (one returning atomic per run) and USED only after the tile's records have been stored: the
+    // round trip to the L2 is off the tile's critical path (round 5; rounds 3-4 waited for the slots before the first store)
     const int64_t tilebase = (int64_t)blockIdx.x * NS;
+    constexpr int PER = (NBIN + 63) / 64;                            // 4
+    int slot[PER];
     if (tid < 64) {
-        constexpr int PER = (NBIN + 63) / 64;                        // 4
         int cn[PER], s = 0;
 #pragma unroll
         for (int i = 0; i < PER; ++i) { const int e = tid * PER + i; cn[i] = e < NBIN ? sm.cnt[e] : 0; s += cn[i]; }
@@ -360,59 +363,26 @@ __global__ __launch_bounds__(NT1, 4) void own_bin(KParams p, BrickGrid bg, const
         for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o); if (tid >= o) incl += t; }
         int run = incl - s;
         if (tid == 63) sm.total = incl;
-        // (all of the lane's descriptor slots are drawn before the first one is used: one round trip to the L2, not PER)
-        int bk[PER], slot[PER];
 #pragma unroll
         for (int i = 0; i < PER; ++i) {
             const int e = tid * PER + i;
             const int r0 = e / (LB * LB), r1 = (e / LB) % LB, r2 = e % LB;
-            bk[i] = (int)b * bg.per_item + ((lo[0] + r0) * bg.nb[1] + (lo[1] + r1)) * bg.nb[2] + (lo[2] + r2);
+            const int bk = (int)b * bg.per_item + ((lo[0] + r0) * bg.nb[1] + (lo[1] + r1)) * bg.nb[2] + (lo[2] + r2);
             slot[i] = 0;
-            if (e < NBIN && cn[i] > 0) slot[i] = atomicAdd(&ndesc[bk[i]], 1);
-            if (IDX && e < NBIN && cn[i] > 0 && slot[i] == 0) bmax[1 + atomicAdd(&bmax[0], 1)] = bk[i];     // first run of the brick: onto the list
-        }
-#pragma unroll
-        for (int i = 0; i < PER; ++i) {
-            const int e = tid * PER + i;
-            if (e < NBIN) {
-                sm.base[e] = run;
-                if (cn[i] > 0) {
-                    if (slot[i] < CAPD) { desc[(int64_t)bk[i] * CAPD + slot[i]] = make_uint2((unsigned)(tilebase + run), (unsigned)cn[i]); sm.gbk[e] = bk[i]; }
-                    else { sm.cnt[e] = -1; sm.orph = 1; }            // the brick's list is full: this run is scattered directly, below
-                }
-                run += cn[i];
-            }
+            if (e < NBIN) sm.base[e] = run;
+            if (e < NBIN && cn[i] > 0) slot[i] = atomicAdd(&ndesc[bk], 1);
+            run += cn[i];
         }
     }
     __syncthreads();
     prof_mark(2);
-    // ---- samples that are not binned (first tap far outside the lattice, tile spread over more than LB bricks, orphan
-    // runs) are scattered directly at the END of the kernel, from re-read coordinates: the out-of-line scatter would
-    // otherwise force every live register of the hot path through scratch around its call
-    unsigned direct = valid & ~local;
-#pragma unroll
-    for (int v = 0; v < VPT1; ++v)
-        if (((local >> v) & 1) && sm.cnt[lbin[v] & 255] < 0) direct |= 1u << v;
-    // ---- sorted position of every binned sample
+    // ---- sorted position of every binned sample (above it: the first-tap cell inside the brick)
     int pos[VPT1];
 #pragma unroll
-    for (int v = 0; v < VPT1; ++v)      // sorted position, and above it the cell
-        pos[v] = ((local >> v) & 1) && sm.cnt[lbin[v] & 255] >= 0 ? (sm.base[lbin[v] & 255] + (int)((unsigned)lbin[v] >> 20)) | (((lbin[v] >> 8) & 0xfff) << 16) : -1;
-    if (IDX) {
-        // index mode: the record (x, y, z, sample index) is all the gather needs -- stored straight to its sorted place, 16 bytes
-        // per lane (the four records of a 64-byte line come from this workgroup within microseconds: the L2 merges them); no
-        // exchange through LDS, no cell table
-#pragma unroll
-        for (int v = 0; v < VPT1; ++v)
-            if (pos[v] >= 0) rec[tilebase + (pos[v] & 0xffff)] = make_float4(c[v][0], c[v][1], c[v][2], v0[v]);
-        if (IDX == 2) { if (direct) gradc_direct<T, K, GM>(p, val, aux, grid, vol, b, g, tid, direct); return; }
-        if (IDX == 3) { if (direct) grad_direct<T, K, GM>(p, val, grid, reinterpret_cast<T *>(vol), b, g, tid, direct); return; }
-        if (direct) gather_direct<T, K, GM>(p, val, grid, reinterpret_cast<T *>(vol), b, g, tid, direct);
-        return;
-    }
+    for (int v = 0; v < VPT1; ++v)
+        pos[v] = ((local >> v) & 1) ? (sm.base[lbin[v] & 255] + (int)((unsigned)lbin[v] >> 20)) | (((lbin[v] >> 8) & 0xfff) << 16) : -1;
     // ---- the sorted records are stored straight to their places (16 + 2 + 4 bytes per lane: the lines are completed by this
-    // workgroup within microseconds and merge in the L2); the samples of an ORPHAN run (its brick's descriptor list was full) are
-    // scattered directly below and leave their places unwritten -- nobody reads those
+    // workgroup within microseconds and merge in the L2).  Index mode: the record (x, y, z, sample index) is all the gather needs
     const bool two = nch > 1;
     int amx0 = 0, amx1 = 0;             // max |source| of what this thread stores (non-negative floats, and NaN, order like ints)
 #pragma unroll
@@ -420,16 +390,23 @@ __global__ __launch_bounds__(NT1, 4) void own_bin(KParams p, BrickGrid bg, const
         if (pos[v] < 0) continue;
         const int64_t at = tilebase + (pos[v] & 0xffff);
         rec[at] = make_float4(c[v][0], c[v][1], c[v][2], v0[v]);
+        if (IDX) continue;
+#ifdef IP_STAGGER
+        if (!(p.dbg & 64))
+#endif
         meta[at] = (unsigned short)(pos[v] >> 16);
         const int a0 = __float_as_int(__builtin_fabsf(v0[v]));
         amx0 = a0 > amx0 ? a0 : amx0;
         if (two) {
+#ifdef IP_STAGGER
+            if (!(p.dbg & 128))
+#endif
             vals[at] = v1[v];
             const int a1 = __float_as_int(__builtin_fabsf(v1[v]));
             amx1 = a1 > amx1 ? a1 : amx1;
         }
     }
-    for (int ch = 2; ch < nch; ++ch) {                               // further channels
+    for (int ch = 2; ch < nch && !IDX; ++ch) {                       // further channels
 #pragma unroll
         for (int v = 0; v < VPT1; ++v) {
             if (pos[v] < 0) continue;
@@ -438,10 +415,29 @@ __global__ __launch_bounds__(NT1, 4) void own_bin(KParams p, BrickGrid bg, const
             vals[(int64_t)(ch - 1) * nrec + tilebase + (pos[v] & 0xffff)] = src_value<T>(p, val, b, ((int64_t)ox * gy + oy) * gz + oz, ch, inb_mask(p, c[v]));
         }
     }
+    // ---- the descriptors, now that the slots have arrived.  A run whose brick's list was full is an ORPHAN: its records stay
+    // where they are (nobody reads them) and its samples are scattered / gathered directly, below
+    if (tid < 64) {
+#pragma unroll
+        for (int i = 0; i < PER; ++i) {
+            const int e = tid * PER + i;
+            const int cn = e < NBIN ? sm.cnt[e] : 0;
+            if (cn <= 0) continue;
+            const int r0 = e / (LB * LB), r1 = (e / LB) % LB, r2 = e % LB;
+            const int bk = (int)b * bg.per_item + ((lo[0] + r0) * bg.nb[1] + (lo[1] + r1)) * bg.nb[2] + (lo[2] + r2);
+            if (slot[i] < CAPD) {
+                desc[(int64_t)bk * CAPD + slot[i]] = make_uint2((unsigned)(tilebase + sm.base[e]), (unsigned)cn);
+                sm.gbk[e] = bk;
+                if (IDX && slot[i] == 0) bmax[1 + atomicAdd(&bmax[0], 1)] = bk;      // first run of the brick: onto the list
+            } else { sm.cnt[e] = -1; sm.orph = 1; }
+        }
+    }
     // max |source| of the first channel pair, per brick: the tile's maximum goes to every brick it published a run for (the
     // fixed-point scale of own_accumulate is as local as the tiled scatter's)
-    amx0 = wave_max(amx0); amx1 = wave_max(amx1);
-    if ((tid & 63) == 0) { if (amx0) atomicMax(&sm.bmx[0], amx0); if (amx1) atomicMax(&sm.bmx[1], amx1); }
+    if (!IDX) {
+        amx0 = wave_max(amx0); amx1 = wave_max(amx1);
+        if ((tid & 63) == 0) { if (amx0) atomicMax(&sm.bmx[0], amx0); if (amx1) atomicMax(&sm.bmx[1], amx1); }
+    }
     __syncthreads();
     for (int e = tid; e < NBIN && !IDX; e += NT1) {                  // (index mode: `bmax` is the brick list)
         const int bk = sm.gbk[e];
@@ -449,6 +445,16 @@ __global__ __launch_bounds__(NT1, 4) void own_bin(KParams p, BrickGrid bg, const
         if (sm.bmx[0]) atomicMax(&bmax[2 * (int64_t)bk], sm.bmx[0]);
         if (sm.bmx[1]) atomicMax(&bmax[2 * (int64_t)bk + 1], sm.bmx[1]);
     }
+    // ---- samples that are not binned (first tap far outside the lattice, tile spread over more than LB bricks, orphan runs)
+    // are handled directly at the END of the kernel, from re-read coordinates: the out-of-line scatter would otherwise force
+    // every live register of the hot path through scratch around its call
+    unsigned direct = valid & ~local;
+    if (sm.orph) {
+#pragma unroll
+        for (int v = 0; v < VPT1; ++v)
+            if (((local >> v) & 1) && sm.cnt[lbin[v] & 255] < 0) direct |= 1u << v;
+    }
+    if (IDX == 3) { if (direct) grad_direct<T, K, GM>(p, val, grid, reinterpret_cast<T *>(vol), b, g, tid, direct); return; }
     if (IDX == 2) { if (direct) gradc_direct<T, K, GM>(p, val, aux, grid, vol, b, g, tid, direct); return; }
     if (IDX) { if (direct) gather_direct<T, K, GM>(p, val, grid, reinterpret_cast<T *>(vol), b, g, tid, direct); return; }
     if (direct) scatter_direct<T, K, GM>(p, val, grid, vol, b, g, tid, direct, nch);
@@ -583,6 +589,18 @@ __global__ __launch_bounds__(NT, 4) void own_accumulate(KParams p, BrickGrid bg,
     // along the faces of the lattice) and visits the ones that hold records.
     const bool dynamic = color < 8;
     __shared__ int next_chunk;
+#ifdef IP_STAGGER
+    // (experiment) the two workgroups of a CU start half a brick apart: one taps (LDS) while the other flushes (HBM)
+    if (dynamic && ((p.dbg >> 9) & 7)) {
+        unsigned tg;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID, 16, 4)" : "=s"(tg));
+        const bool late = (p.dbg & 4096) ? (blockIdx.x >= gridDim.x / 2) : (tg & 1);
+        if (late) {
+            const long long t0 = clock64(), x = (long long)((p.dbg >> 9) & 7) * 8192;
+            while (clock64() - t0 < x) __builtin_amdgcn_s_sleep(20);
+        }
+    }
+#endif
     for (int round = 0; ; ++round) {
     int chunk, stride;
     if (dynamic) {

@@ -26,7 +26,7 @@ FLAG_DISPLACEMENT = 16
 FLAG_WITH_COUNT = 32
 FLAG_BINNED_SCATTER = 64
 FLAG_AUTO_SCATTER = 1 << 24
-FLAG_SMALL_TILES = 1 << 25           # (experimental, opt-in: csrc/pull_direct.hip)
+FLAG_SMALL_TILES = 1 << 25           # (experimental, opt-in: experiments/pull_direct.hip)
 _POISON_SCRATCH = os.environ.get("INTERPOL_POISON_SCRATCH", "0") not in ("", "0")
 FLAG_AFFINE_GRID = 128
 
@@ -40,7 +40,7 @@ SYMBOLS = (
     "interpol_push_bricks", "interpol_push_bricks_workspace", "interpol_host_bound_index", "interpol_host_bound_sign",
     "interpol_host_weight", "interpol_host_weight_f32", "interpol_abi_version",
     "interpol_error_string", "interpol_kernel_name", "interpol_scatter_workspace",
-    "interpol_set_handback", "interpol_release_stream", "interpol_pull_workspace", "interpol_pull_ws", "interpol_push_backward_ws", "interpol_grad_ws",
+    "interpol_set_handback", "interpol_release_stream", "interpol_has_experiments", "interpol_pull_workspace", "interpol_pull_ws", "interpol_push_backward_ws", "interpol_grad_ws",
 )
 
 
