@@ -12,7 +12,7 @@ NAMES = {"pullw": ["setup:read records", "stage (all windows)", "taps (all windo
                    "setup:planner", "setup:records to sorted places"],
          "pull": ["build:read sorted", "stage", "taps", "unsort+store+slow", "build:coords", "build:split+minmax", "build:tables+classify", "build:scan+holes", "build:records"],
          "push": ["bin:load", "bin:brick+rank", "bin:scan+desc", "bin:direct+pos", "bin:exchange", "bin:store", "6", "7",
-                  "acc:desc", "acc:pass1", "acc:density", "acc:taps", "acc:flush"],
+                  "acc:desc", "acc:pass1", "acc:density", "acc:taps", "acc:flush", "acc:stencil counts", "acc:draw+ndesc", "acc:classes+queue"],
          "pushs": ["build+density", "taps (4 passes)", "flush (4 passes)", "slow + tail", "sources+scale", "build:coords", "build:split+minmax", "build:tables+classify", "build:scan+holes", "build:records"]}
 dev = torch.device("cuda", 0)
 sigma = float(sys.argv[1]) if len(sys.argv) > 1 else 2.0
@@ -24,7 +24,7 @@ fn.argtypes = [ctypes.c_void_p, ctypes.c_int]
 buf = (ctypes.c_ulonglong * 16)()
 def run(op):
     if op == "push":
-        _hip.scatter("push", inp, grid, None, [3] * 3, [3] * 3, 1, flags=_hip.FLAG_BINNED_SCATTER)
+        _hip.scatter("push", inp, grid, None, [3] * 3, [3] * 3, 1, flags=_hip.FLAG_BINNED_SCATTER | ((int(sys.argv[3]) if len(sys.argv) > 3 else 0) << 8))
     elif op == "pushs":
         _hip.scatter("push", inp, grid, None, [3] * 3, [3] * 3, 1, flags=128 << 8)
     else:      # pullw: the windowed gather (the default); pull: the four-pass tiles (debug bit 4096)

@@ -489,6 +489,7 @@ struct AccSmem {
     unsigned long long box[BOXSLOTS];
 };
 constexpr int NZ = BOX + 1;                     // row pitch of the stencil counts (even: two slots per 32-bit word)
+struct PlanHdr { int flags, qcap, n, pad_; };   // own_plan's verdict on an interior brick; flags bit 0: SIMPLE (own_taps serves it)
 static_assert(sizeof(AccSmem) <= 80 * 1024, "two workgroups per CU");
 static_assert(sizeof(unsigned) * (BOX * BOX * NZ / 2) <= sizeof(unsigned) * (NCELL / 2) + sizeof(unsigned short) * BATCH, "the stencil counts fit in cells + queue");
 
@@ -677,9 +678,11 @@ __global__ __launch_bounds__(NT, 4) void own_accumulate(KParams p, BrickGrid bg,
                                                         const float4 *__restrict__ rec, const float *__restrict__ vals,
                                                         const unsigned short *__restrict__ meta, const int *__restrict__ bmax, int64_t nrec,
                                                         float *__restrict__ vol, int nch, int color, int nbatch, const int *__restrict__ gate,
-                                                        int *__restrict__ ctr)
+                                                        int *__restrict__ ctr, const PlanHdr *__restrict__ plan, const int *__restrict__ nonsimple)
 {
     if (gate && *gate != 1) return;                                  // INTERPOL_FLAG_AUTO_SCATTER: the probe chose the tiles
+    // colour launches behind own_plan / own_taps: only the bricks that are not simple are left -- usually none
+    if (plan && color < 8 && *nonsimple == 0) return;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     AccSmem &sm = *reinterpret_cast<AccSmem *>(smem_raw);
     Lattice L;
@@ -747,6 +750,10 @@ __global__ __launch_bounds__(NT, 4) void own_accumulate(KParams p, BrickGrid bg,
 #pragma unroll
         for (int d = 0; d < 3; ++d) interior = interior && bxyz[d] >= NLO + (L.bound[d] == B_DST1 ? 1 : 0) && bxyz[d] < NLO + bg.nin[d];
         if (color < 8 ? !interior : (color == 8 && interior)) continue;       // (block-uniform)
+        if (plan && color < 8) {
+            const int ii = (((int)b * bg.nin[0] + (bxyz[0] - NLO)) * bg.nin[1] + (bxyz[1] - NLO)) * bg.nin[2] + (bxyz[2] - NLO);
+            if (plan[ii].flags & 1) continue;                        // (block-uniform) own_taps served it
+        }
         const bool atomic = color >= 8;
         // bricks at the ends of a folding dim (BrickGrid): part of the box lies outside the lattice
         bool edge = false;
@@ -1197,6 +1204,426 @@ __global__ __launch_bounds__(NT, 4) void own_accumulate(KParams p, BrickGrid bg,
 }
 
 // ---------------------------------------------------------------------------
+// own_plan + own_taps (round 5): the colour launches in two kernels.
+//
+// own_accumulate spends less than half of a brick's time on taps and flush: its waves execute ~7 000 instructions per brick one
+// after the other (descriptors -> pieces -> density -> class counts -> queue -> taps -> stencil counts -> flush), two workgroups
+// per CU (the box takes 55 KiB) -- too few waves to hide what every step waits for.  Everything in front of the taps depends on
+// the records' first-tap cells alone and needs no box: own_plan does it for EVERY interior brick in one launch, 24 KiB of LDS and
+// six workgroups per CU, and leaves per brick  (a) the class-sorted queue, in the order the tap loop reads it (entry it * NT + tid:
+// coalesced), (b) the piece table, (c) the stencil count of every slot of the box, already folded at the ends of folding dims,
+// (d) a header: SIMPLE (one batch, 32-bit sums, finite sources, at most one channel pair) or not.  own_taps then runs the eight
+// colours over the simple bricks: queue entry -> record -> taps -> flush, nothing else; own_accumulate keeps the bricks that are
+// not simple (its colour launches return at once when there are none), the shell and shared targets.
+// ---------------------------------------------------------------------------
+#ifndef IP_NTP
+#define IP_NTP 512
+#endif
+constexpr int NTP = IP_NTP, NHWP = NTP / 32, VPTP = 6144 / NTP;      // own_plan / own_taps: threads, half waves, pieces per wave
+constexpr int PLAN_Q = 5120;                    // queue entries kept per brick (bricks that need more are not simple)
+constexpr int PLAN_N = BOX * BOX * NZ;          // stencil counts per brick (8 bits each: a brick whose largest count exceeds 255 is not simple)
+struct Plan {
+    PlanHdr *hdr; uint2 *pieces; unsigned short *queue; unsigned char *nst;
+    int nin[3]; int per_item;                   // interior bricks per dim and per batch item
+};
+struct PlanSmem {
+    int   ppref[CAPD]; unsigned start[CAPD]; int rcnt[CAPD];
+    uint2 piece[NPIECE];
+    int   dmax, n, npieces;
+    int   qcnt[NCLS], qsur[NCLS + 1], qhol[NCLS + 1], qeff[NCLS], qcap;
+    union alignas(16) {
+        struct { unsigned cells[NCELL / 2]; unsigned short queue[BATCH]; };
+        unsigned nreg[BOX * BOX * NZ / 2];
+    };
+};
+// stencil_counts works on any struct with cells / nreg
+template <int K>
+__global__ __launch_bounds__(NTP, NTP / 64) void own_plan(KParams p, BrickGrid bg, Plan pl, const int *__restrict__ ndesc, const uint2 *__restrict__ desc,
+                                                  const unsigned short *__restrict__ meta, const int *__restrict__ bmax, int nch,
+                                                  const int *__restrict__ gate, int *__restrict__ nonsimple)
+{
+    if (gate && *gate != 1) return;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    PlanSmem &sm = *reinterpret_cast<PlanSmem *>(smem_raw);
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int ii = blockIdx.x;
+    int r = ii;
+    const int jz = r % pl.nin[2]; r /= pl.nin[2];
+    const int jy = r % pl.nin[1]; r /= pl.nin[1];
+    const int jx = r % pl.nin[0];
+    const int b = r / pl.nin[0];
+    const int bxyz[3] = { jx + NLO, jy + NLO, jz + NLO };
+    const int brick = b * bg.per_item + (bxyz[0] * bg.nb[1] + bxyz[1]) * bg.nb[2] + bxyz[2];
+    bool interior = true;
+#pragma unroll
+    for (int d = 0; d < 3; ++d) interior = interior && bxyz[d] >= NLO + (p.bound[d] == B_DST1 ? 1 : 0);
+    int nd = interior ? ndesc[brick] : 0;
+    if (nd == 0) { if (tid == 0) pl.hdr[ii] = PlanHdr{ 0, 0, 0, 0 }; return; }          // (block-uniform)
+    nd = nd < CAPD ? nd : CAPD;
+    const int b0[3] = { brick_origin(bxyz[0], bg.lo[0], bg.top[0], bg.nin[0], bg.split[0]), brick_origin(bxyz[1], bg.lo[1], bg.top[1], bg.nin[1], bg.split[1]),
+                        brick_origin(bxyz[2], bg.lo[2], bg.top[2], bg.nin[2], bg.split[2]) };
+    int foldmul = 1;
+    bool edge = false;
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        const int nout = b0[d] < 0 ? -b0[d] : (b0[d] + BOX > p.vol_n[d] ? b0[d] + BOX - p.vol_n[d] : 0);
+        edge = edge || nout != 0;
+        foldmul *= nout == 0 ? 1 : (p.bound[d] == B_REPLICATE ? nout + 1 : 2);
+    }
+    if (tid < 64) {
+        constexpr int PER = CAPD / 64;
+        int cn[PER], np[PER], s1 = 0, sp = 0; unsigned st_[PER];
+#pragma unroll
+        for (int i = 0; i < PER; ++i) {
+            const int e = tid * PER + i;
+            const uint2 dsc = e < nd ? desc[(int64_t)brick * CAPD + e] : make_uint2(0u, 0u);
+            cn[i] = (int)dsc.y; st_[i] = dsc.x; np[i] = (cn[i] + 63) >> 6; s1 += cn[i]; sp += np[i];
+        }
+        int incl = s1, inclp = sp;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int t = __shfl_up(incl, o), tp = __shfl_up(inclp, o);
+            if (tid >= o) { incl += t; inclp += tp; }
+        }
+        int runp = inclp - sp;
+#pragma unroll
+        for (int i = 0; i < PER; ++i) {
+            const int e = tid * PER + i;
+            sm.ppref[e] = e < nd ? runp : 0x7fffffff;
+            sm.start[e] = st_[i];
+            sm.rcnt[e] = cn[i];
+            runp += np[i];
+        }
+        if (tid == 63) { sm.n = incl; sm.npieces = inclp; sm.dmax = 0; }
+    }
+    for (int e = tid; e < NCELL / 2; e += NTP) sm.cells[e] = 0u;
+    if (tid < NCLS) sm.qcnt[tid] = 0;
+    __syncthreads();
+    const int n = sm.n, npieces = sm.npieces;
+    const int mb0 = bmax[2 * (int64_t)brick], mb1 = nch > 1 ? bmax[2 * (int64_t)brick + 1] : 0;
+    const bool fin = (mb0 & 0x7f800000) != 0x7f800000 && (mb1 & 0x7f800000) != 0x7f800000;
+    // (block-uniform) more than one batch of pieces, more than one channel pair, non-finite sources: own_accumulate's
+    if (npieces > NPIECE || nch > 2 || !fin) {
+        if (tid == 0) { pl.hdr[ii] = PlanHdr{ 0, 0, n, 0 }; atomicAdd(nonsimple, 1); }
+        return;
+    }
+    if (tid < NPIECE) {
+        uint2 pc = make_uint2(0u, 0u);
+        if (tid < npieces) {
+            int j = 0;
+#pragma unroll
+            for (int st = CAPD / 2; st > 0; st >>= 1) j += sm.ppref[j + st] <= tid ? st : 0;
+            const int q = tid - sm.ppref[j], left = sm.rcnt[j] - 64 * q;
+            pc = make_uint2(sm.start[j] + 64u * (unsigned)q, (unsigned)(left < 64 ? left : 64));
+        }
+        sm.piece[tid] = pc;
+        pl.pieces[(int64_t)ii * NPIECE + tid] = pc;
+    }
+    __syncthreads();
+    // ---- density of the first-tap cells, class and rank of every record (own_accumulate: pass 1)
+    int qr[VPTP];
+    {
+        unsigned mk[VPTP];
+#pragma unroll
+        for (int k = 0; k < VPTP; ++k) {
+            const uint2 pc = sm.piece[wave + k * (NTP / 64)];
+            mk[k] = lane < (int)pc.y ? (unsigned)meta[pc.x + (unsigned)lane] : 0xffffffffu;
+        }
+#pragma unroll
+        for (int k = 0; k < VPTP; ++k) {
+            qr[k] = -1;
+            if (mk[k] != 0xffffffffu) {
+                const int x0 = (mk[k] >> 8) & 15, y0 = (mk[k] >> 4) & 15, z0 = mk[k] & 15;
+                const int cell = (int)(mk[k] & 4095u);
+                atomicAdd(&sm.cells[cell >> 1], 1u << (16 * (cell & 1)));
+                const int q = (x0 * PLANE + y0 * PZ + z0) & (NCLS - 1);
+                qr[k] = q | (atomicAdd(&sm.qcnt[q], 1) << 5);
+            }
+        }
+    }
+    __syncthreads();
+    {
+        int dm = 0;
+        for (int e = tid; e < NCELL / 2; e += NTP) {
+            const unsigned w2 = sm.cells[e];
+            const int a = (int)(w2 & 0xffffu), c2 = (int)(w2 >> 16);
+            dm = a > dm ? a : dm; dm = c2 > dm ? c2 : dm;
+        }
+        dm = wave_max(dm);
+        if (lane == 0 && dm > 0) atomicMax(&sm.dmax, dm);
+    }
+    if (tid < 32) {
+        const int cq = sm.qcnt[tid];
+        int tot, nsur, nhol;
+        half_excl_scan(cq, tot);
+        const int cap = (((tot + NCLS - 1) / NCLS) + NHWP - 1) / NHWP * NHWP;
+        const int sur = cq > cap ? cq - cap : 0, hol = cq < cap ? cap - cq : 0;
+        const int so = half_excl_scan(sur, nsur), ho = half_excl_scan(hol, nhol);
+        sm.qsur[tid] = so; sm.qhol[tid] = ho;
+        if (tid == 31) { sm.qsur[NCLS] = nsur; sm.qhol[NCLS] = nhol; sm.qcap = cap; }
+        const int fill = nsur - ho < 0 ? 0 : (nsur - ho > hol ? hol : nsur - ho);
+        sm.qeff[tid] = (cq < cap ? cq : cap) + fill;
+    }
+    __syncthreads();
+    const int qcap = sm.qcap;
+    // (a first, cheap test: no cell so dense that the stencil counts could leave 8 bits; the counts themselves decide below)
+    if (sm.dmax > 255 || NCLS * qcap > PLAN_Q) {                     // (block-uniform)
+        if (tid == 0) { pl.hdr[ii] = PlanHdr{ 0, 0, n, 0 }; atomicAdd(nonsimple, 1); }
+        return;
+    }
+#pragma unroll
+    for (int k = 0; k < VPTP; ++k) {
+        if (qr[k] < 0) continue;
+        const int qq = qr[k] & 31, rk = qr[k] >> 5;
+        int slot = qq * qcap + rk;
+        if (rk >= qcap) {
+            const int o = sm.qsur[qq] + rk - qcap;
+            int c2 = 0;
+#pragma unroll
+            for (int st = 16; st > 0; st >>= 1) if (sm.qhol[c2 + st] <= o) c2 += st;
+            slot = c2 * qcap + sm.qcnt[c2] + (o - sm.qhol[c2]);
+        }
+        sm.queue[slot] = (unsigned short)(((wave + k * (NTP / 64)) << 6) | lane);
+    }
+    __syncthreads();
+    // ---- the queue in the order of the tap loop: iteration `it` of thread t (class q = t & 31, half wave t >> 5) at it * NTP + t
+    {
+        const int q = tid & 31, hw = tid >> 5;
+        const int cnt = sm.qeff[q];
+        unsigned short *qo = pl.queue + (int64_t)ii * PLAN_Q;
+        for (int it = 0; it < qcap / NHWP; ++it) {
+            const int j = hw + it * NHWP;
+            qo[it * NTP + tid] = j < cnt ? sm.queue[q * qcap + j] : (unsigned short)0xffff;
+        }
+    }
+    __syncthreads();
+    // ---- stencils per slot, folded like the box at the ends of folding dims (own_accumulate)
+    stencil_counts<K>(sm, tid);
+    if (edge) {
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            const int nlo = b0[d] < 0 ? -b0[d] : 0, nhi = b0[d] + BOX > p.vol_n[d] ? b0[d] + BOX - p.vol_n[d] : 0;
+            if (nlo + nhi == 0) continue;
+            for (int i = tid; i < (nlo + nhi) * (BOX * BOX); i += NTP) {
+                const int o = i / (BOX * BOX), rest = i - o * (BOX * BOX), r1 = rest / BOX, r2 = rest - r1 * BOX;
+                const int rd = o < nlo ? o : BOX - nhi + (o - nlo);
+                const int idx = b0[d] + rd;
+                int j;
+                if (p.bound[d] == B_REPLICATE) j = idx < 0 ? 0 : p.vol_n[d] - 1;
+                else if (p.bound[d] == B_DCT1) j = idx < 0 ? -idx : 2 * p.vol_n[d] - 2 - idx;
+                else j = idx < 0 ? -1 - idx : 2 * p.vol_n[d] - 1 - idx;
+                const int rt = j - b0[d];
+                const int ns = d == 0 ? (rd * BOX + r1) * NZ + r2 : d == 1 ? (r1 * BOX + rd) * NZ + r2 : (r1 * BOX + r2) * NZ + rd;
+                const int nt = d == 0 ? (rt * BOX + r1) * NZ + r2 : d == 1 ? (r1 * BOX + rt) * NZ + r2 : (r1 * BOX + r2) * NZ + rt;
+                unsigned short *nn = reinterpret_cast<unsigned short *>(sm.nreg);
+                const unsigned c2 = nn[ns];
+                if (c2) { nn[ns] = 0; atomicAdd(&sm.nreg[nt >> 1], c2 << (16 * (nt & 1))); }
+            }
+            __syncthreads();
+        }
+    }
+    // ---- SIMPLE: every slot's 32-bit sums hold -- a slot that n stencils cover sums n terms below 2^22 (magic format), and n <= 255
+    // lets the counts travel as bytes.  (Denser bricks: own_accumulate, which has the 64-bit sums.)
+    {
+        unsigned *no = reinterpret_cast<unsigned *>(pl.nst + (int64_t)ii * PLAN_N);
+        unsigned big = 0u;
+        for (int e = tid; e < PLAN_N / 4; e += NTP) {
+            const unsigned w0 = sm.nreg[2 * e], w1 = sm.nreg[2 * e + 1];
+            big |= (w0 | w1) & 0xff00ff00u;
+            no[e] = (w0 & 0xffu) | ((w0 >> 8) & 0xff00u) | ((w1 & 0xffu) << 16) | ((w1 >> 8) & 0xff00u) << 16;
+        }
+        const int anybig = __syncthreads_or(big != 0u);
+        if (tid == 0) {
+            pl.hdr[ii] = PlanHdr{ anybig ? 0 : 1, qcap, n, 0 };
+            if (anybig) atomicAdd(nonsimple, 1);
+        }
+    }
+    (void)foldmul;
+}
+
+struct TapSmem {
+    uint2 piece[NPIECE];
+    int   work;
+    unsigned long long box[BOXSLOTS];
+};
+template <int K>
+__global__ __launch_bounds__(NTP, NTP / 128) void own_taps(KParams p, BrickGrid bg, Plan pl, const float4 *__restrict__ rec, const float *__restrict__ vals,
+                                                  const int *__restrict__ bmax, float *__restrict__ vol, int nch, int color, int nbatch,
+                                                  const int *__restrict__ gate, int *__restrict__ ctr)
+{
+    if (gate && *gate != 1) return;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    TapSmem &sm = *reinterpret_cast<TapSmem *>(smem_raw);
+    const int n3[3] = { p.vol_n[0], p.vol_n[1], p.vol_n[2] };
+    const int ss[3] = { (int)(p.vol_ss[0] / 4), (int)(p.vol_ss[1] / 4), (int)(p.vol_ss[2] / 4) };
+    const int c0[3] = { color_first(color, 0), color_first(color, 1), color_first(color, 2) };
+    const int m0 = color_count(color, 0, bg), m1 = color_count(color, 1, bg), m2 = color_count(color, 2, bg);
+    const int nwork = m0 * m1 * m2 * nbatch;
+    for (int e = threadIdx.x; e < BOXSLOTS; e += NTP) sm.box[e] = 0ull;
+    const bool two = nch > 1;
+    const unsigned boxaddr = (unsigned)(size_t)(__attribute__((address_space(3))) void *)(sm.box);
+    // the work items are drawn one brick ahead (inline assembly: the compiler would wait for the returning atomic on the spot)
+    int drawn = 0;
+    if (threadIdx.x == 0) {
+        asm volatile("global_atomic_add %0, %1, %2, off sc0\n\ts_waitcnt vmcnt(0)" : "=v"(drawn) : "v"(ctr), "v"(1) : "memory");
+        sm.work = drawn;
+    }
+    for (;;) {
+        __syncthreads();                                             // the previous brick's flush is done with the box / the piece table
+        const int work = sm.work;
+        if (work >= nwork) break;
+        if (threadIdx.x == 0) asm volatile("global_atomic_add %0, %1, %2, off sc0" : "=v"(drawn) : "v"(ctr), "v"(1) : "memory");
+        const int tid = opaque((int)threadIdx.x);
+        int r = work;
+        const int iz = r % m2; r /= m2;
+        const int iy = r % m1; r /= m1;
+        const int ix = r % m0;
+        const int b = r / m0;
+        const int bxyz[3] = { ix * 2 + c0[0], iy * 2 + c0[1], iz * 2 + c0[2] };
+        const int ii = ((b * pl.nin[0] + (bxyz[0] - NLO)) * pl.nin[1] + (bxyz[1] - NLO)) * pl.nin[2] + (bxyz[2] - NLO);
+        const PlanHdr h = pl.hdr[ii];
+        if (!(h.flags & 1)) {                                        // (block-uniform) empty, or own_accumulate's
+            __syncthreads();                                         // (everybody has read sm.work)
+            if (threadIdx.x == 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); sm.work = drawn; }
+            continue;
+        }
+        const int brick = b * bg.per_item + (bxyz[0] * bg.nb[1] + bxyz[1]) * bg.nb[2] + bxyz[2];
+        const int b0[3] = { brick_origin(bxyz[0], bg.lo[0], bg.top[0], bg.nin[0], bg.split[0]), brick_origin(bxyz[1], bg.lo[1], bg.top[1], bg.nin[1], bg.split[1]),
+                            brick_origin(bxyz[2], bg.lo[2], bg.top[2], bg.nin[2], bg.split[2]) };
+        bool edge = false;
+#pragma unroll
+        for (int d = 0; d < 3; ++d) edge = edge || b0[d] < 0 || b0[d] + BOX > n3[d];
+        if (tid < NPIECE) sm.piece[tid] = pl.pieces[(int64_t)ii * NPIECE + tid];
+        const int mb0 = bmax[2 * (int64_t)brick], mb1 = two ? bmax[2 * (int64_t)brick + 1] : 0;
+        const float a0 = fmaxf(__int_as_float(mb0), 1e-27f), a1 = fmaxf(__int_as_float(mb1), 1e-27f);
+        const f2 scale = { mb0 ? magic_units<K>() / a0 : 0.f, mb1 ? magic_units<K>() / a1 : 0.f };
+        const float inv0 = a0 * (1.f / magic_units<K>()), inv1 = a1 * (1.f / magic_units<K>());
+        float *vc0 = vol + (int64_t)b * p.vol_sb;
+        float *vc1 = two ? vc0 + p.vol_sc : vc0;
+        const float *vb = two ? vals : nullptr;
+        const unsigned short *qin = pl.queue + (int64_t)ii * PLAN_Q + tid;
+        const int nit = h.qcap / NHWP;
+        __syncthreads();                                             // the piece table
+        // ---- the taps: queue entry (two iterations ahead) -> record (one ahead) -> (K + 1)^3 adds
+        unsigned qn = nit > 1 ? (unsigned)qin[NTP] : 0xffffu;
+        float4 rc = make_float4(0.f, 0.f, 0.f, 0.f); float s1 = 0.f;
+        bool have = false;
+        {
+            const unsigned q0 = qin[0];
+            have = q0 != 0xffffu;
+            if (have) { const unsigned ri = sm.piece[q0 >> 6].x + (q0 & 63u); rc = rec[ri]; s1 = vb ? vb[ri] : 0.f; }
+        }
+#pragma unroll 1
+        for (int it = 0; it < nit; ++it) {
+            const float4 cur = rc; const float cs1 = s1; const bool now = have;
+            const unsigned q1 = qn;
+            qn = it + 2 < nit ? (unsigned)qin[(it + 2) * NTP] : 0xffffu;
+            have = q1 != 0xffffu;
+#ifdef IP_ABLATE
+            if (have && !(p.dbg & 4))
+#else
+            if (have)
+#endif
+            { const unsigned ri = sm.piece[q1 >> 6].x + (q1 & 63u); rc = rec[ri]; s1 = vb ? vb[ri] : 0.f; }
+            if (!now) continue;
+#ifdef IP_ABLATE
+            if (p.dbg & 2) continue;                                 // (ablation: no taps)
+#endif
+            int x0, y0, z0; float tx, ty, tz;
+            record_cell<K>(cur, b0, x0, y0, z0, tx, ty, tz);
+            const unsigned addr = boxaddr + 8u * (unsigned)(x0 * PLANE + y0 * PZ + z0);
+            f2 w[4];
+            weights_yz<K>(f2{ ty, tz }, w);
+            const f2 ssv = f2{ cur.w, cs1 } * scale;
+            scatter_plane<K, 0, false>(addr, ssv, weight_x<K>(tx, 0), w, 0);
+            scatter_plane<K, 1, false>(addr, ssv, weight_x<K>(tx, 1), w, 0);
+            scatter_plane<K, 2, false>(addr, ssv, weight_x<K>(tx, 2), w, 0);
+            if (K == 3) scatter_plane<K, 3, false>(addr, ssv, weight_x<K>(tx, 3), w, 0);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __syncthreads();
+        // ---- bricks at the ends of a folding dim: what lies outside the lattice onto its mirror image, dim after dim (own_accumulate;
+        // the stencil counts of the plan are folded already)
+        if (edge) {
+#pragma unroll
+            for (int d = 0; d < 3; ++d) {
+                const int nlo = b0[d] < 0 ? -b0[d] : 0, nhi = b0[d] + BOX > n3[d] ? b0[d] + BOX - n3[d] : 0;     // (block-uniform)
+                if (nlo + nhi == 0) continue;
+                for (int i = tid; i < (nlo + nhi) * (BOX * BOX); i += NTP) {
+                    const int o = i / (BOX * BOX), rest = i - o * (BOX * BOX), r1 = rest / BOX, r2 = rest - r1 * BOX;
+                    const int rd = o < nlo ? o : BOX - nhi + (o - nlo);
+                    const int idx = b0[d] + rd;
+                    int j;
+                    if (p.bound[d] == B_REPLICATE) j = idx < 0 ? 0 : n3[d] - 1;
+                    else if (p.bound[d] == B_DCT1) j = idx < 0 ? -idx : 2 * n3[d] - 2 - idx;
+                    else j = idx < 0 ? -1 - idx : 2 * n3[d] - 1 - idx;
+                    const int rt = j - b0[d];
+                    const int es = d == 0 ? rd * PLANE + r1 * PZ + r2 : d == 1 ? r1 * PLANE + rd * PZ + r2 : r1 * PLANE + r2 * PZ + rd;
+                    const int et = d == 0 ? rt * PLANE + r1 * PZ + r2 : d == 1 ? r1 * PLANE + rt * PZ + r2 : r1 * PLANE + r2 * PZ + rt;
+                    const unsigned long long v = sm.box[es];
+                    if (v) { sm.box[es] = 0ull; atomicAdd(&sm.box[et], v); }
+                }
+                __syncthreads();
+            }
+        }
+        // Slots that no brick of an earlier colour reaches are STORED (the target is zero there): a slot is shared along a dim with
+        // the brick below when it lies in that brick's box, with the brick above from that brick's first slot on; the neighbour
+        // along a dim runs earlier exactly when this brick's parity in the dim is 1 (the colour index orders the parities).
+        int shlo[3], shhi[3];
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            const int par = (color >> (2 - d)) & 1;
+            const int j = bxyz[d] - NLO;
+            const int below = j > 0 ? brick_origin(bxyz[d] - 1, bg.lo[d], bg.top[d], bg.nin[d], bg.split[d]) + BOX - b0[d] : 0;
+            const int above = j + 1 < bg.nin[d] ? brick_origin(bxyz[d] + 1, bg.lo[d], bg.top[d], bg.nin[d], bg.split[d]) - b0[d] : BOX;
+            shlo[d] = par ? (below > 0 ? below : 0) : 0;             // slots [0, shlo) and [shhi, BOX) were written before
+            shhi[d] = par ? (above < BOX ? above : BOX) : BOX;
+        }
+        // ---- flush: target += box (plain loads and stores: the bricks of a colour are disjoint), the box re-zeroed on the way.  All of
+        // a thread's loads -- stencil counts and target values -- are in flight at once: the addresses of slots outside the lattice
+        // (ends of folding dims: their counts are 0 after the fold) are clamped into it and nothing is stored there.
+#ifdef IP_ABLATE
+        if (!(p.dbg & 1))                                            // (ablation: no flush)
+#endif
+        {
+            constexpr int UF2 = (BOXSLOTS + NTP - 1) / NTP;            // 14
+            const unsigned char *nin_ = pl.nst + (int64_t)ii * PLAN_N;
+            unsigned off[UF2]; float t0[UF2], t1[UF2]; unsigned nst[UF2];
+#pragma unroll
+            for (int u = 0; u < UF2; ++u) {
+                int e = tid + u * NTP;
+                e = e < BOXSLOTS ? e : BOXSLOTS - 1;
+                const int xr = e / PLANE, rem = e - xr * PLANE, yr = rem / PZ, zr = rem - yr * PZ;
+                int gx_ = b0[0] + xr, gy_ = b0[1] + yr, gz_ = b0[2] + zr;
+                gx_ = gx_ < 0 ? 0 : (gx_ >= n3[0] ? n3[0] - 1 : gx_);
+                gy_ = gy_ < 0 ? 0 : (gy_ >= n3[1] ? n3[1] - 1 : gy_);
+                gz_ = gz_ < 0 ? 0 : (gz_ >= n3[2] ? n3[2] - 1 : gz_);
+                off[u] = (unsigned)(gx_ * ss[0] + gy_ * ss[1] + gz_ * ss[2]);
+                nst[u] = nin_[(xr * BOX + yr) * NZ + zr];
+                const bool fresh = xr >= shlo[0] && xr < shhi[0] && yr >= shlo[1] && yr < shhi[1] && zr >= shlo[2] && zr < shhi[2];
+                t0[u] = 0.f; t1[u] = 0.f;
+                if (!fresh) {
+                    t0[u] = vc0[off[u]];
+                    t1[u] = vc1[off[u]];                             // (one channel: vc1 == vc0)
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < UF2; ++u) {
+                const int e = tid + u * NTP;
+                if (e >= BOXSLOTS || nst[u] == 0u) continue;
+                const unsigned long long a = sm.box[e];
+                sm.box[e] = 0ull;
+                int lo_, hi_;
+                magic_decode(a, nst[u], lo_, hi_);
+                vc0[off[u]] = t0[u] + (float)lo_ * inv0;
+                if (two) vc1[off[u]] = t1[u] + (float)hi_ * inv1;
+            }
+        }
+        if (threadIdx.x == 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); sm.work = drawn; }
+    }
+}
+
+// ---------------------------------------------------------------------------
 // own_probe (INTERPOL_FLAG_AUTO_SCATTER): which organisation serves this call?
 // The sample-stationary tiles (ops_tiled.hip) accumulate a tile of 16^3 samples in an LDS box of at most 33 x 33 x 32
 // lattice points centred on the tile's stencils; samples outside it take a slow path, and beyond a few per cent of them the
@@ -1572,10 +1999,11 @@ struct Workspace {
     int *flags;
     ProbeHdr *hdr; int *ndesc; int *bmax; uint2 *desc; float4 *rec; float *vals; unsigned short *meta;
     int64_t nrec; int nbricks;
+    Plan plan; int64_t nint;                                          // (scatter: the plan of the interior bricks)
 };
 static int64_t align256(int64_t x) { return (x + 255) & ~(int64_t)255; }
 
-static int64_t layout(const KParams &k, int B, int ntiles, int nch, void *base, Workspace *w, int64_t nflags = 0)
+static int64_t layout(const KParams &k, int B, int ntiles, int nch, void *base, Workspace *w, int64_t nflags = 0, bool with_plan = false)
 {
     const BrickGrid bg = brick_grid(k);
     const int64_t nbricks = (int64_t)bg.per_item * B;
@@ -1590,7 +2018,17 @@ static int64_t layout(const KParams &k, int B, int ntiles, int nch, void *base, 
     const int64_t o_rec = o; o += align256(nrec * 16);
     const int64_t o_val = o; o += align256(nrec * 4 * (nch > 1 ? nch - 1 : 0));
     const int64_t o_meta = o; o += align256(nrec * 2);
+    const int64_t nint = with_plan ? (int64_t)bg.nin[0] * bg.nin[1] * bg.nin[2] * B : 0;
+    const int64_t o_ph = o; o += align256(nint * (int64_t)sizeof(PlanHdr));
+    const int64_t o_pp = o; o += align256(nint * NPIECE * 8);
+    const int64_t o_pq = o; o += align256(nint * PLAN_Q * 2);
+    const int64_t o_pn = o; o += align256(nint * PLAN_N);
     if (w) {
+        w->nint = nint;
+        w->plan.hdr = (PlanHdr *)(p + o_ph); w->plan.pieces = (uint2 *)(p + o_pp); w->plan.queue = (unsigned short *)(p + o_pq);
+        w->plan.nst = (unsigned char *)(p + o_pn);
+        for (int d = 0; d < 3; ++d) w->plan.nin[d] = bg.nin[d];
+        w->plan.per_item = bg.nin[0] * bg.nin[1] * bg.nin[2];
         w->hdr = (ProbeHdr *)(p + o_hdr); w->ndesc = (int *)(p + o_nd); w->desc = (uint2 *)(p + o_desc);
         w->rec = (float4 *)(p + o_rec); w->vals = (float *)(p + o_val); w->meta = (unsigned short *)(p + o_meta);
         w->bmax = (int *)(p + o_bm); w->flags = (int *)(p + o_fl);
@@ -1632,7 +2070,7 @@ int64_t owner_workspace_bytes(const interpol_problem *p, const KParams &k, bool 
 {
     if (!owner_eligible(p, k)) return 0;
     const int nch = count_only ? 1 : k.C + (k.cc ? 1 : 0);
-    return owner::layout(k, (int)p->batch, owner::tile_count(p), nch, nullptr, nullptr);
+    return owner::layout(k, (int)p->batch, owner::tile_count(p), nch, nullptr, nullptr, 0, true);
 }
 
 namespace owner {
@@ -1672,7 +2110,7 @@ int try_owner_push(const interpol_problem *p, const KParams &k, const void *val,
     const int nch = count_only ? 1 : k.C + (k.cc ? 1 : 0);
     Workspace w;
     if (((uintptr_t)workspace & 255u) != 0) return 0;                // (interpol_hip.h: 256-byte aligned, or the other scatters run)
-    if (layout(k, (int)p->batch, tile_count(p), nch, workspace, &w) > workspace_bytes) return 0;
+    if (layout(k, (int)p->batch, tile_count(p), nch, workspace, &w, 0, true) > workspace_bytes) return 0;
     const BrickGrid bg = brick_grid(k);
     const bool gated = !(p->flags & INTERPOL_FLAG_BINNED_SCATTER);
     // (a kernel, not hipMemsetAsync: under hipGraph capture the memset node of ROCm 7.2 was observed not to re-run on replays)
@@ -1703,11 +2141,38 @@ int try_owner_push(const interpol_problem *p, const KParams &k, const void *val,
     if (rc) return rc;
     const bool shared = p->vol_stride[0] == 0 && p->batch > 1;
     const long long want = 2ll * cu_count();
+    int *const hdri = (int *)w.hdr;
+    int *const nonsimple = hdri + 36;
+    const bool planned = !shared && w.nint > 0 && !(k.dbg & 2048);     // (debug bit 2048: own_accumulate alone, as in rounds 3-4)
+    if (planned) {
+        // the plan of every interior brick (own_plan), in one launch
+#define IP_OWN_PLAN(KK)                                                                                                 \
+        {                                                                                                               \
+            const int attr = big_lds<own_plan<KK>>(sizeof(PlanSmem));                                                   \
+            if (attr) return attr;                                                                                      \
+            hipLaunchKernelGGL((own_plan<KK>), dim3((unsigned)w.nint), dim3(NTP), sizeof(PlanSmem), st, k, bg, w.plan, (const int *)w.ndesc, \
+                               (const uint2 *)w.desc, (const unsigned short *)w.meta, (const int *)w.bmax, nch, gate, nonsimple);   \
+        }
+        if (k.order[0] == 3) IP_OWN_PLAN(3) else IP_OWN_PLAN(2)
+#undef IP_OWN_PLAN
+    }
     for (int color = shared ? 9 : 0; color < (shared ? 10 : 9); ++color) {
         long long nwork = B;
         for (int d = 0; d < 3; ++d) nwork *= color_count(color, d, bg);
         if (nwork <= 0) continue;
         const dim3 agrid((unsigned)(nwork < want ? nwork : want));
+        const bool lean = planned && color < 8;
+        if (lean) {
+#define IP_OWN_TAPS(KK)                                                                                                 \
+            {                                                                                                           \
+                const int attr = big_lds<own_taps<KK>>(sizeof(TapSmem));                                                \
+                if (attr) return attr;                                                                                  \
+                hipLaunchKernelGGL((own_taps<KK>), agrid, dim3(NTP), sizeof(TapSmem), st, k, bg, w.plan, (const float4 *)w.rec, \
+                                   (const float *)w.vals, (const int *)w.bmax, (float *)vol, nch, color, B, gate, hdri + 28 + color);  \
+            }
+            if (k.order[0] == 3) IP_OWN_TAPS(3) else IP_OWN_TAPS(2)
+#undef IP_OWN_TAPS
+        }
 #define IP_OWN_ACC(KK)                                                                                                  \
         {                                                                                                               \
             const int attr = big_lds<own_accumulate<KK>>(sizeof(AccSmem));                                              \
@@ -1715,7 +2180,7 @@ int try_owner_push(const interpol_problem *p, const KParams &k, const void *val,
             hipLaunchKernelGGL((own_accumulate<KK>), agrid, dim3(NT), sizeof(AccSmem), st, k, bg, (const int *)w.ndesc,  \
                                (const uint2 *)w.desc, (const float4 *)w.rec, (const float *)w.vals, (const unsigned short *)w.meta,  \
                                (const int *)w.bmax, w.nrec, (float *)vol, nch, color, B, gate, \
-                               (int *)w.hdr + 16 + color);                                                              \
+                               hdri + 16 + color, lean ? (const PlanHdr *)w.plan.hdr : (const PlanHdr *)nullptr, (const int *)nonsimple);  \
         }
         if (k.order[0] == 3) IP_OWN_ACC(3) else IP_OWN_ACC(2)
 #undef IP_OWN_ACC
