@@ -179,6 +179,20 @@ typedef struct interpol_problem {
  * (it INCLUDES the fp32 accumulator of a BF16 / F16 target, which comes first), or 0 when the
  * organisation does not apply.  With a smaller (or no) scratch -- or one that is not aligned to 256 bytes (the
  * workspace holds 8- and 16-byte records) -- the operators fall back to the tiled / generic scatters: same results.
+ *
+ * Accuracy of the LDS scatters (every fast path of interpol_push / interpol_count and of the scatter halves of the
+ * backward operators; INTERPOL_FLAG_NO_FASTPATH selects the generic kernels, which add floats like the reference's
+ * scatter_add_): contributions are summed in FIXED POINT scaled by the largest |source| of the tile / brick they belong
+ * to, so the error of a lattice point is ABSOLUTE per tile, not relative to the point's own value.
+ *   F32 / BF16 / F16, sample tiles (ops_tiled.hip, ops_tiled2d.hip): each addend rounded to 2^(h-29) of a power of two
+ *     >= that maximum, h = the headroom bits the tile's sample density asks for (at most 7);
+ *   F32 / BF16 / F16, bricks (push_owner.hip, "magic" format): each addend rounded to nearest at
+ *     max|source| * wmax^3 * 2^-22 / 0.999 (wmax = 2/3 cubic, 3/4 quadratic: 2^-23.75 resp. 2^-23.25 of the brick's
+ *     maximum), whatever the density; bricks whose stencil counts could overflow 32-bit sums use 64-bit sums of terms
+ *     rounded at 2^-30 of a power of two >= the maximum;
+ *   F64 (push_f64.hip): each addend rounded at 2^-51 of a power of two > the tile's maximum -- about 2^-52 of the tile's
+ *     largest source per term, again absolute per tile; tiles whose maximum is below 2^-970 use the generic arithmetic.
+ * Sums inside a tile / brick are integers: order-free, bit-reproducible.
  * --------------------------------------------------------------------------- */
 int64_t interpol_scatter_workspace(const interpol_problem *p, int32_t count_only);
 int interpol_pull(const interpol_problem *p, const void *vol, const void *grid, void *val, void *stream);

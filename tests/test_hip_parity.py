@@ -687,7 +687,8 @@ def test_hand_back_two_host_threads_on_one_stream(sample_tiles_only):
 def test_graph_capture_replays_correctly():
     """hipGraph capture of the operators (launch-bound inner loops, the system prompt's HIP graphs): everything is enqueued
     on the capturing stream, nothing synchronises, and the tile hand-back -- whose descriptors carry a per-launch number that
-    a replay would repeat -- stays out of captured launches.  Replays with new inputs must match eager calls."""
+    a replay would repeat -- stays out of captured launches.  Replays with new inputs must match eager calls.  (Round 5: the
+    routed pull's probe of the call decides anew at every replay -- the zoom grows from 1 to 2.6 across them.)"""
     from interpol import _hip
     gen = torch.Generator().manual_seed(77)
     ishape, oshape = (60, 50, 70), (40, 36, 48)
@@ -1521,6 +1522,33 @@ def test_routed_pull_bricks_of_the_image_against_oracle(sigma):
                     assert G.rel_err(got.cpu().numpy(), slow.cpu().numpy()) < 4e-6, (name, "vs generic", sigma, b, order, ex)
     finally:
         oracle.set_threads(1)
+
+
+def test_routed_pull_probe_of_the_call_decides_on_the_device():
+    """Round 5: interpol_pull_ws examines the call first (own_probe, mode -2): more than 1.5 % of the probed samples outside their
+    tile's LDS box -> the bricks of the image take every tile and pull_sorted returns at once; else the sample tiles run with the
+    per-tile hand-over behind them.  The verdict is the first word of the workspace (ProbeHdr::gate); it depends on the
+    coordinates of THIS call alone (the same inputs always take the same organisation: bit-identical reruns), and both verdicts
+    agree with the generic kernels."""
+    from interpol import _hip
+    g = torch.Generator().manual_seed(505)
+    shape = (64, 64, 64)
+    inp = torch.randn([2, 2, *shape], generator=g).to(DEV)
+    ident = interpol.identity_grid(shape)[None].expand(2, *shape, 3)
+    fields = {"identity": (ident.clone(), 0), "sigma 1": (ident + 1.0 * torch.randn(ident.shape, generator=g), 0),
+              "sigma 7": (ident + 7.0 * torch.randn(ident.shape, generator=g), 1), "zoom 2.5": ((ident - 31.5) * 2.5 + 31.5, 1)}
+    for name, (grid, verdict) in fields.items():
+        grid = grid.contiguous().to(DEV)
+        _hip.release_workspaces()
+        got = _hip.gather("pull", inp, grid, [3] * 3, [3] * 3, 1)
+        torch.cuda.synchronize()
+        (ws,) = list(_hip._WS_CACHE.values())
+        assert int(ws[:4].view(torch.int32)[0]) == verdict, (name, ws[:32].view(torch.int32).tolist())
+        want = _hip.gather("pull", inp, grid, [3] * 3, [3] * 3, 1, flags=_hip.FLAG_NO_FASTPATH)
+        assert G.rel_err(got.cpu().numpy(), want.cpu().numpy()) < 4e-6, name
+        again = _hip.gather("pull", inp, grid, [3] * 3, [3] * 3, 1)
+        assert torch.equal(got, again), name
+    _hip.release_workspaces()
 
 
 @pytest.mark.parametrize("sigma", [0.0, 2.0, 7.0])

@@ -61,7 +61,7 @@ int try_push_f64_tiles(const interpol_problem *, const KParams &, const void *, 
 int owner_pull_prepare(const interpol_problem *, const KParams &, void *, int64_t, hipStream_t, int **, int *);
 int owner_pull_finish(const interpol_problem *, const KParams &, const void *, const void *, void *, void *, int64_t, bool, hipStream_t,
                       bool grad = false, const void *gout = nullptr, bool probed = false, bool spatial = false);
-int owner_grad_probe(const interpol_problem *, const KParams &, const void *, void *, int64_t, hipStream_t);
+int owner_grad_probe(const interpol_problem *, const KParams &, const void *, void *, int64_t, hipStream_t, int mode = -1);
 int64_t gather5_workspace_bytes(const interpol_problem *, const KParams &);
 int try_gather5(const interpol_problem *, const KParams &, const void *, const void *, void *, void *, int64_t, int, const void *, hipStream_t, const int **);
 #ifdef IP_EXPERIMENTS
@@ -135,6 +135,8 @@ static int make_params(const interpol_problem *p, Role role, int trailing, KPara
     }
     if (max_off + vb > 0xffffffffull) return INTERPOL_E_SHAPE;      // one (b, c) image must fit 32-bit byte offsets
     k->mask_lo = -(p->extrapolate == 2 ? 0.5 + 5e-2 : 5e-2);
+    k->mask_lo_f = (float)k->mask_lo;
+    for (int d = 0; d < 3; ++d) k->mask_hi_f[d] = (float)k->mask_hi[d];
     // pushpull.py:48-66 : all orders 1 -> iso1 semantics, all 0 -> iso0, else nd
     k->mode = all1 ? MODE_ISO1 : (all0 ? MODE_ISO0 : MODE_ND);
     k->C = (int)p->channels;
@@ -331,8 +333,16 @@ static int routed_pull(const interpol_problem *p, KParams k, int B, const void *
     int rc = owner_pull_prepare(p, k, workspace, workspace_bytes, st, &flags, &nzero);
     if (rc != 1) return rc;
     if (p->flags & INTERPOL_FLAG_BINNED_SCATTER) { rc = owner_pull_finish(p, k, vol, grid, val, workspace, workspace_bytes, true, st); return rc ? rc : 1; }
-    // the sample tiles first: pull_sorted flags the tiles it leaves to the bricks (too many samples outside its LDS box)
-    k.gate = flags; k.gate_n = nzero;
+    // A probe of the call first (round 5; stateless, no host synchronisation, hipGraph-safe -- the same kernel as the scatters' and
+    // the grid gradient's): a rough dense sampling goes to the bricks altogether and pull_sorted returns at once.  Else the sample
+    // tiles run and flag the tiles they leave to the bricks (too many samples outside their LDS box), as in round 4.
+    const bool probe = p->dtype == INTERPOL_F32 && !(k.dbg & (32 | 16384));       // (debug bit 16384: no probe, the per-tile hand-over alone)
+    if (probe) {
+        rc = owner_grad_probe(p, k, grid, workspace, workspace_bytes, st, -2);     // (clears the header and the brick counters as well)
+        if (rc) return rc;
+    }
+    k.gate = flags; k.gate_n = probe ? 0 : nzero;
+    k.verdict = probe ? flags - nzero : nullptr;                     // ProbeHdr::gate, the first word of the header
 #ifdef IP_EXPERIMENTS
     if (p->dtype == INTERPOL_F32 && !(k.dbg & (4096 | 32)) && (p->flags & INTERPOL_FLAG_SMALL_TILES)) {
         // (opt-in experiment) the single-pass small-box tiles first (pull_direct.hip: smooth deformations); they write every flag
@@ -356,7 +366,7 @@ static int routed_pull(const interpol_problem *p, KParams k, int B, const void *
     rc = try_sorted_pull_f32(p, k, vol, grid, val, st);
     if (rc != 1) return rc;
     if (k.dbg & 32768) return 1;                                     // (ablation: the tiles with their flags, no brick kernels behind them)
-    rc = owner_pull_finish(p, k, vol, grid, val, workspace, workspace_bytes, false, st);
+    rc = owner_pull_finish(p, k, vol, grid, val, workspace, workspace_bytes, false, st, false, nullptr, probe);
     return rc ? rc : 1;
 }
 
@@ -877,6 +887,7 @@ int interpol_resample_1d(int32_t dtype, int32_t lin_dtype, int32_t order, int32_
     k.N = n_samples;
     k.mask_lo = -(extrapolate == 2 ? 0.5 + 5e-2 : 5e-2);
     k.mask_hi[0] = (double)(n_lattice - 1) + (extrapolate == 2 ? 0.5 + 5e-2 : 5e-2);
+    k.mask_lo_f = (float)k.mask_lo; k.mask_hi_f[0] = (float)k.mask_hi[0];
     return launch_resample1d(dtype, lin_dtype == INTERPOL_F64, order, k, adjoint, src, lin, dst, (unsigned)n_samples, (unsigned)inner,
                              n_lattice, outer, st);
 }

@@ -157,8 +157,8 @@ struct Tile {
             inbmask = 0;
 #pragma unroll
             for (int v = 0; v < VPT; ++v)
-                if (c[v][0] > (float)p.mask_lo && c[v][0] < (float)p.mask_hi[0] && c[v][1] > (float)p.mask_lo && c[v][1] < (float)p.mask_hi[1]
-                    && c[v][2] > (float)p.mask_lo && c[v][2] < (float)p.mask_hi[2])
+                if (c[v][0] > p.mask_lo_f && c[v][0] < p.mask_hi_f[0] && c[v][1] > p.mask_lo_f && c[v][1] < p.mask_hi_f[1]
+                    && c[v][2] > p.mask_lo_f && c[v][2] < p.mask_hi_f[2])
                     inbmask |= 1u << v;
         }
         // ---- first-tap index (kept as a float: exact, and it saturates nowhere) and stencil coordinate
@@ -316,6 +316,9 @@ __global__ __launch_bounds__(NT, 4) void pull_sorted(KParams p, const T *__restr
 #pragma unroll
     for (int d = 0; d < 3; ++d) { L.bound[d] = p.bound[d]; L.n[d] = p.vol_n[d]; L.ss[d] = p.vol_ss[d] / (int)sizeof(T); L.k[d] = K; }
     L.lin = 0;
+#ifndef IP_NOVERDICT
+    if (p.verdict && *p.verdict == 1) return;                        // the probe of the call gave every tile to the bricks (abi.hip: routed_pull)
+#endif
     if (p.gate && p.gate_n > 0) {
         // interpol_pull_ws: the header, brick counters and brick list of the bricks' workspace lie in front of the tile flags; the
         // sample tiles clear them on their way (own_bin, launched behind this kernel, counts in them): no launch of its own

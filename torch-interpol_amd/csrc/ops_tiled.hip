@@ -235,7 +235,7 @@ __device__ __forceinline__ Sample<C> load_sample(const KParams &p, const float *
 #pragma unroll
     for (int d = 0; d < 3; ++d) {
         if (C::pd(d) < 0) continue;
-        if (p.extrapolate != 1) s.inb = s.inb && x[d] > (float)p.mask_lo && x[d] < (float)p.mask_hi[C::pd(d) < 0 ? 0 : C::pd(d)];
+        if (p.extrapolate != 1) s.inb = s.inb && x[d] > p.mask_lo_f && x[d] < p.mask_hi_f[C::pd(d) < 0 ? 0 : C::pd(d)];
         int i0; float t;
         split(kd[d], x[d], i0, t);
         s.i0[d] = s.valid ? i0 : 0;
@@ -445,7 +445,7 @@ __device__ __forceinline__ bool coords_inb(const KParams &p, const float *x)
     bool in = true;
 #pragma unroll
     for (int d = 0; d < 3; ++d)
-        if (C::pd(d) >= 0) in = in && x[d] > (float)p.mask_lo && x[d] < (float)p.mask_hi[C::pd(d) < 0 ? 0 : C::pd(d)];
+        if (C::pd(d) >= 0) in = in && x[d] > p.mask_lo_f && x[d] < p.mask_hi_f[C::pd(d) < 0 ? 0 : C::pd(d)];
     return in;
 }
 

@@ -244,7 +244,7 @@ struct Tile2 {
         int mn[2] = { 0x7fffffff, 0x7fffffff }, mx[2] = { -0x7fffffff, -0x7fffffff };
 #pragma unroll
         for (int v = 0; v < VPT; ++v) {
-            if (p.extrapolate == 1 || (c[v][0] > (float)p.mask_lo && c[v][0] < (float)p.mask_hi[0] && c[v][1] > (float)p.mask_lo && c[v][1] < (float)p.mask_hi[1]))
+            if (p.extrapolate == 1 || (c[v][0] > p.mask_lo_f && c[v][0] < p.mask_hi_f[0] && c[v][1] > p.mask_lo_f && c[v][1] < p.mask_hi_f[1]))
                 inb |= 1u << v;
             splitk<K0>(c[v][0], i0[v][0], t0[v]);
             splitk<K1>(c[v][1], i0[v][1], t1[v]);

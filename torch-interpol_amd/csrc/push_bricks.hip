@@ -79,7 +79,7 @@ __device__ __forceinline__ int classify(const KParams &p, const float *x, int *i
     bool inb = true, inside = true;
 #pragma unroll
     for (int d = 0; d < 3; ++d) {
-        if (p.extrapolate != 1) inb = inb && x[d] > (float)p.mask_lo && x[d] < (float)p.mask_hi[d];   // nd.py:10-27
+        if (p.extrapolate != 1) inb = inb && x[d] > p.mask_lo_f && x[d] < p.mask_hi_f[d];   // nd.py:10-27
         split1(p, d, x[d], i0[d], t[d]);
         inside = inside && i0[d] >= (p.bound[d] == B_DST1 ? 1 : 0) && i0[d] + p.order[d] < p.vol_n[d];
     }

@@ -103,9 +103,10 @@ __global__ __launch_bounds__(NT) void push_f64_tiled(KParams p, const double *__
     for (int d = 0; d < 3; ++d) {
         int l = sm.lo[d], h = sm.hi[d];
         if (h < l) { l = 0; h = 0; }
-        int sz = h - l + 1;
-        if (sz > CAP) { l += (sz - CAP) / 2; sz = CAP; }              // keep the centre; the rest scatters directly
-        lo[d] = l; S[d] = sz;
+        // (64-bit: first taps clamped to both -2^30 and +2^30 in one tile -- infinite or huge coordinates -- would overflow int)
+        long long sz = (long long)h - (long long)l + 1;
+        if (sz > CAP) { l = (int)((long long)l + (sz - CAP) / 2); sz = CAP; }     // keep the centre; the rest scatters directly
+        lo[d] = l; S[d] = (int)sz;
     }
     if (tid < 3 * CAP) {
         const int d = tid / CAP, slot = tid - d * CAP;
@@ -123,7 +124,7 @@ __global__ __launch_bounds__(NT) void push_f64_tiled(KParams p, const double *__
     for (int v = 0; v < VPT; ++v) {
         inbox[v] = valid[v];
 #pragma unroll
-        for (int d = 0; d < 3; ++d) inbox[v] = inbox[v] && i0[v][d] >= lo[d] && i0[v][d] + p.order[d] <= lo[d] + S[d] - 1;
+        for (int d = 0; d < 3; ++d) inbox[v] = inbox[v] && i0[v][d] >= lo[d] && (long long)i0[v][d] + p.order[d] <= (long long)lo[d] + S[d] - 1;
     }
 
     for (int c = 0; c < p.C; ++c) {
@@ -146,11 +147,13 @@ __global__ __launch_bounds__(NT) void push_f64_tiled(KParams p, const double *__
         if (!fin) sm.nonfinite = 1;
         atomicMax(&sm.amax, am);
         __syncthreads();
-        const bool direct_all = sm.nonfinite != 0;                    // (block-uniform) no fixed-point scale: the generic arithmetic
         const double amaxd = __longlong_as_double((long long)sm.amax);
         // scale = 2^(51 - e) with 2^e > max |source| (weights <= 1: every term below 2^51)
         int ex = 0;
         (void)frexp(amaxd, &ex);
+        // (block-uniform) no fixed-point scale -- non-finite sources, or sources so small that 2^(51 - e) is not a double
+        // (max |source| < 2^-970): the generic arithmetic
+        const bool direct_all = sm.nonfinite != 0 || ex < -960;
         const double scale = ldexp(1., 51 - ex), inv = ldexp(1., ex - 51);
         if (amaxd > 0. || direct_all) {
 #pragma unroll

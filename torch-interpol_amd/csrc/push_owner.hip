@@ -1459,6 +1459,7 @@ __global__ __launch_bounds__(NT, 4) void own_gather(KParams p, BrickGrid bg, con
 constexpr int NPROBE = 128;
 constexpr int BOXVOL = 14500;
 constexpr int DENSEVOL = 13000;
+constexpr int PULLOUT = 15;                     // own_probe, pull: per mille of the probed samples outside their tile's box beyond which the bricks take the call
 struct ProbeHdr { int gate, done, nslow, nfar, nvalid, nbox, nfull, ncorner; };
 
 template <int K, int GM>
@@ -1536,7 +1537,9 @@ __global__ __launch_bounds__(NT1) void own_probe(KParams p, BrickGrid bg, const 
         }
         if (!in) ++slow;
     }
-    atomicAdd(&cnt[0], slow); atomicAdd(&cnt[1], far); atomicAdd(&cnt[2], nv);
+    // (one LDS add per wave: 3 x 512 adds to the same three words took a third of the kernel)
+    slow = wave_sum(slow); far = wave_sum(far); nv = wave_sum(nv);
+    if ((tid & 63) == 0) { atomicAdd(&cnt[0], slow); atomicAdd(&cnt[1], far); atomicAdd(&cnt[2], nv); }
     __syncthreads();
     if (tid == 0) {
         atomicAdd(&hdr->nslow, cnt[0]); atomicAdd(&hdr->nfar, cnt[1]); atomicAdd(&hdr->nvalid, cnt[2]);
@@ -1559,7 +1562,14 @@ __global__ __launch_bounds__(NT1) void own_probe(KParams p, BrickGrid bg, const 
             // of a tile span at most DENSEVOL lattice points on average (19^3 at the identity, 27^3 at zoom 1.5), or the tiles leave
             // samples outside their boxes
             const bool dense = (int64_t)nc <= (int64_t)DENSEVOL * nt;
-            if (nch < 0) hdr->gate = (((int64_t)ns * 250 > nn || dense) && (int64_t)nf * 64 <= nn) ? 1 : 0;
+            // nch == -2, the pull itself (round 5): the sample tiles win while their LDS boxes hold the stencils (identity 1.02 against
+            // 1.39 ms, i.i.d. sigma = 3 -- 0.6 % of the probed samples outside their tile's box -- 1.58 / 1.75) and fall behind quickly
+            // beyond (every sample outside costs a wave: 3.1 % outside -- sigma = 4, a folding smooth field of amplitude 8 -- 2.4 / 1.8
+            // and 5.2 / 1.6 ms; sigma = 6, 15 %: 9.7 / 1.9; zoom 2, 23 %: 7.5 / 3.6): the bricks when more than PULLOUT per mille of the
+            // probed samples lie outside -- BEFORE the tiles pay their coordinate loads and sort (the per-tile hand-over of round 4,
+            // which remains behind it, came after: 2.8 ms at sigma = 6, 2.4 on the folding field)
+            if (nch == -2) hdr->gate = ((int64_t)ns * 1000 > (int64_t)nn * PULLOUT && (int64_t)nf * 64 <= nn) ? 1 : 0;
+            else if (nch < 0) hdr->gate = (((int64_t)ns * 250 > nn || dense) && (int64_t)nf * 64 <= nn) ? 1 : 0;
             else hdr->gate = (((int64_t)ns * 250 > nn || rough) && (int64_t)nf * 64 <= nn) ? 1 : 0;
         }
     }
@@ -1768,7 +1778,7 @@ int owner_pull_prepare(const interpol_problem *p, const KParams &k, void *worksp
 }
 // Step 1b (grid gradient, INTERPOL_FLAG_AUTO_SCATTER): clear the counters and let the probe decide whether EVERY tile goes to the
 // bricks (hdr->gate = 1: gradc_sorted returns at once, own_bin takes every tile) or the sample tiles run and flag what they leave
-int owner_grad_probe(const interpol_problem *p, const KParams &k, const void *grid, void *workspace, int64_t workspace_bytes, hipStream_t st)
+int owner_grad_probe(const interpol_problem *p, const KParams &k, const void *grid, void *workspace, int64_t workspace_bytes, hipStream_t st, int mode)
 {
     using namespace owner;
     const int ntiles = tile_count(p);
@@ -1782,7 +1792,7 @@ int owner_grad_probe(const interpol_problem *p, const KParams &k, const void *gr
     const int nty = (gy + TS - 1) / TS, ntz = (gz + TS - 1) / TS;
     const long long total = (long long)ntiles * B;
     const dim3 pgrid((unsigned)(total < NPROBE ? total : NPROBE));
-#define IP_OWN_PROBE(KK, GM) hipLaunchKernelGGL((own_probe<KK, GM>), pgrid, dim3(NT1), 0, st, k, bg, (const float *)grid, w.hdr, gx, gy, gz, nty, ntz, ntiles, B, -1);
+#define IP_OWN_PROBE(KK, GM) hipLaunchKernelGGL((own_probe<KK, GM>), pgrid, dim3(NT1), 0, st, k, bg, (const float *)grid, w.hdr, gx, gy, gz, nty, ntz, ntiles, B, mode);
 #define IP_OWN_PROBE_GM(KK) { if (k.sep == 0) IP_OWN_PROBE(KK, 0) else if (k.sep == 1) IP_OWN_PROBE(KK, 1) else if (k.sep == 2) IP_OWN_PROBE(KK, 2) else IP_OWN_PROBE(KK, 3) }
     if (k.order[0] == 3) IP_OWN_PROBE_GM(3) else IP_OWN_PROBE_GM(2)
 #undef IP_OWN_PROBE_GM
@@ -1806,7 +1816,7 @@ int owner_pull_finish(const interpol_problem *p, const KParams &k, const void *v
     // (spatial: grid_grad through the bricks -- the records of the pull; with the probe every tile or none, own_gather is gated)
     int rc = grad ? launch_bin<float, 2>(p, kk, bg, w, vol, grid, val, all ? nullptr : w.flags, st, gout, probed ? &w.hdr->gate : nullptr)
            : spatial ? launch_bin<float, 3>(p, kk, bg, w, vol, grid, val, nullptr, st, nullptr, probed ? &w.hdr->gate : nullptr)
-                  : launch_bin<float, 1>(p, kk, bg, w, vol, grid, val, all ? nullptr : w.flags, st);
+                  : launch_bin<float, 1>(p, kk, bg, w, vol, grid, val, all ? nullptr : w.flags, st, nullptr, probed ? &w.hdr->gate : nullptr);
     if (rc) return rc;
     const long long want = 2ll * cu_count();
     const dim3 ggrid((unsigned)(w.nbricks < want ? w.nbricks : want));

@@ -140,8 +140,8 @@ __device__ __forceinline__ void st4(T *p, float4 v)
 __device__ __forceinline__ float inb_mask(const KParams &p, const float *x)
 {
     if (p.extrapolate == 1) return 1.f;
-    const bool inb = x[0] > (float)p.mask_lo && x[0] < (float)p.mask_hi[0] && x[1] > (float)p.mask_lo
-                  && x[1] < (float)p.mask_hi[1] && x[2] > (float)p.mask_lo && x[2] < (float)p.mask_hi[2];
+    const bool inb = x[0] > p.mask_lo_f && x[0] < p.mask_hi_f[0] && x[1] > p.mask_lo_f
+                  && x[1] < p.mask_hi_f[1] && x[2] > p.mask_lo_f && x[2] < p.mask_hi_f[2];
     return inb ? 1.f : 0.f;
 }
 

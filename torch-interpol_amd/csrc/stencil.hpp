@@ -59,7 +59,10 @@ struct KParams {
     int64_t val_sb, val_sc; // val : spatial (+ trailing d,e) dims contiguous
     double mask_lo;         // -threshold
     double mask_hi[3];      // n-1+threshold
+    float mask_lo_f, mask_hi_f[3];   // the same as floats (float kernels: scalar loads instead of a conversion hoisted into -- spilled -- VGPRs)
     int gate_n;             // interpol_pull_ws: ints in front of `gate` (header, brick counters, brick list) that pull_sorted zeroes for own_bin
+    const int *verdict;     // interpol_pull_ws (round 5): the word the probe of THIS call writes (push_owner.hip: own_probe) -- 1: the bricks of the
+                            // image take every tile, pull_sorted returns at once
     const int *gate;        // scatters under INTERPOL_FLAG_AUTO_SCATTER: a device word written by the roughness probe of this call
                             // (push_owner.hip); the tiled / generic scatter kernels return at once when it is non-zero
 };

@@ -72,6 +72,61 @@ class HipExtensionMissing(ImportError):
     pass
 
 
+# Workspaces of the probe-routed organisations (bricks of the target / of the image) are OPTIONAL: every operator has an
+# organisation that needs none.  ONE buffer per (device, stream) is kept between calls and grown on demand (pull, push and the
+# backward passes of a stream share it: their kernels are ordered by the stream, and a captured hipGraph keeps pointing at live
+# memory); `release_workspaces()` gives it back.  A miss asks torch's caching allocator, but only when the request fits
+# comfortably: asking for more than it can give makes the allocator synchronise the device and flush its cache before it
+# raises -- on every call, if the caller runs near capacity.  So a new buffer never takes more than half of what is available
+# (free device memory + the allocator's own free blocks) and a request that failed is not repeated until noticeably more
+# memory is available.  (The allocator's statistics cost ~0.25 ms of host time: they are consulted on misses only.)
+_WS_CACHE = {}                                       # (device index, stream handle) -> uint8 tensor
+_WS_DENIED = {}                                      # device index -> (bytes asked for, bytes available at the time)
+_WS_CHECK_ABOVE = 64 << 20
+
+
+def release_workspaces():
+    """Drop the cached workspaces (they return to torch's caching allocator)."""
+    _WS_CACHE.clear()
+    _WS_DENIED.clear()
+
+
+def _available(idx):
+    free, _ = torch.cuda.mem_get_info(idx)
+    return free + torch.cuda.memory_reserved(idx) - torch.cuda.memory_allocated(idx)
+
+
+def _optional_workspace(nbytes, dev):
+    """nbytes of device scratch, or None when the call should do without (no exception, no allocator flush)."""
+    if nbytes <= 0:
+        return None
+    idx = dev.index if dev.index is not None else torch.cuda.current_device()
+    key = (idx, int(torch.cuda.current_stream(dev).cuda_stream))
+    ws = _WS_CACHE.get(key)
+    if ws is not None and ws.numel() >= nbytes:
+        return ws
+    avail = None
+    if nbytes > _WS_CHECK_ABOVE:
+        if ws is not None:
+            del _WS_CACHE[key]                       # (the old buffer goes back to the allocator first: it counts as available)
+            ws = None
+        avail = _available(idx)
+        denied = _WS_DENIED.get(idx)
+        if denied is not None and nbytes >= denied[0] and avail < denied[1] + denied[0] // 2:
+            return None
+        if 2 * nbytes > avail:
+            return None
+    try:
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    except torch.cuda.OutOfMemoryError:
+        _WS_DENIED[idx] = (nbytes, avail if avail is not None else _available(idx))
+        return None
+    if _WS_DENIED:
+        _WS_DENIED.pop(idx, None)
+    _WS_CACHE[key] = ws
+    return ws
+
+
 def lib():
     """Load the HIP library (once).  Fails loudly when it has not been built."""
     global _lib
@@ -323,12 +378,8 @@ def gather(op, vol, grid, bound, order, extrapolate, flags=0, out=None):
     if routed:
         # workspace of the routed pull (18 B per sample + 2 KiB per brick of the image; 0: the organisation does not apply).  When
         # it cannot be allocated the call is the plain interpol_pull: the sample tiles need none.
-        ws, wbytes = None, int(L.interpol_pull_workspace(ctypes.byref(p)))
-        if wbytes > 0:
-            try:
-                ws = torch.empty(wbytes, dtype=torch.uint8, device=dev)
-            except torch.cuda.OutOfMemoryError:
-                ws, wbytes = None, 0
+        wbytes = int(L.interpol_pull_workspace(ctypes.byref(p)))
+        ws = _optional_workspace(wbytes, dev)
         if ws is not None:
             with torch.cuda.device(dev):
                 rc = (L.interpol_pull_ws if op == "pull" else L.interpol_grad_ws)(ctypes.byref(p), _ptr(vol), _ptr(grid), _ptr(val), _ptr(ws), wbytes, _stream(dev))
@@ -412,21 +463,21 @@ def scatter(op, val, grid, shape, bound, order, extrapolate, flags=0, out=None, 
     if dt in (torch.bfloat16, torch.float16):
         sbytes = max(sbytes, vol.numel() * 4)
     if sbytes > 0:
-        try:
-            scratch = torch.empty(sbytes, dtype=torch.uint8, device=dev)
-        except torch.cuda.OutOfMemoryError:
+        if flags & FLAG_AUTO_SCATTER:
             # The probe-routed default asks for the owner-computes workspace (~22 B per sample + 1 KiB per brick, api.py)
-            # whether or not the probe will pick that organisation; when it does not fit, the call falls back to the tiles,
-            # which need none -- a push that fitted without the router still fits.
-            if not (flags & FLAG_AUTO_SCATTER):
-                raise
-            flags &= ~FLAG_AUTO_SCATTER
-            p = make_problem(dim, dt, gdt, bound, order, extrapolate, B, C, shape, gshape,
-                             vstr, _grid_strides(grid, B, dim), valstr, flags)
-            sbytes = int(L.interpol_scatter_workspace(ctypes.byref(p), 1 if op == "count" else 0))
-            if dt in (torch.bfloat16, torch.float16):
-                sbytes = max(sbytes, vol.numel() * 4)
-            scratch = torch.empty(sbytes, dtype=torch.uint8, device=dev) if sbytes > 0 else None
+            # whether or not the probe will pick that organisation; when it does not fit comfortably (_optional_workspace), the
+            # call falls back to the tiles, which need none -- a push that fitted without the router still fits.
+            scratch = _optional_workspace(sbytes, dev)
+            if scratch is None:
+                flags &= ~FLAG_AUTO_SCATTER
+                p = make_problem(dim, dt, gdt, bound, order, extrapolate, B, C, shape, gshape,
+                                 vstr, _grid_strides(grid, B, dim), valstr, flags)
+                sbytes = int(L.interpol_scatter_workspace(ctypes.byref(p), 1 if op == "count" else 0))
+                if dt in (torch.bfloat16, torch.float16):
+                    sbytes = max(sbytes, vol.numel() * 4)
+                scratch = torch.empty(sbytes, dtype=torch.uint8, device=dev) if sbytes > 0 else None
+        else:
+            scratch = torch.empty(sbytes, dtype=torch.uint8, device=dev)
         if scratch is not None and _POISON_SCRATCH:
             scratch.fill_(0xff)                          # (debugging aid: INTERPOL_POISON_SCRATCH=1 -- the kernels must not depend on stale workspace contents)
     with torch.cuda.device(dev):
@@ -501,11 +552,8 @@ def pull_backward(gout, vol, grid, bound, order, extrapolate, need_vol, need_gri
                      vstr, _grid_strides(grid_c, B, dim), valstr, flags | routed)
     if routed:
         wbytes = int(lib().interpol_pull_workspace(ctypes.byref(p)))
-        if wbytes > 0:
-            try:
-                scratch, sbytes = torch.empty(wbytes, dtype=torch.uint8, device=dev), wbytes
-            except torch.cuda.OutOfMemoryError:
-                scratch, sbytes = None, 0
+        scratch = _optional_workspace(wbytes, dev)
+        sbytes = wbytes if scratch is not None else 0
         if scratch is None:
             p.flags &= ~(FLAG_AUTO_SCATTER | FLAG_BINNED_SCATTER)
     with torch.cuda.device(dev):
@@ -557,12 +605,8 @@ def push_backward(gvol_out, val, grid, bound, order, extrapolate, need_val, need
         routed = FLAG_BINNED_SCATTER
     if routed:
         p.flags |= routed
-        ws, wbytes = None, int(L.interpol_pull_workspace(ctypes.byref(p)))
-        if wbytes > 0:
-            try:
-                ws = torch.empty(wbytes, dtype=torch.uint8, device=dev)
-            except torch.cuda.OutOfMemoryError:
-                ws = None
+        wbytes = int(L.interpol_pull_workspace(ctypes.byref(p)))
+        ws = _optional_workspace(wbytes, dev)
         if ws is not None:
             with torch.cuda.device(dev):
                 rc = L.interpol_push_backward_ws(ctypes.byref(p), _ptr(gvol_out), _ptr(None if count else val), _ptr(grid_c),

@@ -23,9 +23,10 @@ exact_scatter = False
 # `rough_deformations = None` (default): a probe kernel inside every call examines 128 tiles of the sample grid and
 # gates the two organisations on the device (no host synchronisation, stateless, hipGraph-safe; ~50 us).
 # Memory: under the default (and under True) every 3-D quadratic / cubic grid_push / grid_count -- and the image gradient of
-# grid_pull's backward, which is such a push -- allocates the bricks' workspace for the duration of the call: about 22 bytes per
-# sample point plus 1 KiB per 16^3 brick of the target (1.7 GB at 4x2x256^3), whichever organisation the probe then picks.  When
-# that allocation fails the call falls back to the tiles, which need none (interpol/_hip.py: scatter).
+# grid_pull's backward, which is such a push -- uses the bricks' workspace: about 22 bytes per sample point plus 1 KiB per 16^3 brick
+# of the target (1.7 GB at 4x2x256^3), whichever organisation the probe then picks.  One buffer per (device, stream) is kept
+# between calls and grown on demand (`release_workspaces()` frees it); it is only taken when it fits comfortably (at most half of
+# the memory that is available), else the call falls back to the tiles, which need none (interpol/_hip.py: _optional_workspace).
 # grid_pull (3-D quadratic / cubic, float32) is routed too, per TILE: the sample tiles of csrc/ops_sorted.hip leave the tiles whose
 # LDS box cannot hold their stencils to bricks of the IMAGE (csrc/push_owner.hip: own_gather; 18 bytes of workspace per sample,
 # allocated per call like the push's): 4x2x256^3 cubic under i.i.d. noise of sigma = 6 voxels 9.8 -> 3 ms; ~3 % on smooth fields.
@@ -37,6 +38,13 @@ exact_scatter = False
 # (1e-5 of max|ref|).  Under None / True the backward of grid_pull is two passes (image gradient = grid_push of grad_out through
 # this router, then the grid gradient), not the fused kernel.
 rough_deformations = None
+
+
+def release_workspaces():
+    """The routed organisations keep ONE workspace per (device, stream) between calls (interpol/_hip.py: _optional_workspace;
+    1.7 GB at 4x2x256^3 once a push has run, shared by pull / push / backward): this gives them back to torch's allocator."""
+    from . import _hip
+    _hip.release_workspaces()
 
 
 def want_exact_scatter():
