@@ -339,6 +339,12 @@ float   interpol_host_weight_f32(int32_t order, float x, int32_t which);
  *       smooth workloads never pay the second kernel, but a result can depend on the history of the stream;
  *   INTERPOL_HANDBACK_ALWAYS / _NEVER: every launch / no launch hands back: each operator is then a deterministic
  *       function of its inputs, as the reference's gather is (nd.py:118-136).
+ * Round 5: the hand-back only exists where no device-side router does.  Calls that carry a workspace for the bricks --
+ * interpol_push / interpol_count with INTERPOL_FLAG_AUTO_SCATTER or _BINNED_SCATTER, interpol_pull_ws, interpol_grad_ws,
+ * interpol_pull_backward / interpol_push_backward_ws with the bricks' workspace (3-D, orders 2 - 5 as each entry point
+ * documents) -- never hand back: their organisation is chosen by a probe of THIS call's coordinates, so the result is a
+ * function of the inputs under every mode (tests: test_routed_operators_do_not_depend_on_the_streams_history).  The modes
+ * below still govern 2-D problems, order 1, orders 6 - 7, the order 4 - 5 scatters and every call without a workspace.
  * interpol_set_handback(mode) returns the previous mode (process-wide; the environment variable
  * INTERPOL_HANDBACK = adaptive | always | never sets the initial one).
  * interpol_release_stream(stream): the hand-back slot (3 MiB of device memory) of `stream` on the current device goes

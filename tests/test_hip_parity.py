@@ -656,6 +656,34 @@ def test_pinned_hand_back_mode_is_history_independent(mode, sample_tiles_only):
         _hip.set_handback(prev)
 
 
+def test_routed_operators_do_not_depend_on_the_streams_history():
+    """Round 5: under the DEFAULT hand-back mode (adaptive) the operators that have a device-side router --
+    3-D quadratic / cubic pull, grid_grad, push, count and the backward passes, all with the bricks' workspace the Python layer
+    gives them -- are functions of their inputs: the same stretched call before and after a run of smooth and of stretched
+    launches on the same stream is torch.equal (the reference's gather is such a function: nd.py:118-136)."""
+    from interpol import _hip
+    assert _hip.set_handback("adaptive") in ("adaptive", "always", "never")
+    vol, grid = _stretched_problem(12)
+    smooth = _stretched_problem(13, scale=1.0)[1]
+    harsh = _stretched_problem(14, scale=3.5)[1]
+    b, o = [3] * 3, [3] * 3
+    src = torch.randn([vol.shape[0], vol.shape[1], *grid.shape[1:-1]], generator=torch.Generator().manual_seed(9)).to(DEV)
+    ops_ = {
+        "pull": lambda g_: _hip.gather("pull", vol, g_, b, o, 1),
+        "grad": lambda g_: _hip.gather("grad", vol, g_, b, o, 1),
+        "pull backward (grid)": lambda g_: _hip.pull_backward(src, vol, g_, b, o, 1, False, True)[1],
+        "push backward": lambda g_: torch.cat([t.reshape(-1) for t in _hip.push_backward(vol, src, g_, b, o, 1, True, True)]),
+    }
+    for name, fn in ops_.items():
+        first = fn(grid)
+        for _ in range(6):
+            fn(smooth)
+        for _ in range(6):
+            fn(harsh)
+        again = fn(grid)
+        assert torch.equal(first, again), name
+
+
 def test_hand_back_two_host_threads_on_one_stream(sample_tiles_only):
     """Two host threads launch stretched workloads on the SAME stream: the slot's lease keeps each tile kernel and its deferred
     generic kernel together (interleaved, the second launch's descriptors would hide the first's: tiles silently skipped)."""
