@@ -318,8 +318,8 @@ def test_grid_helpers():
 
 def test_double_backward_flows_through_the_operators():
     """create_graph=True: the backward passes are composed from the differentiable Functions
-    (reference pushpull.py:237-325 is plain torch and differentiates twice); third order through
-    grid_grad is refused loudly instead of being dropped."""
+    (reference pushpull.py:237-325 is plain torch and differentiates twice); third order and beyond through
+    grid_grad's backward too (round 5)."""
     import interpol
     torch.manual_seed(3)
     x = torch.randn(1, 2, 5, 6, dtype=torch.float64, requires_grad=True)
@@ -344,11 +344,22 @@ def test_double_backward_flows_through_the_operators():
         fd = (penalty(x + eps * d) - penalty(x - eps * d)) / (2 * eps)
         fd = float(fd.detach())
         assert abs(fd - float((gx * d).sum())) < 1e-5 * max(1.0, abs(fd))
-        # third order through grid_grad's backward: not implemented -> raises
-        z = interpol.grid_grad(x, g, **kw)
-        g1, = torch.autograd.grad(z.square().sum(), g, create_graph=True)
-        with pytest.raises(RuntimeError):
-            torch.autograd.grad(g1.sum(), g)
+        # third order through grid_grad's backward (round 5: autograd differentiates the torch restatement of grid_grad, as the
+        # reference differentiates its own plain-torch backward, pushpull.py:303-325): d/dg and d/dx of sum(d |grid_grad|^2 / dg)
+        # against finite differences, and once more (fourth order) for the shape of it
+        def first(xx, gg_):
+            z = interpol.grid_grad(xx, gg_, **kw)
+            return torch.autograd.grad(z.square().sum(), gg_, create_graph=True)[0]
+        g1 = first(x, g)
+        h_g, h_x = torch.autograd.grad(g1.sum(), (g, x), create_graph=True)
+        dg, dx = torch.randn_like(g), torch.randn_like(x)
+        eps = 1e-5
+        fd_g = float((first(x, g + eps * dg).sum() - first(x, g - eps * dg).sum()).detach()) / (2 * eps)
+        fd_x = float((first(x + eps * dx, g).sum() - first(x - eps * dx, g).sum()).detach()) / (2 * eps)
+        assert abs(fd_g - float((h_g * dg).sum().detach())) < 1e-5 * max(1.0, abs(fd_g))
+        assert abs(fd_x - float((h_x * dx).sum().detach())) < 1e-5 * max(1.0, abs(fd_x))
+        fourth, = torch.autograd.grad(h_g.square().sum(), g)
+        assert fourth.shape == g.shape and bool(torch.isfinite(fourth).all())
 
 
 def test_affine_grid_lazy_lattice_host_logic():

@@ -26,9 +26,11 @@ Autograd.  First-order gradients run the fused HIP kernels.  Under `create_graph
 backward: gradient penalties, Hessian-vector products) the backward is composed from the
 differentiable Functions of `autograd.py` instead, as the reference composes its backward from torch
 ops (pushpull.py:237-325): the gradient with respect to the grid then materialises `grid_grad`'s
-(B, C, *out, D) tensor -- C x D times the memory of the grid, and a second pass -- and third-order
-derivatives through the grid (a backward of that double backward) raise instead of being dropped
-(`GridGrad.backward` is once-differentiable; the reference, being plain torch, differentiates on).
+(B, C, *out, D) tensor -- C x D times the memory of the grid, and a second pass.  Third-order
+derivatives and beyond through the grid (a backward of that double backward) differentiate on, as
+the reference's plain-torch backward does: `GridGrad.backward` under `create_graph=True` lets
+autograd differentiate the PyTorch restatement of `grid_grad` (`torch_kernels.py`) -- correct at
+any order, at PyTorch speed and memory (the fused kernels carry no graph).
 """
 import torch
 

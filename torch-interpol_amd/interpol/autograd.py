@@ -174,11 +174,27 @@ class GridGrad(torch.autograd.Function):
         return output
 
     @staticmethod
-    @torch.autograd.function.once_differentiable      # third-order terms are not implemented: raise instead of dropping them
     @_bwd
     def backward(ctx, grad):
         input, grid = _saved(ctx)
         grad_input = grad_grid = None
+        if _higher_order() and (ctx.needs_input_grad[0] or ctx.needs_input_grad[1]):
+            # Third order and beyond (create_graph=True inside a double backward).  The reference's backward is plain torch and
+            # differentiates on (pushpull.py:303-325); the fused kernels (pushgrad, hess) carry no graph, so here autograd itself
+            # differentiates the differentiable restatement of grid_grad (torch_kernels.py: weights and their derivatives as torch
+            # expressions of the coordinates, one gather per chunk) -- every order from here on, at PyTorch speed.
+            from .torch_kernels import TorchKernels
+            bound, interpolation, extrapolate = ctx.opt
+            bound, interpolation = ops._codes(grid, bound, interpolation)
+            wrt = [t for t, need in ((input, ctx.needs_input_grad[0]), (grid, ctx.needs_input_grad[1])) if need]
+            with torch.enable_grad():
+                out = TorchKernels.grad(input, grid, bound, interpolation, int(extrapolate), displacement=ctx.disp)
+                got = list(torch.autograd.grad(out, wrt, grad.to(out.dtype), create_graph=True, allow_unused=True))
+            if ctx.needs_input_grad[0]:
+                grad_input = got.pop(0)
+            if ctx.needs_input_grad[1]:
+                grad_grid = got.pop(0)
+            return (grad_input, grad_grid, None, None, None) + (None,) * ctx.nextra
         if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
             grad_input, grad_grid = ops.grid_grad_backward(
                 grad, input, grid, *ctx.opt,
