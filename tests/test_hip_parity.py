@@ -769,25 +769,31 @@ def test_tiled_scatter_nonfinite_sources_keep_ieee_semantics():
     assert torch.equal(torch.isinf(fast), torch.isinf(slow))
     ok = torch.isfinite(slow)
     assert float((fast[ok] - slow[ok]).abs().max()) <= 1e-5 * float(slow[ok].abs().max())
-def test_shared_target_push_count():
+@pytest.mark.parametrize("B,bound,order", [(6, "replicate", 3), (24, "dct2", 3), (24, "dft", 2), (12, "zero", 3), (40, "dst2", 3)])
+def test_shared_target_push_count(B, bound, order):
     """BASELINE config 4 miniature: many sources splatted into ONE shared target
-    (batch-stride-0 target in the C-ABI) == reference grid_push(...).sum(0)."""
+    (batch-stride-0 target in the C-ABI) == reference grid_push(...).sum(0).  Round 5: sources that together bring an eighth of
+    a sample per target voxel share the BRICKS of the target (csrc/push_owner.hip: BrickGrid::item = 0, up to CAPX = 512 runs per
+    brick: 24 and 40 sources pass the 128 of a private target) and flush with plain loads and stores; folding (dct2), wrapping
+    (dft: the shell launch) and sign-changing (dst2) boundaries, two channel pairs (C = 2 + the count)."""
     from interpol.distributed import push_count_shared
-    g = torch.Generator().manual_seed(99)
-    B, C, n, m = 6, 2, 24, 64
+    from interpol.codes import bound_to_code
+    g = torch.Generator().manual_seed(99 + B)
+    C, n, m = 2, 24, 64
     inp = torch.randn([B, C, n, n, n], generator=g)
     ident = torch.stack(torch.meshgrid(*[torch.arange(float(n))] * 3, indexing="ij"), -1)
     grid = ident[None] * ((m - 1) / (n - 1)) + 1.5 * torch.randn([B, n, n, n, 3], generator=g)
-    push, count = push_count_shared(inp.to(DEV), grid.to(DEV), [m, m, m], interpolation=3, bound="replicate",
+    push, count = push_count_shared(inp.to(DEV), grid.to(DEV), [m, m, m], interpolation=order, bound=bound,
                                     extrapolate=True, reduce="none")
     oracle.set_threads(8)
     try:
-        want_push = np.asarray(oracle.grid_push(inp.double(), grid.double(), [m, m, m], [1], [3], 1)).sum(0)
-        want_count = np.asarray(oracle.grid_count(grid.double(), [m, m, m], [1], [3], 1)).sum(0)
+        bc = [bound_to_code(bound)]
+        want_push = np.asarray(oracle.grid_push(inp.double(), grid.double(), [m, m, m], bc, [order], 1)).sum(0)
+        want_count = np.asarray(oracle.grid_count(grid.double(), [m, m, m], bc, [order], 1)).sum(0)
     finally:
         oracle.set_threads(1)
-    G.assert_close(push.cpu().numpy(), want_push, 1e-5, 1e-5, "shared push")
-    G.assert_close(count.cpu().numpy(), want_count, 1e-5, 1e-5, "shared count")
+    G.assert_close(push.cpu().numpy(), want_push, 1e-5, 1e-5, ("shared push", B, bound, order))
+    G.assert_close(count.cpu().numpy(), want_count, 1e-5, 1e-5, ("shared count", B, bound, order))
 
 
 @pytest.mark.parametrize("dim,orders", [(3, [1, 3, 2]), (3, [0, 3, 5]), (3, [2, 2, 3]), (2, [2, 3]), (2, [7, 1]), (2, [0, 4])])
@@ -1550,6 +1556,29 @@ def test_routed_pull_bricks_of_the_image_against_oracle(sigma):
                     assert G.rel_err(got.cpu().numpy(), slow.cpu().numpy()) < 4e-6, (name, "vs generic", sigma, b, order, ex)
     finally:
         oracle.set_threads(1)
+
+
+def test_third_order_through_the_grid_on_the_gpu():
+    """Round 5: a backward of a double backward through grid_grad (create_graph=True twice) on CUDA tensors -- forward and first
+    backward are HIP kernels, the higher orders autograd through the torch restatement -- equals the same derivative computed
+    entirely with the PyTorch kernels on the CPU (float64)."""
+    from interpol import ops as iops
+    from interpol.torch_kernels import TorchKernels
+    g0 = torch.Generator().manual_seed(321)
+    x0 = torch.randn(1, 2, 7, 6, 8, dtype=torch.float64, generator=g0)
+    c0 = torch.rand(1, 4, 5, 3, 3, dtype=torch.float64, generator=g0) * 4 + 0.9
+    kw = dict(interpolation=3, bound="dct2", extrapolate=True)
+
+    def third(x, c):
+        z = interpol.grid_grad(x, c, **kw)
+        g1, = torch.autograd.grad(z.square().sum(), c, create_graph=True)
+        return torch.autograd.grad(g1.square().sum(), (c, x))
+    xg, cg = x0.to(DEV).requires_grad_(True), c0.to(DEV).requires_grad_(True)
+    got = third(xg, cg)
+    with iops.use_kernels(TorchKernels):
+        want = third(x0.clone().requires_grad_(True), c0.clone().requires_grad_(True))
+    for a, b in zip(got, want):
+        assert float((a.cpu() - b).abs().max()) <= 1e-9 * max(1.0, float(b.abs().max()))
 
 
 def test_routed_pull_probe_of_the_call_decides_on_the_device():

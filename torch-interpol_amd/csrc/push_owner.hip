@@ -60,6 +60,7 @@ constexpr int PLANE = BOX * PZ;                 // 361
 constexpr int BOXSLOTS = BOX * PLANE;           // 6859 slots = 54 872 B
 constexpr int NCELL = BR * BR * BR;
 constexpr int CAPD = 128;                       // descriptors (runs) per brick
+constexpr int CAPX = 512;                       // ... of a target shared by the batch items (round 5: up to eight tiles of every item reach a brick)
 constexpr int NT = 512;                         // accumulate: threads per workgroup (two workgroups per CU)
 constexpr int NS = TS * TS * TS;                // samples per tile (own_bin)
 constexpr int NT1 = 512, VPT1 = NS / NT1;       // own_bin: threads, samples per thread
@@ -79,6 +80,8 @@ struct BrickGrid {
     int nb[3];                                  // bricks per dim
     int lo[3], top[3], nin[3], split[3];        // interior first-tap cells [lo, top), bricks that hold them, the short brick
     int per_item;                               // nb[0] * nb[1] * nb[2]
+    int item;                                   // brick-index stride of a batch item: per_item, or 0 when the items share ONE target (their bricks are the same)
+    int capd;                                   // descriptors (runs) per brick: CAPD, CAPX for a shared target (every item's tiles feed the brick)
 };
 __host__ __device__ __forceinline__ bool folds(int bound, int n) { return (bound == B_REPLICATE || bound == B_DCT1 || bound == B_DCT2) && n >= 2 * BR; }
 static BrickGrid brick_grid(const KParams &k)
@@ -101,6 +104,7 @@ static BrickGrid brick_grid(const KParams &k)
         g.nb[d] = NLO + g.nin[d] + NHI;
     }
     g.per_item = g.nb[0] * g.nb[1] * g.nb[2];
+    g.item = g.per_item; g.capd = 128;
     return g;
 }
 // brick of a first-tap cell (inside [lo - OFF, top + NHI * BR)) and the cell's index inside its brick (<< 16)
@@ -367,7 +371,7 @@ __global__ __launch_bounds__(NT1, 4) void own_bin(KParams p, BrickGrid bg, const
         for (int i = 0; i < PER; ++i) {
             const int e = tid * PER + i;
             const int r0 = e / (LB * LB), r1 = (e / LB) % LB, r2 = e % LB;
-            const int bk = (int)b * bg.per_item + ((lo[0] + r0) * bg.nb[1] + (lo[1] + r1)) * bg.nb[2] + (lo[2] + r2);
+            const int bk = (int)b * bg.item + ((lo[0] + r0) * bg.nb[1] + (lo[1] + r1)) * bg.nb[2] + (lo[2] + r2);
             slot[i] = 0;
             if (e < NBIN) sm.base[e] = run;
             if (e < NBIN && cn[i] > 0) slot[i] = atomicAdd(&ndesc[bk], 1);
@@ -418,9 +422,9 @@ __global__ __launch_bounds__(NT1, 4) void own_bin(KParams p, BrickGrid bg, const
             const int cn = e < NBIN ? sm.cnt[e] : 0;
             if (cn <= 0) continue;
             const int r0 = e / (LB * LB), r1 = (e / LB) % LB, r2 = e % LB;
-            const int bk = (int)b * bg.per_item + ((lo[0] + r0) * bg.nb[1] + (lo[1] + r1)) * bg.nb[2] + (lo[2] + r2);
-            if (slot[i] < CAPD) {
-                desc[(int64_t)bk * CAPD + slot[i]] = make_uint2((unsigned)(tilebase + sm.base[e]), (unsigned)cn);
+            const int bk = (int)b * bg.item + ((lo[0] + r0) * bg.nb[1] + (lo[1] + r1)) * bg.nb[2] + (lo[2] + r2);
+            if (slot[i] < bg.capd) {
+                desc[(int64_t)bk * bg.capd + slot[i]] = make_uint2((unsigned)(tilebase + sm.base[e]), (unsigned)cn);
                 sm.gbk[e] = bk;
                 if (IDX && slot[i] == 0) bmax[1 + atomicAdd(&bmax[0], 1)] = bk;      // first run of the brick: onto the list
             } else { sm.cnt[e] = -1; sm.orph = 1; }
@@ -462,14 +466,15 @@ constexpr int NPIECE = VPT * (NT / 64);         // pieces (<= 64 consecutive rec
 constexpr int BATCH = NPIECE * 64;              // records per class-sorted batch, at most (a brick holds 4096 on average)
 constexpr int NCLS = 32;                        // classes = 8-byte bank pairs of the LDS
 constexpr int NHW = NT / 32;                    // half waves per workgroup
+constexpr unsigned PMASK = 0x1ffffffu;          // AccSmem::ppref: the prefix field
 static_assert(NPIECE <= 128, "a queue entry is piece << 6 | lane in 16 bits");
 
 struct AccSmem {
     int   taboff[3][BOX + 1];
     float tabsgn[3][BOX + 1];
-    int   ppref[CAPD];                         // exclusive prefix of the runs' piece counts; entries beyond the last run: INT_MAX
-    unsigned start[CAPD];                      // first record of each run
-    int   rcnt[CAPD];                          // records of each run
+    unsigned ppref[CAPX];                      // per run: exclusive prefix of the runs' piece counts (bits 0-24) and the records of its last piece
+                                               // (bits 25-31: 1 .. 64); entries beyond the last run: all ones
+    unsigned start[CAPX];                      // first record of each run
     uint2 piece[NPIECE];                       // pieces of the current batch: first record, records (0: none)
     int   cmax[2];
     int   dmax, n, npieces;
@@ -726,7 +731,7 @@ __global__ __launch_bounds__(NT, 4) void own_accumulate(KParams p, BrickGrid bg,
 #pragma unroll
             for (int d = 0; d < 3; ++d) interior = interior && bx_[d] >= NLO + (L.bound[d] == B_DST1 ? 1 : 0) && bx_[d] < NLO + bg.nin[d];
             if (color < 8 ? interior : (color == 9 || !interior))
-                take = ndesc[bb * bg.per_item + (bx_[0] * bg.nb[1] + bx_[1]) * bg.nb[2] + bx_[2]] != 0;
+                take = ndesc[bb * bg.item + (bx_[0] * bg.nb[1] + bx_[1]) * bg.nb[2] + bx_[2]] != 0;
         }
         pending = __ballot(take);
     }
@@ -763,20 +768,20 @@ __global__ __launch_bounds__(NT, 4) void own_accumulate(KParams p, BrickGrid bg,
                 foldmul *= nout == 0 ? 1 : (L.bound[d] == B_REPLICATE ? nout + 1 : 2);
             }
         }
-        const int brick = (int)b * bg.per_item + (bxyz[0] * bg.nb[1] + bxyz[1]) * bg.nb[2] + bxyz[2];
+        const int brick = (int)b * bg.item + (bxyz[0] * bg.nb[1] + bxyz[1]) * bg.nb[2] + bxyz[2];
         int nd = ndesc[brick];
         if (nd == 0) continue;                                       // (block-uniform)
-        nd = nd < CAPD ? nd : CAPD;
+        nd = nd < bg.capd ? nd : bg.capd;
         __syncthreads();                                             // the previous brick's flush is done with the tables / the box
         prof_mark(-1);
         if (tid < 64) {
             // runs of the brick: records, pieces (<= 64 consecutive records) and the exclusive prefix of the piece counts
-            constexpr int PER = CAPD / 64;
+            constexpr int PER = CAPX / 64;
             int cn[PER], np[PER], s = 0, sp = 0; unsigned st_[PER];
 #pragma unroll
             for (int i = 0; i < PER; ++i) {
                 const int e = tid * PER + i;
-                const uint2 dsc = e < nd ? desc[(int64_t)brick * CAPD + e] : make_uint2(0u, 0u);
+                const uint2 dsc = e < nd ? desc[(int64_t)brick * bg.capd + e] : make_uint2(0u, 0u);
                 cn[i] = (int)dsc.y; st_[i] = dsc.x; np[i] = (cn[i] + 63) >> 6; s += cn[i]; sp += np[i];
             }
             int incl = s, inclp = sp;
@@ -789,9 +794,9 @@ __global__ __launch_bounds__(NT, 4) void own_accumulate(KParams p, BrickGrid bg,
 #pragma unroll
             for (int i = 0; i < PER; ++i) {
                 const int e = tid * PER + i;
-                sm.ppref[e] = e < nd ? runp : 0x7fffffff;
+                const unsigned last = cn[i] > 0 ? (unsigned)(cn[i] - 64 * (np[i] - 1)) : 0u;
+                sm.ppref[e] = e < nd ? ((unsigned)runp & PMASK) | (last << 25) : 0xffffffffu;
                 sm.start[e] = st_[i];
-                sm.rcnt[e] = cn[i];
                 runp += np[i];
             }
             if (tid == 63) { sm.n = incl; sm.npieces = inclp; sm.dmax = 0; sm.cmax[0] = 0; sm.cmax[1] = 0; }
@@ -817,9 +822,13 @@ __global__ __launch_bounds__(NT, 4) void own_accumulate(KParams p, BrickGrid bg,
                 if (g < npieces) {
                     int j = 0;
 #pragma unroll
-                    for (int st = CAPD / 2; st > 0; st >>= 1) j += sm.ppref[j + st] <= g ? st : 0;
-                    const int q = g - sm.ppref[j], left = sm.rcnt[j] - 64 * q;
-                    pc = make_uint2(sm.start[j] + 64u * (unsigned)q, (unsigned)(left < 64 ? left : 64));
+                    for (int st = CAPX / 2; st > 0; st >>= 1) j += (int)(sm.ppref[j + st] & PMASK) <= g ? st : 0;
+                    const unsigned pj = sm.ppref[j];
+                    const int q = g - (int)(pj & PMASK);
+                    // (the run's last piece -- the next run starts behind it -- holds what is left of the run, every other one 64 records)
+                    const int nextp = j + 1 < CAPX ? (int)(sm.ppref[j + 1] & PMASK) : (int)PMASK;
+                    const bool lastp = g + 1 == (nextp < npieces ? nextp : npieces);
+                    pc = make_uint2(sm.start[j] + 64u * (unsigned)q, lastp ? (pj >> 25) : 64u);
                 }
                 sm.piece[tid] = pc;
             }
@@ -1585,10 +1594,11 @@ struct Workspace {
 };
 static int64_t align256(int64_t x) { return (x + 255) & ~(int64_t)255; }
 
-static int64_t layout(const KParams &k, int B, int ntiles, int nch, void *base, Workspace *w, int64_t nflags = 0)
+// shared: the batch items scatter into ONE target -- they share its bricks (BrickGrid::item = 0) and a brick takes CAPX runs
+static int64_t layout(const KParams &k, int B, int ntiles, int nch, void *base, Workspace *w, int64_t nflags = 0, bool shared = false)
 {
     const BrickGrid bg = brick_grid(k);
-    const int64_t nbricks = (int64_t)bg.per_item * B;
+    const int64_t nbricks = (int64_t)bg.per_item * (shared ? 1 : B);
     const int64_t nrec = (int64_t)ntiles * NS * B;
     int64_t o = 0;
     unsigned char *p = (unsigned char *)base;
@@ -1596,7 +1606,7 @@ static int64_t layout(const KParams &k, int B, int ntiles, int nch, void *base, 
     const int64_t o_nd = o; o += nbricks * 4;                        // (header, brick counters and brick maxima: ONE zero-fill)
     const int64_t o_bm = o; o += nbricks * 8;
     const int64_t o_fl = o; o += nflags * 4; o = align256(o);        // (pull: one flag per sample tile; what follows holds 8- and 16-byte elements: aligned)
-    const int64_t o_desc = o; o += align256(nbricks * CAPD * 8);
+    const int64_t o_desc = o; o += align256(nbricks * (shared ? CAPX : CAPD) * 8);
     const int64_t o_rec = o; o += align256(nrec * 16);
     const int64_t o_val = o; o += align256(nrec * 4 * (nch > 1 ? nch - 1 : 0));
     const int64_t o_meta = o; o += align256(nrec * 2);
@@ -1620,29 +1630,33 @@ static int tile_count(const interpol_problem *p)
 
 // Eligible: 3-D, one order 2..3, sample grid about as dense as the target (else the tiled / brick
 // scatters are the better organisation), sizes within 32-bit record counts.
-static bool owner_eligible(const interpol_problem *p, const KParams &k)
+static bool shared_target(const interpol_problem *p) { return p->vol_stride[0] == 0 && p->batch > 1; }
+static bool owner_eligible(const interpol_problem *p, const KParams &k, bool scatter = false)
 {
+    const bool shared = scatter && shared_target(p);
     if (p->dim != 3 || p->batch > 4096) return false;
     if (!(p->flags & (INTERPOL_FLAG_BINNED_SCATTER | INTERPOL_FLAG_AUTO_SCATTER))) return false;   // see interpol_hip.h
     if (k.order[0] != k.order[1] || k.order[0] != k.order[2] || k.order[0] < 2 || k.order[0] > 3) return false;
-    int64_t n = 1, nv = 1, nb = p->batch;
+    int64_t n = 1, nv = 1, nb = shared ? 1 : p->batch;
     for (int d = 0; d < 3; ++d) {
         n *= p->grid_shape[d]; nv *= p->vol_shape[d];
         nb *= owner::NLO + owner::NHI + (p->vol_shape[d] + 15 + owner::BR - 1) / owner::BR;   // (an upper bound of BrickGrid::nb)
         if (p->grid_shape[d] > 0x7fffffff / 4) return false;
     }
     const int64_t nt = owner::tile_count(p);
-    if (n < 4096 || nt == 0 || nt * owner::NS * p->batch > 0x7fffffffll || nb > 0x7fffffffll / owner::CAPD) return false;
+    if (n < 4096 || nt == 0 || nt * owner::NS * p->batch > 0x7fffffffll || nb > 0x7fffffffll / (shared ? owner::CAPX : owner::CAPD)) return false;
     if ((uint64_t)n * 12ull > 0xffffffffull) return false;
-    return 4 * n >= nv;                                              // at least a quarter of a sample per target voxel
+    // at least a quarter of a sample per target voxel -- all the items' samples count when they share the target (round 5:
+    // BASELINE config 4, 64 sources of 128^3 into 512^3, is as dense as config 2 once the sources share the bricks)
+    return (shared ? 8 * n * p->batch : 4 * n) >= nv;
 }
 
 // bytes of workspace the owner-computes organisation needs for this problem (0: not applicable)
 int64_t owner_workspace_bytes(const interpol_problem *p, const KParams &k, bool count_only)
 {
-    if (!owner_eligible(p, k)) return 0;
+    if (!owner_eligible(p, k, true)) return 0;
     const int nch = count_only ? 1 : k.C + (k.cc ? 1 : 0);
-    return owner::layout(k, (int)p->batch, owner::tile_count(p), nch, nullptr, nullptr);
+    return owner::layout(k, (int)p->batch, owner::tile_count(p), nch, nullptr, nullptr, 0, shared_target(p));
 }
 
 namespace owner {
@@ -1677,13 +1691,15 @@ int try_owner_push(const interpol_problem *p, const KParams &k, const void *val,
                    void *workspace, int64_t workspace_bytes, hipStream_t st, const int **gate_out)
 {
     using namespace owner;
-    if (!workspace || !owner_eligible(p, k)) return 0;
+    if (!workspace || !owner_eligible(p, k, true)) return 0;
     const bool count_only = val == nullptr;
     const int nch = count_only ? 1 : k.C + (k.cc ? 1 : 0);
     Workspace w;
     if (((uintptr_t)workspace & 255u) != 0) return 0;                // (interpol_hip.h: 256-byte aligned, or the other scatters run)
-    if (layout(k, (int)p->batch, tile_count(p), nch, workspace, &w) > workspace_bytes) return 0;
-    const BrickGrid bg = brick_grid(k);
+    const bool shared = shared_target(p);
+    if (layout(k, (int)p->batch, tile_count(p), nch, workspace, &w, 0, shared) > workspace_bytes) return 0;
+    BrickGrid bg = brick_grid(k);
+    if (shared) { bg.item = 0; bg.capd = CAPX; }                     // the items' samples meet in the same bricks
     const bool gated = !(p->flags & INTERPOL_FLAG_BINNED_SCATTER);
     // (a kernel, not hipMemsetAsync: under hipGraph capture the memset node of ROCm 7.2 was observed not to re-run on replays)
     hipLaunchKernelGGL(own_zero, dim3((unsigned)((64 + 3ll * w.nbricks + 1023) / 1024)), dim3(1024), 0, st, (int *)w.hdr, 64 + 3 * w.nbricks);
@@ -1711,10 +1727,12 @@ int try_owner_push(const interpol_problem *p, const KParams &k, const void *val,
     default: return 0;
     }
     if (rc) return rc;
-    const bool shared = p->vol_stride[0] == 0 && p->batch > 1;
+    // (a shared target used to take ONE launch over the bricks of every item with an atomic flush, colour 9; since the items share
+    //  the bricks -- round 5 -- it takes the colour launches like any other target: plain loads and stores, one batch item)
     const long long want = 2ll * cu_count();
-    for (int color = shared ? 9 : 0; color < (shared ? 10 : 9); ++color) {
-        long long nwork = B;
+    const int Bw = shared ? 1 : B;
+    for (int color = 0; color < 9; ++color) {
+        long long nwork = Bw;
         for (int d = 0; d < 3; ++d) nwork *= color_count(color, d, bg);
         if (nwork <= 0) continue;
         const dim3 agrid((unsigned)(nwork < want ? nwork : want));
@@ -1724,7 +1742,7 @@ int try_owner_push(const interpol_problem *p, const KParams &k, const void *val,
             if (attr) return attr;                                                                                      \
             hipLaunchKernelGGL((own_accumulate<KK>), agrid, dim3(NT), sizeof(AccSmem), st, k, bg, (const int *)w.ndesc,  \
                                (const uint2 *)w.desc, (const float4 *)w.rec, (const float *)w.vals, (const unsigned short *)w.meta,  \
-                               (const int *)w.bmax, w.nrec, (float *)vol, nch, color, B, gate, \
+                               (const int *)w.bmax, w.nrec, (float *)vol, nch, color, Bw, gate, \
                                (int *)w.hdr + 16 + color);                                                              \
         }
         if (k.order[0] == 3) IP_OWN_ACC(3) else IP_OWN_ACC(2)
