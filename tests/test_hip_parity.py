@@ -1558,6 +1558,38 @@ def test_routed_pull_bricks_of_the_image_against_oracle(sigma):
         oracle.set_threads(1)
 
 
+@pytest.mark.parametrize("sigma", [0.0, 2.0, 7.0])
+def test_orders_4_and_5_push_and_count_through_bricks_of_the_target(sigma):
+    """Round 5 (gather5.hip: scatter5): grid_push / grid_count of orders 4 and 5 in 3-D float32 with the bricks' workspace -- the
+    routed default (probe5 picks the LDS tiles or the bricks) and the bricks alone (INTERPOL_FLAG_BINNED_SCATTER) against the oracle
+    and the generic kernels: every bound (mixed per dim), the three extrapolation modes, 1 - 3 channels, push + count in one call,
+    sample grids that overhang the lattice; sigma = 7 leaves the tiles' boxes everywhere (the cliff of rounds 1 - 4)."""
+    from interpol import _hip
+    g = torch.Generator().manual_seed(int(sigma) + 140)
+    oracle.set_threads(8)
+    try:
+        for (tshape, sshape) in (((40, 33, 50), (37, 45, 29)), ((48, 48, 48), (48, 48, 48))):
+            for bound in range(7):
+                order = 4 + (bound % 2)
+                ex, C = (bound + order) % 3, 1 + (bound + order) % 3
+                src = torch.randn([2, C, *sshape], generator=g)
+                lin = [torch.linspace(-2, n + 1, m) for n, m in zip(tshape, sshape)]
+                grid = torch.stack(torch.meshgrid(*lin, indexing="ij"), -1)[None] + sigma * torch.randn([2, *sshape, 3], generator=g)
+                b = [bound, (bound + 3) % 7, (bound + 5) % 7]
+                want = oracle.grid_push(src.double().numpy(), grid.double().numpy(), list(tshape), b, [order], ex)
+                want_c = oracle.grid_count(grid.double().numpy(), list(tshape), b, [order], ex)
+                for name, fl in (("routed", 0), ("bricks", _hip.FLAG_BINNED_SCATTER)):
+                    got = _hip.scatter("push", src.to(DEV), grid.to(DEV), list(tshape), b, [order] * 3, ex, flags=fl)
+                    G.assert_close(got.cpu().numpy(), want, rtol=1e-5, atol_rel=1e-5, what=("push", name, sigma, b, order, ex))
+                    cnt = _hip.scatter("count", None, grid.to(DEV), list(tshape), b, [order] * 3, ex, flags=fl)
+                    G.assert_close(cnt.cpu().numpy(), want_c, rtol=1e-5, atol_rel=1e-5, what=("count", name, sigma, b, order, ex))
+                both = _hip.scatter("push", src.to(DEV), grid.to(DEV), list(tshape), b, [order] * 3, ex, flags=_hip.FLAG_BINNED_SCATTER, with_count=True)
+                G.assert_close(both[:, :C].cpu().numpy(), want, rtol=1e-5, atol_rel=1e-5, what=("push+count", sigma, b, order, ex))
+                G.assert_close(both[:, C:].cpu().numpy(), want_c, rtol=1e-5, atol_rel=1e-5, what=("push+count: count", sigma, b, order, ex))
+    finally:
+        oracle.set_threads(1)
+
+
 def test_third_order_through_the_grid_on_the_gpu():
     """Round 5: a backward of a double backward through grid_grad (create_graph=True twice) on CUDA tensors -- forward and first
     backward are HIP kernels, the higher orders autograd through the torch restatement -- equals the same derivative computed

@@ -74,6 +74,11 @@ if os.path.exists(raw_path):
         """KB of counter c per launch of `op` spent in the kernels named sub"""
         tot, _ = raw.get("%s|%s|%s" % (sub, c, sg), [0.0, 0])
         n = raw.get("%s|%s|%s" % (KERNELS[op][0] if raw.get("%s|%s|%s" % (KERNELS[op][0], c, sg), [0, 0])[1] else "push_tiled", c, sg), [0, 0])[1]
+        if op == "grid_push":
+            # (round 5: the routed pull launches own_zero / own_probe / own_bin as well -- their traffic is negligible, but they
+            #  cannot count the push launches any more: a push is nine own_accumulate launches, or one push_tiled at the identity)
+            na = raw.get("own_accumulate|%s|%s" % (c, sg), [0, 0])[1]
+            n = na // 9 if na else raw.get("push_tiled|%s|%s" % (c, sg), [0, 0])[1]
         return tot / n if n else 0.0
 
     buf = io.StringIO()

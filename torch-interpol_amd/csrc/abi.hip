@@ -64,6 +64,8 @@ int owner_pull_finish(const interpol_problem *, const KParams &, const void *, c
 int owner_grad_probe(const interpol_problem *, const KParams &, const void *, void *, int64_t, hipStream_t, int mode = -1);
 int64_t gather5_workspace_bytes(const interpol_problem *, const KParams &);
 int try_gather5(const interpol_problem *, const KParams &, const void *, const void *, void *, void *, int64_t, int, const void *, hipStream_t, const int **);
+int64_t scatter5_workspace_bytes(const interpol_problem *, const KParams &);
+int try_scatter5(const interpol_problem *, const KParams &, const void *, const void *, void *, void *, int64_t, hipStream_t, const int **);
 #ifdef IP_EXPERIMENTS
 int try_pull_direct(const interpol_problem *, const KParams &, const void *, const void *, void *, int *, int, hipStream_t);
 #endif
@@ -484,6 +486,10 @@ int interpol_push(const interpol_problem *p, const void *val, const void *grid, 
         if (!(p->flags & INTERPOL_FLAG_NO_FASTPATH)) {
             int rc = try_owner_push(p, k, val, grid, acc, ws, ws_bytes, st, &k.gate);     // needs its workspace: interpol_scatter_workspace
             if (rc != 0 && rc != 2) return rc == 1 ? 0 : rc;       // (2: launched behind the probe's gate; the kernels below read the same gate)
+            if (rc == 0 && p->dtype == INTERPOL_F32) {
+                rc = try_scatter5(p, k, val, grid, acc, ws, ws_bytes, st, &k.gate);      // orders 4 - 5 through bricks of the target (gather5.hip)
+                if (rc != 0 && rc != 2) return rc == 1 ? 0 : rc;
+            }
             rc = try_fast_push(p, k, val, grid, acc, st);           // the tiled kernel splats values and count in one pass
             if (rc != 0) return rc == 1 ? 0 : rc;
         }
@@ -564,7 +570,9 @@ int64_t interpol_scatter_workspace(const interpol_problem *p, int32_t count_only
     if (make_params(p, SCATTER, 1, &k, &B, !count_only)) return 0;
     k.cc = (!count_only && (p->flags & INTERPOL_FLAG_WITH_COUNT)) ? 1 : 0;
     if (p->dtype != INTERPOL_F32 && p->dtype != INTERPOL_BF16 && p->dtype != INTERPOL_F16) return 0;
-    const int64_t ws = owner_workspace_bytes(p, k, count_only != 0);
+    int64_t ws = owner_workspace_bytes(p, k, count_only != 0);
+    if (ws <= 0 && p->dtype == INTERPOL_F32 && (p->flags & (INTERPOL_FLAG_BINNED_SCATTER | INTERPOL_FLAG_AUTO_SCATTER)))
+        ws = scatter5_workspace_bytes(p, k);                         // orders 4 - 5 (gather5.hip: scatter5)
     if (ws <= 0) return 0;
     const bool lowp = (p->dtype == INTERPOL_BF16 || p->dtype == INTERPOL_F16);
     return ws + (lowp ? ((vol_numel(p) * 4 + 255) & ~(int64_t)255) : 0);
@@ -581,6 +589,10 @@ int interpol_count(const interpol_problem *p, const void *grid, void *vol,
         if (!(p->flags & INTERPOL_FLAG_NO_FASTPATH)) {
             int rc = try_owner_push(p, k, nullptr, grid, acc, ws, ws_bytes, st, &k.gate);
             if (rc != 0 && rc != 2) return rc == 1 ? 0 : rc;
+            if (rc == 0 && p->dtype == INTERPOL_F32) {
+                rc = try_scatter5(p, k, nullptr, grid, acc, ws, ws_bytes, st, &k.gate);
+                if (rc != 0 && rc != 2) return rc == 1 ? 0 : rc;
+            }
             rc = try_fast_push(p, k, nullptr, grid, acc, st);
             if (rc != 0) return rc == 1 ? 0 : rc;
         }
@@ -692,7 +704,15 @@ int interpol_pull_backward(const interpol_problem *p, const void *grad_out, cons
             kp.vol_sb = gsb; kp.vol_sc = gsc;
             int64_t dense = 1;
             for (int d = p->dim - 1; d >= 0; --d) { kp.vol_ss[d] = (int)(dense * (int64_t)acc_esize(p->dtype)); dense *= p->vol_shape[d]; }
-            rc = try_fast_push(p, kp, grad_out, grid, acc, st);
+            rc = 0;
+            if (high && scratch && p->dtype == INTERPOL_F32 && (p->flags & (INTERPOL_FLAG_BINNED_SCATTER | INTERPOL_FLAG_AUTO_SCATTER))) {
+                // orders 4 - 5 with the bricks' workspace: the image gradient through bricks of the target (gather5.hip: scatter5; the
+                // grid gradient below reuses the workspace behind it on the stream)
+                rc = try_scatter5(p, kp, grad_out, grid, acc, scratch, scratch_bytes, st, &kp.gate);
+                if (rc < 0 || rc > 2) return rc;
+                if (rc == 2) rc = 0;                                 // (behind the probe: the tiles below read the same verdict)
+            }
+            if (rc == 0) rc = try_fast_push(p, kp, grad_out, grid, acc, st);
             if (rc < 0 || rc > 1) return rc;
             vol_done = rc == 1;
             rc = (vol_done && !grad_grid) ? 1 : 0;

@@ -85,6 +85,15 @@ __device__ __forceinline__ void direct5(const KParams &p, const float *__restric
         int ii[3]; float tt[3];
 #pragma unroll
         for (int d = 0; d < 3; ++d) split(K, x[d], ii[d], tt[d]);
+        if (MODE == 3) {
+            // push / count (scatter5): `img` is the SOURCE image (NULL: count), `out` the target; channel C (p.cc) receives the count
+#pragma unroll 1
+            for (int ch = 0; ch < p.C + p.cc; ++ch) {
+                const float sv = (img && ch < p.C) ? img[b * p.val_sb + ch * p.val_sc + o] * m : m;
+                if (sv != 0.f) tiled::scatter_one_thread(L, out + b * p.vol_sb + ch * p.vol_sc, sv, ii[0], ii[1], ii[2], tt[0], tt[1], tt[2]);
+            }
+            continue;
+        }
         if (MODE == 1) {
             float a[3] = { 0.f, 0.f, 0.f };
 #pragma unroll 1
@@ -488,6 +497,296 @@ __global__ __launch_bounds__(NT, 4) void gather5(KParams p, Grid5 bg, const int 
     }
 }
 
+// ---------------------------------------------------------------------------
+// scatter5 (round 5) -- grid_push / grid_count (nd.py:146-213, pushpull.py:106-142) of orders 4 and 5 through bricks of the TARGET:
+// the adjoint of gather5 and the deformation-independent scatter of these orders (the LDS tiles of ops_tiled.hip leave samples
+// outside their box to a slow list, then to per-thread atomics: BASELINE config 3's image gradient 4.2 ms at sigma = 2 and an order
+// of magnitude more at sigma = 6).  bin5 sorts the samples as for the gathers (records x, y, z, sample index); a workgroup draws a
+// non-empty brick, counts the density of first-tap cells (stencil counts per slot: the box filter of it), and adds every record's
+// (K + 1)^3 taps into the brick's 21^3 box of 32-bit sums in the MAGIC format of push_owner.hip (the float  t + 1.5 * 2^23  IS the
+// fixed-point addend: one v_fma_f32 + one ds_add_u32 per tap, one channel per pass); the box is flushed with float atomics through the
+// boundary tables (boxes of neighbouring bricks overlap by K points: 2.3 atomics per lattice point and channel -- the tiles' flush
+// issues more).  Bricks too dense for 32-bit sums and non-finite sources are scattered tap by tap (always correct).
+// ---------------------------------------------------------------------------
+constexpr int NZ5 = BOX + 1;                    // row pitch of the stencil counts (16 bits each, two to a word)
+constexpr int NCELL5 = BR * BR * BR;
+constexpr float MAGIC5 = 12582912.f;            // 1.5 * 2^23: bits 0x4B400000
+constexpr unsigned MAGIC5_BITS = 0x4B400000u;
+struct ScatSmem {
+    int   taboff[3][BOX + 3];
+    float tabsgn[3][BOX + 3];
+    unsigned start[CAPD];
+    int   pref[CAPD + 2];
+    int   brick, dmax, amax, nonfinite;
+    union alignas(16) {
+        unsigned cells[NCELL5 / 2];             // density of first-tap cells: 16-bit counters
+        unsigned nreg[BOX * BOX * NZ5 / 2];     // stencils per slot, 16 bits each: slot (x, y, z) at (x * BOX + y) * NZ5 + z
+    };
+    unsigned box[BOX * BOX * BOX];              // 37 044 B
+};
+static_assert(sizeof(ScatSmem) <= 80 * 1024, "two workgroups per CU");
+
+template <int K> __device__ __forceinline__ float units5() { return K == 5 ? 4194304.f * 0.999f / (0.55f * 0.55f * 0.55f) : 4194304.f * 0.999f / (0.5989584f * 0.5989584f * 0.5989584f); }
+template <int K> __device__ __forceinline__ float cbmax5() { return 2147483648.f * 0.99f / units5<K>(); }
+
+typedef unsigned short us2_5 __attribute__((ext_vector_type(2)));
+template <int W>
+__device__ __forceinline__ void slide5(const unsigned *in, unsigned *out)
+{
+    us2_5 s = { 0, 0 };
+#pragma unroll
+    for (int j = 0; j < BOX; ++j) {
+        if (j < BR) s += __builtin_bit_cast(us2_5, in[j]);
+        if (j >= W) s -= __builtin_bit_cast(us2_5, in[j - W]);
+        out[j] = __builtin_bit_cast(unsigned, s);
+    }
+}
+// stencils per slot = the (K + 1)^3 box filter of the cell density, dim after dim, in place (push_owner.hip: stencil_counts)
+template <int K>
+__device__ __forceinline__ void counts5(ScatSmem &sm, int tid)
+{
+    constexpr int W = K + 1, HZ = NZ5 / 2;
+    unsigned *rg = sm.nreg;
+    unsigned in[BR], out[BOX];
+    if (tid < BR * BR) {
+        const uint4 lo = reinterpret_cast<const uint4 *>(sm.cells)[2 * tid], hi = reinterpret_cast<const uint4 *>(sm.cells)[2 * tid + 1];
+        in[0] = lo.x; in[1] = lo.y; in[2] = lo.z; in[3] = lo.w; in[4] = hi.x; in[5] = hi.y; in[6] = hi.z; in[7] = hi.w;
+    }
+    __syncthreads();
+    if (tid < BR * BR) {
+        int v[BR], o[NZ5], s = 0;
+#pragma unroll
+        for (int i = 0; i < BR / 2; ++i) { v[2 * i] = (int)(in[i] & 0xffffu); v[2 * i + 1] = (int)(in[i] >> 16); }
+#pragma unroll
+        for (int j = 0; j < BOX; ++j) { if (j < BR) s += v[j]; if (j >= W) s -= v[j - W]; o[j] = s; }
+        o[BOX] = 0;
+#pragma unroll
+        for (int i = 0; i < HZ; ++i) rg[tid * HZ + i] = (unsigned)o[2 * i] | ((unsigned)o[2 * i + 1] << 16);
+    }
+    __syncthreads();
+    {
+        const int x = tid / HZ, zp = tid - x * HZ;
+        if (tid < BR * HZ) {
+#pragma unroll
+            for (int k = 0; k < BR; ++k) in[k] = rg[(x * BR + k) * HZ + zp];
+        }
+        __syncthreads();
+        if (tid < BR * HZ) {
+            slide5<W>(in, out);
+#pragma unroll
+            for (int j = 0; j < BOX; ++j) rg[(x * BOX + j) * HZ + zp] = out[j];
+        }
+        __syncthreads();
+    }
+    {
+        const int y = tid / HZ, zp = tid - y * HZ;
+        if (tid < BOX * HZ) {
+#pragma unroll
+            for (int k = 0; k < BR; ++k) in[k] = rg[(k * BOX + y) * HZ + zp];
+        }
+        __syncthreads();
+        if (tid < BOX * HZ) {
+            slide5<W>(in, out);
+#pragma unroll
+            for (int j = 0; j < BOX; ++j) rg[(j * BOX + y) * HZ + zp] = out[j];
+        }
+        __syncthreads();
+    }
+}
+
+// the K + 1 adds of one row of the stencil at immediate offsets
+template <int K, int I, int J>
+__device__ __forceinline__ void row_adds5(unsigned addr, const float *v)
+{
+    constexpr int o = ((I * BOX + J) * BOX) * 4;
+    if (K == 5)
+        asm volatile("ds_add_u32 %0, %1 offset:%7\n\tds_add_u32 %0, %2 offset:%8\n\tds_add_u32 %0, %3 offset:%9\n\tds_add_u32 %0, %4 offset:%10\n\t"
+                     "ds_add_u32 %0, %5 offset:%11\n\tds_add_u32 %0, %6 offset:%12"
+                     :: "v"(addr), "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "v"(v[4]), "v"(v[5]),
+                        "n"(o), "n"(o + 4), "n"(o + 8), "n"(o + 12), "n"(o + 16), "n"(o + 20) : "memory");
+    else
+        asm volatile("ds_add_u32 %0, %1 offset:%6\n\tds_add_u32 %0, %2 offset:%7\n\tds_add_u32 %0, %3 offset:%8\n\tds_add_u32 %0, %4 offset:%9\n\t"
+                     "ds_add_u32 %0, %5 offset:%10"
+                     :: "v"(addr), "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "v"(v[4]),
+                        "n"(o), "n"(o + 4), "n"(o + 8), "n"(o + 12), "n"(o + 16) : "memory");
+}
+template <int K, int I, int J>
+__device__ __forceinline__ void scatter_row5(unsigned addr, float sx, const float *wy, const float *wz)
+{
+    const float sy = sx * wy[J];
+    float v[6];
+#pragma unroll
+    for (int k = 0; k <= K; ++k) v[k] = __builtin_fmaf(sy, wz[k], MAGIC5);
+    row_adds5<K, I, J>(addr, v);
+}
+template <int K, int I>
+__device__ __forceinline__ void scatter_plane5(unsigned addr, float s, float wxi, const float *wy, const float *wz)
+{
+    const float sx = s * wxi;
+    scatter_row5<K, I, 0>(addr, sx, wy, wz); scatter_row5<K, I, 1>(addr, sx, wy, wz); scatter_row5<K, I, 2>(addr, sx, wy, wz);
+    scatter_row5<K, I, 3>(addr, sx, wy, wz); scatter_row5<K, I, 4>(addr, sx, wy, wz);
+    if (K == 5) scatter_row5<K, I, 5>(addr, sx, wy, wz);
+}
+
+template <int K>
+__global__ __launch_bounds__(NT, 4) void scatter5(KParams p, Grid5 bg, const int *__restrict__ ndesc, const uint2 *__restrict__ desc,
+                                                  const float4 *__restrict__ rec, const int *__restrict__ list, int *__restrict__ draw,
+                                                  const float *__restrict__ src, float *__restrict__ vol, const int *__restrict__ gate)
+{
+    if (gate && *gate != 1) return;                                  // INTERPOL_FLAG_AUTO_SCATTER: the probe chose the tiles
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    ScatSmem &sm = *reinterpret_cast<ScatSmem *>(smem_raw);
+    Lattice L;
+#pragma unroll
+    for (int d = 0; d < 3; ++d) { L.bound[d] = p.bound[d]; L.n[d] = p.vol_n[d]; L.ss[d] = p.vol_ss[d] / 4; L.k[d] = K; }
+    L.lin = 0;
+    const int nlist = list[0];
+    const int nch = p.C + p.cc;
+    for (int e = threadIdx.x; e < BOX * BOX * BOX; e += NT) sm.box[e] = 0u;
+    for (;;) {
+        const int tid = opaque((int)threadIdx.x);
+        __syncthreads();                                             // the previous brick is flushed
+        if (tid == 0) { const int i = atomicAdd(draw, 1); sm.brick = i < nlist ? list[1 + i] : -1; sm.dmax = 0; }
+        __syncthreads();
+        const int bk = sm.brick;
+        if (bk < 0) break;
+        const int64_t b = bk / bg.per_item;
+        int r = bk - (int)b * bg.per_item;
+        const int bz = r % bg.nb[2]; r /= bg.nb[2];
+        const int by = r % bg.nb[1], bx = r / bg.nb[1];
+        const int b0[3] = { bx * BR - OFFB, by * BR - OFFB, bz * BR - OFFB };
+        const int nd = min(ndesc[bk], CAPD);
+        if (tid < 64) {
+            static_assert(CAPD == 128, "two runs per lane");
+            const int e0 = 2 * tid, e1 = e0 + 1;
+            const uint2 d0 = e0 < nd ? desc[(int64_t)bk * CAPD + e0] : make_uint2(0u, 0u), d1 = e1 < nd ? desc[(int64_t)bk * CAPD + e1] : make_uint2(0u, 0u);
+            const int sum = (int)d0.y + (int)d1.y;
+            int incl = sum;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o); if (tid >= o) incl += t; }
+            sm.start[e0] = d0.x; sm.start[e1] = d1.x;
+            sm.pref[e0] = incl - sum; sm.pref[e1] = incl - (int)d1.y;
+            if (tid == 63) { sm.pref[CAPD] = incl; sm.pref[CAPD + 1] = 0x7fffffff; }
+        }
+        if (tid >= 128 && tid < 128 + 3 * 64) {                      // box slot -> wrapped lattice offset and sign (bounds.py:30-89)
+            const int d = (tid - 128) >> 6, slot = tid & 63;
+            if (slot < BOX) {
+                const long long pk = wrap_outofline(p.bound[d], (d == 0 ? b0[0] : d == 1 ? b0[1] : b0[2]) + slot, p.vol_n[d]);
+                sm.taboff[d][slot] = (int)(pk & 0xffffffffll) * (p.vol_ss[d] / 4);
+                sm.tabsgn[d][slot] = (float)(int)(pk >> 32);
+            }
+        }
+        for (int e = tid; e < NCELL5 / 2; e += NT) sm.cells[e] = 0u;
+        __syncthreads();
+        const int ntot = sm.pref[CAPD];
+        // ---- density of the first-tap cells
+        {
+            int rr = 0;
+            for (int j = tid; j < ntot; j += NT) {
+                while (j >= sm.pref[rr + 1]) ++rr;
+                const float4 rc = rec[sm.start[rr] + (unsigned)(j - sm.pref[rr])];
+                int cx = __float2int_rz(floorf(rc.x - 0.5f * (float)(K - 1))) - b0[0], cy = __float2int_rz(floorf(rc.y - 0.5f * (float)(K - 1))) - b0[1],
+                    cz = __float2int_rz(floorf(rc.z - 0.5f * (float)(K - 1))) - b0[2];
+                cx = max(0, min(cx, BR - 1)); cy = max(0, min(cy, BR - 1)); cz = max(0, min(cz, BR - 1));
+                const int cell = (cx * BR + cy) * BR + cz;
+                atomicAdd(&sm.cells[cell >> 1], 1u << (16 * (cell & 1)));
+            }
+        }
+        __syncthreads();
+        {
+            int dm = 0;
+            for (int e = tid; e < NCELL5 / 2; e += NT) {
+                const unsigned w2 = sm.cells[e];
+                const int a = (int)(w2 & 0xffffu), c2 = (int)(w2 >> 16);
+                dm = a > dm ? a : dm; dm = c2 > dm ? c2 : dm;
+            }
+            dm = wave_max(dm);
+            if ((tid & 63) == 0 && dm > 0) atomicMax(&sm.dmax, dm);
+        }
+        __syncthreads();
+        // 32-bit sums hold while density * prod_d sum_j max_t w_j(t) units of max |source| fit (tile_common.hpp: headroom32)
+        const float wsum = K == 5 ? 1.55f : 1.5989584f;
+        const bool dense = ntot >= 60000 || (float)sm.dmax * (wsum * wsum * wsum) > cbmax5<K>();           // (block-uniform)
+        if (!dense) counts5<K>(sm, tid);
+        const unsigned boxaddr = (unsigned)(size_t)(__attribute__((address_space(3))) void *)(sm.box);
+        for (int c = 0; c < nch; ++c) {
+            const float *sc = (src && c < p.C) ? src + b * p.val_sb + (int64_t)c * p.val_sc : nullptr;      // NULL: the count (source = mask)
+            float *vc = vol + b * p.vol_sb + (int64_t)c * p.vol_sc;
+            if (tid == 0) { sm.amax = 0; sm.nonfinite = 0; }
+            __syncthreads();
+            // ---- max |masked source| of the brick's records
+            {
+                int rr = 0, am = 0; bool fin = true;
+                for (int j = tid; j < ntot; j += NT) {
+                    while (j >= sm.pref[rr + 1]) ++rr;
+                    const float4 rc = rec[sm.start[rr] + (unsigned)(j - sm.pref[rr])];
+                    const float xyz[3] = { rc.x, rc.y, rc.z };
+                    const float v = (sc ? sc[__float_as_int(rc.w)] : 1.f) * inb_mask(p, xyz);
+                    const int a = __float_as_int(__builtin_fabsf(v));
+                    if ((a & 0x7f800000) == 0x7f800000) fin = false; else am = a > am ? a : am;
+                }
+                am = wave_max(am);
+                if ((tid & 63) == 0 && am) atomicMax(&sm.amax, am);
+                if (!fin) sm.nonfinite = 1;
+            }
+            __syncthreads();
+            const int mb = sm.amax;
+            const bool direct = dense || sm.nonfinite != 0;          // (block-uniform)
+            if (mb == 0 && !direct) continue;                        // nothing but zeros
+            const float a0 = fmaxf(__int_as_float(mb), 1e-27f);
+            const float scale = units5<K>() / a0, inv = a0 * (1.f / units5<K>());
+            // ---- the taps
+            {
+                int rr = 0;
+                for (int j = tid; j < ntot; j += NT) {
+                    while (j >= sm.pref[rr + 1]) ++rr;
+                    const float4 rc = rec[sm.start[rr] + (unsigned)(j - sm.pref[rr])];
+                    const float fx = floorf(rc.x - 0.5f * (float)(K - 1)), fy = floorf(rc.y - 0.5f * (float)(K - 1)), fz = floorf(rc.z - 0.5f * (float)(K - 1));
+                    const float tx = rc.x - fx, ty = rc.y - fy, tz = rc.z - fz;
+                    const float xyz[3] = { rc.x, rc.y, rc.z };
+                    const float sv = (sc ? sc[__float_as_int(rc.w)] : 1.f) * inb_mask(p, xyz);
+                    // (a zero source adds MAGIC to every slot of its stencil like any other record: the stencil counts include it)
+                    if (direct) {
+                        if (sv != 0.f) tiled::scatter_one_thread(L, vc, sv, __float2int_rz(fx), __float2int_rz(fy), __float2int_rz(fz), tx, ty, tz);
+                        continue;
+                    }
+                    int cx = __float2int_rz(fx) - b0[0], cy = __float2int_rz(fy) - b0[1], cz = __float2int_rz(fz) - b0[2];
+                    cx = max(0, min(cx, BR - 1)); cy = max(0, min(cy, BR - 1)); cz = max(0, min(cz, BR - 1));
+                    const unsigned addr = boxaddr + (unsigned)((cx * BOX + cy) * BOX + cz) * 4u;
+                    float wy[6], wz[6];
+                    wy[5] = 0.f; wz[5] = 0.f;
+                    tiled::weights<K>(0, K, ty, wy);
+                    tiled::weights<K>(0, K, tz, wz);
+                    const float ss = sv * scale;
+                    scatter_plane5<K, 0>(addr, ss, tiled::weight1(0, K, tx, 0, tiled::tap_piece(K, 0)), wy, wz);
+                    scatter_plane5<K, 1>(addr, ss, tiled::weight1(0, K, tx, 1, tiled::tap_piece(K, 1)), wy, wz);
+                    scatter_plane5<K, 2>(addr, ss, tiled::weight1(0, K, tx, 2, tiled::tap_piece(K, 2)), wy, wz);
+                    scatter_plane5<K, 3>(addr, ss, tiled::weight1(0, K, tx, 3, tiled::tap_piece(K, 3)), wy, wz);
+                    scatter_plane5<K, 4>(addr, ss, tiled::weight1(0, K, tx, 4, tiled::tap_piece(K, 4)), wy, wz);
+                    if (K == 5) scatter_plane5<K, 5>(addr, ss, tiled::weight1(0, K, tx, 5, tiled::tap_piece(K, 5)), wy, wz);
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __syncthreads();
+            // ---- flush: a slot that n stencils cover holds n * MAGIC_BITS + the sum of its addends (mod 2^32)
+            if (!direct) {
+                const unsigned short *nn = reinterpret_cast<const unsigned short *>(sm.nreg);
+                for (int e = tid; e < BOX * BOX * BOX; e += NT) {
+                    const int x = e / (BOX * BOX), rem = e - x * (BOX * BOX), y = rem / BOX, z = rem - y * BOX;
+                    const unsigned n = nn[(x * BOX + y) * NZ5 + z];
+                    if (n == 0u) continue;
+                    const unsigned w = sm.box[e];
+                    sm.box[e] = 0u;
+                    const int sq = (int)(w - n * MAGIC5_BITS);
+                    if (sq == 0) continue;
+                    const float sg = sm.tabsgn[0][x] * sm.tabsgn[1][y] * sm.tabsgn[2][z];
+                    __hip_atomic_fetch_add(vc + (sm.taboff[0][x] + sm.taboff[1][y] + sm.taboff[2][z]), (float)sq * (inv * sg), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+        }
+    }
+}
+
 static bool eligible(const interpol_problem *p, const KParams &k)
 {
     if (p->dim != 3 || p->dtype != INTERPOL_F32 || p->grid_dtype != INTERPOL_F32 || p->batch > 4096) return false;
@@ -566,6 +865,70 @@ int try_gather5(const interpol_problem *p, const KParams &k, const void *vol, co
     else { if (mode == 2) IP_G5_GM(4, 2) else if (mode == 1) IP_G5_GM(4, 1) else IP_G5_GM(4, 0) }
 #undef IP_G5_GM
 #undef IP_G5
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return (int)e;
+    if (gate_out) *gate_out = gate;
+    return gated ? 2 : 1;
+}
+
+// grid_push (val != NULL) / grid_count of orders 4 and 5 through bricks of the target (scatter5): 1 = done, 0 = declined, else an error.
+// The target `vol` (float, zeroed or accumulated into by the caller) takes p->channels (+ 1 with k.cc) channels.
+int64_t scatter5_workspace_bytes(const interpol_problem *p, const KParams &k)
+{
+    interpol_problem q = *p;
+    q.val_stride[0] = 0;                                             // (the gathers' test of the output strides does not apply)
+    if (!g5::eligible(&q, k)) return 0;
+    // the bricks when there is at least a quarter of a sample per target voxel (sparser: the tiles / the target-stationary splatting)
+    int64_t n = 1, nv = 1, nt = 1;
+    for (int d = 0; d < 3; ++d) { n *= p->grid_shape[d]; nv *= p->vol_shape[d]; nt *= (p->grid_shape[d] + sorted::TS - 1) / sorted::TS; }
+    if (4 * n < nv || p->vol_stride[0] == 0) return 0;               // (a shared target: not here)
+    return g5::layout(g5::brick_grid(k), (int)p->batch, nt, nullptr, nullptr);
+}
+// INTERPOL_FLAG_AUTO_SCATTER: 2 = launched behind the verdict of probe5 (smooth fields stay with the LDS tiles: 8 x 1 x 192^3 order 5 at the
+// identity 2.22 against 2.37 ms; rough ones go to the bricks: sigma = 2 4.24 / 3.68) -- the caller launches the tiles as well, with
+// KParams::gate = *gate_out (they return at once when the verdict is 1).
+int try_scatter5(const interpol_problem *p, const KParams &k, const void *val, const void *grid, void *vol, void *workspace, int64_t workspace_bytes,
+                 hipStream_t st, const int **gate_out)
+{
+    using namespace g5;
+    if (!workspace || ((uintptr_t)workspace & 255u) != 0) return 0;
+    const int64_t need = scatter5_workspace_bytes(p, k);
+    if (need <= 0 || need > workspace_bytes) return 0;
+    const int gx = (int)p->grid_shape[0], gy = (int)p->grid_shape[1], gz = (int)p->grid_shape[2];
+    const int nty = (gy + TS - 1) / TS, ntz = (gz + TS - 1) / TS, ntiles = ((gx + TS - 1) / TS) * nty * ntz;
+    const Grid5 bg = brick_grid(k);
+    Workspace w;
+    if (layout(bg, (int)p->batch, ntiles, workspace, &w) > workspace_bytes) return 0;
+    const int64_t nz = 64 + 2 * w.nbricks + 1;
+    if (nz > 0x7fffffffll) return 0;
+    hipLaunchKernelGGL(zero5, dim3((unsigned)((nz + 1023) / 1024)), dim3(1024), 0, st, w.hdr, (int)nz);
+    const bool gated = !(p->flags & INTERPOL_FLAG_BINNED_SCATTER);
+    const int *gate = gated ? w.hdr : nullptr;
+    if (gated) {
+        const long long total = (long long)ntiles * p->batch;
+        const dim3 pgrid((unsigned)(total < NPROBE ? total : NPROBE));
+#define IP_P5(KK, GM) hipLaunchKernelGGL((probe5<KK, GM>), pgrid, dim3(NT1), 0, st, k, (const float *)grid, w.hdr, gx, gy, gz, nty, ntz, ntiles, (int)p->batch);
+#define IP_P5_GM(KK) { if (k.sep == 0) IP_P5(KK, 0) else if (k.sep == 1) IP_P5(KK, 1) else if (k.sep == 2) IP_P5(KK, 2) else IP_P5(KK, 3) }
+        if (k.order[0] == 5) IP_P5_GM(5) else IP_P5_GM(4)
+#undef IP_P5_GM
+#undef IP_P5
+    }
+    const dim3 tgrid((unsigned)(ntiles * (int)p->batch));
+    const long long want = 2ll * cu_count();
+    const dim3 ggrid((unsigned)(w.nbricks < want ? w.nbricks : want));
+#define IP_S5(KK, GM)                                                                                                   \
+    {                                                                                                                   \
+        hipLaunchKernelGGL((bin5<KK, GM, 3>), tgrid, dim3(NT1), 0, st, k, bg, (const float *)val, (const float *)grid, (float *)vol, \
+                           w.ndesc, w.list, w.desc, w.rec, gx, gy, gz, nty, ntz, ntiles, gate, (const float *)nullptr); \
+        const int attr = big_lds<scatter5<KK>>(sizeof(ScatSmem));                                                       \
+        if (attr) return attr;                                                                                          \
+        hipLaunchKernelGGL((scatter5<KK>), ggrid, dim3(NT), sizeof(ScatSmem), st, k, bg, (const int *)w.ndesc, (const uint2 *)w.desc, \
+                           (const float4 *)w.rec, (const int *)w.list, w.hdr + 40, (const float *)val, (float *)vol, gate);   \
+    }
+#define IP_S5_GM(KK) { if (k.sep == 0) IP_S5(KK, 0) else if (k.sep == 1) IP_S5(KK, 1) else if (k.sep == 2) IP_S5(KK, 2) else IP_S5(KK, 3) }
+    if (k.order[0] == 5) IP_S5_GM(5) else IP_S5_GM(4)
+#undef IP_S5_GM
+#undef IP_S5
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) return (int)e;
     if (gate_out) *gate_out = gate;

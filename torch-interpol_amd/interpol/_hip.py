@@ -541,12 +541,13 @@ def pull_backward(gout, vol, grid, bound, order, extrapolate, need_vol, need_gri
     vstr = [_bstride(vol, B), vol.stride(1)] + _pad_to([vol.stride(2 + d) for d in range(dim)], 3)
     valstr = [_bstride(gout, B), gout.stride(1)] + _pad_to([gout.stride(2 + d) for d in range(dim)], 3) + [0, 0]
     routed = 0
-    if (need_grid and dim == 3 and dt == torch.float32 and gdt == torch.float32 and (flags >> 8) == 0
+    high = dim == 3 and all(int(o) == int(order[0]) for o in order[:3]) and int(order[0]) in (4, 5)   # image gradient through scatter5
+    if ((need_grid or (need_vol and high)) and dim == 3 and dt == torch.float32 and gdt == torch.float32 and (flags >> 8) == 0
             and not (flags & (FLAG_NO_FASTPATH | FLAG_FORCE_TILED | FLAG_BINNED_SCATTER))):
         # the grid gradient takes the router of the pull (csrc/push_owner.hip: own_gather<K, true>): tiles whose samples leave the
         # LDS box go to the bricks of the image; the workspace rides in the `scratch` argument (interpol_hip.h)
         routed = FLAG_AUTO_SCATTER if backend.rough_deformations is None else (FLAG_BINNED_SCATTER if backend.rough_deformations else 0)
-    elif need_grid and (flags & FLAG_BINNED_SCATTER):
+    elif (need_grid or (need_vol and high)) and (flags & FLAG_BINNED_SCATTER):
         routed = FLAG_BINNED_SCATTER
     p = make_problem(dim, dt, gdt, bound, order, extrapolate, B, C, ishape, oshape,
                      vstr, _grid_strides(grid_c, B, dim), valstr, flags | routed)
