@@ -34,6 +34,7 @@ for order in [int(a) for a in (os.environ.get("ORDERS", "5,4").split(","))]:
         backend.rough_deformations = None
         a = _hip.scatter("push", x, grid, None, bc, o, 1)
         res["push_bricks"] = round(timeit(lambda: _hip.scatter("push", x, grid, None, bc, o, 1)), 3)
+        res["push_bricks_forced"] = round(timeit(lambda: _hip.scatter("push", x, grid, None, bc, o, 1, flags=_hip.FLAG_BINNED_SCATTER)), 3)
         res["bwd_both_bricks"] = round(timeit(lambda: _hip.pull_backward(x, x, grid, bc, o, 1, True, True)), 3)
         ga = _hip.pull_backward(x, x, grid, bc, o, 1, True, True)
         backend.rough_deformations = False
