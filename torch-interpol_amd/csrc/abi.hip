@@ -712,8 +712,16 @@ int interpol_pull_backward(const interpol_problem *p, const void *grad_out, cons
                 if (rc < 0 || rc > 2) return rc;
                 if (rc == 2) rc = 0;                                 // (behind the probe: the tiles below read the same verdict)
             }
+            const bool behind_probe = kp.gate != nullptr;
             if (rc == 0) rc = try_fast_push(p, kp, grad_out, grid, acc, st);
             if (rc < 0 || rc > 1) return rc;
+            if (rc == 0 && behind_probe) {
+                // scatter5 is enqueued behind the probe and the tiles declined (a separable / affine lattice at these orders): the generic
+                // push, which reads the same verdict, is the other organisation -- not the fused kernel below, which does not
+                rc = launch_push_f32(kp, grad_out, grid, acc, B, st);
+                if (rc) return rc;
+                rc = 1;
+            }
             vol_done = rc == 1;
             rc = (vol_done && !grad_grid) ? 1 : 0;
         }
