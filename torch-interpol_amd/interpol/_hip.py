@@ -101,6 +101,13 @@ def _optional_workspace(nbytes, dev):
     if nbytes <= 0:
         return None
     idx = dev.index if dev.index is not None else torch.cuda.current_device()
+    if torch.cuda.is_current_stream_capturing():
+        # inside a hipGraph capture the buffer must belong to the graph (its private pool keeps it alive for the replays): a cached
+        # buffer could be replaced by a larger one -- and freed -- after the capture
+        try:
+            return torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        except torch.cuda.OutOfMemoryError:
+            return None
     key = (idx, int(torch.cuda.current_stream(dev).cuda_stream))
     ws = _WS_CACHE.get(key)
     if ws is not None and ws.numel() >= nbytes:
