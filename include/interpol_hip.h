@@ -180,6 +180,15 @@ typedef struct interpol_problem {
  * organisation does not apply.  With a smaller (or no) scratch -- or one that is not aligned to 256 bytes (the
  * workspace holds 8- and 16-byte records) -- the operators fall back to the tiled / generic scatters: same results.
  *
+ * Round 5: (a) a target SHARED by the batch items (batch stride 0) takes the same organisation -- the items' samples are sorted
+ * into ONE brick grid (up to 512 runs per brick) and the bricks flush with plain loads and stores, no atomics; it applies once
+ * all items together bring an eighth of a sample per target voxel (BASELINE config 4: 64 sources of 128^3 into 512^3, push + count
+ * 16.3 -> 6.3 ms).  (b) Orders 4 and 5 (3-D, F32, private targets with at least a quarter of a sample per voxel):
+ * interpol_scatter_workspace returns 16 B per sample + 1 KiB per brick for them and interpol_push / interpol_count -- and the image
+ * gradient of interpol_pull_backward, which takes the workspace in its `scratch` -- go through bricks of the target (gather5.hip:
+ * scatter5), behind a probe of the call under INTERPOL_FLAG_AUTO_SCATTER (smooth fields keep the LDS tiles): cost independent of
+ * the deformation (8 x 1 x 192^3 order 5: 2.9 ms at sigma = 2, 3.1 ms at sigma = 6, where the tiles took 4.2 ms and fell off a cliff).
+ *
  * Accuracy of the LDS scatters (every fast path of interpol_push / interpol_count and of the scatter halves of the
  * backward operators; INTERPOL_FLAG_NO_FASTPATH selects the generic kernels, which add floats like the reference's
  * scatter_add_): contributions are summed in FIXED POINT scaled by the largest |source| of the tile / brick they belong
@@ -189,7 +198,8 @@ typedef struct interpol_problem {
  *   F32 / BF16 / F16, bricks (push_owner.hip, "magic" format): each addend rounded to nearest at
  *     max|source| * wmax^3 * 2^-22 / 0.999 (wmax = 2/3 cubic, 3/4 quadratic: 2^-23.75 resp. 2^-23.25 of the brick's
  *     maximum), whatever the density; bricks whose stencil counts could overflow 32-bit sums use 64-bit sums of terms
- *     rounded at 2^-30 of a power of two >= the maximum;
+ *     rounded at 2^-30 of a power of two >= the maximum; orders 4 - 5 (gather5.hip: scatter5): the same format in 32-bit
+ *     sums, one channel per pass, wmax = 0.599 (order 4) / 0.55 (order 5): 2^-24.2 / 2^-24.6 of the brick's maximum per addend;
  *   F64 (push_f64.hip): each addend rounded at 2^-51 of a power of two > the tile's maximum -- about 2^-52 of the tile's
  *     largest source per term, again absolute per tile; tiles whose maximum is below 2^-970 use the generic arithmetic.
  * Sums inside a tile / brick are integers: order-free, bit-reproducible.
