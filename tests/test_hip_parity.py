@@ -1594,6 +1594,116 @@ def test_orders_4_and_5_push_and_count_through_bricks_of_the_target(sigma):
         oracle.set_threads(1)
 
 
+@pytest.mark.parametrize("sigma", [0.0, 3.0, 12.0])
+def test_two_d_operators_through_bricks(sigma):
+    """Round 5 (csrc/scatter2d.hip): every 2-D operator with per-dim orders 1..3 has a deformation-independent organisation behind a
+    probe of the call -- grid_push / grid_count through bricks of the target (scatter2d), grid_pull and the grid gradients through
+    bricks of the image (gather2d).  The routed default (probe2d keeps the lean tiles or hands the call to the bricks) and the
+    bricks alone (backend.rough_deformations = True) against the oracle: every bound (mixed per dim), mixed orders -- the
+    reference's +sign(dist) gradient of order 1 in its general path included (splines.py:93-97) --, the three extrapolation modes,
+    1 - 5 channels (channel groups of a record), sample grids that overhang the lattice; sigma = 12 leaves the tiles' 64 x 64 boxes
+    everywhere (pull 3.6 ms, push 13 ms at config 5's shape before this round)."""
+    from interpol import _hip, backend
+    g = torch.Generator().manual_seed(int(sigma) + 2200)
+    oracle.set_threads(8)
+    prev = backend.rough_deformations
+    try:
+        for (tshape, sshape) in (((90, 77), (84, 101)), ((128, 128), (128, 128))):
+            for bound in range(7):
+                o = [1 + bound % 3, 1 + (bound // 2) % 3]
+                ex, C = (bound + o[0]) % 3, 1 + (2 * bound) % 5
+                b = [bound, (bound + 3) % 7]
+                src = torch.randn([2, C, *sshape], generator=g)
+                img = torch.randn([2, C, *tshape], generator=g)
+                lin = [torch.linspace(-2, n + 1, m) for n, m in zip(tshape, sshape)]
+                grid = torch.stack(torch.meshgrid(*lin, indexing="ij"), -1)[None] + sigma * torch.randn([2, *sshape, 2], generator=g)
+                gn, sn, im = grid.double().numpy(), src.double().numpy(), img.double().numpy()
+                want_push = oracle.grid_push(sn, gn, list(tshape), b, o, ex)
+                want_cnt = oracle.grid_count(gn, list(tshape), b, o, ex)
+                want_pull = oracle.grid_pull(im, gn, b, o, ex)
+                want_gi, want_gg = oracle.grid_pull_backward(sn, im, gn, b, o, ex)
+                want_pi, want_pg = oracle.grid_push_backward(im, sn, gn, b, o, ex)
+                want_cg = oracle.grid_count_backward(im[:, :1], gn, b, o, ex)
+                srcd, imgd, gridd = src.to(DEV), img.to(DEV), grid.to(DEV)
+                for name, rd in (("routed", None), ("bricks", True)):
+                    backend.rough_deformations = rd
+                    what = (name, sigma, b, o, ex, C)
+                    tol = dict(rtol=1e-5, atol_rel=1e-5)
+                    G.assert_close(_hip.scatter("push", srcd, gridd, list(tshape), b, o, ex).cpu().numpy(), want_push, what=("push",) + what, **tol)
+                    G.assert_close(_hip.scatter("count", None, gridd, list(tshape), b, o, ex).cpu().numpy(), want_cnt, what=("count",) + what, **tol)
+                    both = _hip.scatter("push", srcd, gridd, list(tshape), b, o, ex, with_count=True)
+                    G.assert_close(both[:, :C].cpu().numpy(), want_push, what=("push+count",) + what, **tol)
+                    G.assert_close(both[:, C:].cpu().numpy(), want_cnt, what=("push+count: count",) + what, **tol)
+                    G.assert_close(_hip.gather("pull", imgd, gridd, b, o, ex).cpu().numpy(), want_pull, what=("pull",) + what, **tol)
+                    gi, gg = _hip.pull_backward(srcd, imgd, gridd, b, o, ex, True, True)
+                    G.assert_close(gi.cpu().numpy(), want_gi, what=("pull bwd image",) + what, **tol)
+                    G.assert_close(gg.cpu().numpy(), want_gg, what=("pull bwd grid",) + what, **tol)
+                    G.assert_close(_hip.pull_backward(srcd, imgd, gridd, b, o, ex, False, True)[1].cpu().numpy(), want_gg, what=("pull bwd grid only",) + what, **tol)
+                    pi, pg = _hip.push_backward(imgd, srcd, gridd, b, o, ex, True, True)
+                    G.assert_close(pi.cpu().numpy(), want_pi, what=("push bwd values",) + what, **tol)
+                    G.assert_close(pg.cpu().numpy(), want_pg, what=("push bwd grid",) + what, **tol)
+                    cg = _hip.push_backward(imgd[:, :1].contiguous(), None, gridd, b, o, ex, False, True)[1]
+                    G.assert_close(cg.cpu().numpy(), want_cg, what=("count bwd",) + what, **tol)
+    finally:
+        backend.rough_deformations = prev
+        oracle.set_threads(1)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_two_d_bricks_low_precision_storage(dtype):
+    """The 2-D bricks with 16-bit storage (BASELINE config 5's contract: bf16 images, fp32 coordinates and sums): a record carries four
+    channels in the source's own format; results within the storage rounding of the float32 kernels on the same (rounded) inputs."""
+    from interpol import _hip, backend
+    g = torch.Generator().manual_seed(77)
+    prev = backend.rough_deformations
+    try:
+        for sigma in (1.0, 10.0):
+            for C in (1, 3, 6):
+                tshape, sshape = (120, 96), (110, 130)
+                b, o, ex = [2, 5], [2, 3], 1
+                src = torch.randn([2, C, *sshape], generator=g).to(dtype).to(DEV)
+                img = torch.randn([2, C, *tshape], generator=g).to(dtype).to(DEV)
+                lin = [torch.linspace(-1, n, m) for n, m in zip(tshape, sshape)]
+                grid = (torch.stack(torch.meshgrid(*lin, indexing="ij"), -1)[None] + sigma * torch.randn([2, *sshape, 2], generator=g)).to(DEV)
+                backend.rough_deformations = False
+                ref_push = _hip.scatter("push", src.float(), grid, list(tshape), b, o, ex, with_count=True)
+                ref_pull = _hip.gather("pull", img.float(), grid, b, o, ex)
+                ref_gg = _hip.pull_backward(src.float(), img.float(), grid, b, o, ex, False, True)[1]
+                tol = 6e-3 if dtype == torch.bfloat16 else 8e-4
+                for rd in (True, None):
+                    backend.rough_deformations = rd
+                    got = _hip.scatter("push", src, grid, list(tshape), b, o, ex, with_count=True)
+                    assert got.dtype == dtype and G.rel_err(got.float().cpu().numpy(), ref_push.cpu().numpy()) < tol, ("push", rd, sigma, C)
+                    got = _hip.gather("pull", img, grid, b, o, ex)
+                    assert got.dtype == dtype and G.rel_err(got.float().cpu().numpy(), ref_pull.cpu().numpy()) < tol, ("pull", rd, sigma, C)
+                    got = _hip.pull_backward(src, img, grid, b, o, ex, False, True)[1]
+                    assert got.dtype == torch.float32 and G.rel_err(got.cpu().numpy(), ref_gg.cpu().numpy()) < 1e-5, ("grid gradient", rd, sigma, C)
+    finally:
+        backend.rough_deformations = prev
+
+
+def test_two_d_router_verdict_follows_the_field():
+    """probe2d examines every 16th tile of the call with the lean tiles' own box rule; the verdict (a word of the workspace) is a function
+    of the coordinates of this call alone: a smooth field keeps the tiles, i.i.d. noise of sigma = 8 px hands the call to the bricks
+    -- seen from outside as bit-identical results with the forced organisations' (the bricks of the image gather deterministically)."""
+    from interpol import _hip, backend
+    g = torch.Generator().manual_seed(5)
+    n = 256
+    img = torch.randn([2, 2, n, n], generator=g).to(DEV)
+    ident = interpol.identity_grid([n, n])[None]
+    prev = backend.rough_deformations
+    try:
+        for sigma, organisation in ((0.5, False), (8.0, True)):
+            grid = (ident + sigma * torch.randn([2, n, n, 2], generator=g)).to(DEV)
+            backend.rough_deformations = None
+            routed = _hip.gather("pull", img, grid, [3, 1], [3, 2], 1)
+            backend.rough_deformations = organisation
+            forced = _hip.gather("pull", img, grid, [3, 1], [3, 2], 1)
+            assert torch.equal(routed, forced), sigma
+    finally:
+        backend.rough_deformations = prev
+
+
 def test_third_order_through_the_grid_on_the_gpu():
     """Round 5: a backward of a double backward through grid_grad (create_graph=True twice) on CUDA tensors -- forward and first
     backward are HIP kernels, the higher orders autograd through the torch restatement -- equals the same derivative computed

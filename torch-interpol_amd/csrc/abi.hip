@@ -66,6 +66,10 @@ int64_t gather5_workspace_bytes(const interpol_problem *, const KParams &);
 int try_gather5(const interpol_problem *, const KParams &, const void *, const void *, void *, void *, int64_t, int, const void *, hipStream_t, const int **);
 int64_t scatter5_workspace_bytes(const interpol_problem *, const KParams &);
 int try_scatter5(const interpol_problem *, const KParams &, const void *, const void *, void *, void *, int64_t, hipStream_t, const int **);
+int64_t scatter2d_workspace_bytes(const interpol_problem *, const KParams &);
+int64_t gather2d_workspace_bytes(const interpol_problem *, const KParams &);
+int try_gather2d(const interpol_problem *, const KParams &, const void *, const void *, void *, void *, int64_t, int, const void *, hipStream_t, const int **);
+int try_scatter2d(const interpol_problem *, const KParams &, const void *, const void *, void *, void *, int64_t, hipStream_t, const int **);
 #ifdef IP_EXPERIMENTS
 int try_pull_direct(const interpol_problem *, const KParams &, const void *, const void *, void *, int *, int, hipStream_t);
 #endif
@@ -311,6 +315,7 @@ int64_t interpol_pull_workspace(const interpol_problem *p)
     KParams k; int B;
     if (make_params(p, GATHER, 1, &k, &B, false)) return 0;          // (the layout of `val` -- pull, grad, a gradient -- plays no part)
     if (p->flags & INTERPOL_FLAG_NO_FASTPATH) return 0;
+    if (p->dim == 2) return gather2d_workspace_bytes(p, k);         // 2-D (scatter2d.hip: gather2d)
     const int64_t b5 = gather5_workspace_bytes(p, k);               // orders 4 and 5 (gather5.hip)
     return b5 ? b5 : owner_pull_workspace_bytes(p, k);
 }
@@ -321,6 +326,21 @@ static int routed_pull(const interpol_problem *p, KParams k, int B, const void *
 {
     int *flags = nullptr;
     int nzero = 0;
+    if (p->dim == 2) {
+        // 2-D (scatter2d.hip: gather2d): the bricks always, or behind a probe of the call next to the lean tiles, which read the verdict
+        const int *gate = nullptr;
+        int r2 = try_gather2d(p, k, vol, grid, val, workspace, workspace_bytes, 0, nullptr, st, &gate);
+        if (r2 != 2) return r2;
+        k.gate = gate; k.gate_n = -1;
+        r2 = try_fast_pull(p, k, vol, grid, val, st);
+        if (r2 != 0) return r2;
+        r2 = by_dtype(p->dtype,                                      // (the tiles declined: the generic kernel, behind the same verdict)
+            [&] { return launch_pull_f32(k, vol, grid, val, B, st); },
+            [&] { return INTERPOL_E_DTYPE; },
+            [&] { return launch_pull_bf16(k, vol, grid, val, B, st); },
+            [&] { return launch_pull_f16(k, vol, grid, val, B, st); });
+        return r2 ? r2 : 1;
+    }
     if (k.order[0] >= 4) {
         // orders 4 and 5 (gather5.hip): the bricks always, or behind a probe of the call next to the tiles, which read the same verdict
         const int *gate = nullptr;
@@ -490,6 +510,10 @@ int interpol_push(const interpol_problem *p, const void *val, const void *grid, 
                 rc = try_scatter5(p, k, val, grid, acc, ws, ws_bytes, st, &k.gate);      // orders 4 - 5 through bricks of the target (gather5.hip)
                 if (rc != 0 && rc != 2) return rc == 1 ? 0 : rc;
             }
+            if (rc == 0 && p->dim == 2) {
+                rc = try_scatter2d(p, k, val, grid, acc, ws, ws_bytes, st, &k.gate);    // 2-D through bricks of the target (scatter2d.hip)
+                if (rc != 0 && rc != 2) return rc == 1 ? 0 : rc;
+            }
             rc = try_fast_push(p, k, val, grid, acc, st);           // the tiled kernel splats values and count in one pass
             if (rc != 0) return rc == 1 ? 0 : rc;
         }
@@ -573,6 +597,7 @@ int64_t interpol_scatter_workspace(const interpol_problem *p, int32_t count_only
     int64_t ws = owner_workspace_bytes(p, k, count_only != 0);
     if (ws <= 0 && p->dtype == INTERPOL_F32 && (p->flags & (INTERPOL_FLAG_BINNED_SCATTER | INTERPOL_FLAG_AUTO_SCATTER)))
         ws = scatter5_workspace_bytes(p, k);                         // orders 4 - 5 (gather5.hip: scatter5)
+    if (ws <= 0) ws = scatter2d_workspace_bytes(p, k);               // 2-D (scatter2d.hip)
     if (ws <= 0) return 0;
     const bool lowp = (p->dtype == INTERPOL_BF16 || p->dtype == INTERPOL_F16);
     return ws + (lowp ? ((vol_numel(p) * 4 + 255) & ~(int64_t)255) : 0);
@@ -591,6 +616,10 @@ int interpol_count(const interpol_problem *p, const void *grid, void *vol,
             if (rc != 0 && rc != 2) return rc == 1 ? 0 : rc;
             if (rc == 0 && p->dtype == INTERPOL_F32) {
                 rc = try_scatter5(p, k, nullptr, grid, acc, ws, ws_bytes, st, &k.gate);
+                if (rc != 0 && rc != 2) return rc == 1 ? 0 : rc;
+            }
+            if (rc == 0 && p->dim == 2) {
+                rc = try_scatter2d(p, k, nullptr, grid, acc, ws, ws_bytes, st, &k.gate);
                 if (rc != 0 && rc != 2) return rc == 1 ? 0 : rc;
             }
             rc = try_fast_push(p, k, nullptr, grid, acc, st);
@@ -629,6 +658,16 @@ static int routed_gradc(const interpol_problem *p, const KParams &k, const void 
 {
     int *flags = nullptr;
     int nzero = 0;
+    if (p->dim == 2) {
+        // 2-D (scatter2d.hip: gather2d, mode 1): the bricks always, or behind a probe of the call next to the lean tiles (gradc2d)
+        const int *gate = nullptr;
+        int r2 = try_gather2d(p, k, vol, grid, ggrid, scratch, scratch_bytes, 1, gout, st, &gate);
+        if (r2 != 2) return r2;
+        KParams kg = k;
+        kg.gate = gate; kg.gate_n = -1;
+        r2 = try_fast_pullbwd(p, kg, gout, vol, grid, nullptr, ggrid, 0, 0, st);
+        return r2;                                                   // (0: the tiles declined -- the caller's kernels write the same numbers over the bricks')
+    }
     if (k.order[0] >= 4) {                                           // orders 4 and 5: gather5.hip, the bricks always (1), or declined (0)
         const int r5 = try_gather5(p, k, vol, grid, ggrid, scratch, scratch_bytes, 1, gout, st, nullptr);
         return r5 == 2 ? INTERPOL_E_SHAPE : r5;
@@ -725,7 +764,8 @@ int interpol_pull_backward(const interpol_problem *p, const void *grad_out, cons
             vol_done = rc == 1;
             rc = (vol_done && !grad_grid) ? 1 : 0;
         }
-        if (rc == 0 && grad_grid && (vol_done || !grad_vol) && p->dtype == INTERPOL_F32 && scratch) {
+        if (rc == 0 && grad_grid && (vol_done || !grad_vol) && scratch && (p->dtype == INTERPOL_F32 || (p->dim == 2 && !grad_vol && p->dtype != INTERPOL_F64))) {
+            // (a 16-bit image gradient uses `scratch` as its accumulator: the workspace only when there is none)
             rc = routed_gradc(p, k, grad_out, vol, grid, grad_grid, scratch, scratch_bytes, st);
             if (rc != 0 && rc != 1) return rc;
         }
@@ -796,7 +836,7 @@ int interpol_push_backward_ws(const interpol_problem *p, const void *grad_vol_ou
     if (!grad_val && !grad_grid) return 0;
     if (grad_grid && (p->flags & (INTERPOL_FLAG_SEPARABLE_GRID | INTERPOL_FLAG_AFFINE_GRID))) return INTERPOL_E_STRIDE;
     hipStream_t st = (hipStream_t)stream;
-    if (!(p->flags & INTERPOL_FLAG_NO_FASTPATH) && p->dtype == INTERPOL_F32 && workspace) {
+    if (!(p->flags & INTERPOL_FLAG_NO_FASTPATH) && (p->dtype == INTERPOL_F32 || (p->dim == 2 && p->dtype != INTERPOL_F64)) && workspace) {
         if (grad_grid) {
             rc = routed_gradc(p, k, val, grad_vol_out, grid, grad_grid, workspace, workspace_bytes, st);
             if (rc != 0 && rc != 1) return rc;

@@ -1,0 +1,1014 @@
+// ===========================================================================
+// scatter2d.hip (round 5) -- the 2-D operators with per-dim orders 1..3 (BASELINE config 5: batches of 2-D images, f32 / bf16 / f16
+// storage, fp32 coordinates and sums) through BRICKS: grid_push / grid_count (reference interpol/nd.py:146-213, pushpull.py:106-142)
+// through bricks of the target, grid_pull and the grid gradients (nd.py:80-143, pushpull.py:256-257, 278-281) through bricks of the
+// image, each behind a probe of the call.  The organisation of gather5.hip for 4 - 16-tap stencils.
+//
+// Why.  The lean tiles of ops_tiled2d.hip serve a 32 x 32-pixel tile from an LDS box of at most 64 x 64 lattice points; a pixel whose
+// stencil leaves the box is handled by its own thread, tap by tap, from / into global memory.  At config 5's shape (32 x 3 x 1024^2
+// bf16, orders [2, 3]) under i.i.d. noise: push 1.04 ms at sigma = 2, 4.3 at 8, 13.4 at 16; pull 0.43 / 2.8 / 3.6; the pull's backward
+// 1.4 / 7.1 / 17 -- the last cliffs of the library (missing 2), with only the host-state hand-back of defer.hip in front.
+//
+// How.  bin2d / binidx2d: one workgroup per tile of the sample grid sorts its samples by the 32 x 32 brick of first-tap cells and writes
+// 16-byte records, run by run per (tile, brick) as gather5.hip's bin5 does.  A scatter record CARRIES the masked source values --
+// (x, y, v0, v1) for float32 sources, (x, y, v0 v1, v2 v3) for 16-bit ones, more channels: the pair of kernels again per group -- and a
+// run's descriptor the tile's max |v| per channel, so the brick pass reads nothing but records; a gather record is (x, y, sample index).
+//   scatter2d: a workgroup walks bricks of the list; per brick it adds every record's (K0 + 1)(K1 + 1) taps, all channels of the record,
+// into 35 x 35 boxes of 32-bit sums -- round(v * w * units / max|v|) taken from the mantissa of the float t + 1.5 * 2^23 (one v_fma +
+// one v_sub per tap, ds_add_u32) -- and flushes the boxes through the boundary tables with float atomics: (35 / 32)^2 = 1.2 per pixel
+// and channel whatever the deformation (the tiles: 2.5 at sigma = 2).  units = 2^22 / prod wmax, lowered to 2^31 / (records of the
+// brick) so that no slot can overflow (2^21 at one sample per pixel); a crowded brick (> 2048 records) counts the density of its cells
+// for the bound, and beyond 2^19 -- or with a non-finite source in a tile -- its records are scattered tap by tap.
+//   gather2d: per brick the 35 x 35 lattice points of up to four channels are staged through the boundary tables (1.2 lattice points
+// per pixel) and the records gather from the boxes (pull), or contract the channels with grad_out per tap (grid gradient).
+//   The runs of the NEXT brick are fetched while the current one is processed (list -> counter -> descriptors: three dependent loads).
+//   probe2d: under INTERPOL_FLAG_AUTO_SCATTER every 16th tile is examined with the tiles' own box rule; beyond 1 (scatters) / 10
+// (gathers) pixels per thousand outside the boxes the bricks take the call.  Both organisations are enqueued behind the verdict -- a word
+// of the workspace -- and the loser returns at once: no host synchronisation, hipGraph-safe, a function of the call's coordinates alone.
+// Measured (profiles/r05_2d_bricks.txt): the bricks cost the same at every sigma -- push 1.10 ms, pull 0.88, pull backward 2.1 -- so the
+// routed call follows the tiles up to sigma ~ 4 (+3 %: probe and two empty launches) and stays flat beyond.
+// Samples whose stencil starts more than 256 points outside the lattice, tiles that spread over more than 6 bricks per dim and runs
+// beyond a brick's 64 descriptors are handled by their own thread in the binning kernel (always correct).
+// Workspace: 16 B per sample + 1 KiB per brick (interpol_scatter_workspace / interpol_pull_workspace).
+// ===========================================================================
+#include "sorted_util.hpp"
+#include "launch.hpp"
+
+namespace ip {
+namespace s2d {
+
+using namespace sorted;
+
+constexpr int TS2 = 32, NS2 = TS2 * TS2;        // tile of the sample grid
+constexpr int NT1 = 256, VPT1 = NS2 / NT1;      // bin2d: threads, samples per thread
+constexpr int BR2 = 32;                         // brick edge, in first-tap cells
+constexpr int OFF2 = 256;                       // first taps in [-OFF2, n + OFF2) are binned (a multiple of BR2)
+constexpr int BOX2 = BR2 + 3;                   // lattice points a brick's stencils touch per dim (K <= 3)
+constexpr int BOXN = BOX2 * BOX2;
+constexpr int LB2 = 6, NBIN2 = LB2 * LB2;       // bricks around a tile that are sorted locally
+constexpr int CAPD2 = 64;                       // runs per brick
+constexpr int NT2 = 256;                        // scatter2d: threads
+constexpr int NCELL2 = BR2 * BR2;
+constexpr int GCMAX = 4;                        // channels a record holds at most
+constexpr int CROWD = 2048;                     // records of a brick beyond which the density of its cells is counted
+constexpr float MAGIC2 = 12582912.f;            // 1.5 * 2^23: bits 0x4B400000
+constexpr unsigned MAGIC2_BITS = 0x4B400000u;
+
+struct Grid2 { int nb[2]; int per_item; };
+static Grid2 brick_grid(const KParams &k)
+{
+    Grid2 g;
+    for (int d = 0; d < 2; ++d) g.nb[d] = (k.vol_n[d] + 2 * OFF2 + BR2 - 1) / BR2;
+    g.per_item = g.nb[0] * g.nb[1];
+    return g;
+}
+struct Workspace { int *hdr; int *ndesc; int *list; uint4 *desc; float4 *rec; int64_t nbricks, nrec; };
+static int64_t align256(int64_t x) { return (x + 255) & ~(int64_t)255; }
+static int64_t layout(const Grid2 &bg, int B, int64_t ntiles, void *base, Workspace *w)
+{
+    const int64_t nbricks = (int64_t)bg.per_item * B, nrec = ntiles * NS2 * B;
+    unsigned char *p = (unsigned char *)base;
+    int64_t o = 0;
+    const int64_t o_hdr = o; o += 256;                               // header (64 ints), brick counters, brick list: ONE zero-fill
+    const int64_t o_nd = o; o += nbricks * 4;
+    const int64_t o_li = o; o += (nbricks + 1) * 4; o = align256(o);
+    const int64_t o_desc = o; o += align256(nbricks * CAPD2 * 16);
+    const int64_t o_rec = o; o += align256(nrec * 16);
+    if (w) { w->hdr = (int *)(p + o_hdr); w->ndesc = (int *)(p + o_nd); w->list = (int *)(p + o_li); w->desc = (uint4 *)(p + o_desc);
+             w->rec = (float4 *)(p + o_rec); w->nbricks = nbricks; w->nrec = nrec; }
+    return o;
+}
+
+__global__ void zero2(int *p, int n)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = 0;
+}
+
+__device__ __forceinline__ float mask2(const KParams &p, const float *x)
+{
+    if (p.extrapolate == 1) return 1.f;
+    return (x[0] > p.mask_lo_f && x[0] < p.mask_hi_f[0] && x[1] > p.mask_lo_f && x[1] < p.mask_hi_f[1]) ? 1.f : 0.f;
+}
+__device__ __forceinline__ tiled::Lattice lattice2(const KParams &p)
+{
+    tiled::Lattice L;
+    L.bound[0] = 1; L.n[0] = 1; L.ss[0] = 0; L.k[0] = 0;               // degenerate x
+    L.bound[1] = p.bound[0]; L.n[1] = p.vol_n[0]; L.ss[1] = p.vol_ss[0] / 4; L.k[1] = p.order[0];
+    L.bound[2] = p.bound[1]; L.n[2] = p.vol_n[1]; L.ss[2] = p.vol_ss[1] / 4; L.k[2] = p.order[1];
+    L.lin = (p.order[0] == 1 && p.order[1] == 1 && p.mode == MODE_ISO1);
+    return L;
+}
+
+// the values of a record: two floats, or four 16-bit values in the source's own format
+template <typename T> struct Vals {
+    static constexpr int GC = 4;
+    static __device__ __forceinline__ void pack(const float *v, float &a, float &b)
+    {
+        unsigned short h[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) { const T t = Cvt<float, T>::st(v[c]); __builtin_memcpy(&h[c], &t, 2); }
+        a = __uint_as_float((unsigned)h[0] | ((unsigned)h[1] << 16)); b = __uint_as_float((unsigned)h[2] | ((unsigned)h[3] << 16));
+    }
+    static __device__ __forceinline__ void unpack(float a, float b, float *v)
+    {
+        const unsigned w[2] = { __float_as_uint(a), __float_as_uint(b) };
+#pragma unroll
+        for (int c = 0; c < 4; ++c) { const unsigned short h = (unsigned short)(w[c >> 1] >> (16 * (c & 1))); T t; __builtin_memcpy(&t, &h, 2); v[c] = Cvt<float, T>::ld(t); }
+    }
+};
+template <> struct Vals<float> {
+    static constexpr int GC = 2;
+    static __device__ __forceinline__ void pack(const float *v, float &a, float &b) { a = v[0]; b = v[1]; }
+    static __device__ __forceinline__ void unpack(float a, float b, float *v) { v[0] = a; v[1] = b; v[2] = 0.f; v[3] = 0.f; }
+};
+
+// The probe of a call under INTERPOL_FLAG_AUTO_SCATTER: the lean tiles of ops_tiled2d.hip serve a tile from a box of CAP = 64 lattice
+// points per dim placed on the range of the tile's first taps; a pixel whose stencil leaves the box is scattered by its own thread, tap by
+// tap, at ~100 times the cost.  Every 16th tile of the call (at most 2000 tiles) is examined with the tiles' own rule; more than 1 pixel per thousand outside
+// (sigma ~ 4 px of i.i.d. noise, a zoom beyond 2, folds; 10 per thousand for the gathers, whose stray pixels cost loads, not atomics) and
+// the bricks take the call.  hdr[32]: the verdict (1 bricks, 0 tiles),
+// hdr[34..35]: one 64-bit word -- pixels outside, pixels examined, workgroups done.
+constexpr int PROBE_STRIDE = 16, PROBE_CAP = 64, PROBE_MAXT = 2000, PROBE_WG = 500;       // (22-bit fields: at most 4095 tiles of 1024 pixels)
+constexpr int PERMILLE_SCATTER = 1, PERMILLE_GATHER = 10;      // pixels outside the tiles' boxes, per thousand, beyond which the bricks take the call
+template <int GM>
+__global__ __launch_bounds__(NT1) void probe2d(KParams p, const float *__restrict__ grid, int *__restrict__ hdr, int gy, int gz, int ntz, int ntiles, int nwork, int stride,
+                                               int permille)
+{
+    __shared__ int lo[2], hi[2], nout, nseen;
+    const int tid = threadIdx.x;
+    if (tid == 0) { nout = 0; nseen = 0; }
+    // (a workgroup examines several tiles: the closing add is one per workgroup on ONE address, ~10 ns each)
+    for (int pt = (int)blockIdx.x; pt * stride < nwork; pt += (int)gridDim.x) {
+        const int wk = min(pt * stride + pt % stride, nwork - 1);    // (a diagonal through the tiles)
+        const int64_t b = wk / ntiles;
+        const int tile = wk % ntiles;
+        const int oy0 = (tile / ntz) * TS2, oz0 = (tile % ntz) * TS2;
+        __syncthreads();
+        if (tid < 2) { lo[tid] = 0x7fffffff; hi[tid] = -0x7fffffff; }
+        int i0[VPT1][2];
+        unsigned valid = 0;
+        int mn[2] = { 0x7fffffff, 0x7fffffff }, mx[2] = { -0x7fffffff, -0x7fffffff };
+#pragma unroll
+        for (int v = 0; v < VPT1; ++v) {
+            int oy = oy0 + (tid >> 3), oz = oz0 + (tid & 7) * VPT1 + v;
+            if (oy < gy && oz < gz) valid |= 1u << v;
+            oy = oy < gy ? oy : gy - 1; oz = oz < gz ? oz : gz - 1;
+            const float2 gv = *reinterpret_cast<const float2 *>(grid + b * p.grid_sb + ((int64_t)oy * gz + oz) * 2);
+            float c[2] = { gv.x, gv.y };
+            if (GM == 2) { c[0] += (float)oy; c[1] += (float)oz; }
+#pragma unroll
+            for (int d = 0; d < 2; ++d) {
+                float fl = floorf(c[d] - 0.5f * (float)(p.order[d] - 1));
+                fl = fl < -1073741824.f ? -1073741824.f : (fl > 1073741824.f ? 1073741824.f : fl);   // (tile_common.hpp: split; NaN -> the cast's 0)
+                i0[v][d] = (int)fl;
+                if ((valid >> v) & 1) { mn[d] = i0[v][d] < mn[d] ? i0[v][d] : mn[d]; mx[d] = i0[v][d] > mx[d] ? i0[v][d] : mx[d]; }
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int d = 0; d < 2; ++d) {
+            const int a = wave_min(mn[d]), e = wave_max(mx[d]);
+            if ((tid & 63) == 0) { atomicMin(&lo[d], a); atomicMax(&hi[d], e); }
+        }
+        __syncthreads();
+        int l[2], sz[2];
+#pragma unroll
+        for (int d = 0; d < 2; ++d) {                                // (ops_tiled2d.hip: Tile2::build)
+            int l_ = lo[d];
+            long long h_ = (long long)hi[d] + p.order[d];
+            if (h_ < l_) { l_ = 0; h_ = 0; }
+            if (d == 1) l_ &= ~3;
+            long long s_ = h_ - l_ + 1;
+            if (s_ > PROBE_CAP) { l_ += (int)((s_ - PROBE_CAP) / 2); s_ = PROBE_CAP; }
+            l[d] = l_; sz[d] = (int)s_;
+        }
+        int mine = 0, seen = 0;
+#pragma unroll
+        for (int v = 0; v < VPT1; ++v) {
+            if (!((valid >> v) & 1)) continue;
+            ++seen;
+            bool in = true;
+#pragma unroll
+            for (int d = 0; d < 2; ++d) in = in && i0[v][d] >= l[d] && (long long)i0[v][d] + p.order[d] < (long long)l[d] + sz[d];
+            mine += in ? 0 : 1;
+        }
+        mine = (int)wave_sum((float)mine); seen = (int)wave_sum((float)seen);
+        if ((tid & 63) == 0) { atomicAdd(&nout, mine); atomicAdd(&nseen, seen); }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        // ONE relaxed 64-bit add carries the workgroup's pixels outside (bits 42..63), pixels examined (20..41) and a 1 (0..19): the
+        // workgroup that finds gridDim.x - 1 others in the old value holds the totals -- no fence, no second word to order against
+        const unsigned long long add = ((unsigned long long)nout << 42) | ((unsigned long long)nseen << 20) | 1ull;
+        const unsigned long long tot = __hip_atomic_fetch_add(reinterpret_cast<unsigned long long *>(hdr + 34), add, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + add;
+        if ((tot & 0xfffffull) == (unsigned long long)gridDim.x) {
+            const unsigned long long no = tot >> 42, ns = (tot >> 20) & 0x3fffffull;
+            __hip_atomic_store(&hdr[32], (no * 1000ull > ns * (unsigned long long)permille) ? 1 : 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+
+struct BinSmem { int lo[2], amax[GCMAX]; int cnt[NBIN2], base[NBIN2]; };
+
+// One workgroup per 32 x 32 tile of the sample grid: its samples sorted by the brick of their first tap (nd.py:45), records with the
+// masked values of channels c0 .. c0 + nc - 1 (channel p.C, when p.cc: the count -- the mask itself; src == NULL: grid_count)
+template <typename T, int GM>
+__global__ __launch_bounds__(NT1) void bin2d(KParams p, Grid2 bg, const T *__restrict__ src, const float *__restrict__ grid, float *__restrict__ vol,
+                                             int *__restrict__ ndesc, int *__restrict__ list, uint4 *__restrict__ desc, float4 *__restrict__ rec,
+                                             int gy, int gz, int ntz, int ntiles, int c0, int nc, int vec, const int *__restrict__ gate)
+{
+    __shared__ BinSmem sm;
+    if (gate && *gate == 0) return;                                  // the probe of this call kept the LDS tiles (probe2d)
+    const int tid = threadIdx.x;
+    const int64_t b = blockIdx.x / ntiles;
+    const int tile = blockIdx.x % ntiles;
+    const int oy0 = (tile / ntz) * TS2, oz0 = (tile % ntz) * TS2;
+    if (tid < NBIN2) sm.cnt[tid] = 0;
+    if (tid < 2) sm.lo[tid] = 0x7fffffff;
+    if (tid >= 4 && tid < 4 + GCMAX) sm.amax[tid - 4] = 0;
+    float c[VPT1][2], va[VPT1], vb[VPT1];
+    int bx[VPT1][2];
+    unsigned valid = 0, ok = 0;
+    int mn[2] = { 0x7fffffff, 0x7fffffff }, am[GCMAX] = { 0, 0, 0, 0 };
+    // a thread takes 4 consecutive samples of a row: two 16-byte loads of the grid, one 8 / 16-byte load per channel of the source
+    const int ry = oy0 + (tid >> 3), rz = oz0 + (tid & 7) * VPT1;
+    static_assert(VPT1 == 4 && TS2 == 32, "8 threads x 4 samples per row of the tile");
+    float sv[VPT1][GCMAX];
+    const bool row4 = vec && ry < gy && rz + 3 < gz;                 // (vec: rows and channels start on 16-byte boundaries, host)
+    if (row4) {
+        const float4 *g4 = reinterpret_cast<const float4 *>(grid + b * p.grid_sb + ((int64_t)ry * gz + rz) * 2);
+        const float4 ga = g4[0], gb = g4[1];
+        c[0][0] = ga.x; c[0][1] = ga.y; c[1][0] = ga.z; c[1][1] = ga.w; c[2][0] = gb.x; c[2][1] = gb.y; c[3][0] = gb.z; c[3][1] = gb.w;
+#pragma unroll
+        for (int q = 0; q < GCMAX; ++q) {
+            const int ch = c0 + q;
+            if (q < Vals<T>::GC && q < nc && src && ch < p.C) {
+                struct alignas(4 * sizeof(T)) Q { T e[4]; };
+                const Q qv = *reinterpret_cast<const Q *>(src + b * p.val_sb + (int64_t)ch * p.val_sc + (int64_t)ry * gz + rz);
+#pragma unroll
+                for (int v = 0; v < VPT1; ++v) sv[v][q] = Cvt<float, T>::ld(qv.e[v]);
+            } else {
+#pragma unroll
+                for (int v = 0; v < VPT1; ++v) sv[v][q] = (q < Vals<T>::GC && q < nc) ? 1.f : 0.f;
+            }
+        }
+    }
+#pragma unroll
+    for (int v = 0; v < VPT1; ++v) {
+        int oy = ry, oz = rz + v;
+        if (oy < gy && oz < gz) valid |= 1u << v;
+        oy = oy < gy ? oy : gy - 1; oz = oz < gz ? oz : gz - 1;
+        if (!row4) {
+            const float2 gv = *reinterpret_cast<const float2 *>(grid + b * p.grid_sb + ((int64_t)oy * gz + oz) * 2);
+            c[v][0] = gv.x; c[v][1] = gv.y;
+#pragma unroll
+            for (int q = 0; q < GCMAX; ++q) {
+                const int ch = c0 + q;
+                float s_ = 0.f;
+                if (q < Vals<T>::GC && q < nc) s_ = (src && ch < p.C) ? Cvt<float, T>::ld(src[b * p.val_sb + (int64_t)ch * p.val_sc + (int64_t)oy * gz + oz]) : 1.f;
+                sv[v][q] = s_;
+            }
+        }
+        if (GM == 2) { c[v][0] += (float)oy; c[v][1] += (float)oz; }
+        const float m = mask2(p, c[v]);
+#pragma unroll
+        for (int q = 0; q < GCMAX; ++q) {
+            sv[v][q] *= m;                                           // (nd.py:199: the source times the mask, NaN * 0 included)
+            const int a = __float_as_int(__builtin_fabsf(sv[v][q])); // (NaN and Inf compare above every finite value)
+            if ((valid >> v) & 1) am[q] = a > am[q] ? a : am[q];
+        }
+        Vals<T>::pack(sv[v], va[v], vb[v]);
+        bool in = (valid >> v) & 1;
+#pragma unroll
+        for (int d = 0; d < 2; ++d) {
+            const float fl = floorf(c[v][d] - 0.5f * (float)(p.order[d] - 1));
+            in = in && fl >= (float)(-OFF2) && fl < (float)(bg.nb[d] * BR2 - OFF2);       // (false for NaN)
+            bx[v][d] = in ? (__float2int_rz(fl) + OFF2) / BR2 : 0;                  // (BR2 = 32: a shift)
+        }
+        if (in) { ok |= 1u << v; mn[0] = bx[v][0] < mn[0] ? bx[v][0] : mn[0]; mn[1] = bx[v][1] < mn[1] ? bx[v][1] : mn[1]; }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int d = 0; d < 2; ++d) {
+        const int a = wave_min(mn[d]);
+        if ((tid & 63) == 0) atomicMin(&sm.lo[d], a);
+    }
+    // max |masked value| of the TILE per channel, rounded up to 16 bits (sign, exponent, 7 bits): the scale of the bricks' 32-bit sums is
+    // the max over the tiles that reach a brick; 0x7f80 and above: a non-finite value somewhere in the tile
+#pragma unroll
+    for (int q = 0; q < Vals<T>::GC; ++q) {
+        const int a = wave_max(am[q]);
+        if ((tid & 63) == 0 && a) atomicMax(&sm.amax[q], a);
+    }
+    __syncthreads();
+    const int lo[2] = { sm.lo[0], sm.lo[1] };
+    int lbin[VPT1];
+    unsigned local = 0;
+#pragma unroll
+    for (int v = 0; v < VPT1; ++v) {
+        const int r0 = bx[v][0] - lo[0], r1 = bx[v][1] - lo[1];
+        const bool l = ((ok >> v) & 1) && (unsigned)r0 < (unsigned)LB2 && (unsigned)r1 < (unsigned)LB2;
+        lbin[v] = l ? r0 * LB2 + r1 : 0;
+        if (l) { local |= 1u << v; lbin[v] |= atomicAdd(&sm.cnt[lbin[v]], 1) << 8; }
+    }
+    __syncthreads();
+    const int64_t tilebase = (int64_t)blockIdx.x * NS2;
+    if (tid < 64) {
+        static_assert(NBIN2 <= 64, "one lane per local brick");
+        const int e = tid, cn = e < NBIN2 ? sm.cnt[e] : 0;
+        int run = cn;                                                // exclusive prefix over the local bricks
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(run, o); if (tid >= o) run += t; }
+        run -= cn;
+        const int bk = (int)b * bg.per_item + (lo[0] + e / LB2) * bg.nb[1] + (lo[1] + e % LB2);
+        if (e < NBIN2) sm.base[e] = run;
+        if (cn > 0) {
+            const int slot = atomicAdd(&ndesc[bk], 1);
+            if (slot == 0) list[1 + atomicAdd(&list[0], 1)] = bk;    // first run of the brick
+            if (slot < CAPD2) {
+                unsigned h[GCMAX];
+#pragma unroll
+                for (int q = 0; q < GCMAX; ++q) { const unsigned a = (unsigned)sm.amax[q]; h[q] = a >= 0x7f800000u ? 0x7f80u : (a + 0xffffu) >> 16; }
+                desc[(int64_t)bk * CAPD2 + slot] = make_uint4((unsigned)(tilebase + run), (unsigned)cn, h[0] | (h[1] << 16), h[2] | (h[3] << 16));
+            }
+            else sm.cnt[e] = -1;                                     // the brick's list is full: scattered directly, below
+        }
+    }
+    __syncthreads();
+    unsigned direct = valid & ~local;
+#pragma unroll
+    for (int v = 0; v < VPT1; ++v) {
+        if (!((local >> v) & 1)) continue;
+        const int e = lbin[v] & 255;
+        if (sm.cnt[e] < 0) { direct |= 1u << v; continue; }
+        rec[tilebase + sm.base[e] + (lbin[v] >> 8)] = make_float4(c[v][0], c[v][1], va[v], vb[v]);
+    }
+    if (direct) {
+        const tiled::Lattice L = lattice2(p);
+#pragma unroll 1
+        for (int v = 0; v < VPT1; ++v) {
+            if (!((direct >> v) & 1)) continue;
+            float sv[GCMAX];
+            Vals<T>::unpack(va[v], vb[v], sv);
+            int i0, i1; float t0, t1;
+            tiled::split(p.order[0], c[v][0], i0, t0);
+            tiled::split(p.order[1], c[v][1], i1, t1);
+#pragma unroll 1
+            for (int q = 0; q < nc; ++q) {
+                const float s = q == 0 ? sv[0] : q == 1 ? sv[1] : q == 2 ? sv[2] : sv[3];
+                if (s != 0.f) tiled::scatter_one_thread(L, vol + b * p.vol_sb + (int64_t)(c0 + q) * p.vol_sc, s, 0, i0, i1, 0.f, t0, t1);
+            }
+        }
+    }
+}
+
+struct ScatSmem {
+    int   taboff[2][BOX2 + 1];
+    float tabsgn[2][BOX2 + 1];
+    unsigned start[2][CAPD2];                   // the runs of this brick and of the next
+    int   pref[2][CAPD2 + 2];
+    int   dmax, amax[2][GCMAX];
+    unsigned cells[NCELL2 / 2];                 // density of first-tap cells: 16-bit counters, cell c0 * BR2 + c1
+    unsigned box[1][BOXN];                      // nc boxes (dynamic)
+};
+static size_t scat_lds(int nc) { return sizeof(ScatSmem) + (size_t)(nc - 1) * BOXN * 4; }
+
+// the K + 1 weights of a stencil coordinate t (closed forms of splines.py:30-44 on the interval `split` produces)
+template <int K>
+__device__ __forceinline__ void wts(float t, float *w)
+{
+    if (K == 1) { w[0] = 1.f - t; w[1] = t; w[2] = 0.f; w[3] = 0.f; }
+    else if (K == 2) {
+        const float a = 1.5f - t, c = t - 0.5f, m = t - 1.f;
+        w[0] = (a * a) * 0.5f; w[1] = __builtin_fmaf(-m, m, 0.75f); w[2] = (c * c) * 0.5f; w[3] = 0.f;
+    } else {
+        const float u = t - 1.f, v = 2.f - t;
+        w[0] = (v * v * v) * (1.f / 6.f); w[3] = (u * u * u) * (1.f / 6.f);
+        w[1] = __builtin_fmaf(u * u, __builtin_fmaf(u, 0.5f, -1.f), 2.f / 3.f);
+        w[2] = __builtin_fmaf(v * v, __builtin_fmaf(v, 0.5f, -1.f), 2.f / 3.f);
+    }
+}
+template <int K> __device__ __host__ constexpr float wmax1() { return K == 1 ? 1.f : (K == 2 ? 0.75f : 2.f / 3.f); }
+
+template <int K1, int I>
+__device__ __forceinline__ void row_adds2(unsigned addr, const unsigned *v)
+{
+    constexpr int o = I * BOX2 * 4;
+    if (K1 == 3)
+        asm volatile("ds_add_u32 %0, %1 offset:%5\n\tds_add_u32 %0, %2 offset:%6\n\tds_add_u32 %0, %3 offset:%7\n\tds_add_u32 %0, %4 offset:%8"
+                     :: "v"(addr), "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "n"(o), "n"(o + 4), "n"(o + 8), "n"(o + 12) : "memory");
+    else if (K1 == 2)
+        asm volatile("ds_add_u32 %0, %1 offset:%4\n\tds_add_u32 %0, %2 offset:%5\n\tds_add_u32 %0, %3 offset:%6"
+                     :: "v"(addr), "v"(v[0]), "v"(v[1]), "v"(v[2]), "n"(o), "n"(o + 4), "n"(o + 8) : "memory");
+    else
+        asm volatile("ds_add_u32 %0, %1 offset:%3\n\tds_add_u32 %0, %2 offset:%4"
+                     :: "v"(addr), "v"(v[0]), "v"(v[1]), "n"(o), "n"(o + 4) : "memory");
+}
+template <int K1, int I>
+__device__ __forceinline__ void scatter_row2(unsigned addr, float sx, const float *w1)
+{
+    unsigned v[4];                                                   // round(sx * w) as a 32-bit integer: the float t + 1.5 * 2^23 holds it in its mantissa
+#pragma unroll
+    for (int j = 0; j <= K1; ++j) v[j] = __float_as_uint(__builtin_fmaf(sx, w1[j], MAGIC2)) - MAGIC2_BITS;
+    row_adds2<K1, I>(addr, v);
+}
+
+// the runs of a brick: start of each run in the records, exclusive prefix of the run lengths (wave 0; one run per lane)
+__device__ __forceinline__ uint4 runs_fetch(const int *__restrict__ ndesc, const uint4 *__restrict__ desc, int bk, int lane)
+{
+    static_assert(CAPD2 == 64, "one run per lane");
+    if (bk < 0) return make_uint4(0u, 0u, 0u, 0u);
+    const int nd = min(ndesc[bk], CAPD2);
+    return lane < nd ? desc[(int64_t)bk * CAPD2 + lane] : make_uint4(0u, 0u, 0u, 0u);
+}
+__device__ __forceinline__ void runs_store(unsigned *start, int *pref, int *amax, int lane, const uint4 &d)
+{
+    int incl = (int)d.y;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o); if (lane >= o) incl += t; }
+    start[lane] = d.x;
+    pref[lane] = incl - (int)d.y;
+    if (lane == 63) { pref[CAPD2] = incl; pref[CAPD2 + 1] = 0x7fffffff; }
+    // max |v| per channel over the tiles of the runs (bin2d: 16-bit fields)
+    const int h0 = wave_max((int)(d.z & 0xffffu)), h1 = wave_max((int)(d.z >> 16)), h2 = wave_max((int)(d.w & 0xffffu)), h3 = wave_max((int)(d.w >> 16));
+    if (lane == 0) { amax[0] = h0; amax[1] = h1; amax[2] = h2; amax[3] = h3; }
+}
+
+// A workgroup walks the bricks blockIdx.x, blockIdx.x + gridDim.x, ... of the list; the runs of the NEXT brick are fetched while the
+// current one is accumulated (the chain list -> counters -> descriptors is three dependent loads).
+template <typename T, int K0, int K1>
+__global__ __launch_bounds__(NT2) void scatter2d(KParams p, Grid2 bg, const int *__restrict__ ndesc, const uint4 *__restrict__ desc,
+                                                 const float4 *__restrict__ rec, const int *__restrict__ list,
+                                                 float *__restrict__ vol, int c0, int nc, const int *__restrict__ gate)
+{
+    if (gate && *gate == 0) return;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    ScatSmem &sm = *reinterpret_cast<ScatSmem *>(smem_raw);
+    const tiled::Lattice L = lattice2(p);
+    const int nlist = list[0];
+    const int G = (int)gridDim.x;
+    constexpr float units0 = 4194304.f * 0.999f / (wmax1<K0>() * wmax1<K1>());
+    for (int e = threadIdx.x; e < BOXN * nc; e += NT2) sm.box[0][e] = 0u;
+    int it = (int)blockIdx.x, cur = 0;
+    int bk = it < nlist ? list[1 + it] : -1;
+    int bk1 = it + G < nlist ? list[1 + it + G] : -1;
+    if (threadIdx.x < 64) runs_store(sm.start[0], sm.pref[0], sm.amax[0], (int)threadIdx.x, runs_fetch(ndesc, desc, bk, (int)threadIdx.x));
+    while (bk >= 0) {
+        const int tid = opaque((int)threadIdx.x);
+        const int bk2 = it + 2 * G < nlist ? list[1 + it + 2 * G] : -1;
+        uint4 nx = make_uint4(0u, 0u, 0u, 0u);
+        if (tid < 64) nx = runs_fetch(ndesc, desc, bk1, tid);        // (in flight until the end of this brick)
+        if (tid == 0) sm.dmax = 0;
+        const int64_t b = bk / bg.per_item;
+        const int r = bk - (int)b * bg.per_item;
+        const int b0[2] = { (r / bg.nb[1]) * BR2 - OFF2, (r % bg.nb[1]) * BR2 - OFF2 };     // lattice index of box slot 0
+        if (tid >= 128) {                                            // box slot -> wrapped lattice offset and sign (bounds.py:30-89)
+            const int d = (tid - 128) >> 6, slot = tid & 63;
+            static_assert(BOX2 <= 64 && NT2 == 256, "one lane per slot, waves 2 and 3");
+            if (slot < BOX2) {
+                const long long pk = wrap_outofline(p.bound[d], (d == 0 ? b0[0] : b0[1]) + slot, p.vol_n[d]);
+                sm.taboff[d][slot] = (int)(pk & 0xffffffffll) * (p.vol_ss[d] / 4);
+                sm.tabsgn[d][slot] = (float)(int)(pk >> 32);
+            }
+        }
+        __syncthreads();                                             // the runs of this brick (stored at the end of the previous one), tables
+        const unsigned *start = sm.start[cur];
+        const int *pref = sm.pref[cur];
+        const int ntot = pref[CAPD2];
+        // first-tap cell of a record inside the brick (0 .. 31 by construction of the bins; clamped, should a coordinate be off)
+        auto cell_of = [&](const float4 &rc, int &c0_, int &c1_) {
+            c0_ = __float2int_rz(floorf(rc.x - 0.5f * (float)(K0 - 1))) - b0[0]; c1_ = __float2int_rz(floorf(rc.y - 0.5f * (float)(K1 - 1))) - b0[1];
+            c0_ = max(0, min(c0_, BR2 - 1)); c1_ = max(0, min(c1_, BR2 - 1));
+        };
+        // ---- 32-bit sums hold while (stencils over a slot) * units * prod_d max_t w(t) stays below 2^31.  No more stencils than records:
+        // up to CROWD records the units follow from the count alone (2^21 .. 2^22 at one sample per pixel); a crowded brick counts the
+        // density of its first-tap cells first (stencils over a slot <= taps * the densest cell), and scatters directly beyond 2^19.
+        int cover = ntot;
+        if (ntot > CROWD) {                                          // (block-uniform)
+            for (int e = tid; e < NCELL2 / 2; e += NT2) sm.cells[e] = 0u;
+            __syncthreads();
+            int rr = 0;
+            for (int j = tid; j < ntot; j += NT2) {
+                while (j >= pref[rr + 1]) ++rr;
+                const float4 rc = rec[start[rr] + (unsigned)(j - pref[rr])];
+                int cc0, cc1;
+                cell_of(rc, cc0, cc1);
+                const int cell = cc0 * BR2 + cc1;
+                const unsigned old = atomicAdd(&sm.cells[cell >> 1], 1u << (16 * (cell & 1)));
+                if (((old >> (16 * (cell & 1))) & 0xffffu) >= 0xfff0u) sm.dmax = 0x7fffff;       // (a 16-bit counter about to wrap)
+            }
+            __syncthreads();
+            int dm = 0;
+            for (int e = tid; e < NCELL2 / 2; e += NT2) {
+                const unsigned w2 = sm.cells[e];
+                const int a = (int)(w2 & 0xffffu), c2 = (int)(w2 >> 16);
+                dm = a > dm ? a : dm; dm = c2 > dm ? c2 : dm;
+            }
+            dm = wave_max(dm);
+            if ((tid & 63) == 0 && dm > 0) atomicMax(&sm.dmax, dm);
+            __syncthreads();
+            cover = min(ntot, min(sm.dmax, 0x7fffff) * ((K0 + 1) * (K1 + 1)));
+        }
+        const float units = fminf(units0, 2147483648.f * 0.99f / ((float)cover * (wmax1<K0>() * wmax1<K1>())));
+        const bool dense = units < 524288.f;                         // (block-uniform)
+        float scale[GCMAX], inv[GCMAX];
+        unsigned how = 0;                                            // per channel: 1 direct (dense / non-finite), 2 nothing but zeros
+#pragma unroll
+        for (int q = 0; q < GCMAX; ++q) {
+            const int mb = q < Vals<T>::GC ? sm.amax[cur][q] : 0;    // (16 bits: sign, exponent, 7 bits of the fraction, rounded up)
+            const bool direct = dense || mb >= 0x7f80;
+            const float a0 = fmaxf(__int_as_float(mb << 16), 1e-27f);
+            scale[q] = units / a0; inv[q] = a0 / units;
+            if (q >= nc) how |= 2u << (2 * q);
+            else if (direct) how |= 1u << (2 * q);
+            else if (mb == 0) how |= 2u << (2 * q);
+        }
+        const unsigned boxaddr = (unsigned)(size_t)(__attribute__((address_space(3))) void *)(&sm.box[0][0]);
+        float *vb = vol + b * p.vol_sb + (int64_t)c0 * p.vol_sc;
+        // ---- the taps: every record's stencil into the boxes of its channels (the records come from L2 this time)
+        {
+            int rr = 0;
+            for (int j = tid; j < ntot; j += NT2) {
+                while (j >= pref[rr + 1]) ++rr;
+                const float4 rc = rec[start[rr] + (unsigned)(j - pref[rr])];
+                const float f0 = floorf(rc.x - 0.5f * (float)(K0 - 1)), f1 = floorf(rc.y - 0.5f * (float)(K1 - 1));
+                const float t0 = rc.x - f0, t1 = rc.y - f1;
+                int cc0, cc1;
+                cell_of(rc, cc0, cc1);
+                const unsigned addr = boxaddr + (unsigned)(cc0 * BOX2 + cc1) * 4u;
+                float w0[4], w1[4], sv[GCMAX];
+                wts<K0>(t0, w0);
+                wts<K1>(t1, w1);
+                Vals<T>::unpack(rc.z, rc.w, sv);
+#pragma unroll
+                for (int q = 0; q < Vals<T>::GC; ++q) {
+                    const unsigned h = (how >> (2 * q)) & 3u;        // (block-uniform)
+                    if (h == 2u) continue;
+                    if (h == 1u) {
+                        if (sv[q] != 0.f) tiled::scatter_one_thread(L, vb + (int64_t)q * p.vol_sc, sv[q], 0, __float2int_rz(f0), __float2int_rz(f1), 0.f, t0, t1);
+                        continue;
+                    }
+                    const float ss = sv[q] * scale[q];
+                    const unsigned aq = addr + (unsigned)(q * BOXN * 4);
+                    scatter_row2<K1, 0>(aq, ss * w0[0], w1);
+                    scatter_row2<K1, 1>(aq, ss * w0[1], w1);
+                    if (K0 >= 2) scatter_row2<K1, 2>(aq, ss * w0[2], w1);
+                    if (K0 >= 3) scatter_row2<K1, 3>(aq, ss * w0[3], w1);
+                }
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __syncthreads();
+        // ---- flush: the box holds the sums in units of max |v| / units
+        for (int e = tid; e < BOXN; e += NT2) {
+            const int x = e / BOX2, y = e - x * BOX2;
+            const float sg = sm.tabsgn[0][x] * sm.tabsgn[1][y];
+            const int off = sm.taboff[0][x] + sm.taboff[1][y];
+#pragma unroll
+            for (int q = 0; q < Vals<T>::GC; ++q) {
+                if (((how >> (2 * q)) & 3u) != 0u) continue;         // (block-uniform)
+                const int sq = (int)sm.box[0][q * BOXN + e];
+                if (sq == 0) continue;
+                sm.box[0][q * BOXN + e] = 0u;
+                if (sg != 0.f) __hip_atomic_fetch_add(vb + (int64_t)q * p.vol_sc + off, (float)sq * (inv[q] * sg), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        if (tid < 64) runs_store(sm.start[cur ^ 1], sm.pref[cur ^ 1], sm.amax[cur ^ 1], tid, nx);
+        cur ^= 1; bk = bk1; bk1 = bk2; it += G;
+        __syncthreads();                                             // the brick is flushed: tables, cells and counters are free
+    }
+}
+
+// ---------------------------------------------------------------------------
+// The gathers through bricks of the IMAGE: grid_pull (MODE 0, nd.py:80-143) and the grid gradient of the pull's backward (MODE 1,
+// pushpull.py:256-257: ggrid[b,o,:] = mask * sum_c gout[b,c,o] * grad pull(img[b,c])(x_o); gout == NULL: ones; p.val_* describe gout).
+// The tiles of ops_tiled2d.hip gather a pixel whose stencil leaves the 64 x 64 box from global memory, one thread, 12 dependent loads:
+// config 5's pull 0.43 ms at sigma = 2, 2.8 at 8, 3.6 at 16.  Here binidx2d sorts the samples as bin2d does (records x, y, sample
+// index); a workgroup per non-empty brick stages the brick's 35 x 35 lattice points of up to four channels through the boundary tables
+// -- 1.2 lattice points per pixel whatever the deformation -- and its records gather from the box.
+// ---------------------------------------------------------------------------
+template <typename T>
+__device__ __forceinline__ tiled::Lattice lattice2t(const KParams &p)
+{
+    tiled::Lattice L = lattice2(p);
+    L.ss[1] = p.vol_ss[0] / (int)sizeof(T); L.ss[2] = p.vol_ss[1] / (int)sizeof(T);
+    return L;
+}
+template <typename T, int MODE>
+__device__ __forceinline__ void gather_sample(const KParams &p, const tiled::Lattice &L, const T *__restrict__ img, const T *__restrict__ gout, void *__restrict__ out,
+                                              int64_t b, int64_t o, const float *x)
+{
+    const float m = mask2(p, x);
+    int i0, i1; float t0, t1;
+    tiled::split(p.order[0], x[0], i0, t0);
+    tiled::split(p.order[1], x[1], i1, t1);
+    if (MODE == 0) {
+#pragma unroll 1
+        for (int ch = 0; ch < p.C; ++ch)
+            ((T *)out)[b * p.val_sb + ch * p.val_sc + o] = Cvt<float, T>::st(m * tiled::gather_one_thread<T>(L, img + b * p.vol_sb + ch * p.vol_sc, 0, i0, i1, 0.f, t0, t1, -1));
+    } else {
+        float a[2] = { 0.f, 0.f };
+#pragma unroll 1
+        for (int ch = 0; ch < p.C; ++ch) {
+            const float gv = gout ? Cvt<float, T>::ld(gout[b * p.val_sb + ch * p.val_sc + o]) : 1.f;
+#pragma unroll 1
+            for (int d = 0; d < 2; ++d) a[d] = __builtin_fmaf(gv, tiled::gather_one_thread<T>(L, img + b * p.vol_sb + ch * p.vol_sc, 0, i0, i1, 0.f, t0, t1, 1 + d), a[d]);
+        }
+        float *dst = (float *)out + (b * p.N + o) * 2;
+        dst[0] = a[0] * m; dst[1] = a[1] * m;
+    }
+}
+
+// One workgroup per 32 x 32 tile of the sample grid: records (x, y, sample index) sorted by the brick of the first tap; the samples
+// the bricks do not take (see the header) are gathered here, by their own thread
+template <typename T, int GM, int MODE>
+__global__ __launch_bounds__(NT1) void binidx2d(KParams p, Grid2 bg, const T *__restrict__ img, const T *__restrict__ gout, const float *__restrict__ grid,
+                                                void *__restrict__ out, int *__restrict__ ndesc, int *__restrict__ list, uint4 *__restrict__ desc,
+                                                float4 *__restrict__ rec, int gy, int gz, int ntz, int ntiles, int vec, const int *__restrict__ gate)
+{
+    __shared__ BinSmem sm;
+    if (gate && *gate == 0) return;                                  // the probe of this call kept the LDS tiles (probe2d)
+    const int tid = threadIdx.x;
+    const int64_t b = blockIdx.x / ntiles;
+    const int tile = blockIdx.x % ntiles;
+    const int oy0 = (tile / ntz) * TS2, oz0 = (tile % ntz) * TS2;
+    if (tid < NBIN2) sm.cnt[tid] = 0;
+    if (tid < 2) sm.lo[tid] = 0x7fffffff;
+    float c[VPT1][2];
+    int bx[VPT1][2], idx[VPT1];
+    unsigned valid = 0, ok = 0;
+    int mn[2] = { 0x7fffffff, 0x7fffffff };
+    const int ry = oy0 + (tid >> 3), rz = oz0 + (tid & 7) * VPT1;
+    const bool row4 = vec && ry < gy && rz + 3 < gz;
+    if (row4) {
+        const float4 *g4 = reinterpret_cast<const float4 *>(grid + b * p.grid_sb + ((int64_t)ry * gz + rz) * 2);
+        const float4 ga = g4[0], gb = g4[1];
+        c[0][0] = ga.x; c[0][1] = ga.y; c[1][0] = ga.z; c[1][1] = ga.w; c[2][0] = gb.x; c[2][1] = gb.y; c[3][0] = gb.z; c[3][1] = gb.w;
+    }
+#pragma unroll
+    for (int v = 0; v < VPT1; ++v) {
+        int oy = ry, oz = rz + v;
+        if (oy < gy && oz < gz) valid |= 1u << v;
+        oy = oy < gy ? oy : gy - 1; oz = oz < gz ? oz : gz - 1;
+        if (!row4) {
+            const float2 gv = *reinterpret_cast<const float2 *>(grid + b * p.grid_sb + ((int64_t)oy * gz + oz) * 2);
+            c[v][0] = gv.x; c[v][1] = gv.y;
+        }
+        if (GM == 2) { c[v][0] += (float)oy; c[v][1] += (float)oz; }
+        idx[v] = oy * gz + oz;
+        bool in = (valid >> v) & 1;
+#pragma unroll
+        for (int d = 0; d < 2; ++d) {
+            const float fl = floorf(c[v][d] - 0.5f * (float)(p.order[d] - 1));
+            in = in && fl >= (float)(-OFF2) && fl < (float)(bg.nb[d] * BR2 - OFF2);       // (false for NaN)
+            bx[v][d] = in ? (__float2int_rz(fl) + OFF2) / BR2 : 0;
+        }
+        if (in) { ok |= 1u << v; mn[0] = bx[v][0] < mn[0] ? bx[v][0] : mn[0]; mn[1] = bx[v][1] < mn[1] ? bx[v][1] : mn[1]; }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int d = 0; d < 2; ++d) {
+        const int a = wave_min(mn[d]);
+        if ((tid & 63) == 0) atomicMin(&sm.lo[d], a);
+    }
+    __syncthreads();
+    const int lo[2] = { sm.lo[0], sm.lo[1] };
+    int lbin[VPT1];
+    unsigned local = 0;
+#pragma unroll
+    for (int v = 0; v < VPT1; ++v) {
+        const int r0 = bx[v][0] - lo[0], r1 = bx[v][1] - lo[1];
+        const bool l = ((ok >> v) & 1) && (unsigned)r0 < (unsigned)LB2 && (unsigned)r1 < (unsigned)LB2;
+        lbin[v] = l ? r0 * LB2 + r1 : 0;
+        if (l) { local |= 1u << v; lbin[v] |= atomicAdd(&sm.cnt[lbin[v]], 1) << 8; }
+    }
+    __syncthreads();
+    const int64_t tilebase = (int64_t)blockIdx.x * NS2;
+    if (tid < 64) {
+        const int e = tid, cn = e < NBIN2 ? sm.cnt[e] : 0;
+        int run = cn;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(run, o); if (tid >= o) run += t; }
+        run -= cn;
+        const int bk = (int)b * bg.per_item + (lo[0] + e / LB2) * bg.nb[1] + (lo[1] + e % LB2);
+        if (e < NBIN2) sm.base[e] = run;
+        if (cn > 0) {
+            const int slot = atomicAdd(&ndesc[bk], 1);
+            if (slot == 0) list[1 + atomicAdd(&list[0], 1)] = bk;
+            if (slot < CAPD2) desc[(int64_t)bk * CAPD2 + slot] = make_uint4((unsigned)(tilebase + run), (unsigned)cn, 0u, 0u);
+            else sm.cnt[e] = -1;
+        }
+    }
+    __syncthreads();
+    unsigned direct = valid & ~local;
+#pragma unroll
+    for (int v = 0; v < VPT1; ++v) {
+        if (!((local >> v) & 1)) continue;
+        const int e = lbin[v] & 255;
+        if (sm.cnt[e] < 0) { direct |= 1u << v; continue; }
+        rec[tilebase + sm.base[e] + (lbin[v] >> 8)] = make_float4(c[v][0], c[v][1], __int_as_float(idx[v]), 0.f);
+    }
+    if (direct) {
+        const tiled::Lattice L = lattice2t<T>(p);
+#pragma unroll 1
+        for (int v = 0; v < VPT1; ++v)
+            if ((direct >> v) & 1) gather_sample<T, MODE>(p, L, img, gout, out, b, idx[v], c[v]);
+    }
+}
+
+struct GatSmem {
+    int   taboff[2][BOX2 + 1];
+    float tabsgn[2][BOX2 + 1];
+    unsigned start[2][CAPD2];
+    int   pref[2][CAPD2 + 2];
+    int   amax[2][GCMAX];                       // (unused by the gathers: runs_store writes them)
+    float box[GCMAX][BOXN];
+};
+
+// the gradient weights of the reference on the same intervals (splines.py:90-139).  Order 1: the reference's general path returns
+// +sign(dist) (splines.py:93-97 -- the opposite of the slope, kept for parity), its all-linear fast path -1, +1 (iso1.py:311-313)
+template <int K>
+__device__ __forceinline__ void wgs(float t, float *g, bool lin)
+{
+    if (K == 1) { g[0] = lin ? -1.f : (t > 0.f ? 1.f : 0.f); g[1] = lin ? 1.f : -1.f; g[2] = 0.f; g[3] = 0.f; }
+    else if (K == 2) { g[0] = t - 1.5f; g[1] = 2.f - 2.f * t; g[2] = t - 0.5f; g[3] = 0.f; }
+    else {
+        const float u = t - 1.f, v = 2.f - t;
+        g[0] = -0.5f * (v * v); g[3] = 0.5f * (u * u);
+        g[1] = u * __builtin_fmaf(u, 1.5f, -2.f);
+        g[2] = -v * __builtin_fmaf(v, 1.5f, -2.f);
+    }
+}
+
+template <typename T, int K0, int K1, int MODE>
+__global__ __launch_bounds__(NT2) void gather2d(KParams p, Grid2 bg, const int *__restrict__ ndesc, const uint4 *__restrict__ desc,
+                                                const float4 *__restrict__ rec, const int *__restrict__ list,
+                                                const T *__restrict__ img, const T *__restrict__ gout, void *__restrict__ out, const int *__restrict__ gate)
+{
+    if (gate && *gate == 0) return;
+    __shared__ GatSmem sm;
+    const int nlist = list[0];
+    const int G = (int)gridDim.x;
+    int it = (int)blockIdx.x, cur = 0;
+    int bk = it < nlist ? list[1 + it] : -1;
+    int bk1 = it + G < nlist ? list[1 + it + G] : -1;
+    if (threadIdx.x < 64) runs_store(sm.start[0], sm.pref[0], sm.amax[0], (int)threadIdx.x, runs_fetch(ndesc, desc, bk, (int)threadIdx.x));
+    while (bk >= 0) {
+        const int tid = opaque((int)threadIdx.x);
+        const int bk2 = it + 2 * G < nlist ? list[1 + it + 2 * G] : -1;
+        uint4 nx = make_uint4(0u, 0u, 0u, 0u);
+        if (tid < 64) nx = runs_fetch(ndesc, desc, bk1, tid);        // (in flight until the end of this brick)
+        const int64_t b = bk / bg.per_item;
+        const int r = bk - (int)b * bg.per_item;
+        const int b0[2] = { (r / bg.nb[1]) * BR2 - OFF2, (r % bg.nb[1]) * BR2 - OFF2 };     // lattice index of box slot 0
+        if (tid >= 128) {                                            // box slot -> wrapped lattice offset and sign (bounds.py:30-89)
+            const int d = (tid - 128) >> 6, slot = tid & 63;
+            if (slot < BOX2) {
+                const long long pk = wrap_outofline(p.bound[d], (d == 0 ? b0[0] : b0[1]) + slot, p.vol_n[d]);
+                sm.taboff[d][slot] = (int)(pk & 0xffffffffll) * (p.vol_ss[d] / (int)sizeof(T));
+                sm.tabsgn[d][slot] = (float)(int)(pk >> 32);
+            }
+        }
+        __syncthreads();                                             // the runs of this brick, the tables
+        const unsigned *start = sm.start[cur];
+        const int *pref = sm.pref[cur];
+        const int ntot = pref[CAPD2];
+        for (int cg = 0; cg < p.C; cg += GCMAX) {
+            const int nc = min(p.C - cg, GCMAX);                     // (block-uniform)
+            if (cg) __syncthreads();                                 // the previous group's readers are done
+            for (int e = tid; e < BOXN; e += NT2) {
+                const int x = e / BOX2, y = e - x * BOX2;
+                const float sg = sm.tabsgn[0][x] * sm.tabsgn[1][y];
+                const int64_t off = sm.taboff[0][x] + sm.taboff[1][y];
+#pragma unroll
+                for (int q = 0; q < GCMAX; ++q)
+                    if (q < nc) sm.box[q][e] = Cvt<float, T>::ld(img[b * p.vol_sb + (int64_t)(cg + q) * p.vol_sc + off]) * sg;
+            }
+            __syncthreads();
+            int rr = 0;
+            for (int j = tid; j < ntot; j += NT2) {
+                while (j >= pref[rr + 1]) ++rr;
+                const float4 rc = rec[start[rr] + (unsigned)(j - pref[rr])];
+                const float f0 = floorf(rc.x - 0.5f * (float)(K0 - 1)), f1 = floorf(rc.y - 0.5f * (float)(K1 - 1));
+                const float t0 = rc.x - f0, t1 = rc.y - f1;
+                int c0 = __float2int_rz(f0) - b0[0], c1 = __float2int_rz(f1) - b0[1];
+                c0 = max(0, min(c0, BR2 - 1)); c1 = max(0, min(c1, BR2 - 1));   // (0 .. 31 by construction of the bins)
+                const int slot = c0 * BOX2 + c1;
+                float w0[4], w1[4];
+                wts<K0>(t0, w0);
+                wts<K1>(t1, w1);
+                const float xy[2] = { rc.x, rc.y };
+                const float m = mask2(p, xy);                        // nd.py:139-140
+                const int64_t o = (int64_t)__float_as_int(rc.z);
+                if (MODE == 0) {
+#pragma unroll
+                    for (int q = 0; q < GCMAX; ++q) {
+                        if (q >= nc) break;
+                        float acc = 0.f;
+#pragma unroll
+                        for (int i = 0; i <= K0; ++i) {
+                            float row = 0.f;
+#pragma unroll
+                            for (int j2 = 0; j2 <= K1; ++j2) row = __builtin_fmaf(w1[j2], sm.box[q][slot + i * BOX2 + j2], row);
+                            acc = __builtin_fmaf(w0[i], row, acc);
+                        }
+                        ((T *)out)[b * p.val_sb + (int64_t)(cg + q) * p.val_sc + o] = Cvt<float, T>::st(acc * m);
+                    }
+                } else {
+                    float g0[4], g1[4];
+                    const bool lin = K0 == 1 && K1 == 1 && p.mode == MODE_ISO1;
+                    wgs<K0>(t0, g0, lin);
+                    wgs<K1>(t1, g1, lin);
+                    float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+                    for (int q = 0; q < GCMAX; ++q) {
+                        if (q >= nc) break;
+                        float d0 = 0.f, d1 = 0.f;
+#pragma unroll
+                        for (int i = 0; i <= K0; ++i) {
+                            float row = 0.f, rowg = 0.f;
+#pragma unroll
+                            for (int j2 = 0; j2 <= K1; ++j2) {
+                                const float v = sm.box[q][slot + i * BOX2 + j2];
+                                row = __builtin_fmaf(w1[j2], v, row);
+                                rowg = __builtin_fmaf(g1[j2], v, rowg);
+                            }
+                            d0 = __builtin_fmaf(g0[i], row, d0);
+                            d1 = __builtin_fmaf(w0[i], rowg, d1);
+                        }
+                        const float gv = gout ? Cvt<float, T>::ld(gout[b * p.val_sb + (int64_t)(cg + q) * p.val_sc + o]) : 1.f;
+                        a0 = __builtin_fmaf(gv, d0, a0);
+                        a1 = __builtin_fmaf(gv, d1, a1);
+                    }
+                    // written with the first group of channels, accumulated with the following ones (the same thread meets the record again)
+                    float2 *dst = reinterpret_cast<float2 *>((float *)out + (b * p.N + o) * 2);
+                    if (cg == 0) *dst = make_float2(a0 * m, a1 * m);
+                    else { const float2 old = *dst; *dst = make_float2(old.x + a0 * m, old.y + a1 * m); }
+                }
+            }
+        }
+        if (tid < 64) runs_store(sm.start[cur ^ 1], sm.pref[cur ^ 1], sm.amax[cur ^ 1], tid, nx);
+        cur ^= 1; bk = bk1; bk1 = bk2; it += G;
+        __syncthreads();                                             // the brick's readers are done: tables and boxes are free
+    }
+}
+
+static bool eligible(const interpol_problem *p, const KParams &k, bool scatter = true)
+{
+    if (p->dim != 2 || p->grid_dtype != INTERPOL_F32 || p->batch > 4096) return false;
+    if (p->dtype != INTERPOL_F32 && p->dtype != INTERPOL_BF16 && p->dtype != INTERPOL_F16) return false;
+    if (!(p->flags & (INTERPOL_FLAG_BINNED_SCATTER | INTERPOL_FLAG_AUTO_SCATTER))) return false;
+    if (k.sep != 0 && k.sep != 2) return false;                      // dense grids and displacement fields
+    if (scatter && p->vol_stride[0] == 0 && p->batch > 1) return false;   // (a shared target: not here)
+    if (k.dbg & (16 | 32)) return false;                             // (debug bits that switch the 2-D tiles off: no router without them)
+    int64_t n = 1, nv = 1, nt = p->batch, nb = p->batch;
+    for (int d = 0; d < 2; ++d) {
+        if (k.order[d] < 1 || k.order[d] > 3 || p->grid_shape[d] > 0x3fffffff) return false;
+        n *= p->grid_shape[d]; nv *= p->vol_shape[d];
+        nt *= (p->grid_shape[d] + TS2 - 1) / TS2;
+        nb *= (p->vol_shape[d] + 2 * OFF2 + BR2 - 1) / BR2;
+    }
+    if (n < 4096 || nt * NS2 > 0x7fffffffll || nb > 0x7fffffffll / CAPD2 || (uint64_t)n * 8ull > 0xffffffffull) return false;   // (and ops_tiled2d.hip: t2d_eligible)
+    return 4 * n >= nv;                                              // at least a quarter of a sample per target pixel
+}
+
+static void launch_probe(const interpol_problem *p, const KParams &k, const Workspace &w, const void *grid, int gy, int gz, int ntz, int ntiles, int permille, hipStream_t st)
+{
+    const int nwork = ntiles * (int)p->batch;
+    const int stride = nwork / PROBE_STRIDE > PROBE_MAXT ? (nwork + PROBE_MAXT - 1) / PROBE_MAXT : PROBE_STRIDE;
+    const int npt = (nwork + stride - 1) / stride, np = npt < PROBE_WG ? npt : PROBE_WG;
+    if (k.sep == 0) hipLaunchKernelGGL((probe2d<0>), dim3((unsigned)np), dim3(NT1), 0, st, k, (const float *)grid, w.hdr, gy, gz, ntz, ntiles, nwork, stride, permille);
+    else hipLaunchKernelGGL((probe2d<2>), dim3((unsigned)np), dim3(NT1), 0, st, k, (const float *)grid, w.hdr, gy, gz, ntz, ntiles, nwork, stride, permille);
+}
+
+template <typename T>
+static int launch(const interpol_problem *p, const KParams &k, const Grid2 &bg, const Workspace &w, const void *val, const void *grid, void *vol, hipStream_t st,
+                  const int *gate)
+{
+    const int gy = (int)p->grid_shape[0], gz = (int)p->grid_shape[1];
+    const int nty = (gy + TS2 - 1) / TS2, ntz = (gz + TS2 - 1) / TS2, ntiles = nty * ntz;
+    const dim3 tgrid((unsigned)(ntiles * (int)p->batch));
+    const int nch = k.C + k.cc;
+    const int64_t nz = 64 + 2 * w.nbricks + 1;
+    // 16-byte rows: the grid's and, per channel, the source's
+    int vec = (gz % 4 == 0) && ((uintptr_t)grid % 16 == 0) && (k.grid_sb % 4 == 0);
+    if (val) vec = vec && ((uintptr_t)val % (4 * sizeof(T)) == 0) && (k.val_sb % 4 == 0) && (k.val_sc % 4 == 0);
+    for (int c0 = 0; c0 < nch; c0 += Vals<T>::GC) {
+        const int nc = nch - c0 < Vals<T>::GC ? nch - c0 : Vals<T>::GC;
+        // (the header -- the probe's words -- is zeroed with the first group only)
+        const int skip = c0 == 0 ? 0 : 64;
+        hipLaunchKernelGGL(zero2, dim3((unsigned)((nz - skip + 1023) / 1024)), dim3(1024), 0, st, w.hdr + skip, (int)(nz - skip));
+        if (gate && c0 == 0) launch_probe(p, k, w, grid, gy, gz, ntz, ntiles, PERMILLE_SCATTER, st);
+        if (k.sep == 0) hipLaunchKernelGGL((bin2d<T, 0>), tgrid, dim3(NT1), 0, st, k, bg, (const T *)val, (const float *)grid, (float *)vol, w.ndesc, w.list, w.desc, w.rec, gy, gz, ntz, ntiles, c0, nc, vec, gate);
+        else hipLaunchKernelGGL((bin2d<T, 2>), tgrid, dim3(NT1), 0, st, k, bg, (const T *)val, (const float *)grid, (float *)vol, w.ndesc, w.list, w.desc, w.rec, gy, gz, ntz, ntiles, c0, nc, vec, gate);
+        const size_t lds = scat_lds(nc);
+        const long long want = 8ll * cu_count();
+        const dim3 ggrid((unsigned)(w.nbricks < want ? w.nbricks : want));
+        int rc = 0;
+#define IP_S2(A, B) if (k.order[0] == A && k.order[1] == B) {                                                          \
+        rc = big_lds<scatter2d<T, A, B>>(scat_lds(GCMAX));                                                             \
+        if (rc) return rc;                                                                                              \
+        hipLaunchKernelGGL((scatter2d<T, A, B>), ggrid, dim3(NT2), lds, st, k, bg, (const int *)w.ndesc, (const uint4 *)w.desc,     \
+                           (const float4 *)w.rec, (const int *)w.list, (float *)vol, c0, nc, gate); }
+        IP_S2(1, 1) IP_S2(1, 2) IP_S2(1, 3) IP_S2(2, 1) IP_S2(2, 2) IP_S2(2, 3) IP_S2(3, 1) IP_S2(3, 2) IP_S2(3, 3)
+#undef IP_S2
+    }
+    const hipError_t e = hipGetLastError();
+    return e == hipSuccess ? (gate ? 2 : 1) : (int)e;
+}
+
+template <typename T, int MODE>
+static int launch_gather(const interpol_problem *p, const KParams &k, const Grid2 &bg, const Workspace &w, const void *img, const void *gout, const void *grid, void *out,
+                         hipStream_t st, const int *gate)
+{
+    const int gy = (int)p->grid_shape[0], gz = (int)p->grid_shape[1];
+    const int nty = (gy + TS2 - 1) / TS2, ntz = (gz + TS2 - 1) / TS2, ntiles = nty * ntz;
+    const dim3 tgrid((unsigned)(ntiles * (int)p->batch));
+    const int64_t nz = 64 + 2 * w.nbricks + 1;
+    const int vec = (gz % 4 == 0) && ((uintptr_t)grid % 16 == 0) && (k.grid_sb % 4 == 0);
+    hipLaunchKernelGGL(zero2, dim3((unsigned)((nz + 1023) / 1024)), dim3(1024), 0, st, w.hdr, (int)nz);
+    if (gate) launch_probe(p, k, w, grid, gy, gz, ntz, ntiles, PERMILLE_GATHER, st);
+    if (k.sep == 0) hipLaunchKernelGGL((binidx2d<T, 0, MODE>), tgrid, dim3(NT1), 0, st, k, bg, (const T *)img, (const T *)gout, (const float *)grid, out, w.ndesc, w.list, w.desc, w.rec, gy, gz, ntz, ntiles, vec, gate);
+    else hipLaunchKernelGGL((binidx2d<T, 2, MODE>), tgrid, dim3(NT1), 0, st, k, bg, (const T *)img, (const T *)gout, (const float *)grid, out, w.ndesc, w.list, w.desc, w.rec, gy, gz, ntz, ntiles, vec, gate);
+    const long long want = 8ll * cu_count();
+    const dim3 ggrid((unsigned)(w.nbricks < want ? w.nbricks : want));
+#define IP_G2(A, B) if (k.order[0] == A && k.order[1] == B)                                                            \
+        hipLaunchKernelGGL((gather2d<T, A, B, MODE>), ggrid, dim3(NT2), 0, st, k, bg, (const int *)w.ndesc, (const uint4 *)w.desc,   \
+                           (const float4 *)w.rec, (const int *)w.list, (const T *)img, (const T *)gout, out, gate);
+    IP_G2(1, 1) IP_G2(1, 2) IP_G2(1, 3) IP_G2(2, 1) IP_G2(2, 2) IP_G2(2, 3) IP_G2(3, 1) IP_G2(3, 2) IP_G2(3, 3)
+#undef IP_G2
+    const hipError_t e = hipGetLastError();
+    return e == hipSuccess ? (gate ? 2 : 1) : (int)e;
+}
+
+} // namespace s2d
+
+int64_t gather2d_workspace_bytes(const interpol_problem *p, const KParams &k)
+{
+    if (!s2d::eligible(p, k, false)) return 0;
+    int64_t nt = 1;
+    for (int d = 0; d < 2; ++d) nt *= (p->grid_shape[d] + s2d::TS2 - 1) / s2d::TS2;
+    return s2d::layout(s2d::brick_grid(k), (int)p->batch, nt, nullptr, nullptr);
+}
+
+// grid_pull (mode 0: out = val, typed like the image) / the grid gradient of a pull's backward (mode 1: out = ggrid (B, *out, 2) float,
+// gout typed like the image or NULL for ones) in 2-D through bricks of the image: 1 = done, 2 = enqueued behind the probe of this call
+// (*gate_out: the word the tiles read -- 1: the bricks took the call), 0 = declined, else an error.
+int try_gather2d(const interpol_problem *p, const KParams &k, const void *img, const void *grid, void *out, void *workspace, int64_t workspace_bytes,
+                 int mode, const void *gout, hipStream_t st, const int **gate_out)
+{
+    using namespace s2d;
+    if (!workspace || ((uintptr_t)workspace & 255u) != 0 || !eligible(p, k, false)) return 0;
+    int64_t ntiles = 1;
+    for (int d = 0; d < 2; ++d) ntiles *= (p->grid_shape[d] + TS2 - 1) / TS2;
+    const Grid2 bg = brick_grid(k);
+    Workspace w;
+    if (layout(bg, (int)p->batch, ntiles, workspace, &w) > workspace_bytes) return 0;
+    if (64 + 2 * w.nbricks + 1 > 0x7fffffffll) return 0;
+    const int *gate = (p->flags & INTERPOL_FLAG_BINNED_SCATTER) ? nullptr : w.hdr + 32;
+    if (gate_out) *gate_out = gate;
+#define IP_GM(T) (mode == 0 ? launch_gather<T, 0>(p, k, bg, w, img, gout, grid, out, st, gate) : launch_gather<T, 1>(p, k, bg, w, img, gout, grid, out, st, gate))
+    switch (p->dtype) {
+    case INTERPOL_F32: return IP_GM(float);
+    case INTERPOL_BF16: return IP_GM(bf16_t);
+    case INTERPOL_F16: return IP_GM(f16_t);
+    default: return 0;
+    }
+#undef IP_GM
+}
+
+int64_t scatter2d_workspace_bytes(const interpol_problem *p, const KParams &k)
+{
+    if (!s2d::eligible(p, k)) return 0;
+    int64_t nt = 1;
+    for (int d = 0; d < 2; ++d) nt *= (p->grid_shape[d] + s2d::TS2 - 1) / s2d::TS2;
+    return s2d::layout(s2d::brick_grid(k), (int)p->batch, nt, nullptr, nullptr);
+}
+
+// grid_push (val != NULL) / grid_count in 2-D through bricks of the target: 1 = done, 2 = enqueued behind the probe of this call
+// (INTERPOL_FLAG_AUTO_SCATTER; *gate_out: the device word the other organisations read -- non-zero: the bricks took the call), 0 = declined,
+// else an error.  `vol`: the float target (the fp32 accumulator of a 16-bit target), zeroed or accumulated into by the caller; k.C (+ 1
+// with k.cc) channels.
+int try_scatter2d(const interpol_problem *p, const KParams &k, const void *val, const void *grid, void *vol, void *workspace, int64_t workspace_bytes,
+                  hipStream_t st, const int **gate_out)
+{
+    using namespace s2d;
+    if (!workspace || ((uintptr_t)workspace & 255u) != 0 || !eligible(p, k)) return 0;
+    int64_t ntiles = 1;
+    for (int d = 0; d < 2; ++d) ntiles *= (p->grid_shape[d] + TS2 - 1) / TS2;
+    const Grid2 bg = brick_grid(k);
+    Workspace w;
+    if (layout(bg, (int)p->batch, ntiles, workspace, &w) > workspace_bytes) return 0;
+    if (64 + 2 * w.nbricks + 1 > 0x7fffffffll) return 0;
+    const int *gate = (p->flags & INTERPOL_FLAG_BINNED_SCATTER) ? nullptr : w.hdr + 32;
+    if (gate_out) *gate_out = gate;
+    switch (val ? p->dtype : INTERPOL_F32) {
+    case INTERPOL_F32: return launch<float>(p, k, bg, w, val, grid, vol, st, gate);
+    case INTERPOL_BF16: return launch<bf16_t>(p, k, bg, w, val, grid, vol, st, gate);
+    case INTERPOL_F16: return launch<f16_t>(p, k, bg, w, val, grid, vol, st, gate);
+    default: return 0;
+    }
+}
+
+} // namespace ip

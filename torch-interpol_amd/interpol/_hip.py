@@ -26,6 +26,7 @@ FLAG_DISPLACEMENT = 16
 FLAG_WITH_COUNT = 32
 FLAG_BINNED_SCATTER = 64
 FLAG_AUTO_SCATTER = 1 << 24
+_ROUTED_2D = (torch.float32, torch.bfloat16, torch.float16)   # storage types of the 2-D bricks (csrc/scatter2d.hip)
 FLAG_SMALL_TILES = 1 << 25           # (experimental, opt-in: experiments/pull_direct.hip)
 _POISON_SCRATCH = os.environ.get("INTERPOL_POISON_SCRATCH", "0") not in ("", "0")
 FLAG_AFFINE_GRID = 128
@@ -355,8 +356,9 @@ def gather(op, vol, grid, bound, order, extrapolate, flags=0, out=None):
     grid, gflag = _prep_grid(grid, gdt)
     flags |= gflag
     routed = False
-    if op in ("pull", "grad") and dim == 3 and dt == torch.float32 and not (flags & (FLAG_NO_FASTPATH | FLAG_FORCE_TILED | FLAG_BINNED_SCATTER)) and (flags >> 8) == 0:
-        # the router of the pull (csrc/push_owner.hip: own_gather): like the push's, see interpol/backend.py
+    if (((op in ("pull", "grad") and dim == 3 and dt == torch.float32) or (op == "pull" and dim == 2 and dt in _ROUTED_2D and gdt == torch.float32))
+            and not (flags & (FLAG_NO_FASTPATH | FLAG_FORCE_TILED | FLAG_BINNED_SCATTER)) and (flags >> 8) == 0):
+        # the router of the pull (csrc/push_owner.hip: own_gather; 2-D: csrc/scatter2d.hip: gather2d): like the push's, see interpol/backend.py
         from . import backend
         if backend.rough_deformations is None:
             flags |= FLAG_AUTO_SCATTER
@@ -512,6 +514,16 @@ def pull_backward(gout, vol, grid, bound, order, extrapolate, need_vol, need_gri
         gvol = scatter("push", gout, grid, list(vol.shape[2:]), bound, order, extrapolate)
         ggrid = pull_backward(gout, vol, grid, bound, order, extrapolate, False, True, flags)[1] if need_grid else None
         return gvol, ggrid
+    if (need_vol and flags == 0 and dim == 2 and torch.is_tensor(grid) and 1 <= min(order[:2]) and max(order[:2]) <= 3
+            and vol.dtype == gout.dtype and vol.dtype in _ROUTED_2D and grid.dtype == torch.float32
+            and vol.shape[0] == grid.shape[0] == gout.shape[0] and (vol.shape[1] >= 2 or not need_grid)
+            and not backend.want_exact_scatter() and backend.rough_deformations is not False):
+        # 2-D, orders 1..3: the library splits this backward into a push of grad_out and the contracted grid gradient anyway
+        # (csrc/abi.hip: interpol_pull_backward); through `scatter` the push gets its router (csrc/scatter2d.hip), and so does
+        # the grid gradient below
+        gvol = scatter("push", gout, grid, list(vol.shape[2:]), bound, order, extrapolate)
+        ggrid = pull_backward(gout, vol, grid, bound, order, extrapolate, False, True, flags)[1] if need_grid else None
+        return gvol, ggrid
     if (need_vol and flags == 0 and dim == 3 and torch.is_tensor(grid) and max(order[:3]) <= 3 and max(order[:3]) > 0
             and vol.dtype == gout.dtype == grid.dtype == torch.float64 and vol.shape[0] == grid.shape[0] == gout.shape[0]
             and grid[0, ..., 0].numel() >= 4096 and not backend.want_exact_scatter()):
@@ -549,12 +561,13 @@ def pull_backward(gout, vol, grid, bound, order, extrapolate, need_vol, need_gri
     valstr = [_bstride(gout, B), gout.stride(1)] + _pad_to([gout.stride(2 + d) for d in range(dim)], 3) + [0, 0]
     routed = 0
     high = dim == 3 and all(int(o) == int(order[0]) for o in order[:3]) and int(order[0]) in (4, 5)   # image gradient through scatter5
-    if ((need_grid or (need_vol and high)) and dim == 3 and dt == torch.float32 and gdt == torch.float32 and (flags >> 8) == 0
+    two_d = dim == 2 and need_grid and dt in _ROUTED_2D and (not need_vol or dt == torch.float32)   # (a 16-bit image gradient keeps `scratch` for its accumulator)
+    if ((((need_grid or (need_vol and high)) and dim == 3 and dt == torch.float32) or two_d) and gdt == torch.float32 and (flags >> 8) == 0
             and not (flags & (FLAG_NO_FASTPATH | FLAG_FORCE_TILED | FLAG_BINNED_SCATTER))):
         # the grid gradient takes the router of the pull (csrc/push_owner.hip: own_gather<K, true>): tiles whose samples leave the
         # LDS box go to the bricks of the image; the workspace rides in the `scratch` argument (interpol_hip.h)
         routed = FLAG_AUTO_SCATTER if backend.rough_deformations is None else (FLAG_BINNED_SCATTER if backend.rough_deformations else 0)
-    elif (need_grid or (need_vol and high)) and (flags & FLAG_BINNED_SCATTER):
+    elif (need_grid or (need_vol and high)) and (flags & FLAG_BINNED_SCATTER) and (dim == 3 or two_d):
         routed = FLAG_BINNED_SCATTER
     p = make_problem(dim, dt, gdt, bound, order, extrapolate, B, C, ishape, oshape,
                      vstr, _grid_strides(grid_c, B, dim), valstr, flags | routed)
@@ -605,7 +618,7 @@ def push_backward(gvol_out, val, grid, bound, order, extrapolate, need_val, need
     L = lib()
     from . import backend
     routed = 0
-    if (dim == 3 and dt == torch.float32 and gdt == torch.float32 and (flags >> 8) == 0
+    if (((dim == 3 and dt == torch.float32) or (dim == 2 and dt in _ROUTED_2D)) and gdt == torch.float32 and (flags >> 8) == 0
             and not (flags & (FLAG_NO_FASTPATH | FLAG_FORCE_TILED | FLAG_BINNED_SCATTER))):
         # both gradients are gathers: they take the router of the pull (bricks of the image, csrc/push_owner.hip: own_gather)
         routed = FLAG_AUTO_SCATTER if backend.rough_deformations is None else (FLAG_BINNED_SCATTER if backend.rough_deformations else 0)
