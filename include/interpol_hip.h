@@ -188,6 +188,12 @@ typedef struct interpol_problem {
  * gradient of interpol_pull_backward, which takes the workspace in its `scratch` -- go through bricks of the target (gather5.hip:
  * scatter5), behind a probe of the call under INTERPOL_FLAG_AUTO_SCATTER (smooth fields keep the LDS tiles): cost independent of
  * the deformation (8 x 1 x 192^3 order 5: 2.9 ms at sigma = 2, 3.1 ms at sigma = 6, where the tiles took 4.2 ms and fell off a cliff).
+ * (c) 2-D, per-dim orders 1..3, F32 / BF16 / F16 sources, float32 coordinates (dense grids and displacement fields), private targets
+ * with at least a quarter of a sample per pixel: interpol_scatter_workspace returns 16 B per sample + 1 KiB per 32 x 32 brick (plus
+ * the accumulator of a 16-bit target) and interpol_push / interpol_count go through bricks of the target (scatter2d.hip) -- always
+ * under INTERPOL_FLAG_BINNED_SCATTER, behind a probe of the call under INTERPOL_FLAG_AUTO_SCATTER (more than 1 pixel per thousand
+ * outside the lean tiles' 64 x 64 boxes; smooth fields keep the tiles at +3 %).  BASELINE config 5's shape (32 x 3 x 1024^2 bf16,
+ * orders [2, 3]): 1.1 ms at every sigma, where the tiles take 1.04 ms at sigma = 2, 4.3 at 8 and 13.4 at 16.
  *
  * Accuracy of the LDS scatters (every fast path of interpol_push / interpol_count and of the scatter halves of the
  * backward operators; INTERPOL_FLAG_NO_FASTPATH selects the generic kernels, which add floats like the reference's
@@ -200,6 +206,9 @@ typedef struct interpol_problem {
  *     maximum), whatever the density; bricks whose stencil counts could overflow 32-bit sums use 64-bit sums of terms
  *     rounded at 2^-30 of a power of two >= the maximum; orders 4 - 5 (gather5.hip: scatter5): the same format in 32-bit
  *     sums, one channel per pass, wmax = 0.599 (order 4) / 0.55 (order 5): 2^-24.2 / 2^-24.6 of the brick's maximum per addend;
+ *     2-D (scatter2d.hip): 32-bit sums, each addend rounded to nearest at M * wmax0 * wmax1 / U, M = the largest |source| of the sample
+ *     tiles that reach the brick (rounded up to 8 bits), U = min(2^22 * 0.999, 2^31 * 0.99 / n) with n the records of the brick (its
+ *     densest cell times the taps when n > 2048): 2^-22 .. 2^-23 of M at one sample per pixel, and never an overflow;
  *   F64 (push_f64.hip): each addend rounded at 2^-51 of a power of two > the tile's maximum -- about 2^-52 of the tile's
  *     largest source per term, again absolute per tile; tiles whose maximum is below 2^-970 use the generic arithmetic.
  * Sums inside a tile / brick are integers: order-free, bit-reproducible.
@@ -219,6 +228,11 @@ int interpol_pull(const interpol_problem *p, const void *vol, const void *grid, 
  * interpol_pull_backward serve them through bricks of the image of their own (16 B per sample + 1 KiB per brick of workspace).
  * AUTO: order 5 always (8 x 1 x 192^3, sigma = 2: pull 2.57 -> 1.77 ms, grad 2.89 -> 1.96; sigma = 6: 43 -> 1.9 ms), order 4 for
  * grid_grad and the grid gradient, its pull behind a probe of the call (smooth fields stay with the LDS tiles). */
+/* 2-D (round 5, scatter2d.hip: gather2d; per-dim orders 1..3, F32 / BF16 / F16 images, float32 coordinates): interpol_pull_ws, the grid
+ * gradient of interpol_pull_backward (grad_vol == NULL for a 16-bit image, whose accumulator owns `scratch`) and both gradients of
+ * interpol_push_backward_ws go through 32 x 32 bricks of the image -- 16 B per sample + 1 KiB per brick of workspace -- always under
+ * INTERPOL_FLAG_BINNED_SCATTER, behind a probe of the call under INTERPOL_FLAG_AUTO_SCATTER (more than 10 pixels per thousand outside
+ * the lean tiles' boxes).  Config 5's shape: pull 0.88 ms at every sigma (tiles: 0.43 at sigma = 2, 2.8 at 8, 3.6 at 16). */
 int64_t interpol_pull_workspace(const interpol_problem *p);
 int interpol_pull_ws(const interpol_problem *p, const void *vol, const void *grid, void *val, void *workspace, int64_t workspace_bytes, void *stream);
 /* grid_grad (interpol_grad) with the same workspace (interpol_pull_workspace(p) bytes; for the grad problem the same number as for
@@ -266,7 +280,7 @@ int interpol_count_backward(const interpol_problem *p, const void *grad_vol_out,
                             void *grad_grid, void *stream);
 /* interpol_push_backward (val != NULL) / interpol_count_backward (val == NULL, grad_val == NULL) with the bricks workspace of the two
  * gathers they consist of -- interpol_pull_workspace(p) bytes, 256-byte aligned, contents undefined on entry; float32, 3-D quadratic /
- * cubic, INTERPOL_FLAG_AUTO_SCATTER or INTERPOL_FLAG_BINNED_SCATTER: grad_val is the routed pull of grad_vol_out (interpol_pull_ws),
+ * cubic (2-D: see interpol_pull_workspace), INTERPOL_FLAG_AUTO_SCATTER or INTERPOL_FLAG_BINNED_SCATTER: grad_val is the routed pull of grad_vol_out (interpol_pull_ws),
  * grad_grid the routed grid gradient (as interpol_pull_backward's, the roles of the two images swapped: pushpull.py:276-281).
  * Otherwise, or without a workspace: exactly the two calls above. */
 int interpol_push_backward_ws(const interpol_problem *p, const void *grad_vol_out, const void *val, const void *grid,
@@ -351,10 +365,10 @@ float   interpol_host_weight_f32(int32_t order, float x, int32_t which);
  *       function of its inputs, as the reference's gather is (nd.py:118-136).
  * Round 5: the hand-back only exists where no device-side router does.  Calls that carry a workspace for the bricks --
  * interpol_push / interpol_count with INTERPOL_FLAG_AUTO_SCATTER or _BINNED_SCATTER, interpol_pull_ws, interpol_grad_ws,
- * interpol_pull_backward / interpol_push_backward_ws with the bricks' workspace (3-D, orders 2 - 5 as each entry point
- * documents) -- never hand back: their organisation is chosen by a probe of THIS call's coordinates, so the result is a
+ * interpol_pull_backward / interpol_push_backward_ws with the bricks' workspace (3-D orders 2 - 5 and 2-D orders 1 - 3, as each
+ * entry point documents) -- never hand back: their organisation is chosen by a probe of THIS call's coordinates, so the result is a
  * function of the inputs under every mode (tests: test_routed_operators_do_not_depend_on_the_streams_history).  The modes
- * below still govern 2-D problems, order 1, orders 6 - 7, the order 4 - 5 scatters and every call without a workspace.
+ * below still govern 3-D order 1, orders 6 - 7, 2-D grid_grad (a generic kernel) and every call without a workspace.
  * interpol_set_handback(mode) returns the previous mode (process-wide; the environment variable
  * INTERPOL_HANDBACK = adaptive | always | never sets the initial one).
  * interpol_release_stream(stream): the hand-back slot (3 MiB of device memory) of `stream` on the current device goes

@@ -1683,9 +1683,11 @@ def test_two_d_bricks_low_precision_storage(dtype):
 
 
 def test_two_d_router_verdict_follows_the_field():
-    """probe2d examines every 16th tile of the call with the lean tiles' own box rule; the verdict (a word of the workspace) is a function
+    """probe2d examines every 32nd tile of the call with the lean tiles' own box rule; the verdict (a word of the workspace) is a function
     of the coordinates of this call alone: a smooth field keeps the tiles, i.i.d. noise of sigma = 8 px hands the call to the bricks
-    -- seen from outside as bit-identical results with the forced organisations' (the bricks of the image gather deterministically)."""
+    -- seen from outside as bit-identical results with the forced organisations' (the bricks of the image gather deterministically) --
+    and a zoom of 2.5, whose samples see a quarter of a sample per pixel, goes to the generic kernels (verdict 2), pull, push and
+    gradients alike, with results that agree with the oracle-checked generic path."""
     from interpol import _hip, backend
     g = torch.Generator().manual_seed(5)
     n = 256
@@ -1700,6 +1702,17 @@ def test_two_d_router_verdict_follows_the_field():
             backend.rough_deformations = organisation
             forced = _hip.gather("pull", img, grid, [3, 1], [3, 2], 1)
             assert torch.equal(routed, forced), sigma
+        backend.rough_deformations = None
+        grid = ((ident - n / 2) * 2.5 + n / 2 + 0.3 * torch.randn([2, n, n, 2], generator=g)).to(DEV)
+        gout = torch.randn([2, 2, n, n], generator=g).to(DEV)
+        b, o = [3, 1], [3, 2]
+        assert torch.equal(_hip.gather("pull", img, grid, b, o, 1), _hip.gather("pull", img, grid, b, o, 1, flags=_hip.FLAG_NO_FASTPATH))
+        for got, want in zip(_hip.pull_backward(gout, img, grid, b, o, 1, True, True), _hip.pull_backward(gout, img, grid, b, o, 1, True, True, flags=_hip.FLAG_NO_FASTPATH)):
+            assert G.rel_err(got.cpu().numpy(), want.cpu().numpy()) < 4e-6
+        for got, want in zip(_hip.push_backward(img, gout, grid, b, o, 1, True, True), _hip.push_backward(img, gout, grid, b, o, 1, True, True, flags=_hip.FLAG_NO_FASTPATH)):
+            assert G.rel_err(got.cpu().numpy(), want.cpu().numpy()) < 4e-6
+        got = _hip.scatter("push", gout, grid, [n, n], b, o, 1, with_count=True)
+        assert G.rel_err(got.cpu().numpy(), _hip.scatter("push", gout, grid, [n, n], b, o, 1, with_count=True, flags=_hip.FLAG_NO_FASTPATH).cpu().numpy()) < 4e-6
     finally:
         backend.rough_deformations = prev
 

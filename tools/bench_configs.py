@@ -98,6 +98,14 @@ if "5" in which:    # cfg5: 2-D, orders [2,3,5]->[2,3], bounds [dct1,dst2,zero]-
     rec(res, "cfg5_pull_backward_both_bf16_o23", timeit(lambda: _hip.pull_backward(x, x, gr, b2, o2, 1, True, True), 3), vox, nb + vox * C * 4)
     rec(res, "cfg5_push_backward_both_bf16_o23", timeit(lambda: _hip.push_backward(x, x, gr, b2, o2, 1, True, True), 3), vox, nb + vox * C * 2)
     rec(res, "cfg5_prefilter_f32_o23_dct1dct2", timeit(lambda: interpol.spline_coeff_nd(xf, [2, 3], ["dct1", "dct2"], 2), 3), vox, 2 * 2 * B * C * n * n * 4)
+    # round 5: the same calls on rougher fields -- the routed default (probe2d: lean tiles or the bricks of csrc/scatter2d.hip)
+    for sg in (4.0, 8.0, 16.0):
+        del gr
+        gr = ident([n, n], B, sg, g)
+        rec(res, "cfg5_pull_bf16_o23_sigma%d" % sg, timeit(lambda: interpol.grid_pull(x, gr, **kw), 3), vox, vox * (8 + C * 2) + B * C * n * n * 2)
+        rec(res, "cfg5_push_bf16_o23_sigma%d" % sg, timeit(lambda: interpol.grid_push(x, gr, **kw), 3), vox, vox * (8 + C * 2) + B * C * n * n * 2)
+        rec(res, "cfg5_pull_backward_both_bf16_o23_sigma%d" % sg, timeit(lambda: _hip.pull_backward(x, x, gr, b2, o2, 1, True, True), 3), vox, nb + vox * C * 4)
+        rec(res, "cfg5_push_backward_both_bf16_o23_sigma%d" % sg, timeit(lambda: _hip.push_backward(x, x, gr, b2, o2, 1, True, True), 3), vox, nb + vox * C * 2)
 
 if "f" in which:    # row f2: resize / restrict on a separable lattice vs the same call with a dense grid tensor
     B, C, n = 4, 2, 128

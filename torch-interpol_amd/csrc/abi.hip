@@ -333,10 +333,12 @@ static int routed_pull(const interpol_problem *p, KParams k, int B, const void *
         if (r2 != 2) return r2;
         k.gate = gate; k.gate_n = -1;
         r2 = try_fast_pull(p, k, vol, grid, val, st);
-        if (r2 != 0) return r2;
-        r2 = by_dtype(p->dtype,                                      // (the tiles declined: the generic kernel, behind the same verdict)
+        if (r2 != 0 && r2 != 1) return r2;
+        // the generic kernel: the third organisation (verdict 2: an expanding field); with the tiles declined, whatever the bricks left
+        if (r2 == 1) k.gate_n = -2;
+        r2 = by_dtype(p->dtype,
             [&] { return launch_pull_f32(k, vol, grid, val, B, st); },
-            [&] { return INTERPOL_E_DTYPE; },
+            [&] { return (int)INTERPOL_E_DTYPE; },
             [&] { return launch_pull_bf16(k, vol, grid, val, B, st); },
             [&] { return launch_pull_f16(k, vol, grid, val, B, st); });
         return r2 ? r2 : 1;
@@ -503,6 +505,7 @@ int interpol_push(const interpol_problem *p, const void *val, const void *grid, 
     return scatter_driver(p, 1, true, val, grid, vol, scratch, scratch_bytes, st, [&](const KParams &k0, int B, void *acc, void *ws, int64_t ws_bytes) {
         KParams k = k0;
         k.cc = with_count ? 1 : 0;
+        bool routed2d = false;
         if (!(p->flags & INTERPOL_FLAG_NO_FASTPATH)) {
             int rc = try_owner_push(p, k, val, grid, acc, ws, ws_bytes, st, &k.gate);     // needs its workspace: interpol_scatter_workspace
             if (rc != 0 && rc != 2) return rc == 1 ? 0 : rc;       // (2: launched behind the probe's gate; the kernels below read the same gate)
@@ -513,9 +516,11 @@ int interpol_push(const interpol_problem *p, const void *val, const void *grid, 
             if (rc == 0 && p->dim == 2) {
                 rc = try_scatter2d(p, k, val, grid, acc, ws, ws_bytes, st, &k.gate);    // 2-D through bricks of the target (scatter2d.hip)
                 if (rc != 0 && rc != 2) return rc == 1 ? 0 : rc;
+                routed2d = rc == 2;
             }
             rc = try_fast_push(p, k, val, grid, acc, st);           // the tiled kernel splats values and count in one pass
-            if (rc != 0) return rc == 1 ? 0 : rc;
+            if (rc != 0 && !(rc == 1 && routed2d)) return rc == 1 ? 0 : rc;
+            if (rc == 1) k.gate_n = -2;                              // (2-D router: the generic kernels below run on verdict 2 alone -- a target sampled sparsely)
         }
         k.cc = 0;
         if (!(p->flags & INTERPOL_FLAG_NO_FASTPATH) && p->dtype == INTERPOL_F64) {
@@ -611,6 +616,7 @@ int interpol_count(const interpol_problem *p, const void *grid, void *vol,
     hipStream_t st = (hipStream_t)stream;
     return scatter_driver(p, 1, false, nullptr, grid, vol, scratch, scratch_bytes, st, [&](const KParams &k0, int B, void *acc, void *ws, int64_t ws_bytes) {
         KParams k = k0;
+        bool routed2d = false;
         if (!(p->flags & INTERPOL_FLAG_NO_FASTPATH)) {
             int rc = try_owner_push(p, k, nullptr, grid, acc, ws, ws_bytes, st, &k.gate);
             if (rc != 0 && rc != 2) return rc == 1 ? 0 : rc;
@@ -621,9 +627,11 @@ int interpol_count(const interpol_problem *p, const void *grid, void *vol,
             if (rc == 0 && p->dim == 2) {
                 rc = try_scatter2d(p, k, nullptr, grid, acc, ws, ws_bytes, st, &k.gate);
                 if (rc != 0 && rc != 2) return rc == 1 ? 0 : rc;
+                routed2d = rc == 2;
             }
             rc = try_fast_push(p, k, nullptr, grid, acc, st);
-            if (rc != 0) return rc == 1 ? 0 : rc;
+            if (rc != 0 && !(rc == 1 && routed2d)) return rc == 1 ? 0 : rc;
+            if (rc == 1) k.gate_n = -2;
         }
         if (!(p->flags & INTERPOL_FLAG_NO_FASTPATH) && p->dtype == INTERPOL_F64) {
             const int rc = try_push_f64_tiles(p, k, nullptr, grid, acc, st);          // float64 on LDS tiles (push_f64.hip)
@@ -666,7 +674,20 @@ static int routed_gradc(const interpol_problem *p, const KParams &k, const void 
         KParams kg = k;
         kg.gate = gate; kg.gate_n = -1;
         r2 = try_fast_pullbwd(p, kg, gout, vol, grid, nullptr, ggrid, 0, 0, st);
-        return r2;                                                   // (0: the tiles declined -- the caller's kernels write the same numbers over the bricks')
+        if (r2 != 1) return r2;                                      // (0: the tiles declined -- the caller's kernels write the same numbers over the bricks')
+        kg.gate_n = -2;                                              // the generic kernel: the organisation of expanding fields (verdict 2)
+        const int B = (int)p->batch;
+        r2 = gout ? by_dtype(p->dtype,
+                [&] { return launch_pullbwd_f32(kg, gout, vol, grid, nullptr, ggrid, B, 0, 0, st); },
+                [&] { return (int)INTERPOL_E_DTYPE; },
+                [&] { return launch_pullbwd_bf16(kg, gout, vol, grid, nullptr, ggrid, B, 0, 0, st); },
+                [&] { return launch_pullbwd_f16(kg, gout, vol, grid, nullptr, ggrid, B, 0, 0, st); })
+                  : by_dtype(p->dtype,
+                [&] { return launch_pushbwd_f32(kg, vol, nullptr, grid, nullptr, ggrid, B, st); },
+                [&] { return (int)INTERPOL_E_DTYPE; },
+                [&] { return launch_pushbwd_bf16(kg, vol, nullptr, grid, nullptr, ggrid, B, st); },
+                [&] { return launch_pushbwd_f16(kg, vol, nullptr, grid, nullptr, ggrid, B, st); });
+        return r2 ? r2 : 1;
     }
     if (k.order[0] >= 4) {                                           // orders 4 and 5: gather5.hip, the bricks always (1), or declined (0)
         const int r5 = try_gather5(p, k, vol, grid, ggrid, scratch, scratch_bytes, 1, gout, st, nullptr);

@@ -124,6 +124,7 @@ __global__ __launch_bounds__(BLOCK) void pull_generic(KParams p, const T *__rest
                                                       const G *__restrict__ grid, T *__restrict__ val, int B, TileList tl)
 {
     if (p.gate_n == -1 && p.gate && *p.gate == 1) return;   // a probe of the call gave it to the bricks of the image (interpol_pull_ws / interpol_grad_ws)
+    if (p.gate_n == -2 && p.gate && *p.gate != 2) return;   // 2-D router (scatter2d.hip: probe2d): this kernel is the organisation of expanding fields only
     IP_FOR_SAMPLES {
         const int64_t b = it_.b, o = it_.o;
         R x[D];
@@ -266,7 +267,8 @@ template <typename T, typename G, typename R, typename AccT, int D, int KMAX, bo
 __global__ __launch_bounds__(BLOCK) void push_generic(KParams p, const T *__restrict__ val,
                                                       const G *__restrict__ grid, AccT *__restrict__ vol, int B, TileList tl)
 {
-    if (p.gate && *p.gate) return;                     // the owner-computes organisation took this call (push_owner.hip: own_probe)
+    if (p.gate && (p.gate_n == -2 ? *p.gate != 2 : *p.gate != 0)) return;   // the owner-computes organisation took this call (push_owner.hip: own_probe); 2-D router
+                                                       // (scatter2d.hip: probe2d, gate_n = -2): this kernel takes the sparsely sampled targets only
     IP_FOR_SAMPLES {
         const int64_t b = it_.b, o = it_.o;
         R x[D];
@@ -347,6 +349,7 @@ __global__ __launch_bounds__(BLOCK) void pullbwd_generic(KParams p, const T *__r
                                                          const G *__restrict__ grid, AccT *__restrict__ gvol,
                                                          G *__restrict__ ggrid, int B, int64_t gvol_sb, int64_t gvol_sc, TileList tl)
 {
+    if (p.gate_n == -2 && p.gate && *p.gate != 2) return;   // 2-D router (scatter2d.hip: probe2d): the organisation of expanding fields only
     // gvol has vol's spatial layout (host guarantees both spatially contiguous) but AccT elements
     constexpr unsigned ACC_SCALE = sizeof(AccT) / sizeof(T);
     IP_FOR_SAMPLES {
@@ -410,6 +413,7 @@ __global__ __launch_bounds__(BLOCK) void pushbwd_generic(KParams p, const T *__r
                                                          const G *__restrict__ grid, T *__restrict__ gval,
                                                          G *__restrict__ ggrid, int B, TileList tl)
 {
+    if (p.gate_n == -2 && p.gate && *p.gate != 2) return;   // 2-D router (scatter2d.hip: probe2d): the organisation of expanding fields only
     IP_FOR_SAMPLES {
         const int64_t b = it_.b, o = it_.o;
         R x[D];

@@ -314,7 +314,7 @@ __global__ __launch_bounds__(NT, 3) void pull2d(KParams p, const T *__restrict__
                                              int gy, int gz, int ntz, int ntiles, DeferArgs defer)
 {
     __shared__ Smem sm;
-    if (p.gate_n == -1 && p.gate && *p.gate == 1) return;   // a probe of the call gave it to the bricks of the image (scatter2d.hip: gather2d)
+    if (p.gate_n == -1 && p.gate && *p.gate != 0) return;   // a probe of the call gave it to the bricks of the image or, an expanding field, to the generic kernel (scatter2d.hip: probe2d)
     constexpr int NC = Slot<T>::NC;
     const Lattice L = lattice2d(p, (int)sizeof(T), K0, K1);
     const int64_t b = blockIdx.x / ntiles;
@@ -494,7 +494,7 @@ __global__ __launch_bounds__(NT, 3) void gradc2d(KParams p, const T *__restrict_
                                               float *__restrict__ ggrid, int gy, int gz, int ntz, int ntiles, DeferArgs defer)
 {
     __shared__ Smem sm;
-    if (p.gate_n == -1 && p.gate && *p.gate == 1) return;   // a probe of the call gave it to the bricks of the image (scatter2d.hip: gather2d)
+    if (p.gate_n == -1 && p.gate && *p.gate != 0) return;   // a probe of the call gave it to the bricks of the image or, an expanding field, to the generic kernel (scatter2d.hip: probe2d)
     constexpr int NC = Slot<T>::NC;
     const Lattice L = lattice2d(p, (int)sizeof(T), K0, K1);
     const int64_t b = blockIdx.x / ntiles;

@@ -22,11 +22,14 @@
 //   gather2d: per brick the 35 x 35 lattice points of up to four channels are staged through the boundary tables (1.2 lattice points
 // per pixel) and the records gather from the boxes (pull), or contract the channels with grad_out per tap (grid gradient).
 //   The runs of the NEXT brick are fetched while the current one is processed (list -> counter -> descriptors: three dependent loads).
-//   probe2d: under INTERPOL_FLAG_AUTO_SCATTER every 16th tile is examined with the tiles' own box rule; beyond 1 (scatters) / 10
-// (gathers) pixels per thousand outside the boxes the bricks take the call.  Both organisations are enqueued behind the verdict -- a word
-// of the workspace -- and the loser returns at once: no host synchronisation, hipGraph-safe, a function of the call's coordinates alone.
-// Measured (profiles/r05_2d_bricks.txt): the bricks cost the same at every sigma -- push 1.10 ms, pull 0.88, pull backward 2.1 -- so the
-// routed call follows the tiles up to sigma ~ 4 (+3 %: probe and two empty launches) and stays flat beyond.
+//   probe2d: under INTERPOL_FLAG_AUTO_SCATTER every 32nd tile is examined with the tiles' own box rule: up to 50 (scatters) / 400
+// (gathers) pixels per million outside the boxes the lean tiles keep the call; beyond, the bricks take it when the samples see a density
+// of at least 0.6 (a map of the domain onto itself, however rough), else -- a zoom -- the generic kernel (gathers; scatters below a
+// density of 0.22) or the tiles.  The organisations are enqueued behind the verdict -- a word of the workspace -- and the losers return at
+// once: no host synchronisation, hipGraph-safe, a function of the call's coordinates alone (no hand-back of defer.hip behind it).
+// Measured (profiles/r05_2d_bricks.txt): the bricks cost the same at every sigma -- push 1.10 ms, pull 0.9, pull backward 2.1 -- so the
+// routed call follows the tiles up to sigma ~ 5 (+4-6 %: probe and the empty launches) and stays flat beyond; a zoom of 2 - 3 pulls in
+// 1.2 ms (rounds 3 - 4, hand-back: 1.7).
 // Samples whose stencil starts more than 256 points outside the lattice, tiles that spread over more than 6 bricks per dim and runs
 // beyond a brick's 64 descriptors are handled by their own thread in the binning kernel (always correct).
 // Workspace: 16 B per sample + 1 KiB per brick (interpol_scatter_workspace / interpol_pull_workspace).
@@ -123,43 +126,61 @@ template <> struct Vals<float> {
     static __device__ __forceinline__ void unpack(float a, float b, float *v) { v[0] = a; v[1] = b; v[2] = 0.f; v[3] = 0.f; }
 };
 
-// The probe of a call under INTERPOL_FLAG_AUTO_SCATTER: the lean tiles of ops_tiled2d.hip serve a tile from a box of CAP = 64 lattice
-// points per dim placed on the range of the tile's first taps; a pixel whose stencil leaves the box is scattered by its own thread, tap by
-// tap, at ~100 times the cost.  Every 16th tile of the call (at most 2000 tiles) is examined with the tiles' own rule; more than 1 pixel per thousand outside
-// (sigma ~ 4 px of i.i.d. noise, a zoom beyond 2, folds; 10 per thousand for the gathers, whose stray pixels cost loads, not atomics) and
-// the bricks take the call.  hdr[32]: the verdict (1 bricks, 0 tiles),
-// hdr[34..35]: one 64-bit word -- pixels outside, pixels examined, workgroups done.
-constexpr int PROBE_STRIDE = 16, PROBE_CAP = 64, PROBE_MAXT = 2000, PROBE_WG = 500;       // (22-bit fields: at most 4095 tiles of 1024 pixels)
-constexpr int PERMILLE_SCATTER = 1, PERMILLE_GATHER = 10;      // pixels outside the tiles' boxes, per thousand, beyond which the bricks take the call
+// The probe of a call under INTERPOL_FLAG_AUTO_SCATTER.  The lean tiles of ops_tiled2d.hip serve a tile from a box of CAP = 64 lattice
+// points per dim placed on the range of the tile's first taps; a pixel whose stencil leaves the box is handled by its own thread, tap by
+// tap, at ~100 times the cost.  Every 32nd tile of the call (at most 512 tiles) is examined with the tiles' own rule:
+//   * no more than `ppm` pixels per million outside the boxes (50 for the scatters, 400 for the gathers, whose stray pixels cost loads,
+//     not atomics: sigma ~ 4.7 / 5.3 px of i.i.d. noise at config 5's shape)            -> verdict 0, the tiles;
+//   * else the DENSITY the samples see decides: the mean over the tiles of 1 / |det J|, J the tile's mean stretch (first against last
+//     row and column: noise averages out, a zoom does not; a tile with a sample outside the binned range counts 0).  A map of the
+//     domain onto itself has density >= 1 however rough (Jensen); a zoom by z per dim has 1 / z^2 and would leave the 32 x 32 bricks
+//     with a fraction of their 1024 records.  Density >= 0.6                            -> verdict 1, the bricks;
+//   * else the gathers                                                                   -> verdict 2, the generic kernel (what the
+//     hand-back of defer.hip picked in rounds 3 - 4); the scatters keep the tiles (verdict 0) down to a density of 0.22 (zoom ~2.1), where
+//     their per-thread atomics still beat the generic kernel's, and take the generic kernel (2) below.
+// hdr[32]: the verdict; hdr[34..35]: one 64-bit word -- pixels outside (bits 41..61), density sum in 1/32 (22..40), tiles examined
+// (10..21), workgroups done (0..9).
+constexpr int PROBE_STRIDE = 32, PROBE_CAP = 64, PROBE_MAXT = 512, PROBE_WG = 256;       // (12-bit tile count, 10-bit ticket)
+constexpr int PPM_SCATTER = 50, PPM_GATHER = 400;
 template <int GM>
-__global__ __launch_bounds__(NT1) void probe2d(KParams p, const float *__restrict__ grid, int *__restrict__ hdr, int gy, int gz, int ntz, int ntiles, int nwork, int stride,
-                                               int permille)
+__global__ __launch_bounds__(NT1) void probe2d(KParams p, Grid2 bg, const float *__restrict__ grid, int *__restrict__ hdr, int gy, int gz, int ntz, int ntiles, int nwork,
+                                               int stride, int ppm, int alt)
 {
-    __shared__ int lo[2], hi[2], nout, nseen;
+    __shared__ int lo[2], hi[2], nout, ntile, esum, unbinned;
+    __shared__ float jac[4];
     const int tid = threadIdx.x;
-    if (tid == 0) { nout = 0; nseen = 0; }
+    if (tid == 0) { nout = 0; ntile = 0; esum = 0; }
     // (a workgroup examines several tiles: the closing add is one per workgroup on ONE address, ~10 ns each)
     for (int pt = (int)blockIdx.x; pt * stride < nwork; pt += (int)gridDim.x) {
         const int wk = min(pt * stride + pt % stride, nwork - 1);    // (a diagonal through the tiles)
         const int64_t b = wk / ntiles;
         const int tile = wk % ntiles;
         const int oy0 = (tile / ntz) * TS2, oz0 = (tile % ntz) * TS2;
+        const bool whole = oy0 + TS2 <= gy && oz0 + TS2 <= gz;       // (block-uniform)
         __syncthreads();
         if (tid < 2) { lo[tid] = 0x7fffffff; hi[tid] = -0x7fffffff; }
+        if (tid < 4) jac[tid] = 0.f;
+        if (tid == 0) unbinned = 0;
         int i0[VPT1][2];
         unsigned valid = 0;
         int mn[2] = { 0x7fffffff, 0x7fffffff }, mx[2] = { -0x7fffffff, -0x7fffffff };
+        float dj[4] = { 0.f, 0.f, 0.f, 0.f };                        // d(x0, x1) along the rows' index, d(x0, x1) along the columns' index
+        bool stray = false;
+        const int ry = tid >> 3, cz = (tid & 7) * VPT1;
 #pragma unroll
         for (int v = 0; v < VPT1; ++v) {
-            int oy = oy0 + (tid >> 3), oz = oz0 + (tid & 7) * VPT1 + v;
+            int oy = oy0 + ry, oz = oz0 + cz + v;
             if (oy < gy && oz < gz) valid |= 1u << v;
             oy = oy < gy ? oy : gy - 1; oz = oz < gz ? oz : gz - 1;
             const float2 gv = *reinterpret_cast<const float2 *>(grid + b * p.grid_sb + ((int64_t)oy * gz + oz) * 2);
             float c[2] = { gv.x, gv.y };
             if (GM == 2) { c[0] += (float)oy; c[1] += (float)oz; }
+            const float wy = ry == TS2 - 1 ? 1.f : (ry == 0 ? -1.f : 0.f), wz = cz + v == TS2 - 1 ? 1.f : (cz + v == 0 ? -1.f : 0.f);
+            dj[0] += wy * c[0]; dj[1] += wy * c[1]; dj[2] += wz * c[0]; dj[3] += wz * c[1];
 #pragma unroll
             for (int d = 0; d < 2; ++d) {
                 float fl = floorf(c[d] - 0.5f * (float)(p.order[d] - 1));
+                if (((valid >> v) & 1) && !(fl >= (float)(-OFF2) && fl < (float)(bg.nb[d] * BR2 - OFF2))) stray = true;   // (NaN as well)
                 fl = fl < -1073741824.f ? -1073741824.f : (fl > 1073741824.f ? 1073741824.f : fl);   // (tile_common.hpp: split; NaN -> the cast's 0)
                 i0[v][d] = (int)fl;
                 if ((valid >> v) & 1) { mn[d] = i0[v][d] < mn[d] ? i0[v][d] : mn[d]; mx[d] = i0[v][d] > mx[d] ? i0[v][d] : mx[d]; }
@@ -171,6 +192,11 @@ __global__ __launch_bounds__(NT1) void probe2d(KParams p, const float *__restric
             const int a = wave_min(mn[d]), e = wave_max(mx[d]);
             if ((tid & 63) == 0) { atomicMin(&lo[d], a); atomicMax(&hi[d], e); }
         }
+        if (whole) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { const float t = wave_sum(dj[q]); if ((tid & 63) == 0) atomicAdd(&jac[q], t); }
+        }
+        if (__any(stray) && (tid & 63) == 0) unbinned = 1;
         __syncthreads();
         int l[2], sz[2];
 #pragma unroll
@@ -183,28 +209,38 @@ __global__ __launch_bounds__(NT1) void probe2d(KParams p, const float *__restric
             if (s_ > PROBE_CAP) { l_ += (int)((s_ - PROBE_CAP) / 2); s_ = PROBE_CAP; }
             l[d] = l_; sz[d] = (int)s_;
         }
-        int mine = 0, seen = 0;
+        int mine = 0;
 #pragma unroll
         for (int v = 0; v < VPT1; ++v) {
             if (!((valid >> v) & 1)) continue;
-            ++seen;
             bool in = true;
 #pragma unroll
             for (int d = 0; d < 2; ++d) in = in && i0[v][d] >= l[d] && (long long)i0[v][d] + p.order[d] < (long long)l[d] + sz[d];
             mine += in ? 0 : 1;
         }
-        mine = (int)wave_sum((float)mine); seen = (int)wave_sum((float)seen);
-        if ((tid & 63) == 0) { atomicAdd(&nout, mine); atomicAdd(&nseen, seen); }
+        mine = (int)wave_sum((float)mine);
+        if ((tid & 63) == 0) atomicAdd(&nout, mine);
+        if (tid == 0) {
+            // 1 / |det J| of the tile's mean stretch, in 1/32, at most 8 (a partial tile counts 1; a tile with an unbinned sample, or NaN, 0)
+            constexpr float sc = 1.f / (float)((TS2 - 1) * TS2);
+            const float e = whole ? __builtin_fabsf(jac[0] * jac[3] - jac[1] * jac[2]) * (sc * sc) : 1.f;
+            const float dens = unbinned ? 0.f : (e > 0.125f ? 1.f / e : (e >= 0.f ? 8.f : 0.f));
+            esum += (int)(dens * 32.f + 0.5f);
+            ntile += 1;
+        }
     }
     __syncthreads();
     if (tid == 0) {
-        // ONE relaxed 64-bit add carries the workgroup's pixels outside (bits 42..63), pixels examined (20..41) and a 1 (0..19): the
-        // workgroup that finds gridDim.x - 1 others in the old value holds the totals -- no fence, no second word to order against
-        const unsigned long long add = ((unsigned long long)nout << 42) | ((unsigned long long)nseen << 20) | 1ull;
+        // ONE relaxed 64-bit add carries the workgroup's share and a 1: the workgroup that finds gridDim.x - 1 others in the old value holds
+        // the totals -- no fence, no second word to order against
+        const unsigned long long add = ((unsigned long long)nout << 41) | ((unsigned long long)esum << 22) | ((unsigned long long)ntile << 10) | 1ull;
         const unsigned long long tot = __hip_atomic_fetch_add(reinterpret_cast<unsigned long long *>(hdr + 34), add, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + add;
-        if ((tot & 0xfffffull) == (unsigned long long)gridDim.x) {
-            const unsigned long long no = tot >> 42, ns = (tot >> 20) & 0x3fffffull;
-            __hip_atomic_store(&hdr[32], (no * 1000ull > ns * (unsigned long long)permille) ? 1 : 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if ((tot & 0x3ffull) == (unsigned long long)gridDim.x) {
+            const unsigned long long no = tot >> 41, es = (tot >> 22) & 0x7ffffull, nt = (tot >> 10) & 0xfffull;
+            int verdict = 0;
+            if (no * 1000000ull > nt * 1024ull * (unsigned long long)ppm)
+                verdict = (es * 100ull >= nt * 32ull * 60ull) ? 1 : ((alt == 2 || es * 100ull < nt * 32ull * 22ull) ? 2 : 0);
+            __hip_atomic_store(&hdr[32], verdict, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
 }
@@ -219,7 +255,7 @@ __global__ __launch_bounds__(NT1) void bin2d(KParams p, Grid2 bg, const T *__res
                                              int gy, int gz, int ntz, int ntiles, int c0, int nc, int vec, const int *__restrict__ gate)
 {
     __shared__ BinSmem sm;
-    if (gate && *gate == 0) return;                                  // the probe of this call kept the LDS tiles (probe2d)
+    if (gate && *gate != 1) return;                                  // the probe of this call chose another organisation (probe2d)
     const int tid = threadIdx.x;
     const int64_t b = blockIdx.x / ntiles;
     const int tile = blockIdx.x % ntiles;
@@ -442,7 +478,7 @@ __global__ __launch_bounds__(NT2) void scatter2d(KParams p, Grid2 bg, const int 
                                                  const float4 *__restrict__ rec, const int *__restrict__ list,
                                                  float *__restrict__ vol, int c0, int nc, const int *__restrict__ gate)
 {
-    if (gate && *gate == 0) return;
+    if (gate && *gate != 1) return;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     ScatSmem &sm = *reinterpret_cast<ScatSmem *>(smem_raw);
     const tiled::Lattice L = lattice2(p);
@@ -628,7 +664,7 @@ __global__ __launch_bounds__(NT1) void binidx2d(KParams p, Grid2 bg, const T *__
                                                 float4 *__restrict__ rec, int gy, int gz, int ntz, int ntiles, int vec, const int *__restrict__ gate)
 {
     __shared__ BinSmem sm;
-    if (gate && *gate == 0) return;                                  // the probe of this call kept the LDS tiles (probe2d)
+    if (gate && *gate != 1) return;                                  // the probe of this call chose another organisation (probe2d)
     const int tid = threadIdx.x;
     const int64_t b = blockIdx.x / ntiles;
     const int tile = blockIdx.x % ntiles;
@@ -746,7 +782,7 @@ __global__ __launch_bounds__(NT2) void gather2d(KParams p, Grid2 bg, const int *
                                                 const float4 *__restrict__ rec, const int *__restrict__ list,
                                                 const T *__restrict__ img, const T *__restrict__ gout, void *__restrict__ out, const int *__restrict__ gate)
 {
-    if (gate && *gate == 0) return;
+    if (gate && *gate != 1) return;
     __shared__ GatSmem sm;
     const int nlist = list[0];
     const int G = (int)gridDim.x;
@@ -873,13 +909,14 @@ static bool eligible(const interpol_problem *p, const KParams &k, bool scatter =
     return 4 * n >= nv;                                              // at least a quarter of a sample per target pixel
 }
 
-static void launch_probe(const interpol_problem *p, const KParams &k, const Workspace &w, const void *grid, int gy, int gz, int ntz, int ntiles, int permille, hipStream_t st)
+static void launch_probe(const interpol_problem *p, const KParams &k, const Grid2 &bg, const Workspace &w, const void *grid, int gy, int gz, int ntz, int ntiles,
+                         int ppm, int alt, hipStream_t st)
 {
     const int nwork = ntiles * (int)p->batch;
     const int stride = nwork / PROBE_STRIDE > PROBE_MAXT ? (nwork + PROBE_MAXT - 1) / PROBE_MAXT : PROBE_STRIDE;
     const int npt = (nwork + stride - 1) / stride, np = npt < PROBE_WG ? npt : PROBE_WG;
-    if (k.sep == 0) hipLaunchKernelGGL((probe2d<0>), dim3((unsigned)np), dim3(NT1), 0, st, k, (const float *)grid, w.hdr, gy, gz, ntz, ntiles, nwork, stride, permille);
-    else hipLaunchKernelGGL((probe2d<2>), dim3((unsigned)np), dim3(NT1), 0, st, k, (const float *)grid, w.hdr, gy, gz, ntz, ntiles, nwork, stride, permille);
+    if (k.sep == 0) hipLaunchKernelGGL((probe2d<0>), dim3((unsigned)np), dim3(NT1), 0, st, k, bg, (const float *)grid, w.hdr, gy, gz, ntz, ntiles, nwork, stride, ppm, alt);
+    else hipLaunchKernelGGL((probe2d<2>), dim3((unsigned)np), dim3(NT1), 0, st, k, bg, (const float *)grid, w.hdr, gy, gz, ntz, ntiles, nwork, stride, ppm, alt);
 }
 
 template <typename T>
@@ -899,7 +936,7 @@ static int launch(const interpol_problem *p, const KParams &k, const Grid2 &bg, 
         // (the header -- the probe's words -- is zeroed with the first group only)
         const int skip = c0 == 0 ? 0 : 64;
         hipLaunchKernelGGL(zero2, dim3((unsigned)((nz - skip + 1023) / 1024)), dim3(1024), 0, st, w.hdr + skip, (int)(nz - skip));
-        if (gate && c0 == 0) launch_probe(p, k, w, grid, gy, gz, ntz, ntiles, PERMILLE_SCATTER, st);
+        if (gate && c0 == 0) launch_probe(p, k, bg, w, grid, gy, gz, ntz, ntiles, PPM_SCATTER, 0, st);   // (alt 0: tiles between the bricks' and the generic kernel's densities)
         if (k.sep == 0) hipLaunchKernelGGL((bin2d<T, 0>), tgrid, dim3(NT1), 0, st, k, bg, (const T *)val, (const float *)grid, (float *)vol, w.ndesc, w.list, w.desc, w.rec, gy, gz, ntz, ntiles, c0, nc, vec, gate);
         else hipLaunchKernelGGL((bin2d<T, 2>), tgrid, dim3(NT1), 0, st, k, bg, (const T *)val, (const float *)grid, (float *)vol, w.ndesc, w.list, w.desc, w.rec, gy, gz, ntz, ntiles, c0, nc, vec, gate);
         const size_t lds = scat_lds(nc);
@@ -928,7 +965,7 @@ static int launch_gather(const interpol_problem *p, const KParams &k, const Grid
     const int64_t nz = 64 + 2 * w.nbricks + 1;
     const int vec = (gz % 4 == 0) && ((uintptr_t)grid % 16 == 0) && (k.grid_sb % 4 == 0);
     hipLaunchKernelGGL(zero2, dim3((unsigned)((nz + 1023) / 1024)), dim3(1024), 0, st, w.hdr, (int)nz);
-    if (gate) launch_probe(p, k, w, grid, gy, gz, ntz, ntiles, PERMILLE_GATHER, st);
+    if (gate) launch_probe(p, k, bg, w, grid, gy, gz, ntz, ntiles, PPM_GATHER, 2, st);
     if (k.sep == 0) hipLaunchKernelGGL((binidx2d<T, 0, MODE>), tgrid, dim3(NT1), 0, st, k, bg, (const T *)img, (const T *)gout, (const float *)grid, out, w.ndesc, w.list, w.desc, w.rec, gy, gz, ntz, ntiles, vec, gate);
     else hipLaunchKernelGGL((binidx2d<T, 2, MODE>), tgrid, dim3(NT1), 0, st, k, bg, (const T *)img, (const T *)gout, (const float *)grid, out, w.ndesc, w.list, w.desc, w.rec, gy, gz, ntz, ntiles, vec, gate);
     const long long want = 8ll * cu_count();
