@@ -1682,6 +1682,44 @@ def test_two_d_bricks_low_precision_storage(dtype):
         backend.rough_deformations = prev
 
 
+def test_two_d_router_in_a_captured_graph():
+    """The 2-D router has no host state: captured once, a graph's replays take the tiles (a smooth field), the bricks (sigma = 9) and
+    the generic kernels (a zoom of 2.4) as the coordinates in the captured buffer change, and match eager calls of the generic path."""
+    from interpol import _hip
+    gen = torch.Generator().manual_seed(78)
+    n = 192
+    img = torch.randn([2, 3, n, n], generator=gen).to(torch.bfloat16).to(DEV)
+    src = torch.randn([2, 3, n, n], generator=gen).to(torch.bfloat16).to(DEV)
+    ident = interpol.identity_grid([n, n])[None]
+    grid = (ident + 0.3 * torch.randn([2, n, n, 2], generator=gen)).to(DEV)
+    b, o = [2, 5], [2, 3]
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        _hip.gather("pull", img, grid, b, o, 1); _hip.scatter("push", src, grid, [n, n], b, o, 1); _hip.pull_backward(src, img, grid, b, o, 1, True, True)
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        out_pull = _hip.gather("pull", img, grid, b, o, 1)
+        out_push = _hip.scatter("push", src, grid, [n, n], b, o, 1)
+        out_bwd = _hip.pull_backward(src, img, grid, b, o, 1, True, True)
+    fields = [ident + 0.3 * torch.randn([2, n, n, 2], generator=gen), ident + 9.0 * torch.randn([2, n, n, 2], generator=gen),
+              (ident - n / 2) * 2.4 + n / 2 + 0.2 * torch.randn([2, n, n, 2], generator=gen)]
+    for it, f in enumerate(fields):
+        grid.copy_(f)
+        g.replay()
+        torch.cuda.synchronize()
+        f32 = lambda t: t.float()
+        ref = _hip.gather("pull", f32(img), grid, b, o, 1, flags=_hip.FLAG_NO_FASTPATH)
+        assert G.rel_err(f32(out_pull).cpu().numpy(), ref.cpu().numpy()) < 6e-3, ("graph pull", it)
+        ref = _hip.scatter("push", f32(src), grid, [n, n], b, o, 1, flags=_hip.FLAG_NO_FASTPATH)
+        assert G.rel_err(f32(out_push).cpu().numpy(), ref.cpu().numpy()) < 6e-3, ("graph push", it)
+        ref = _hip.pull_backward(f32(src), f32(img), grid, b, o, 1, True, True, flags=_hip.FLAG_NO_FASTPATH)
+        assert G.rel_err(f32(out_bwd[0]).cpu().numpy(), ref[0].cpu().numpy()) < 6e-3, ("graph bwd image", it)
+        assert G.rel_err(out_bwd[1].cpu().numpy(), ref[1].cpu().numpy()) < 2e-5, ("graph bwd grid", it)
+
+
 def test_two_d_router_verdict_follows_the_field():
     """probe2d examines every 32nd tile of the call with the lean tiles' own box rule; the verdict (a word of the workspace) is a function
     of the coordinates of this call alone: a smooth field keeps the tiles, i.i.d. noise of sigma = 8 px hands the call to the bricks

@@ -225,6 +225,30 @@ static int by_dtype(int dtype, F32 f32, F64 f64, BF bf, HF hf)
     }
 }
 
+// Zero-fill of a target / accumulator on the stream.  A KERNEL, not hipMemsetAsync: inside a captured hipGraph the memset nodes of ROCm 7.2
+// were observed to leave every fourth float of a 0.9 MB accumulator holding garbage from the second replay on, when other nodes of the
+// graph had used the same addresses (tools/r5/graph2d_dbg.py: bf16 2-D push behind a bricks pull, one replay in two;
+// push_owner.hip met the same with its header).  16 bytes per thread where the range allows, bytes at the edges.
+__global__ __launch_bounds__(256) void zero_fill(unsigned char *__restrict__ ptr, size_t head, size_t n16, size_t tail)
+{
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x, step = (size_t)gridDim.x * 256;
+    uint4 *q = reinterpret_cast<uint4 *>(ptr + head);
+    for (size_t j = i; j < n16; j += step) q[j] = make_uint4(0u, 0u, 0u, 0u);
+    if (i < head) ptr[i] = 0;
+    if (i < tail) ptr[head + n16 * 16 + i] = 0;
+}
+static hipError_t zero_async(void *ptr, size_t bytes, hipStream_t st)
+{
+    if (bytes == 0) return hipSuccess;
+    const size_t mis = (size_t)((uintptr_t)ptr & 15u);
+    const size_t head = mis ? (16 - mis < bytes ? 16 - mis : bytes) : 0;
+    const size_t n16 = (bytes - head) / 16, tail = bytes - head - n16 * 16;
+    size_t blocks = (n16 + 255) / 256;
+    blocks = blocks < 1 ? 1 : (blocks > 16384 ? 16384 : blocks);
+    hipLaunchKernelGGL(zero_fill, dim3((unsigned)blocks), dim3(256), 0, st, (unsigned char *)ptr, head, n16, tail);
+    return hipGetLastError();
+}
+
 // common driver of the scatter-type operators
 template <typename Launch>
 static int scatter_driver(const interpol_problem *p, int trailing, bool need_val, const void *val, const void *grid,
@@ -252,7 +276,7 @@ static int scatter_driver(const interpol_problem *p, int trailing, bool need_val
     }
     if (ws_bytes <= 0) { ws = nullptr; ws_bytes = 0; }
     if (!(p->flags & INTERPOL_FLAG_ACCUMULATE) || lowp) {
-        hipError_t e = hipMemsetAsync(acc, 0, (size_t)numel * acc_esize(p->dtype), st);
+        hipError_t e = zero_async(acc, (size_t)numel * acc_esize(p->dtype), st);
         if (e != hipSuccess) return (int)e;
     }
     rc = launch(k, B, acc, ws, ws_bytes);
@@ -585,7 +609,7 @@ int interpol_push_bricks(const interpol_problem *p, const void *val, const void 
     if (!val || !grid || !vol || !workspace) return INTERPOL_E_NULL;
     hipStream_t st = (hipStream_t)stream;
     if (!(p->flags & INTERPOL_FLAG_ACCUMULATE)) {
-        const hipError_t e = hipMemsetAsync(vol, 0, (size_t)vol_numel(p) * 4, st);
+        const hipError_t e = zero_async(vol, (size_t)vol_numel(p) * 4, st);
         if (e != hipSuccess) return (int)e;
     }
     rc = launch_push_bricks(k, B, p->vol_stride[0] == 0, val, grid, vol, workspace, workspace_bytes, st);
@@ -744,7 +768,7 @@ int interpol_pull_backward(const interpol_problem *p, const void *grad_out, cons
             acc = scratch;
         }
         if (!(p->flags & INTERPOL_FLAG_ACCUMULATE) || lowp) {
-            hipError_t e = hipMemsetAsync(acc, 0, (size_t)numel * acc_esize(p->dtype), st);
+            hipError_t e = zero_async(acc, (size_t)numel * acc_esize(p->dtype), st);
             if (e != hipSuccess) return (int)e;
         }
     }
@@ -961,7 +985,7 @@ int interpol_resample_1d(int32_t dtype, int32_t lin_dtype, int32_t order, int32_
     if ((uint64_t)n_samples * (uint64_t)inner > 0xffffffffull) return INTERPOL_E_SHAPE;
     hipStream_t st = (hipStream_t)stream;
     if (adjoint) {
-        const hipError_t e = hipMemsetAsync(dst, 0, (size_t)outer * (size_t)n_lattice * (size_t)inner * es, st);
+        const hipError_t e = zero_async(dst, (size_t)outer * (size_t)n_lattice * (size_t)inner * es, st);
         if (e != hipSuccess) return (int)e;
     }
     if (outer == 0 || n_samples == 0 || inner == 0) return 0;

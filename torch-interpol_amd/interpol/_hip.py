@@ -29,6 +29,7 @@ FLAG_AUTO_SCATTER = 1 << 24
 _ROUTED_2D = (torch.float32, torch.bfloat16, torch.float16)   # storage types of the 2-D bricks (csrc/scatter2d.hip)
 FLAG_SMALL_TILES = 1 << 25           # (experimental, opt-in: experiments/pull_direct.hip)
 _POISON_SCRATCH = os.environ.get("INTERPOL_POISON_SCRATCH", "0") not in ("", "0")
+_WS_NOCACHE = os.environ.get("INTERPOL_WS_NOCACHE", "0") not in ("", "0")     # (debugging aid: a fresh workspace per call, as inside a hipGraph capture)
 FLAG_AFFINE_GRID = 128
 
 _DTYPE_CODE = {torch.float32: F32, torch.float64: F64, torch.bfloat16: BF16, torch.float16: F16}
@@ -102,7 +103,7 @@ def _optional_workspace(nbytes, dev):
     if nbytes <= 0:
         return None
     idx = dev.index if dev.index is not None else torch.cuda.current_device()
-    if torch.cuda.is_current_stream_capturing():
+    if torch.cuda.is_current_stream_capturing() or _WS_NOCACHE:
         # inside a hipGraph capture the buffer must belong to the graph (its private pool keeps it alive for the replays): a cached
         # buffer could be replaced by a larger one -- and freed -- after the capture
         try:
@@ -390,6 +391,8 @@ def gather(op, vol, grid, bound, order, extrapolate, flags=0, out=None):
         wbytes = int(L.interpol_pull_workspace(ctypes.byref(p)))
         ws = _optional_workspace(wbytes, dev)
         if ws is not None:
+            if _POISON_SCRATCH:
+                ws.fill_(0xff)
             with torch.cuda.device(dev):
                 rc = (L.interpol_pull_ws if op == "pull" else L.interpol_grad_ws)(ctypes.byref(p), _ptr(vol), _ptr(grid), _ptr(val), _ptr(ws), wbytes, _stream(dev))
             _check(rc, "interpol_%s_ws" % op)
