@@ -8,7 +8,7 @@
 // is evaluated for the labels of the stencil only, and the winner is the reference's: the largest
 // soft value if it is > 0 (pmax starts at 0), the SMALLEST such label on ties (unique() is
 // sorted ascending and the update is a strict `>`), else 0.  Covered: isotropic orders 0..3 in
-// 1 / 2 / 3 dims (up to the 64 taps of the 3-D cubic, pull_labels_wide_kernel); the host keeps the
+// 1 / 2 / 3 dims (up to the 64 taps of the 3-D cubic: pull_labels_hash_kernel, float32 coordinates; pull_labels_wide_kernel, float64); the host keeps the
 // reference's loop for anything else and for prefilter = True.
 // No FMA contraction in this translation unit: the winner of an arg-max can hinge on the last
 // bit of a weight (coordinates exactly half-way between voxels give exact ties in the reference),
@@ -179,6 +179,92 @@ __global__ __launch_bounds__(WIDE_NT, 3) void pull_labels_wide_kernel(KParams p,
     }
 }
 
+// The 3-D cubic arg-max for label maps with MANY labels under a stencil (i.i.d. labels: ~36 distinct ones among the 64 taps, where the
+// pass-per-distinct-label walk above costs 36 x 64 compare-adds per voxel: 10 ms for 192^3).  One pass over the taps, in tap order, into
+// a per-thread hash table of 64 (label, sum) slots in LDS -- slot s of thread t at [s][t]: a wave touches 64 different banks whatever the
+// slots -- with linear probing and the occupancy in a 64-bit register (no sentinel: any int32 is a label).  A label's sum receives its
+// taps' weights in tap order, starting from 0 + w: the very additions of the per-label pull (the zeros it adds for the other taps change
+// nothing).  The label of the previous tap and its running sum stay in registers.  32 KiB per 64 threads: five waves per CU -- enough here, the
+// gathers of a plane are in flight together.  192^3 voxels (tools/r5/labels_ab.py): i.i.d. labels out of 50 10.0 -> 3.0 ms, 8^3 blocks of labels
+// 2.8 -> 2.2, i.i.d. labels out of 2 1.5 -> 2.1; 64 DISTINCT labels under every stencil (int32 noise) fill the table: 14 ms either way.
+constexpr int HASH_NT = 64;
+template <typename G, int D, int K>
+__global__ __launch_bounds__(HASH_NT) void pull_labels_hash_kernel(KParams p, const int *__restrict__ vol, const G *__restrict__ grid,
+                                                                      int *__restrict__ val, int B)
+{
+    typedef float R;
+    __shared__ int keys[64][HASH_NT];
+    __shared__ float sums[64][HASH_NT];
+    const int64_t o = (int64_t)blockIdx.x * HASH_NT + threadIdx.x;
+    if (o >= p.N) return;
+    constexpr int T0 = K + 1, T1 = K + 1, T2 = K + 1, NT = T0 * T1 * T2;
+    static_assert(D == 3 && K == 3 && NT == 64, "64 taps, 64 slots");
+    const int tid = threadIdx.x;
+    for (int64_t b = blockIdx.y; b < B; b += gridDim.y) {
+        R x[D];
+        load_coords<R, G, D>(p, grid, b, o, x);
+        Stencil<R, D, K, true, NEED_W> s;
+        s.setup(p, x);
+        R wd[3][K + 1];
+#pragma unroll
+        for (int d = 0; d < D; ++d) {                                // the reference's own operations (see pull_labels_kernel)
+            const R fl = (R)floorf((float)(x[d] - R(1)));
+            const R t = x[d] - fl;
+#pragma unroll
+            for (int j = 0; j <= K; ++j) {
+                R a = t - R(j); a = a < R(0) ? -a : a;
+                const R u = R(2) - a;
+                const R we = a < R(1) ? (a * a * (a - R(2)) * R(3) + R(4)) / R(6) : (u * u * u) / R(6);
+                wd[d][j] = s.w[d][j] == R(0) ? R(0) : (s.w[d][j] < R(0) ? -we : we);
+            }
+        }
+        for (int c = 0; c < p.C; ++c) {
+            const char *v0 = reinterpret_cast<const char *>(vol + b * p.vol_sb + c * p.vol_sc);
+            unsigned long long occ = 0ull;
+            // the label of the previous tap and its running sum stay in registers: a smooth map (one or two labels under most stencils)
+            // touches the table a few times per voxel, not 64
+            int cur_l = 0, cur_h = -1;
+            R cur_s = R(0);
+#pragma unroll 1
+            for (int i = 0; i < T0; ++i) {
+                // one x-plane (16 gathers) in flight at a time
+                const unsigned oi = s.off[0][i == 0 ? 0 : i == 1 ? 1 : i == 2 ? 2 : 3];
+                const R wx = i == 0 ? wd[0][0] : i == 1 ? wd[0][1] : i == 2 ? wd[0][2] : wd[0][3];
+                int tmp[T1 * T2];
+#pragma unroll
+                for (int j = 0; j < T1; ++j)
+#pragma unroll
+                    for (int k = 0; k < T2; ++k) tmp[j * T2 + k] = *reinterpret_cast<const int *>(v0 + (oi + s.off[1][j] + s.off[2][k]));
+#pragma unroll
+                for (int jk = 0; jk < T1 * T2; ++jk) {
+                    const int l = tmp[jk];
+                    const R w = (wx * wd[1][jk / T2]) * wd[2][jk % T2];       // node-major product, sign folded in
+                    if (cur_h >= 0 && l == cur_l) { cur_s += w; continue; }
+                    if (cur_h >= 0) sums[cur_h][tid] = cur_s;
+                    unsigned h = ((unsigned)l * 0x9E3779B1u) >> 26;
+                    for (;;) {
+                        if (!((occ >> h) & 1ull)) { keys[h][tid] = l; cur_s = R(0) + w; occ |= 1ull << h; break; }
+                        if (keys[h][tid] == l) { cur_s = sums[h][tid] + w; break; }
+                        h = (h + 1u) & 63u;
+                    }
+                    cur_l = l; cur_h = (int)h;
+                }
+            }
+            if (cur_h >= 0) sums[cur_h][tid] = cur_s;
+            int best_l = 0x7fffffff;
+            R best_w = R(0);
+            while (occ) {
+                const int h = __ffsll((long long)occ) - 1;
+                occ &= occ - 1ull;
+                const int l = keys[h][tid];
+                const R sum = sums[h][tid] * s.mask;
+                if (sum > best_w || (sum == best_w && l < best_l)) { best_w = sum; best_l = l; }
+            }
+            val[b * p.val_sb + c * p.val_sc + o] = best_w > R(0) ? best_l : 0;
+        }
+    }
+}
+
 template <typename G, typename R>
 int launch_g(const KParams &p, const void *vol, const void *grid, void *val, int B, hipStream_t st)
 {
@@ -188,6 +274,11 @@ int launch_g(const KParams &p, const void *vol, const void *grid, void *val, int
                                                                         p, (const int *)vol, (const G *)grid, (int *)val, B); goto done; }
     IP_L(1, 0) IP_L(1, 1) IP_L(1, 2) IP_L(1, 3) IP_L(2, 0) IP_L(2, 1) IP_L(2, 2) IP_L(2, 3) IP_L(3, 0) IP_L(3, 1) IP_L(3, 2)
 #undef IP_L
+    if (p.dim == 3 && K == 3 && sizeof(R) == 4 && !(p.dbg & 2)) {     // (debug bit 2: the walk below, for A/B)
+        const dim3 hgrid((unsigned)((p.N + HASH_NT - 1) / HASH_NT), (unsigned)(B < 65535 ? B : 65535), 1);
+        hipLaunchKernelGGL((pull_labels_hash_kernel<G, 3, 3>), hgrid, dim3(HASH_NT), 0, st, p, (const int *)vol, (const G *)grid, (int *)val, B);
+        goto done;
+    }
     if (p.dim == 3 && K == 3) {
         const dim3 wgrid((unsigned)((p.N + WIDE_NT - 1) / WIDE_NT), (unsigned)(B < 65535 ? B : 65535), 1);
         hipLaunchKernelGGL((pull_labels_wide_kernel<G, R, 3, 3>), wgrid, dim3(WIDE_NT), 0, st, p, (const int *)vol, (const G *)grid, (int *)val, B);
