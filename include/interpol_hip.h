@@ -191,8 +191,9 @@ typedef struct interpol_problem {
  * (c) 2-D, per-dim orders 1..3, F32 / BF16 / F16 sources, float32 coordinates (dense grids and displacement fields), private targets
  * with at least a quarter of a sample per pixel: interpol_scatter_workspace returns 16 B per sample + 1 KiB per 32 x 32 brick (plus
  * the accumulator of a 16-bit target) and interpol_push / interpol_count go through bricks of the target (scatter2d.hip) -- always
- * under INTERPOL_FLAG_BINNED_SCATTER, behind a probe of the call under INTERPOL_FLAG_AUTO_SCATTER (more than 1 pixel per thousand
- * outside the lean tiles' 64 x 64 boxes; smooth fields keep the tiles at +3 %).  BASELINE config 5's shape (32 x 3 x 1024^2 bf16,
+ * under INTERPOL_FLAG_BINNED_SCATTER, behind a probe of the call under INTERPOL_FLAG_AUTO_SCATTER (the bricks take the call when more than 50
+ * pixels per million leave the lean tiles' 64 x 64 boxes AND the samples see a density of at least 0.6 per pixel; a sparser sampling -- a zoom --
+ * stays with the tiles, below 0.22 it goes to the generic kernel; smooth fields keep the tiles at +3 %).  BASELINE config 5's shape (32 x 3 x 1024^2 bf16,
  * orders [2, 3]): 1.1 ms at every sigma, where the tiles take 1.04 ms at sigma = 2, 4.3 at 8 and 13.4 at 16.
  *
  * Accuracy of the LDS scatters (every fast path of interpol_push / interpol_count and of the scatter halves of the
@@ -231,8 +232,9 @@ int interpol_pull(const interpol_problem *p, const void *vol, const void *grid, 
 /* 2-D (round 5, scatter2d.hip: gather2d; per-dim orders 1..3, F32 / BF16 / F16 images, float32 coordinates): interpol_pull_ws, the grid
  * gradient of interpol_pull_backward (grad_vol == NULL for a 16-bit image, whose accumulator owns `scratch`) and both gradients of
  * interpol_push_backward_ws go through 32 x 32 bricks of the image -- 16 B per sample + 1 KiB per brick of workspace -- always under
- * INTERPOL_FLAG_BINNED_SCATTER, behind a probe of the call under INTERPOL_FLAG_AUTO_SCATTER (more than 10 pixels per thousand outside
- * the lean tiles' boxes).  Config 5's shape: pull 0.88 ms at every sigma (tiles: 0.43 at sigma = 2, 2.8 at 8, 3.6 at 16). */
+ * INTERPOL_FLAG_BINNED_SCATTER, behind a probe of the call under INTERPOL_FLAG_AUTO_SCATTER (more than 400 pixels per million outside
+ * the lean tiles' boxes and a density of at least 0.6 samples per pixel; sparser samplings -- a zoom beyond ~1.3 whose tiles leave their boxes --
+ * go to the generic kernel, as the hand-back of rounds 3 - 4 sent them).  Config 5's shape: pull 0.88 ms at every sigma (tiles: 0.43 at sigma = 2, 2.8 at 8, 3.6 at 16). */
 int64_t interpol_pull_workspace(const interpol_problem *p);
 int interpol_pull_ws(const interpol_problem *p, const void *vol, const void *grid, void *val, void *workspace, int64_t workspace_bytes, void *stream);
 /* grid_grad (interpol_grad) with the same workspace (interpol_pull_workspace(p) bytes; for the grad problem the same number as for
