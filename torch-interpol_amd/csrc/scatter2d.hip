@@ -780,7 +780,7 @@ __device__ __forceinline__ void wgs(float t, float *g, bool lin)
 template <typename T, int K0, int K1, int MODE>
 __global__ __launch_bounds__(NT2) void gather2d(KParams p, Grid2 bg, const int *__restrict__ ndesc, const uint4 *__restrict__ desc,
                                                 const float4 *__restrict__ rec, const int *__restrict__ list,
-                                                const T *__restrict__ img, const T *__restrict__ gout, void *__restrict__ out, const int *__restrict__ gate)
+                                                const T *__restrict__ img, const T *__restrict__ gout, void *__restrict__ out, const int *__restrict__ gate, int quads)
 {
     if (gate && *gate != 1) return;
     __shared__ GatSmem sm;
@@ -813,6 +813,25 @@ __global__ __launch_bounds__(NT2) void gather2d(KParams p, Grid2 bg, const int *
         for (int cg = 0; cg < p.C; cg += GCMAX) {
             const int nc = min(p.C - cg, GCMAX);                     // (block-uniform)
             if (cg) __syncthreads();                                 // the previous group's readers are done
+            // rows of the box that are runs of the image's unit-stride dim (no wrap, sign +1): quads of T (8 / 16 bytes) instead of single
+            // elements -- 9 loads per row and channel instead of 35 (config 5: staging 0.24 -> see profiles/r05_2d_bricks.txt)
+            const bool zlin = p.vol_ss[1] == (int)sizeof(T) && quads && b0[1] >= (p.bound[1] == B_DST1 ? 1 : 0) && b0[1] + 36 <= p.vol_n[1];   // (block-uniform)
+            if (zlin) {
+                for (int e = tid; e < BOX2 * 9; e += NT2) {
+                    const int x = e / 9, k = e - x * 9;
+                    const float sg = sm.tabsgn[0][x];
+                    const int64_t off = sm.taboff[0][x] + b0[1] + 4 * k;
+#pragma unroll
+                    for (int q = 0; q < GCMAX; ++q) {
+                        if (q >= nc) break;
+                        struct alignas(4 * sizeof(T)) Q4 { T e[4]; };
+                        const Q4 v = *reinterpret_cast<const Q4 *>(img + b * p.vol_sb + (int64_t)(cg + q) * p.vol_sc + off);
+                        float *dst = &sm.box[q][x * BOX2 + 4 * k];
+                        dst[0] = Cvt<float, T>::ld(v.e[0]) * sg; dst[1] = Cvt<float, T>::ld(v.e[1]) * sg; dst[2] = Cvt<float, T>::ld(v.e[2]) * sg;
+                        if (k < 8) dst[3] = Cvt<float, T>::ld(v.e[3]) * sg;
+                    }
+                }
+            } else
             for (int e = tid; e < BOXN; e += NT2) {
                 const int x = e / BOX2, y = e - x * BOX2;
                 const float sg = sm.tabsgn[0][x] * sm.tabsgn[1][y];
@@ -970,9 +989,11 @@ static int launch_gather(const interpol_problem *p, const KParams &k, const Grid
     else hipLaunchKernelGGL((binidx2d<T, 2, MODE>), tgrid, dim3(NT1), 0, st, k, bg, (const T *)img, (const T *)gout, (const float *)grid, out, w.ndesc, w.list, w.desc, w.rec, gy, gz, ntz, ntiles, vec, gate);
     const long long want = 8ll * cu_count();
     const dim3 ggrid((unsigned)(w.nbricks < want ? w.nbricks : want));
+    // quads of the image's rows: every row, channel and item starts on a 4-element boundary
+    const int quads = ((uintptr_t)img % (4 * sizeof(T)) == 0) && k.vol_ss[0] % (4 * (int)sizeof(T)) == 0 && k.vol_sb % 4 == 0 && k.vol_sc % 4 == 0;
 #define IP_G2(A, B) if (k.order[0] == A && k.order[1] == B)                                                            \
         hipLaunchKernelGGL((gather2d<T, A, B, MODE>), ggrid, dim3(NT2), 0, st, k, bg, (const int *)w.ndesc, (const uint4 *)w.desc,   \
-                           (const float4 *)w.rec, (const int *)w.list, (const T *)img, (const T *)gout, out, gate);
+                           (const float4 *)w.rec, (const int *)w.list, (const T *)img, (const T *)gout, out, gate, quads);
     IP_G2(1, 1) IP_G2(1, 2) IP_G2(1, 3) IP_G2(2, 1) IP_G2(2, 2) IP_G2(2, 3) IP_G2(3, 1) IP_G2(3, 2) IP_G2(3, 3)
 #undef IP_G2
     const hipError_t e = hipGetLastError();
