@@ -11,9 +11,10 @@ namespace ip {
 inline dim3 sample_grid(const KParams &p, int B)
 {
     const int64_t bx = (p.N + 255) / 256;
-    // (gate_n == -2: one of several organisations enqueued behind the 2-D router's verdict, usually not the one that runs -- two batch
-    //  items' worth of blocks, which stride over the batch, keep the launch that returns at once cheap: 131 072 empty workgroups cost 32 us)
-    const int by = p.gate_n == -2 && B > 2 ? 2 : B;
+    // (gate_n == -2: one of several organisations enqueued behind the 2-D router's verdict, usually not the one that runs -- eight batch
+    //  items' worth of blocks, which stride over the batch, keep the launch that returns at once cheap: 131 072 empty workgroups cost 32 us;
+    //  two items' worth cost the kernel 15 % when it does run)
+    const int by = p.gate_n == -2 && B > 8 ? 8 : B;
     return dim3((unsigned)bx, (unsigned)(by < 65535 ? by : 65535), 1);
 }
 

@@ -27,9 +27,9 @@
 // of at least 0.6 (a map of the domain onto itself, however rough), else -- a zoom -- the generic kernel (gathers; scatters below a
 // density of 0.22) or the tiles.  The organisations are enqueued behind the verdict -- a word of the workspace -- and the losers return at
 // once: no host synchronisation, hipGraph-safe, a function of the call's coordinates alone (no hand-back of defer.hip behind it).
-// Measured (profiles/r05_2d_bricks.txt): the bricks cost the same at every sigma -- push 1.10 ms, pull 0.9, pull backward 2.1 -- so the
+// Measured (profiles/r05_2d_bricks.txt): the bricks cost the same at every sigma -- push 1.10 ms, pull 0.8, pull backward 2.0 -- so the
 // routed call follows the tiles up to sigma ~ 5 (+4-6 %: probe and the empty launches) and stays flat beyond; a zoom of 2 - 3 pulls in
-// 1.2 ms (rounds 3 - 4, hand-back: 1.7).
+// 1.3 ms (rounds 3 - 4, hand-back: 1.7).
 // Samples whose stencil starts more than 256 points outside the lattice, tiles that spread over more than 6 bricks per dim and runs
 // beyond a brick's 64 descriptors are handled by their own thread in the binning kernel (always correct).
 // Workspace: 16 B per sample + 1 KiB per brick (interpol_scatter_workspace / interpol_pull_workspace).
