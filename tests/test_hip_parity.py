@@ -1682,6 +1682,34 @@ def test_two_d_bricks_low_precision_storage(dtype):
         backend.rough_deformations = prev
 
 
+def test_two_d_bricks_displacement_fields():
+    """The 2-D bricks read displacement fields (INTERPOL_FLAG_DISPLACEMENT: coordinates = pixel index + field, evaluated in the binning
+    kernels and the probe) like dense grids: same results as the call on identity + field, routed and forced, smooth and rough."""
+    from interpol import _hip, backend
+    g = torch.Generator().manual_seed(61)
+    prev = backend.rough_deformations
+    try:
+        for (B, C, n0, n1) in ((2, 3, 200, 131), (1, 5, 97, 140)):
+            ident = interpol.identity_grid([n0, n1])[None]
+            for sigma in (1.0, 9.0):
+                for bound, order, ex in (([2, 5], [2, 3], 1), ([0, 6], [3, 1], 0)):
+                    disp = (sigma * torch.randn([B, n0, n1, 2], generator=g)).to(DEV)
+                    grid = (ident.to(DEV) + disp).contiguous()
+                    img = torch.randn([B, C, n0, n1], generator=g).to(DEV)
+                    for rd in (True, None):
+                        backend.rough_deformations = rd
+                        D = _hip.FLAG_DISPLACEMENT
+                        pairs = [(_hip.gather("pull", img, disp, bound, order, ex, flags=D), _hip.gather("pull", img, grid, bound, order, ex)),
+                                 (_hip.scatter("push", img, disp, [n0, n1], bound, order, ex, flags=D, with_count=True),
+                                  _hip.scatter("push", img, grid, [n0, n1], bound, order, ex, with_count=True)),
+                                 (_hip.scatter("count", None, disp, [n0, n1], bound, order, ex, flags=D), _hip.scatter("count", None, grid, [n0, n1], bound, order, ex)),
+                                 (_hip.pull_backward(img, img, disp, bound, order, ex, False, True, flags=D)[1], _hip.pull_backward(img, img, grid, bound, order, ex, False, True)[1])]
+                        for i, (a, r) in enumerate(pairs):
+                            assert G.rel_err(a.cpu().numpy(), r.cpu().numpy()) < 4e-6, (i, B, C, sigma, bound, order, ex, rd)
+    finally:
+        backend.rough_deformations = prev
+
+
 def test_two_d_router_in_a_captured_graph():
     """The 2-D router has no host state: captured once, a graph's replays take the tiles (a smooth field), the bricks (sigma = 9) and
     the generic kernels (a zoom of 2.4) as the coordinates in the captured buffer change, and match eager calls of the generic path."""
