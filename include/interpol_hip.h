@@ -320,8 +320,12 @@ int interpol_pull_labels(const interpol_problem *p, const void *vol, const void 
  * output instead of (K+1)^D; no grid tensor).  Contiguous (outer, n, inner) arrays.
  *   adjoint == 0 : src (outer, n_lattice, inner), lin[n_samples] -> dst (outer, n_samples, inner)
  *                  dst[b,s,c] = mask(lin[s]) * sum_j w_j sign_j src[b, wrap(i0+j), c]
- *   adjoint == 1 : src (outer, n_samples, inner) -> dst (outer, n_lattice, inner), zero-filled
- *                  here; the exact adjoint of the above (f32 / f64 only)
+ *   adjoint == 1 : src (outer, n_samples, inner) -> dst (outer, n_lattice, inner); the exact adjoint of the above (f32 / f64 only).
+ *                  Round 5: with n_samples <= 4096 and inner == 1 or inner >= 64 it is a GATHER -- for a non-decreasing `lin` the samples
+ *                  whose stencil covers a lattice point are a contiguous range (bisection), the samples that leave the lattice come back
+ *                  through the boundary condition and are visited by every output; an unsorted `lin` is detected on the device and served by
+ *                  visiting every sample: no atomics, every element of dst written once, bit-reproducible.  Otherwise dst is zero-filled
+ *                  here and the taps are added with float atomics.
  * `mode`: 0 nd, 1 iso1, 2 iso0 semantics -- decided by ALL dims of the D-dimensional
  * operator (pushpull.py:48-66), so the caller passes it.  lin is float32 (float64 for F64
  * data).  n_lattice * inner * sizeof(element) must be < 4 GiB, n_samples * inner < 2^32. */

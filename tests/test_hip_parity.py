@@ -1121,6 +1121,41 @@ def test_resample1d_passes(order):
         _hip.resample1d(y.bfloat16(), lin.float(), dim, order, 3, 1, 0, adjoint=True, n_lattice=n)
 
 
+def test_separable_push_by_gathering_passes():
+    """Round 5 (csrc/resample1d.hip: resample1d_adj_gather): the adjoint of a tensor-product resampling -- restrict, the backward of
+    resize -- as D passes that GATHER (the samples whose stencil covers a lattice point are a contiguous range of a non-decreasing
+    `lin`, found by bisection; the samples that leave the lattice come back through the boundary condition and are visited by every
+    output; no atomics: bit-reproducible) equals the ONE D-dimensional push on the separable lattice it replaces: 1 - 3 dims, orders 0 -
+    5, every bound, the three extrapolation modes, float32 / float64, lattices that are affine, overhang the image by three points,
+    repeat coordinates (runs of equal values), or are not sorted at all (served by visiting every sample)."""
+    from interpol import ops, separable
+    from interpol.sepgrid import SeparableGrid
+    g = torch.Generator().manual_seed(9)
+
+    def lattice(kind, ns, nl):
+        if kind == "affine":
+            return torch.linspace(-0.7, nl - 0.4, ns)
+        if kind == "wide":
+            return torch.linspace(-3.3, nl + 2.6, ns)
+        if kind == "runs":
+            return torch.linspace(0.2, nl - 1.1, ns).round()
+        return torch.linspace(-0.5, nl - 0.5, ns)[torch.randperm(ns, generator=g)]
+    for dt, tol in ((torch.float32, 2e-5), (torch.float64, 1e-12)):
+        for D, sshape, tshape in ((3, (70, 64, 130), (33, 40, 61)), (2, (150, 260), (64, 100)), (1, (3000,), (1100,))):
+            for kind in ("affine", "wide", "runs", "unsorted"):
+                for order in (0, 1, 3, 5):
+                    for bound in range(7):
+                        ex = (order + bound) % 3
+                        x = torch.randn([2, 3, *sshape], generator=g).to(dt).to(DEV)
+                        lin = [lattice(kind, ns, nl).to(dt).to(DEV) for ns, nl in zip(sshape, tshape)]
+                        o, b = [order] * D, [bound] * D
+                        assert separable._gathers(x, lin)
+                        got = separable._SepPush.apply(x, lin, list(tshape), o, b, ex)
+                        ref = ops.grid_push(x, SeparableGrid(lin), list(tshape), b, o, ex)
+                        assert torch.equal(got, separable._SepPush.apply(x, lin, list(tshape), o, b, ex))      # no atomics
+                        assert G.rel_err(got.cpu().numpy(), ref.cpu().numpy()) < tol, (dt, D, kind, order, bound, ex)
+
+
 # ---------------------------------------------------------------------------
 # SURVEY 8 row f4: label maps, arg-max of the interpolated indicator images in one pass
 # ---------------------------------------------------------------------------

@@ -35,6 +35,7 @@ IP_DECL2(f32) IP_DECL2(f64)
 #undef IP_DECL2
 
 int launch_filter(int dtype, const FilterParams &fp, const void *src, void *data, hipStream_t st);
+bool resample1d_adjoint_gathers(int64_t n_samples, int64_t inner);
 int64_t bricks_workspace_bytes(const KParams &p, int B, int shared);
 int launch_push_bricks(const KParams &p, int B, int shared, const void *val, const void *grid, void *vol,
                        void *workspace, int64_t workspace_bytes, hipStream_t st);
@@ -984,7 +985,7 @@ int interpol_resample_1d(int32_t dtype, int32_t lin_dtype, int32_t order, int32_
     if ((uint64_t)n_lattice * (uint64_t)inner * es > 0xffffffffull) return INTERPOL_E_SHAPE;
     if ((uint64_t)n_samples * (uint64_t)inner > 0xffffffffull) return INTERPOL_E_SHAPE;
     hipStream_t st = (hipStream_t)stream;
-    if (adjoint) {
+    if (adjoint && (!resample1d_adjoint_gathers(n_samples, inner) || outer == 0 || n_samples == 0 || inner == 0)) {
         const hipError_t e = zero_async(dst, (size_t)outer * (size_t)n_lattice * (size_t)inner * es, st);
         if (e != hipSuccess) return (int)e;
     }

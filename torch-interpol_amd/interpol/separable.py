@@ -51,15 +51,38 @@ class _SepPull(torch.autograd.Function):
         return gx, None, None, None, None
 
 
+def _gathers(x, lin):
+    """Do the adjoint passes of `x` along its last len(lin) dims all take the gathering kernel (csrc/resample1d.hip:
+    resample1d_adj_gather -- float32 / float64, at most 4096 samples per dim, lanes along an inner dim of 64 elements or more, or
+    along the lattice of the last dim)?"""
+    if not (x.is_cuda and x.dtype in (torch.float32, torch.float64)):
+        return False
+    D = len(lin)
+    for d in range(D):
+        inner = 1
+        for e in range(d + 1, D):
+            inner *= x.shape[e - D]
+        if lin[d].numel() > 4096 or not (inner == 1 or inner >= 64):
+            return False
+    return True
+
+
 class _SepPush(torch.autograd.Function):
-    """The adjoint: ONE D-dimensional push on the separable lattice (the LDS-tiled scatter reads
-    the D lattice vectors; measured faster than D scattering passes, whose last-dim pass piles
-    same-address atomics: 1.15 vs 3.0 ms for 4x2x256^3 -> 128^3).  backward = `_SepPull`."""
+    """The adjoint.  Round 5: D adjoint passes that GATHER (interpol_resample_1d, adjoint: for a non-decreasing `lin` the samples
+    whose stencil covers a lattice point are a contiguous range -- no atomics, no zero-fill, K + 1 taps per pass), first dim first:
+    the tensor shrinks before the pass whose lanes run along the lattice (4 x 2 x 256^3 -> 128^3: see profiles/r05_other_configs.json,
+    f2).  Else ONE D-dimensional push on the separable lattice (the LDS-tiled scatter reads the D lattice vectors: 0.92 ms linear /
+    2.27 cubic for that shape; D scattering passes with atomics 3.0 ms).  backward = `_SepPull`."""
 
     @staticmethod
     def forward(ctx, x, lin, shape, orders, bounds, extrapolate):
         D = len(lin)
         ctx.args = (lin, orders, bounds, extrapolate)
+        if _gathers(x, lin) and all(int(x.shape[d - D]) == lin[d].numel() for d in range(D)):
+            mode, out = _mode(orders), x
+            for d in range(D):
+                out = ops.resample1d(out, lin[d], d - D, orders[d], bounds[d], extrapolate, mode, adjoint=True, n_lattice=int(shape[d]))
+            return out
         lead = x.shape[:-D]
         xf = x.reshape(-1, 1, *x.shape[-D:]) if len(lead) != 2 else x
         out = ops.grid_push(xf, SeparableGrid(lin), list(shape), bounds, orders, extrapolate)
