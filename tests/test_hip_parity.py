@@ -1121,6 +1121,43 @@ def test_resample1d_passes(order):
         _hip.resample1d(y.bfloat16(), lin.float(), dim, order, 3, 1, 0, adjoint=True, n_lattice=n)
 
 
+def test_trilinear_pull_router():
+    """Round 5: the float32 trilinear grid_pull has a router of its own (csrc/push_owner.hip: lin_probe -> the class-sorted LDS tiles
+    with K = 1 for rough fields, the generic kernel for smooth ones; the verdict is a word of a 256-byte workspace).  Forced tiles,
+    the routed default and the generic kernel against the oracle: every bound (mixed per dim), the three extrapolation modes, sample
+    grids that overhang the image, dense grids and displacement fields, smooth and rough."""
+    from interpol import _hip
+    g = torch.Generator().manual_seed(12)
+    oracle.set_threads(8)
+    try:
+        for shape, oshape in (((40, 33, 50), (37, 45, 29)), ((30, 40, 36), (48, 40, 52))):
+            for bound in range(7):
+                ex = bound % 3
+                for sigma in (0.05, 5.0):
+                    img = torch.randn([2, 3, *shape], generator=g)
+                    lin = [torch.linspace(-2, n + 1, m) for n, m in zip(shape, oshape)]
+                    grid = torch.stack(torch.meshgrid(*lin, indexing="ij"), -1)[None] + sigma * torch.randn([2, *oshape, 3], generator=g)
+                    b = [bound, (bound + 3) % 7, (bound + 5) % 7]
+                    want = oracle.grid_pull(img.double().numpy(), grid.double().numpy(), b, [1], ex)
+                    # (a float32 coordinate EQUAL to a float32 extrapolation threshold is masked by the float32 reference, not by the float64 oracle)
+                    want[np.broadcast_to(G.f32_masked_samples(grid.numpy(), shape, ex)[:, None], want.shape)] = 0.0
+                    for name, fl in (("routed", 0), ("tiles", _hip.FLAG_BINNED_SCATTER), ("generic", _hip.FLAG_NO_FASTPATH)):
+                        got = _hip.gather("pull", img.to(DEV), grid.to(DEV), b, [1] * 3, ex, flags=fl)
+                        G.assert_close(got.cpu().numpy(), want, rtol=1e-5, atol_rel=1e-5, what=("trilinear pull", name, shape, b, ex, sigma))
+        # displacement fields, and the same inputs always take the same organisation
+        n = 64
+        img = torch.randn([2, 2, n, n, n], generator=g).to(DEV)
+        ident = interpol.identity_grid([n, n, n])[None]
+        for sigma in (0.05, 3.0):
+            disp = (sigma * torch.randn([2, n, n, n, 3], generator=g)).to(DEV)
+            dense = (ident.to(DEV) + disp).contiguous()
+            a = _hip.gather("pull", img, disp, [3] * 3, [1] * 3, 1, flags=_hip.FLAG_DISPLACEMENT)
+            assert torch.equal(a, _hip.gather("pull", img, disp, [3] * 3, [1] * 3, 1, flags=_hip.FLAG_DISPLACEMENT))
+            assert G.rel_err(a.cpu().numpy(), _hip.gather("pull", img, dense, [3] * 3, [1] * 3, 1, flags=_hip.FLAG_NO_FASTPATH).cpu().numpy()) < 2e-6
+    finally:
+        oracle.set_threads(1)
+
+
 def test_separable_push_by_gathering_passes():
     """Round 5 (csrc/resample1d.hip: resample1d_adj_gather): the adjoint of a tensor-product resampling -- restrict, the backward of
     resize -- as D passes that GATHER (the samples whose stencil covers a lattice point are a contiguous range of a non-decreasing

@@ -63,6 +63,7 @@ int owner_pull_prepare(const interpol_problem *, const KParams &, void *, int64_
 int owner_pull_finish(const interpol_problem *, const KParams &, const void *, const void *, void *, void *, int64_t, bool, hipStream_t,
                       bool grad = false, const void *gout = nullptr, bool probed = false, bool spatial = false);
 int owner_grad_probe(const interpol_problem *, const KParams &, const void *, void *, int64_t, hipStream_t, int mode = -1);
+int linear_pull_probe(const interpol_problem *, const KParams &, const void *, void *, hipStream_t, const int **);
 int64_t gather5_workspace_bytes(const interpol_problem *, const KParams &);
 int try_gather5(const interpol_problem *, const KParams &, const void *, const void *, void *, void *, int64_t, int, const void *, hipStream_t, const int **);
 int64_t scatter5_workspace_bytes(const interpol_problem *, const KParams &);
@@ -335,12 +336,23 @@ int interpol_pull(const interpol_problem *p, const void *vol, const void *grid, 
 /* grid_pull with a workspace: the deformation-independent organisation (bricks of the image, push_owner.hip: own_gather) for
  * fields too rough for the sample tiles, chosen by a probe of the call (INTERPOL_FLAG_AUTO_SCATTER) or always
  * (INTERPOL_FLAG_BINNED_SCATTER); without a (large enough, 256-byte aligned) workspace: interpol_pull. */
+// the trilinear pull with a router (push_owner.hip: lin_probe): float32, dense grids and displacement fields, tiles' sizes
+static bool linear_routed(const interpol_problem *p, const KParams &k)
+{
+    if (p->dim != 3 || p->dtype != INTERPOL_F32 || p->grid_dtype != INTERPOL_F32 || (k.sep != 0 && k.sep != 2)) return false;
+    if (!(p->flags & (INTERPOL_FLAG_AUTO_SCATTER | INTERPOL_FLAG_BINNED_SCATTER)) || (k.dbg & 32)) return false;
+    int64_t n = 1;
+    for (int d = 0; d < 3; ++d) { if (k.order[d] != 1 || p->grid_shape[d] > 0x7fffffff / 4) return false; n *= p->grid_shape[d]; }
+    return n >= 32768 && p->batch <= 65535 && (uint64_t)n * 12ull <= 0xffffffffull;
+}
+
 int64_t interpol_pull_workspace(const interpol_problem *p)
 {
     KParams k; int B;
     if (make_params(p, GATHER, 1, &k, &B, false)) return 0;          // (the layout of `val` -- pull, grad, a gradient -- plays no part)
     if (p->flags & INTERPOL_FLAG_NO_FASTPATH) return 0;
     if (p->dim == 2) return gather2d_workspace_bytes(p, k);         // 2-D (scatter2d.hip: gather2d)
+    if (linear_routed(p, k)) return 256;                             // trilinear: the verdict of the call's probe, nothing else
     const int64_t b5 = gather5_workspace_bytes(p, k);               // orders 4 and 5 (gather5.hip)
     return b5 ? b5 : owner_pull_workspace_bytes(p, k);
 }
@@ -351,6 +363,23 @@ static int routed_pull(const interpol_problem *p, KParams k, int B, const void *
 {
     int *flags = nullptr;
     int nzero = 0;
+    if (linear_routed(p, k) && workspace && workspace_bytes >= 256 && ((uintptr_t)workspace & 255u) == 0) {
+        // trilinear (round 5): the class-sorted tiles for rough fields, the generic kernel for smooth ones, chosen by a probe of the call
+        KParams kt = k;
+        if (!(p->flags & INTERPOL_FLAG_BINNED_SCATTER)) {
+            const int *gate = nullptr;
+            int rl = linear_pull_probe(p, k, grid, workspace, st, &gate);
+            if (rl) return rl;
+            kt.verdict = gate; kt.gate_n = -3;                       // the tiles run on verdict 1 ...
+            k.gate = gate; k.gate_n = -1;                            // ... the generic kernel unless the verdict is 1
+        }
+        int rl = try_sorted_pull_f32(p, kt, vol, grid, val, st);
+        if (rl != 0 && rl != 1) return rl;
+        if (rl == 1 && (p->flags & INTERPOL_FLAG_BINNED_SCATTER)) return 1;
+        if (rl == 0) { k.gate = nullptr; k.gate_n = 0; }             // (the tiles declined: the generic kernel, unconditionally)
+        rl = launch_pull_f32(k, vol, grid, val, B, st);
+        return rl ? rl : 1;
+    }
     if (p->dim == 2) {
         // 2-D (scatter2d.hip: gather2d): the bricks always, or behind a probe of the call next to the lean tiles, which read the verdict
         const int *gate = nullptr;

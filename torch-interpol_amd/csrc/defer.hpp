@@ -56,7 +56,7 @@ struct Defer {
         // No hand-back behind a device-side router (k.gate: the probe-routed scatters, interpol_pull_ws, interpol_grad_ws, the routed
         // backward passes): what the tiles cannot hold goes to the bricks, decided from the coordinates of the call alone -- the
         // operator is a function of its inputs whatever the stream did before (round 5).  dbg 256: A/B switch, no hand-back.
-        lease = ((k.dbg & 256) || k.gate) ? DeferLease{ { nullptr, nullptr, nullptr, 0u }, -1, -1 } : defer_acquire(st, ntiles * batch, batch, ntx, nty, ntz);
+        lease = ((k.dbg & 256) || k.gate || k.verdict) ? DeferLease{ { nullptr, nullptr, nullptr, 0u }, -1, -1 } : defer_acquire(st, ntiles * batch, batch, ntx, nty, ntz);
         args = lease.args;
         desc = args.desc;
         tl.desc = desc; tl.gen = args.gen; tl.cur = args.cur; tl.nwork = (int)(ntiles * batch); tl.e[0] = ex; tl.e[1] = ey; tl.e[2] = ez;

@@ -11,10 +11,13 @@ namespace ip {
 inline dim3 sample_grid(const KParams &p, int B)
 {
     const int64_t bx = (p.N + 255) / 256;
-    // (gate_n == -2: one of several organisations enqueued behind the 2-D router's verdict, usually not the one that runs -- eight batch
-    //  items' worth of blocks, which stride over the batch, keep the launch that returns at once cheap: 131 072 empty workgroups cost 32 us;
-    //  two items' worth cost the kernel 15 % when it does run)
-    const int by = p.gate_n == -2 && B > 8 ? 8 : B;
+    // gate_n == -1 / -2: one of several organisations enqueued behind a router's verdict, usually not the one that runs: a few batch
+    // items' worth of blocks, which stride over the batch -- 131 072 workgroups that return at once cost 32 us, 262 144 (config 2's
+    // trilinear pull) 60.  (Striding over the samples as well was tried: the loop-variant sample index costs the generic kernels
+    // 35 - 50 % on rough fields.)
+    const bool gated = p.gate && (p.gate_n == -1 || p.gate_n == -2);
+    int by = B;
+    if (gated) { by = (int)(32768 / (bx > 0 ? bx : 1)); by = by < 1 ? 1 : (by > B ? B : by); }
     return dim3((unsigned)bx, (unsigned)(by < 65535 ? by : 65535), 1);
 }
 

@@ -1,6 +1,7 @@
 // ===========================================================================
 // ops_sorted.hip -- LDS tiles with CLASS-SORTED lanes: 3-D, one spline order 2..3 for all
-// dims, f32 / bf16 / f16 storage (fp32 math), any boundary / extrapolation mode.
+// dims (the pull: 1..3 -- round 5, trilinear under rough fields, behind the router of abi.hip: routed_pull / push_owner.hip: lin_probe),
+// f32 / bf16 / f16 storage (fp32 math), any boundary / extrapolation mode.
 //   pull  (gather)   : reference interpol/nd.py:80-143
 //   push, count      : reference interpol/nd.py:146-213, pushpull.py:106-142   (see push section)
 //
@@ -92,6 +93,13 @@ __device__ __forceinline__ void stencil_reads(unsigned addr, f2 (&v)[16])
                  : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]), "=&v"(v[4]), "=&v"(v[5]), "=&v"(v[6]), "=&v"(v[7]),
                    "=&v"(v[8]), "=&v"(v[9]), "=&v"(v[10]), "=&v"(v[11]), "=&v"(v[12]), "=&v"(v[13]), "=&v"(v[14]), "=&v"(v[15])
                  : "v"(addr) : "memory");
+}
+// K == 1: the 2 x 2 slots of one x-plane of a trilinear stencil
+__device__ __forceinline__ void stencil_reads_k1(unsigned addr, f2 (&v)[4])
+{
+    asm volatile("ds_read_b64 %0, %4\n\tds_read_b64 %1, %4 offset:8\n\tds_read_b64 %2, %4 offset:288\n\tds_read_b64 %3, %4 offset:296\n\t"
+                 "s_waitcnt lgkmcnt(0)"
+                 : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]) : "v"(addr) : "memory");
 }
 #undef IP_RD
 
@@ -317,7 +325,8 @@ __global__ __launch_bounds__(NT, 4) void pull_sorted(KParams p, const T *__restr
     for (int d = 0; d < 3; ++d) { L.bound[d] = p.bound[d]; L.n[d] = p.vol_n[d]; L.ss[d] = p.vol_ss[d] / (int)sizeof(T); L.k[d] = K; }
     L.lin = 0;
 #ifndef IP_NOVERDICT
-    if (p.verdict && *p.verdict == 1) return;                        // the probe of the call gave every tile to the bricks (abi.hip: routed_pull)
+    // the probe of the call gave every tile to the bricks (abi.hip: routed_pull); gate_n == -3 (trilinear): the tiles run on verdict 1 alone
+    if (p.verdict && (p.gate_n == -3 ? *p.verdict != 1 : *p.verdict == 1)) return;
 #endif
     if (p.gate && p.gate_n > 0) {
         // interpol_pull_ws: the header, brick counters and brick list of the bricks' workspace lie in front of the tile flags; the
@@ -483,6 +492,19 @@ __global__ __launch_bounds__(NT, 4) void pull_sorted(KParams p, const T *__restr
                     const int x0 = key & 31;
                     const int i = (ps - x0) & 3;                     // the x-tap of this pass
                     const int xq = (x0 + (K == 3 || i <= K ? i : 0)) >> 2;
+                    if (K == 1) {
+                        // trilinear: two of the four passes hold an x-tap of the sample, four slots each
+                        if (i <= 1) {
+                            f2 t4[4];
+                            stencil_reads_k1(boxaddr + 8u * (unsigned)(xq * PLANE + ((key >> 5) & 2047)), t4);
+                            const float wxi = i == 0 ? 1.f - tx : tx;
+                            const f2 w0 = 1.f - tyz, w1 = tyz;
+                            const f2 q0 = f2{ w0.y, w0.y } * t4[0] + f2{ w1.y, w1.y } * t4[1], q1 = f2{ w0.y, w0.y } * t4[2] + f2{ w1.y, w1.y } * t4[3];
+                            acc[j] = f2{ wxi, wxi } * (f2{ w0.x, w0.x } * q0 + f2{ w1.x, w1.x } * q1) + acc[j];
+                        }
+                        asm volatile("" : "+v"(acc[j]));
+                        continue;
+                    }
                     f2 t2[16];
                     stencil_reads(boxaddr + 8u * (unsigned)(xq * PLANE + ((key >> 5) & 2047)), t2);
                     const float wxi = weight_x<K>(tx, i);
@@ -1281,7 +1303,7 @@ static int launch_push(const interpol_problem *p, const KParams &k, const void *
 } // namespace sorted
 
 // Eligibility: 3-D, one order 2..3 for all dims, enough samples, 32-bit offsets into one item's grid.
-static int sorted_order(const interpol_problem *p, const KParams &k)
+static int sorted_order(const interpol_problem *p, const KParams &k, bool linear = false)
 {
     if (p->dim != 3 || p->batch > 65535) return -1;
     if (k.dbg & 32) return -1;                                     // A/B switch: the natural-order tiles of ops_tiled.hip
@@ -1294,7 +1316,7 @@ static int sorted_order(const interpol_problem *p, const KParams &k)
     if (n < 4096 || nt > 0x7fffffff) return -1;
     if ((uint64_t)n * 12ull > 0xffffffffull) return -1;
     if (k.order[0] != k.order[1] || k.order[0] != k.order[2]) return -1;
-    if (k.order[0] < 2 || k.order[0] > 3) return -1;
+    if (k.order[0] < (linear ? 1 : 2) || k.order[0] > 3) return -1;
     return k.order[0];
 }
 
@@ -1309,8 +1331,17 @@ int IP_SYM(try_window_pull_, IP_TSFX)(const interpol_problem *p, const KParams &
 // returns 1 when it took the problem, 0 to decline, anything else: error
 int IP_SYM(try_sorted_pull_, IP_TSFX)(const interpol_problem *p, const KParams &k, const void *vol, const void *grid, void *val, hipStream_t st)
 {
-    const int K = sorted_order(p, k);
+    const int K = sorted_order(p, k, true);
     if (K < 0) return 0;
+    if (K == 1) {                                                    // trilinear (round 5): dense grids and displacement fields
+        using T1 = IP_TT;
+        if (k.sep == 0) return sorted::launch_pull<T1, 1, 0>(p, k, vol, grid, val, st);
+        if constexpr (std::is_same<T1, float>::value) {
+            return k.sep == 1 ? sorted::launch_pull<T1, 1, 1>(p, k, vol, grid, val, st)
+                 : (k.sep == 2 ? sorted::launch_pull<T1, 1, 2>(p, k, vol, grid, val, st) : sorted::launch_pull<T1, 1, 3>(p, k, vol, grid, val, st));
+        }
+        return 0;
+    }
 #ifdef IP_EXPERIMENTS
     if (k.dbg & 4096) {                                            // opt-in: the windowed gather (experimental: 1.75 ms against 1.35 ms at config 2)
         const int rc = IP_SYM(try_window_pull_, IP_TSFX)(p, k, K, vol, grid, val, st);

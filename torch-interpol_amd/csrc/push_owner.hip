@@ -1818,6 +1818,75 @@ int owner_grad_probe(const interpol_problem *p, const KParams &k, const void *gr
     const hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : (int)e;
 }
+// ---------------------------------------------------------------------------
+// The router of the TRILINEAR pull (round 5).  Eight taps leave an LDS box nothing to amortise on a smooth field -- the generic kernel
+// gathers at the HBM roofline there (4 x 2 x 256^3: 0.56 ms; the class-sorted tiles 0.78) -- but under roughness its gathers miss the
+// caches: i.i.d. noise of sigma = 1 / 2 / 4 voxels 1.27 / 2.49 / 4.5 ms against 0.89 / 1.02 / 1.7 for the tiles.  lin_probe looks at up to
+// 512 sample tiles: mean absolute second difference of the coordinates along the last dim, summed over the dims (tile_common.hpp:
+// tile_smooth's measure), above one voxel -> word 0 of the 256-byte workspace = 1, the tiles; else 0, the generic kernel.  Both are
+// enqueued behind it; one relaxed 64-bit add per workgroup carries sum, count and ticket (no fence).
+// ---------------------------------------------------------------------------
+namespace owner {
+template <int GM>
+__global__ __launch_bounds__(256) void lin_probe(KParams p, const float *__restrict__ grid, int *__restrict__ hdr, int gx, int gy, int gz, int nty, int ntz,
+                                                 int ntiles, long long total, int stride)
+{
+    __shared__ int acc[2];
+    const int tid = threadIdx.x;
+    if (tid < 2) acc[tid] = 0;
+    __syncthreads();
+    const long long work = (long long)blockIdx.x * stride;
+    const long long wk = work < total ? work : total - 1;
+    const int64_t b = wk / ntiles;
+    const TileGeom g = tile_geom((int)(wk % ntiles), gx, gy, gz, nty, ntz);
+    float s = 0.f; int n = 0;
+    for (int id = tid; id < TS * TS * TS; id += 512) {               // a sample of the tile is plenty
+        int ox, oy, oz;
+        sample_pos(g, id, ox, oy, oz);
+        if (ox >= gx || oy >= gy || oz + 2 >= gz || (id & 15) + 2 >= TS) continue;
+        float q0[3], q1[3], q2[3];
+        load_xyz<GM>(p, grid, b, g, ox, oy, oz, q0);
+        load_xyz<GM>(p, grid, b, g, ox, oy, oz + 1, q1);
+        load_xyz<GM>(p, grid, b, g, ox, oy, oz + 2, q2);
+        for (int d = 0; d < 3; ++d) s += __builtin_fabsf(q0[d] - 2.f * q1[d] + q2[d]);
+        ++n;
+    }
+    s = s < 1e4f ? s : 1e4f;                                         // (also catches NaN)
+    if (n) { atomicAdd(&acc[0], (int)(s * 16.f)); atomicAdd(&acc[1], n); }
+    __syncthreads();
+    if (tid == 0) {
+        // sum (bits 34..63: <= 512 tiles x 2^20), count (12..33), ticket (0..11)
+        const unsigned long long a0 = (unsigned long long)(acc[0] < (1 << 20) ? acc[0] : (1 << 20)), a1 = (unsigned long long)acc[1];
+        const unsigned long long add = work < total ? (a0 << 34) | (a1 << 12) | 1ull : 1ull;
+        const unsigned long long tot = __hip_atomic_fetch_add(reinterpret_cast<unsigned long long *>(hdr + 2), add, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + add;
+        if ((tot & 0xfffull) == (unsigned long long)gridDim.x) {
+            const unsigned long long sum16 = tot >> 34, cnt = (tot >> 12) & 0x3fffffull;
+            __hip_atomic_store(&hdr[0], (cnt > 0 && sum16 > cnt * 16ull) ? 1 : 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+
+} // namespace owner
+
+// 0 = enqueued (*gate_out: the verdict word), else an error
+int linear_pull_probe(const interpol_problem *p, const KParams &k, const void *grid, void *workspace, hipStream_t st, const int **gate_out)
+{
+    using namespace owner;
+    int *hdr = (int *)workspace;
+    hipLaunchKernelGGL(own_zero, dim3(1), dim3(64), 0, st, hdr, 8);
+    const int gx = (int)p->grid_shape[0], gy = (int)p->grid_shape[1], gz = (int)p->grid_shape[2];
+    const int ntx = (gx + TS - 1) / TS, nty = (gy + TS - 1) / TS, ntz = (gz + TS - 1) / TS, ntiles = ntx * nty * ntz;
+    const long long total = (long long)ntiles * p->batch;
+    int stride = (int)((total + 511) / 512);
+    stride = stride < 1 ? 1 : (stride | 1);                          // (odd: the probed tiles do not line up along an axis)
+    const unsigned nb = (unsigned)((total + stride - 1) / stride);
+    if (k.sep == 0) hipLaunchKernelGGL((lin_probe<0>), dim3(nb), dim3(256), 0, st, k, (const float *)grid, hdr, gx, gy, gz, nty, ntz, ntiles, total, stride);
+    else hipLaunchKernelGGL((lin_probe<2>), dim3(nb), dim3(256), 0, st, k, (const float *)grid, hdr, gx, gy, gz, nty, ntz, ntiles, total, stride);
+    *gate_out = hdr;
+    const hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : (int)e;
+}
+
 // Step 2 (behind the sample tiles, or alone: all == true, INTERPOL_FLAG_BINNED_SCATTER): the flagged tiles' samples sorted by the
 // brick of the image they read (own_bin, index mode; unbinned samples are gathered on the spot), then the bricks (own_gather).
 // grad == true: the grid gradient of the pull (val := the dense grid gradient, gout := grad_out or NULL for ones).

@@ -160,6 +160,9 @@ __device__ __forceinline__ void weights_yz(f2 t, f2 *w)
         w[3] = (u2 * u) * (1.f / 6.f);
         w[1] = u2 * (u * 0.5f - 1.f) + 2.f / 3.f;
         w[2] = v2 * (v * 0.5f - 1.f) + 2.f / 3.f;
+    } else if (K == 1) {
+        // t in [0, 1): taps at distances t, 1 - t (iso1.py:19-20)
+        w[0] = 1.f - t; w[1] = t; w[2] = f2{ 0.f, 0.f }; w[3] = f2{ 0.f, 0.f };
     } else {
         // K == 2, t in [0.5, 1.5): taps at distances t, |t - 1|, 2 - t
         const f2 a = 1.5f - t, c = t - 0.5f, m = t - 1.f;
@@ -178,6 +181,8 @@ __device__ __forceinline__ float weight_x(float t, int i)
         const float e = 2.f - d;
         const float near = __builtin_fmaf(d * d, __builtin_fmaf(d, 0.5f, -1.f), 2.f / 3.f), far = (e * e * e) * (1.f / 6.f);
         return d < 1.f ? near : far;
+    } else if (K == 1) {
+        return i == 0 ? 1.f - t : (i == 1 ? t : 0.f);
     } else {
         const float e = 1.5f - d;
         const float near = 0.75f - d * d, far = 0.5f * (e * e);
