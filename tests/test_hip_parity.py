@@ -1144,6 +1144,14 @@ def test_trilinear_pull_router():
                     for name, fl in (("routed", 0), ("tiles", _hip.FLAG_BINNED_SCATTER), ("generic", _hip.FLAG_NO_FASTPATH)):
                         got = _hip.gather("pull", img.to(DEV), grid.to(DEV), b, [1] * 3, ex, flags=fl)
                         G.assert_close(got.cpu().numpy(), want, rtol=1e-5, atol_rel=1e-5, what=("trilinear pull", name, shape, b, ex, sigma))
+                    # the grid gradient of the backward (all-linear stencils: the reference's iso1 gradients -1, +1) has the same router
+                    if bound in (1, 3, 6):
+                        gout = torch.randn([2, 3, *oshape], generator=g)
+                        want_g = oracle.grid_pull_backward(gout.double().numpy(), img.double().numpy(), grid.double().numpy(), b, [1], ex)[1]
+                        want_g[G.f32_masked_samples(grid.numpy(), shape, ex)] = 0.0
+                        for name, fl in (("routed", 0), ("tiles", _hip.FLAG_BINNED_SCATTER)):
+                            gg = _hip.pull_backward(gout.to(DEV), img.to(DEV), grid.to(DEV), b, [1] * 3, ex, False, True, flags=fl)[1]
+                            G.assert_close(gg.cpu().numpy(), want_g, rtol=1e-5, atol_rel=1e-5, what=("trilinear grid gradient", name, shape, b, ex, sigma))
         # displacement fields, and the same inputs always take the same organisation
         n = 64
         img = torch.randn([2, 2, n, n, n], generator=g).to(DEV)

@@ -35,6 +35,17 @@ for shape, oshape in (((40, 33, 50), (37, 45, 29)), ((64, 64, 64), (64, 64, 64))
                 for fl in (_hip.FLAG_FORCE_TILED, 0, _hip.FLAG_BINNED_SCATTER):
                     a = _hip.gather("pull", img, grid, b, [1] * 3, ex, flags=fl)
                     e = max(e, float((a - r).abs().max() / r.abs().max()))
+                gout = torch.randn(2, 3, *oshape, generator=g, device=dev)
+                rg = _hip.pull_backward(gout, img, grid, b, [1] * 3, ex, False, True, flags=_hip.FLAG_NO_FASTPATH)[1]
+                rp = _hip.push_backward(img, gout, grid, b, [1] * 3, ex, True, True, flags=_hip.FLAG_NO_FASTPATH)
+                for fl in (_hip.FLAG_FORCE_TILED, 0, _hip.FLAG_BINNED_SCATTER):
+                    ag = _hip.pull_backward(gout, img, grid, b, [1] * 3, ex, False, True, flags=fl)[1]
+                    e = max(e, float((ag - rg).abs().max() / rg.abs().max()) / 4)
+                    if fl != _hip.FLAG_FORCE_TILED:
+                        ab = _hip.pull_backward(gout, img, grid, b, [1] * 3, ex, True, True, flags=fl)
+                        e = max(e, float((ab[1] - rg).abs().max() / rg.abs().max()) / 4)
+                        ap = _hip.push_backward(img, gout, grid, b, [1] * 3, ex, True, True, flags=fl)
+                        e = max(e, float((ap[0] - rp[0]).abs().max() / rp[0].abs().max()), float((ap[1] - rp[1]).abs().max() / rp[1].abs().max()) / 4)
                 if not e < 2e-6:
                     bad += 1; print("BAD", shape, bound, ex, sigma, e, flush=True)
 print("parity: bad =", bad, flush=True)

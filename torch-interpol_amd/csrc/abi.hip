@@ -63,7 +63,7 @@ int owner_pull_prepare(const interpol_problem *, const KParams &, void *, int64_
 int owner_pull_finish(const interpol_problem *, const KParams &, const void *, const void *, void *, void *, int64_t, bool, hipStream_t,
                       bool grad = false, const void *gout = nullptr, bool probed = false, bool spatial = false);
 int owner_grad_probe(const interpol_problem *, const KParams &, const void *, void *, int64_t, hipStream_t, int mode = -1);
-int linear_pull_probe(const interpol_problem *, const KParams &, const void *, void *, hipStream_t, const int **);
+int linear_pull_probe(const interpol_problem *, const KParams &, const void *, void *, hipStream_t, const int **, int);
 int64_t gather5_workspace_bytes(const interpol_problem *, const KParams &);
 int try_gather5(const interpol_problem *, const KParams &, const void *, const void *, void *, void *, int64_t, int, const void *, hipStream_t, const int **);
 int64_t scatter5_workspace_bytes(const interpol_problem *, const KParams &);
@@ -368,7 +368,7 @@ static int routed_pull(const interpol_problem *p, KParams k, int B, const void *
         KParams kt = k;
         if (!(p->flags & INTERPOL_FLAG_BINNED_SCATTER)) {
             const int *gate = nullptr;
-            int rl = linear_pull_probe(p, k, grid, workspace, st, &gate);
+            int rl = linear_pull_probe(p, k, grid, workspace, st, &gate, 16);
             if (rl) return rl;
             kt.verdict = gate; kt.gate_n = -3;                       // the tiles run on verdict 1 ...
             k.gate = gate; k.gate_n = -1;                            // ... the generic kernel unless the verdict is 1
@@ -720,6 +720,24 @@ static int routed_gradc(const interpol_problem *p, const KParams &k, const void 
 {
     int *flags = nullptr;
     int nzero = 0;
+    if (linear_routed(p, k) && k.mode == MODE_ISO1 && scratch && scratch_bytes >= 256 && ((uintptr_t)scratch & 255u) == 0) {
+        // trilinear (round 5): the class-sorted tiles for rough fields, the generic fused kernel for smooth ones (push_owner.hip: lin_probe)
+        KParams kt = k, kg = k;
+        if (!(p->flags & INTERPOL_FLAG_BINNED_SCATTER)) {
+            const int *gate = nullptr;
+            const int rl = linear_pull_probe(p, k, grid, scratch, st, &gate, 64);
+            if (rl) return rl;
+            kt.verdict = gate; kt.gate_n = -3;
+            kg.gate = gate; kg.gate_n = -1;
+        }
+        int rl = try_sorted_gradc_f32(p, kt, gout, vol, grid, ggrid, st);
+        if (rl != 0 && rl != 1) return rl;
+        if (rl == 1 && (p->flags & INTERPOL_FLAG_BINNED_SCATTER)) return 1;
+        if (rl == 0) { kg.gate = nullptr; kg.gate_n = 0; }
+        const int B = (int)p->batch;
+        rl = gout ? launch_pullbwd_f32(kg, gout, vol, grid, nullptr, ggrid, B, 0, 0, st) : launch_pushbwd_f32(kg, vol, nullptr, grid, nullptr, ggrid, B, st);
+        return rl ? rl : 1;
+    }
     if (p->dim == 2) {
         // 2-D (scatter2d.hip: gather2d, mode 1): the bricks always, or behind a probe of the call next to the lean tiles (gradc2d)
         const int *gate = nullptr;

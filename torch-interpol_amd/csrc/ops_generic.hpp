@@ -349,6 +349,7 @@ __global__ __launch_bounds__(BLOCK) void pullbwd_generic(KParams p, const T *__r
                                                          const G *__restrict__ grid, AccT *__restrict__ gvol,
                                                          G *__restrict__ ggrid, int B, int64_t gvol_sb, int64_t gvol_sc, TileList tl)
 {
+    if (p.gate_n == -1 && p.gate && *p.gate == 1) return;   // a probe of the call gave it to another organisation (abi.hip: routed_gradc, trilinear)
     if (p.gate_n == -2 && p.gate && *p.gate != 2) return;   // 2-D router (scatter2d.hip: probe2d): the organisation of expanding fields only
     // gvol has vol's spatial layout (host guarantees both spatially contiguous) but AccT elements
     constexpr unsigned ACC_SCALE = sizeof(AccT) / sizeof(T);
@@ -413,6 +414,7 @@ __global__ __launch_bounds__(BLOCK) void pushbwd_generic(KParams p, const T *__r
                                                          const G *__restrict__ grid, T *__restrict__ gval,
                                                          G *__restrict__ ggrid, int B, TileList tl)
 {
+    if (p.gate_n == -1 && p.gate && *p.gate == 1) return;   // a probe of the call gave it to another organisation (abi.hip: routed_gradc, trilinear)
     if (p.gate_n == -2 && p.gate && *p.gate != 2) return;   // 2-D router (scatter2d.hip: probe2d): the organisation of expanding fields only
     IP_FOR_SAMPLES {
         const int64_t b = it_.b, o = it_.o;

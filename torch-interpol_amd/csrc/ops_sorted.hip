@@ -611,10 +611,11 @@ __global__ __launch_bounds__(NT, 4) void gradc_sorted(KParams p, const T *__rest
     Lattice L;
 #pragma unroll
     for (int d = 0; d < 3; ++d) { L.bound[d] = p.bound[d]; L.n[d] = p.vol_n[d]; L.ss[d] = p.vol_ss[d] / (int)sizeof(T); L.k[d] = K; }
-    L.lin = 0;
+    L.lin = K == 1;                                                  // (all-linear: the reference's iso1 gradients -1, +1 in the out-of-box paths as well)
     // interpol_pull_backward with a bricks workspace: the probe's verdict lies -gate_n ints in front of the tile flags; 1 = every
     // tile goes to the bricks of the image (push_owner.hip: own_probe, nch < 0)
     if (p.gate && p.gate_n < 0 && p.gate[p.gate_n] == 1) return;
+    if (!p.gate && p.verdict && p.gate_n == -3 && *p.verdict != 1) return;      // trilinear (abi.hip: routed_gradc): the tiles run on verdict 1 alone
     const WorkRange wr(ntiles * nbatch);
     if (p.gate)
         for (int w_ = wr.first + (int)threadIdx.x * wr.step; w_ < wr.end; w_ += NT * wr.step) const_cast<int *>(p.gate)[w_] = 0;
@@ -776,6 +777,25 @@ __global__ __launch_bounds__(NT, 4) void gradc_sorted(KParams p, const T *__rest
                     const int x0 = key & 31;
                     const int i = (ps - x0) & 3;                     // the x-tap of this pass
                     const int xq = (x0 + (K == 3 || i <= K ? i : 0)) >> 2;
+                    if (K == 1) {
+                        // trilinear: two of the four passes hold an x-tap of the sample, four slots each
+                        if (i <= 1) {
+                            f2 t4[4];
+                            stencil_reads_k1(boxaddr + 8u * (unsigned)(xq * PLANE + ((key >> 5) & 2047)), t4);
+                            float sg4[4];
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) sg4[k] = __builtin_fmaf(go[j].y, t4[k].y, go[j].x * t4[k].x);
+                            const float wxi = i == 0 ? 1.f - tx : tx, gxi = i == 0 ? -1.f : 1.f;
+                            const f2 w0 = 1.f - tyz, w1 = tyz;       // (.x: y, .y: z)
+                            const float q0 = __builtin_fmaf(w1.y, sg4[1], w0.y * sg4[0]), q1 = __builtin_fmaf(w1.y, sg4[3], w0.y * sg4[2]);
+                            const float z0 = sg4[1] - sg4[0], z1 = sg4[3] - sg4[2];
+                            ag[j][0] = __builtin_fmaf(gxi, __builtin_fmaf(w1.x, q1, w0.x * q0), ag[j][0]);
+                            ag[j][1] = __builtin_fmaf(wxi, q1 - q0, ag[j][1]);
+                            ag[j][2] = __builtin_fmaf(wxi, __builtin_fmaf(w1.x, z1, w0.x * z0), ag[j][2]);
+                        }
+                        asm volatile("" : "+v"(ag[j][0]), "+v"(ag[j][1]), "+v"(ag[j][2]));
+                        continue;
+                    }
                     f2 t2[16];
                     stencil_reads(boxaddr + 8u * (unsigned)(xq * PLANE + ((key >> 5) & 2047)), t2);
                     const float wxi = weight_x<K>(tx, i), gxi = wgrad_x<K>(tx, i);
@@ -1367,9 +1387,15 @@ int IP_SYM(try_sorted_pull_, IP_TSFX)(const interpol_problem *p, const KParams &
 // displacement fields; 1 when it took the problem, 0 to decline
 int IP_SYM(try_sorted_gradc_, IP_TSFX)(const interpol_problem *p, const KParams &k, const void *gout, const void *vol, const void *grid, void *ggrid, hipStream_t st)
 {
-    const int K = sorted_order(p, k);
+    const int K = sorted_order(p, k, true);
     if (K < 0 || (k.dbg & 16)) return 0;
     using T = IP_TT;
+    if (K == 1) {                                                    // trilinear (round 5; mode iso1: every dim linear)
+        if (k.mode != MODE_ISO1) return 0;
+        if (k.sep == 0) return sorted::launch_gradc<T, 1, 0>(p, k, gout, vol, grid, ggrid, st);
+        if constexpr (std::is_same<T, float>::value) { if (k.sep == 2) return sorted::launch_gradc<T, 1, 2>(p, k, gout, vol, grid, ggrid, st); }
+        return 0;
+    }
     if (k.sep == 2) {
         if constexpr (std::is_same<T, float>::value) {
             if (K == 3) return sorted::launch_gradc<T, 3, 2>(p, k, gout, vol, grid, ggrid, st);

@@ -1823,13 +1823,14 @@ int owner_grad_probe(const interpol_problem *p, const KParams &k, const void *gr
 // gathers at the HBM roofline there (4 x 2 x 256^3: 0.56 ms; the class-sorted tiles 0.78) -- but under roughness its gathers miss the
 // caches: i.i.d. noise of sigma = 1 / 2 / 4 voxels 1.27 / 2.49 / 4.5 ms against 0.89 / 1.02 / 1.7 for the tiles.  lin_probe looks at up to
 // 512 sample tiles: mean absolute second difference of the coordinates along the last dim, summed over the dims (tile_common.hpp:
-// tile_smooth's measure), above one voxel -> word 0 of the 256-byte workspace = 1, the tiles; else 0, the generic kernel.  Both are
+// tile_smooth's measure), above thr16 / 16 voxels -> word 0 of the 256-byte workspace = 1, the tiles; else 0, the generic kernel (the pull:
+// one voxel, sigma ~ 0.17; the grid gradient, whose tile kernel costs 2.4 ms whatever the field: four voxels, sigma ~ 0.7).  Both are
 // enqueued behind it; one relaxed 64-bit add per workgroup carries sum, count and ticket (no fence).
 // ---------------------------------------------------------------------------
 namespace owner {
 template <int GM>
 __global__ __launch_bounds__(256) void lin_probe(KParams p, const float *__restrict__ grid, int *__restrict__ hdr, int gx, int gy, int gz, int nty, int ntz,
-                                                 int ntiles, long long total, int stride)
+                                                 int ntiles, long long total, int stride, int thr16)
 {
     __shared__ int acc[2];
     const int tid = threadIdx.x;
@@ -1861,7 +1862,7 @@ __global__ __launch_bounds__(256) void lin_probe(KParams p, const float *__restr
         const unsigned long long tot = __hip_atomic_fetch_add(reinterpret_cast<unsigned long long *>(hdr + 2), add, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + add;
         if ((tot & 0xfffull) == (unsigned long long)gridDim.x) {
             const unsigned long long sum16 = tot >> 34, cnt = (tot >> 12) & 0x3fffffull;
-            __hip_atomic_store(&hdr[0], (cnt > 0 && sum16 > cnt * 16ull) ? 1 : 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&hdr[0], (cnt > 0 && sum16 > cnt * (unsigned long long)thr16) ? 1 : 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
 }
@@ -1869,7 +1870,7 @@ __global__ __launch_bounds__(256) void lin_probe(KParams p, const float *__restr
 } // namespace owner
 
 // 0 = enqueued (*gate_out: the verdict word), else an error
-int linear_pull_probe(const interpol_problem *p, const KParams &k, const void *grid, void *workspace, hipStream_t st, const int **gate_out)
+int linear_pull_probe(const interpol_problem *p, const KParams &k, const void *grid, void *workspace, hipStream_t st, const int **gate_out, int thr16)
 {
     using namespace owner;
     int *hdr = (int *)workspace;
@@ -1880,8 +1881,8 @@ int linear_pull_probe(const interpol_problem *p, const KParams &k, const void *g
     int stride = (int)((total + 511) / 512);
     stride = stride < 1 ? 1 : (stride | 1);                          // (odd: the probed tiles do not line up along an axis)
     const unsigned nb = (unsigned)((total + stride - 1) / stride);
-    if (k.sep == 0) hipLaunchKernelGGL((lin_probe<0>), dim3(nb), dim3(256), 0, st, k, (const float *)grid, hdr, gx, gy, gz, nty, ntz, ntiles, total, stride);
-    else hipLaunchKernelGGL((lin_probe<2>), dim3(nb), dim3(256), 0, st, k, (const float *)grid, hdr, gx, gy, gz, nty, ntz, ntiles, total, stride);
+    if (k.sep == 0) hipLaunchKernelGGL((lin_probe<0>), dim3(nb), dim3(256), 0, st, k, (const float *)grid, hdr, gx, gy, gz, nty, ntz, ntiles, total, stride, thr16);
+    else hipLaunchKernelGGL((lin_probe<2>), dim3(nb), dim3(256), 0, st, k, (const float *)grid, hdr, gx, gy, gz, nty, ntz, ntiles, total, stride, thr16);
     *gate_out = hdr;
     const hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : (int)e;

@@ -200,6 +200,9 @@ __device__ __forceinline__ void wgrads_yz(f2 t, f2 *g)
         g[3] = (u * u) * 0.5f;
         g[1] = u * (u * 1.5f - 2.f);
         g[2] = v * (v * -1.5f + 2.f);
+    } else if (K == 1) {
+        // all-linear stencils take the reference's iso1 path: -1, +1 (iso1.py:311-313)
+        g[0] = f2{ -1.f, -1.f }; g[1] = f2{ 1.f, 1.f }; g[2] = f2{ 0.f, 0.f }; g[3] = f2{ 0.f, 0.f };
     } else {
         // K == 2: w0 = a^2 / 2 (a = 1.5 - t), w1 = 0.75 - m^2 (m = t - 1), w2 = c^2 / 2 (c = t - 0.5)
         g[0] = t - 1.5f;
@@ -216,6 +219,8 @@ __device__ __forceinline__ float wgrad_x(float t, int i)
     if (K == 3) {
         const float e = 2.f - d;
         return (d < 1.f ? d * __builtin_fmaf(d, 1.5f, -2.f) : -0.5f * (e * e)) * s;
+    } else if (K == 1) {
+        return i == 0 ? -1.f : (i == 1 ? 1.f : 0.f);                 // iso1.py:311-313
     } else {
         return i > 2 ? 0.f : (d < 0.5f ? -2.f * d : d - 1.5f) * s;
     }
