@@ -194,6 +194,13 @@ if "r" in which:    # config 2 vs the roughness of the deformation: identity + s
             rec(res, "cfg2_push_owner_sigma_%g" % sigma, timeit(lambda: interpol.grid_push(inp, grid, **kw), 3), vox, nb)
         finally:
             backend.rough_deformations = None
+        if sigma in (0.0, 1.0, 2.0, 4.0):
+            # round 5: the reference's DEFAULT interpolation (trilinear) at the same shape -- routed: class-sorted tiles with K = 1 or the generic kernel
+            from interpol import _hip
+            kl = dict(interpolation=1, bound="dct2", extrapolate=True)
+            rec(res, "cfg2shape_trilinear_pull_sigma_%g" % sigma, timeit(lambda: interpol.grid_pull(inp, grid, **kl), 3), vox, nb)
+            rec(res, "cfg2shape_trilinear_pull_generic_sigma_%g" % sigma, timeit(lambda: _hip.gather("pull", inp, grid, [3] * 3, [1] * 3, 1, flags=_hip.FLAG_NO_FASTPATH), 3), vox, nb)
+            rec(res, "cfg2shape_trilinear_backward_grid_only_sigma_%g" % sigma, timeit(lambda: _hip.pull_backward(inp, inp, grid, [3] * 3, [1] * 3, 1, False, True), 3), vox, nb + vox * 12)
         del inp, grid
 
 if "r" in which:    # SURVEY 8(d)'s smooth variant: 12^3 control points, sigma = 2 / 8 voxels, cubic-upsampled displacement (a registration field)
