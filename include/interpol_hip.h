@@ -235,7 +235,8 @@ int interpol_pull(const interpol_problem *p, const void *vol, const void *grid, 
  * INTERPOL_FLAG_BINNED_SCATTER, behind a probe of the call under INTERPOL_FLAG_AUTO_SCATTER (more than 400 pixels per million outside
  * the lean tiles' boxes and a density of at least 0.6 samples per pixel; sparser samplings -- a zoom beyond ~1.3 whose tiles leave their boxes --
  * go to the generic kernel, as the hand-back of rounds 3 - 4 sent them).  Config 5's shape: pull 0.88 ms at every sigma (tiles: 0.43 at sigma = 2, 2.8 at 8, 3.6 at 16). */
-/* Trilinear pulls (round 5; 3-D, order 1 in every dim, F32, dense grids and displacement fields, 32768 samples and more):
+/* Trilinear pulls (round 5; 3-D, order 1 in every dim, F32 with dense grids and displacement fields, BF16 / F16 with dense grids, 32768
+ * samples and more; the grid gradient of interpol_pull_backward: F32):
  * interpol_pull_workspace returns 256 -- the verdict of the call's probe (mean absolute second difference of the coordinates above one
  * voxel: rough) is all the workspace holds.  AUTO: rough fields take the class-sorted LDS tiles with K = 1 (4 x 2 x 256^3, i.i.d. noise
  * of sigma = 2: 2.5 -> 1.0 ms), smooth ones the generic kernel, which gathers at the HBM roofline there (0.47 ms); BINNED: the tiles. */

@@ -1162,6 +1162,15 @@ def test_trilinear_pull_router():
             a = _hip.gather("pull", img, disp, [3] * 3, [1] * 3, 1, flags=_hip.FLAG_DISPLACEMENT)
             assert torch.equal(a, _hip.gather("pull", img, disp, [3] * 3, [1] * 3, 1, flags=_hip.FLAG_DISPLACEMENT))
             assert G.rel_err(a.cpu().numpy(), _hip.gather("pull", img, dense, [3] * 3, [1] * 3, 1, flags=_hip.FLAG_NO_FASTPATH).cpu().numpy()) < 2e-6
+        # 16-bit storage takes the same router (dense grids): the float32 kernel's result on the rounded image, to storage rounding
+        for dt, tol in ((torch.bfloat16, 8e-3), (torch.float16, 1e-3)):
+            for sigma in (0.05, 3.0):
+                im16 = img.to(dt)
+                grid = (ident.to(DEV) + sigma * torch.randn([2, n, n, n, 3], generator=g).to(DEV)).contiguous()
+                ref = _hip.gather("pull", im16.float(), grid, [3] * 3, [1] * 3, 1, flags=_hip.FLAG_NO_FASTPATH)
+                for fl in (0, _hip.FLAG_BINNED_SCATTER):
+                    a = _hip.gather("pull", im16, grid, [3] * 3, [1] * 3, 1, flags=fl)
+                    assert a.dtype == dt and G.rel_err(a.float().cpu().numpy(), ref.cpu().numpy()) < tol, (dt, sigma, fl)
     finally:
         oracle.set_threads(1)
 

@@ -76,6 +76,8 @@ int try_scatter2d(const interpol_problem *, const KParams &, const void *, const
 int try_pull_direct(const interpol_problem *, const KParams &, const void *, const void *, void *, int *, int, hipStream_t);
 #endif
 int try_sorted_pull_f32(const interpol_problem *, const KParams &, const void *, const void *, void *, hipStream_t);
+int try_sorted_pull_bf16(const interpol_problem *, const KParams &, const void *, const void *, void *, hipStream_t);
+int try_sorted_pull_f16(const interpol_problem *, const KParams &, const void *, const void *, void *, hipStream_t);
 int try_sorted_gradc_f32(const interpol_problem *, const KParams &, const void *, const void *, const void *, void *, hipStream_t);
 int64_t owner_pull_workspace_bytes(const interpol_problem *, const KParams &);
 int64_t owner_workspace_bytes(const interpol_problem *, const KParams &, bool);
@@ -339,7 +341,9 @@ int interpol_pull(const interpol_problem *p, const void *vol, const void *grid, 
 // the trilinear pull with a router (push_owner.hip: lin_probe): float32, dense grids and displacement fields, tiles' sizes
 static bool linear_routed(const interpol_problem *p, const KParams &k)
 {
-    if (p->dim != 3 || p->dtype != INTERPOL_F32 || p->grid_dtype != INTERPOL_F32 || (k.sep != 0 && k.sep != 2)) return false;
+    // (16-bit storage: dense grids, the pull alone -- what ops_sorted.hip instantiates)
+    const bool lowp = p->dtype == INTERPOL_BF16 || p->dtype == INTERPOL_F16;
+    if (p->dim != 3 || (p->dtype != INTERPOL_F32 && !lowp) || p->grid_dtype != INTERPOL_F32 || (k.sep != 0 && (k.sep != 2 || lowp))) return false;
     if (!(p->flags & (INTERPOL_FLAG_AUTO_SCATTER | INTERPOL_FLAG_BINNED_SCATTER)) || (k.dbg & 32)) return false;
     int64_t n = 1;
     for (int d = 0; d < 3; ++d) { if (k.order[d] != 1 || p->grid_shape[d] > 0x7fffffff / 4) return false; n *= p->grid_shape[d]; }
@@ -373,11 +377,16 @@ static int routed_pull(const interpol_problem *p, KParams k, int B, const void *
             kt.verdict = gate; kt.gate_n = -3;                       // the tiles run on verdict 1 ...
             k.gate = gate; k.gate_n = -1;                            // ... the generic kernel unless the verdict is 1
         }
-        int rl = try_sorted_pull_f32(p, kt, vol, grid, val, st);
+        int rl = p->dtype == INTERPOL_F32 ? try_sorted_pull_f32(p, kt, vol, grid, val, st)
+               : (p->dtype == INTERPOL_BF16 ? try_sorted_pull_bf16(p, kt, vol, grid, val, st) : try_sorted_pull_f16(p, kt, vol, grid, val, st));
         if (rl != 0 && rl != 1) return rl;
         if (rl == 1 && (p->flags & INTERPOL_FLAG_BINNED_SCATTER)) return 1;
         if (rl == 0) { k.gate = nullptr; k.gate_n = 0; }             // (the tiles declined: the generic kernel, unconditionally)
-        rl = launch_pull_f32(k, vol, grid, val, B, st);
+        rl = by_dtype(p->dtype,
+            [&] { return launch_pull_f32(k, vol, grid, val, B, st); },
+            [&] { return (int)INTERPOL_E_DTYPE; },
+            [&] { return launch_pull_bf16(k, vol, grid, val, B, st); },
+            [&] { return launch_pull_f16(k, vol, grid, val, B, st); });
         return rl ? rl : 1;
     }
     if (p->dim == 2) {
@@ -720,7 +729,7 @@ static int routed_gradc(const interpol_problem *p, const KParams &k, const void 
 {
     int *flags = nullptr;
     int nzero = 0;
-    if (linear_routed(p, k) && k.mode == MODE_ISO1 && scratch && scratch_bytes >= 256 && ((uintptr_t)scratch & 255u) == 0) {
+    if (linear_routed(p, k) && p->dtype == INTERPOL_F32 && k.mode == MODE_ISO1 && scratch && scratch_bytes >= 256 && ((uintptr_t)scratch & 255u) == 0) {
         // trilinear (round 5): the class-sorted tiles for rough fields, the generic fused kernel for smooth ones (push_owner.hip: lin_probe)
         KParams kt = k, kg = k;
         if (!(p->flags & INTERPOL_FLAG_BINNED_SCATTER)) {

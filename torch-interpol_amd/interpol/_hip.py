@@ -357,7 +357,8 @@ def gather(op, vol, grid, bound, order, extrapolate, flags=0, out=None):
     grid, gflag = _prep_grid(grid, gdt)
     flags |= gflag
     routed = False
-    if (((op in ("pull", "grad") and dim == 3 and dt == torch.float32) or (op == "pull" and dim == 2 and dt in _ROUTED_2D and gdt == torch.float32))
+    lin3 = op == "pull" and dim == 3 and dt in (torch.bfloat16, torch.float16) and gdt == torch.float32 and all(int(o) == 1 for o in order[:3])   # trilinear: routed in 16 bits too
+    if (((op in ("pull", "grad") and dim == 3 and dt == torch.float32) or lin3 or (op == "pull" and dim == 2 and dt in _ROUTED_2D and gdt == torch.float32))
             and not (flags & (FLAG_NO_FASTPATH | FLAG_FORCE_TILED | FLAG_BINNED_SCATTER)) and (flags >> 8) == 0):
         # the router of the pull (csrc/push_owner.hip: own_gather; 2-D: csrc/scatter2d.hip: gather2d): like the push's, see interpol/backend.py
         from . import backend
