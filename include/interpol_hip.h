@@ -131,7 +131,8 @@ typedef struct interpol_problem {
  * depends on the deformation (4x2x256^3 cubic: 2.8 - 3.6 ms from the identity to i.i.d. noise of sigma = 6
  * voxels), where the sample-stationary tiles need the stencils of a 16^3 tile of samples to fit a
  * 33 x 33 x 32 LDS box (2.2 ms at the identity, 3.5 at sigma = 2, 126 at sigma = 6).
- * 3-D, one order 2..3, float32 coordinates.  Needs the workspace announced by
+ * 3-D, one order 1..3 (trilinear since round 5: 4x2x256^3, 2.3 - 3.1 ms from the identity to sigma = 6, where its tiles take
+ * 1.3 - 16 ms), float32 coordinates.  Needs the workspace announced by
  * interpol_scatter_workspace(); ignored (tiles / generic kernels) when it does not apply.
  *   INTERPOL_FLAG_BINNED_SCATTER: always;
  *   INTERPOL_FLAG_AUTO_SCATTER:   a probe kernel of the same call examines 128 tiles of the sample grid

@@ -1175,6 +1175,64 @@ def test_trilinear_pull_router():
         oracle.set_threads(1)
 
 
+def test_trilinear_push_through_owner_bricks():
+    """Round 5: the trilinear grid_push / grid_count (and with them the image gradient of the trilinear pull's backward) take the
+    owner-computes bricks when the probe finds the field rough (csrc/push_owner.hip: own_accumulate<1> -- a 2 x 2 x 2 stencil in the
+    magic fixed-point format, stencil counts from a box filter of width 2).  Forced bricks, the routed default and the atomics-only
+    kernel against the oracle: every bound (mixed per dim), the three extrapolation modes, sample grids that overhang the lattice,
+    lattices whose end bricks fold, one to three channels with the count channel, smooth and rough; 16-bit storage against the
+    float32 kernel on the rounded source."""
+    from interpol import _hip, backend
+    g = torch.Generator().manual_seed(21)
+    oracle.set_threads(8)
+    try:
+        for shape, oshape in (((40, 33, 50), (37, 45, 29)), ((64, 48, 36), (60, 50, 70))):
+            for bound in range(7):
+                ex = bound % 3
+                C = 1 + bound % 3
+                for sigma in (0.3, 6.0):
+                    src = torch.randn([2, C, *oshape], generator=g)
+                    lin = [torch.linspace(-2, n + 1, m) for n, m in zip(shape, oshape)]
+                    grid = torch.stack(torch.meshgrid(*lin, indexing="ij"), -1)[None] + sigma * torch.randn([2, *oshape, 3], generator=g)
+                    b = [bound, (bound + 3) % 7, (bound + 5) % 7]
+                    # (float32 coordinates EQUAL to a float32 extrapolation threshold: masked by the float32 reference only -- drop their source)
+                    keep = torch.from_numpy(~G.f32_masked_samples(grid.numpy(), shape, ex))
+                    assert keep.float().mean() > 0.5
+                    src = src * keep[:, None]
+                    want = oracle.grid_push(src.double().numpy(), grid.double().numpy(), list(shape), b, [1], ex)
+                    ones = keep[:, None].double().numpy()
+                    want_c = oracle.grid_push(ones, grid.double().numpy(), list(shape), b, [1], ex)
+                    for name, fl in (("routed", 0), ("bricks", _hip.FLAG_BINNED_SCATTER), ("atomics", _hip.FLAG_NO_FASTPATH)):
+                        got = _hip.scatter("push", src.to(DEV), grid.to(DEV), list(shape), b, [1] * 3, ex, flags=fl, with_count=True)
+                        G.assert_close(got[:, :C].cpu().numpy(), want, rtol=1e-5, atol_rel=1e-5, what=("trilinear push", name, shape, b, ex, sigma))
+                        if bool(keep.all()):
+                            G.assert_close(got[:, C:].cpu().numpy(), want_c, rtol=1e-5, atol_rel=1e-5, what=("trilinear push count", name, shape, b, ex, sigma))
+                            cnt = _hip.scatter("count", None, grid.to(DEV), list(shape), b, [1] * 3, ex, flags=fl)
+                            G.assert_close(cnt.cpu().numpy(), want_c, rtol=1e-5, atol_rel=1e-5, what=("trilinear count", name, shape, b, ex, sigma))
+        # the image gradient of the pull's backward goes the same way (two channels: the library splits the backward), and
+        # 16-bit storage: the float32 result on the rounded source, to storage rounding
+        n = 64
+        ident = interpol.identity_grid([n, n, n])[None].to(DEV)
+        for sigma in (0.1, 6.0):
+            grid = (ident + sigma * torch.randn([2, n, n, n, 3], generator=g).to(DEV)).contiguous()
+            gout = torch.randn([2, 2, n, n, n], generator=g).to(DEV)
+            ref = _hip.scatter("push", gout, grid, [n] * 3, [3] * 3, [1] * 3, 1, flags=_hip.FLAG_NO_FASTPATH)
+            for rd in (None, True, False):
+                backend.rough_deformations = rd
+                try:
+                    gv = _hip.pull_backward(gout, gout, grid, [3] * 3, [1] * 3, 1, True, False)[0]
+                finally:
+                    backend.rough_deformations = None
+                assert G.rel_err(gv.cpu().numpy(), ref.cpu().numpy()) < 4e-6, (sigma, rd)
+            for dt, tol in ((torch.bfloat16, 8e-3), (torch.float16, 1e-3)):
+                ref16 = _hip.scatter("push", gout.to(dt).float(), grid, [n] * 3, [3] * 3, [1] * 3, 1, flags=_hip.FLAG_NO_FASTPATH)
+                for fl in (0, _hip.FLAG_BINNED_SCATTER):
+                    a = _hip.scatter("push", gout.to(dt), grid, [n] * 3, [3] * 3, [1] * 3, 1, flags=fl)
+                    assert a.dtype == dt and G.rel_err(a.float().cpu().numpy(), ref16.cpu().numpy()) < tol, (dt, sigma, fl)
+    finally:
+        oracle.set_threads(1)
+
+
 def test_separable_push_by_gathering_passes():
     """Round 5 (csrc/resample1d.hip: resample1d_adj_gather): the adjoint of a tensor-product resampling -- restrict, the backward of
     resize -- as D passes that GATHER (the samples whose stencil covers a lattice point are a contiguous range of a non-decreasing

@@ -510,7 +510,7 @@ static_assert(sizeof(unsigned) * (BOX * BOX * NZ / 2) <= sizeof(unsigned) * (NCE
 // ---------------------------------------------------------------------------
 constexpr float MAGIC = 12582912.f;             // 1.5 * 2^23
 constexpr unsigned MAGIC_ODD = 301u;            // bits(MAGIC) = 0x4B400000 = 301 << 22
-template <int K> __device__ __forceinline__ float magic_units() { return K == 3 ? 4194304.f * 0.999f * 3.375f : 4194304.f * 0.999f * (64.f / 27.f); }    // 2^22 * 0.999 / wmax^3
+template <int K> __device__ __forceinline__ float magic_units() { return K == 3 ? 4194304.f * 0.999f * 3.375f : (K == 2 ? 4194304.f * 0.999f * (64.f / 27.f) : 4194304.f * 0.999f); }    // 2^22 * 0.999 / wmax^3 (wmax = 1 for K = 1)
 // the largest  density * prod_d sum_j max_t w_j(t)  (tile_common.hpp: headroom32) whose slot sums stay inside 32 bits
 template <int K> __device__ __forceinline__ float magic_cbmax() { return 2147483648.f * 0.99f / magic_units<K>(); }
 
@@ -532,9 +532,12 @@ __device__ __forceinline__ void row_adds(unsigned addr, unsigned long long v0, u
     if (NZT == 4)
         asm volatile("ds_add_u64 %0, %1 offset:%5\n\tds_add_u64 %0, %2 offset:%6\n\tds_add_u64 %0, %3 offset:%7\n\tds_add_u64 %0, %4 offset:%8"
                      :: "v"(addr), "v"(v0), "v"(v1), "v"(v2), "v"(v3), "n"(o), "n"(o + 8), "n"(o + 16), "n"(o + 24) : "memory");
-    else
+    else if (NZT == 3)
         asm volatile("ds_add_u64 %0, %1 offset:%4\n\tds_add_u64 %0, %2 offset:%5\n\tds_add_u64 %0, %3 offset:%6"
                      :: "v"(addr), "v"(v0), "v"(v1), "v"(v2), "n"(o), "n"(o + 8), "n"(o + 16) : "memory");
+    else
+        asm volatile("ds_add_u64 %0, %1 offset:%3\n\tds_add_u64 %0, %2 offset:%4"
+                     :: "v"(addr), "v"(v0), "v"(v1), "n"(o), "n"(o + 8) : "memory");
 }
 // WIDE: one channel, 64-bit sums of 31-bit terms (dense bricks); else the channel pair in the magic format (above)
 template <int K, int I, int J, bool WIDE>
@@ -568,7 +571,8 @@ __device__ __forceinline__ void scatter_plane(unsigned addr, f2 s, float wxi, co
     }
 #endif
     const f2 sx = s * f2{ wxi, wxi };
-    scatter_row<K, I, 0, WIDE>(addr, sx, w, dbg); scatter_row<K, I, 1, WIDE>(addr, sx, w, dbg); scatter_row<K, I, 2, WIDE>(addr, sx, w, dbg);
+    scatter_row<K, I, 0, WIDE>(addr, sx, w, dbg); scatter_row<K, I, 1, WIDE>(addr, sx, w, dbg);
+    if (K >= 2) scatter_row<K, I, 2, WIDE>(addr, sx, w, dbg);
     if (K == 3) scatter_row<K, I, 3, WIDE>(addr, sx, w, dbg);
 }
 
@@ -583,7 +587,7 @@ __device__ __forceinline__ void slide(const unsigned *in, unsigned *out)
 #pragma unroll
     for (int j = 0; j < BOX; ++j) {
         if (j < BR) s += __builtin_bit_cast(us2, in[j]);
-        if (j >= W) s -= __builtin_bit_cast(us2, in[j - W]);
+        if (j >= W && j - W < BR) s -= __builtin_bit_cast(us2, in[j - W]);      // (K = 1: the window leaves the 16 cells before the box ends)
         out[j] = __builtin_bit_cast(unsigned, s);
     }
 }
@@ -604,7 +608,7 @@ __device__ __forceinline__ void stencil_counts(SM &sm, int tid)
 #pragma unroll
         for (int i = 0; i < BR / 2; ++i) { v[2 * i] = (int)(in[i] & 0xffffu); v[2 * i + 1] = (int)(in[i] >> 16); }
 #pragma unroll
-        for (int j = 0; j < BOX; ++j) { if (j < BR) s += v[j]; if (j >= W) s -= v[j - W]; o[j] = s; }
+        for (int j = 0; j < BOX; ++j) { if (j < BR) s += v[j]; if (j >= W && j - W < BR) s -= v[j - W]; o[j] = s; }
         o[BOX] = 0;
 #pragma unroll
         for (int i = 0; i < HZ; ++i) rg[tid * HZ + i] = (unsigned)o[2 * i] | ((unsigned)o[2 * i + 1] << 16);
@@ -894,7 +898,7 @@ __global__ __launch_bounds__(NT, 4) void own_accumulate(KParams p, BrickGrid bg,
         prof_mark(10);
         // 32-bit channel pairs while no slot's sums can leave 32 bits: density * prod_d sum_j max_t w_j(t) units of max |source|
         // (tile_common.hpp: headroom32) -- 32 samples per first-tap cell for cubic stencils; beyond: 64-bit sums, one channel per pass
-        const float wsum = K == 3 ? 1.6666667f : 1.75f;
+        const float wsum = K == 3 ? 1.6666667f : (K == 2 ? 1.75f : 2.f);
         const bool dense = n >= 60000 || (float)(sm.dmax * foldmul) * (wsum * wsum * wsum) > magic_cbmax<K>();    // (16-bit density counters)
         const bool one_batch = npieces <= NPIECE;
         for (int c = 0; c < nch; c += 2) {
@@ -1030,13 +1034,13 @@ __global__ __launch_bounds__(NT, 4) void own_accumulate(KParams p, BrickGrid bg,
                             const f2 ss = sub ? f2{ cs1 * scalew.y, 0.f } : f2{ cs0 * scalew.x, 0.f };
                             scatter_plane<K, 0, true>(addr, ss, weight_x<K>(tx, 0), w, p.dbg);
                             scatter_plane<K, 1, true>(addr, ss, weight_x<K>(tx, 1), w, p.dbg);
-                            scatter_plane<K, 2, true>(addr, ss, weight_x<K>(tx, 2), w, p.dbg);
+                            if (K >= 2) scatter_plane<K, 2, true>(addr, ss, weight_x<K>(tx, 2), w, p.dbg);
                             if (K == 3) scatter_plane<K, 3, true>(addr, ss, weight_x<K>(tx, 3), w, p.dbg);
                         } else {
                             const f2 ss = f2{ cs0, cs1 } * scale;
                             scatter_plane<K, 0, false>(addr, ss, weight_x<K>(tx, 0), w, p.dbg);
                             scatter_plane<K, 1, false>(addr, ss, weight_x<K>(tx, 1), w, p.dbg);
-                            scatter_plane<K, 2, false>(addr, ss, weight_x<K>(tx, 2), w, p.dbg);
+                            if (K >= 2) scatter_plane<K, 2, false>(addr, ss, weight_x<K>(tx, 2), w, p.dbg);
                             if (K == 3) scatter_plane<K, 3, false>(addr, ss, weight_x<K>(tx, 3), w, p.dbg);
                         }
                     } else {
@@ -1636,7 +1640,8 @@ static bool owner_eligible(const interpol_problem *p, const KParams &k, bool sca
     const bool shared = scatter && shared_target(p);
     if (p->dim != 3 || p->batch > 4096) return false;
     if (!(p->flags & (INTERPOL_FLAG_BINNED_SCATTER | INTERPOL_FLAG_AUTO_SCATTER))) return false;   // see interpol_hip.h
-    if (k.order[0] != k.order[1] || k.order[0] != k.order[2] || k.order[0] < 2 || k.order[0] > 3) return false;
+    // (round 5: the trilinear push / count take the organisation as well; the gathers' bricks stay with orders 2 - 3)
+    if (k.order[0] != k.order[1] || k.order[0] != k.order[2] || k.order[0] < (scatter ? 1 : 2) || k.order[0] > 3) return false;
     int64_t n = 1, nv = 1, nb = shared ? 1 : p->batch;
     for (int d = 0; d < 3; ++d) {
         n *= p->grid_shape[d]; nv *= p->vol_shape[d];
@@ -1677,7 +1682,7 @@ static int launch_bin(const interpol_problem *p, const KParams &k, const BrickGr
     }
 #define IP_OWN_BY_GM(KK)                                                                                                \
     { if (k.sep == 0) IP_OWN_BIN(KK, 0) else if (k.sep == 1) IP_OWN_BIN(KK, 1) else if (k.sep == 2) IP_OWN_BIN(KK, 2) else IP_OWN_BIN(KK, 3) }
-    if (k.order[0] == 3) IP_OWN_BY_GM(3) else IP_OWN_BY_GM(2)
+    if (k.order[0] == 3) IP_OWN_BY_GM(3) else if (k.order[0] == 2) IP_OWN_BY_GM(2) else IP_OWN_BY_GM(1)
 #undef IP_OWN_BY_GM
 #undef IP_OWN_BIN
     return 0;
@@ -1714,7 +1719,7 @@ int try_owner_push(const interpol_problem *p, const KParams &k, const void *val,
         const dim3 pgrid((unsigned)(total < NPROBE ? total : NPROBE));
 #define IP_OWN_PROBE(KK, GM) hipLaunchKernelGGL((own_probe<KK, GM>), pgrid, dim3(NT1), 0, st, k, bg, (const float *)grid, w.hdr, gx, gy, gz, nty, ntz, ntiles, B, nch);
 #define IP_OWN_PROBE_GM(KK) { if (k.sep == 0) IP_OWN_PROBE(KK, 0) else if (k.sep == 1) IP_OWN_PROBE(KK, 1) else if (k.sep == 2) IP_OWN_PROBE(KK, 2) else IP_OWN_PROBE(KK, 3) }
-        if (k.order[0] == 3) IP_OWN_PROBE_GM(3) else IP_OWN_PROBE_GM(2)
+        if (k.order[0] == 3) IP_OWN_PROBE_GM(3) else if (k.order[0] == 2) IP_OWN_PROBE_GM(2) else IP_OWN_PROBE_GM(1)
 #undef IP_OWN_PROBE_GM
 #undef IP_OWN_PROBE
         gate = &w.hdr->gate;
@@ -1745,7 +1750,7 @@ int try_owner_push(const interpol_problem *p, const KParams &k, const void *val,
                                (const int *)w.bmax, w.nrec, (float *)vol, nch, color, Bw, gate, \
                                (int *)w.hdr + 16 + color);                                                              \
         }
-        if (k.order[0] == 3) IP_OWN_ACC(3) else IP_OWN_ACC(2)
+        if (k.order[0] == 3) IP_OWN_ACC(3) else if (k.order[0] == 2) IP_OWN_ACC(2) else IP_OWN_ACC(1)
 #undef IP_OWN_ACC
     }
     e = hipGetLastError();
