@@ -194,6 +194,15 @@ if "r" in which:    # config 2 vs the roughness of the deformation: identity + s
             rec(res, "cfg2_push_owner_sigma_%g" % sigma, timeit(lambda: interpol.grid_push(inp, grid, **kw), 3), vox, nb)
         finally:
             backend.rough_deformations = None
+        if sigma in (0.0, 2.0, 4.0, 6.0):
+            # round 5: the trilinear push behind the owner-computes probe (own_accumulate<1>) against its sample tiles alone
+            kl = dict(interpolation=1, bound="dct2", extrapolate=True)
+            rec(res, "cfg2shape_trilinear_push_sigma_%g" % sigma, timeit(lambda: interpol.grid_push(inp, grid, **kl), 3), vox, nb)
+            backend.rough_deformations = False
+            try:
+                rec(res, "cfg2shape_trilinear_push_tiles_sigma_%g" % sigma, timeit(lambda: interpol.grid_push(inp, grid, **kl), 3), vox, nb)
+            finally:
+                backend.rough_deformations = None
         if sigma in (0.0, 1.0, 2.0, 4.0):
             # round 5: the reference's DEFAULT interpolation (trilinear) at the same shape -- routed: class-sorted tiles with K = 1 or the generic kernel
             from interpol import _hip
