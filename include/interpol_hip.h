@@ -246,7 +246,9 @@ int interpol_pull_ws(const interpol_problem *p, const void *vol, const void *gri
 /* grid_grad (interpol_grad) with the same workspace (interpol_pull_workspace(p) bytes; for the grad problem the same number as for
  * the pull of its image): float32, 3-D quadratic / cubic.  INTERPOL_FLAG_BINNED_SCATTER: the bricks of the image always;
  * INTERPOL_FLAG_AUTO_SCATTER: when the probe of the call finds a dense or rough sampling (4 x 2 x 256^3 cubic, sigma = 2: the
- * natural-order tiles 3.5 ms, the bricks ~2.3), the tile / generic kernels otherwise; else, or without a workspace: interpol_grad. */
+ * natural-order tiles 3.5 ms, the bricks ~2.3), the tile / generic kernels otherwise; else, or without a workspace: interpol_grad.
+ * Trilinear (float32, 3-D, dense or displacement grids; the 256-byte workspace of the trilinear pull): AUTO -- rough fields take the
+ * LDS tiles (sigma = 2: 2.7 -> 1.8 ms), smooth ones the generic kernel (0.7 ms), on the verdict of the pull's probe; BINNED: the tiles. */
 int interpol_grad_ws(const interpol_problem *p, const void *vol, const void *grid, void *val, void *workspace, int64_t workspace_bytes, void *stream);
 int interpol_push(const interpol_problem *p, const void *val, const void *grid, void *vol,
                   void *scratch, int64_t scratch_bytes, void *stream);

@@ -1152,6 +1152,13 @@ def test_trilinear_pull_router():
                         for name, fl in (("routed", 0), ("tiles", _hip.FLAG_BINNED_SCATTER)):
                             gg = _hip.pull_backward(gout.to(DEV), img.to(DEV), grid.to(DEV), b, [1] * 3, ex, False, True, flags=fl)[1]
                             G.assert_close(gg.cpu().numpy(), want_g, rtol=1e-5, atol_rel=1e-5, what=("trilinear grid gradient", name, shape, b, ex, sigma))
+                    # grid_grad: the round-1 LDS tiles for rough fields, the generic kernel for smooth ones, behind the same probe
+                    if bound in (0, 2, 4, 5):
+                        want_d = oracle.grid_grad(img.double().numpy(), grid.double().numpy(), b, [1], ex)
+                        want_d[np.broadcast_to(G.f32_masked_samples(grid.numpy(), shape, ex)[:, None, ..., None], want_d.shape)] = 0.0
+                        for name, fl in (("routed", 0), ("tiles", _hip.FLAG_BINNED_SCATTER), ("generic", _hip.FLAG_NO_FASTPATH)):
+                            gd = _hip.gather("grad", img.to(DEV), grid.to(DEV), b, [1] * 3, ex, flags=fl)
+                            G.assert_close(gd.cpu().numpy(), want_d, rtol=1e-5, atol_rel=1e-5, what=("trilinear grid_grad", name, shape, b, ex, sigma))
         # displacement fields, and the same inputs always take the same organisation
         n = 64
         img = torch.randn([2, 2, n, n, n], generator=g).to(DEV)

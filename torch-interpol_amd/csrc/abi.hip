@@ -517,6 +517,28 @@ int interpol_grad_ws(const interpol_problem *p, const void *vol, const void *gri
     hipStream_t st = (hipStream_t)stream;
     int *flags = nullptr;
     int nzero = 0;
+    if (!(p->flags & INTERPOL_FLAG_NO_FASTPATH) && p->dtype == INTERPOL_F32 && linear_routed(p, k) && workspace && workspace_bytes >= 256
+        && ((uintptr_t)workspace & 255u) == 0) {
+        // trilinear (round 5): the generic kernel up to sigma ~ 1 (0.67 ms at the identity against 1.36 for the tiles, 4 x 2 x 256^3), the LDS
+        // tiles beyond (sigma = 2 / 4: 1.8 / 3.6 against 2.7 / 4.7 ms) -- the probe of the trilinear pull, its threshold at 3.5 voxels of mean
+        // |second difference| of the coordinates summed over the dims (sigma ~ 0.6: the gated generic launch, which strides over the batch,
+        // loses to the tiles from there on -- sigma = 1: 2.1 against 1.5 ms); both kernels enqueued behind the verdict
+        interpol_problem pt = *p;
+        pt.flags |= INTERPOL_FLAG_FORCE_TILED;
+        KParams kt = k, kg = k;
+        if (!(p->flags & INTERPOL_FLAG_BINNED_SCATTER)) {
+            const int *gate = nullptr;
+            rc = linear_pull_probe(p, k, grid, workspace, st, &gate, 56);
+            if (rc) return rc;
+            kt.verdict = gate; kt.gate_n = -3;                       // the tiles run on verdict 1 ...
+            kg.gate = gate; kg.gate_n = -1;                          // ... the generic kernel unless the verdict is 1
+        }
+        rc = try_fast_grad(&pt, kt, vol, grid, val, st);
+        if (rc != 0 && rc != 1) return rc;
+        if (rc == 1 && (p->flags & INTERPOL_FLAG_BINNED_SCATTER)) return 0;
+        if (rc == 0) { kg.gate = nullptr; kg.gate_n = 0; }           // (the tiles declined: the generic kernel, unconditionally)
+        return launch_grad_f32(kg, vol, grid, val, B, st);
+    }
     if (!(p->flags & INTERPOL_FLAG_NO_FASTPATH) && k.order[0] >= 4) {
         const int *gate = nullptr;
         rc = try_gather5(p, k, vol, grid, val, workspace, workspace_bytes, 2, nullptr, st, &gate);

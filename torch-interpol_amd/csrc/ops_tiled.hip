@@ -550,6 +550,7 @@ __global__ __launch_bounds__(C::NT) void gather_tiled(KParams p, const typename 
                                                       typename C::T *__restrict__ val, int gx, int gy, int gz, int nty, int ntz, int ntiles, int nbatch, DeferArgs defer)
 {
     if (p.gate_n == -1 && p.gate && *p.gate == 1) return;   // a probe of the call gave it to the bricks of the image (interpol_pull_ws / interpol_grad_ws)
+    if (p.gate_n == -3 && p.verdict && *p.verdict != 1) return;   // trilinear grid_grad (abi.hip: interpol_grad_ws): the tiles run on the probe's verdict 1
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     Smem &sm = *reinterpret_cast<Smem *>(smem_raw);
     constexpr int D = C::D;
@@ -964,6 +965,7 @@ __global__ __launch_bounds__(C::NT) void grad1s_tiled(KParams p, const typename 
                                                      int ntiles, int nbatch, DeferArgs defer)
 {
     if (p.gate_n == -1 && p.gate && *p.gate == 1) return;   // a probe of the call gave it to the bricks of the image (interpol_pull_ws / interpol_grad_ws)
+    if (p.gate_n == -3 && p.verdict && *p.verdict != 1) return;   // trilinear grid_grad (abi.hip: interpol_grad_ws): the tiles run on the probe's verdict 1
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     Smem &sm = *reinterpret_cast<Smem *>(smem_raw);
     static_assert(C::D == 3 && C::ISO, "shifted-pair mode: 3-D, one compile-time order");
