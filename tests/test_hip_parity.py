@@ -1182,13 +1182,17 @@ def test_trilinear_pull_router():
         oracle.set_threads(1)
 
 
-def test_trilinear_push_through_owner_bricks():
+@pytest.mark.parametrize("order", [1, 0])
+def test_trilinear_push_through_owner_bricks(order):
     """Round 5: the trilinear grid_push / grid_count (and with them the image gradient of the trilinear pull's backward) take the
     owner-computes bricks when the probe finds the field rough (csrc/push_owner.hip: own_accumulate<1> -- a 2 x 2 x 2 stencil in the
     magic fixed-point format, stencil counts from a box filter of width 2).  Forced bricks, the routed default and the atomics-only
     kernel against the oracle: every bound (mixed per dim), the three extrapolation modes, sample grids that overhang the lattice,
     lattices whose end bricks fold, one to three channels with the count channel, smooth and rough; 16-bit storage against the
-    float32 kernel on the rounded source."""
+    float32 kernel on the rounded source.
+    order = 0: the NEAREST-NEIGHBOUR push / count ride the same bricks as a trilinear scatter of the rounded coordinates (own_bin rounds
+    half to even after the mask saw the real ones, iso0.py:12), behind the trilinear pull's probe (the other organisation is the generic
+    kernel, one global atomic per sample and channel)."""
     from interpol import _hip, backend
     g = torch.Generator().manual_seed(21)
     oracle.set_threads(8)
@@ -1206,16 +1210,16 @@ def test_trilinear_push_through_owner_bricks():
                     keep = torch.from_numpy(~G.f32_masked_samples(grid.numpy(), shape, ex))
                     assert keep.float().mean() > 0.5
                     src = src * keep[:, None]
-                    want = oracle.grid_push(src.double().numpy(), grid.double().numpy(), list(shape), b, [1], ex)
+                    want = oracle.grid_push(src.double().numpy(), grid.double().numpy(), list(shape), b, [order], ex)
                     ones = keep[:, None].double().numpy()
-                    want_c = oracle.grid_push(ones, grid.double().numpy(), list(shape), b, [1], ex)
+                    want_c = oracle.grid_push(ones, grid.double().numpy(), list(shape), b, [order], ex)
                     for name, fl in (("routed", 0), ("bricks", _hip.FLAG_BINNED_SCATTER), ("atomics", _hip.FLAG_NO_FASTPATH)):
-                        got = _hip.scatter("push", src.to(DEV), grid.to(DEV), list(shape), b, [1] * 3, ex, flags=fl, with_count=True)
-                        G.assert_close(got[:, :C].cpu().numpy(), want, rtol=1e-5, atol_rel=1e-5, what=("trilinear push", name, shape, b, ex, sigma))
+                        got = _hip.scatter("push", src.to(DEV), grid.to(DEV), list(shape), b, [order] * 3, ex, flags=fl, with_count=True)
+                        G.assert_close(got[:, :C].cpu().numpy(), want, rtol=1e-5, atol_rel=1e-5, what=("push order %d" % order, name, shape, b, ex, sigma))
                         if bool(keep.all()):
-                            G.assert_close(got[:, C:].cpu().numpy(), want_c, rtol=1e-5, atol_rel=1e-5, what=("trilinear push count", name, shape, b, ex, sigma))
-                            cnt = _hip.scatter("count", None, grid.to(DEV), list(shape), b, [1] * 3, ex, flags=fl)
-                            G.assert_close(cnt.cpu().numpy(), want_c, rtol=1e-5, atol_rel=1e-5, what=("trilinear count", name, shape, b, ex, sigma))
+                            G.assert_close(got[:, C:].cpu().numpy(), want_c, rtol=1e-5, atol_rel=1e-5, what=("push count order %d" % order, name, shape, b, ex, sigma))
+                            cnt = _hip.scatter("count", None, grid.to(DEV), list(shape), b, [order] * 3, ex, flags=fl)
+                            G.assert_close(cnt.cpu().numpy(), want_c, rtol=1e-5, atol_rel=1e-5, what=("count order %d" % order, name, shape, b, ex, sigma))
         # the image gradient of the pull's backward goes the same way (two channels: the library splits the backward), and
         # 16-bit storage: the float32 result on the rounded source, to storage rounding
         n = 64
@@ -1223,18 +1227,18 @@ def test_trilinear_push_through_owner_bricks():
         for sigma in (0.1, 6.0):
             grid = (ident + sigma * torch.randn([2, n, n, n, 3], generator=g).to(DEV)).contiguous()
             gout = torch.randn([2, 2, n, n, n], generator=g).to(DEV)
-            ref = _hip.scatter("push", gout, grid, [n] * 3, [3] * 3, [1] * 3, 1, flags=_hip.FLAG_NO_FASTPATH)
+            ref = _hip.scatter("push", gout, grid, [n] * 3, [3] * 3, [order] * 3, 1, flags=_hip.FLAG_NO_FASTPATH)
             for rd in (None, True, False):
                 backend.rough_deformations = rd
                 try:
-                    gv = _hip.pull_backward(gout, gout, grid, [3] * 3, [1] * 3, 1, True, False)[0]
+                    gv = _hip.pull_backward(gout, gout, grid, [3] * 3, [order] * 3, 1, True, False)[0]
                 finally:
                     backend.rough_deformations = None
                 assert G.rel_err(gv.cpu().numpy(), ref.cpu().numpy()) < 4e-6, (sigma, rd)
             for dt, tol in ((torch.bfloat16, 8e-3), (torch.float16, 1e-3)):
-                ref16 = _hip.scatter("push", gout.to(dt).float(), grid, [n] * 3, [3] * 3, [1] * 3, 1, flags=_hip.FLAG_NO_FASTPATH)
+                ref16 = _hip.scatter("push", gout.to(dt).float(), grid, [n] * 3, [3] * 3, [order] * 3, 1, flags=_hip.FLAG_NO_FASTPATH)
                 for fl in (0, _hip.FLAG_BINNED_SCATTER):
-                    a = _hip.scatter("push", gout.to(dt), grid, [n] * 3, [3] * 3, [1] * 3, 1, flags=fl)
+                    a = _hip.scatter("push", gout.to(dt), grid, [n] * 3, [3] * 3, [order] * 3, 1, flags=fl)
                     assert a.dtype == dt and G.rel_err(a.float().cpu().numpy(), ref16.cpu().numpy()) < tol, (dt, sigma, fl)
     finally:
         oracle.set_threads(1)

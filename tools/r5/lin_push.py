@@ -2,6 +2,7 @@ import os, sys, json
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(ROOT, "torch-interpol_amd")); sys.path.insert(0, ROOT)
 import torch, interpol
+O = int(os.environ.get("LP_ORDER", "1"))      # 1: trilinear, 0: nearest neighbour (the bricks, always)
 from interpol import _hip, backend
 dev = torch.device("cuda", 0)
 def timeit(fn, reps=5, inner=3):
@@ -30,12 +31,12 @@ for shape, oshape in (((40, 33, 50), (37, 45, 29)), ((64, 64, 64), (64, 64, 64))
                 lin = [torch.linspace(-2, n + 1, m, device=dev) for n, m in zip(shape, oshape)]
                 grid = (torch.stack(torch.meshgrid(*lin, indexing="ij"), -1)[None] + sigma * torch.randn(2, *oshape, 3, generator=g, device=dev)).contiguous()
                 b = [bound, (bound + 3) % 7, (bound + 5) % 7]
-                r = _hip.scatter("push", src.float(), grid, list(shape), b, [1] * 3, ex, flags=_hip.FLAG_NO_FASTPATH, with_count=True)
-                rc = _hip.scatter("count", None, grid, list(shape), b, [1] * 3, ex, flags=_hip.FLAG_NO_FASTPATH)
+                r = _hip.scatter("push", src.float(), grid, list(shape), b, [O] * 3, ex, flags=_hip.FLAG_NO_FASTPATH, with_count=True)
+                rc = _hip.scatter("count", None, grid, list(shape), b, [O] * 3, ex, flags=_hip.FLAG_NO_FASTPATH)
                 tol = 4e-6 if dt == torch.float32 else 8e-3
                 for fl in (0, _hip.FLAG_BINNED_SCATTER):
-                    a = _hip.scatter("push", src, grid, list(shape), b, [1] * 3, ex, flags=fl, with_count=True)
-                    c = _hip.scatter("count", None, grid, list(shape), b, [1] * 3, ex, flags=fl)
+                    a = _hip.scatter("push", src, grid, list(shape), b, [O] * 3, ex, flags=fl, with_count=True)
+                    c = _hip.scatter("count", None, grid, list(shape), b, [O] * 3, ex, flags=fl)
                     e = max(float((a.float() - r).abs().max() / r.abs().max()), float((c - rc).abs().max() / rc.abs().max()) * (tol / 4e-6 if False else 1))
                     if not e < tol:
                         bad += 1; print("BAD", shape, bound, sigma, dt, fl, e, flush=True)
@@ -43,13 +44,13 @@ print("parity: bad =", bad, flush=True)
 B, C, n = 4, 2, 256
 ident = interpol.identity_grid([n, n, n], device=dev)[None]
 x = torch.randn(B, C, n, n, n, generator=g, device=dev)
-for s in (0.0, 1.0, 2.0, 4.0, 6.0):
+for s in ((0.0, 0.1, 0.2, 0.3, 0.5, 1.0, 2.0, 6.0) if O == 0 else (0.0, 1.0, 2.0, 4.0, 6.0)):
     grid = (ident + s * torch.randn(B, n, n, n, 3, generator=g, device=dev)).contiguous()
     res = {"sigma": s}
     for name, rd in (("tiles", False), ("bricks", True), ("default", None)):
         backend.rough_deformations = rd
-        res["push_" + name] = round(timeit(lambda: _hip.scatter("push", x, grid, None, [3] * 3, [1] * 3, 1)), 3)
+        res["push_" + name] = round(timeit(lambda: _hip.scatter("push", x, grid, None, [3] * 3, [O] * 3, 1)), 3)
     backend.rough_deformations = None
-    res["gvol_default"] = round(timeit(lambda: _hip.pull_backward(x, x, grid, [3] * 3, [1] * 3, 1, True, False)), 3)
+    res["gvol_default"] = round(timeit(lambda: _hip.pull_backward(x, x, grid, [3] * 3, [O] * 3, 1, True, False)), 3)
     print(json.dumps(res), flush=True)
     del grid

@@ -162,6 +162,7 @@ __device__ __forceinline__ void scatter_direct(const KParams &p, const T *__rest
         load_xyz<GM>(p, grid, b, g, ox, oy, oz, x);
         const int64_t o = ((int64_t)ox * g.gy + oy) * g.gz + oz;
         const float m = inb_mask(p, x);
+        if (K == 1 && p.mode == MODE_ISO0) { x[0] = rintf(x[0]); x[1] = rintf(x[1]); x[2] = rintf(x[2]); }   // nearest neighbour (own_bin)
         int ii[3]; float tt[3];
 #pragma unroll
         for (int d = 0; d < 3; ++d) split(K, x[d], ii[d], tt[d]);
@@ -306,10 +307,18 @@ __global__ __launch_bounds__(NT1, 4) void own_bin(KParams p, BrickGrid bg, const
         v0[v] = Cvt<float, T>::ld(vp0[has0 ? o : 0]);
         v1[v] = Cvt<float, T>::ld(vp1[has1 ? o : 0]);
     }
+    unsigned inbits = 0;
 #pragma unroll
     for (int v = 0; v < VPT1 && !IDX; ++v) {                          // masked sources (nd.py:201-203); count: the mask itself
         const float m = inb_mask(p, c[v]);
         v0[v] = has0 ? v0[v] * m : m; v1[v] = has1 ? v1[v] * m : m;
+        if (K == 1 && m != 0.f) inbits |= 1u << v;                   // (kept for the further channels: the nearest-neighbour mode rounds c below)
+    }
+    // nearest-neighbour scatters (all orders 0; the host passes them as trilinear ones, KParams::mode still MODE_ISO0): the coordinates
+    // rounded half to even (iso0.py:12) AFTER the mask saw the real ones -- a 2 x 2 x 2 stencil at t = 0: weight 1 on the first tap, +0 elsewhere
+    if (K == 1 && !IDX && p.mode == MODE_ISO0) {
+#pragma unroll
+        for (int v = 0; v < VPT1; ++v) { c[v][0] = rintf(c[v][0]); c[v][1] = rintf(c[v][1]); c[v][2] = rintf(c[v][2]); }
     }
     // ---- brick of the first tap (nd.py:45: i0 = floor(x - (K-1)/2)), block minimum of the brick coordinates
     int bx[VPT1][3];
@@ -410,7 +419,7 @@ __global__ __launch_bounds__(NT1, 4) void own_bin(KParams p, BrickGrid bg, const
             if (pos[v] < 0) continue;
             int ox, oy, oz;
             sample_pos(g, tid + NT1 * v, ox, oy, oz);
-            vals[(int64_t)(ch - 1) * nrec + tilebase + (pos[v] & 0xffff)] = src_value<T>(p, val, b, ((int64_t)ox * gy + oy) * gz + oz, ch, inb_mask(p, c[v]));
+            vals[(int64_t)(ch - 1) * nrec + tilebase + (pos[v] & 0xffff)] = src_value<T>(p, val, b, ((int64_t)ox * gy + oy) * gz + oz, ch, K == 1 ? (float)((inbits >> v) & 1u) : inb_mask(p, c[v]));
         }
     }
     // ---- the descriptors, now that the slots have arrived.  A run whose brick's list was full is an ORPHAN: its records stay
@@ -1656,9 +1665,23 @@ static bool owner_eligible(const interpol_problem *p, const KParams &k, bool sca
     return (shared ? 8 * n * p->batch : 4 * n) >= nv;
 }
 
-// bytes of workspace the owner-computes organisation needs for this problem (0: not applicable)
-int64_t owner_workspace_bytes(const interpol_problem *p, const KParams &k, bool count_only)
+// Nearest-neighbour push / count (3-D, all orders 0; round 5): the generic kernel's one global atomic per sample and channel costs 5.7 ms
+// for 4 x 2 x 256^3 whatever the field; as a trilinear scatter of the ROUNDED coordinates (own_bin) the bricks take 2.3 - 3 ms.  The
+// organisation sees orders 1 (lattice bricks, stencil counts, flush), KParams::mode stays MODE_ISO0 and tells own_bin to round.
+int linear_pull_probe(const interpol_problem *p, const KParams &k, const void *grid, void *workspace, hipStream_t st, const int **gate_out, int thr16);
+constexpr int NEAREST_THR16 = 24;
+static bool nearest_scatter(const KParams &k) { return k.dim == 3 && k.mode == MODE_ISO0 && k.order[0] == 0 && k.order[1] == 0 && k.order[2] == 0; }
+static KParams nearest_as_trilinear(const KParams &k)
 {
+    KParams q = k;
+    if (nearest_scatter(k)) { q.order[0] = 1; q.order[1] = 1; q.order[2] = 1; }
+    return q;
+}
+
+// bytes of workspace the owner-computes organisation needs for this problem (0: not applicable)
+int64_t owner_workspace_bytes(const interpol_problem *p, const KParams &k_in, bool count_only)
+{
+    const KParams k = nearest_as_trilinear(k_in);
     if (!owner_eligible(p, k, true)) return 0;
     const int nch = count_only ? 1 : k.C + (k.cc ? 1 : 0);
     return owner::layout(k, (int)p->batch, owner::tile_count(p), nch, nullptr, nullptr, 0, shared_target(p));
@@ -1692,10 +1715,12 @@ static int launch_bin(const interpol_problem *p, const KParams &k, const BrickGr
 // returns 1 when it took the problem, 2 when it launched itself GATED behind the roughness probe (INTERPOL_FLAG_AUTO_SCATTER:
 // the caller launches the tiled / generic scatter as well, with KParams::gate = *gate_out), 0 to decline (workspace missing /
 // not eligible), else an error
-int try_owner_push(const interpol_problem *p, const KParams &k, const void *val, const void *grid, void *vol,
+int try_owner_push(const interpol_problem *p, const KParams &k_in, const void *val, const void *grid, void *vol,
                    void *workspace, int64_t workspace_bytes, hipStream_t st, const int **gate_out)
 {
     using namespace owner;
+    const bool nearest = nearest_scatter(k_in);
+    const KParams k = nearest_as_trilinear(k_in);
     if (!workspace || !owner_eligible(p, k, true)) return 0;
     const bool count_only = val == nullptr;
     const int nch = count_only ? 1 : k.C + (k.cc ? 1 : 0);
@@ -1706,13 +1731,20 @@ int try_owner_push(const interpol_problem *p, const KParams &k, const void *val,
     BrickGrid bg = brick_grid(k);
     if (shared) { bg.item = 0; bg.capd = CAPX; }                     // the items' samples meet in the same bricks
     const bool gated = !(p->flags & INTERPOL_FLAG_BINNED_SCATTER);
+    if (nearest && gated && k.sep != 0 && k.sep != 2) return 0;     // (the nearest-neighbour probe reads dense grids and displacement fields)
     // (a kernel, not hipMemsetAsync: under hipGraph capture the memset node of ROCm 7.2 was observed not to re-run on replays)
     hipLaunchKernelGGL(own_zero, dim3((unsigned)((64 + 3ll * w.nbricks + 1023) / 1024)), dim3(1024), 0, st, (int *)w.hdr, 64 + 3 * w.nbricks);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return (int)e;
     const int *gate = nullptr;
     const int B = (int)p->batch;
-    if (gated) {
+    if (gated && nearest) {
+        // the other organisation is the generic kernel, one global atomic per sample and channel: at the HBM roofline on the identity
+        // (4 x 2 x 256^3: 0.59 ms, the bricks 2.3), 4.5 ms at sigma = 1 (2.4).  The trilinear pull's probe decides (lin_probe: mean |second
+        // difference| of the coordinates; word 0 of the header is the gate, its ticket sits in words 2 - 3, the colour counters behind)
+        const int rp = linear_pull_probe(p, k, grid, w.hdr, st, &gate, NEAREST_THR16);
+        if (rp) return rp;
+    } else if (gated) {
         const int gx = (int)p->grid_shape[0], gy = (int)p->grid_shape[1], gz = (int)p->grid_shape[2];
         const int nty = (gy + TS - 1) / TS, ntz = (gz + TS - 1) / TS, ntiles = tile_count(p);
         const long long total = (long long)ntiles * B;
