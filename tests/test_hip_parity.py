@@ -761,6 +761,45 @@ def test_graph_capture_replays_correctly():
         _same(out_pbwd[0], ref[0], 1e-5, ("graph push bwd val", it)); _same(out_pbwd[1], ref[1], 2e-5, ("graph push bwd grid", it))
 
 
+def test_round5_routers_in_a_captured_graph():
+    """The routers added late in round 5 -- trilinear push (own_accumulate<1> behind own_probe), nearest-neighbour push (the same bricks
+    behind lin_probe), trilinear pull and grid_grad (lin_probe) -- captured ONCE; the replays see fields whose roughness changes (smooth,
+    rough, smooth again): every verdict is taken anew on the device, the zero-fills are kernels (no memset nodes)."""
+    from interpol import _hip
+    gen = torch.Generator().manual_seed(78)
+    n = 48
+    shape = (n, n, n)
+    vol = torch.randn([2, 2, *shape], generator=gen).to(DEV)
+    src = torch.randn([2, 2, *shape], generator=gen).to(DEV)
+    base = interpol.identity_grid(shape)[None].expand(2, *shape, 3)
+    grid = (base + 0.05 * torch.randn(base.shape, generator=gen)).contiguous().to(DEV)
+    b = [3, 1, 6]
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):                                    # warm-up on the side stream (workspaces, module loads)
+        for o in ([1] * 3, [0] * 3):
+            _hip.scatter("push", src, grid, list(shape), b, o, 1, with_count=True)
+        _hip.gather("pull", vol, grid, b, [1] * 3, 1); _hip.gather("grad", vol, grid, b, [1] * 3, 1)
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        out_p1 = _hip.scatter("push", src, grid, list(shape), b, [1] * 3, 1, with_count=True)
+        out_p0 = _hip.scatter("push", src, grid, list(shape), b, [0] * 3, 1, with_count=True)
+        out_pull = _hip.gather("pull", vol, grid, b, [1] * 3, 1)
+        out_grad = _hip.gather("grad", vol, grid, b, [1] * 3, 1)
+    for it, sigma in enumerate((0.05, 5.0, 0.5, 5.0, 0.05)):
+        vol.copy_(torch.randn(vol.shape, generator=gen)); src.copy_(torch.randn(src.shape, generator=gen))
+        grid.copy_(base + sigma * torch.randn(base.shape, generator=gen))
+        g.replay()
+        torch.cuda.synchronize()
+        nf = _hip.FLAG_NO_FASTPATH
+        _same(out_p1, _hip.scatter("push", src, grid, list(shape), b, [1] * 3, 1, flags=nf, with_count=True), 1e-5, ("graph trilinear push", it))
+        _same(out_p0, _hip.scatter("push", src, grid, list(shape), b, [0] * 3, 1, flags=nf, with_count=True), 1e-5, ("graph nearest push", it))
+        _same(out_pull, _hip.gather("pull", vol, grid, b, [1] * 3, 1, flags=nf), 1e-5, ("graph trilinear pull", it))
+        _same(out_grad, _hip.gather("grad", vol, grid, b, [1] * 3, 1, flags=nf), 2e-5, ("graph trilinear grad", it))
+
+
 def test_tiled_scatter_nonfinite_sources_keep_ieee_semantics():
     from interpol import _hip
     vol, grid, tshape, sshape = _tiled_problem(3, 1.0, seed=5)
