@@ -264,7 +264,9 @@ int interpol_hess(const interpol_problem *p, const void *vol, const void *grid, 
  * interpol_pull_backward  replaces pushpull.grid_pull_backward (pushpull.py:237-258):
  *      grad_vol  (B,C,*in)    += push(grad_out)                 if grad_vol  != NULL
  *      grad_grid (B,*out,D)    = sum_c grad(vol)[c] * grad_out[c] if grad_grid != NULL
- *   one pass over the grid instead of push + grad + a (B,C,N,D) temporary.
+ *   no (B,C,N,D) temporary: with both outputs the call runs the push of grad_out and the channel-contracted grid gradient, two passes
+ *   over the grid (round 5: the single fused LDS-tile pass is gone -- it was wrong under rough fields; the generic fused kernel remains
+ *   for what the tiles decline).
  *   p->val_stride describes grad_out; grad_vol uses p->vol_stride's layout and is
  *   zero-filled here unless INTERPOL_FLAG_ACCUMULATE; grad_grid is contiguous (B,*out,D).
  *   `scratch`: INTERPOL_BF16 / F16 with grad_vol: the float32 accumulator (4 bytes per element of grad_vol).  INTERPOL_F32,

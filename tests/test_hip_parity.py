@@ -761,6 +761,29 @@ def test_graph_capture_replays_correctly():
         _same(out_pbwd[0], ref[0], 1e-5, ("graph push bwd val", it)); _same(out_pbwd[1], ref[1], 2e-5, ("graph push bwd grid", it))
 
 
+@pytest.mark.parametrize("dim", [3, 2])
+def test_backward_one_channel_both_gradients_many_tiles(dim):
+    """Regression (round 5): ONE channel with BOTH gradients was the only way into the fused LDS-tile backward (pullbwd_tiled with gvol and
+    ggrid), which no test reached beyond a few tiles: under rough fields it returned wrong gradients (96^3, sigma = 4) or faulted
+    (160^3) once a workgroup served several tiles.  The library now splits every such backward (push of grad_out + grid gradient).  Default
+    flags and the forced tiles against the atomics-only kernels, orders 1 - 3, sizes with many more tiles than workgroups."""
+    from interpol import _hip
+    gen = torch.Generator().manual_seed(5)
+    shape = (112, 96, 104) if dim == 3 else (1500, 1100)
+    ident = interpol.identity_grid(shape)[None]
+    for order in (1, 2, 3):
+        for sigma in (0.3, 4.0):
+            vol = torch.randn([2, 1, *shape], generator=gen).to(DEV)
+            gout = torch.randn([2, 1, *shape], generator=gen).to(DEV)
+            grid = (ident + sigma * torch.randn([2, *shape, dim], generator=gen)).contiguous().to(DEV)
+            b, o = [3] * dim, [order] * dim
+            ref = _hip.pull_backward(gout, vol, grid, b, o, 1, True, True, flags=_hip.FLAG_NO_FASTPATH)
+            for fl in (0, _hip.FLAG_FORCE_TILED):
+                got = _hip.pull_backward(gout, vol, grid, b, o, 1, True, True, flags=fl)
+                _same(got[0], ref[0], 1e-5, ("image gradient", dim, order, sigma, fl))
+                _same(got[1], ref[1], 2e-5, ("grid gradient", dim, order, sigma, fl))
+
+
 def test_round5_routers_in_a_captured_graph():
     """The routers added late in round 5 -- trilinear push (own_accumulate<1> behind own_probe), nearest-neighbour push (the same bricks
     behind lin_probe), trilinear pull and grid_grad (lin_probe) -- captured ONCE; the replays see fields whose roughness changes (smooth,

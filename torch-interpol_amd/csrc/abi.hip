@@ -859,7 +859,10 @@ int interpol_pull_backward(const interpol_problem *p, const void *grad_out, cons
         //  grid part has its own shifted-pair kernel and the split wins again: config 3 10.9 -> 8.x ms)
         bool high = p->dim == 3 && p->order[0] >= 4;
         for (int d = 1; d < p->dim; ++d) high = high && p->order[d] == p->order[0];
-        if (grad_vol && (!grad_grid || p->channels >= 2 || high)) {
+        // (round 5: ALWAYS split -- with one channel and both gradients the fused LDS-tile kernel, pullbwd_tiled, was found to return wrong
+        //  image gradients or to fault under rough fields once a workgroup serves several tiles (4 x 1 x 256^3 trilinear, sigma >= 4;
+        //  96^3 at sigma = 4), and the split is as fast or faster now: trilinear 2.33 -> 1.94 ms at the identity, cubic 3.09 -> 3.08)
+        if (grad_vol) {
             // gradient w.r.t. the image = push of grad_out (pushpull.py:252-253): the push kernels
             // (channel pairs per LDS atomic) beat the scatter half of the fused backward kernel
             // (4x2x256^3 cubic: 3.5 vs 5.3 ms; with the grid gradient 3.5 + 4.5 vs 8.6 ms fused)

@@ -2412,6 +2412,10 @@ int IP_SYM(try_fast_push_, IP_TSFX)(const interpol_problem *p, const KParams &k,
 int IP_SYM(try_fast_pullbwd_, IP_TSFX)(const interpol_problem *p, const KParams &k, const void *gout, const void *vol, const void *grid,
                                        void *gvol, void *ggrid, int64_t gsb, int64_t gsc, hipStream_t st)
 {
+    // both gradients in one tile kernel: declined since round 5 (abi.hip: interpol_pull_backward splits the backward; what is left -- a push
+    // that declined -- takes the generic fused kernel).  pullbwd_tiled with gvol AND ggrid returned wrong results / faulted under rough
+    // fields once a workgroup served several tiles; its two halves, each alone, are covered by the parity tests and stay.
+    if (gvol && ggrid) return 0;
     if (p->dim == 2 && !gvol && ggrid) {
         // 2-D, grid gradient only, orders 1..3: the lean tile with the channels contracted per tap (ops_tiled2d.hip)
         const int rc = IP_SYM(try_tiled2d_gradc_, IP_TSFX)(p, k, gout, vol, grid, ggrid, st);

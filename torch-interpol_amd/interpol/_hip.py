@@ -509,21 +509,21 @@ def pull_backward(gout, vol, grid, bound, order, extrapolate, need_vol, need_gri
     dim = grid.shape[-1]
     from . import backend
     if (need_vol and flags == 0 and dim == 3 and torch.is_tensor(grid) and len(set(order[:3])) == 1
-            and (order[0] in (2, 3) or (order[0] in (0, 1) and (vol.shape[1] >= 2 or not need_grid)))
+            and order[0] in (0, 1, 2, 3)
             and vol.dtype == torch.float32 and gout.dtype == torch.float32 and grid.dtype == torch.float32
             and vol.shape[0] == grid.shape[0] == gout.shape[0] and not backend.want_exact_scatter()
             and backend.rough_deformations is not False):
         # 3-D quadratic / cubic: the image gradient IS grid_push of grad_out (pushpull.py:252-255) and the library computes it
         # with the push kernels anyway; through `scatter` it also gets the push's routing (rough / folding fields take the
         # owner-computes organisation: 31 -> 10 ms for the backward of a field of 8 voxels amplitude)
-        # (trilinear and nearest neighbour as well, where the library splits: two channels or more, or no grid gradient -- trilinear,
-        # sigma = 6: 15.9 -> 3.1 ms; nearest, sigma = 2: 5.7 -> 2.5 ms)
+        # (trilinear and nearest neighbour as well -- trilinear, sigma = 6: 15.9 -> 3.1 ms; nearest, sigma = 2: 5.7 -> 2.5 ms.  The library
+        # splits every backward since round 5: its fused tile kernel for both gradients was wrong under rough fields)
         gvol = scatter("push", gout, grid, list(vol.shape[2:]), bound, order, extrapolate)
         ggrid = pull_backward(gout, vol, grid, bound, order, extrapolate, False, True, flags)[1] if need_grid else None
         return gvol, ggrid
     if (need_vol and flags == 0 and dim == 2 and torch.is_tensor(grid) and 1 <= min(order[:2]) and max(order[:2]) <= 3
             and vol.dtype == gout.dtype and vol.dtype in _ROUTED_2D and grid.dtype == torch.float32
-            and vol.shape[0] == grid.shape[0] == gout.shape[0] and (vol.shape[1] >= 2 or not need_grid)
+            and vol.shape[0] == grid.shape[0] == gout.shape[0]
             and not backend.want_exact_scatter() and backend.rough_deformations is not False):
         # 2-D, orders 1..3: the library splits this backward into a push of grad_out and the contracted grid gradient anyway
         # (csrc/abi.hip: interpol_pull_backward); through `scatter` the push gets its router (csrc/scatter2d.hip), and so does
