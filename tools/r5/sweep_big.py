@@ -24,9 +24,11 @@ def check(name, got, ref, tol, what):
             bad += 1
             print("BAD", name, i, what, e, flush=True)
 BIG = os.environ.get("SWEEP_BIG") == "1"          # 2 x C x 256^3 / 2 x C x 4096^2, orders 1 and 3: the sizes of the benchmark configs
-for dim, shape in (((3, (256, 256, 256)), (2, (4096, 4096))) if BIG else ((3, (112, 96, 104)), (2, (1500, 1100)))):
+MANY = os.environ.get("SWEEP_MANY") == "1"        # many small batch items instead: 300 x C x 24x20x28 / 300 x C x 70x90
+NB = 300 if MANY else 2
+for dim, shape in (((3, (256, 256, 256)), (2, (4096, 4096))) if BIG else (((3, (24, 20, 28)), (2, (70, 90))) if MANY else ((3, (112, 96, 104)), (2, (1500, 1100))))):
     for order in ((1, 3) if BIG else (0, 1, 2, 3, 4, 5, 7)):
-        if order == 7 and dim == 3:
+        if order == 7 and dim == 3 and not MANY:
             shape_ = (64, 72, 80)
         else:
             shape_ = shape
@@ -34,9 +36,9 @@ for dim, shape in (((3, (256, 256, 256)), (2, (4096, 4096))) if BIG else ((3, (1
         for C in (1, 3):
             for sigma in ((0.3, 6.0) if BIG else (0.3, 4.0)):
                 for bound, ex in (((3, 1), (0, 0)) if BIG else ((3, 1), (0, 0), (6, 2))):
-                    vol = torch.randn([2, C, *shape_], generator=gen).to(dev)
-                    src = torch.randn([2, C, *shape_], generator=gen).to(dev)
-                    grid = (ident + sigma * torch.randn([2, *shape_, dim], generator=gen)).contiguous().to(dev)
+                    vol = torch.randn([NB, C, *shape_], generator=gen).to(dev)
+                    src = torch.randn([NB, C, *shape_], generator=gen).to(dev)
+                    grid = (ident + sigma * torch.randn([NB, *shape_, dim], generator=gen)).contiguous().to(dev)
                     b, o = [bound] * dim, [order] * dim
                     what = (dim, order, C, sigma, bound, ex)
                     check("pull", _hip.gather("pull", vol, grid, b, o, ex), _hip.gather("pull", vol, grid, b, o, ex, flags=NF), 1e-5, what)
