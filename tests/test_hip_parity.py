@@ -784,6 +784,36 @@ def test_backward_one_channel_both_gradients_many_tiles(dim):
                 _same(got[1], ref[1], 2e-5, ("grid gradient", dim, order, sigma, fl))
 
 
+@pytest.mark.parametrize("dim,shape", [(3, (112, 96, 104)), (2, (1500, 1100))])
+def test_default_routing_where_a_workgroup_serves_several_tiles(dim, shape):
+    """The regime the other tests' shapes do not reach (and where the one-channel both-gradients backward hid its bug for four rounds):
+    more sample tiles than workgroups.  Every operator with the default flags against the atomics-only / generic kernels: orders 0 - 5,
+    one and three channels, a rough field, three bounds x extrapolation modes (tools/r5/sweep_big*.py are the long form: smooth fields,
+    order 7, mixed orders, displacement and separable grids, shared targets, float64 and 16-bit storage, many small batch items)."""
+    from interpol import _hip
+    gen = torch.Generator().manual_seed(11)
+    NF = _hip.FLAG_NO_FASTPATH
+    ident = interpol.identity_grid(shape)[None]
+    for order in (0, 1, 2, 3, 4, 5):
+        for C in (1, 3):
+            bound, ex = [(3, 1), (0, 0), (6, 2)][(order + C) % 3]
+            vol = torch.randn([2, C, *shape], generator=gen).to(DEV)
+            src = torch.randn([2, C, *shape], generator=gen).to(DEV)
+            grid = (ident + 4.0 * torch.randn([2, *shape, dim], generator=gen)).contiguous().to(DEV)
+            b, o = [bound] * dim, [order] * dim
+            what = (dim, order, C, bound, ex)
+            _same(_hip.gather("pull", vol, grid, b, o, ex), _hip.gather("pull", vol, grid, b, o, ex, flags=NF), 1e-5, ("pull",) + what)
+            _same(_hip.gather("grad", vol, grid, b, o, ex), _hip.gather("grad", vol, grid, b, o, ex, flags=NF), 2e-5, ("grad",) + what)
+            _same(_hip.scatter("push", src, grid, list(shape), b, o, ex, with_count=True),
+                  _hip.scatter("push", src, grid, list(shape), b, o, ex, flags=NF, with_count=True), 1e-5, ("push",) + what)
+            for nv, ng in ((True, True), (True, False), (False, True)):
+                for name, fn, x, y in (("pull_backward", _hip.pull_backward, src, vol), ("push_backward", _hip.push_backward, vol, src)):
+                    got, ref = fn(x, y, grid, b, o, ex, nv, ng), fn(x, y, grid, b, o, ex, nv, ng, flags=NF)
+                    for a, r in zip(got, ref):
+                        if a is not None:
+                            _same(a, r, 2e-5, (name, nv, ng) + what)
+
+
 def test_round5_routers_in_a_captured_graph():
     """The routers added late in round 5 -- trilinear push (own_accumulate<1> behind own_probe), nearest-neighbour push (the same bricks
     behind lin_probe), trilinear pull and grid_grad (lin_probe) -- captured ONCE; the replays see fields whose roughness changes (smooth,
