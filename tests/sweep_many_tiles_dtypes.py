@@ -1,7 +1,7 @@
 #!/usr/bin/env python
-"""sweep_big.py's regime in float64 and float16 storage (3-D and 2-D, orders 1 - 3)."""
+"""sweep_many_tiles.py's regime in float64 and float16 storage (3-D and 2-D, orders 1 - 3)."""
 import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "torch-interpol_amd")); sys.path.insert(0, ROOT)
 import torch, interpol
 from interpol import _hip
@@ -41,3 +41,4 @@ for dim, shape in ((3, (112, 96, 104)), (2, (1500, 1100))):
                     torch.cuda.synchronize()
         print("done", dim, dt, "bad so far", bad, flush=True)
 print("sweep3: bad =", bad, flush=True)
+sys.exit(1 if bad else 0)

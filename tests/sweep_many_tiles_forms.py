@@ -1,8 +1,8 @@
 #!/usr/bin/env python
-"""sweep_big.py's regime (several tiles per workgroup) for the other forms of input: mixed orders, displacement fields, separable lattices,
+"""sweep_many_tiles.py's regime (several tiles per workgroup) for the other forms of input: mixed orders, displacement fields, separable lattices,
 a target shared by the batch items."""
 import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "torch-interpol_amd")); sys.path.insert(0, ROOT)
 import torch, interpol
 from interpol import _hip
@@ -24,7 +24,7 @@ def check(name, got, ref, tol, what):
             print("BAD", name, i, what, e, flush=True)
 for dim, shape in ((3, (112, 96, 104)), (2, (1500, 1100))):
     ident = interpol.identity_grid(shape)[None].to(dev)
-    for orders in ([1, 2, 3][:dim], [3, 1, 2][:dim], [0, 3, 3][:dim], [1] * dim, [3] * dim):
+    for orders in (([1, 2, 3][:dim], [3, 1, 2][:dim]) if os.environ.get("SWEEP_TRIM") == "1" else ([1, 2, 3][:dim], [3, 1, 2][:dim], [0, 3, 3][:dim], [1] * dim, [3] * dim)):
         for C in (1, 2):
             for sigma in (0.3, 4.0):
                 vol = torch.randn([2, C, *shape], generator=gen).to(dev)
@@ -59,3 +59,4 @@ for dim, shape in ((3, (112, 96, 104)), (2, (1500, 1100))):
                 torch.cuda.synchronize()
         print("done", dim, orders, "bad so far", bad, flush=True)
 print("sweep2: bad =", bad, flush=True)
+sys.exit(1 if bad else 0)

@@ -788,7 +788,7 @@ def test_backward_one_channel_both_gradients_many_tiles(dim):
 def test_default_routing_where_a_workgroup_serves_several_tiles(dim, shape):
     """The regime the other tests' shapes do not reach (and where the one-channel both-gradients backward hid its bug for four rounds):
     more sample tiles than workgroups.  Every operator with the default flags against the atomics-only / generic kernels: orders 0 - 5,
-    one and three channels, a rough field, three bounds x extrapolation modes (tools/r5/sweep_big*.py are the long form: smooth fields,
+    one and three channels, a rough field, three bounds x extrapolation modes (tests/sweep_many_tiles*.py are the long form: smooth fields,
     order 7, mixed orders, displacement and separable grids, shared targets, float64 and 16-bit storage, many small batch items)."""
     from interpol import _hip
     gen = torch.Generator().manual_seed(11)
@@ -812,6 +812,69 @@ def test_default_routing_where_a_workgroup_serves_several_tiles(dim, shape):
                     for a, r in zip(got, ref):
                         if a is not None:
                             _same(a, r, 2e-5, (name, nv, ng) + what)
+
+
+@pytest.mark.parametrize("n", [96, 160])
+def test_tile_grid_gradient_many_tiles(n):
+    """Regression (round 6): the LDS-tile kernel of the grid gradient of pull_backward (pullbwd_tiled, csrc/ops_tiled.hip) where a workgroup
+    serves several tiles of a rough field -- the regime in which its round-5 form left entries unwritten (tools/r6/repro_ggrid.py,
+    profiles/r06_pullbwd_repro.txt).  FORCE_TILED with debug bit 16 (no class-sorted / shifted-pair kernels in front of it) reaches
+    the kernel for every order; against the generic kernels.  Semantics: pushpull.py:256-257."""
+    from interpol import _hip
+    gen = torch.Generator().manual_seed(5)
+    shape = (n, n, n)
+    ident = interpol.identity_grid(shape)[None]
+    for C in (1, 2):
+        for order in ([1] * 3, [2] * 3, [3] * 3, [1, 2, 3], [2, 3, 5], [4] * 3, [5] * 3, [7] * 3):
+            if n > 96 and (C == 2 or order[0] > 5):
+                continue
+            vol = torch.randn([2, C, *shape], generator=gen).to(DEV)
+            gout = torch.randn([2, C, *shape], generator=gen).to(DEV)
+            grid = (ident + 4.0 * torch.randn([2, *shape, 3], generator=gen)).contiguous().to(DEV)
+            ref = _hip.pull_backward(gout, vol, grid, [3] * 3, order, 1, False, True, flags=_hip.FLAG_NO_FASTPATH)[1]
+            for fl in (_hip.FLAG_FORCE_TILED, _hip.FLAG_FORCE_TILED | (16 << 8)):
+                got = _hip.pull_backward(gout, vol, grid, [3] * 3, order, 1, False, True, flags=fl)[1]
+                _same(got, ref, 2e-5, ("grid gradient", n, C, order, fl))
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("dim,shape", [(3, (112, 96, 104)), (2, (1500, 1100))])
+def test_many_tiles_default_routing_against_the_oracle(dim, shape):
+    """The same regime -- more sample tiles and bricks than workgroups -- with the DEFAULT routing compared DIRECTLY with the C oracle
+    (float64 evaluation of the same float32 inputs, all host cores), not with the generic HIP kernels: pull, push + count, grad, and both
+    gradients of pull_backward and push_backward; orders 1, 3, 5, one and two channels, a gentle and a rough field, two bounds.
+    Reference: nd.py:81-288, pushpull.py:237-281."""
+    import os
+    from interpol import _hip
+    gen = torch.Generator().manual_seed(23)
+    ident = interpol.identity_grid(shape)[None]
+    oracle.set_threads(os.cpu_count() or 8)
+    try:
+        for order in (1, 3, 5):
+            for C in (1, 2):
+                for sigma in (0.3, 4.0):
+                    bound = 3 if (order + C + (sigma > 1)) % 2 else 6                     # dct2 / dft
+                    b, o = [bound] * dim, [order] * dim
+                    rtol, atol_rel = G.fp32_tol(o)
+                    vol = torch.randn([2, C, *shape], generator=gen)
+                    src = torch.randn([2, C, *shape], generator=gen)
+                    grid = (ident + sigma * torch.randn([2, *shape, dim], generator=gen)).contiguous()
+                    vd, sd, gd = vol.to(DEV), src.to(DEV), grid.to(DEV)
+                    v64, s64, g64 = vol.double(), src.double(), grid.double()
+                    what = (dim, order, C, sigma, bound)
+                    G.assert_close(_hip.gather("pull", vd, gd, b, o, 1).cpu().numpy(), oracle.grid_pull(v64, g64, b, o, 1), rtol, atol_rel, ("pull",) + what)
+                    G.assert_close(_hip.gather("grad", vd, gd, b, o, 1).cpu().numpy(), oracle.grid_grad(v64, g64, b, o, 1), 2 * rtol, 2 * atol_rel, ("grad",) + what)
+                    got = _hip.scatter("push", sd, gd, list(shape), b, o, 1, with_count=True).cpu().numpy()
+                    G.assert_close(got[:, :C], oracle.grid_push(s64, g64, list(shape), b, o, 1), rtol, atol_rel, ("push",) + what)
+                    G.assert_close(got[:, C:], oracle.grid_count(g64, list(shape), b, o, 1), rtol, atol_rel, ("count",) + what)
+                    for name, fn, ofn, x, x64, y, y64 in (("pull_backward", _hip.pull_backward, oracle.grid_pull_backward, sd, s64, vd, v64),
+                                                          ("push_backward", _hip.push_backward, oracle.grid_push_backward, vd, v64, sd, s64)):
+                        gi, gg = fn(x, y, gd, b, o, 1, True, True)
+                        ri, rg = ofn(x64, y64, g64, b, o, 1)
+                        G.assert_close(gi.cpu().numpy(), ri, rtol, atol_rel, (name, "value") + what)
+                        G.assert_close(gg.cpu().numpy(), rg, 2 * rtol, 2 * atol_rel, (name, "grid") + what)
+    finally:
+        oracle.set_threads(1)
 
 
 def test_round5_routers_in_a_captured_graph():

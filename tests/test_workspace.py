@@ -22,11 +22,24 @@ def test_optional_workspace_policy(monkeypatch):
     big = 128 << 20
     ws = _hip._optional_workspace(big, dev)
     assert ws is not None and ws.numel() == big and ws.device.type == "cuda"
-    # one buffer per (device, stream), kept between calls and shared by smaller requests
+    # one buffer per (device, stream, host thread), kept between calls and shared by smaller requests
     assert _hip._optional_workspace(big // 2, dev) is ws
     with torch.cuda.stream(torch.cuda.Stream(dev)):
         assert _hip._optional_workspace(1 << 20, dev) is not ws
-    del ws
+    # ... and per HOST THREAD (ctypes releases the GIL inside the library -- two threads on one stream must not
+    # interleave their kernels on one buffer)
+    import threading
+    other = []
+    th = threading.Thread(target=lambda: other.append(_hip._optional_workspace(big // 2, dev)))
+    th.start(); th.join()
+    assert other[0] is not None and other[0] is not ws
+    # at most _WS_MAX buffers are kept, least recently used first out
+    streams = [torch.cuda.Stream(dev) for _ in range(_hip._WS_MAX + 2)]
+    for st in streams:
+        with torch.cuda.stream(st):
+            _hip._optional_workspace(1 << 20, dev)
+    assert len(_hip._WS_CACHE) == _hip._WS_MAX
+    del ws, other
     _hip.release_workspaces()
     assert _hip._optional_workspace(0, dev) is None
     # not even half of what is available: declined without an allocation attempt

@@ -1788,14 +1788,27 @@ __global__ __launch_bounds__(C::NT) void push_tiled(KParams p, const typename C:
 }
 
 // ---------------------------------------------------------------------------
-// Fused backward of pull (pushpull.py:237-258):
-//   gvol[b,c,tap] += w * mask * gout[b,c,o]                        (if gvol)
-//   ggrid[b,o,d]   = mask * sum_c gout[b,c,o] * d/dx_d pull(vol)   (if ggrid)
+// Grid gradient of the backward of pull (pushpull.py:256-257), the channels contracted per sample:
+//   ggrid[b,o,d] = mask * sum_c gout[b,c,o] * d/dx_d pull(vol[b,c])(x_o)
+// Structured like gather_tiled<C, true> (one staged box per channel, the three derivative sums of a sample kept in registers over
+// the channels and stored behind the last one).
+//
+// Round 6: this kernel used to take gvol as well (the image gradient scattered from the same tile).  That fused mode, and the grid
+// gradient of THIS kernel under it, returned wrong or unwritten values for the isotropic 16^3 tiles of orders 1 - 3 once a workgroup
+// served several tiles of a rough field (tools/r6/repro_ggrid.py reproduces it on the round-5 source, commit 0f8bfa2: 2 x C x 96^3,
+// sigma = 4, FORCE_TILED + debug bit 16; profiles/r06_pullbwd_repro.txt).  What the reproducer showed: the grid gradient alone fails the same way (so the scatter half is not
+// the cause), the wrong entries are entries the kernel never wrote (they change with the allocation, zeros in fresh memory), the
+// failure needs neither the density pass of Box::build nor the tile hand-back, and it disappears under EITHER of two changes that do
+// not touch the arithmetic -- the XCD-wise work range of the other gather kernels instead of a plain stride, or storing a sample's
+// sums inside the channel loop instead of in a second loop over the samples behind it -- and even under a recompilation with those
+// two alternatives present but switched off.  No missing barrier or stale LDS state was found by reading; the cause is not isolated
+// (a code-generation or timing sensitivity of the old loop nest is what the evidence points to).  The scatter half is gone (every
+// backward is split since round 5: push of grad_out + this gradient), the gather half has the loop nest of gather_tiled, which the
+// many-tiles sweeps have exercised since round 5, and tests/test_hip_parity.py::test_tile_grid_gradient_many_tiles pins the regime.
 // ---------------------------------------------------------------------------
 template <typename C>
 __global__ __launch_bounds__(C::NT) void pullbwd_tiled(KParams p, const typename C::T *__restrict__ gout, const typename C::T *__restrict__ vol,
-                                                       const float *__restrict__ grid, float *__restrict__ gvol,
-                                                       float *__restrict__ ggrid, int64_t gvol_sb, int64_t gvol_sc,
+                                                       const float *__restrict__ grid, float *__restrict__ ggrid,
                                                        int gx, int gy, int gz, int nty, int ntz, int ntiles, int nbatch, DeferArgs defer)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -1803,15 +1816,15 @@ __global__ __launch_bounds__(C::NT) void pullbwd_tiled(KParams p, const typename
     constexpr int D = C::D;
     using T = typename C::T;
     const int tid = threadIdx.x;
-    const Lattice L = make_lattice<C>(p, (int)sizeof(T));    // vol strides; gvol (float) shares the element offsets
-    const WorkRange wr(ntiles * nbatch, false);
+    const Lattice L = make_lattice<C>(p, (int)sizeof(T));
+    const WorkRange wr(ntiles * nbatch);
     for (int work = wr.first; work < wr.end; work += wr.step) {
     const int64_t b = work / ntiles;
     const TileGeom g = tile_geom<C>(work % ntiles, gx, gy, gz, nty, ntz);
     Box<C> box;
-    const unsigned fastmask = box.template build<true>(p, L, grid, b, g, sm);
-    const int nslow = sm.nslow, dmax = sm.dmax;
-    if (hand_back<C>(defer, work, b, g, nslow, p, grid, sm, gvol != nullptr)) continue;
+    const unsigned fastmask = box.build(p, L, grid, b, g, sm);
+    const int nslow = sm.nslow;
+    if (hand_back<C>(defer, work, b, g, nslow, p, grid, sm)) continue;
 
     float gg[C::VPT][3];
 #pragma unroll
@@ -1820,75 +1833,59 @@ __global__ __launch_bounds__(C::NT) void pullbwd_tiled(KParams p, const typename
     for (int c = 0; c < p.C; ++c) {
         const T *vc = vol + b * p.vol_sb + c * p.vol_sc;
         const T *gc = gout + b * p.val_sb + c * p.val_sc;
-        if (ggrid) {
-            __syncthreads();
-            stage_box<C>(vc, box.S, sm);
-            __syncthreads();
-#pragma unroll
-            for (int v = 0; v < C::VPT; ++v) {
-                const bool fast = (fastmask >> v) & 1;
-                if (!fast && nslow <= SLOWCAP) continue;
-                const Sample<C> s = load_sample<C>(p, grid, b, g, tid, v);
-                if (!s.valid) continue;
-                float r[4] = { 0.f, 0.f, 0.f, 0.f };
-                if (fast) gather_box<C, true>(sm, box, s, L, r);
-                else {
-                    if (D == 3) r[1] = gather_one_thread<T>(L, vc, s.i0[0], s.i0[1], s.i0[2], s.t[0], s.t[1], s.t[2], 0);
-                    r[2] = gather_one_thread<T>(L, vc, s.i0[0], s.i0[1], s.i0[2], s.t[0], s.t[1], s.t[2], 1);
-                    r[3] = gather_one_thread<T>(L, vc, s.i0[0], s.i0[1], s.i0[2], s.t[0], s.t[1], s.t[2], 2);
-                }
-                const float gv = Cvt<float, T>::ld(gc[s.o]);
-                const float go = (p.extrapolate != 1 && !s.inb) ? 0.f * gv : gv;
-                gg[v][0] = __builtin_fmaf(r[1], go, gg[v][0]);
-                gg[v][1] = __builtin_fmaf(r[2], go, gg[v][1]);
-                gg[v][2] = __builtin_fmaf(r[3], go, gg[v][2]);
-            }
-            // slow list: gradient of the slow samples, accumulated straight into ggrid
-            // (the same lane of the same wave owns a slow sample for every channel)
-            if (nslow > 0 && nslow <= SLOWCAP) {
-                const int wave = tid >> 6, lane = tid & 63;
-                const int NTAP = (L.k[0] + 1) * (L.k[1] + 1) * (L.k[2] + 1);
-                for (int sidx = wave; sidx < nslow; sidx += C::NT / 64) {
-                    float x[3];
-                    const int64_t o = slow_sample<C>(g, sm.slow[sidx], p, grid, b, x);
-                    float a[3] = { 0.f, 0.f, 0.f };
-                    for (int t0 = 0; t0 < NTAP; t0 += 64) {
-                        int off; float gr[3];
-                        tap_weight<C>(L, x[0], x[1], x[2], t0 + lane, &off, gr);
-                        const float vv = (t0 + lane < NTAP) ? Cvt<float, T>::ld(vc[off]) : 0.f;
-                        a[0] += gr[0] * vv; a[1] += gr[1] * vv; a[2] += gr[2] * vv;
-                    }
-                    const float go = (p.extrapolate != 1 && !coords_inb<C>(p, x)) ? 0.f : Cvt<float, T>::ld(gc[o]);
-#pragma unroll
-                    for (int d = 0; d < D; ++d) {
-                        const float r = wave_sum(a[(3 - D) + d]);
-                        if (lane == 0) {
-                            float *q = ggrid + (b * p.N + o) * D + d;
-                            *q = (c == 0 ? 0.f : *q) + r * go;
-                        }
-                    }
-                }
-            }
-        }
-        if (gvol) {
-            float *qc = gvol + b * gvol_sb + c * gvol_sc;
-            scatter_channel<C>(p, L, grid, b, g, box, fastmask, nslow, dmax, -1, false, qc, sm,
-                [&](const Sample<C> &s) { const float gv = Cvt<float, T>::ld(gc[s.o]); return (p.extrapolate != 1 && !s.inb) ? 0.f * gv : gv; },
-                [&](int64_t o) { return Cvt<float, T>::ld(gc[o]); });
-        }
-    }
-    if (ggrid) {
+        __syncthreads();                               // previous channel's readers are done
+        stage_box<C>(vc, box.S, sm);
+        __syncthreads();
 #pragma unroll
         for (int v = 0; v < C::VPT; ++v) {
             const bool fast = (fastmask >> v) & 1;
-            if (!fast && nslow <= SLOWCAP) continue;   // slow-list samples were written above
-            int ox, oy, oz;
-            sample_pos<C>(g, tid, v, ox, oy, oz);
-            if (!(ox < gx && oy < gy && oz < gz)) continue;
-            const int64_t o = ((int64_t)ox * gy + oy) * gz + oz;
-            float *q = ggrid + (b * p.N + o) * D;
+            if (!fast && nslow <= SLOWCAP) continue;   // invalid, or waiting in the slow list
+            const Sample<C> s = load_sample<C>(p, grid, b, g, tid, v);
+            if (!s.valid) continue;
+            float r[4] = { 0.f, 0.f, 0.f, 0.f };
+            if (fast) gather_box<C, true>(sm, box, s, L, r);
+            else {
+                // slow list overflowed (pathological deformation): per-thread global gather
+                if (D == 3) r[1] = gather_one_thread<T>(L, vc, s.i0[0], s.i0[1], s.i0[2], s.t[0], s.t[1], s.t[2], 0);
+                r[2] = gather_one_thread<T>(L, vc, s.i0[0], s.i0[1], s.i0[2], s.t[0], s.t[1], s.t[2], 1);
+                r[3] = gather_one_thread<T>(L, vc, s.i0[0], s.i0[1], s.i0[2], s.t[0], s.t[1], s.t[2], 2);
+            }
+            const float gv = Cvt<float, T>::ld(gc[s.o]);
+            const float go = (p.extrapolate != 1 && !s.inb) ? 0.f * gv : gv;
+            gg[v][0] = __builtin_fmaf(r[1], go, gg[v][0]);
+            gg[v][1] = __builtin_fmaf(r[2], go, gg[v][1]);
+            gg[v][2] = __builtin_fmaf(r[3], go, gg[v][2]);
+            if (c == p.C - 1) {                        // the sample's sums are complete: stored here, like gather_tiled's outputs
+                float *q = ggrid + (b * p.N + s.o) * D;
 #pragma unroll
-            for (int d = 0; d < D; ++d) q[d] = gg[v][(3 - D) + d];
+                for (int d = 0; d < D; ++d) q[d] = gg[v][(3 - D) + d];
+            }
+        }
+        // slow list: one wave per sample, lanes = taps; accumulated straight into ggrid (the same lane of the same wave owns a slow
+        // sample for every channel)
+        if (nslow > 0 && nslow <= SLOWCAP) {
+            const int wave = tid >> 6, lane = tid & 63;
+            const int NTAP = (L.k[0] + 1) * (L.k[1] + 1) * (L.k[2] + 1);
+            for (int sidx = wave; sidx < nslow; sidx += C::NT / 64) {
+                float x[3];
+                const int64_t o = slow_sample<C>(g, sm.slow[sidx], p, grid, b, x);
+                float a[3] = { 0.f, 0.f, 0.f };
+                for (int t0 = 0; t0 < NTAP; t0 += 64) {
+                    int off; float gr[3];
+                    tap_weight<C>(L, x[0], x[1], x[2], t0 + lane, &off, gr);
+                    const float vv = (t0 + lane < NTAP) ? Cvt<float, T>::ld(vc[off]) : 0.f;
+                    a[0] += gr[0] * vv; a[1] += gr[1] * vv; a[2] += gr[2] * vv;
+                }
+                const float go = (p.extrapolate != 1 && !coords_inb<C>(p, x)) ? 0.f : Cvt<float, T>::ld(gc[o]);
+#pragma unroll
+                for (int d = 0; d < D; ++d) {
+                    const float r = wave_sum(a[(3 - D) + d]);
+                    if (lane == 0) {
+                        float *q = ggrid + (b * p.N + o) * D + d;
+                        *q = (c == 0 ? 0.f : *q) + r * go;
+                    }
+                }
+            }
         }
     }
     __syncthreads();                                   // the next tile reuses the LDS tables / lists
@@ -2232,9 +2229,9 @@ static int launch_pullbwd(const interpol_problem *p, const KParams &k, const voi
                           void *gvol, void *ggrid, int64_t gsb, int64_t gsc, hipStream_t st)
 {
     using T = typename C::T;
-    if (k.sep) return 0;                                   // declined: generic kernels
+    if (k.sep || gvol || !ggrid) return 0;                 // declined: generic kernels (the tiles hold the grid gradient only, see pullbwd_tiled)
     if constexpr (C::D == 3 && C::ISO && C::VPT == 1) {
-        if (!gvol && ggrid && !(k.dbg & 16)) {
+        if (!(k.dbg & 16)) {
             // grid gradient alone, high orders: the shifted-pair gather
             using CW = typename WideTile<C>::type;
             const int attr1 = big_lds<CW>(gradc1s_tiled<CW>);
@@ -2252,9 +2249,9 @@ static int launch_pullbwd(const interpol_problem *p, const KParams &k, const voi
     const TileCount<C> t(p);
     IP_DEFER(df, t, C);
     hipLaunchKernelGGL((pullbwd_tiled<C>), t.grid((int)p->batch), dim3(C::NT), smem_bytes<C>(), st,
-                       k, (const T *)gout, (const T *)vol, (const float *)grid, (float *)gvol, (float *)ggrid,
-                       gsb, gsc, t.gx, t.gy, t.gz, t.nty, t.ntz, t.ntiles(), (int)p->batch, df.args);
-    IP_CHECK_LAUNCH_THEN(df.desc ? DeferOps<T>::pullbwd(k, gout, vol, grid, gvol, ggrid, gsb, gsc, df.tl, st) : 0);
+                       k, (const T *)gout, (const T *)vol, (const float *)grid, (float *)ggrid,
+                       t.gx, t.gy, t.gz, t.nty, t.ntz, t.ntiles(), (int)p->batch, df.args);
+    IP_CHECK_LAUNCH_THEN(df.desc ? DeferOps<T>::pullbwd(k, gout, vol, grid, nullptr, ggrid, 0, 0, df.tl, st) : 0);
 }
 
 template <typename C>
@@ -2412,10 +2409,9 @@ int IP_SYM(try_fast_push_, IP_TSFX)(const interpol_problem *p, const KParams &k,
 int IP_SYM(try_fast_pullbwd_, IP_TSFX)(const interpol_problem *p, const KParams &k, const void *gout, const void *vol, const void *grid,
                                        void *gvol, void *ggrid, int64_t gsb, int64_t gsc, hipStream_t st)
 {
-    // both gradients in one tile kernel: declined since round 5 (abi.hip: interpol_pull_backward splits the backward; what is left -- a push
-    // that declined -- takes the generic fused kernel).  pullbwd_tiled with gvol AND ggrid returned wrong results / faulted under rough
-    // fields once a workgroup served several tiles; its two halves, each alone, are covered by the parity tests and stay.
-    if (gvol && ggrid) return 0;
+    // the LDS tiles hold the GRID gradient only (round 6: the scatter half of pullbwd_tiled is gone, see the kernel): abi.hip splits every
+    // backward -- the image gradient is a push of grad_out; where that push declined, the generic fused kernel takes what is left
+    if (gvol || !ggrid) return 0;
     if (p->dim == 2 && !gvol && ggrid) {
         // 2-D, grid gradient only, orders 1..3: the lean tile with the channels contracted per tap (ops_tiled2d.hip)
         const int rc = IP_SYM(try_tiled2d_gradc_, IP_TSFX)(p, k, gout, vol, grid, ggrid, st);

@@ -6,6 +6,7 @@ NO CPU fallback: without the built library, or with CPU tensors, every
 operator raises.
 """
 import ctypes
+import threading
 import os
 
 import torch
@@ -75,14 +76,19 @@ class HipExtensionMissing(ImportError):
 
 
 # Workspaces of the probe-routed organisations (bricks of the target / of the image) are OPTIONAL: every operator has an
-# organisation that needs none.  ONE buffer per (device, stream) is kept between calls and grown on demand (pull, push and the
-# backward passes of a stream share it: their kernels are ordered by the stream, and a captured hipGraph keeps pointing at live
-# memory); `release_workspaces()` gives it back.  A miss asks torch's caching allocator, but only when the request fits
+# organisation that needs none.  ONE buffer per (device, stream, HOST THREAD) is kept between calls and grown on demand (pull, push
+# and the backward passes of a stream share it: their kernels are ordered by the stream, and a captured hipGraph keeps pointing at
+# live memory).  The host thread is part of the key because ctypes releases the GIL inside the library: two threads issuing routed
+# operators on ONE stream could otherwise interleave their kernel enqueues on one buffer (A's bin, B's header zeroing and bin, A's
+# accumulate).  At most _WS_MAX buffers are kept (least recently used first out -- a warm-up on a side stream, the usual hipGraph
+# recipe, does not pin a second 1 - 2 GB buffer for good); `release_workspaces()` gives them all back (call it next to
+# `torch.cuda.empty_cache()`).  A miss asks torch's caching allocator, but only when the request fits
 # comfortably: asking for more than it can give makes the allocator synchronise the device and flush its cache before it
 # raises -- on every call, if the caller runs near capacity.  So a new buffer never takes more than half of what is available
 # (free device memory + the allocator's own free blocks) and a request that failed is not repeated until noticeably more
 # memory is available.  (The allocator's statistics cost ~0.25 ms of host time: they are consulted on misses only.)
-_WS_CACHE = {}                                       # (device index, stream handle) -> uint8 tensor
+_WS_CACHE = {}                                       # (device index, stream handle, host thread) -> uint8 tensor; insertion order = age
+_WS_MAX = 4
 _WS_DENIED = {}                                      # device index -> (bytes asked for, bytes available at the time)
 _WS_CHECK_ABOVE = 64 << 20
 
@@ -110,9 +116,10 @@ def _optional_workspace(nbytes, dev):
             return torch.empty(nbytes, dtype=torch.uint8, device=dev)
         except torch.cuda.OutOfMemoryError:
             return None
-    key = (idx, int(torch.cuda.current_stream(dev).cuda_stream))
+    key = (idx, int(torch.cuda.current_stream(dev).cuda_stream), threading.get_ident())
     ws = _WS_CACHE.get(key)
     if ws is not None and ws.numel() >= nbytes:
+        _WS_CACHE[key] = _WS_CACHE.pop(key)          # (most recently used: last)
         return ws
     avail = None
     if nbytes > _WS_CHECK_ABOVE:
@@ -132,7 +139,10 @@ def _optional_workspace(nbytes, dev):
         return None
     if _WS_DENIED:
         _WS_DENIED.pop(idx, None)
+    _WS_CACHE.pop(key, None)
     _WS_CACHE[key] = ws
+    while len(_WS_CACHE) > _WS_MAX:                  # (the kernels that use an evicted buffer are enqueued: the caching allocator
+        _WS_CACHE.pop(next(iter(_WS_CACHE)))         #  hands its memory to later work of the same stream only)
     return ws
 
 
