@@ -362,8 +362,9 @@ def main():
                          "traffic_source": traffic_source,
                          "algorithmic_bytes_per_launch": dom_bytes, "avg_launch_ms": round(dom_ms, 4), "median_launch_ms": round(dom_med, 4),
                          "timing": "average of %d launches (HIP events on the launch stream)" % args.steps,
-                         "launch": "one interpol_push call = the kernels its probe routes to (rough fields: own_bin + 9 own_accumulate "
-                                   "of csrc/push_owner.hip; smooth: push_tiled) + zero-fill; per-kernel times: profiles/*_kernel_stats.txt"},
+                         "launch": "one interpol_push call = the kernels its probe routes to + zero-fill; on this workload's i.i.d. field the probe "
+                                   "picks own_bin + 9 own_accumulate of csrc/push_owner.hip (a smooth field would take push_tiled: the "
+                                   "other_deformations rows); per-kernel times: profiles/*_kernel_stats.txt"},
         }
         line["roofline_per_op"] = ops_roof
         if pre:
