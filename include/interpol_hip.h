@@ -343,6 +343,9 @@ int interpol_pull_labels(const interpol_problem *p, const void *vol, const void 
 int interpol_resample_1d(int32_t dtype, int32_t lin_dtype, int32_t order, int32_t bound, int32_t extrapolate, int32_t mode,
                          int32_t adjoint, int64_t outer, int64_t n_samples, int64_t n_lattice, int64_t inner,
                          const void *src, const void *lin, void *dst, void *stream);
+/* 1 when interpol_resample_1d(adjoint = 1) serves (dtype, n_samples, inner) with the gathering kernel (no atomics, no zero-fill), else 0:
+ * the ONE statement of that rule -- the host layer (interpol/separable.py) asks instead of repeating it. */
+int32_t interpol_resample_1d_gathers(int32_t dtype, int64_t n_samples, int64_t inner);
 
 /* --- prefilter -----------------------------------------------------------------
  * interpol_spline_filter replaces coeff.spline_coeff (interpol/coeff.py:288-313,

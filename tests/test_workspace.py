@@ -83,3 +83,24 @@ def test_push_and_pull_do_without_a_workspace(monkeypatch):
     tol = 1e-5
     assert float((got_pull - want_pull).abs().max()) <= tol * float(want_pull.abs().max())
     assert float((got_push - want_push).abs().max()) <= tol * float(want_push.abs().max())
+
+
+def test_shared_target_goes_on_when_the_merged_bricks_workspace_is_denied(monkeypatch):
+    """a dense shared-target push asks for the merged bricks' workspace (~22 B per sample over all sources); when that is
+    denied the call must go on to the other organisations (and still be right), not stop at a half-configured route."""
+    import interpol
+    from interpol import _hip, ops
+    dev = torch.device("cuda", 0)
+    g = torch.Generator(device=dev).manual_seed(4)
+    n, m = 32, 48
+    x = torch.randn(6, 2, n, n, n, generator=g, device=dev)
+    grid = (interpol.identity_grid([n, n, n], device=dev)[None] * (m / n) + torch.randn(6, n, n, n, 3, generator=g, device=dev)).contiguous()
+    b, o = [1] * 3, [3] * 3
+    want = _hip.scatter("push", x, grid, [m] * 3, b, o, 1, flags=_hip.FLAG_NO_FASTPATH).sum(0, keepdim=True)
+    assert ops.kernels().dense_when_merged(grid, [m] * 3, o)
+    for deny in (False, True):
+        if deny:
+            monkeypatch.setattr(_hip, "_optional_workspace", lambda nbytes, dev: None)
+        out = torch.zeros(1, 2, m, m, m, device=dev)
+        ops.kernels().push_shared_(out, x, grid, b, o, 1)
+        assert float((out - want).abs().max()) <= 1e-5 * float(want.abs().max()), deny

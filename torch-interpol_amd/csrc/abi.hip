@@ -606,6 +606,7 @@ int interpol_push(const interpol_problem *p, const void *val, const void *grid, 
             rc = try_fast_push(p, k, val, grid, acc, st);           // the tiled kernel splats values and count in one pass
             if (rc != 0 && !(rc == 1 && routed2d)) return rc == 1 ? 0 : rc;
             if (rc == 1) k.gate_n = -2;                              // (2-D router: the generic kernels below run on verdict 2 alone -- a target sampled sparsely)
+            else if (routed2d) k.gate_n = -4;                        // (... and where the tiles declined they serve every verdict but 1, the bricks')
         }
         k.cc = 0;
         if (!(p->flags & INTERPOL_FLAG_NO_FASTPATH) && p->dtype == INTERPOL_F64) {
@@ -717,6 +718,7 @@ int interpol_count(const interpol_problem *p, const void *grid, void *vol,
             rc = try_fast_push(p, k, nullptr, grid, acc, st);
             if (rc != 0 && !(rc == 1 && routed2d)) return rc == 1 ? 0 : rc;
             if (rc == 1) k.gate_n = -2;
+            else if (routed2d) k.gate_n = -4;                        // (the tiles declined: the generic kernel serves every verdict but the bricks')
         }
         if (!(p->flags & INTERPOL_FLAG_NO_FASTPATH) && p->dtype == INTERPOL_F64) {
             const int rc = try_push_f64_tiles(p, k, nullptr, grid, acc, st);          // float64 on LDS tiles (push_f64.hip)
@@ -1049,6 +1051,11 @@ int interpol_spline_filter_to(const void *src, void *data, int32_t dtype, int64_
     for (int i = 0; i < fp.npoles; ++i) fp.gain *= (1. - fp.pole[i]) * (1. - 1. / fp.pole[i]);   // coeff.py:69-73
     make_pole_pre(fp);
     return launch_filter(dtype, fp, src, data, (hipStream_t)stream);
+}
+
+int32_t interpol_resample_1d_gathers(int32_t dtype, int64_t n_samples, int64_t inner)
+{
+    return (dtype == INTERPOL_F32 || dtype == INTERPOL_F64) && resample1d_adjoint_gathers(n_samples, inner) ? 1 : 0;
 }
 
 int interpol_resample_1d(int32_t dtype, int32_t lin_dtype, int32_t order, int32_t bound, int32_t extrapolate, int32_t mode,

@@ -15,7 +15,7 @@ inline dim3 sample_grid(const KParams &p, int B)
     // items' worth of blocks, which stride over the batch -- 131 072 workgroups that return at once cost 32 us, 262 144 (config 2's
     // trilinear pull) 60.  (Striding over the samples as well was tried: the loop-variant sample index costs the generic kernels
     // 35 - 50 % on rough fields.)
-    const bool gated = p.gate && (p.gate_n == -1 || p.gate_n == -2);
+    const bool gated = p.gate && (p.gate_n == -1 || p.gate_n == -2);      // (-4 stands in for the tiles: sized like an ungated launch)
     int by = B;
     if (gated) { by = (int)(32768 / (bx > 0 ? bx : 1)); by = by < 1 ? 1 : (by > B ? B : by); }
     return dim3((unsigned)bx, (unsigned)(by < 65535 ? by : 65535), 1);

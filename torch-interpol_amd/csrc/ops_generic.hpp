@@ -267,8 +267,10 @@ template <typename T, typename G, typename R, typename AccT, int D, int KMAX, bo
 __global__ __launch_bounds__(BLOCK) void push_generic(KParams p, const T *__restrict__ val,
                                                       const G *__restrict__ grid, AccT *__restrict__ vol, int B, TileList tl)
 {
-    if (p.gate && (p.gate_n == -2 ? *p.gate != 2 : *p.gate != 0)) return;   // the owner-computes organisation took this call (push_owner.hip: own_probe); 2-D router
-                                                       // (scatter2d.hip: probe2d, gate_n = -2): this kernel takes the sparsely sampled targets only
+    // the owner-computes organisation took this call (push_owner.hip: own_probe); 2-D router (scatter2d.hip: probe2d), gate_n = -2: this
+    // kernel takes the sparsely sampled targets only (verdict 2); gate_n = -4: the tiles of the 2-D router declined -- this kernel stands in
+    // for them as well (every verdict but 1, the bricks)
+    if (p.gate && (p.gate_n == -2 ? *p.gate != 2 : (p.gate_n == -4 ? *p.gate == 1 : *p.gate != 0))) return;
     IP_FOR_SAMPLES {
         const int64_t b = it_.b, o = it_.o;
         R x[D];

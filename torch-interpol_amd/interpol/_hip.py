@@ -39,7 +39,7 @@ _DTYPE_CODE = {torch.float32: F32, torch.float64: F64, torch.bfloat16: BF16, tor
 SYMBOLS = (
     "interpol_pull", "interpol_push", "interpol_count", "interpol_grad", "interpol_pushgrad",
     "interpol_hess", "interpol_pull_backward", "interpol_push_backward", "interpol_count_backward",
-    "interpol_spline_filter", "interpol_spline_filter_to", "interpol_resample_1d", "interpol_pull_labels",
+    "interpol_spline_filter", "interpol_spline_filter_to", "interpol_resample_1d", "interpol_resample_1d_gathers", "interpol_pull_labels",
     "interpol_push_bricks", "interpol_push_bricks_workspace", "interpol_host_bound_index", "interpol_host_bound_sign",
     "interpol_host_weight", "interpol_host_weight_f32", "interpol_abi_version",
     "interpol_error_string", "interpol_kernel_name", "interpol_scatter_workspace",
@@ -190,6 +190,8 @@ def lib():
     L.interpol_release_stream.argtypes = [ctypes.c_void_p]
     L.interpol_release_stream.restype = i32
     L.interpol_resample_1d.argtypes = [i32, i32, i32, i32, i32, i32, i32, i64, i64, i64, i64, vp, vp, vp, vp]
+    L.interpol_resample_1d_gathers.argtypes = [i32, i64, i64]
+    L.interpol_resample_1d_gathers.restype = i32
     for name in ("interpol_pull", "interpol_grad", "interpol_hess", "interpol_push", "interpol_pushgrad",
                  "interpol_count", "interpol_pull_backward", "interpol_push_backward",
                  "interpol_count_backward", "interpol_spline_filter", "interpol_spline_filter_to", "interpol_resample_1d", "interpol_pull_labels"):
@@ -416,13 +418,15 @@ def gather(op, vol, grid, bound, order, extrapolate, flags=0, out=None):
     return val.to(out_dt)
 
 
-def scatter(op, val, grid, shape, bound, order, extrapolate, flags=0, out=None, shared=False, with_count=False):
+def scatter(op, val, grid, shape, bound, order, extrapolate, flags=0, out=None, shared=False, with_count=False, need_workspace=False):
     """push / count / pushgrad: val (B,C,*in[,D]) , grid (B,*in,D) -> vol (B,C,*shape).
     `out` (dense, same dtype) + FLAG_ACCUMULATE adds into an existing target.
     `shared=True`: ONE target (1,C,*shape) that all batch items accumulate into
     (the reference's grid_push(...).sum(0), without the B per-item volumes).
     `with_count=True` (push only): the target has C + 1 channels and channel C receives the count
-    image of the same grid, splatted in the same pass (INTERPOL_FLAG_WITH_COUNT)."""
+    image of the same grid, splatted in the same pass (INTERPOL_FLAG_WITH_COUNT).
+    `need_workspace=True`: return None (nothing launched) when the probe-routed organisation's workspace is denied, so that the caller
+    can pick another organisation instead of the tiles."""
     dev = _require_gpu(val, grid)
     dim = grid.shape[-1]
     if dim not in (1, 2, 3):
@@ -491,6 +495,8 @@ def scatter(op, val, grid, shape, bound, order, extrapolate, flags=0, out=None, 
             # whether or not the probe will pick that organisation; when it does not fit comfortably (_optional_workspace), the
             # call falls back to the tiles, which need none -- a push that fitted without the router still fits.
             scratch = _optional_workspace(sbytes, dev)
+            if scratch is None and need_workspace:
+                return None
             if scratch is None:
                 flags &= ~FLAG_AUTO_SCATTER
                 p = make_problem(dim, dt, gdt, bound, order, extrapolate, B, C, shape, gshape,

@@ -70,11 +70,15 @@ class _HipKernels:
         op = "count" if inp is None else "push"
         shape = list(out.shape[2:])
         # Round 5: the batch items that share a target share its bricks too (csrc/push_owner.hip: BrickGrid::item = 0) -- once all
-        # the sources together bring a quarter of a sample per target voxel (BASELINE config 4: 64 sources of 128^3 into 512^3)
-        # the owner-computes organisation serves the call like a dense one (the probe of the call sends it there): no atomics.
+        # the sources together bring an EIGHTH of a sample per target voxel (dense_when_merged; BASELINE config 4: 64 sources of 128^3
+        # into 512^3 bring a full one) the owner-computes organisation serves the call like a dense one (the probe of the call sends
+        # it there): no atomics.  It needs ~22 B of workspace per sample over all sources: where that is denied the call goes on to
+        # the organisations below (the target-stationary bricks first) instead of straight to the tiles.
         if _HipKernels.dense_when_merged(grid, shape, order):
-            return _hip.scatter(op, inp, grid, shape, bound, order, extrapolate,
-                                flags=_hip.FLAG_ACCUMULATE, out=out, shared=True, with_count=with_count)
+            r = _hip.scatter(op, inp, grid, shape, bound, order, extrapolate,
+                             flags=_hip.FLAG_ACCUMULATE, out=out, shared=True, with_count=with_count, need_workspace=True)
+            if r is not None:
+                return r
         if _HipKernels.expanding(inp, grid, shape, with_count, order):
             return _hip.push_bricks(inp, grid, shape, bound, order, extrapolate, flags=_hip.FLAG_ACCUMULATE, out=out,
                                     shared=True, with_count=with_count)

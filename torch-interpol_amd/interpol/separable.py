@@ -53,16 +53,21 @@ class _SepPull(torch.autograd.Function):
 
 def _gathers(x, lin):
     """Do the adjoint passes of `x` along its last len(lin) dims all take the gathering kernel (csrc/resample1d.hip:
-    resample1d_adj_gather -- float32 / float64, at most 4096 samples per dim, lanes along an inner dim of 64 elements or more, or
-    along the lattice of the last dim)?"""
-    if not (x.is_cuda and x.dtype in (torch.float32, torch.float64)):
+    resample1d_adj_gather)?  The rule is the library's (interpol_resample_1d_gathers, include/interpol_hip.h): asked, not repeated.
+    (A `lin` that is not non-decreasing is still served correctly by that kernel -- it detects it on the device and visits every
+    sample -- but slowly; resize / restrict, the callers, build increasing lattices.)"""
+    if not x.is_cuda:
+        return False
+    from . import _hip
+    code = _hip._DTYPE_CODE.get(x.dtype)
+    if code is None:
         return False
     D = len(lin)
     for d in range(D):
         inner = 1
         for e in range(d + 1, D):
             inner *= x.shape[e - D]
-        if lin[d].numel() > 4096 or not (inner == 1 or inner >= 64):
+        if not _hip.lib().interpol_resample_1d_gathers(code, lin[d].numel(), inner):
             return False
     return True
 
