@@ -132,8 +132,10 @@ typedef struct interpol_problem {
  * voxels), where the sample-stationary tiles need the stencils of a 16^3 tile of samples to fit a
  * 33 x 33 x 32 LDS box (2.2 ms at the identity, 3.5 at sigma = 2, 126 at sigma = 6).
  * 3-D, one order 1..3 (trilinear since round 5: 4x2x256^3, 2.3 - 3.1 ms from the identity to sigma = 6, where its tiles take
- * 1.3 - 16 ms; all orders 0, nearest neighbour, as a trilinear scatter of the rounded coordinates: under AUTO the probe chooses between
- * the bricks and the generic kernel's global atomics), float32 coordinates.  Needs the workspace announced by
+ * 1.3 - 16 ms; all orders 0, nearest neighbour, through the same bricks with the box held in FLOATS -- round 6: no fixed point at order
+ * 0, one LDS float add per sample and channel, so a lattice point hit by one sample holds that sample's value bit for bit and a
+ * non-finite source stays on its own lattice point, like iso0.py:65-118 -- 2.5 - 2.9 ms; under AUTO the probe chooses between the bricks
+ * and the generic kernel's global atomics), float32 coordinates.  Needs the workspace announced by
  * interpol_scatter_workspace(); ignored (tiles / generic kernels) when it does not apply.
  *   INTERPOL_FLAG_BINNED_SCATTER: always;
  *   INTERPOL_FLAG_AUTO_SCATTER:   a probe kernel of the same call examines 128 tiles of the sample grid

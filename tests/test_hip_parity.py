@@ -814,6 +814,35 @@ def test_default_routing_where_a_workgroup_serves_several_tiles(dim, shape):
                             _same(a, r, 2e-5, (name, nv, ng) + what)
 
 
+@pytest.mark.parametrize("flag", ["binned", "default"])
+def test_nearest_push_through_bricks_is_exact_where_the_reference_is(flag):
+    """Order 0 is the order north_star singles out for exactness.  grid_push with all orders 0 through the owner-computes bricks
+    (csrc/push_owner.hip, round 6: one float atomic per record, no fixed point) against the oracle (iso0.py:65-118): a lattice point hit
+    by ONE sample holds that sample's value bit for bit; non-finite sources stay on their own lattice point (no NaN in the neighbours);
+    points hit several times agree to float rounding of the sum; the count image is exact."""
+    from interpol import _hip
+    gen = torch.Generator().manual_seed(31)
+    shape = (72, 64, 80)
+    for bound, sigma in ((3, 3.0), (0, 3.0), (6, 1.0)):
+        ident = interpol.identity_grid(shape)[None]
+        grid = (ident + sigma * torch.randn([2, *shape, 3], generator=gen)).contiguous()
+        src = torch.randn([2, 2, *shape], generator=gen) * torch.exp(4 * torch.randn([2, 2, *shape], generator=gen))      # a wide dynamic range
+        src[0, 0, 5, 6, 7] = float("inf"); src[1, 1, 40, 33, 21] = float("-inf"); src[0, 1, 20, 20, 20] = float("nan")
+        b, o = [bound] * 3, [0] * 3
+        fl = _hip.FLAG_BINNED_SCATTER if flag == "binned" else 0
+        got = _hip.scatter("push", src.to(DEV), grid.to(DEV), list(shape), b, o, 1, flags=fl, with_count=True).cpu()
+        ref = torch.as_tensor(oracle.grid_push(src, grid, list(shape), b, o, 1))
+        cnt = torch.as_tensor(oracle.grid_count(grid, list(shape), b, o, 1))
+        assert torch.equal(got[:, 2:], cnt.to(got.dtype)), ("count", bound)
+        assert torch.equal(torch.isnan(got[:, :2]), torch.isnan(ref)) and torch.equal(torch.isinf(got[:, :2]), torch.isinf(ref)), ("non-finite", bound)
+        single = (cnt == 1).expand(2, 2, *shape) & torch.isfinite(ref)
+        assert single.sum() > 1000
+        assert torch.equal(got[:, :2][single], ref.to(got.dtype)[single]), ("single hits", bound, flag)
+        fin = torch.isfinite(ref)
+        err = (got[:, :2][fin].double() - ref[fin].double()).abs()
+        assert float((err / (ref[fin].double().abs() + 1e-30)).max()) < 1e-5 or float(err.max()) <= 1e-5 * float(ref[fin].abs().max()), bound
+
+
 @pytest.mark.parametrize("n", [96, 160])
 def test_tile_grid_gradient_many_tiles(n):
     """Regression (round 6): the LDS-tile kernel of the grid gradient of pull_backward (pullbwd_tiled, csrc/ops_tiled.hip) where a workgroup

@@ -162,7 +162,18 @@ __device__ __forceinline__ void scatter_direct(const KParams &p, const T *__rest
         load_xyz<GM>(p, grid, b, g, ox, oy, oz, x);
         const int64_t o = ((int64_t)ox * g.gy + oy) * g.gz + oz;
         const float m = inb_mask(p, x);
-        if (K == 1 && p.mode == MODE_ISO0) { x[0] = rintf(x[0]); x[1] = rintf(x[1]); x[2] = rintf(x[2]); }   // nearest neighbour (own_bin)
+        if (K == 1 && p.mode == MODE_ISO0) {
+            // nearest neighbour: ONE lattice point, weight 1 (iso0.py:12, 65-118) -- see own_accumulate
+            const long long pk0 = wrap_outofline(L.bound[0], __float2int_rn(rintf(x[0])), L.n[0]);
+            const long long pk1 = wrap_outofline(L.bound[1], __float2int_rn(rintf(x[1])), L.n[1]);
+            const long long pk2 = wrap_outofline(L.bound[2], __float2int_rn(rintf(x[2])), L.n[2]);
+            const float sgn = (float)((int)(pk0 >> 32) * (int)(pk1 >> 32) * (int)(pk2 >> 32));
+            float *q = vol + b * p.vol_sb + (int)(pk0 & 0xffffffffll) * L.ss[0] + (int)(pk1 & 0xffffffffll) * L.ss[1] + (int)(pk2 & 0xffffffffll) * L.ss[2];
+#pragma unroll 1
+            for (int ch = 0; ch < nch; ++ch)
+                __hip_atomic_fetch_add(q + (int64_t)ch * p.vol_sc, src_value<T>(p, val, b, o, ch, m) * sgn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            continue;
+        }
         int ii[3]; float tt[3];
 #pragma unroll
         for (int d = 0; d < 3; ++d) split(K, x[d], ii[d], tt[d]);
@@ -848,6 +859,94 @@ __global__ __launch_bounds__(NT, 4) void own_accumulate(KParams p, BrickGrid bg,
             __syncthreads();
         };
         prof_mark(8);
+        if (K == 1 && p.mode == MODE_ISO0) {
+            // Nearest neighbour (all orders 0; own_bin stored the ROUNDED coordinates): a sample touches ONE lattice point with weight 1
+            // (iso0.py:65-118: inp * sign * mask, scatter_add_ in no particular order).  Round 6: no fixed point here -- the box holds the
+            // channel pair as two FLOATS and every record adds its sources with one ds_add_f32 each (slow LDS atomics, ~190 clk per wave
+            // instruction, but 2 per record instead of the 64 packed ones of a cubic stencil), the flush adds the non-zero slots to the
+            // target.  A lattice point hit by a single sample holds that sample's value bit for bit, a non-finite source stays on its own
+            // lattice point (round 5's 2 x 2 x 2 stencil at t = 0 quantised the value to the brick's fixed point and turned the seven
+            // zero-weight neighbours of an inf into NaN), sums of several hits round like the reference's.  Stencils of one point need
+            // no folding pass: a record outside the lattice goes to its image under the boundary condition, which lies in the same box
+            // (BrickGrid).  Shell bricks (colour 8: few records) add straight to the target, one float atomic per record and channel
+            // (all bricks that way: 5.8 ms at config-2 size -- scattered global atomics, profiles/r06_nearest_push.txt).
+            float *boxf = reinterpret_cast<float *>(sm.box);
+            for (int c = 0; c < nch; c += 2) {
+                const bool two = c + 1 < nch;
+                float *vc0 = vol + b * p.vol_sb + c * p.vol_sc;
+                float *vc1 = two ? vc0 + p.vol_sc : vc0;
+                const float *va = c == 0 ? nullptr : vals + (int64_t)(c - 1) * nrec;
+                const float *vb = two ? vals + (int64_t)c * nrec : nullptr;
+                for (int pb0 = 0; pb0 < npieces; pb0 += NPIECE) {
+                    if (pb0 > 0 || c > 0) __syncthreads();
+                    build_pieces(pb0);
+#pragma unroll 1
+                    for (int k = 0; k < VPT; ++k) {
+                        const uint2 pc = sm.piece[wave + k * (NT / 64)];
+                        if (lane >= (int)pc.y) continue;
+                        const unsigned ri = pc.x + (unsigned)lane;
+                        const float4 rc = rec[ri];
+                        const float s0 = va ? va[ri] : rc.w, s1 = vb ? vb[ri] : 0.f;
+                        int ii[3] = { __float2int_rn(rc.x), __float2int_rn(rc.y), __float2int_rn(rc.z) };
+                        float sgn = 1.f;
+                        if (atomic || ii[0] < 0 || ii[0] >= L.n[0] || ii[1] < 0 || ii[1] >= L.n[1] || ii[2] < 0 || ii[2] >= L.n[2]) {
+#pragma unroll
+                            for (int d = 0; d < 3; ++d) {
+                                const long long pk = wrap_outofline(L.bound[d], ii[d], L.n[d]);
+                                ii[d] = (int)(pk & 0xffffffffll); sgn *= (float)(int)(pk >> 32);
+                            }
+                        }
+                        const int xr = ii[0] - b0[0], yr = ii[1] - b0[1], zr = ii[2] - b0[2];
+                        if (atomic || (unsigned)xr >= (unsigned)BOX || (unsigned)yr >= (unsigned)BOX || (unsigned)zr >= (unsigned)BOX) {
+                            // shell bricks; (never for interior ones: the image of a point of an end brick's box lies in the box)
+                            const int off = ii[0] * L.ss[0] + ii[1] * L.ss[1] + ii[2] * L.ss[2];
+                            __hip_atomic_fetch_add(vc0 + off, s0 * sgn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            if (two) __hip_atomic_fetch_add(vc1 + off, s1 * sgn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            continue;
+                        }
+                        float *slot = boxf + 2 * (xr * PLANE + yr * PZ + zr);
+                        __builtin_amdgcn_ds_faddf((__attribute__((address_space(3))) float *)slot, s0 * sgn, 0, 0, false);
+                        if (two) __builtin_amdgcn_ds_faddf((__attribute__((address_space(3))) float *)(slot + 1), s1 * sgn, 0, 0, false);
+                    }
+                }
+                __syncthreads();
+                if (!atomic) {
+                    constexpr int UF0 = 7;
+#pragma unroll 1
+                    for (int e0 = tid; e0 < BOXSLOTS; e0 += UF0 * NT) {
+                        int off[UF0]; float a0[UF0], a1[UF0], t0[UF0], t1[UF0];
+                        unsigned nz = 0;
+#pragma unroll
+                        for (int u = 0; u < UF0; ++u) {
+                            const int e = e0 + u * NT;
+                            off[u] = 0; a0[u] = 0.f; a1[u] = 0.f;
+                            if (e < BOXSLOTS) {
+                                a0[u] = boxf[2 * e]; a1[u] = boxf[2 * e + 1];
+                                if (a0[u] != 0.f || a1[u] != 0.f) {           // (true for NaN)
+                                    const int xr = e / PLANE, rem = e - xr * PLANE, yr = rem / PZ, zr = rem - yr * PZ;
+                                    off[u] = (b0[0] + xr) * L.ss[0] + (b0[1] + yr) * L.ss[1] + (b0[2] + zr) * L.ss[2];
+                                    nz |= 1u << u;
+                                    sm.box[e] = 0ull;
+                                }
+                            }
+                        }
+#pragma unroll
+                        for (int u = 0; u < UF0; ++u) {
+                            t0[u] = ((nz >> u) & 1) ? vc0[off[u]] : 0.f;
+                            t1[u] = (((nz >> u) & 1) && two) ? vc1[off[u]] : 0.f;
+                        }
+#pragma unroll
+                        for (int u = 0; u < UF0; ++u) {
+                            if (!((nz >> u) & 1)) continue;
+                            vc0[off[u]] = t0[u] + a0[u];
+                            if (two) vc1[off[u]] = t1[u] + a1[u];
+                        }
+                    }
+                }
+                __syncthreads();
+            }
+            continue;                                                // (block-uniform) next brick
+        }
         // ---- pass 1 over all records: density of the first-tap cells (own_bin left every record's cell in `meta`, 2 bytes, and the
         // brick's max |source| of the first channel pair in `bmax`); the records of the first batch are also counted into their
         // classes (rank kept in registers: qr = class | rank << 5)
