@@ -54,7 +54,7 @@ for name in ("bench.json", "other_configs.json"):
 ALG_READ = 4 * 256 ** 3 * 12 + 4 * 2 * 256 ** 3 * 4     # algorithmic HBM read bytes per launch at BASELINE config 2: grid + source
 # kernels of one grid_pull / grid_push launch (substrings of the kernel names); the first one counts the launches
 KERNELS = {"grid_pull": ["pull_sorted"],
-           "grid_push": ["own_probe", "own_bin", "own_accumulate", "own_zero", "push_tiled", "fillBuffer"]}   # (own_bin also runs,
+           "grid_push": ["own_probe", "own_bin", "own_accumulate", "own_zero", "push_tiled", "fillBuffer", "zero_fill"]}   # (own_bin also runs,
            # nearly empty, in index mode behind every routed pull since round 4: the probe counts the push launches)
 raw_path = os.path.join(src, "pmc_raw.json")
 if all(dbs("pmc_%s_s%s" % (c, sg)) for c in ("FETCH_SIZE", "WRITE_SIZE") for sg in ("2.0", "0.0")):
@@ -97,7 +97,7 @@ if os.path.exists(raw_path):
               "#    reads counted 1/2 like wide streaming reads, its read bytes would double (the 'x2' column).\n"
               "# The push moves more than its algorithmic bytes by design: own_bin writes 22 bytes per sample of sorted records that\n"
               "# own_accumulate reads back, and the target is flushed brick by brick with loads + stores (shell bricks: float atomics,\n"
-              "# executed memory-side and counted as writes); the zero-fill of the target (fillBuffer) is part of the launch.\n" % (tag, rnd))
+              "# executed memory-side and counted as writes); the zero-fill of the target (zero_fill, a kernel of the library; fillBuffer where a memset served it) is part of the launch.\n" % (tag, rnd))
     out = {"_comment": "HBM-side bytes per launch at BASELINE config 2 (sigma = 2) from rocprofv3 PMC passes (profiles/%s_pmc_hbm_traffic.txt): "
                        "FETCH_SIZE KB x 1024 x calibration factor + WRITE_SIZE KB x 1024, summed over the kernels of the launch" % rnd}
     buf.write("%-10s %-15s %14s %14s %8s %14s %14s\n" % ("op", "kernel", "FETCH KB/launch", "WRITE KB/launch", "f_fetch", "read bytes", "write bytes"))

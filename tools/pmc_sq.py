@@ -47,6 +47,8 @@ for i, g in enumerate(GROUPS):
                     res.setdefault(short, {})[name] = v
         except sqlite3.Error as e:
             print("db error", db, e)
+    import shutil
+    shutil.rmtree(d, ignore_errors=True)             # (the databases stay on the box: gpurun merges at most 64 MiB back)
 json.dump(res, open(os.path.join(out, "sq_counters.json"), "w"), indent=1)
 with open(os.path.join(out, "sq_counters.txt"), "w") as f:
     f.write("# rocprofv3 --kernel-trace --pmc <group> -- python tools/pmc_workload.py %s   (tools/pmc_sq.py; per-dispatch averages, summed over instances)\n" % sigma)

@@ -361,7 +361,7 @@ int64_t interpol_pull_workspace(const interpol_problem *p)
     return b5 ? b5 : owner_pull_workspace_bytes(p, k);
 }
 
-// The routed pull.  1: done, 0: declined (nothing launched that the caller's fallback would not overwrite), else an error.
+// The routed pull (HISTORY.md 4.2e).  1: done, 0: declined (nothing launched that the caller's fallback would not overwrite), else an error.
 static int routed_pull(const interpol_problem *p, KParams k, int B, const void *vol, const void *grid, void *val, void *workspace, int64_t workspace_bytes,
                        hipStream_t st)
 {
@@ -505,7 +505,7 @@ int interpol_grad(const interpol_problem *p, const void *vol, const void *grid, 
         [&] { return launch_grad_f16(k, vol, grid, val, B, st); });
 }
 
-// grid_grad with the bricks workspace of interpol_pull_workspace(p) (float32, 3-D quadratic / cubic): the bricks of the
+// grid_grad with the bricks workspace of interpol_pull_workspace(p) (float32, 3-D quadratic / cubic; DESIGN.md 4.4, HISTORY.md 4.2e): the bricks of the
 // image always (INTERPOL_FLAG_BINNED_SCATTER) or when the probe of the call finds a dense or rough sampling
 // (INTERPOL_FLAG_AUTO_SCATTER: the tile / generic kernels are enqueued as well and return at once behind the probe's gate).
 int interpol_grad_ws(const interpol_problem *p, const void *vol, const void *grid, void *val, void *workspace, int64_t workspace_bytes, void *stream)
@@ -745,7 +745,7 @@ int interpol_pushgrad(const interpol_problem *p, const void *val, const void *gr
 }
 
 // The grid gradient of a gather through the router (float32, 3-D quadratic / cubic, a bricks workspace of interpol_pull_workspace(p)
-// bytes): ggrid[b,o,:] = mask * sum_c gout[b,c,o] * grad pull(vol[b,c])(x_o) (pushpull.py:256-257; gout == NULL: ones).
+// bytes; DESIGN.md 4.4, HISTORY.md 4.2e): ggrid[b,o,:] = mask * sum_c gout[b,c,o] * grad pull(vol[b,c])(x_o) (pushpull.py:256-257; gout == NULL: ones).
 // The sample tiles flag the tiles whose samples leave their LDS box; those samples go to the bricks of the image
 // (own_gather<K, true>, push_owner.hip) -- 4 x 2 x 256^3 cubic, sigma = 6: 20 -> 2.9 ms.  1: done, 0: declined, else an error.
 static int routed_gradc(const interpol_problem *p, const KParams &k, const void *gout, const void *vol, const void *grid, void *ggrid,

@@ -1,6 +1,6 @@
 // ===========================================================================
 // gather5.hip -- grid_pull / grid_grad (reference interpol/nd.py:80-143, 216-288) for spline orders 4 and 5 in 3-D, float32,
-// through BRICKS OF THE IMAGE: the organisation of push_owner.hip's own_gather for the 125 / 216-tap stencils of
+// through BRICKS OF THE IMAGE: the organisation of push_owner.hip's own_gather (HISTORY.md 4.2e) for the 125 / 216-tap stencils of
 // BASELINE config 3 (8 x 1 x 192^3, order 5).
 //
 // The LDS tiles of ops_tiled.hip stage, per 16^3-sample tile, the bounding box of the tile's stencils -- (16 + 5 + 4 sigma)^3

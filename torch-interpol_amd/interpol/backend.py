@@ -14,7 +14,7 @@ jitfields = False
 exact_scatter = False
 
 # grid_push / grid_count: two organisations of the same scatter (same results within float32 rounding).  Times: 4x2x256^3 cubic
-# dct2 on one MI355X, round 5 (profiles/r05_rough_rows.txt).
+# dct2 on one MI355X, round 5 (HISTORY.md 4.2c, profiles/r05_rough_rows.txt).
 #   * sample-stationary tiles (csrc/ops_tiled.hip): 16^3 tiles of samples accumulate in an LDS box that their
 #     stencils must fit (33 x 33 x 32 lattice points); fastest for smooth deformations (2.2 ms at the identity,
 #     3.5 ms under i.i.d. displacements of sigma = 2 voxels) and sharply slower beyond that (sigma = 3 / 4 / 6:
