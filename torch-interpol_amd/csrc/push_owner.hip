@@ -484,8 +484,8 @@ __global__ __launch_bounds__(NT1, 4) void own_bin(KParams p, BrickGrid bg, const
 constexpr int VPT = 12;                         // pieces per wave and batch
 constexpr int NPIECE = VPT * (NT / 64);         // pieces (<= 64 consecutive records of one run) per batch: 96
 constexpr int BATCH = NPIECE * 64;              // records per class-sorted batch, at most (a brick holds 4096 on average)
-constexpr int NCLS = 32;                        // classes = 8-byte bank pairs of the LDS
-constexpr int NHW = NT / 32;                    // half waves per workgroup
+constexpr int NCLS = 16;                        // classes = (8-byte slot) mod 16: ds_add_u64 is served in groups of 16 contiguous lanes (round 6, tools/microbench/lds_add_classes.hip)
+constexpr int NHW = NT / NCLS;                  // groups of 16 lanes per workgroup
 constexpr unsigned PMASK = 0x1ffffffu;          // AccSmem::ppref: the prefix field
 static_assert(NPIECE <= 128, "a queue entry is piece << 6 | lane in 16 bits");
 
@@ -970,7 +970,7 @@ __global__ __launch_bounds__(NT, 4) void own_accumulate(KParams p, BrickGrid bg,
                     atomicAdd(&sm.cells[cell >> 1], 1u << (16 * (cell & 1)));
                     if (pb0 == 0) {
                         const int q = (x0 * PLANE + y0 * PZ + z0) & (NCLS - 1);
-                        qr[k] = q | (atomicAdd(&sm.qcnt[q], 1) << 5);
+                        qr[k] = q | (atomicAdd(&sm.qcnt[q], 1) << 4);
                     }
                 }
             }
@@ -1071,7 +1071,7 @@ __global__ __launch_bounds__(NT, 4) void own_accumulate(KParams p, BrickGrid bg,
                             const unsigned mk = meta[pc.x + (unsigned)lane];
                             const int x0 = (mk >> 8) & 15, y0 = (mk >> 4) & 15, z0 = mk & 15;
                             const int q = (x0 * PLANE + y0 * PZ + z0) & (NCLS - 1);
-                            qr[k] = q | (atomicAdd(&sm.qcnt[q], 1) << 5);
+                            qr[k] = q | (atomicAdd(&sm.qcnt[q], 1) << 4);
                         }
                     }
                     __syncthreads();
@@ -1084,36 +1084,37 @@ __global__ __launch_bounds__(NT, 4) void own_accumulate(KParams p, BrickGrid bg,
                 // so that every lane walks the same number of entries -- the classes of an i.i.d. field are Poisson-filled, the
                 // fullest of 32 holds 20 % more than the mean.
                 if (tid < 32) {
-                    const int cq = sm.qcnt[tid];
+                    const bool cls = tid < NCLS;
+                    const int cq = cls ? sm.qcnt[tid] : 0;
                     int tot, nsur, nhol;
                     half_excl_scan(cq, tot);
                     const int cap = (((tot + NCLS - 1) / NCLS) + NHW - 1) / NHW * NHW;
-                    const int sur = cq > cap ? cq - cap : 0, hol = cq < cap ? cap - cq : 0;
+                    const int sur = cls && cq > cap ? cq - cap : 0, hol = cls && cq < cap ? cap - cq : 0;
                     const int so = half_excl_scan(sur, nsur), ho = half_excl_scan(hol, nhol);
-                    sm.qsur[tid] = so; sm.qhol[tid] = ho;
+                    if (cls) { sm.qsur[tid] = so; sm.qhol[tid] = ho; }
                     if (tid == 31) { sm.qsur[NCLS] = nsur; sm.qhol[NCLS] = nhol; sm.qcap = cap; }
                     const int fill = nsur - ho < 0 ? 0 : (nsur - ho > hol ? hol : nsur - ho);
-                    sm.qeff[tid] = (cq < cap ? cq : cap) + fill;
+                    if (cls) sm.qeff[tid] = (cq < cap ? cq : cap) + fill;
                 }
                 __syncthreads();
                 const int qcap = sm.qcap;
 #pragma unroll
                 for (int k = 0; k < VPT; ++k) {
                     if (qr[k] < 0) continue;
-                    const int qq = qr[k] & 31, r = qr[k] >> 5;
+                    const int qq = qr[k] & (NCLS - 1), r = qr[k] >> 4;
                     int slot = qq * qcap + r;
                     if (r >= qcap) {                                 // surplus record o of the batch: into the o-th free slot
                         const int o = sm.qsur[qq] + r - qcap;
                         int c2 = 0;
 #pragma unroll
-                        for (int st = 16; st > 0; st >>= 1) if (sm.qhol[c2 + st] <= o) c2 += st;      // last class with qhol <= o
+                        for (int st = NCLS / 2; st > 0; st >>= 1) if (sm.qhol[c2 + st] <= o) c2 += st;      // last class with qhol <= o
                         slot = c2 * qcap + sm.qcnt[c2] + (o - sm.qhol[c2]);
                     }
                     sm.queue[slot] = (unsigned short)(((wave + k * (NT / 64)) << 6) | lane);
                 }
                 __syncthreads();
                 // ---- the taps: lane q of half wave hw walks the slots of class q
-                const int q = tid & 31, hw = tid >> 5;
+                const int q = tid & (NCLS - 1), hw = tid >> 4;
                 const int ebeg = q * qcap + hw, eend = q * qcap + sm.qeff[q];
                 const int nit = qcap / NHW;                          // (block-uniform)
                 auto fetch = [&](int e, float4 &rc, float &s0, float &s1) {
