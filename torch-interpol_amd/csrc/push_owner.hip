@@ -65,6 +65,7 @@ constexpr int NT = 512;                         // accumulate: threads per workg
 constexpr int NS = TS * TS * TS;                // samples per tile (own_bin)
 constexpr int NT1 = 512, VPT1 = NS / NT1;       // own_bin: threads, samples per thread
 constexpr int LB = 6, NBIN = LB * LB * LB;      // bricks around a tile that are sorted locally
+constexpr int HDR_SHELL = 34;                   // word of the workspace header own_bin sets when a shell brick received a run
 
 // Bricks of first-tap cells, per dim.  INTERIOR cells [lo, top) lie in nin bricks of BR cells: the bricks up to index
 // `split` are aligned to lo, the ones above it to top (brick `split` is the short one in between).  Two cases:
@@ -446,6 +447,13 @@ __global__ __launch_bounds__(NT1, 4) void own_bin(KParams p, BrickGrid bg, const
             if (slot[i] < bg.capd) {
                 desc[(int64_t)bk * bg.capd + slot[i]] = make_uint2((unsigned)(tilebase + sm.base[e]), (unsigned)cn);
                 sm.gbk[e] = bk;
+                // a run in a brick of the SHELL (outside the interior bricks of some dim): the shell launch of own_accumulate has work (round 6:
+                // else it returns at once -- 36 us of candidate scanning at config 2 for nothing)
+                const int bc[3] = { lo[0] + r0, lo[1] + r1, lo[2] + r2 };
+                bool shell = false;
+#pragma unroll
+                for (int d = 0; d < 3; ++d) shell = shell || bc[d] < NLO + (p.bound[d] == B_DST1 ? 1 : 0) || bc[d] >= NLO + bg.nin[d];
+                if (!IDX && shell) ndesc[HDR_SHELL - 64] = 1;        // (the header lies 64 words in front of the brick counters, layout())
                 if (IDX && slot[i] == 0) bmax[1 + atomicAdd(&bmax[0], 1)] = bk;      // first run of the brick: onto the list
             } else { sm.cnt[e] = -1; sm.orph = 1; }
         }
@@ -709,6 +717,7 @@ __global__ __launch_bounds__(NT, 4) void own_accumulate(KParams p, BrickGrid bg,
                                                         int *__restrict__ ctr)
 {
     if (gate && *gate != 1) return;                                  // INTERPOL_FLAG_AUTO_SCATTER: the probe chose the tiles
+    if (color == 8 && ctr[HDR_SHELL - 16 - 8] == 0) return;          // the shell launch: own_bin published no run outside the interior bricks
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     AccSmem &sm = *reinterpret_cast<AccSmem *>(smem_raw);
     Lattice L;
