@@ -61,6 +61,33 @@ def test_cfg2_full_size_pull_push_properties():
     assert _rel(psh[:1], _hip.scatter("push", y[:1], grid[:1], None, b, o, 1, flags=_hip.FLAG_NO_FASTPATH)) < 5e-6
 
 
+@pytest.mark.timeout(900)
+def test_cfg2_full_size_against_the_oracle():
+    """Round 6: the headline workload itself -- configs[1] at FULL size, default routing (pull_sorted; own_bin + own_accumulate behind the
+    probe) -- compared DIRECTLY with the C oracle on all host cores (float64 evaluation of the same float32 inputs): two of the four batch
+    items (the oracle takes ~3 s per item and operator), pull and push + count, rtol 1e-5 + atol 1e-5 max|ref|."""
+    import os
+    import numpy as np
+    from oracle import oracle
+    inp, grid = _cfg2()
+    b, o = [3] * 3, [3] * 3
+    pull = _hip.gather("pull", inp, grid, b, o, 1)
+    push = _hip.scatter("push", inp, grid, [256] * 3, b, o, 1, with_count=True)
+    oracle.set_threads(os.cpu_count() or 8)
+    try:
+        for item in (0, 3):
+            x64, g64 = inp[item:item + 1].cpu().double(), grid[item:item + 1].cpu().double()
+            for name, got, ref in (("pull", pull[item:item + 1], oracle.grid_pull(x64, g64, b, o, 1)),
+                                   ("push", push[item:item + 1, :2], oracle.grid_push(x64, g64, [256] * 3, b, o, 1)),
+                                   ("count", push[item:item + 1, 2:], oracle.grid_count(g64, [256] * 3, b, o, 1))):
+                ref = np.asarray(ref, dtype=np.float64)
+                err = np.abs(got.cpu().double().numpy() - ref)
+                tol = 1e-5 * np.abs(ref) + 1e-5 * np.abs(ref).max()
+                assert (err <= tol).all(), (name, item, float(err.max()), float(np.abs(ref).max()))
+    finally:
+        oracle.set_threads(1)
+
+
 def test_cfg2_full_size_identity_and_prefilter():
     inp, _ = _cfg2(7)
     inp = inp[:2]
@@ -98,6 +125,53 @@ def test_cfg3_full_size_grad_and_backward():
     gg = interpol.grid_grad(inp, grid, **kw)                                   # (B, C, *out, 3)
     want = (gg * gout.unsqueeze(-1)).sum(1)
     assert _rel(gr.grad, want) < 1e-5
+
+
+@pytest.mark.timeout(900)
+def test_cfg3_and_cfg5_full_size_against_the_oracle():
+    """Round 6: configs[2] (8x1x192^3, order 5, dft) and configs[4] (32x3x1024^2 bf16 storage, orders [2,3], bounds [dct1,dst2]) at FULL
+    size against the C oracle on all host cores, one batch item each: cfg3 pull, grid_grad and both gradients of the pull's backward;
+    cfg5 pull and push (bf16 tolerance 1e-2 of max|ref| on the rounded inputs)."""
+    import os
+    import numpy as np
+    from oracle import oracle
+
+    def close(name, got, ref, rtol, atol_rel):
+        ref = np.asarray(ref, dtype=np.float64)
+        err = np.abs(got.detach().cpu().double().numpy() - ref)
+        assert (err <= rtol * np.abs(ref) + atol_rel * np.abs(ref).max()).all(), (name, float(err.max()), float(np.abs(ref).max()))
+
+    oracle.set_threads(os.cpu_count() or 8)
+    try:
+        g = torch.Generator(device=DEV).manual_seed(3)
+        n = 192
+        inp = torch.randn([8, 1, n, n, n], generator=g, device=DEV)
+        grid = torch.randn([8, n, n, n, 3], generator=g, device=DEV).mul_(2.0) + interpol.identity_grid([n] * 3, device=DEV)
+        gout = torch.randn([8, 1, n, n, n], generator=g, device=DEV)
+        b, o = [6] * 3, [5] * 3
+        pull = _hip.gather("pull", inp, grid, b, o, 1)
+        grad = _hip.gather("grad", inp, grid, b, o, 1)
+        gi, gg = _hip.pull_backward(gout, inp, grid, b, o, 1, True, True)
+        it = 5
+        x64, g64, go64 = inp[it:it + 1].cpu().double(), grid[it:it + 1].cpu().double(), gout[it:it + 1].cpu().double()
+        close("cfg3 pull", pull[it:it + 1], oracle.grid_pull(x64, g64, b, o, 1), 1e-5, 1e-5)
+        close("cfg3 grad", grad[it:it + 1], oracle.grid_grad(x64, g64, b, o, 1), 2e-5, 2e-5)
+        ri, rg = oracle.grid_pull_backward(go64, x64, g64, b, o, 1)
+        close("cfg3 backward image", gi[it:it + 1], ri, 1e-5, 1e-5)
+        close("cfg3 backward grid", gg[it:it + 1], rg, 2e-5, 2e-5)
+        del inp, grid, gout, pull, grad, gi, gg
+        g = torch.Generator(device=DEV).manual_seed(5)
+        x = torch.randn(32, 3, 1024, 1024, generator=g, device=DEV).to(torch.bfloat16)
+        g2 = torch.randn([32, 1024, 1024, 2], generator=g, device=DEV).mul_(2.0) + interpol.identity_grid([1024, 1024], device=DEV)
+        b, o = [2, 5], [2, 3]
+        pull = _hip.gather("pull", x, g2, b, o, 1)
+        push = _hip.scatter("push", x, g2, [1024, 1024], b, o, 1)
+        it = 17
+        x64, g64 = x[it:it + 1].float().cpu().double(), g2[it:it + 1].cpu().double()
+        close("cfg5 pull", pull[it:it + 1].float(), oracle.grid_pull(x64, g64, b, o, 1), 1e-2, 1e-2)
+        close("cfg5 push", push[it:it + 1].float(), oracle.grid_push(x64, g64, [1024, 1024], b, o, 1), 1e-2, 1e-2)
+    finally:
+        oracle.set_threads(1)
 
 
 def test_cfg4_full_size_shared_target_mass():
