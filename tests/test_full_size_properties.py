@@ -192,6 +192,22 @@ def test_cfg4_full_size_shared_target_mass():
     ref = _hip.scatter("push", x[:1], grid[:1], [m] * 3, [1] * 3, [3] * 3, 1, with_count=True)
     one_p, one_c = push_count_shared(x[:1], grid[:1], [m] * 3, interpolation=3, bound="replicate", extrapolate=True, reduce="none")
     assert _rel(one_p[None], ref[:, :1]) < 5e-6 and _rel(one_c[None], ref[:, 1:]) < 5e-6
+    # round 6: all 8 sources (one GPU's share of the 8-GPU run) against the C oracle, source by source, summed in float64
+    import os
+    import numpy as np
+    from oracle import oracle
+    oracle.set_threads(os.cpu_count() or 8)
+    try:
+        want_p, want_c = np.zeros([m] * 3), np.zeros([m] * 3)
+        for i in range(nsrc):
+            x64, g64 = x[i:i + 1].cpu().double(), grid[i:i + 1].cpu().double()
+            want_p += np.asarray(oracle.grid_push(x64, g64, [m] * 3, [1] * 3, [3] * 3, 1), dtype=np.float64)[0, 0]
+            want_c += np.asarray(oracle.grid_count(g64, [m] * 3, [1] * 3, [3] * 3, 1), dtype=np.float64)[0, 0]
+    finally:
+        oracle.set_threads(1)
+    for name, got, want in (("push", push, want_p), ("count", count, want_c)):
+        err = np.abs(got[0].cpu().double().numpy() - want)
+        assert (err <= 1e-5 * np.abs(want) + 1e-5 * np.abs(want).max()).all(), (name, float(err.max()), float(np.abs(want).max()))
 
 
 def test_cfg5_full_size_2d_bf16():
