@@ -1009,6 +1009,72 @@ def test_tiled_mixed_orders_match_generic(dim, orders, sigma):
         _same(ggrid, (gg * src.unsqueeze(-1)).sum(1), 2e-5, "bwd ggrid")
 
 
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("orders", [[1, 2, 3], [3, 1, 2], [2, 3, 1], [3, 3, 1], [1, 1, 2], [2, 3, 3], [3, 2, 2]])
+def test_sorted_tiles_mixed_orders_against_the_oracle(orders):
+    """Round 6: 3-D mixed orders 1..3 run in the class-sorted cubic tiles (csrc/ops_sorted.hip: pull_sorted / gradc_sorted <.., MIX>:
+    first tap floor(x - (k_d - 1)/2), the taps beyond a dim's order cleared) instead of the round-1 tiles.  DEFAULT routing against the
+    C oracle (float64 evaluation of the same float32 inputs) and the generic kernels: pull, the grid gradients of pull_backward and
+    push_backward (the same gather with the two images swapped), count backward; every bound, the three extrapolation modes, 1 - 3
+    channels, ragged sample grids larger than one tile, a gentle and a rough field; 16-bit storage against the generic kernels.
+    A non-finite lattice point must reach exactly the samples whose TRUE stencil holds it (nd.py:110-136)."""
+    import os
+    from interpol import _hip
+    gen = torch.Generator().manual_seed(100 * orders[0] + 10 * orders[1] + orders[2])
+    ishape, oshape = (50, 37, 41), (37, 45, 50)
+    ident = torch.stack(torch.meshgrid(*[torch.linspace(0, n - 1, m) for n, m in zip(ishape, oshape)], indexing="ij"), -1)[None]
+    rtol, atol_rel = G.fp32_tol(orders)
+    oracle.set_threads(os.cpu_count() or 8)
+    try:
+        for case, (bounds, ex, C, sigma) in enumerate((([3, 3, 3], 1, 2, 2.0), ([2, 5, 0], 0, 1, 0.5), ([6, 1, 4], 2, 3, 3.0), ([4, 0, 6], 1, 2, 0.5))):
+            vol = torch.randn([2, C, *ishape], generator=gen)
+            src = torch.randn([2, C, *oshape], generator=gen)
+            grid = (ident + sigma * torch.randn([2, *oshape, 3], generator=gen)).contiguous()
+            grid[0, 0, 0, 0] = -3.0 * torch.tensor(ishape)             # far outside
+            grid[1, 1, 2, 3] = 3.0 * torch.tensor(ishape) + 0.25
+            # (the mask of nd.py:10-27 compares with n - 1 + 0.05 / + 0.55 ROUNDED TO FLOAT32 in the reference and in the kernels, exactly
+            #  in the float64 oracle: a coordinate that IS that float32 number -- seen once in 166 500 -- is in for one and out for the other)
+            for d, n in enumerate(ishape):
+                for thr in (-0.55, -0.05, n - 1 + 0.05, n - 1 + 0.55):
+                    near = (grid[..., d] - thr).abs() < 1e-3
+                    grid[..., d] = torch.where(near, grid[..., d] + 4e-3, grid[..., d])
+            vd, sd, gd = vol.to(DEV), src.to(DEV), grid.to(DEV)
+            v64, s64, g64 = vol.double(), src.double(), grid.double()
+            what = (orders, bounds, ex, C, sigma)
+            got = _hip.gather("pull", vd, gd, bounds, orders, ex)
+            G.assert_close(got.cpu().numpy(), oracle.grid_pull(v64, g64, bounds, orders, ex), rtol, atol_rel, ("pull",) + what)
+            _same(got, _hip.gather("pull", vd, gd, bounds, orders, ex, flags=_hip.FLAG_NO_FASTPATH), 4e-6, ("pull vs generic",) + what)
+            ggrid = _hip.pull_backward(sd, vd, gd, bounds, orders, ex, False, True)[1]
+            G.assert_close(ggrid.cpu().numpy(), np.asarray(oracle.grid_pull_backward(s64, v64, g64, bounds, orders, ex)[1]), 2 * rtol, 2 * atol_rel,
+                           ("pull_backward grid",) + what)
+            gval, ggrid = _hip.push_backward(vd, sd, gd, bounds, orders, ex, True, True)
+            want = oracle.grid_push_backward(v64, s64, g64, bounds, orders, ex)
+            G.assert_close(gval.cpu().numpy(), np.asarray(want[0]), rtol, atol_rel, ("push_backward values",) + what)
+            G.assert_close(ggrid.cpu().numpy(), np.asarray(want[1]), 2 * rtol, 2 * atol_rel, ("push_backward grid",) + what)
+            if case == 0:
+                for dtype, eps in ((torch.bfloat16, 2 ** -7), (torch.float16, 2 ** -10)):
+                    fast = _hip.gather("pull", vd.to(dtype), gd, bounds, orders, ex)
+                    slow = _hip.gather("pull", vd.to(dtype), gd, bounds, orders, ex, flags=_hip.FLAG_NO_FASTPATH)
+                    assert fast.dtype == dtype
+                    _same(fast.float(), slow.float(), 2 * eps, ("pull", dtype) + what)
+                # non-finite lattice points: the same samples are non-finite as in the generic kernel, the others agree
+                vbad = vol.clone()
+                vbad[0, 0, 20, 18, 21] = float("inf"); vbad[1, C - 1, 31, 9, 30] = float("nan"); vbad[0, 0, 0, 0, 0] = float("-inf")
+                fast = _hip.gather("pull", vbad.to(DEV), gd, bounds, orders, ex)
+                slow = _hip.gather("pull", vbad.to(DEV), gd, bounds, orders, ex, flags=_hip.FLAG_NO_FASTPATH)
+                fin = torch.isfinite(slow)
+                assert bool((torch.isfinite(fast) == fin).all()), ("non-finite samples",) + what
+                assert 0 < int((~fin).sum()) < fin.numel() // 4
+                _same(torch.where(fin, fast, 0), torch.where(fin, slow, 0), 4e-6, ("finite samples next to a non-finite point",) + what)
+                gfast = _hip.pull_backward(sd, vbad.to(DEV), gd, bounds, orders, ex, False, True)[1]
+                gslow = _hip.pull_backward(sd, vbad.to(DEV), gd, bounds, orders, ex, False, True, flags=_hip.FLAG_NO_FASTPATH)[1]
+                fin = torch.isfinite(gslow)
+                assert bool((torch.isfinite(gfast) == fin).all()), ("non-finite gradients",) + what
+                _same(torch.where(fin, gfast, 0), torch.where(fin, gslow, 0), 2e-5, ("finite gradients next to a non-finite point",) + what)
+    finally:
+        oracle.set_threads(1)
+
+
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("dim,orders", [(3, [3, 3, 3]), (2, [2, 3]), (2, [1, 1])])
 def test_tiled_low_precision_storage_matches_generic(dtype, dim, orders):

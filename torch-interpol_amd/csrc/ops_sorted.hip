@@ -109,7 +109,10 @@ __device__ __forceinline__ void stencil_reads_k1(unsigned addr, f2 (&v)[4])
 // SORTED samples (coordinates + natural id) and, for the natural order, which of the thread's
 // own samples are fast / must be handled by the thread itself.
 // ---------------------------------------------------------------------------
-template <int K, int GM>
+// MIX (K == 3 only): per-dim runtime orders 1..3 of KParams inside the cubic's four-tap stencil -- first tap floor(x - (k_d-1)/2),
+// taps beyond a dim's order carry weight 0 and their slots are never used (cleared after the reads: a non-finite lattice point
+// outside the true stencil must not reach the sums); box, classes, sort and passes are the cubic's.
+template <int K, int GM, bool MIX = false>
 struct Tile {
     int lo[3], S[3];
     // sorted samples: stencil coordinates t = x - i0 per dim and the packed key
@@ -177,7 +180,7 @@ struct Tile {
         for (int v = 0; v < VPT; ++v) {
 #pragma unroll
             for (int d = 0; d < 3; ++d) {
-                fl[v][d] = floorf(c[v][d] - 0.5f * (float)(K - 1));
+                fl[v][d] = floorf(c[v][d] - (MIX ? 0.5f * (float)(p.order[d] - 1) : 0.5f * (float)(K - 1)));
                 c[v][d] -= fl[v][d];                                 // c becomes t
                 const float fv = ((validmask >> v) & 1) ? fl[v][d] : fmn[d];     // (folds away for full tiles)
                 fmn[d] = __builtin_fminf(fmn[d], fv);
@@ -313,16 +316,17 @@ struct Tile {
 // ---------------------------------------------------------------------------
 // pull: val[b,c,o] = mask * sum_taps w vol        (nd.py:80-143)
 // ---------------------------------------------------------------------------
-template <typename T, int K, int GM>
+template <typename T, int K, int GM, bool MIX = false>
 __global__ __launch_bounds__(NT, 4) void pull_sorted(KParams p, const T *__restrict__ vol, const float *__restrict__ grid,
                                                      T *__restrict__ val, int gx, int gy, int gz, int nty, int ntz, int ntiles, int nbatch,
                                                      DeferArgs defer)
 {
+    static_assert(!MIX || K == 3, "mixed orders live in the cubic's stencil");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     Smem &sm = *reinterpret_cast<Smem *>(smem_raw);
     Lattice L;
 #pragma unroll
-    for (int d = 0; d < 3; ++d) { L.bound[d] = p.bound[d]; L.n[d] = p.vol_n[d]; L.ss[d] = p.vol_ss[d] / (int)sizeof(T); L.k[d] = K; }
+    for (int d = 0; d < 3; ++d) { L.bound[d] = p.bound[d]; L.n[d] = p.vol_n[d]; L.ss[d] = p.vol_ss[d] / (int)sizeof(T); L.k[d] = MIX ? p.order[d] : K; }
     L.lin = 0;
 #ifndef IP_NOVERDICT
     // the probe of the call gave every tile to the bricks (abi.hip: routed_pull); gate_n == -3 (trilinear): the tiles run on verdict 1 alone
@@ -351,9 +355,9 @@ __global__ __launch_bounds__(NT, 4) void pull_sorted(KParams p, const T *__restr
         int tile = work % ntiles;
         const TileGeom g = tile_geom(tile, gx, gy, gz, nty, ntz);
         prof_mark(-1);
-        Tile<K, GM> tl;
+        Tile<K, GM, MIX> tl;
         float cnext[VPT][3];
-        Tile<K, GM>::load(p, grid, b, g, tid, cnext);
+        Tile<K, GM, MIX>::load(p, grid, b, g, tid, cnext);
         tl.build(p, L, g, sm, tid, cnext);
         const int nslow = sm.nslow < SLOWCAP ? sm.nslow : SLOWCAP;
         // interpol_pull_ws: a tile with many samples outside the box -- each costs a wave -- is left to the bricks of the image
@@ -507,9 +511,13 @@ __global__ __launch_bounds__(NT, 4) void pull_sorted(KParams p, const T *__restr
                     }
                     f2 t2[16];
                     stencil_reads(boxaddr + 8u * (unsigned)(xq * PLANE + ((key >> 5) & 2047)), t2);
-                    const float wxi = weight_x<K>(tx, i);
+                    const float wxi = mixed_or_weight_x<K, MIX>(L.k[0], tx, i);
                     f2 w[4];
-                    weights_yz<K>(tyz, w);
+                    if constexpr (MIX) {
+                        clear_unused_taps(L.k[1], L.k[2], t2);
+                        mixed_weights_yz(L.k[1], L.k[2], tyz, w);
+                    } else
+                        weights_yz<K>(tyz, w);
                     f2 pp = { 0.f, 0.f };
 #pragma unroll
                     for (int jy = 0; jy <= K; ++jy) {
@@ -518,6 +526,7 @@ __global__ __launch_bounds__(NT, 4) void pull_sorted(KParams p, const T *__restr
                         for (int k = 0; k <= K; ++k) q = f2{ w[k].y, w[k].y } * t2[4 * jy + k] + q;
                         pp = f2{ w[jy].x, w[jy].x } * q + pp;
                     }
+                    if constexpr (MIX) { if (i > L.k[0]) pp = f2{ 0.f, 0.f }; }     // (a plane beyond the x-stencil may hold anything)
                     acc[j] = f2{ wxi, wxi } * pp + acc[j];
                     // the sums are pinned here: otherwise the FMAs sink past the pass loop's back edge and
                     // the read results of several samples stay live across the barriers (spilled)
@@ -542,7 +551,7 @@ __global__ __launch_bounds__(NT, 4) void pull_sorted(KParams p, const T *__restr
                 const int wave = tid >> 6, lane = tid & 63;
                 for (int sidx = wave; sidx < nslow; sidx += NT / 64) {
                     float a0, a1, m;
-                    slow_taps<T, K, GM>(p, L, grid, b, g, sm.slow[sidx], lane, vc0, vc1, a0, a1, m);
+                    slow_taps<T, K, GM, MIX>(p, L, grid, b, g, sm.slow[sidx], lane, vc0, vc1, a0, a1, m);
                     a0 = wave_sum(a0); a1 = wave_sum(a1);
                     if (lane == 0) outb[sm.slow[sidx]] = make_float2(a0 * m, a1 * m);
                 }
@@ -556,7 +565,7 @@ __global__ __launch_bounds__(NT, 4) void pull_sorted(KParams p, const T *__restr
                     load_xyz<GM>(p, grid, b, g, ox, oy, oz, x);
                     int ii[3]; float tt[3];
 #pragma unroll
-                    for (int d = 0; d < 3; ++d) split(K, x[d], ii[d], tt[d]);
+                    for (int d = 0; d < 3; ++d) split(MIX ? L.k[d] : K, x[d], ii[d], tt[d]);
                     const float m = inb_mask(p, x);
                     outb[tid + NT * v] = make_float2(m * tiled::gather_one_thread<T>(L, vc0, ii[0], ii[1], ii[2], tt[0], tt[1], tt[2], -1),
                                                      m * tiled::gather_one_thread<T>(L, vc1, ii[0], ii[1], ii[2], tt[0], tt[1], tt[2], -1));
@@ -601,16 +610,17 @@ __global__ __launch_bounds__(NT, 4) void pull_sorted(KParams p, const T *__restr
 //   ggrid[b,o,d] = mask * sum_c gout[b,c,o] * d/dx_d pull(vol[b,c])(x_o)
 // The class-sorted gather of pull_sorted with the channels contracted per tap and three derivative sums.
 // ===========================================================================
-template <typename T, int K, int GM>
+template <typename T, int K, int GM, bool MIX = false>
 __global__ __launch_bounds__(NT, 4) void gradc_sorted(KParams p, const T *__restrict__ vol, const T *__restrict__ gout, const float *__restrict__ grid,
                                                       float *__restrict__ ggrid, int gx, int gy, int gz, int nty, int ntz, int ntiles, int nbatch,
                                                       DeferArgs defer)
 {
+    static_assert(!MIX || K == 3, "mixed orders live in the cubic's stencil");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     Smem &sm = *reinterpret_cast<Smem *>(smem_raw);
     Lattice L;
 #pragma unroll
-    for (int d = 0; d < 3; ++d) { L.bound[d] = p.bound[d]; L.n[d] = p.vol_n[d]; L.ss[d] = p.vol_ss[d] / (int)sizeof(T); L.k[d] = K; }
+    for (int d = 0; d < 3; ++d) { L.bound[d] = p.bound[d]; L.n[d] = p.vol_n[d]; L.ss[d] = p.vol_ss[d] / (int)sizeof(T); L.k[d] = MIX ? p.order[d] : K; }
     L.lin = K == 1;                                                  // (all-linear: the reference's iso1 gradients -1, +1 in the out-of-box paths as well)
     // interpol_pull_backward with a bricks workspace: the probe's verdict lies -gate_n ints in front of the tile flags; 1 = every
     // tile goes to the bricks of the image (push_owner.hip: own_probe, nch < 0)
@@ -627,9 +637,9 @@ __global__ __launch_bounds__(NT, 4) void gradc_sorted(KParams p, const T *__rest
         int tile = work % ntiles;
         const TileGeom g = tile_geom(tile, gx, gy, gz, nty, ntz);
         prof_mark(-1);
-        Tile<K, GM> tl;
+        Tile<K, GM, MIX> tl;
         float cnext[VPT][3];
-        Tile<K, GM>::load(p, grid, b, g, tid, cnext);
+        Tile<K, GM, MIX>::load(p, grid, b, g, tid, cnext);
         tl.build(p, L, g, sm, tid, cnext);
         const int nslow = sm.nslow < SLOWCAP ? sm.nslow : SLOWCAP;
         // interpol_pull_backward with a bricks workspace: the tile is left to the bricks of the image (as pull_sorted)
@@ -798,10 +808,19 @@ __global__ __launch_bounds__(NT, 4) void gradc_sorted(KParams p, const T *__rest
                     }
                     f2 t2[16];
                     stencil_reads(boxaddr + 8u * (unsigned)(xq * PLANE + ((key >> 5) & 2047)), t2);
-                    const float wxi = weight_x<K>(tx, i), gxi = wgrad_x<K>(tx, i);
+                    float wxi, gxi;
                     f2 w[4], dq[4];
-                    weights_yz<K>(tyz, w);
-                    wgrads_yz<K>(tyz, dq);
+                    if constexpr (MIX) {
+                        clear_unused_taps(L.k[1], L.k[2], t2);
+                        mixed_weights_yz(L.k[1], L.k[2], tyz, w);
+                        mixed_wgrads_yz(L.k[1], L.k[2], tyz, dq);
+                        wxi = mixed_weight_x(L.k[0], tx, i);
+                        gxi = mixed_wgrad_x(L.k[0], tx, i);
+                    } else {
+                        wxi = weight_x<K>(tx, i); gxi = wgrad_x<K>(tx, i);
+                        weights_yz<K>(tyz, w);
+                        wgrads_yz<K>(tyz, dq);
+                    }
                     // channels contracted with grad_out FIRST (s = g0 v0 + g1 v1 per tap), then the three derivative sums
                     // of a single image (pushpull.py:256-257)
                     float pp = 0.f, ppy = 0.f, ppz = 0.f;
@@ -818,9 +837,11 @@ __global__ __launch_bounds__(NT, 4) void gradc_sorted(KParams p, const T *__rest
                         ppy = __builtin_fmaf(dq[jy].x, q, ppy);
                         ppz = __builtin_fmaf(w[jy].x, qz, ppz);
                     }
-                    ag[j][0] = __builtin_fmaf(gxi, pp, ag[j][0]);
-                    ag[j][1] = __builtin_fmaf(wxi, ppy, ag[j][1]);
-                    ag[j][2] = __builtin_fmaf(wxi, ppz, ag[j][2]);
+                    if (!MIX || i <= L.k[0]) {                        // (mixed orders: a plane beyond the x-stencil may hold anything)
+                        ag[j][0] = __builtin_fmaf(gxi, pp, ag[j][0]);
+                        ag[j][1] = __builtin_fmaf(wxi, ppy, ag[j][1]);
+                        ag[j][2] = __builtin_fmaf(wxi, ppz, ag[j][2]);
+                    }
                     asm volatile("" : "+v"(ag[j][0]), "+v"(ag[j][1]), "+v"(ag[j][2]));
                 }
                 prof_mark(2);
@@ -849,9 +870,9 @@ __global__ __launch_bounds__(NT, 4) void gradc_sorted(KParams p, const T *__rest
                     load_xyz<GM>(p, grid, b, g, ox, oy, oz, x);
                     const int64_t o = ((int64_t)ox * g.gy + oy) * g.gz + oz;
                     int off; float gr[3];
-                    tiled::tap_weight_t<K, K>(L, x[0], x[1], x[2], lane, &off, gr);
+                    tiled::tap_weight_t<MIX ? -1 : K, MIX ? -1 : K>(L, x[0], x[1], x[2], lane, &off, gr);
                     float sgl = 0.f;
-                    if (lane < (K + 1) * (K + 1) * (K + 1))
+                    if (lane < (MIX ? (L.k[0] + 1) * (L.k[1] + 1) * (L.k[2] + 1) : (K + 1) * (K + 1) * (K + 1)))
                         for (int cc = 0; cc < p.C; ++cc)
                             sgl = __builtin_fmaf(gout ? Cvt<float, T>::ld(gout[b * p.val_sb + cc * p.val_sc + o]) : 1.f, Cvt<float, T>::ld(vol[b * p.vol_sb + cc * p.vol_sc + off]), sgl);
                     const float m = inb_mask(p, x);
@@ -869,7 +890,7 @@ __global__ __launch_bounds__(NT, 4) void gradc_sorted(KParams p, const T *__rest
                     const int64_t o = ((int64_t)ox * g.gy + oy) * g.gz + oz;
                     int ii[3]; float tt[3];
 #pragma unroll
-                    for (int d = 0; d < 3; ++d) split(K, x[d], ii[d], tt[d]);
+                    for (int d = 0; d < 3; ++d) split(MIX ? L.k[d] : K, x[d], ii[d], tt[d]);
                     const float m = inb_mask(p, x);
                     float a[3] = { 0.f, 0.f, 0.f };
                     for (int cc = 0; cc < p.C; ++cc) {
@@ -1261,17 +1282,17 @@ struct TileCount {
     }
 };
 
-template <typename T, int K, int GM>
+template <typename T, int K, int GM, bool MIX = false>
 static int launch_pull(const interpol_problem *p, const KParams &k, const void *vol, const void *grid, void *val, hipStream_t st)
 {
-    const int attr = big_lds<pull_sorted<T, K, GM>>(sizeof(Smem));
+    const int attr = big_lds<pull_sorted<T, K, GM, MIX>>(sizeof(Smem));
     if (attr) return attr;
     const TileCount t(p);
     const Defer df(k, st, t.ntiles(), p->batch, t.ntx, t.nty, t.ntz, TS, TS, TS);
     // two tiles per workgroup, dealt by the dispatcher as workgroups retire: 1.36 -> 1.28 ms at config 2 against two persistent
     // workgroups per CU walking equal shares (tiles differ in cost: slow lists, box sizes); debug bits 13-15: 7 = persistent, 1-4 = tiles
     const int mopt = (k.dbg >> 13) & 7, mult = mopt == 0 ? 2 : mopt;
-    hipLaunchKernelGGL((pull_sorted<T, K, GM>), mopt == 7 ? t.grid((int)p->batch) : t.grid_each((int)p->batch, mult), dim3(NT), sizeof(Smem), st,
+    hipLaunchKernelGGL((pull_sorted<T, K, GM, MIX>), mopt == 7 ? t.grid((int)p->batch) : t.grid_each((int)p->batch, mult), dim3(NT), sizeof(Smem), st,
                        k, (const T *)vol, (const float *)grid, (T *)val, t.gx, t.gy, t.gz, t.nty, t.ntz, t.ntiles(), (int)p->batch, df.args);
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) return (int)e;
@@ -1279,17 +1300,17 @@ static int launch_pull(const interpol_problem *p, const KParams &k, const void *
     return rc ? rc : 1;
 }
 
-template <typename T, int K, int GM>
+template <typename T, int K, int GM, bool MIX = false>
 static int launch_gradc(const interpol_problem *p, const KParams &k, const void *gout, const void *vol, const void *grid, void *ggrid, hipStream_t st)
 {
-    const int attr = big_lds<gradc_sorted<T, K, GM>>(sizeof(Smem));
+    const int attr = big_lds<gradc_sorted<T, K, GM, MIX>>(sizeof(Smem));
     if (attr) return attr;
     const TileCount t(p);
     const Defer df(k, st, t.ntiles(), p->batch, t.ntx, t.nty, t.ntz, TS, TS, TS);
     const int mopt = (k.dbg >> 13) & 7, mult = mopt == 0 ? 2 : mopt;   // (as launch_pull)
     // (behind the probe of interpol_pull_backward's router -- gate_n < 0 -- the kernel usually returns at once: two workgroups per CU
     //  instead of 8192 that are dispatched for nothing, 50 us)
-    hipLaunchKernelGGL((gradc_sorted<T, K, GM>), (mopt == 7 || (k.gate && k.gate_n < 0)) ? t.grid((int)p->batch) : t.grid_each((int)p->batch, mult), dim3(NT), sizeof(Smem), st,
+    hipLaunchKernelGGL((gradc_sorted<T, K, GM, MIX>), (mopt == 7 || (k.gate && k.gate_n < 0)) ? t.grid((int)p->batch) : t.grid_each((int)p->batch, mult), dim3(NT), sizeof(Smem), st,
                        k, (const T *)vol, (const T *)gout, (const float *)grid, (float *)ggrid, t.gx, t.gy, t.gz, t.nty, t.ntz, t.ntiles(), (int)p->batch, df.args);
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) return (int)e;
@@ -1323,6 +1344,7 @@ static int launch_push(const interpol_problem *p, const KParams &k, const void *
 } // namespace sorted
 
 // Eligibility: 3-D, one order 2..3 for all dims, enough samples, 32-bit offsets into one item's grid.
+constexpr int MIXED = 13;                                          // sorted_order: orders 1..3, not all equal
 static int sorted_order(const interpol_problem *p, const KParams &k, bool linear = false)
 {
     if (p->dim != 3 || p->batch > 65535) return -1;
@@ -1335,13 +1357,28 @@ static int sorted_order(const interpol_problem *p, const KParams &k, bool linear
     }
     if (n < 4096 || nt > 0x7fffffff) return -1;
     if ((uint64_t)n * 12ull > 0xffffffffull) return -1;
-    if (k.order[0] != k.order[1] || k.order[0] != k.order[2]) return -1;
+    if (k.order[0] != k.order[1] || k.order[0] != k.order[2]) {
+        // mixed orders 1..3 (round 6): the cubic tiles with per-dim runtime weights -- gathers on dense grids only
+        for (int d = 0; d < 3; ++d) if (k.order[d] < 1 || k.order[d] > 3) return -1;
+        return linear && k.sep == 0 ? MIXED : -1;
+    }
     if (k.order[0] < (linear ? 1 : 2) || k.order[0] > 3) return -1;
     return k.order[0];
 }
 
 #define IP_SYM2(a, b) a##b
 #define IP_SYM(a, b) IP_SYM2(a, b)
+
+// The mixed-order instantiations live in a translation unit of their own (the same file compiled with -DIP_SORTED_MIX_TU): with them in
+// one module the register allocation of the ISOTROPIC kernels changes (pull_sorted<float, 3, 0>: 96 -> 128 B of scratch, +3.5 % at config 2).
+int IP_SYM(sorted_pull_mixed_, IP_TSFX)(const interpol_problem *p, const KParams &k, const void *vol, const void *grid, void *val, hipStream_t st);
+int IP_SYM(sorted_gradc_mixed_, IP_TSFX)(const interpol_problem *p, const KParams &k, const void *gout, const void *vol, const void *grid, void *ggrid, hipStream_t st);
+#ifdef IP_SORTED_MIX_TU
+int IP_SYM(sorted_pull_mixed_, IP_TSFX)(const interpol_problem *p, const KParams &k, const void *vol, const void *grid, void *val, hipStream_t st)
+{ return sorted::launch_pull<IP_TT, 3, 0, true>(p, k, vol, grid, val, st); }
+int IP_SYM(sorted_gradc_mixed_, IP_TSFX)(const interpol_problem *p, const KParams &k, const void *gout, const void *vol, const void *grid, void *ggrid, hipStream_t st)
+{ return sorted::launch_gradc<IP_TT, 3, 0, true>(p, k, gout, vol, grid, ggrid, st); }
+#else
 
 #ifdef IP_EXPERIMENTS
 // the windowed gather (experiments/pull_window.hip, `make experiments`): every sample visited once -- measured slower, not in the product
@@ -1353,6 +1390,7 @@ int IP_SYM(try_sorted_pull_, IP_TSFX)(const interpol_problem *p, const KParams &
 {
     const int K = sorted_order(p, k, true);
     if (K < 0) return 0;
+    if (K == MIXED) return (k.dbg & 16) ? 0 : IP_SYM(sorted_pull_mixed_, IP_TSFX)(p, k, vol, grid, val, st);
     if (K == 1) {                                                    // trilinear (round 5): dense grids and displacement fields
         using T1 = IP_TT;
         if (k.sep == 0) return sorted::launch_pull<T1, 1, 0>(p, k, vol, grid, val, st);
@@ -1390,6 +1428,7 @@ int IP_SYM(try_sorted_gradc_, IP_TSFX)(const interpol_problem *p, const KParams 
     const int K = sorted_order(p, k, true);
     if (K < 0 || (k.dbg & 16)) return 0;
     using T = IP_TT;
+    if (K == MIXED) return IP_SYM(sorted_gradc_mixed_, IP_TSFX)(p, k, gout, vol, grid, ggrid, st);
     if (K == 1) {                                                    // trilinear (round 5; mode iso1: every dim linear)
         if (k.mode != MODE_ISO1) return 0;
         if (k.sep == 0) return sorted::launch_gradc<T, 1, 0>(p, k, gout, vol, grid, ggrid, st);
@@ -1431,9 +1470,11 @@ int IP_SYM(try_sorted_push_, IP_TSFX)(const interpol_problem *p, const KParams &
     return sorted::launch_push<T, 2, 0>(p, k, val, grid, vol, st);
 }
 
+#endif // IP_SORTED_MIX_TU
+
 } // namespace ip
 
-#ifdef IP_PROF
+#if defined(IP_PROF) && !defined(IP_SORTED_MIX_TU)
 #define IP_PROF_NAME3(s) interpol_debug_prof_sorted_##s
 #define IP_PROF_NAME2(s) IP_PROF_NAME3(s)
 extern "C" __attribute__((visibility("default"))) int IP_PROF_NAME2(IP_TSFX)(unsigned long long *out, int reset)

@@ -228,7 +228,76 @@ __device__ __forceinline__ float wgrad_x(float t, int i)
 
 // One out-of-box sample gathered tap-parallel by a wave: lane = tap; returns this lane's products
 // for the two channels (to be summed over the wave) and the sample's extrapolation mask.
-template <typename T, int K, int GM>
+// Mixed orders (1..3 per dim, kernel-uniform) in the cubic tiles: the four weights of one dim in the closed forms of weights_yz /
+// wgrads_yz above, chosen by a uniform branch on the dim's order; taps beyond the order 0 ...
+__device__ __forceinline__ void weights4(int k, float t, float *w)
+{
+    if (k == 3) {
+        const float u = t - 1.f, v = 2.f - t, u2 = u * u, v2 = v * v;
+        w[0] = (v2 * v) * (1.f / 6.f); w[3] = (u2 * u) * (1.f / 6.f);
+        w[1] = u2 * (u * 0.5f - 1.f) + 2.f / 3.f; w[2] = v2 * (v * 0.5f - 1.f) + 2.f / 3.f;
+    } else if (k == 2) {
+        const float a = 1.5f - t, c = t - 0.5f, m = t - 1.f;
+        w[0] = (a * a) * 0.5f; w[1] = 0.75f - m * m; w[2] = (c * c) * 0.5f; w[3] = 0.f;
+    } else {
+        w[0] = 1.f - t; w[1] = t; w[2] = 0.f; w[3] = 0.f;
+    }
+}
+// (order 1 outside the all-linear mode: the reference's nd path, +sign(t - j) -- quirk B-4, spline_math.hpp: bspline_g)
+__device__ __forceinline__ void wgrads4(int k, float t, float *g)
+{
+    if (k == 3) {
+        const float u = t - 1.f, v = 2.f - t;
+        g[0] = (v * v) * -0.5f; g[3] = (u * u) * 0.5f; g[1] = u * (u * 1.5f - 2.f); g[2] = v * (v * -1.5f + 2.f);
+    } else if (k == 2) {
+        g[0] = t - 1.5f; g[1] = (t - 1.f) * -2.f; g[2] = t - 0.5f; g[3] = 0.f;
+    } else {
+        g[0] = t > 0.f ? 1.f : 0.f; g[1] = -1.f; g[2] = 0.f; g[3] = 0.f;
+    }
+}
+__device__ __forceinline__ void mixed_weights_yz(int ky, int kz, f2 t, f2 *w)
+{
+    float wy[4], wz[4];
+    weights4(ky, t.x, wy);
+    weights4(kz, t.y, wz);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) w[j] = f2{ wy[j], wz[j] };
+}
+__device__ __forceinline__ void mixed_wgrads_yz(int ky, int kz, f2 t, f2 *g)
+{
+    float gy[4], gz[4];
+    wgrads4(ky, t.x, gy);
+    wgrads4(kz, t.y, gz);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) g[j] = f2{ gy[j], gz[j] };
+}
+// the x-weight of tap i (per lane: i = the tap this pass serves) and its derivative
+__device__ __forceinline__ float mixed_weight_x(int kx, float t, int i)
+{
+    return kx == 3 ? weight_x<3>(t, i) : (kx == 2 ? weight_x<2>(t, i) : weight_x<1>(t, i));
+}
+__device__ __forceinline__ float mixed_wgrad_x(int kx, float t, int i)
+{
+    return kx == 3 ? wgrad_x<3>(t, i) : (kx == 2 ? wgrad_x<2>(t, i) : (i == 0 ? (t > 0.f ? 1.f : 0.f) : (i == 1 ? -1.f : 0.f)));
+}
+// ... and the slots they would have multiplied cleared (t2[4 * jy + kz_tap]: 0 * inf is not 0)
+__device__ __forceinline__ void clear_unused_taps(int ky, int kz, f2 *t2)
+{
+    const f2 z = { 0.f, 0.f };
+    if (kz < 3) { t2[3] = z; t2[7] = z; t2[11] = z; t2[15] = z; }
+    if (kz < 2) { t2[2] = z; t2[6] = z; t2[10] = z; t2[14] = z; }
+    if (ky < 3) { t2[12] = z; t2[13] = z; t2[14] = z; t2[15] = z; }
+    if (ky < 2) { t2[8] = z; t2[9] = z; t2[10] = z; t2[11] = z; }
+}
+
+template <int K, bool MIX>
+__device__ __forceinline__ float mixed_or_weight_x(int kx, float t, int i)
+{
+    if constexpr (MIX) return mixed_weight_x(kx, t, i);
+    else return weight_x<K>(t, i);
+}
+
+template <typename T, int K, int GM, bool MIX = false>
 __device__ __forceinline__ void slow_taps(const KParams &p, const Lattice &L, const float *__restrict__ grid, int64_t b, const TileGeom &g,
                                           int id, int lane, const T *__restrict__ vc0, const T *__restrict__ vc1, float &a0, float &a1, float &m)
 {
@@ -236,9 +305,9 @@ __device__ __forceinline__ void slow_taps(const KParams &p, const Lattice &L, co
     sample_pos(g, id, ox, oy, oz);
     load_xyz<GM>(p, grid, b, g, ox, oy, oz, x);
     int off;
-    const float w = tiled::tap_weight_t<K, K>(L, x[0], x[1], x[2], lane, &off, nullptr);
+    const float w = tiled::tap_weight_t<MIX ? -1 : K, MIX ? -1 : K>(L, x[0], x[1], x[2], lane, &off, nullptr);
     a0 = 0.f; a1 = 0.f;
-    if (lane < (K + 1) * (K + 1) * (K + 1)) { a0 = w * Cvt<float, T>::ld(vc0[off]); a1 = w * Cvt<float, T>::ld(vc1[off]); }
+    if (lane < (MIX ? (L.k[0] + 1) * (L.k[1] + 1) * (L.k[2] + 1) : (K + 1) * (K + 1) * (K + 1))) { a0 = w * Cvt<float, T>::ld(vc0[off]); a1 = w * Cvt<float, T>::ld(vc1[off]); }
     m = inb_mask(p, x);
 }
 
