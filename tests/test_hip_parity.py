@@ -1010,6 +1010,67 @@ def test_tiled_mixed_orders_match_generic(dim, orders, sigma):
 
 
 @pytest.mark.timeout(600)
+@pytest.mark.parametrize("order", [1, 2, 3, 4, 5, 6, 7])
+def test_push1d_tiles_against_the_oracle(order):
+    """Round 6: 1-D push / count on LDS tiles (csrc/push1d.hip; until then the generic kernel's per-tap float atomics).  DEFAULT routing
+    against the C oracle (float64 evaluation of the same float32 inputs) and the generic kernel: every bound, the three extrapolation
+    modes, 1 - 3 channels, ragged sample counts (whole and partial tiles), a gentle and a rough field, a contraction (many samples per
+    lattice point: the headroom of the fixed point), an expansion beyond the LDS box (the centre in the box, the rest per thread), wild
+    coordinates, push + count in one call, count alone, one shared target, 16-bit sources, non-finite sources.
+    Reference: nd.py:146-213, pushpull.py:106-142, bounds.py:30-89."""
+    import os
+    from interpol import _hip
+    gen = torch.Generator().manual_seed(40 + order)
+    rtol, atol_rel = G.fp32_tol([order])
+    o = [order]
+    oracle.set_threads(os.cpu_count() or 8)
+    try:
+        for case, (bound, ex, C, n_in, n_out, zoom, sigma) in enumerate(((3, 1, 2, 5000, 5000, 1.0, 2.0), (0, 0, 1, 4096, 4100, 1.0, 0.5),
+                                                                         (6, 2, 3, 9001, 2003, 0.22, 3.0), (4, 1, 2, 3000, 20000, 6.5, 1.0),
+                                                                         (1, 2, 1, 7000, 6000, 0.85, 400.0), (5, 0, 3, 5000, 5003, 1.0, 1.0),
+                                                                         (2, 1, 2, 6000, 5800, 0.97, 0.3))):
+            src = torch.randn([3, C, n_in], generator=gen)
+            grid = (torch.arange(n_in, dtype=torch.float32) * zoom + sigma * torch.randn([3, n_in], generator=gen))[..., None].contiguous()
+            grid[0, 0] = -3.0 * n_out                                  # far outside
+            grid[1, 7] = 3.0 * n_out + 0.25
+            for thr in (-0.55, -0.05, n_out - 1 + 0.05, n_out - 1 + 0.55):      # (float32 vs float64 mask thresholds, nd.py:10-27: see the mixed-orders test)
+                grid = torch.where((grid - thr).abs() < 1e-3, grid + 4e-3, grid)
+            sd, gd = src.to(DEV), grid.to(DEV)
+            s64, g64 = src.double(), grid.double()
+            what = (order, bound, ex, C, n_in, n_out, zoom, sigma)
+            b = [bound]
+            want_p = np.asarray(oracle.grid_push(s64, g64, [n_out], b, o, ex))
+            want_c = np.asarray(oracle.grid_count(g64, [n_out], b, o, ex))
+            got = _hip.scatter("push", sd, gd, [n_out], b, o, ex, with_count=True)
+            assert list(got.shape) == [3, C + 1, n_out]
+            G.assert_close(got[:, :C].cpu().numpy(), want_p, rtol, atol_rel, ("push",) + what)
+            G.assert_close(got[:, C:].cpu().numpy(), want_c, rtol, atol_rel, ("count with push",) + what)
+            G.assert_close(_hip.scatter("push", sd, gd, [n_out], b, o, ex).cpu().numpy(), want_p, rtol, atol_rel, ("push alone",) + what)
+            G.assert_close(_hip.scatter("count", None, gd, [n_out], b, o, ex).cpu().numpy(), want_c, rtol, atol_rel, ("count",) + what)
+            _same(got, _hip.scatter("push", sd, gd, [n_out], b, o, ex, with_count=True, flags=_hip.FLAG_NO_FASTPATH), 1e-5, ("vs generic",) + what)
+            sh = torch.zeros([1, C + 1, n_out], device=DEV)
+            _hip.scatter("push", sd, gd, [n_out], b, o, ex, flags=_hip.FLAG_ACCUMULATE, out=sh, shared=True, with_count=True)
+            G.assert_close(sh[:, :C].cpu().numpy(), want_p.sum(0, keepdims=True), rtol, atol_rel, ("shared target",) + what)
+            if case in (0, 2):
+                for dtype, eps in ((torch.bfloat16, 2 ** -7), (torch.float16, 2 ** -10)):
+                    lp = _hip.scatter("push", sd.to(dtype), gd, [n_out], b, o, ex)
+                    assert lp.dtype == dtype
+                    ref = np.asarray(oracle.grid_push(sd.to(dtype).double().cpu(), g64, [n_out], b, o, ex))
+                    G.assert_close(lp.double().cpu().numpy(), ref, 2 * eps, 2 * eps, ("push", dtype) + what)
+            if case == 0:
+                # non-finite sources: they reach their own stencils and nothing else (a tile that holds one scatters per thread)
+                bad = src.clone()
+                bad[0, 0, 1234] = float("inf"); bad[2, C - 1, 4999] = float("nan")
+                fast = _hip.scatter("push", bad.to(DEV), gd, [n_out], b, o, ex)
+                slow = _hip.scatter("push", bad.to(DEV), gd, [n_out], b, o, ex, flags=_hip.FLAG_NO_FASTPATH)
+                fin = torch.isfinite(slow)
+                assert bool((torch.isfinite(fast) == fin).all()) and 0 < int((~fin).sum()) < 64, ("non-finite sources",) + what
+                _same(torch.where(fin, fast, 0), torch.where(fin, slow, 0), 1e-5, ("next to non-finite sources",) + what)
+    finally:
+        oracle.set_threads(1)
+
+
+@pytest.mark.timeout(600)
 @pytest.mark.parametrize("orders", [[1, 2, 3], [3, 1, 2], [2, 3, 1], [3, 3, 1], [1, 1, 2], [2, 3, 3], [3, 2, 2]])
 def test_sorted_tiles_mixed_orders_against_the_oracle(orders):
     """Round 6: 3-D mixed orders 1..3 run in the class-sorted cubic tiles (csrc/ops_sorted.hip: pull_sorted / gradc_sorted <.., MIX>:

@@ -2391,13 +2391,16 @@ int IP_SYM(try_fast_grad_, IP_TSFX)(const interpol_problem *p, const KParams &k,
 #endif
 
 int IP_SYM(try_sorted_push_, IP_TSFX)(const interpol_problem *p, const KParams &k, const void *val, const void *grid, void *vol, hipStream_t st);
+// 1-D scatter tiles (push1d.hip)
+int IP_SYM(try_push1d_, IP_TSFX)(const interpol_problem *p, const KParams &k, const void *val, const void *grid, void *vol, hipStream_t st);
 
 #if !defined(IP_TPART) || IP_TPART == 2
 // `vol` is the (already zero-filled or accumulating) FLOAT target; `val` == NULL means count.
 int IP_SYM(try_fast_push_, IP_TSFX)(const interpol_problem *p, const KParams &k, const void *val, const void *grid, void *vol, hipStream_t st)
 {
     {
-        const int rc = p->dim == 2 ? IP_SYM(try_tiled2d_push_, IP_TSFX)(p, k, val, grid, vol, st) : IP_SYM(try_sorted_push_, IP_TSFX)(p, k, val, grid, vol, st);
+        const int rc = p->dim == 2 ? IP_SYM(try_tiled2d_push_, IP_TSFX)(p, k, val, grid, vol, st)
+                     : (p->dim == 1 ? IP_SYM(try_push1d_, IP_TSFX)(p, k, val, grid, vol, st) : IP_SYM(try_sorted_push_, IP_TSFX)(p, k, val, grid, vol, st));
         if (rc != 0) return rc;
     }
     IP_BY_ORDER(tiled::launch_push, >(p, k, val, grid, vol, st))
