@@ -486,6 +486,15 @@ __global__ __launch_bounds__(NT, 4) void pull_sorted(KParams p, const T *__restr
                 prof_mark(1);
                 if (p.dbg & 2) continue;
                 const unsigned boxaddr = (unsigned)(size_t)(__attribute__((address_space(3))) void *)(sm.box);
+                // (mixed orders: the loop below once per combination of per-dim orders, chosen by a uniform branch -- the orders are
+                //  compile-time constants inside, like K in the isotropic kernels)
+#ifdef IP_SORTED_MIX_TU
+                auto taps = [&](auto kxc, auto kyc, auto kzc) {
+                [[maybe_unused]] constexpr int KX = decltype(kxc)::value, KY = decltype(kyc)::value, KZ = decltype(kzc)::value;
+#else
+                {                                                    // (the isotropic module: no lambda -- its code is kept as it was, to the byte)
+                [[maybe_unused]] constexpr int KX = K, KY = K, KZ = K;
+#endif
 #pragma unroll
                 for (int j = 0; j < VPT; ++j) {
                     // (opaque per pass: the weights are recomputed -- hoisted out of the pass loop they
@@ -511,27 +520,33 @@ __global__ __launch_bounds__(NT, 4) void pull_sorted(KParams p, const T *__restr
                     }
                     f2 t2[16];
                     stencil_reads(boxaddr + 8u * (unsigned)(xq * PLANE + ((key >> 5) & 2047)), t2);
-                    const float wxi = mixed_or_weight_x<K, MIX>(L.k[0], tx, i);
+                    const float wxi = mixed_or_weight_x<K, MIX>(KX, tx, i);
                     f2 w[4];
-                    if constexpr (MIX) {
-                        clear_unused_taps(L.k[1], L.k[2], t2);
-                        mixed_weights_yz(L.k[1], L.k[2], tyz, w);
-                    } else
-                        weights_yz<K>(tyz, w);
+                    if constexpr (MIX) mixed_weights_yz(KY, KZ, tyz, w);
+                    else weights_yz<K>(tyz, w);
+                    // (mixed orders: KY, KZ <= K = 3 bound the loops -- the slots beyond a dim's order are read but never used:
+                    //  a non-finite lattice point outside the true stencil stays out of the sums)
                     f2 pp = { 0.f, 0.f };
 #pragma unroll
-                    for (int jy = 0; jy <= K; ++jy) {
+                    for (int jy = 0; jy <= KY; ++jy) {
                         f2 q = { 0.f, 0.f };
 #pragma unroll
-                        for (int k = 0; k <= K; ++k) q = f2{ w[k].y, w[k].y } * t2[4 * jy + k] + q;
+                        for (int k = 0; k <= KZ; ++k) q = f2{ w[k].y, w[k].y } * t2[4 * jy + k] + q;
                         pp = f2{ w[jy].x, w[jy].x } * q + pp;
                     }
-                    if constexpr (MIX) { if (i > L.k[0]) pp = f2{ 0.f, 0.f }; }     // (a plane beyond the x-stencil may hold anything)
+                    if constexpr (MIX) { if (i > KX) pp = f2{ 0.f, 0.f }; }     // (a plane beyond the x-stencil may hold anything)
                     acc[j] = f2{ wxi, wxi } * pp + acc[j];
                     // the sums are pinned here: otherwise the FMAs sink past the pass loop's back edge and
                     // the read results of several samples stay live across the barriers (spilled)
                     asm volatile("" : "+v"(acc[j]));
                 }
+#ifdef IP_SORTED_MIX_TU
+                };
+                if constexpr (MIX) mix_dispatch(L.k[0], L.k[1], L.k[2], taps);
+                else taps(std::integral_constant<int, K>{}, std::integral_constant<int, K>{}, std::integral_constant<int, K>{});
+#else
+                }
+#endif
                 prof_mark(2);
             }
             {
@@ -777,6 +792,15 @@ __global__ __launch_bounds__(NT, 4) void gradc_sorted(KParams p, const T *__rest
                 prof_mark(1);
                 if (p.dbg & 2) continue;
                 const unsigned boxaddr = (unsigned)(size_t)(__attribute__((address_space(3))) void *)(sm.box);
+                // (mixed orders: the loop below once per combination of per-dim orders, chosen by a uniform branch -- the orders are
+                //  compile-time constants inside, like K in the isotropic kernels)
+#ifdef IP_SORTED_MIX_TU
+                auto taps = [&](auto kxc, auto kyc, auto kzc) {
+                [[maybe_unused]] constexpr int KX = decltype(kxc)::value, KY = decltype(kyc)::value, KZ = decltype(kzc)::value;
+#else
+                {                                                    // (the isotropic module: no lambda -- its code is kept as it was, to the byte)
+                [[maybe_unused]] constexpr int KX = K, KY = K, KZ = K;
+#endif
 #pragma unroll
                 for (int j = 0; j < VPT; ++j) {
                     // (opaque per pass: the weights are recomputed -- hoisted out of the pass loop they
@@ -811,11 +835,10 @@ __global__ __launch_bounds__(NT, 4) void gradc_sorted(KParams p, const T *__rest
                     float wxi, gxi;
                     f2 w[4], dq[4];
                     if constexpr (MIX) {
-                        clear_unused_taps(L.k[1], L.k[2], t2);
-                        mixed_weights_yz(L.k[1], L.k[2], tyz, w);
-                        mixed_wgrads_yz(L.k[1], L.k[2], tyz, dq);
-                        wxi = mixed_weight_x(L.k[0], tx, i);
-                        gxi = mixed_wgrad_x(L.k[0], tx, i);
+                        mixed_weights_yz(KY, KZ, tyz, w);
+                        mixed_wgrads_yz(KY, KZ, tyz, dq);
+                        wxi = mixed_weight_x(KX, tx, i);
+                        gxi = mixed_wgrad_x(KX, tx, i);
                     } else {
                         wxi = weight_x<K>(tx, i); gxi = wgrad_x<K>(tx, i);
                         weights_yz<K>(tyz, w);
@@ -825,10 +848,10 @@ __global__ __launch_bounds__(NT, 4) void gradc_sorted(KParams p, const T *__rest
                     // of a single image (pushpull.py:256-257)
                     float pp = 0.f, ppy = 0.f, ppz = 0.f;
 #pragma unroll
-                    for (int jy = 0; jy <= K; ++jy) {
+                    for (int jy = 0; jy <= KY; ++jy) {                // (KY, KZ: = K, or the dims' own orders in the mixed kernels)
                         float q = 0.f, qz = 0.f;
 #pragma unroll
-                        for (int k = 0; k <= K; ++k) {
+                        for (int k = 0; k <= KZ; ++k) {
                             const float sgl = __builtin_fmaf(go[j].y, t2[4 * jy + k].y, go[j].x * t2[4 * jy + k].x);
                             q = __builtin_fmaf(w[k].y, sgl, q);
                             qz = __builtin_fmaf(dq[k].y, sgl, qz);
@@ -837,13 +860,20 @@ __global__ __launch_bounds__(NT, 4) void gradc_sorted(KParams p, const T *__rest
                         ppy = __builtin_fmaf(dq[jy].x, q, ppy);
                         ppz = __builtin_fmaf(w[jy].x, qz, ppz);
                     }
-                    if (!MIX || i <= L.k[0]) {                        // (mixed orders: a plane beyond the x-stencil may hold anything)
+                    if (!MIX || i <= KX) {                             // (mixed orders: a plane beyond the x-stencil may hold anything)
                         ag[j][0] = __builtin_fmaf(gxi, pp, ag[j][0]);
                         ag[j][1] = __builtin_fmaf(wxi, ppy, ag[j][1]);
                         ag[j][2] = __builtin_fmaf(wxi, ppz, ag[j][2]);
                     }
                     asm volatile("" : "+v"(ag[j][0]), "+v"(ag[j][1]), "+v"(ag[j][2]));
                 }
+#ifdef IP_SORTED_MIX_TU
+                };
+                if constexpr (MIX) mix_dispatch(L.k[0], L.k[1], L.k[2], taps);
+                else taps(std::integral_constant<int, K>{}, std::integral_constant<int, K>{}, std::integral_constant<int, K>{});
+#else
+                }
+#endif
                 prof_mark(2);
             }
             prof_mark(3);

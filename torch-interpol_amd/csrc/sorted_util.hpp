@@ -229,7 +229,7 @@ __device__ __forceinline__ float wgrad_x(float t, int i)
 // One out-of-box sample gathered tap-parallel by a wave: lane = tap; returns this lane's products
 // for the two channels (to be summed over the wave) and the sample's extrapolation mask.
 // Mixed orders (1..3 per dim, kernel-uniform) in the cubic tiles: the four weights of one dim in the closed forms of weights_yz /
-// wgrads_yz above, chosen by a uniform branch on the dim's order; taps beyond the order 0 ...
+// wgrads_yz above, chosen by the dim's order (a compile-time constant after mix_dispatch); taps beyond the order 0
 __device__ __forceinline__ void weights4(int k, float t, float *w)
 {
     if (k == 3) {
@@ -280,14 +280,18 @@ __device__ __forceinline__ float mixed_wgrad_x(int kx, float t, int i)
 {
     return kx == 3 ? wgrad_x<3>(t, i) : (kx == 2 ? wgrad_x<2>(t, i) : (i == 0 ? (t > 0.f ? 1.f : 0.f) : (i == 1 ? -1.f : 0.f)));
 }
-// ... and the slots they would have multiplied cleared (t2[4 * jy + kz_tap]: 0 * inf is not 0)
-__device__ __forceinline__ void clear_unused_taps(int ky, int kz, f2 *t2)
+// f(kx, ky, kz) with the three orders (1..3 each, kernel-uniform) as integral constants
+template <typename F>
+__device__ __forceinline__ void mix_dispatch(int kx, int ky, int kz, F &&f)
 {
-    const f2 z = { 0.f, 0.f };
-    if (kz < 3) { t2[3] = z; t2[7] = z; t2[11] = z; t2[15] = z; }
-    if (kz < 2) { t2[2] = z; t2[6] = z; t2[10] = z; t2[14] = z; }
-    if (ky < 3) { t2[12] = z; t2[13] = z; t2[14] = z; t2[15] = z; }
-    if (ky < 2) { t2[8] = z; t2[9] = z; t2[10] = z; t2[11] = z; }
+    using std::integral_constant;
+    auto dz = [&](auto a, auto b) {
+        if (kz == 1) f(a, b, integral_constant<int, 1>{}); else if (kz == 2) f(a, b, integral_constant<int, 2>{}); else f(a, b, integral_constant<int, 3>{});
+    };
+    auto dy = [&](auto a) {
+        if (ky == 1) dz(a, integral_constant<int, 1>{}); else if (ky == 2) dz(a, integral_constant<int, 2>{}); else dz(a, integral_constant<int, 3>{});
+    };
+    if (kx == 1) dy(integral_constant<int, 1>{}); else if (kx == 2) dy(integral_constant<int, 2>{}); else dy(integral_constant<int, 3>{});
 }
 
 template <int K, bool MIX>
