@@ -2,7 +2,7 @@
 """Randomised parity run against the oracle (not collected by pytest; run by hand on a GPU box: python tests/fuzz_oracle.py
 [n_cases] [seed]).  Operators through the C-ABI with the default routing (tile kernels, hand-back, ...) vs the fp64 oracle
 (oracle/: test infrastructure, the CPU restatement of nd.py / pushpull.py) on random problems of a size the tile kernels
-accept: dims 2-3, mixed orders and bounds, the three extrapolation modes, identity / noisy / zoomed / rough lattices,
+accept: dims 1-3 (1-D: the scatter tiles of push1d.hip), mixed orders and bounds, the three extrapolation modes, identity / noisy / zoomed / rough lattices,
 broadcast batches.  Tolerance: the parity bar of tests/golden_util.py (fp32: 1e-5 relative + 1e-5 of the largest value,
 looser for scatters that pile thousands of samples on a voxel)."""
 import sys, os, random
@@ -21,9 +21,9 @@ def rel(a, r):
     return float(np.abs(a - r).max() / max(np.abs(r).max(), 1e-20))
 bad = 0
 for case in range(n_cases):
-    dim = rnd.choice([2, 3, 3]); B = rnd.choice([1, 2]); C = rnd.choice([1, 2, 3])
-    ishape = [rnd.randint(17, 40) for _ in range(3)] if dim == 3 else [rnd.randint(40, 150) for _ in range(2)]
-    oshape = [rnd.randint(17, 40) for _ in range(3)] if dim == 3 else [rnd.randint(65, 150) for _ in range(2)]
+    dim = rnd.choice([1, 2, 3, 3, 3]); B = rnd.choice([1, 2]); C = rnd.choice([1, 2, 3])
+    ishape = [rnd.randint(17, 40) for _ in range(3)] if dim == 3 else ([rnd.randint(40, 150) for _ in range(2)] if dim == 2 else [rnd.randint(300, 7000)])
+    oshape = [rnd.randint(17, 40) for _ in range(3)] if dim == 3 else ([rnd.randint(65, 150) for _ in range(2)] if dim == 2 else [rnd.randint(4096, 9000)])
     order = [rnd.choice([0, 1, 2, 3, 3, 4, 5, 7])] * dim if rnd.random() < 0.6 else [rnd.choice([1, 2, 3]) for _ in range(dim)]
     bound = [rnd.randrange(7) for _ in range(dim)] if rnd.random() < 0.5 else [rnd.randrange(7)] * dim
     ex = rnd.choice([0, 1, 1, 2])
