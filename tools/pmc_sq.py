@@ -3,7 +3,8 @@
        python tools/pmc_sq.py <tag> [sigma]
    One rocprofv3 --pmc pass per counter group (no trace domains besides --kernel-trace) over
    tools/pmc_workload.py; per-kernel averages go to gpurun_out/<tag>/sq_counters.json and a
-   table to gpurun_out/<tag>/sq_counters.txt (copied to profiles/ by hand when it is evidence)."""
+   table to gpurun_out/<tag>/sq_counters.txt (copied to profiles/ by hand when it is evidence).
+   PMC_GROUPS=0,2,6 selects counter groups, PMC_WORKLOAD=r6/gradc_workload.py another workload under tools/."""
 import glob, json, os, sqlite3, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag = sys.argv[1] if len(sys.argv) > 1 else "pmc"
@@ -36,7 +37,7 @@ for i, g in enumerate(GROUPS):
     if only and str(i) not in only.split(","):
         continue
     d = os.path.join(out, "pass%d" % i)
-    cmd = ["rocprofv3", "--kernel-trace", "--pmc"] + g + ["-d", d, "--", sys.executable, os.path.join(ROOT, "tools", "pmc_workload.py"), sigma]
+    cmd = ["rocprofv3", "--kernel-trace", "--pmc"] + g + ["-d", d, "--", sys.executable, os.path.join(ROOT, "tools", os.environ.get("PMC_WORKLOAD", "pmc_workload.py")), sigma]
     r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=900)
     open(os.path.join(out, "pass%d.log" % i), "w").write(r.stdout[-4000:] + "\n" + r.stderr[-4000:])
     for db in glob.glob(os.path.join(d, "**", "*.db"), recursive=True):

@@ -860,11 +860,10 @@ __global__ __launch_bounds__(NT, 4) void gradc_sorted(KParams p, const T *__rest
                         ppy = __builtin_fmaf(dq[jy].x, q, ppy);
                         ppz = __builtin_fmaf(w[jy].x, qz, ppz);
                     }
-                    if (!MIX || i <= KX) {                             // (mixed orders: a plane beyond the x-stencil may hold anything)
-                        ag[j][0] = __builtin_fmaf(gxi, pp, ag[j][0]);
-                        ag[j][1] = __builtin_fmaf(wxi, ppy, ag[j][1]);
-                        ag[j][2] = __builtin_fmaf(wxi, ppz, ag[j][2]);
-                    }
+                    if constexpr (MIX) { if (i > KX) { pp = 0.f; ppy = 0.f; ppz = 0.f; } }     // (a plane beyond the x-stencil may hold anything)
+                    ag[j][0] = __builtin_fmaf(gxi, pp, ag[j][0]);
+                    ag[j][1] = __builtin_fmaf(wxi, ppy, ag[j][1]);
+                    ag[j][2] = __builtin_fmaf(wxi, ppz, ag[j][2]);
                     asm volatile("" : "+v"(ag[j][0]), "+v"(ag[j][1]), "+v"(ag[j][2]));
                 }
 #ifdef IP_SORTED_MIX_TU
