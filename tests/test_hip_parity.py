@@ -1009,6 +1009,78 @@ def test_tiled_mixed_orders_match_generic(dim, orders, sigma):
         _same(ggrid, (gg * src.unsqueeze(-1)).sum(1), 2e-5, "bwd ggrid")
 
 
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("orders", [[1, 2, 3], [3, 1, 2], [2, 3, 1], [1, 1, 3], [2, 2, 1]])
+def test_mixed_orders_through_bricks_against_the_oracle(orders):
+    """Round 6: 3-D mixed orders 1..3 in the owner-computes organisation (csrc/push_owner.hip, K = KMIX: the cubic's bricks, boxes, counts
+    and flush with every dim's own first tap and weights) -- until then a rough field sent them to per-sample paths (push at sigma = 6:
+    72 ms where the cubic takes 3.6).  The bricks alone (INTERPOL_FLAG_BINNED_SCATTER) on a gentle field and the DEFAULT routing (probe)
+    on a rough one against the C oracle: pull, grid_grad, push + count, count, both gradients of pull_backward and push_backward; folding
+    and non-folding bounds (end bricks, shell bricks), the three extrapolation modes, 1 - 3 channels, ragged sample grids; bf16 sources;
+    non-finite sources and lattice points reach exactly the stencils that hold them.  Reference: nd.py:81-288, pushpull.py:237-281."""
+    import os
+    from interpol import _hip
+    gen = torch.Generator().manual_seed(7 + 100 * orders[0] + 10 * orders[1] + orders[2])
+    ishape, oshape = (50, 37, 41), (45, 40, 52)
+    ident = torch.stack(torch.meshgrid(*[torch.linspace(0, n - 1, m) for n, m in zip(ishape, oshape)], indexing="ij"), -1)[None]
+    rtol, atol_rel = G.fp32_tol(orders)
+    oracle.set_threads(os.cpu_count() or 8)
+    try:
+        for case, (bounds, ex, C, sigma, fl) in enumerate((([3, 3, 3], 1, 2, 0.5, _hip.FLAG_BINNED_SCATTER), ([1, 2, 3], 0, 1, 7.0, 0),
+                                                           ([6, 0, 4], 2, 3, 7.0, 0), ([5, 6, 0], 1, 2, 0.5, _hip.FLAG_BINNED_SCATTER),
+                                                           ([3, 1, 2], 1, 2, 2.0, 0))):
+            vol = torch.randn([2, C, *ishape], generator=gen)
+            src = torch.randn([2, C, *oshape], generator=gen)
+            grid = (ident + sigma * torch.randn([2, *oshape, 3], generator=gen)).contiguous()
+            grid[0, 0, 0, 0] = -30.0 * torch.tensor(ishape)            # far outside
+            grid[1, 1, 2, 3] = 30.0 * torch.tensor(ishape) + 0.25
+            for d, n in enumerate(ishape):                             # (float32 vs float64 mask thresholds, nd.py:10-27: see the test above)
+                for thr in (-0.55, -0.05, n - 1 + 0.05, n - 1 + 0.55):
+                    near = (grid[..., d] - thr).abs() < 1e-3
+                    grid[..., d] = torch.where(near, grid[..., d] + 4e-3, grid[..., d])
+            vd, sd, gd = vol.to(DEV), src.to(DEV), grid.to(DEV)
+            v64, s64, g64 = vol.double(), src.double(), grid.double()
+            what = (orders, bounds, ex, C, sigma, fl)
+            G.assert_close(_hip.gather("pull", vd, gd, bounds, orders, ex, flags=fl).cpu().numpy(), oracle.grid_pull(v64, g64, bounds, orders, ex),
+                           rtol, atol_rel, ("pull",) + what)
+            G.assert_close(_hip.gather("grad", vd, gd, bounds, orders, ex, flags=fl).cpu().numpy(), oracle.grid_grad(v64, g64, bounds, orders, ex),
+                           2 * rtol, 2 * atol_rel, ("grad",) + what)
+            got = _hip.scatter("push", sd, gd, list(ishape), bounds, orders, ex, with_count=True, flags=fl).cpu().numpy()
+            G.assert_close(got[:, :C], oracle.grid_push(s64, g64, list(ishape), bounds, orders, ex), rtol, atol_rel, ("push",) + what)
+            want_c = oracle.grid_count(g64, list(ishape), bounds, orders, ex)
+            G.assert_close(got[:, C:], want_c, rtol, atol_rel, ("count with push",) + what)
+            G.assert_close(_hip.scatter("count", None, gd, list(ishape), bounds, orders, ex, flags=fl).cpu().numpy(), want_c, rtol, atol_rel, ("count",) + what)
+            gi, gg = _hip.pull_backward(sd, vd, gd, bounds, orders, ex, True, True, flags=fl)
+            wi, wg = oracle.grid_pull_backward(s64, v64, g64, bounds, orders, ex)
+            G.assert_close(gi.cpu().numpy(), np.asarray(wi), rtol, atol_rel, ("pull_backward image",) + what)
+            G.assert_close(gg.cpu().numpy(), np.asarray(wg), 2 * rtol, 2 * atol_rel, ("pull_backward grid",) + what)
+            gi, gg = _hip.push_backward(vd, sd, gd, bounds, orders, ex, True, True, flags=fl)
+            wi, wg = oracle.grid_push_backward(v64, s64, g64, bounds, orders, ex)
+            G.assert_close(gi.cpu().numpy(), np.asarray(wi), rtol, atol_rel, ("push_backward values",) + what)
+            G.assert_close(gg.cpu().numpy(), np.asarray(wg), 2 * rtol, 2 * atol_rel, ("push_backward grid",) + what)
+            if case == 0:
+                lp = _hip.scatter("push", sd.bfloat16(), gd, list(ishape), bounds, orders, ex, flags=fl)
+                assert lp.dtype == torch.bfloat16
+                G.assert_close(lp.double().cpu().numpy(), oracle.grid_push(sd.bfloat16().double().cpu(), g64, list(ishape), bounds, orders, ex),
+                               2 ** -6, 2 ** -6, ("push bf16",) + what)
+                bad = src.clone()
+                bad[0, 0, 20, 18, 21] = float("inf"); bad[1, C - 1, 31, 9, 30] = float("nan")
+                fast = _hip.scatter("push", bad.to(DEV), gd, list(ishape), bounds, orders, ex, flags=fl)
+                slow = _hip.scatter("push", bad.to(DEV), gd, list(ishape), bounds, orders, ex, flags=_hip.FLAG_NO_FASTPATH)
+                fin = torch.isfinite(slow)
+                assert bool((torch.isfinite(fast) == fin).all()) and 0 < int((~fin).sum()) < 200, ("non-finite sources",) + what
+                _same(torch.where(fin, fast, 0), torch.where(fin, slow, 0), 1e-5, ("next to non-finite sources",) + what)
+                vbad = vol.clone()
+                vbad[0, 0, 20, 18, 21] = float("inf"); vbad[1, C - 1, 31, 9, 30] = float("nan")
+                fast = _hip.gather("pull", vbad.to(DEV), gd, bounds, orders, ex, flags=fl)
+                slow = _hip.gather("pull", vbad.to(DEV), gd, bounds, orders, ex, flags=_hip.FLAG_NO_FASTPATH)
+                fin = torch.isfinite(slow)
+                assert bool((torch.isfinite(fast) == fin).all()) and 0 < int((~fin).sum()), ("non-finite lattice points",) + what
+                _same(torch.where(fin, fast, 0), torch.where(fin, slow, 0), 4e-6, ("next to non-finite lattice points",) + what)
+    finally:
+        oracle.set_threads(1)
+
+
 @pytest.mark.timeout(600)
 @pytest.mark.parametrize("order", [1, 2, 3, 4, 5, 6, 7])
 def test_push1d_tiles_against_the_oracle(order):

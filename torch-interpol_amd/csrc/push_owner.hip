@@ -66,6 +66,25 @@ constexpr int NS = TS * TS * TS;                // samples per tile (own_bin)
 constexpr int NT1 = 512, VPT1 = NS / NT1;       // own_bin: threads, samples per thread
 constexpr int LB = 6, NBIN = LB * LB * LB;      // bricks around a tile that are sorted locally
 constexpr int HDR_SHELL = 34;                   // word of the workspace header own_bin sets when a shell brick received a run
+// Mixed per-dim orders 1..3 (round 6): the kernels instantiated with K = KMIX run the CUBIC organisation -- bricks, 19^3 boxes, all 64 taps
+// (the adds of taps beyond a dim's order carry weight 0: exactly MAGIC, so the stencil counts stay the cubic's), colours, flush -- with the
+// first tap floor(x - (k_d - 1)/2) and the weights of each dim's own order (KParams::order).  KSV<K>: the order the organisation sees.
+constexpr int KMIX = 13;
+template <int K> constexpr int KSV = K == KMIX ? 3 : K;
+template <int K> __device__ __forceinline__ int kd(const KParams &p, int d) { return K == KMIX ? p.order[d] : K; }
+// own_accumulate and its helpers are written through these: in the isotropic module they expand to the expressions of rounds 3 - 5 token
+// for token (with the template forms above, equivalent as they are, the compiler allocated own_accumulate<3>'s registers differently)
+#ifdef IP_OWNER_MIX_TU
+#define IP_KS KSV<K>
+#define IP_KD(d) kd<K>(p, d)
+#define IP_WX(i) own_weight_x<K>(p, tx, i)
+#define IP_MU magic_units_p<K>(p)
+#else
+#define IP_KS K
+#define IP_KD(d) K
+#define IP_WX(i) weight_x<K>(tx, i)
+#define IP_MU magic_units<K>()
+#endif
 
 // Bricks of first-tap cells, per dim.  INTERIOR cells [lo, top) lie in nin bricks of BR cells: the bricks up to index
 // `split` are aligned to lo, the ones above it to top (brick `split` is the short one in between).  Two cases:
@@ -88,8 +107,9 @@ __host__ __device__ __forceinline__ bool folds(int bound, int n) { return (bound
 static BrickGrid brick_grid(const KParams &k)
 {
     BrickGrid g;
+    const bool mixed = k.order[0] != k.order[1] || k.order[0] != k.order[2];   // mixed orders (K = KMIX below): the cubic's bricks
     for (int d = 0; d < 3; ++d) {
-        const int K = k.order[d], n = k.vol_n[d];
+        const int K = mixed ? 3 : k.order[d], n = k.vol_n[d];
         const bool f = folds(k.bound[d], n);
         // folding dims: as far out as the mirror image of every point of the end bricks' boxes stays inside the box
         g.lo[d] = f ? -(BOX - 1) / 2 : 0;
@@ -153,7 +173,7 @@ __device__ __forceinline__ void scatter_direct(const KParams &p, const T *__rest
 {
     Lattice L;
 #pragma unroll
-    for (int d = 0; d < 3; ++d) { L.bound[d] = p.bound[d]; L.n[d] = p.vol_n[d]; L.ss[d] = p.vol_ss[d] / 4; L.k[d] = K; }
+    for (int d = 0; d < 3; ++d) { L.bound[d] = p.bound[d]; L.n[d] = p.vol_n[d]; L.ss[d] = p.vol_ss[d] / 4; L.k[d] = kd<K>(p, d); }
     L.lin = 0;
 #pragma unroll 1
     for (int v = 0; v < VPT1; ++v) {
@@ -163,7 +183,7 @@ __device__ __forceinline__ void scatter_direct(const KParams &p, const T *__rest
         load_xyz<GM>(p, grid, b, g, ox, oy, oz, x);
         const int64_t o = ((int64_t)ox * g.gy + oy) * g.gz + oz;
         const float m = inb_mask(p, x);
-        if (K == 1 && p.mode == MODE_ISO0) {
+        if (KSV<K> == 1 && p.mode == MODE_ISO0) {
             // nearest neighbour: ONE lattice point, weight 1 (iso0.py:12, 65-118) -- see own_accumulate
             const long long pk0 = wrap_outofline(L.bound[0], __float2int_rn(rintf(x[0])), L.n[0]);
             const long long pk1 = wrap_outofline(L.bound[1], __float2int_rn(rintf(x[1])), L.n[1]);
@@ -177,7 +197,7 @@ __device__ __forceinline__ void scatter_direct(const KParams &p, const T *__rest
         }
         int ii[3]; float tt[3];
 #pragma unroll
-        for (int d = 0; d < 3; ++d) split(K, x[d], ii[d], tt[d]);
+        for (int d = 0; d < 3; ++d) split(kd<K>(p, d), x[d], ii[d], tt[d]);
 #pragma unroll 1
         for (int ch = 0; ch < nch; ++ch)
             tiled::scatter_one_thread(L, vol + b * p.vol_sb + ch * p.vol_sc, src_value<T>(p, val, b, o, ch, m), ii[0], ii[1], ii[2], tt[0], tt[1], tt[2]);
@@ -192,7 +212,7 @@ __device__ __forceinline__ void gather_direct(const KParams &p, const T *__restr
 {
     Lattice L;
 #pragma unroll
-    for (int d = 0; d < 3; ++d) { L.bound[d] = p.bound[d]; L.n[d] = p.vol_n[d]; L.ss[d] = p.vol_ss[d] / (int)sizeof(T); L.k[d] = K; }
+    for (int d = 0; d < 3; ++d) { L.bound[d] = p.bound[d]; L.n[d] = p.vol_n[d]; L.ss[d] = p.vol_ss[d] / (int)sizeof(T); L.k[d] = kd<K>(p, d); }
     L.lin = 0;
 #pragma unroll 1
     for (int v = 0; v < VPT1; ++v) {
@@ -204,7 +224,7 @@ __device__ __forceinline__ void gather_direct(const KParams &p, const T *__restr
         const float m = inb_mask(p, x);
         int ii[3]; float tt[3];
 #pragma unroll
-        for (int d = 0; d < 3; ++d) split(K, x[d], ii[d], tt[d]);
+        for (int d = 0; d < 3; ++d) split(kd<K>(p, d), x[d], ii[d], tt[d]);
 #pragma unroll 1
         for (int ch = 0; ch < p.C; ++ch)
             out[b * p.val_sb + ch * p.val_sc + o] = Cvt<float, T>::st(m * tiled::gather_one_thread<T>(L, img + b * p.vol_sb + ch * p.vol_sc, ii[0], ii[1], ii[2], tt[0], tt[1], tt[2], -1));
@@ -219,7 +239,7 @@ __device__ __forceinline__ void gradc_direct(const KParams &p, const T *__restri
 {
     Lattice L;
 #pragma unroll
-    for (int d = 0; d < 3; ++d) { L.bound[d] = p.bound[d]; L.n[d] = p.vol_n[d]; L.ss[d] = p.vol_ss[d] / (int)sizeof(T); L.k[d] = K; }
+    for (int d = 0; d < 3; ++d) { L.bound[d] = p.bound[d]; L.n[d] = p.vol_n[d]; L.ss[d] = p.vol_ss[d] / (int)sizeof(T); L.k[d] = kd<K>(p, d); }
     L.lin = 0;
 #pragma unroll 1
     for (int v = 0; v < VPT1; ++v) {
@@ -231,7 +251,7 @@ __device__ __forceinline__ void gradc_direct(const KParams &p, const T *__restri
         const float m = inb_mask(p, x);
         int ii[3]; float tt[3];
 #pragma unroll
-        for (int d = 0; d < 3; ++d) split(K, x[d], ii[d], tt[d]);
+        for (int d = 0; d < 3; ++d) split(kd<K>(p, d), x[d], ii[d], tt[d]);
         float a[3] = { 0.f, 0.f, 0.f };
 #pragma unroll 1
         for (int ch = 0; ch < p.C; ++ch) {
@@ -252,7 +272,7 @@ __device__ __forceinline__ void grad_direct(const KParams &p, const T *__restric
 {
     Lattice L;
 #pragma unroll
-    for (int d = 0; d < 3; ++d) { L.bound[d] = p.bound[d]; L.n[d] = p.vol_n[d]; L.ss[d] = p.vol_ss[d] / (int)sizeof(T); L.k[d] = K; }
+    for (int d = 0; d < 3; ++d) { L.bound[d] = p.bound[d]; L.n[d] = p.vol_n[d]; L.ss[d] = p.vol_ss[d] / (int)sizeof(T); L.k[d] = kd<K>(p, d); }
     L.lin = 0;
 #pragma unroll 1
     for (int v = 0; v < VPT1; ++v) {
@@ -264,7 +284,7 @@ __device__ __forceinline__ void grad_direct(const KParams &p, const T *__restric
         const float m = inb_mask(p, x);
         int ii[3]; float tt[3];
 #pragma unroll
-        for (int d = 0; d < 3; ++d) split(K, x[d], ii[d], tt[d]);
+        for (int d = 0; d < 3; ++d) split(kd<K>(p, d), x[d], ii[d], tt[d]);
 #pragma unroll 1
         for (int ch = 0; ch < p.C; ++ch)
 #pragma unroll 1
@@ -324,11 +344,11 @@ __global__ __launch_bounds__(NT1, 4) void own_bin(KParams p, BrickGrid bg, const
     for (int v = 0; v < VPT1 && !IDX; ++v) {                          // masked sources (nd.py:201-203); count: the mask itself
         const float m = inb_mask(p, c[v]);
         v0[v] = has0 ? v0[v] * m : m; v1[v] = has1 ? v1[v] * m : m;
-        if (K == 1 && m != 0.f) inbits |= 1u << v;                   // (kept for the further channels: the nearest-neighbour mode rounds c below)
+        if (KSV<K> == 1 && m != 0.f) inbits |= 1u << v;                   // (kept for the further channels: the nearest-neighbour mode rounds c below)
     }
     // nearest-neighbour scatters (all orders 0; the host passes them as trilinear ones, KParams::mode still MODE_ISO0): the coordinates
     // rounded half to even (iso0.py:12) AFTER the mask saw the real ones -- a 2 x 2 x 2 stencil at t = 0: weight 1 on the first tap, +0 elsewhere
-    if (K == 1 && !IDX && p.mode == MODE_ISO0) {
+    if (KSV<K> == 1 && !IDX && p.mode == MODE_ISO0) {
 #pragma unroll
         for (int v = 0; v < VPT1; ++v) { c[v][0] = rintf(c[v][0]); c[v][1] = rintf(c[v][1]); c[v][2] = rintf(c[v][2]); }
     }
@@ -341,7 +361,7 @@ __global__ __launch_bounds__(NT1, 4) void own_bin(KParams p, BrickGrid bg, const
         bool in = (valid >> v) & 1;
 #pragma unroll
         for (int d = 0; d < 3; ++d) {
-            const float fl = floorf(c[v][d] - 0.5f * (float)(K - 1));
+            const float fl = floorf(c[v][d] - 0.5f * (float)(kd<K>(p, d) - 1));
             in = in && fl >= (float)(bg.lo[d] - OFF) && fl < (float)(bg.top[d] + NHI * BR);        // (false for NaN)
             // brick, and above it the cell inside the brick
             bx[v][d] = in ? brick_and_cell(__float2int_rz(fl), bg.lo[d], bg.top[d], bg.nin[d], bg.split[d]) : 0;
@@ -431,7 +451,7 @@ __global__ __launch_bounds__(NT1, 4) void own_bin(KParams p, BrickGrid bg, const
             if (pos[v] < 0) continue;
             int ox, oy, oz;
             sample_pos(g, tid + NT1 * v, ox, oy, oz);
-            vals[(int64_t)(ch - 1) * nrec + tilebase + (pos[v] & 0xffff)] = src_value<T>(p, val, b, ((int64_t)ox * gy + oy) * gz + oz, ch, K == 1 ? (float)((inbits >> v) & 1u) : inb_mask(p, c[v]));
+            vals[(int64_t)(ch - 1) * nrec + tilebase + (pos[v] & 0xffff)] = src_value<T>(p, val, b, ((int64_t)ox * gy + oy) * gz + oz, ch, KSV<K> == 1 ? (float)((inbits >> v) & 1u) : inb_mask(p, c[v]));
         }
     }
     // ---- the descriptors, now that the slots have arrived.  A run whose brick's list was full is an ORPHAN: its records stay
@@ -541,6 +561,15 @@ constexpr unsigned MAGIC_ODD = 301u;            // bits(MAGIC) = 0x4B400000 = 30
 template <int K> __device__ __forceinline__ float magic_units() { return K == 3 ? 4194304.f * 0.999f * 3.375f : (K == 2 ? 4194304.f * 0.999f * (64.f / 27.f) : 4194304.f * 0.999f); }    // 2^22 * 0.999 / wmax^3 (wmax = 1 for K = 1)
 // the largest  density * prod_d sum_j max_t w_j(t)  (tile_common.hpp: headroom32) whose slot sums stay inside 32 bits
 template <int K> __device__ __forceinline__ float magic_cbmax() { return 2147483648.f * 0.99f / magic_units<K>(); }
+// ... and for mixed orders (K = KMIX): wmax per dim, 1 / (3/4) / (2/3) for orders 1 / 2 / 3
+template <int K> __device__ __forceinline__ float magic_units_p(const KParams &p)
+{
+    if (K != KMIX) return magic_units<K>();
+    float u = 4194304.f * 0.999f;
+#pragma unroll
+    for (int d = 0; d < 3; ++d) u *= p.order[d] == 3 ? 1.5f : (p.order[d] == 2 ? 4.f / 3.f : 1.f);
+    return u;
+}
 
 __device__ __forceinline__ void magic_decode(unsigned long long W, unsigned n, int &s0, int &s1)
 {
@@ -585,7 +614,7 @@ __device__ __forceinline__ void scatter_row(unsigned addr, f2 sx, const f2 *w, i
 #ifdef IP_ABLATE
     if (dbg & 4) { asm volatile("" :: "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3])); return; }     // (ablation: the arithmetic without the LDS adds)
 #endif
-    row_adds<I, J, WIDE ? 4 : K + 1>(addr, v[0], v[1], v[2], v[3]);
+    row_adds<I, J, WIDE ? 4 : IP_KS + 1>(addr, v[0], v[1], v[2], v[3]);
 }
 template <int K, int I, bool WIDE>
 __device__ __forceinline__ void scatter_plane(unsigned addr, f2 s, float wxi, const f2 *w, int dbg)
@@ -594,14 +623,14 @@ __device__ __forceinline__ void scatter_plane(unsigned addr, f2 s, float wxi, co
     if (dbg & 16) {                                                  // (ablation: the LDS adds without the arithmetic)
         const unsigned long long c = 0x100000001ull;
         row_adds<I, 0>(addr, c, c, c, c); row_adds<I, 1>(addr, c, c, c, c); row_adds<I, 2>(addr, c, c, c, c);
-        if (K == 3) row_adds<I, 3>(addr, c, c, c, c);
+        if (IP_KS == 3) row_adds<I, 3>(addr, c, c, c, c);
         return;
     }
 #endif
     const f2 sx = s * f2{ wxi, wxi };
     scatter_row<K, I, 0, WIDE>(addr, sx, w, dbg); scatter_row<K, I, 1, WIDE>(addr, sx, w, dbg);
-    if (K >= 2) scatter_row<K, I, 2, WIDE>(addr, sx, w, dbg);
-    if (K == 3) scatter_row<K, I, 3, WIDE>(addr, sx, w, dbg);
+    if (IP_KS >= 2) scatter_row<K, I, 2, WIDE>(addr, sx, w, dbg);
+    if (IP_KS == 3) scatter_row<K, I, 3, WIDE>(addr, sx, w, dbg);
 }
 
 // Stencils per slot of the box: the (K + 1)^3 box filter of the density of first-tap cells, dim after dim, in place (every thread
@@ -622,7 +651,7 @@ __device__ __forceinline__ void slide(const unsigned *in, unsigned *out)
 template <int K, typename SM>
 __device__ __forceinline__ void stencil_counts(SM &sm, int tid)
 {
-    constexpr int W = K + 1, HZ = NZ / 2;
+    constexpr int W = IP_KS + 1, HZ = NZ / 2;
     unsigned *rg = sm.nreg;
     unsigned in[BR], out[BOX];
     // z: thread = row (x0, y0) of 16 cells -> 19 slots (+ one of padding)
@@ -678,11 +707,31 @@ __device__ __forceinline__ unsigned stencils_at(const AccSmem &sm, int xr, int y
     return (unsigned)reinterpret_cast<const unsigned short *>(sm.nreg)[(xr * BOX + yr) * NZ + zr];
 }
 
+// the x-weight of tap i (mixed orders: by the dim's own order; 0 beyond it)
+template <int K> __device__ __forceinline__ float own_weight_x(const KParams &p, float t, int i)
+{
+    if constexpr (K == KMIX) return mixed_weight_x(p.order[0], t, i);
+    else return weight_x<K>(t, i);
+}
+template <int K> __device__ __forceinline__ float own_wgrad_x(const KParams &p, float t, int i)
+{
+    if constexpr (K == KMIX) return mixed_wgrad_x(p.order[0], t, i);
+    else return wgrad_x<K>(t, i);
+}
 // first-tap cell and stencil coordinates of a record (same arithmetic as own_bin: nd.py:45-46)
+#ifdef IP_OWNER_MIX_TU
+#define IP_RECORD_CELL(...) record_cell<K>(p, __VA_ARGS__)
+template <int K>
+__device__ __forceinline__ void record_cell(const KParams &p, const float4 &r, const int *b0, int &x0, int &y0, int &z0, float &tx, float &ty, float &tz)
+{
+    const float fx = floorf(r.x - 0.5f * (float)(kd<K>(p, 0) - 1)), fy = floorf(r.y - 0.5f * (float)(kd<K>(p, 1) - 1)), fz = floorf(r.z - 0.5f * (float)(kd<K>(p, 2) - 1));
+#else
+#define IP_RECORD_CELL(...) record_cell<K>(__VA_ARGS__)
 template <int K>
 __device__ __forceinline__ void record_cell(const float4 &r, const int *b0, int &x0, int &y0, int &z0, float &tx, float &ty, float &tz)
 {
     const float fx = floorf(r.x - 0.5f * (float)(K - 1)), fy = floorf(r.y - 0.5f * (float)(K - 1)), fz = floorf(r.z - 0.5f * (float)(K - 1));
+#endif
     tx = r.x - fx; ty = r.y - fy; tz = r.z - fz;
     x0 = (__float2int_rz(fx) - b0[0]) & (BR - 1); y0 = (__float2int_rz(fy) - b0[1]) & (BR - 1); z0 = (__float2int_rz(fz) - b0[2]) & (BR - 1);
 }
@@ -722,7 +771,7 @@ __global__ __launch_bounds__(NT, 4) void own_accumulate(KParams p, BrickGrid bg,
     AccSmem &sm = *reinterpret_cast<AccSmem *>(smem_raw);
     Lattice L;
 #pragma unroll
-    for (int d = 0; d < 3; ++d) { L.bound[d] = p.bound[d]; L.n[d] = p.vol_n[d]; L.ss[d] = p.vol_ss[d] / 4; L.k[d] = K; }
+    for (int d = 0; d < 3; ++d) { L.bound[d] = p.bound[d]; L.n[d] = p.vol_n[d]; L.ss[d] = p.vol_ss[d] / 4; L.k[d] = IP_KD(d); }
     L.lin = 0;
     // bricks of this launch: a colour enumerates the INTERIOR bricks of its parity only (every work item then carries a
     // brick's worth of samples: the workgroups stay balanced); the other launches enumerate all bricks
@@ -868,7 +917,7 @@ __global__ __launch_bounds__(NT, 4) void own_accumulate(KParams p, BrickGrid bg,
             __syncthreads();
         };
         prof_mark(8);
-        if (K == 1 && p.mode == MODE_ISO0) {
+        if (IP_KS == 1 && p.mode == MODE_ISO0) {
             // Nearest neighbour (all orders 0; own_bin stored the ROUNDED coordinates): a sample touches ONE lattice point with weight 1
             // (iso0.py:65-118: inp * sign * mask, scatter_add_ in no particular order).  Round 6: no fixed point here -- the box holds the
             // channel pair as two FLOATS and every record adds its sources with one ds_add_f32 each (slow LDS atomics, ~190 clk per wave
@@ -1015,8 +1064,15 @@ __global__ __launch_bounds__(NT, 4) void own_accumulate(KParams p, BrickGrid bg,
         prof_mark(10);
         // 32-bit channel pairs while no slot's sums can leave 32 bits: density * prod_d sum_j max_t w_j(t) units of max |source|
         // (tile_common.hpp: headroom32) -- 32 samples per first-tap cell for cubic stencils; beyond: 64-bit sums, one channel per pass
+#ifdef IP_OWNER_MIX_TU
+        float wsum3 = 1.f;                                           // prod_d sum_j max_t w_j(t): 2 / 1.75 / 1.6667 for orders 1 / 2 / 3
+#pragma unroll
+        for (int d = 0; d < 3; ++d) wsum3 *= kd<K>(p, d) == 3 ? 1.6666667f : (kd<K>(p, d) == 2 ? 1.75f : 2.f);
+        const bool dense = n >= 60000 || (float)(sm.dmax * foldmul) * wsum3 > 2147483648.f * 0.99f / magic_units_p<K>(p);    // (16-bit density counters)
+#else
         const float wsum = K == 3 ? 1.6666667f : (K == 2 ? 1.75f : 2.f);
         const bool dense = n >= 60000 || (float)(sm.dmax * foldmul) * (wsum * wsum * wsum) > magic_cbmax<K>();    // (16-bit density counters)
+#endif
         const bool one_batch = npieces <= NPIECE;
         for (int c = 0; c < nch; c += 2) {
             const bool two = c + 1 < nch;
@@ -1058,8 +1114,8 @@ __global__ __launch_bounds__(NT, 4) void own_accumulate(KParams p, BrickGrid bg,
             // magic format: |source| * scale * w_x w_y w_z < 2^22 -- scale = magic_units / max |source| (not a power of two: the
             // products carry float roundings like the reference's own)
             const float a0 = fmaxf(__int_as_float(mb0), 1e-27f), a1 = fmaxf(__int_as_float(mb1), 1e-27f);
-            const f2 scale = { mb0 ? magic_units<K>() / a0 : 0.f, mb1 ? magic_units<K>() / a1 : 0.f };
-            const float inv0 = a0 * (1.f / magic_units<K>()), inv1 = a1 * (1.f / magic_units<K>());
+            const f2 scale = { mb0 ? IP_MU / a0 : 0.f, mb1 ? IP_MU / a1 : 0.f };
+            const float inv0 = a0 * (1.f / IP_MU), inv1 = a1 * (1.f / IP_MU);
             const f2 scalew = { mb0 ? __int_as_float((127 + 30 - ex0) << 23) : 0.f, mb1 ? __int_as_float((127 + 30 - ex1) << 23) : 0.f };
             const float invw0 = __int_as_float((127 - 30 + ex0) << 23), invw1 = __int_as_float((127 - 30 + ex1) << 23);
             const unsigned boxaddr = (unsigned)(size_t)(__attribute__((address_space(3))) void *)(sm.box);
@@ -1140,26 +1196,30 @@ __global__ __launch_bounds__(NT, 4) void own_accumulate(KParams p, BrickGrid bg,
                     if (e + NHW < eend) fetch(e + NHW, rc, s0, s1);
                     if (e >= eend) continue;
                     int x0, y0, z0; float tx, ty, tz;
-                    record_cell<K>(cur, b0, x0, y0, z0, tx, ty, tz);
+                    IP_RECORD_CELL(cur, b0, x0, y0, z0, tx, ty, tz);
                     if (fixedpt) {
 #ifdef IP_ABLATE
                         if (p.dbg & 2) continue;                     // (ablation: no taps)
 #endif
                         unsigned addr = boxaddr + 8u * (unsigned)(x0 * PLANE + y0 * PZ + z0);
                         f2 w[4];
+#ifdef IP_OWNER_MIX_TU
+                        if constexpr (K == KMIX) mixed_weights_yz(p.order[1], p.order[2], f2{ ty, tz }, w);
+                        else
+#endif
                         weights_yz<K>(f2{ ty, tz }, w);
                         if (wide) {
                             const f2 ss = sub ? f2{ cs1 * scalew.y, 0.f } : f2{ cs0 * scalew.x, 0.f };
-                            scatter_plane<K, 0, true>(addr, ss, weight_x<K>(tx, 0), w, p.dbg);
-                            scatter_plane<K, 1, true>(addr, ss, weight_x<K>(tx, 1), w, p.dbg);
-                            if (K >= 2) scatter_plane<K, 2, true>(addr, ss, weight_x<K>(tx, 2), w, p.dbg);
-                            if (K == 3) scatter_plane<K, 3, true>(addr, ss, weight_x<K>(tx, 3), w, p.dbg);
+                            scatter_plane<K, 0, true>(addr, ss, IP_WX(0), w, p.dbg);
+                            scatter_plane<K, 1, true>(addr, ss, IP_WX(1), w, p.dbg);
+                            if (IP_KS >= 2) scatter_plane<K, 2, true>(addr, ss, IP_WX(2), w, p.dbg);
+                            if (IP_KS == 3) scatter_plane<K, 3, true>(addr, ss, IP_WX(3), w, p.dbg);
                         } else {
                             const f2 ss = f2{ cs0, cs1 } * scale;
-                            scatter_plane<K, 0, false>(addr, ss, weight_x<K>(tx, 0), w, p.dbg);
-                            scatter_plane<K, 1, false>(addr, ss, weight_x<K>(tx, 1), w, p.dbg);
-                            if (K >= 2) scatter_plane<K, 2, false>(addr, ss, weight_x<K>(tx, 2), w, p.dbg);
-                            if (K == 3) scatter_plane<K, 3, false>(addr, ss, weight_x<K>(tx, 3), w, p.dbg);
+                            scatter_plane<K, 0, false>(addr, ss, IP_WX(0), w, p.dbg);
+                            scatter_plane<K, 1, false>(addr, ss, IP_WX(1), w, p.dbg);
+                            if (IP_KS >= 2) scatter_plane<K, 2, false>(addr, ss, IP_WX(2), w, p.dbg);
+                            if (IP_KS == 3) scatter_plane<K, 3, false>(addr, ss, IP_WX(3), w, p.dbg);
                         }
                     } else {
                         // no fixed point for this brick (density beyond the precision rule, non-finite sources): float atomics,
@@ -1249,8 +1309,8 @@ __global__ __launch_bounds__(NT, 4) void own_accumulate(KParams p, BrickGrid bg,
                 // (atomic launches: the slots [rlo, rhi + K] per dim, enumerated with a float reciprocal -- exact: the quotients
                 // stay half a unit away from the integers)
                 const int fl0 = atomic ? sm.rlo[0] : 0, fl1 = atomic ? sm.rlo[1] : 0, fl2 = atomic ? sm.rlo[2] : 0;
-                const int fe1 = atomic ? sm.rhi[1] + K - fl1 + 1 : BOX, fe2 = atomic ? sm.rhi[2] + K - fl2 + 1 : BOX;
-                const int nflush = atomic ? (sm.rhi[0] + K - fl0 + 1) * fe1 * fe2 : BOXSLOTS;
+                const int fe1 = atomic ? sm.rhi[1] + IP_KS - fl1 + 1 : BOX, fe2 = atomic ? sm.rhi[2] + IP_KS - fl2 + 1 : BOX;
+                const int nflush = atomic ? (sm.rhi[0] + IP_KS - fl0 + 1) * fe1 * fe2 : BOXSLOTS;
                 const float r2 = 1.f / (float)fe2, r1 = 1.f / (float)fe1;
                 for (int e0 = tid; e0 < nflush; e0 += UF * NT) {
                     long long a[UF]; int off[UF]; float sg[UF]; unsigned nst[UF];
@@ -1338,7 +1398,7 @@ __global__ __launch_bounds__(NT, 4) void own_accumulate(KParams p, BrickGrid bg,
 // back to per-sample atomics -- else 0 (tiles).  Every scatter kernel of the call reads the word on entry: one of the two
 // organisations returns at once.  Stateless and deterministic: the choice depends on the coordinates of this call alone.
 // ---------------------------------------------------------------------------
-__global__ void own_zero(int *__restrict__ p, int n)
+static __global__ void own_zero(int *__restrict__ p, int n)      // (static: this file is two translation units, see IP_OWNER_MIX_TU)
 {
     const int i = blockIdx.x * 1024 + threadIdx.x;
     if (i < n) p[i] = 0;
@@ -1473,7 +1533,7 @@ __global__ __launch_bounds__(NT, 4) void own_gather(KParams p, BrickGrid bg, con
                 {
                     while (j >= sm.pref[rr + 1]) ++rr;               // (runs beyond the last hold nothing: their prefix is the total)
                     const float4 rc = rec[sm.start[rr] + (unsigned)(j - sm.pref[rr])];
-                    const float fx = floorf(rc.x - 0.5f * (float)(K - 1)), fy = floorf(rc.y - 0.5f * (float)(K - 1)), fz = floorf(rc.z - 0.5f * (float)(K - 1));
+                    const float fx = floorf(rc.x - 0.5f * (float)(kd<K>(p, 0) - 1)), fy = floorf(rc.y - 0.5f * (float)(kd<K>(p, 1) - 1)), fz = floorf(rc.z - 0.5f * (float)(kd<K>(p, 2) - 1));
                     const float tx = rc.x - fx; const f2 tyz = f2{ rc.y - fy, rc.z - fz };
                     // first-tap cell inside the brick: 0 .. 15 by construction of the bins (own_bin); clamped, should a coordinate be off
                     int cx = __float2int_rz(fx) - b0[0], cy = __float2int_rz(fy) - b0[1], cz = __float2int_rz(fz) - b0[2];
@@ -1481,26 +1541,31 @@ __global__ __launch_bounds__(NT, 4) void own_gather(KParams p, BrickGrid bg, con
                     const unsigned addr = boxaddr + (unsigned)((cx * BOX + cy) * GPZ + cz) * 8u;
                     float wx[4];
                     { // the K + 1 weights of the x-stencil (scalar form of weights_yz; splines.py:30-80)
-                        if (K == 3) { const float u = tx - 1.f, v = 2.f - tx, u2 = u * u, v2 = v * v;
+                        if constexpr (K == KMIX) weights4(p.order[0], tx, wx);
+                        else if (K == 3) { const float u = tx - 1.f, v = 2.f - tx, u2 = u * u, v2 = v * v;
                                       wx[0] = (v2 * v) * (1.f / 6.f); wx[3] = (u2 * u) * (1.f / 6.f); wx[1] = u2 * (u * 0.5f - 1.f) + 2.f / 3.f; wx[2] = v2 * (v * 0.5f - 1.f) + 2.f / 3.f; }
                         else { const float a = 1.5f - tx, cc = tx - 0.5f, m = tx - 1.f; wx[0] = (a * a) * 0.5f; wx[1] = 0.75f - m * m; wx[2] = (cc * cc) * 0.5f; wx[3] = 0.f; }
                     }
                     f2 w[4];
-                    weights_yz<K>(tyz, w);
+                    if constexpr (K == KMIX) mixed_weights_yz(p.order[1], p.order[2], tyz, w);
+                    else weights_yz<K>(tyz, w);
                     if (GRAD == 2) {
                         f2 dq[4];
-                        wgrads_yz<K>(tyz, dq);
+                        if constexpr (K == KMIX) mixed_wgrads_yz(p.order[1], p.order[2], tyz, dq);
+                        else wgrads_yz<K>(tyz, dq);
                         f2 g0 = { 0.f, 0.f }, g1 = { 0.f, 0.f }, g2 = { 0.f, 0.f };
 #pragma unroll
-                        for (int ii = 0; ii <= K; ++ii) {
+                        for (int ii = 0; ii <= KSV<K>; ++ii) {
+                            if (K == KMIX && ii > p.order[0]) continue;                  // (mixed orders: no plane, no slot beyond a dim's own stencil)
                             f2 t2[16];
                             gather_reads(addr + (unsigned)(ii * GPLANE * 8), t2);
+                            if constexpr (K == KMIX) clear_unused_taps(p.order[1], p.order[2], t2);
                             f2 pp = { 0.f, 0.f }, ppy = { 0.f, 0.f }, ppz = { 0.f, 0.f };
 #pragma unroll
-                            for (int jy = 0; jy <= K; ++jy) {
+                            for (int jy = 0; jy <= KSV<K>; ++jy) {
                                 f2 q = { 0.f, 0.f }, qz = { 0.f, 0.f };
 #pragma unroll
-                                for (int k = 0; k <= K; ++k) {
+                                for (int k = 0; k <= KSV<K>; ++k) {
                                     q = f2{ w[k].y, w[k].y } * t2[4 * jy + k] + q;
                                     qz = f2{ dq[k].y, dq[k].y } * t2[4 * jy + k] + qz;
                                 }
@@ -1508,7 +1573,7 @@ __global__ __launch_bounds__(NT, 4) void own_gather(KParams p, BrickGrid bg, con
                                 ppy = f2{ dq[jy].x, dq[jy].x } * q + ppy;
                                 ppz = f2{ w[jy].x, w[jy].x } * qz + ppz;
                             }
-                            const float wxi = weight_x<K>(tx, ii), gxi = wgrad_x<K>(tx, ii);
+                            const float wxi = own_weight_x<K>(p, tx, ii), gxi = own_wgrad_x<K>(p, tx, ii);
                             g0 = f2{ gxi, gxi } * pp + g0;
                             g1 = f2{ wxi, wxi } * ppy + g1;
                             g2 = f2{ wxi, wxi } * ppz + g2;
@@ -1526,18 +1591,21 @@ __global__ __launch_bounds__(NT, 4) void own_gather(KParams p, BrickGrid bg, con
                         const float *gc0 = gout ? gout + b * p.val_sb + (int64_t)c * p.val_sc : nullptr;
                         const float go0 = gc0 ? gc0[o] : 1.f, go1 = two ? (gc0 ? gc0[p.val_sc + o] : 1.f) : 0.f;   // (no grad_out: ones -- the backward of count)
                         f2 dq[4];
-                        wgrads_yz<K>(tyz, dq);
+                        if constexpr (K == KMIX) mixed_wgrads_yz(p.order[1], p.order[2], tyz, dq);
+                        else wgrads_yz<K>(tyz, dq);
                         float ag0 = 0.f, ag1 = 0.f, ag2 = 0.f;
 #pragma unroll
-                        for (int ii = 0; ii <= K; ++ii) {
+                        for (int ii = 0; ii <= KSV<K>; ++ii) {
+                            if (K == KMIX && ii > p.order[0]) continue;                  // (mixed orders: no plane, no slot beyond a dim's own stencil)
                             f2 t2[16];
                             gather_reads(addr + (unsigned)(ii * GPLANE * 8), t2);
+                            if constexpr (K == KMIX) clear_unused_taps(p.order[1], p.order[2], t2);
                             float pp = 0.f, ppy = 0.f, ppz = 0.f;
 #pragma unroll
-                            for (int jy = 0; jy <= K; ++jy) {
+                            for (int jy = 0; jy <= KSV<K>; ++jy) {
                                 float q = 0.f, qz = 0.f;
 #pragma unroll
-                                for (int k = 0; k <= K; ++k) {
+                                for (int k = 0; k <= KSV<K>; ++k) {
                                     const float sgl = __builtin_fmaf(go1, t2[4 * jy + k].y, go0 * t2[4 * jy + k].x);
                                     q = __builtin_fmaf(w[k].y, sgl, q);
                                     qz = __builtin_fmaf(dq[k].y, sgl, qz);
@@ -1546,8 +1614,8 @@ __global__ __launch_bounds__(NT, 4) void own_gather(KParams p, BrickGrid bg, con
                                 ppy = __builtin_fmaf(dq[jy].x, q, ppy);
                                 ppz = __builtin_fmaf(w[jy].x, qz, ppz);
                             }
-                            const float wxi = weight_x<K>(tx, ii);
-                            ag0 = __builtin_fmaf(wgrad_x<K>(tx, ii), pp, ag0);
+                            const float wxi = own_weight_x<K>(p, tx, ii);
+                            ag0 = __builtin_fmaf(own_wgrad_x<K>(p, tx, ii), pp, ag0);
                             ag1 = __builtin_fmaf(wxi, ppy, ag1);
                             ag2 = __builtin_fmaf(wxi, ppz, ag2);
                             asm volatile("" : "+v"(ag0), "+v"(ag1), "+v"(ag2));      // (one x-plane at a time: the planes' 16 reads each interleaved spill)
@@ -1561,16 +1629,18 @@ __global__ __launch_bounds__(NT, 4) void own_gather(KParams p, BrickGrid bg, con
                     }
                     f2 a = { 0.f, 0.f };
 #pragma unroll
-                    for (int ii = 0; ii <= K; ++ii) {
+                    for (int ii = 0; ii <= KSV<K>; ++ii) {
                         if (p.dbg & 2) { a = f2{ w[0].x + wx[ii], w[1].y }; break; }      // (ablation: no taps)
+                        if (K == KMIX && ii > p.order[0]) continue;                      // (mixed orders: no plane, no slot beyond a dim's own stencil)
                         f2 t2[16];
                         gather_reads(addr + (unsigned)(ii * GPLANE * 8), t2);
+                        if constexpr (K == KMIX) clear_unused_taps(p.order[1], p.order[2], t2);
                         f2 pp = { 0.f, 0.f };
 #pragma unroll
-                        for (int jy = 0; jy <= K; ++jy) {
+                        for (int jy = 0; jy <= KSV<K>; ++jy) {
                             f2 q = { 0.f, 0.f };
 #pragma unroll
-                            for (int k = 0; k <= K; ++k) q = f2{ w[k].y, w[k].y } * t2[4 * jy + k] + q;
+                            for (int k = 0; k <= KSV<K>; ++k) q = f2{ w[k].y, w[k].y } * t2[4 * jy + k] + q;
                             pp = f2{ w[jy].x, w[jy].x } * q + pp;
                         }
                         a = f2{ wx[ii], wx[ii] } * pp + a;
@@ -1748,18 +1818,82 @@ static int tile_count(const interpol_problem *p)
     return n > 0x7fffffff ? 0 : (int)n;
 }
 
+// Mixed orders 1..3: the K = KMIX instantiations and their launchers live in a translation unit of their own (this file compiled with
+// -DIP_OWNER_MIX_TU, as ops_sorted.hip's mixed kernels: the isotropic kernels of this module keep their code to the byte).
+// dtype: of the sources (own_bin, idx == 0); idx 1 / 2 / 3: the pull / the grid gradient of its backward / grid_grad (float).
+int mix_launch_bin(int dtype, int idx, const KParams &k, const BrickGrid &bg, const Workspace &w, const void *val, const void *grid, void *vol,
+                   const int *gate, const void *aux, const int *all, int gx, int gy, int gz, int ntiles, int B, hipStream_t st);
+int mix_launch_acc(const KParams &k, const BrickGrid &bg, const Workspace &w, void *vol, int nch, int color, int Bw, const int *gate,
+                   unsigned nblocks, hipStream_t st);
+int mix_launch_gather(int grad, const KParams &k, const BrickGrid &bg, const Workspace &w, const void *vol, void *val, const int *gate,
+                      const void *gout, unsigned nblocks, hipStream_t st);
+
+#ifdef IP_OWNER_MIX_TU
+int mix_launch_bin(int dtype, int idx, const KParams &k, const BrickGrid &bg, const Workspace &w, const void *val, const void *grid, void *vol,
+                   const int *gate, const void *aux, const int *all, int gx, int gy, int gz, int ntiles, int B, hipStream_t st)
+{
+    const int nty = (gy + TS - 1) / TS, ntz = (gz + TS - 1) / TS;
+    const dim3 tgrid((unsigned)(ntiles * B));
+#define IP_MIX_BIN(T, IDX)                                                                                              \
+    {                                                                                                                   \
+        const int attr = big_lds<own_bin<T, KMIX, 0, IDX>>(sizeof(BinSmem));                                            \
+        if (attr) return attr;                                                                                          \
+        hipLaunchKernelGGL((own_bin<T, KMIX, 0, IDX>), tgrid, dim3(NT1), sizeof(BinSmem), st, k, bg, (const T *)val, (const float *)grid, \
+                           (float *)vol, w.ndesc, w.desc, w.rec, w.vals, w.meta, w.bmax, w.nrec, gx, gy, gz, nty, ntz, ntiles, gate, (const T *)aux, all); \
+    }
+    if (idx == 0) { if (dtype == INTERPOL_F32) IP_MIX_BIN(float, 0) else if (dtype == INTERPOL_BF16) IP_MIX_BIN(bf16_t, 0) else if (dtype == INTERPOL_F16) IP_MIX_BIN(f16_t, 0) else return INTERPOL_E_DTYPE; }
+    else if (idx == 1) IP_MIX_BIN(float, 1) else if (idx == 2) IP_MIX_BIN(float, 2) else IP_MIX_BIN(float, 3)
+#undef IP_MIX_BIN
+    const hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : (int)e;
+}
+int mix_launch_acc(const KParams &k, const BrickGrid &bg, const Workspace &w, void *vol, int nch, int color, int Bw, const int *gate,
+                   unsigned nblocks, hipStream_t st)
+{
+    const int attr = big_lds<own_accumulate<KMIX>>(sizeof(AccSmem));
+    if (attr) return attr;
+    hipLaunchKernelGGL((own_accumulate<KMIX>), dim3(nblocks), dim3(NT), sizeof(AccSmem), st, k, bg, (const int *)w.ndesc,
+                       (const uint2 *)w.desc, (const float4 *)w.rec, (const float *)w.vals, (const unsigned short *)w.meta,
+                       (const int *)w.bmax, w.nrec, (float *)vol, nch, color, Bw, gate, (int *)w.hdr + 16 + color);
+    const hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : (int)e;
+}
+int mix_launch_gather(int grad, const KParams &k, const BrickGrid &bg, const Workspace &w, const void *vol, void *val, const int *gate,
+                      const void *gout, unsigned nblocks, hipStream_t st)
+{
+#define IP_MIX_GAT(GR)                                                                                                  \
+    {                                                                                                                   \
+        const int attr = big_lds<own_gather<KMIX, GR>>(sizeof(GatSmem));                                                \
+        if (attr) return attr;                                                                                          \
+        hipLaunchKernelGGL((own_gather<KMIX, GR>), dim3(nblocks), dim3(NT), sizeof(GatSmem), st, k, bg, (const int *)w.ndesc, (const uint2 *)w.desc, \
+                           (const float4 *)w.rec, (const int *)w.bmax, (int *)w.hdr + 40, (const float *)vol, (float *)val, gate, (const float *)gout); \
+    }
+    if (grad == 1) IP_MIX_GAT(1) else if (grad == 2) IP_MIX_GAT(2) else IP_MIX_GAT(0)
+#undef IP_MIX_GAT
+    const hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : (int)e;
+}
+#endif
+
 } // namespace owner
+
+#ifndef IP_OWNER_MIX_TU
 
 // Eligible: 3-D, one order 2..3, sample grid about as dense as the target (else the tiled / brick
 // scatters are the better organisation), sizes within 32-bit record counts.
 static bool shared_target(const interpol_problem *p) { return p->vol_stride[0] == 0 && p->batch > 1; }
+static bool mixed_orders(const KParams &k) { return k.order[0] != k.order[1] || k.order[0] != k.order[2]; }
 static bool owner_eligible(const interpol_problem *p, const KParams &k, bool scatter = false)
 {
     const bool shared = scatter && shared_target(p);
     if (p->dim != 3 || p->batch > 4096) return false;
     if (!(p->flags & (INTERPOL_FLAG_BINNED_SCATTER | INTERPOL_FLAG_AUTO_SCATTER))) return false;   // see interpol_hip.h
     // (round 5: the trilinear push / count take the organisation as well; the gathers' bricks stay with orders 2 - 3)
-    if (k.order[0] != k.order[1] || k.order[0] != k.order[2] || k.order[0] < (scatter ? 1 : 2) || k.order[0] > 3) return false;
+    if (k.order[0] != k.order[1] || k.order[0] != k.order[2]) {
+        // mixed orders 1 .. 3 (round 6): the cubic's organisation with the dims' own first taps and weights (K = KMIX), dense grids
+        for (int d = 0; d < 3; ++d) if (k.order[d] < 1 || k.order[d] > 3) return false;
+        if (k.sep != 0) return false;
+    } else if (k.order[0] < (scatter ? 1 : 2) || k.order[0] > 3) return false;
     int64_t n = 1, nv = 1, nb = shared ? 1 : p->batch;
     for (int d = 0; d < 3; ++d) {
         n *= p->grid_shape[d]; nv *= p->vol_shape[d];
@@ -1805,6 +1939,9 @@ static int launch_bin(const interpol_problem *p, const KParams &k, const BrickGr
     const int nty = (gy + TS - 1) / TS, ntz = (gz + TS - 1) / TS;
     const int ntiles = tile_count(p);
     const dim3 tgrid((unsigned)(ntiles * (int)p->batch));
+    if (k.order[0] != k.order[1] || k.order[0] != k.order[2])
+        return mix_launch_bin(std::is_same<T, float>::value ? INTERPOL_F32 : (std::is_same<T, bf16_t>::value ? INTERPOL_BF16 : INTERPOL_F16), IDX, k, bg, w,
+                              val, grid, vol, gate, aux, all, gx, gy, gz, ntiles, (int)p->batch, st);
 #define IP_OWN_BIN(KK, GM)                                                                                              \
     {                                                                                                                   \
         const int attr = big_lds<own_bin<T, KK, GM, IDX>>(sizeof(BinSmem));                                               \
@@ -1860,7 +1997,7 @@ int try_owner_push(const interpol_problem *p, const KParams &k_in, const void *v
         const dim3 pgrid((unsigned)(total < NPROBE ? total : NPROBE));
 #define IP_OWN_PROBE(KK, GM) hipLaunchKernelGGL((own_probe<KK, GM>), pgrid, dim3(NT1), 0, st, k, bg, (const float *)grid, w.hdr, gx, gy, gz, nty, ntz, ntiles, B, nch);
 #define IP_OWN_PROBE_GM(KK) { if (k.sep == 0) IP_OWN_PROBE(KK, 0) else if (k.sep == 1) IP_OWN_PROBE(KK, 1) else if (k.sep == 2) IP_OWN_PROBE(KK, 2) else IP_OWN_PROBE(KK, 3) }
-        if (k.order[0] == 3) IP_OWN_PROBE_GM(3) else if (k.order[0] == 2) IP_OWN_PROBE_GM(2) else IP_OWN_PROBE_GM(1)
+        if (k.order[0] == 3 || mixed_orders(k)) IP_OWN_PROBE_GM(3) else if (k.order[0] == 2) IP_OWN_PROBE_GM(2) else IP_OWN_PROBE_GM(1)
 #undef IP_OWN_PROBE_GM
 #undef IP_OWN_PROBE
         gate = &w.hdr->gate;
@@ -1891,7 +2028,8 @@ int try_owner_push(const interpol_problem *p, const KParams &k_in, const void *v
                                (const int *)w.bmax, w.nrec, (float *)vol, nch, color, Bw, gate, \
                                (int *)w.hdr + 16 + color);                                                              \
         }
-        if (k.order[0] == 3) IP_OWN_ACC(3) else if (k.order[0] == 2) IP_OWN_ACC(2) else IP_OWN_ACC(1)
+        if (mixed_orders(k)) { const int rm = mix_launch_acc(k, bg, w, vol, nch, color, Bw, gate, agrid.x, st); if (rm) return rm; }
+        else if (k.order[0] == 3) IP_OWN_ACC(3) else if (k.order[0] == 2) IP_OWN_ACC(2) else IP_OWN_ACC(1)
 #undef IP_OWN_ACC
     }
     e = hipGetLastError();
@@ -1958,7 +2096,7 @@ int owner_grad_probe(const interpol_problem *p, const KParams &k, const void *gr
     const dim3 pgrid((unsigned)(total < NPROBE ? total : NPROBE));
 #define IP_OWN_PROBE(KK, GM) hipLaunchKernelGGL((own_probe<KK, GM>), pgrid, dim3(NT1), 0, st, k, bg, (const float *)grid, w.hdr, gx, gy, gz, nty, ntz, ntiles, B, mode);
 #define IP_OWN_PROBE_GM(KK) { if (k.sep == 0) IP_OWN_PROBE(KK, 0) else if (k.sep == 1) IP_OWN_PROBE(KK, 1) else if (k.sep == 2) IP_OWN_PROBE(KK, 2) else IP_OWN_PROBE(KK, 3) }
-    if (k.order[0] == 3) IP_OWN_PROBE_GM(3) else IP_OWN_PROBE_GM(2)
+    if (k.order[0] == 3 || mixed_orders(k)) IP_OWN_PROBE_GM(3) else IP_OWN_PROBE_GM(2)
 #undef IP_OWN_PROBE_GM
 #undef IP_OWN_PROBE
     const hipError_t e = hipGetLastError();
@@ -2062,7 +2200,11 @@ int owner_pull_finish(const interpol_problem *p, const KParams &k, const void *v
                            (const float4 *)w.rec, (const int *)w.bmax, (int *)w.hdr + 40, (const float *)vol, (float *)val,            \
                            (spatial && probed) ? (const int *)&w.hdr->gate : (const int *)nullptr, (const float *)gout);  \
     }
-    if (grad) { if (k.order[0] == 3) IP_OWN_GAT(3, 1) else IP_OWN_GAT(2, 1) }
+    if (mixed_orders(k)) {
+        const int rm = mix_launch_gather(grad ? 1 : (spatial ? 2 : 0), kk, bg, w, vol, val, (spatial && probed) ? (const int *)&w.hdr->gate : (const int *)nullptr, gout, ggrid.x, st);
+        if (rm) return rm;
+    }
+    else if (grad) { if (k.order[0] == 3) IP_OWN_GAT(3, 1) else IP_OWN_GAT(2, 1) }
     else if (spatial) { if (k.order[0] == 3) IP_OWN_GAT(3, 2) else IP_OWN_GAT(2, 2) }
     else { if (k.order[0] == 3) IP_OWN_GAT(3, 0) else IP_OWN_GAT(2, 0) }
 #undef IP_OWN_GAT
@@ -2080,4 +2222,7 @@ extern "C" __attribute__((visibility("default"))) int interpol_debug_prof_owner(
     if (reset && hipMemcpyToSymbol(HIP_SYMBOL(ip::sorted::g_prof), z, sizeof z) != hipSuccess) return -1;
     return 0;
 }
+#endif
+#else // IP_OWNER_MIX_TU
+} // namespace ip
 #endif

@@ -280,6 +280,16 @@ __device__ __forceinline__ float mixed_wgrad_x(int kx, float t, int i)
 {
     return kx == 3 ? wgrad_x<3>(t, i) : (kx == 2 ? wgrad_x<2>(t, i) : (i == 0 ? (t > 0.f ? 1.f : 0.f) : (i == 1 ? -1.f : 0.f)));
 }
+// where the orders are runtime (push_owner.hip: own_gather<KMIX>): the slots of taps beyond a dim's order cleared after the reads
+// (t2[4 * jy + k]; 0 * inf is not 0: a non-finite lattice point outside the true stencil must not reach the sums)
+__device__ __forceinline__ void clear_unused_taps(int ky, int kz, f2 *t2)
+{
+    const f2 z = { 0.f, 0.f };
+    if (kz < 3) { t2[3] = z; t2[7] = z; t2[11] = z; t2[15] = z; }
+    if (kz < 2) { t2[2] = z; t2[6] = z; t2[10] = z; t2[14] = z; }
+    if (ky < 3) { t2[12] = z; t2[13] = z; t2[14] = z; t2[15] = z; }
+    if (ky < 2) { t2[8] = z; t2[9] = z; t2[10] = z; t2[11] = z; }
+}
 // f(kx, ky, kz) with the three orders (1..3 each, kernel-uniform) as integral constants
 template <typename F>
 __device__ __forceinline__ void mix_dispatch(int kx, int ky, int kz, F &&f)
