@@ -131,7 +131,9 @@ typedef struct interpol_problem {
  * depends on the deformation (4x2x256^3 cubic: 2.8 - 3.6 ms from the identity to i.i.d. noise of sigma = 6
  * voxels), where the sample-stationary tiles need the stencils of a 16^3 tile of samples to fit a
  * 33 x 33 x 32 LDS box (2.2 ms at the identity, 3.5 at sigma = 2, 126 at sigma = 6).
- * 3-D, one order 1..3 (trilinear since round 5: 4x2x256^3, 2.3 - 3.1 ms from the identity to sigma = 6, where its tiles take
+ * 3-D, one order 1..3 or -- round 6 -- any mix of orders 1..3 on a dense grid (the cubic's bricks with every dim's own first tap and
+ * weights: [1,2,3] at sigma = 6, 4x2x256^3: 3.9 ms where the tiles took 72; the gathers of interpol_pull_ws / interpol_grad_ws / the
+ * backward passes likewise) (trilinear since round 5: 4x2x256^3, 2.3 - 3.1 ms from the identity to sigma = 6, where its tiles take
  * 1.3 - 16 ms; all orders 0, nearest neighbour, through the same bricks with the box held in FLOATS -- round 6: no fixed point at order
  * 0, one LDS float add per sample and channel, so a lattice point hit by one sample holds that sample's value bit for bit and a
  * non-finite source stays on its own lattice point, like iso0.py:65-118 -- 2.5 - 2.9 ms; under AUTO the probe chooses between the bricks
