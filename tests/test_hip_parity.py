@@ -2439,19 +2439,21 @@ def test_routed_grid_grad_bricks_of_the_image_against_oracle(sigma):
         oracle.set_threads(1)
 
 
+@pytest.mark.parametrize("hi", [5, 7])
 @pytest.mark.parametrize("sigma", [0.0, 5.0])
-def test_orders_4_and_5_through_bricks_of_the_image_against_oracle(sigma):
+def test_orders_4_and_5_through_bricks_of_the_image_against_oracle(sigma, hi):
     """csrc/gather5.hip: grid_pull and grid_grad of orders 4 and 5 (3-D, float32) through bricks of the image -- default flags (a probe
     of the call chooses bricks or tiles; sigma = 5: the bricks) and the bricks alone against the oracle and the generic kernels:
     every bound (mixed per dim), the three extrapolation modes, 1 - 3 channels, overhanging ragged sample grids; a ninefold zoom
-    (samples gathered directly by bin5).  Samples on a float32 extrapolation threshold: expected zeros (the float32 reference masks them, G.f32_masked_samples)."""
+    (samples gathered directly by bin5).  Samples on a float32 extrapolation threshold: expected zeros (the float32 reference masks them, G.f32_masked_samples).
+    hi = 7 (round 6): orders 6 and 7 through the same file's second compilation (csrc/gather7.hip: 14^3-cell bricks, eight-slot rows)."""
     from interpol import _hip
-    g = torch.Generator().manual_seed(int(sigma) + 110)
+    g = torch.Generator().manual_seed(int(sigma) + 110 + hi)
     oracle.set_threads(8)
     try:
         for (ishape, oshape) in (((40, 33, 50), (37, 45, 29)), ((48, 48, 48), (48, 48, 48))):
             for bound in range(7):
-                order = 5 - (bound % 2)
+                order = hi - (bound % 2)
                 ex, C = (bound + order) % 3, 1 + (bound + order) % 3
                 inp = torch.randn([2, C, *ishape], generator=g)
                 lin = [torch.linspace(-2, n + 1, m) for n, m in zip(ishape, oshape)]
@@ -2464,7 +2466,7 @@ def test_orders_4_and_5_through_bricks_of_the_image_against_oracle(sigma):
                     slow = _hip.gather(op, inp.to(DEV), grid.to(DEV), b, [order] * 3, ex, flags=_hip.FLAG_NO_FASTPATH).cpu().numpy()
                     for name, fl in (("routed", 0), ("bricks", _hip.FLAG_BINNED_SCATTER)):
                         got = _hip.gather(op, inp.to(DEV), grid.to(DEV), b, [order] * 3, ex, flags=fl).cpu().numpy()
-                        assert float(np.abs(got - slow).max()) <= 8e-6 * float(np.abs(slow).max()), (op, name, "vs generic", sigma, b, order, ex)
+                        assert float(np.abs(got - slow).max()) <= (8e-6 if hi == 5 else 1.5e-5) * float(np.abs(slow).max()), (op, name, "vs generic", sigma, b, order, ex)
                         G.assert_close(got, want, rtol=1e-5, atol_rel=1e-5, what=(op, name, sigma, b, order, ex))
                 # the backward of the pull: grid gradient through the same bricks (gather5 mode 1), alone and next to the image gradient
                 gout = torch.randn([2, C, *oshape], generator=g)
@@ -2476,7 +2478,7 @@ def test_orders_4_and_5_through_bricks_of_the_image_against_oracle(sigma):
                         _same(got[0], slow[0], 1e-5, ("image gradient next to it", sigma, b, order, ex))
         inp = torch.randn([2, 3, 25, 47, 58], generator=g).to(DEV)
         grid = ((interpol.identity_grid((43, 25, 19)) - 10.0) * 9.0)[None].expand(2, 43, 25, 19, 3).contiguous().to(DEV)
-        for order, b in ((5, [6, 5, 6]), (4, [3, 1, 2])):
+        for order, b in ((hi, [6, 5, 6]), (hi - 1, [3, 1, 2])):
             for op in ("pull", "grad"):
                 slow = _hip.gather(op, inp, grid, b, [order] * 3, 0, flags=_hip.FLAG_NO_FASTPATH)
                 _same(_hip.gather(op, inp, grid, b, [order] * 3, 0, flags=_hip.FLAG_BINNED_SCATTER), slow, 1e-5, ("zoomed", op, order, b))

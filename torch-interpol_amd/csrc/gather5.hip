@@ -15,16 +15,42 @@
 // Every boundary condition (a box slot is a lattice point through the tables), the three extrapolation modes, the four coordinate
 // sources.  Workspace: 16 B per sample + 1 KiB per brick (interpol_pull_workspace).
 // ===========================================================================
+//
+// Orders 6 and 7 (round 6): the same file compiled a second time (gather7.hip: -DIP_G5_HIGH) -- bricks of 14^3 first-tap cells so that the
+// 343 / 512-tap stencils of a brick still touch 21^3 lattice points (the same LDS box, two workgroups per CU), rows of four pair slots
+// (the eighth z-slot of an order-6 stencil is cleared after the read), gathers only; namespace g7, entry points try_gather7 /
+// gather7_workspace_bytes, reached through try_gather5 / gather5_workspace_bytes.  Until then these orders had the 8^3-sample round-1
+// tiles alone (4 x 2 x 256^3: pull 14 ms, grid_grad 18).
 #include "sorted_util.hpp"
 
+#ifdef IP_G5_HIGH
+#define IP_G5_NS g7
+#define IP_G5_KLO 6
+#define IP_G5_KHI 7
+#define IP_G5_TRY try_gather7
+#define IP_G5_WSB gather7_workspace_bytes
+#else
+#define IP_G5_NS g5
+#define IP_G5_KLO 4
+#define IP_G5_KHI 5
+#define IP_G5_TRY try_gather5
+#define IP_G5_WSB gather5_workspace_bytes
+#endif
+
 namespace ip {
-namespace g5 {
+namespace IP_G5_NS {
 
 using namespace sorted;
 
+#ifdef IP_G5_HIGH
+constexpr int BR = 14;                          // brick edge, in first-tap cells
+constexpr int OFFB = 160;                       // first taps in [-OFFB, n + OFFB) are binned
+constexpr int BOX = BR + 7;                     // lattice points a brick's stencils touch per dim (K <= 7)
+#else
 constexpr int BR = 16;                          // brick edge, in first-tap cells
 constexpr int OFFB = 160;                       // first taps in [-OFFB, n + OFFB) are binned
 constexpr int BOX = BR + 5;                     // lattice points a brick's stencils touch per dim (K <= 5)
+#endif
 constexpr int PZ = BOX - 1;                     // pair slots per row: slot z = (v[z], v[z + 1])
 constexpr int PLANE = BOX * PZ;
 constexpr int NT = 512;                         // gather5: threads (two workgroups per CU)
@@ -158,7 +184,11 @@ __global__ __launch_bounds__(NT1, 4) void bin5(KParams p, Grid5 bg, const float 
         for (int d = 0; d < 3; ++d) {
             const float fl = floorf(c[v][d] - 0.5f * (float)(K - 1));
             in = in && fl >= (float)(-OFFB) && fl < (float)(bg.nb[d] * BR - OFFB);     // (false for NaN)
+#ifdef IP_G5_HIGH
+            bx[v][d] = in ? (__float2int_rz(fl) + OFFB) / BR : 0;
+#else
             bx[v][d] = in ? (__float2int_rz(fl) + OFFB) >> 4 : 0;
+#endif
         }
         if (in) {
             ok |= 1u << v;
@@ -342,6 +372,28 @@ __device__ __forceinline__ void plane_reads(unsigned addr, f2 (&v)[18])
                  : "v"(addr) : "memory");
 }
 #undef IP_RD
+#ifdef IP_G5_HIGH
+// orders 6 / 7: the 64 taps of one x-plane of a stencil -- eight rows 160 bytes apart, four pairs per row (two blocks: an asm statement takes
+// at most 30 operands)
+#define IP_RD(o, off) "ds_read_b64 %" #o ", %16 offset:" #off "\n\t"
+__device__ __forceinline__ void plane_reads8(unsigned addr, f2 (&v)[32])
+{
+    static_assert(PZ * 8 == 160, "the immediate offsets are (row * PZ + 2 k) * 8");
+    asm volatile(IP_RD(0, 0) IP_RD(1, 16) IP_RD(2, 32) IP_RD(3, 48) IP_RD(4, 160) IP_RD(5, 176) IP_RD(6, 192) IP_RD(7, 208)
+                 IP_RD(8, 320) IP_RD(9, 336) IP_RD(10, 352) IP_RD(11, 368) IP_RD(12, 480) IP_RD(13, 496) IP_RD(14, 512) IP_RD(15, 528)
+                 "s_waitcnt lgkmcnt(0)"
+                 : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]), "=&v"(v[4]), "=&v"(v[5]), "=&v"(v[6]), "=&v"(v[7]),
+                   "=&v"(v[8]), "=&v"(v[9]), "=&v"(v[10]), "=&v"(v[11]), "=&v"(v[12]), "=&v"(v[13]), "=&v"(v[14]), "=&v"(v[15])
+                 : "v"(addr) : "memory");
+    asm volatile(IP_RD(0, 640) IP_RD(1, 656) IP_RD(2, 672) IP_RD(3, 688) IP_RD(4, 800) IP_RD(5, 816) IP_RD(6, 832) IP_RD(7, 848)
+                 IP_RD(8, 960) IP_RD(9, 976) IP_RD(10, 992) IP_RD(11, 1008) IP_RD(12, 1120) IP_RD(13, 1136) IP_RD(14, 1152) IP_RD(15, 1168)
+                 "s_waitcnt lgkmcnt(0)"
+                 : "=&v"(v[16]), "=&v"(v[17]), "=&v"(v[18]), "=&v"(v[19]), "=&v"(v[20]), "=&v"(v[21]), "=&v"(v[22]), "=&v"(v[23]),
+                   "=&v"(v[24]), "=&v"(v[25]), "=&v"(v[26]), "=&v"(v[27]), "=&v"(v[28]), "=&v"(v[29]), "=&v"(v[30]), "=&v"(v[31])
+                 : "v"(addr) : "memory");
+}
+#undef IP_RD
+#endif
 
 template <int K, int MODE>
 __global__ __launch_bounds__(NT, 4) void gather5(KParams p, Grid5 bg, const int *__restrict__ ndesc, const uint2 *__restrict__ desc,
@@ -428,6 +480,63 @@ __global__ __launch_bounds__(NT, 4) void gather5(KParams p, Grid5 bg, const int 
                     int cx = __float2int_rz(fx) - b0[0], cy = __float2int_rz(fy) - b0[1], cz = __float2int_rz(fz) - b0[2];
                     cx = max(0, min(cx, BR - 1)); cy = max(0, min(cy, BR - 1)); cz = max(0, min(cz, BR - 1));
                     const unsigned addr = boxaddr + (unsigned)((cx * BOX + cy) * PZ + cz) * 8u;
+#ifdef IP_G5_HIGH
+                    // eight z-slots in four pairs; order 6: the eighth carries weight 0 and its slot is cleared after the read (a lattice
+                    // point outside the stencil must not reach the sums: 0 * inf)
+                    float wy[8], wz[8];
+                    wy[7] = 0.f; wz[7] = 0.f;
+                    tiled::weights<K>(0, K, ty, wy);
+                    tiled::weights<K>(0, K, tz, wz);
+                    const f2 wzp[4] = { f2{ wz[0], wz[1] }, f2{ wz[2], wz[3] }, f2{ wz[4], wz[5] }, f2{ wz[6], wz[7] } };
+                    const float xyz[3] = { rc.x, rc.y, rc.z };
+                    const float m = inb_mask(p, xyz);                // nd.py:139-140
+                    const int64_t o = (int64_t)__float_as_int(rc.w);
+                    if (MODE == 0) {
+                        float acc = 0.f;
+#pragma unroll
+                        for (int ii = 0; ii <= K; ++ii) {
+                            f2 t[32];
+                            plane_reads8(addr + (unsigned)(ii * PLANE * 8), t);
+                            float pl = 0.f;
+#pragma unroll
+                            for (int j = 0; j <= K; ++j) {
+                                if (K == 6) t[4 * j + 3].y = 0.f;
+                                const f2 s = (wzp[0] * t[4 * j] + wzp[1] * t[4 * j + 1]) + (wzp[2] * t[4 * j + 2] + wzp[3] * t[4 * j + 3]);
+                                pl = __builtin_fmaf(wy[j], s.x + s.y, pl);
+                            }
+                            acc = __builtin_fmaf(tiled::weight1(0, K, tx, ii, tiled::tap_piece(K, ii)), pl, acc);
+                            asm volatile("" : "+v"(acc));            // (one x-plane at a time)
+                        }
+                        oc[o] = acc * m;
+                    } else {
+                        float gy[8], gzz[8];
+                        gy[7] = 0.f; gzz[7] = 0.f;
+                        tiled::wgrads<K>(0, K, ty, gy);
+                        tiled::wgrads<K>(0, K, tz, gzz);
+                        const f2 gzp[4] = { f2{ gzz[0], gzz[1] }, f2{ gzz[2], gzz[3] }, f2{ gzz[4], gzz[5] }, f2{ gzz[6], gzz[7] } };
+                        float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+#pragma unroll
+                        for (int ii = 0; ii <= K; ++ii) {
+                            f2 t[32];
+                            plane_reads8(addr + (unsigned)(ii * PLANE * 8), t);
+                            float pl = 0.f, ply = 0.f, plz = 0.f;
+#pragma unroll
+                            for (int j = 0; j <= K; ++j) {
+                                if (K == 6) t[4 * j + 3].y = 0.f;
+                                const f2 s = (wzp[0] * t[4 * j] + wzp[1] * t[4 * j + 1]) + (wzp[2] * t[4 * j + 2] + wzp[3] * t[4 * j + 3]);
+                                const f2 sz = (gzp[0] * t[4 * j] + gzp[1] * t[4 * j + 1]) + (gzp[2] * t[4 * j + 2] + gzp[3] * t[4 * j + 3]);
+                                const float rv = s.x + s.y, rz = sz.x + sz.y;
+                                pl = __builtin_fmaf(wy[j], rv, pl);
+                                ply = __builtin_fmaf(gy[j], rv, ply);
+                                plz = __builtin_fmaf(wy[j], rz, plz);
+                            }
+                            const float wxi = tiled::weight1(0, K, tx, ii, tiled::tap_piece(K, ii)), gxi = tiled::wgrad1(0, K, tx, ii, tiled::tap_piece(K, ii));
+                            a0 = __builtin_fmaf(gxi, pl, a0);
+                            a1 = __builtin_fmaf(wxi, ply, a1);
+                            a2 = __builtin_fmaf(wxi, plz, a2);
+                            asm volatile("" : "+v"(a0), "+v"(a1), "+v"(a2));
+                        }
+#else
                     float wy[6], wz[6];
                     wy[5] = 0.f; wz[5] = 0.f;                        // (K == 4: the sixth weight is 0)
                     tiled::weights<K>(0, K, ty, wy);
@@ -479,6 +588,7 @@ __global__ __launch_bounds__(NT, 4) void gather5(KParams p, Grid5 bg, const int 
                             a2 = __builtin_fmaf(wxi, plz, a2);
                             asm volatile("" : "+v"(a0), "+v"(a1), "+v"(a2));
                         }
+#endif
                         if (MODE == 1) {
                             // contracted with grad_out; written by the first channel, accumulated by the following ones (the same thread
                             // meets the sample in every channel)
@@ -497,6 +607,7 @@ __global__ __launch_bounds__(NT, 4) void gather5(KParams p, Grid5 bg, const int 
     }
 }
 
+#ifndef IP_G5_HIGH
 // ---------------------------------------------------------------------------
 // scatter5 (round 5) -- grid_push / grid_count (nd.py:146-213, pushpull.py:106-142) of orders 4 and 5 through bricks of the TARGET:
 // the adjoint of gather5 and the deformation-independent scatter of these orders (the LDS tiles of ops_tiled.hip leave samples
@@ -835,11 +946,13 @@ __global__ __launch_bounds__(NT, 4) void scatter5(KParams p, Grid5 bg, const int
     }
 }
 
+#endif // IP_G5_HIGH
+
 static bool eligible(const interpol_problem *p, const KParams &k)
 {
     if (p->dim != 3 || p->dtype != INTERPOL_F32 || p->grid_dtype != INTERPOL_F32 || p->batch > 4096) return false;
     if (!(p->flags & (INTERPOL_FLAG_BINNED_SCATTER | INTERPOL_FLAG_AUTO_SCATTER))) return false;
-    if (k.order[0] != k.order[1] || k.order[0] != k.order[2] || k.order[0] < 4 || k.order[0] > 5) return false;
+    if (k.order[0] != k.order[1] || k.order[0] != k.order[2] || k.order[0] < IP_G5_KLO || k.order[0] > IP_G5_KHI) return false;
     if (p->val_stride[0] < 0) return false;
     int64_t n = 1, nt = p->batch, nb = p->batch;
     for (int d = 0; d < 3; ++d) {
@@ -853,25 +966,35 @@ static bool eligible(const interpol_problem *p, const KParams &k)
     return true;
 }
 
-} // namespace g5
+} // namespace g5 / g7
 
-int64_t gather5_workspace_bytes(const interpol_problem *p, const KParams &k)
+int64_t gather7_workspace_bytes(const interpol_problem *p, const KParams &k);
+int try_gather7(const interpol_problem *p, const KParams &k, const void *vol, const void *grid, void *val, void *workspace, int64_t workspace_bytes,
+                int mode, const void *gout, hipStream_t st, const int **gate_out);
+
+int64_t IP_G5_WSB(const interpol_problem *p, const KParams &k)
 {
-    if (!g5::eligible(p, k)) return 0;
+#ifndef IP_G5_HIGH
+    if (k.order[0] >= 6) return gather7_workspace_bytes(p, k);      // orders 6 - 7: this file's second compilation (gather7.hip)
+#endif
+    if (!IP_G5_NS::eligible(p, k)) return 0;
     int64_t nt = 1;
     for (int d = 0; d < 3; ++d) nt *= (p->grid_shape[d] + sorted::TS - 1) / sorted::TS;
-    return g5::layout(g5::brick_grid(k), (int)p->batch, nt, nullptr, nullptr);
+    return IP_G5_NS::layout(IP_G5_NS::brick_grid(k), (int)p->batch, nt, nullptr, nullptr);
 }
 
 // grid_pull (grad == false) / grid_grad through the bricks: 1 = done, 0 = declined, else an error
 // INTERPOL_FLAG_AUTO_SCATTER: 2 = launched behind the probe's verdict -- the caller launches the tile / generic kernels as well, with
 // KParams::gate = *gate_out and gate_n = -1 (they return at once when the verdict is 1).
 // mode 0: grid_pull, 2: grid_grad, 1: the grid gradient of the pull's backward (val := the dense (B, *out, 3) gradient, gout := grad_out)
-int try_gather5(const interpol_problem *p, const KParams &k, const void *vol, const void *grid, void *val, void *workspace, int64_t workspace_bytes,
-                int mode, const void *gout, hipStream_t st, const int **gate_out)
+int IP_G5_TRY(const interpol_problem *p, const KParams &k, const void *vol, const void *grid, void *val, void *workspace, int64_t workspace_bytes,
+              int mode, const void *gout, hipStream_t st, const int **gate_out)
 {
+#ifndef IP_G5_HIGH
+    if (k.order[0] >= 6) return try_gather7(p, k, vol, grid, val, workspace, workspace_bytes, mode, gout, st, gate_out);
+#endif
     const bool grad = mode != 0;
-    using namespace g5;
+    using namespace IP_G5_NS;
     if (!workspace || ((uintptr_t)workspace & 255u) != 0 || !eligible(p, k)) return 0;
     const int gx = (int)p->grid_shape[0], gy = (int)p->grid_shape[1], gz = (int)p->grid_shape[2];
     const int nty = (gy + TS - 1) / TS, ntz = (gz + TS - 1) / TS, ntiles = ((gx + TS - 1) / TS) * nty * ntz;
@@ -885,8 +1008,13 @@ int try_gather5(const interpol_problem *p, const KParams &k, const void *vol, co
     // zoom 2 3.5 / 9.3; grad 1.70 / 2.02, 1.95 / 2.89 -- a tie at zoom 1.5): no probe, no tiles.  Order 4: the tiles keep smooth fields
     // (identity 1.19 against 1.27 ms, zoom 1.2 1.23 / 1.51), the probe gives rough ones to the bricks.
     // grid_grad of order 4: the bricks as well (identity 1.50 against 1.54, sigma = 2 1.72 / 2.31).
+#ifdef IP_G5_HIGH
+    const bool gated = false && grad;                              // orders 6 - 7: the bricks always (the tiles behind them are the 8^3 ones of round 1)
+#else
     const bool gated = !(p->flags & INTERPOL_FLAG_BINNED_SCATTER) && k.order[0] == 4 && !grad;
+#endif
     const int *gate = gated ? w.hdr : nullptr;
+#ifndef IP_G5_HIGH
     if (gated) {
         const long long total = (long long)ntiles * p->batch;
         const dim3 pgrid((unsigned)(total < NPROBE ? total : NPROBE));
@@ -896,6 +1024,7 @@ int try_gather5(const interpol_problem *p, const KParams &k, const void *vol, co
 #undef IP_P5_GM
 #undef IP_P5
     }
+#endif
     const dim3 tgrid((unsigned)(ntiles * (int)p->batch));
     const long long want = 2ll * cu_count();
     const dim3 ggrid((unsigned)(w.nbricks < want ? w.nbricks : want));
@@ -909,8 +1038,8 @@ int try_gather5(const interpol_problem *p, const KParams &k, const void *vol, co
                            (const float4 *)w.rec, (const int *)w.list, w.hdr + 40, (const float *)vol, (float *)val, gate, (const float *)gout); \
     }
 #define IP_G5_GM(KK, MD) { if (k.sep == 0) IP_G5(KK, 0, MD) else if (k.sep == 1) IP_G5(KK, 1, MD) else if (k.sep == 2) IP_G5(KK, 2, MD) else IP_G5(KK, 3, MD) }
-    if (k.order[0] == 5) { if (mode == 2) IP_G5_GM(5, 2) else if (mode == 1) IP_G5_GM(5, 1) else IP_G5_GM(5, 0) }
-    else { if (mode == 2) IP_G5_GM(4, 2) else if (mode == 1) IP_G5_GM(4, 1) else IP_G5_GM(4, 0) }
+    if (k.order[0] == IP_G5_KHI) { if (mode == 2) IP_G5_GM(IP_G5_KHI, 2) else if (mode == 1) IP_G5_GM(IP_G5_KHI, 1) else IP_G5_GM(IP_G5_KHI, 0) }
+    else { if (mode == 2) IP_G5_GM(IP_G5_KLO, 2) else if (mode == 1) IP_G5_GM(IP_G5_KLO, 1) else IP_G5_GM(IP_G5_KLO, 0) }
 #undef IP_G5_GM
 #undef IP_G5
     const hipError_t e = hipGetLastError();
@@ -919,18 +1048,19 @@ int try_gather5(const interpol_problem *p, const KParams &k, const void *vol, co
     return gated ? 2 : 1;
 }
 
+#ifndef IP_G5_HIGH
 // grid_push (val != NULL) / grid_count of orders 4 and 5 through bricks of the target (scatter5): 1 = done, 0 = declined, else an error.
 // The target `vol` (float, zeroed or accumulated into by the caller) takes p->channels (+ 1 with k.cc) channels.
 int64_t scatter5_workspace_bytes(const interpol_problem *p, const KParams &k)
 {
     interpol_problem q = *p;
     q.val_stride[0] = 0;                                             // (the gathers' test of the output strides does not apply)
-    if (!g5::eligible(&q, k)) return 0;
+    if (!IP_G5_NS::eligible(&q, k)) return 0;
     // the bricks when there is at least a quarter of a sample per target voxel (sparser: the tiles / the target-stationary splatting)
     int64_t n = 1, nv = 1, nt = 1;
     for (int d = 0; d < 3; ++d) { n *= p->grid_shape[d]; nv *= p->vol_shape[d]; nt *= (p->grid_shape[d] + sorted::TS - 1) / sorted::TS; }
     if (4 * n < nv || p->vol_stride[0] == 0) return 0;               // (a shared target: not here)
-    return g5::layout(g5::brick_grid(k), (int)p->batch, nt, nullptr, nullptr);
+    return IP_G5_NS::layout(IP_G5_NS::brick_grid(k), (int)p->batch, nt, nullptr, nullptr);
 }
 // INTERPOL_FLAG_AUTO_SCATTER: 2 = launched behind the verdict of probe5 (smooth fields stay with the LDS tiles: 8 x 1 x 192^3 order 5 at the
 // identity 2.22 against 2.37 ms; rough ones go to the bricks: sigma = 2 4.24 / 3.68) -- the caller launches the tiles as well, with
@@ -938,7 +1068,7 @@ int64_t scatter5_workspace_bytes(const interpol_problem *p, const KParams &k)
 int try_scatter5(const interpol_problem *p, const KParams &k, const void *val, const void *grid, void *vol, void *workspace, int64_t workspace_bytes,
                  hipStream_t st, const int **gate_out)
 {
-    using namespace g5;
+    using namespace IP_G5_NS;
     if (!workspace || ((uintptr_t)workspace & 255u) != 0) return 0;
     const int64_t need = scatter5_workspace_bytes(p, k);
     if (need <= 0 || need > workspace_bytes) return 0;
@@ -982,5 +1112,7 @@ int try_scatter5(const interpol_problem *p, const KParams &k, const void *val, c
     if (gate_out) *gate_out = gate;
     return gated ? 2 : 1;
 }
+
+#endif // IP_G5_HIGH
 
 } // namespace ip
