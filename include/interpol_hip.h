@@ -234,7 +234,9 @@ int interpol_pull(const interpol_problem *p, const void *vol, const void *grid, 
 /* Orders 4 and 5 (3-D, float32; round 4, gather5.hip): the same two entry points, interpol_grad_ws and the grid gradient of
  * interpol_pull_backward serve them through bricks of the image of their own (16 B per sample + 1 KiB per brick of workspace).
  * AUTO: order 5 always (8 x 1 x 192^3, sigma = 2: pull 2.57 -> 1.77 ms, grad 2.89 -> 1.96; sigma = 6: 43 -> 1.9 ms), order 4 for
- * grid_grad and the grid gradient, its pull behind a probe of the call (smooth fields stay with the LDS tiles). */
+ * grid_grad and the grid gradient, its pull behind a probe of the call (smooth fields stay with the LDS tiles).
+ * Orders 6 and 7 (round 6, gather7.hip: bricks of 14^3 cells, always under AUTO): 4 x 2 x 256^3 order 7 pull 14.1 -> 7.2 ms, grid_grad
+ * 18.0 -> 8.0; sigma = 6: 167 / 436 -> 7.6 / 8.5 ms. */
 /* 2-D (round 5, scatter2d.hip: gather2d; per-dim orders 1..3, F32 / BF16 / F16 images, float32 coordinates): interpol_pull_ws, the grid
  * gradient of interpol_pull_backward (grad_vol == NULL for a 16-bit image, whose accumulator owns `scratch`) and both gradients of
  * interpol_push_backward_ws go through 32 x 32 bricks of the image -- 16 B per sample + 1 KiB per brick of workspace -- always under
@@ -389,7 +391,7 @@ float   interpol_host_weight_f32(int32_t order, float x, int32_t which);
  *       function of its inputs, as the reference's gather is (nd.py:118-136).
  * Round 5: the hand-back only exists where no device-side router does.  Calls that carry a workspace for the bricks --
  * interpol_push / interpol_count with INTERPOL_FLAG_AUTO_SCATTER or _BINNED_SCATTER, interpol_pull_ws, interpol_grad_ws,
- * interpol_pull_backward / interpol_push_backward_ws with the bricks' workspace (3-D orders 2 - 5 and 2-D orders 1 - 3, as each
+ * interpol_pull_backward / interpol_push_backward_ws with the bricks' workspace (3-D orders 2 - 7 and mixed 1 - 3, 2-D orders 1 - 3, as each
  * entry point documents) -- never hand back: their organisation is chosen by a probe of THIS call's coordinates, so the result is a
  * function of the inputs under every mode (tests: test_routed_operators_do_not_depend_on_the_streams_history).  The modes
  * below still govern 3-D order 1, orders 6 - 7, 2-D grid_grad (a generic kernel) and every call without a workspace.
