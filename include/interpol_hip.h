@@ -236,7 +236,8 @@ int interpol_pull(const interpol_problem *p, const void *vol, const void *grid, 
  * AUTO: order 5 always (8 x 1 x 192^3, sigma = 2: pull 2.57 -> 1.77 ms, grad 2.89 -> 1.96; sigma = 6: 43 -> 1.9 ms), order 4 for
  * grid_grad and the grid gradient, its pull behind a probe of the call (smooth fields stay with the LDS tiles).
  * Orders 6 and 7 (round 6, gather7.hip: bricks of 14^3 cells, always under AUTO): 4 x 2 x 256^3 order 7 pull 14.1 -> 7.2 ms, grid_grad
- * 18.0 -> 8.0; sigma = 6: 167 / 436 -> 7.6 / 8.5 ms. */
+ * 18.0 -> 8.0; sigma = 6: 167 / 436 -> 7.6 / 8.5 ms; their push / count likewise through scatter5's second compilation: 15.5 -> 11.2 ms,
+ * sigma = 6: 250 -> 11.7). */
 /* 2-D (round 5, scatter2d.hip: gather2d; per-dim orders 1..3, F32 / BF16 / F16 images, float32 coordinates): interpol_pull_ws, the grid
  * gradient of interpol_pull_backward (grad_vol == NULL for a 16-bit image, whose accumulator owns `scratch`) and both gradients of
  * interpol_push_backward_ws go through 32 x 32 bricks of the image -- 16 B per sample + 1 KiB per brick of workspace -- always under

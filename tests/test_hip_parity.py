@@ -2103,19 +2103,21 @@ def test_routed_pull_bricks_of_the_image_against_oracle(sigma):
         oracle.set_threads(1)
 
 
+@pytest.mark.parametrize("lo", [4, 6])
 @pytest.mark.parametrize("sigma", [0.0, 2.0, 7.0])
-def test_orders_4_and_5_push_and_count_through_bricks_of_the_target(sigma):
+def test_orders_4_and_5_push_and_count_through_bricks_of_the_target(sigma, lo):
     """Round 5 (gather5.hip: scatter5): grid_push / grid_count of orders 4 and 5 in 3-D float32 with the bricks' workspace -- the
     routed default (probe5 picks the LDS tiles or the bricks) and the bricks alone (INTERPOL_FLAG_BINNED_SCATTER) against the oracle
     and the generic kernels: every bound (mixed per dim), the three extrapolation modes, 1 - 3 channels, push + count in one call,
-    sample grids that overhang the lattice; sigma = 7 leaves the tiles' boxes everywhere (the cliff of rounds 1 - 4)."""
+    sample grids that overhang the lattice; sigma = 7 leaves the tiles' boxes everywhere (the cliff of rounds 1 - 4).
+    lo = 6 (round 6): orders 6 and 7 through the same file's second compilation (csrc/gather7.hip: 14^3-cell bricks, rows of 7 / 8 adds)."""
     from interpol import _hip
-    g = torch.Generator().manual_seed(int(sigma) + 140)
+    g = torch.Generator().manual_seed(int(sigma) + 140 + lo)
     oracle.set_threads(8)
     try:
         for (tshape, sshape) in (((40, 33, 50), (37, 45, 29)), ((48, 48, 48), (48, 48, 48))):
             for bound in range(7):
-                order = 4 + (bound % 2)
+                order = lo + (bound % 2)
                 ex, C = (bound + order) % 3, 1 + (bound + order) % 3
                 src = torch.randn([2, C, *sshape], generator=g)
                 lin = [torch.linspace(-2, n + 1, m) for n, m in zip(tshape, sshape)]

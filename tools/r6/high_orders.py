@@ -8,7 +8,7 @@ sys.path.insert(0, os.path.join(ROOT, "torch-interpol_amd")); sys.path.insert(0,
 import torch, bench
 from interpol import _hip, backend
 dev = torch.device("cuda", 0)
-sigma = float(sys.argv[1]) if len(sys.argv) > 1 else 2.0
+sigma = float(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1][0] != "-" else 2.0
 inp, grid = bench.make_inputs(4, 2, 256, sigma, dev, 1234)
 src = torch.randn_like(inp)
 
@@ -36,5 +36,7 @@ for order in (5, 6, 7):
         row["pull_" + name] = timeit(lambda: _hip.gather("pull", inp, grid, b, o, 1))
         row["grad_" + name] = timeit(lambda: _hip.gather("grad", inp, grid, b, o, 1))
         row["ggrid_" + name] = timeit(lambda: _hip.pull_backward(src, inp, grid, b, o, 1, False, True))
+        if "--push" in sys.argv:
+            row["push_" + name] = timeit(lambda: _hip.scatter("push", src, grid, [256] * 3, b, o, 1))
     backend.rough_deformations = None
     print(json.dumps(row), flush=True)

@@ -18,23 +18,29 @@
 //
 // Orders 6 and 7 (round 6): the same file compiled a second time (gather7.hip: -DIP_G5_HIGH) -- bricks of 14^3 first-tap cells so that the
 // 343 / 512-tap stencils of a brick still touch 21^3 lattice points (the same LDS box, two workgroups per CU), rows of four pair slots
-// (the eighth z-slot of an order-6 stencil is cleared after the read), gathers only; namespace g7, entry points try_gather7 /
-// gather7_workspace_bytes, reached through try_gather5 / gather5_workspace_bytes.  Until then these orders had the 8^3-sample round-1
+// (the eighth z-slot of an order-6 stencil is cleared after the read; scatter5: rows of 7 / 8 adds, first-tap cells in rows of 16); namespace g7,
+// entry points try_gather7 / try_scatter7 / *_workspace_bytes, reached through try_gather5 / try_scatter5 / their *_workspace_bytes.  Until then these orders had the 8^3-sample round-1
 // tiles alone (4 x 2 x 256^3: pull 14 ms, grid_grad 18).
 #include "sorted_util.hpp"
 
 #ifdef IP_G5_HIGH
+#define IP_G5_CP 16                             /* pitch of the first-tap cell arrays of scatter5 (bricks of 14 cells in rows of 16) */
 #define IP_G5_NS g7
 #define IP_G5_KLO 6
 #define IP_G5_KHI 7
 #define IP_G5_TRY try_gather7
 #define IP_G5_WSB gather7_workspace_bytes
+#define IP_S5_TRY try_scatter7
+#define IP_S5_WSB scatter7_workspace_bytes
 #else
+#define IP_G5_CP BR
 #define IP_G5_NS g5
 #define IP_G5_KLO 4
 #define IP_G5_KHI 5
 #define IP_G5_TRY try_gather5
 #define IP_G5_WSB gather5_workspace_bytes
+#define IP_S5_TRY try_scatter5
+#define IP_S5_WSB scatter5_workspace_bytes
 #endif
 
 namespace ip {
@@ -607,7 +613,6 @@ __global__ __launch_bounds__(NT, 4) void gather5(KParams p, Grid5 bg, const int 
     }
 }
 
-#ifndef IP_G5_HIGH
 // ---------------------------------------------------------------------------
 // scatter5 (round 5) -- grid_push / grid_count (nd.py:146-213, pushpull.py:106-142) of orders 4 and 5 through bricks of the TARGET:
 // the adjoint of gather5 and the deformation-independent scatter of these orders (the LDS tiles of ops_tiled.hip leave samples
@@ -620,7 +625,7 @@ __global__ __launch_bounds__(NT, 4) void gather5(KParams p, Grid5 bg, const int 
 // issues more).  Bricks too dense for 32-bit sums and non-finite sources are scattered tap by tap (always correct).
 // ---------------------------------------------------------------------------
 constexpr int NZ5 = BOX + 1;                    // row pitch of the stencil counts (16 bits each, two to a word)
-constexpr int NCELL5 = BR * BR * BR;
+constexpr int NCELL5 = IP_G5_CP * IP_G5_CP * IP_G5_CP;
 constexpr int QCAP5 = 6144;                     // records of a brick that are walked in class order (more: in list order)
 constexpr float MAGIC5 = 12582912.f;            // 1.5 * 2^23: bits 0x4B400000
 constexpr unsigned MAGIC5_BITS = 0x4B400000u;
@@ -640,7 +645,12 @@ struct ScatSmem {
 };
 static_assert(sizeof(ScatSmem) <= 80 * 1024, "two workgroups per CU");
 
+#ifdef IP_G5_HIGH
+// wmax = the spline at 0: 151 / 315 (order 7), 5887 / 11520 (order 6)
+template <int K> __device__ __forceinline__ float units5() { return K == 7 ? 4194304.f * 0.999f / (0.4793651f * 0.4793651f * 0.4793651f) : 4194304.f * 0.999f / (0.5110244f * 0.5110244f * 0.5110244f); }
+#else
 template <int K> __device__ __forceinline__ float units5() { return K == 5 ? 4194304.f * 0.999f / (0.55f * 0.55f * 0.55f) : 4194304.f * 0.999f / (0.5989584f * 0.5989584f * 0.5989584f); }
+#endif
 template <int K> __device__ __forceinline__ float cbmax5() { return 2147483648.f * 0.99f / units5<K>(); }
 
 typedef unsigned short us2_5 __attribute__((ext_vector_type(2)));
@@ -650,7 +660,7 @@ __device__ __forceinline__ void slide5(const unsigned *in, unsigned *out)
     us2_5 s = { 0, 0 };
 #pragma unroll
     for (int j = 0; j < BOX; ++j) {
-        if (j < BR) s += __builtin_bit_cast(us2_5, in[j]);
+        if (j < IP_G5_CP) s += __builtin_bit_cast(us2_5, in[j]);
         if (j >= W) s -= __builtin_bit_cast(us2_5, in[j - W]);
         out[j] = __builtin_bit_cast(unsigned, s);
     }
@@ -661,18 +671,18 @@ __device__ __forceinline__ void counts5(ScatSmem &sm, int tid)
 {
     constexpr int W = K + 1, HZ = NZ5 / 2;
     unsigned *rg = sm.nreg;
-    unsigned in[BR], out[BOX];
-    if (tid < BR * BR) {
+    unsigned in[IP_G5_CP], out[BOX];
+    if (tid < IP_G5_CP * IP_G5_CP) {
         const uint4 lo = reinterpret_cast<const uint4 *>(sm.cells)[2 * tid], hi = reinterpret_cast<const uint4 *>(sm.cells)[2 * tid + 1];
         in[0] = lo.x; in[1] = lo.y; in[2] = lo.z; in[3] = lo.w; in[4] = hi.x; in[5] = hi.y; in[6] = hi.z; in[7] = hi.w;
     }
     __syncthreads();
-    if (tid < BR * BR) {
-        int v[BR], o[NZ5], s = 0;
+    if (tid < IP_G5_CP * IP_G5_CP) {
+        int v[IP_G5_CP], o[NZ5], s = 0;
 #pragma unroll
-        for (int i = 0; i < BR / 2; ++i) { v[2 * i] = (int)(in[i] & 0xffffu); v[2 * i + 1] = (int)(in[i] >> 16); }
+        for (int i = 0; i < IP_G5_CP / 2; ++i) { v[2 * i] = (int)(in[i] & 0xffffu); v[2 * i + 1] = (int)(in[i] >> 16); }
 #pragma unroll
-        for (int j = 0; j < BOX; ++j) { if (j < BR) s += v[j]; if (j >= W) s -= v[j - W]; o[j] = s; }
+        for (int j = 0; j < BOX; ++j) { if (j < IP_G5_CP) s += v[j]; if (j >= W) s -= v[j - W]; o[j] = s; }
         o[BOX] = 0;
 #pragma unroll
         for (int i = 0; i < HZ; ++i) rg[tid * HZ + i] = (unsigned)o[2 * i] | ((unsigned)o[2 * i + 1] << 16);
@@ -680,12 +690,12 @@ __device__ __forceinline__ void counts5(ScatSmem &sm, int tid)
     __syncthreads();
     {
         const int x = tid / HZ, zp = tid - x * HZ;
-        if (tid < BR * HZ) {
+        if (tid < IP_G5_CP * HZ) {
 #pragma unroll
-            for (int k = 0; k < BR; ++k) in[k] = rg[(x * BR + k) * HZ + zp];
+            for (int k = 0; k < IP_G5_CP; ++k) in[k] = rg[(x * IP_G5_CP + k) * HZ + zp];
         }
         __syncthreads();
-        if (tid < BR * HZ) {
+        if (tid < IP_G5_CP * HZ) {
             slide5<W>(in, out);
 #pragma unroll
             for (int j = 0; j < BOX; ++j) rg[(x * BOX + j) * HZ + zp] = out[j];
@@ -696,7 +706,7 @@ __device__ __forceinline__ void counts5(ScatSmem &sm, int tid)
         const int y = tid / HZ, zp = tid - y * HZ;
         if (tid < BOX * HZ) {
 #pragma unroll
-            for (int k = 0; k < BR; ++k) in[k] = rg[(k * BOX + y) * HZ + zp];
+            for (int k = 0; k < IP_G5_CP; ++k) in[k] = rg[(k * BOX + y) * HZ + zp];
         }
         __syncthreads();
         if (tid < BOX * HZ) {
@@ -713,6 +723,14 @@ template <int K, int I, int J>
 __device__ __forceinline__ void row_adds5(unsigned addr, const float *v)
 {
     constexpr int o = ((I * BOX + J) * BOX) * 4;
+#ifdef IP_G5_HIGH
+    asm volatile("ds_add_u32 %0, %1 offset:%8\n\tds_add_u32 %0, %2 offset:%9\n\tds_add_u32 %0, %3 offset:%10\n\tds_add_u32 %0, %4 offset:%11\n\t"
+                 "ds_add_u32 %0, %5 offset:%12\n\tds_add_u32 %0, %6 offset:%13\n\tds_add_u32 %0, %7 offset:%14"
+                 :: "v"(addr), "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "v"(v[4]), "v"(v[5]), "v"(v[6]),
+                    "n"(o), "n"(o + 4), "n"(o + 8), "n"(o + 12), "n"(o + 16), "n"(o + 20), "n"(o + 24) : "memory");
+    if (K == 7) asm volatile("ds_add_u32 %0, %1 offset:%2" :: "v"(addr), "v"(v[7]), "n"(o + 28) : "memory");
+    return;
+#endif
     if (K == 5)
         asm volatile("ds_add_u32 %0, %1 offset:%7\n\tds_add_u32 %0, %2 offset:%8\n\tds_add_u32 %0, %3 offset:%9\n\tds_add_u32 %0, %4 offset:%10\n\t"
                      "ds_add_u32 %0, %5 offset:%11\n\tds_add_u32 %0, %6 offset:%12"
@@ -728,7 +746,11 @@ template <int K, int I, int J>
 __device__ __forceinline__ void scatter_row5(unsigned addr, float sx, const float *wy, const float *wz)
 {
     const float sy = sx * wy[J];
+#ifdef IP_G5_HIGH
+    float v[8];
+#else
     float v[6];
+#endif
 #pragma unroll
     for (int k = 0; k <= K; ++k) v[k] = __builtin_fmaf(sy, wz[k], MAGIC5);
     row_adds5<K, I, J>(addr, v);
@@ -739,7 +761,11 @@ __device__ __forceinline__ void scatter_plane5(unsigned addr, float s, float wxi
     const float sx = s * wxi;
     scatter_row5<K, I, 0>(addr, sx, wy, wz); scatter_row5<K, I, 1>(addr, sx, wy, wz); scatter_row5<K, I, 2>(addr, sx, wy, wz);
     scatter_row5<K, I, 3>(addr, sx, wy, wz); scatter_row5<K, I, 4>(addr, sx, wy, wz);
-    if (K == 5) scatter_row5<K, I, 5>(addr, sx, wy, wz);
+    if (K >= 5) scatter_row5<K, I, 5>(addr, sx, wy, wz);
+#ifdef IP_G5_HIGH
+    scatter_row5<K, I, 6>(addr, sx, wy, wz);
+    if (K == 7) scatter_row5<K, I, 7>(addr, sx, wy, wz);
+#endif
 }
 
 template <int K>
@@ -804,7 +830,7 @@ __global__ __launch_bounds__(NT, 4) void scatter5(KParams p, Grid5 bg, const int
                 int cx = __float2int_rz(floorf(rc.x - 0.5f * (float)(K - 1))) - b0[0], cy = __float2int_rz(floorf(rc.y - 0.5f * (float)(K - 1))) - b0[1],
                     cz = __float2int_rz(floorf(rc.z - 0.5f * (float)(K - 1))) - b0[2];
                 cx = max(0, min(cx, BR - 1)); cy = max(0, min(cy, BR - 1)); cz = max(0, min(cz, BR - 1));
-                const int cell = (cx * BR + cy) * BR + cz;
+                const int cell = (cx * IP_G5_CP + cy) * IP_G5_CP + cz;
                 atomicAdd(&sm.cells[cell >> 1], 1u << (16 * (cell & 1)));
                 if (sorted_) atomicAdd(&sm.qcnt[((cx * BOX + cy) * BOX + cz) & 31], 1);
             }
@@ -849,7 +875,11 @@ __global__ __launch_bounds__(NT, 4) void scatter5(KParams p, Grid5 bg, const int
         }
         __syncthreads();
         // 32-bit sums hold while density * prod_d sum_j max_t w_j(t) units of max |source| fit (tile_common.hpp: headroom32)
+#ifdef IP_G5_HIGH
+        const float wsum = K == 7 ? 1.4793651f : 1.5110244f;
+#else
         const float wsum = K == 5 ? 1.55f : 1.5989584f;
+#endif
         const bool dense = ntot >= 60000 || (float)sm.dmax * (wsum * wsum * wsum) > cbmax5<K>();           // (block-uniform)
         if (!dense) counts5<K>(sm, tid);
         const unsigned boxaddr = (unsigned)(size_t)(__attribute__((address_space(3))) void *)(sm.box);
@@ -912,8 +942,13 @@ __global__ __launch_bounds__(NT, 4) void scatter5(KParams p, Grid5 bg, const int
                     int cx = __float2int_rz(fx) - b0[0], cy = __float2int_rz(fy) - b0[1], cz = __float2int_rz(fz) - b0[2];
                     cx = max(0, min(cx, BR - 1)); cy = max(0, min(cy, BR - 1)); cz = max(0, min(cz, BR - 1));
                     const unsigned addr = boxaddr + (unsigned)((cx * BOX + cy) * BOX + cz) * 4u;
+#ifdef IP_G5_HIGH
+                    float wy[8], wz[8];
+                    wy[7] = 0.f; wz[7] = 0.f;
+#else
                     float wy[6], wz[6];
                     wy[5] = 0.f; wz[5] = 0.f;
+#endif
                     tiled::weights<K>(0, K, ty, wy);
                     tiled::weights<K>(0, K, tz, wz);
                     const float ss = sv * scale;
@@ -922,7 +957,11 @@ __global__ __launch_bounds__(NT, 4) void scatter5(KParams p, Grid5 bg, const int
                     scatter_plane5<K, 2>(addr, ss, tiled::weight1(0, K, tx, 2, tiled::tap_piece(K, 2)), wy, wz);
                     scatter_plane5<K, 3>(addr, ss, tiled::weight1(0, K, tx, 3, tiled::tap_piece(K, 3)), wy, wz);
                     scatter_plane5<K, 4>(addr, ss, tiled::weight1(0, K, tx, 4, tiled::tap_piece(K, 4)), wy, wz);
-                    if (K == 5) scatter_plane5<K, 5>(addr, ss, tiled::weight1(0, K, tx, 5, tiled::tap_piece(K, 5)), wy, wz);
+                    if (K >= 5) scatter_plane5<K, 5>(addr, ss, tiled::weight1(0, K, tx, 5, tiled::tap_piece(K, 5)), wy, wz);
+#ifdef IP_G5_HIGH
+                    scatter_plane5<K, 6>(addr, ss, tiled::weight1(0, K, tx, 6, tiled::tap_piece(K, 6)), wy, wz);
+                    if (K == 7) scatter_plane5<K, 7>(addr, ss, tiled::weight1(0, K, tx, 7, tiled::tap_piece(K, 7)), wy, wz);
+#endif
                 }
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -945,8 +984,6 @@ __global__ __launch_bounds__(NT, 4) void scatter5(KParams p, Grid5 bg, const int
         }
     }
 }
-
-#endif // IP_G5_HIGH
 
 static bool eligible(const interpol_problem *p, const KParams &k)
 {
@@ -1048,11 +1085,17 @@ int IP_G5_TRY(const interpol_problem *p, const KParams &k, const void *vol, cons
     return gated ? 2 : 1;
 }
 
-#ifndef IP_G5_HIGH
 // grid_push (val != NULL) / grid_count of orders 4 and 5 through bricks of the target (scatter5): 1 = done, 0 = declined, else an error.
 // The target `vol` (float, zeroed or accumulated into by the caller) takes p->channels (+ 1 with k.cc) channels.
-int64_t scatter5_workspace_bytes(const interpol_problem *p, const KParams &k)
+int64_t scatter7_workspace_bytes(const interpol_problem *p, const KParams &k);
+int try_scatter7(const interpol_problem *p, const KParams &k, const void *val, const void *grid, void *vol, void *workspace, int64_t workspace_bytes,
+                 hipStream_t st, const int **gate_out);
+
+int64_t IP_S5_WSB(const interpol_problem *p, const KParams &k)
 {
+#ifndef IP_G5_HIGH
+    if (k.order[0] >= 6) return scatter7_workspace_bytes(p, k);     // orders 6 - 7: this file's second compilation (gather7.hip)
+#endif
     interpol_problem q = *p;
     q.val_stride[0] = 0;                                             // (the gathers' test of the output strides does not apply)
     if (!IP_G5_NS::eligible(&q, k)) return 0;
@@ -1065,12 +1108,15 @@ int64_t scatter5_workspace_bytes(const interpol_problem *p, const KParams &k)
 // INTERPOL_FLAG_AUTO_SCATTER: 2 = launched behind the verdict of probe5 (smooth fields stay with the LDS tiles: 8 x 1 x 192^3 order 5 at the
 // identity 2.22 against 2.37 ms; rough ones go to the bricks: sigma = 2 4.24 / 3.68) -- the caller launches the tiles as well, with
 // KParams::gate = *gate_out (they return at once when the verdict is 1).
-int try_scatter5(const interpol_problem *p, const KParams &k, const void *val, const void *grid, void *vol, void *workspace, int64_t workspace_bytes,
-                 hipStream_t st, const int **gate_out)
+int IP_S5_TRY(const interpol_problem *p, const KParams &k, const void *val, const void *grid, void *vol, void *workspace, int64_t workspace_bytes,
+              hipStream_t st, const int **gate_out)
 {
+#ifndef IP_G5_HIGH
+    if (k.order[0] >= 6) return try_scatter7(p, k, val, grid, vol, workspace, workspace_bytes, st, gate_out);
+#endif
     using namespace IP_G5_NS;
     if (!workspace || ((uintptr_t)workspace & 255u) != 0) return 0;
-    const int64_t need = scatter5_workspace_bytes(p, k);
+    const int64_t need = IP_S5_WSB(p, k);
     if (need <= 0 || need > workspace_bytes) return 0;
     const int gx = (int)p->grid_shape[0], gy = (int)p->grid_shape[1], gz = (int)p->grid_shape[2];
     const int nty = (gy + TS - 1) / TS, ntz = (gz + TS - 1) / TS, ntiles = ((gx + TS - 1) / TS) * nty * ntz;
@@ -1080,8 +1126,13 @@ int try_scatter5(const interpol_problem *p, const KParams &k, const void *val, c
     const int64_t nz = 64 + 2 * w.nbricks + 1;
     if (nz > 0x7fffffffll) return 0;
     hipLaunchKernelGGL(zero5, dim3((unsigned)((nz + 1023) / 1024)), dim3(1024), 0, st, w.hdr, (int)nz);
+#ifdef IP_G5_HIGH
+    const bool gated = false;                                        // orders 6 - 7: the bricks always
+#else
     const bool gated = !(p->flags & INTERPOL_FLAG_BINNED_SCATTER);
+#endif
     const int *gate = gated ? w.hdr : nullptr;
+#ifndef IP_G5_HIGH
     if (gated) {
         const long long total = (long long)ntiles * p->batch;
         const dim3 pgrid((unsigned)(total < NPROBE ? total : NPROBE));
@@ -1091,6 +1142,7 @@ int try_scatter5(const interpol_problem *p, const KParams &k, const void *val, c
 #undef IP_P5_GM
 #undef IP_P5
     }
+#endif
     const dim3 tgrid((unsigned)(ntiles * (int)p->batch));
     const long long want = 2ll * cu_count();
     const dim3 ggrid((unsigned)(w.nbricks < want ? w.nbricks : want));
@@ -1104,7 +1156,7 @@ int try_scatter5(const interpol_problem *p, const KParams &k, const void *val, c
                            (const float4 *)w.rec, (const int *)w.list, w.hdr + 40, (const float *)val, (float *)vol, gate);   \
     }
 #define IP_S5_GM(KK) { if (k.sep == 0) IP_S5(KK, 0) else if (k.sep == 1) IP_S5(KK, 1) else if (k.sep == 2) IP_S5(KK, 2) else IP_S5(KK, 3) }
-    if (k.order[0] == 5) IP_S5_GM(5) else IP_S5_GM(4)
+    if (k.order[0] == IP_G5_KHI) IP_S5_GM(IP_G5_KHI) else IP_S5_GM(IP_G5_KLO)
 #undef IP_S5_GM
 #undef IP_S5
     const hipError_t e = hipGetLastError();
@@ -1112,7 +1164,5 @@ int try_scatter5(const interpol_problem *p, const KParams &k, const void *val, c
     if (gate_out) *gate_out = gate;
     return gated ? 2 : 1;
 }
-
-#endif // IP_G5_HIGH
 
 } // namespace ip
