@@ -24,7 +24,7 @@ for case in range(n_cases):
     dim = rnd.choice([1, 2, 3, 3, 3]); B = rnd.choice([1, 2]); C = rnd.choice([1, 2, 3])
     ishape = [rnd.randint(17, 40) for _ in range(3)] if dim == 3 else ([rnd.randint(40, 150) for _ in range(2)] if dim == 2 else [rnd.randint(300, 7000)])
     oshape = [rnd.randint(17, 40) for _ in range(3)] if dim == 3 else ([rnd.randint(65, 150) for _ in range(2)] if dim == 2 else [rnd.randint(4096, 9000)])
-    order = [rnd.choice([0, 1, 2, 3, 3, 4, 5, 7])] * dim if rnd.random() < 0.6 else [rnd.choice([1, 2, 3]) for _ in range(dim)]
+    order = [rnd.choice([0, 1, 2, 3, 3, 4, 5, 6, 7])] * dim if rnd.random() < 0.6 else [rnd.choice([1, 2, 3]) for _ in range(dim)]
     bound = [rnd.randrange(7) for _ in range(dim)] if rnd.random() < 0.5 else [rnd.randrange(7)] * dim
     ex = rnd.choice([0, 1, 1, 2])
     kind = rnd.choice(["identity", "noise", "zoom", "rough"])
