@@ -427,15 +427,19 @@ def test_tiled_scatter_matches_generic(dim, order, sigma):
     from interpol import _hip
     vol, grid, tshape, sshape = _tiled_problem(dim, sigma, seed=int(order * 10 + sigma) + dim + 1)
     src = torch.randn([2, 3, *sshape], generator=torch.Generator().manual_seed(11)).to(DEV)
+    # (orders 6 - 7 in 3-D, round 6: bricks of 14^3 cells -- under `replicate` and sigma = 9 a corner voxel of value ~ 50 collects several
+    #  hundred float32 atomic adds in either organisation, each rounded at 4e-6 of the running sum: the two sums differ by 1.3e-5 of the
+    #  maximum; north_star's bar is rtol 1e-5 + atol 1e-5 max = 2e-5 at the maximum, and the oracle tests of these orders hold it)
+    tol = 2e-5 if (order >= 6 and dim == 3) else 1e-5
     for bound in range(7):
         for ex in ((1, 0, 2) if bound in (0, 3, 5) else (1,)):
             b, o = [bound] * dim, [order] * dim
             fast = _hip.scatter("push", src, grid, list(tshape), b, o, ex)
             slow = _hip.scatter("push", src, grid, list(tshape), b, o, ex, flags=_hip.FLAG_NO_FASTPATH)
-            _same(fast, slow, 1e-5, ("push", dim, bound, ex, order, sigma))
+            _same(fast, slow, tol, ("push", dim, bound, ex, order, sigma))
             fast = _hip.scatter("count", None, grid, list(tshape), b, o, ex)
             slow = _hip.scatter("count", None, grid, list(tshape), b, o, ex, flags=_hip.FLAG_NO_FASTPATH)
-            _same(fast, slow, 1e-5, ("count", dim, bound, ex, order, sigma))
+            _same(fast, slow, tol, ("count", dim, bound, ex, order, sigma))
     # fused pull backward (tiled) vs its composition from the generic forward operators
     for bound, ex in ((3, 1), (0, 0), (6, 1), (4, 2)):
         b, o = [bound] * dim, [order] * dim
@@ -443,7 +447,7 @@ def test_tiled_scatter_matches_generic(dim, order, sigma):
         want_gvol = _hip.scatter("push", src, grid, list(tshape), b, o, ex, flags=_hip.FLAG_NO_FASTPATH)
         gg = _hip.gather("grad", vol, grid, b, o, ex, flags=_hip.FLAG_NO_FASTPATH)
         want_ggrid = (gg * src.unsqueeze(-1)).sum(1)
-        _same(gvol, want_gvol, 1e-5, ("bwd gvol", dim, bound, ex, order, sigma))
+        _same(gvol, want_gvol, tol, ("bwd gvol", dim, bound, ex, order, sigma))
         _same(ggrid, want_ggrid, 2e-5, ("bwd ggrid", dim, bound, ex, order, sigma))
         only_grid = _hip.pull_backward(src, vol, grid, b, o, ex, False, True)
         assert only_grid[0] is None
@@ -453,7 +457,7 @@ def test_tiled_scatter_matches_generic(dim, order, sigma):
         _same(only_grid[1], ggrid, 1e-6, ("bwd ggrid alone", dim, bound, ex, order, sigma))
         only_vol = _hip.pull_backward(src, vol, grid, b, o, ex, True, False)
         assert only_vol[1] is None
-        _same(only_vol[0], want_gvol, 1e-5, "bwd gvol only")
+        _same(only_vol[0], want_gvol, tol, "bwd gvol only")
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])

@@ -354,12 +354,15 @@ __global__ __launch_bounds__(NT1) void probe5(KParams p, const float *__restrict
     }
 }
 
+constexpr int QCAPG = 4480;                     // records of a brick that are walked in class order (a brick holds 4096 at unit density; more: in list order)
 struct GatSmem {
     int   taboff[3][BOX + 3];
     float tabsgn[3][BOX + 3];
     unsigned start[CAPD];
     int   pref[CAPD + 2];                      // records in front of each run of the brick; [nd ...]: all of them
-    int   brick, pad;
+    int   brick, qmax;
+    int   qcnt[32], qoff[33];                  // records per bank class of the brick, their offsets in the queue; qmax: the fullest class
+    unsigned short queue[QCAPG];               // the brick's records (index in its list) sorted by the class of their first pair slot
     float2 box[BOX * PLANE + 64];              // 21 x 21 x 20 pair slots = 70 560 B (+ the quartic stencil's unused sixth row / plane)
 };
 static_assert(sizeof(GatSmem) <= 80 * 1024, "two workgroups per CU");
@@ -446,10 +449,55 @@ __global__ __launch_bounds__(NT, 4) void gather5(KParams p, Grid5 bg, const int 
             }
         }
         const unsigned boxaddr = (unsigned)(size_t)(__attribute__((address_space(3))) void *)(sm.box);
+        // ---- class-sorted queue of the brick's records (round 6, as scatter5's): a ds_read_b64 is served per half wave and is conflict-free
+        // when its 32 lanes read 32 different pair slots mod 32 -- all reads of a stencil add the same offsets in every lane, so lane q of
+        // every half wave walks the records whose FIRST slot has class q (list order: 7.6 clk per read, sorted: 2.7 -- ops_sorted.hip)
+        if (tid < 32) sm.qcnt[tid] = 0;
+        __syncthreads();                                             // prefix of the runs written, counters zero
+        const int ntot = sm.pref[CAPD];
+        // The price: in class order a wave's record reads, grad_out reads and result stores are scattered where list order (a tile's samples
+        // side by side) half coalesces them.  Measured (tools/r6/gather5_queue.py, profiles/r06_orders_6_7.txt): it pays for the pull when a
+        // sample costs >= 400 taps (order 7, two channels: 7.2 -> 5.9 ms; order 5, two channels: 3.65 -> 3.45) and loses below (config 3, one
+        // channel of 216 taps: 1.76 -> 1.85) and for the gradient modes, whose 12-byte results it scatters (order 5 grid_grad 4.1 -> 5.0).
+        const bool sorted_ = MODE == 0 && ntot <= QCAPG && p.C * (K + 1) * (K + 1) * (K + 1) >= 400 && !(p.dbg & 64);   // (block-uniform; debug bit 64: list order)
+        if (MODE == 0 && sorted_) {
+            int rr = 0;
+            for (int j = tid; j < ntot; j += NT) {
+                while (j >= sm.pref[rr + 1]) ++rr;
+                const float4 rc = rec[sm.start[rr] + (unsigned)(j - sm.pref[rr])];
+                int cx = __float2int_rz(floorf(rc.x - 0.5f * (float)(K - 1))) - b0[0], cy = __float2int_rz(floorf(rc.y - 0.5f * (float)(K - 1))) - b0[1],
+                    cz = __float2int_rz(floorf(rc.z - 0.5f * (float)(K - 1))) - b0[2];
+                cx = max(0, min(cx, BR - 1)); cy = max(0, min(cy, BR - 1)); cz = max(0, min(cz, BR - 1));
+                atomicAdd(&sm.qcnt[((cx * BOX + cy) * PZ + cz) & 31], 1);
+            }
+            __syncthreads();
+            if (tid < 32) {
+                const int cq = sm.qcnt[tid];
+                int tot;
+                const int off = half_excl_scan(cq, tot);
+                sm.qoff[tid] = off;
+                int mx = cq;
+#pragma unroll
+                for (int o = 16; o > 0; o >>= 1) { const int t = __shfl_xor(mx, o, 32); mx = t > mx ? t : mx; }
+                if (tid == 0) { sm.qoff[32] = tot; sm.qmax = mx; }
+                sm.qcnt[tid] = 0;                                    // (becomes the fill position)
+            }
+            __syncthreads();
+            rr = 0;
+            for (int j = tid; j < ntot; j += NT) {
+                while (j >= sm.pref[rr + 1]) ++rr;
+                const float4 rc = rec[sm.start[rr] + (unsigned)(j - sm.pref[rr])];
+                int cx = __float2int_rz(floorf(rc.x - 0.5f * (float)(K - 1))) - b0[0], cy = __float2int_rz(floorf(rc.y - 0.5f * (float)(K - 1))) - b0[1],
+                    cz = __float2int_rz(floorf(rc.z - 0.5f * (float)(K - 1))) - b0[2];
+                cx = max(0, min(cx, BR - 1)); cy = max(0, min(cy, BR - 1)); cz = max(0, min(cz, BR - 1));
+                const int q = ((cx * BOX + cy) * PZ + cz) & 31;
+                sm.queue[sm.qoff[q] + atomicAdd(&sm.qcnt[q], 1)] = (unsigned short)j;
+            }
+        }
         for (int c = 0; c < p.C; ++c) {
             const float *vc = img + b * p.vol_sb + (int64_t)c * p.vol_sc;
             float *oc = out + b * p.val_sb + (int64_t)c * p.val_sc;
-            __syncthreads();                                         // tables written / the previous channel's readers are done
+            __syncthreads();                                         // tables / queue written / the previous channel's readers are done
             // rows that are contiguous runs of the image's unit-stride dim with sign +1: five quads of pair slots per row from a
             // 16-byte load and the value behind it; else slot by slot through the z table
             const bool zlin = p.vol_ss[2] == 4 && b0[2] >= (p.bound[2] == B_DST1 ? 1 : 0) && b0[2] + BOX <= p.vol_n[2];
@@ -474,11 +522,25 @@ __global__ __launch_bounds__(NT, 4) void gather5(KParams p, Grid5 bg, const int 
                 }
             }
             __syncthreads();
-            const int ntot = sm.pref[CAPD];
             int rr = 0;
-            for (int j = tid; j < ntot; j += NT) {
-                {
+            const int q_ = tid & 31, hw = tid >> 5;
+            const int qbeg = sorted_ ? sm.qoff[q_] : 0, qn = sorted_ ? sm.qoff[q_ + 1] - qbeg : 0;
+            const int nwalk = sorted_ ? (sm.qmax + NT / 32 - 1) / (NT / 32) : (ntot + NT - 1) / NT;     // (block-uniform)
+            for (int it = 0; it < nwalk; ++it) {
+                int j;
+                if (sorted_) {
+                    const int i = hw + it * (NT / 32);
+                    if (i >= qn) continue;
+                    j = sm.queue[qbeg + i];
+                    rr = 0;                                          // the run of record j: the last one whose prefix is <= j
+#pragma unroll
+                    for (int st = CAPD / 2; st > 0; st >>= 1) rr += sm.pref[rr + st] <= j ? st : 0;
+                } else {
+                    j = tid + it * NT;
+                    if (j >= ntot) continue;
                     while (j >= sm.pref[rr + 1]) ++rr;               // (runs beyond the last hold nothing: their prefix is the total)
+                }
+                {
                     const float4 rc = rec[sm.start[rr] + (unsigned)(j - sm.pref[rr])];
                     const float fx = floorf(rc.x - 0.5f * (float)(K - 1)), fy = floorf(rc.y - 0.5f * (float)(K - 1)), fz = floorf(rc.z - 0.5f * (float)(K - 1));
                     const float tx = rc.x - fx, ty = rc.y - fy, tz = rc.z - fz;
