@@ -354,17 +354,18 @@ __global__ __launch_bounds__(NT1) void probe5(KParams p, const float *__restrict
     }
 }
 
-constexpr int QCAPG = 4480;                     // records of a brick that are walked in class order (a brick holds 4096 at unit density; more: in list order)
 struct GatSmem {
     int   taboff[3][BOX + 3];
     float tabsgn[3][BOX + 3];
     unsigned start[CAPD];
     int   pref[CAPD + 2];                      // records in front of each run of the brick; [nd ...]: all of them
-    int   brick, qmax;
-    int   qcnt[32], qoff[33];                  // records per bank class of the brick, their offsets in the queue; qmax: the fullest class
-    unsigned short queue[QCAPG];               // the brick's records (index in its list) sorted by the class of their first pair slot
+    int   brick, qmax;                         // qmax: the fullest bank class (QUEUE)
     float2 box[BOX * PLANE + 64];              // 21 x 21 x 20 pair slots = 70 560 B (+ the quartic stencil's unused sixth row / plane)
+    // gather5<K, MODE, QUEUE = true> only (the list-order kernels are launched with the bytes up to here):
+    int   qcnt[32], qoff[33];                  // records per bank class of the brick, their offsets in the queue
+    unsigned short queue[4480];                // the brick's records (index in its list) sorted by the class of their first pair slot
 };
+constexpr int QCAPG = 4480;                     // records of a brick that are walked in class order (a brick holds 4096 at unit density; more: in list order)
 static_assert(sizeof(GatSmem) <= 80 * 1024, "two workgroups per CU");
 
 #define IP_RD(o, off) "ds_read_b64 %" #o ", %18 offset:" #off "\n\t"
@@ -404,7 +405,14 @@ __device__ __forceinline__ void plane_reads8(unsigned addr, f2 (&v)[32])
 #undef IP_RD
 #endif
 
-template <int K, int MODE>
+// QUEUE (round 6, the pull of >= 400 taps per sample): the brick's records walked through a class-sorted queue, as scatter5's -- a ds_read_b64
+// is served per half wave and is conflict-free when its 32 lanes read 32 different pair slots mod 32; all reads of a stencil add the same
+// offsets in every lane, so lane q of every half wave walks the records whose FIRST slot has class q.  The price: in class order a wave's
+// record reads and result stores are scattered where list order (a tile's samples side by side) half coalesces them.  Measured
+// (tools/r6/gather5_queue.py, profiles/r06_orders_6_7.txt): order 7, two channels: 7.2 -> 5.7 ms; order 5, two channels: 3.68 -> 3.32;
+// config 3 (one channel of 216 taps): 1.76 -> 1.85; the gradient modes lose (order 5 grid_grad 4.1 -> 5.0): they keep the list order,
+// and their kernels (QUEUE = false) the code of round 5 -- the tap code is gather5_taps.inc, included by both walks.
+template <int K, int MODE, bool QUEUE = false>
 __global__ __launch_bounds__(NT, 4) void gather5(KParams p, Grid5 bg, const int *__restrict__ ndesc, const uint2 *__restrict__ desc,
                                                  const float4 *__restrict__ rec, const int *__restrict__ list, int *__restrict__ draw,
                                                  const float *__restrict__ img, float *__restrict__ out, const int *__restrict__ gate,
@@ -449,55 +457,51 @@ __global__ __launch_bounds__(NT, 4) void gather5(KParams p, Grid5 bg, const int 
             }
         }
         const unsigned boxaddr = (unsigned)(size_t)(__attribute__((address_space(3))) void *)(sm.box);
-        // ---- class-sorted queue of the brick's records (round 6, as scatter5's): a ds_read_b64 is served per half wave and is conflict-free
-        // when its 32 lanes read 32 different pair slots mod 32 -- all reads of a stencil add the same offsets in every lane, so lane q of
-        // every half wave walks the records whose FIRST slot has class q (list order: 7.6 clk per read, sorted: 2.7 -- ops_sorted.hip)
-        if (tid < 32) sm.qcnt[tid] = 0;
-        __syncthreads();                                             // prefix of the runs written, counters zero
-        const int ntot = sm.pref[CAPD];
-        // The price: in class order a wave's record reads, grad_out reads and result stores are scattered where list order (a tile's samples
-        // side by side) half coalesces them.  Measured (tools/r6/gather5_queue.py, profiles/r06_orders_6_7.txt): it pays for the pull when a
-        // sample costs >= 400 taps (order 7, two channels: 7.2 -> 5.9 ms; order 5, two channels: 3.65 -> 3.45) and loses below (config 3, one
-        // channel of 216 taps: 1.76 -> 1.85) and for the gradient modes, whose 12-byte results it scatters (order 5 grid_grad 4.1 -> 5.0).
-        const bool sorted_ = MODE == 0 && ntot <= QCAPG && p.C * (K + 1) * (K + 1) * (K + 1) >= 400 && !(p.dbg & 64);   // (block-uniform; debug bit 64: list order)
-        if (MODE == 0 && sorted_) {
-            int rr = 0;
-            for (int j = tid; j < ntot; j += NT) {
-                while (j >= sm.pref[rr + 1]) ++rr;
-                const float4 rc = rec[sm.start[rr] + (unsigned)(j - sm.pref[rr])];
-                int cx = __float2int_rz(floorf(rc.x - 0.5f * (float)(K - 1))) - b0[0], cy = __float2int_rz(floorf(rc.y - 0.5f * (float)(K - 1))) - b0[1],
-                    cz = __float2int_rz(floorf(rc.z - 0.5f * (float)(K - 1))) - b0[2];
-                cx = max(0, min(cx, BR - 1)); cy = max(0, min(cy, BR - 1)); cz = max(0, min(cz, BR - 1));
-                atomicAdd(&sm.qcnt[((cx * BOX + cy) * PZ + cz) & 31], 1);
-            }
-            __syncthreads();
-            if (tid < 32) {
-                const int cq = sm.qcnt[tid];
-                int tot;
-                const int off = half_excl_scan(cq, tot);
-                sm.qoff[tid] = off;
-                int mx = cq;
+        [[maybe_unused]] bool sorted_ = false;
+        if constexpr (QUEUE) {
+            if (tid < 32) sm.qcnt[tid] = 0;
+            __syncthreads();                                         // prefix of the runs written, counters zero
+            const int nq = sm.pref[CAPD];
+            sorted_ = nq <= QCAPG && !(p.dbg & 64);                  // (block-uniform; debug bit 64: list order, the A/B)
+            if (sorted_) {
+                int rq = 0;
+                for (int j = tid; j < nq; j += NT) {
+                    while (j >= sm.pref[rq + 1]) ++rq;
+                    const float4 rc = rec[sm.start[rq] + (unsigned)(j - sm.pref[rq])];
+                    int cx = __float2int_rz(floorf(rc.x - 0.5f * (float)(K - 1))) - b0[0], cy = __float2int_rz(floorf(rc.y - 0.5f * (float)(K - 1))) - b0[1],
+                        cz = __float2int_rz(floorf(rc.z - 0.5f * (float)(K - 1))) - b0[2];
+                    cx = max(0, min(cx, BR - 1)); cy = max(0, min(cy, BR - 1)); cz = max(0, min(cz, BR - 1));
+                    atomicAdd(&sm.qcnt[((cx * BOX + cy) * PZ + cz) & 31], 1);
+                }
+                __syncthreads();
+                if (tid < 32) {
+                    const int cq = sm.qcnt[tid];
+                    int tot;
+                    const int off = half_excl_scan(cq, tot);
+                    sm.qoff[tid] = off;
+                    int mx = cq;
 #pragma unroll
-                for (int o = 16; o > 0; o >>= 1) { const int t = __shfl_xor(mx, o, 32); mx = t > mx ? t : mx; }
-                if (tid == 0) { sm.qoff[32] = tot; sm.qmax = mx; }
-                sm.qcnt[tid] = 0;                                    // (becomes the fill position)
-            }
-            __syncthreads();
-            rr = 0;
-            for (int j = tid; j < ntot; j += NT) {
-                while (j >= sm.pref[rr + 1]) ++rr;
-                const float4 rc = rec[sm.start[rr] + (unsigned)(j - sm.pref[rr])];
-                int cx = __float2int_rz(floorf(rc.x - 0.5f * (float)(K - 1))) - b0[0], cy = __float2int_rz(floorf(rc.y - 0.5f * (float)(K - 1))) - b0[1],
-                    cz = __float2int_rz(floorf(rc.z - 0.5f * (float)(K - 1))) - b0[2];
-                cx = max(0, min(cx, BR - 1)); cy = max(0, min(cy, BR - 1)); cz = max(0, min(cz, BR - 1));
-                const int q = ((cx * BOX + cy) * PZ + cz) & 31;
-                sm.queue[sm.qoff[q] + atomicAdd(&sm.qcnt[q], 1)] = (unsigned short)j;
+                    for (int o = 16; o > 0; o >>= 1) { const int t = __shfl_xor(mx, o, 32); mx = t > mx ? t : mx; }
+                    if (tid == 0) { sm.qoff[32] = tot; sm.qmax = mx; }
+                    sm.qcnt[tid] = 0;                                // (becomes the fill position)
+                }
+                __syncthreads();
+                rq = 0;
+                for (int j = tid; j < nq; j += NT) {
+                    while (j >= sm.pref[rq + 1]) ++rq;
+                    const float4 rc = rec[sm.start[rq] + (unsigned)(j - sm.pref[rq])];
+                    int cx = __float2int_rz(floorf(rc.x - 0.5f * (float)(K - 1))) - b0[0], cy = __float2int_rz(floorf(rc.y - 0.5f * (float)(K - 1))) - b0[1],
+                        cz = __float2int_rz(floorf(rc.z - 0.5f * (float)(K - 1))) - b0[2];
+                    cx = max(0, min(cx, BR - 1)); cy = max(0, min(cy, BR - 1)); cz = max(0, min(cz, BR - 1));
+                    const int q = ((cx * BOX + cy) * PZ + cz) & 31;
+                    sm.queue[sm.qoff[q] + atomicAdd(&sm.qcnt[q], 1)] = (unsigned short)j;
+                }
             }
         }
         for (int c = 0; c < p.C; ++c) {
             const float *vc = img + b * p.vol_sb + (int64_t)c * p.vol_sc;
             float *oc = out + b * p.val_sb + (int64_t)c * p.val_sc;
-            __syncthreads();                                         // tables / queue written / the previous channel's readers are done
+            __syncthreads();                                         // tables (queue) written / the previous channel's readers are done
             // rows that are contiguous runs of the image's unit-stride dim with sign +1: five quads of pair slots per row from a
             // 16-byte load and the value behind it; else slot by slot through the z table
             const bool zlin = p.vol_ss[2] == 4 && b0[2] >= (p.bound[2] == B_DST1 ? 1 : 0) && b0[2] + BOX <= p.vol_n[2];
@@ -522,7 +526,16 @@ __global__ __launch_bounds__(NT, 4) void gather5(KParams p, Grid5 bg, const int 
                 }
             }
             __syncthreads();
+            const int ntot = sm.pref[CAPD];
             int rr = 0;
+            if constexpr (!QUEUE) {
+            for (int j = tid; j < ntot; j += NT) {
+                {
+                    while (j >= sm.pref[rr + 1]) ++rr;               // (runs beyond the last hold nothing: their prefix is the total)
+#include "gather5_taps.inc"
+                }
+            }
+            } else {
             const int q_ = tid & 31, hw = tid >> 5;
             const int qbeg = sorted_ ? sm.qoff[q_] : 0, qn = sorted_ ? sm.qoff[q_ + 1] - qbeg : 0;
             const int nwalk = sorted_ ? (sm.qmax + NT / 32 - 1) / (NT / 32) : (ntot + NT - 1) / NT;     // (block-uniform)
@@ -535,141 +548,15 @@ __global__ __launch_bounds__(NT, 4) void gather5(KParams p, Grid5 bg, const int 
                     rr = 0;                                          // the run of record j: the last one whose prefix is <= j
 #pragma unroll
                     for (int st = CAPD / 2; st > 0; st >>= 1) rr += sm.pref[rr + st] <= j ? st : 0;
-                } else {
+                } else {                                             // (a brick beyond the queue's capacity: list order)
                     j = tid + it * NT;
                     if (j >= ntot) continue;
-                    while (j >= sm.pref[rr + 1]) ++rr;               // (runs beyond the last hold nothing: their prefix is the total)
+                    while (j >= sm.pref[rr + 1]) ++rr;
                 }
                 {
-                    const float4 rc = rec[sm.start[rr] + (unsigned)(j - sm.pref[rr])];
-                    const float fx = floorf(rc.x - 0.5f * (float)(K - 1)), fy = floorf(rc.y - 0.5f * (float)(K - 1)), fz = floorf(rc.z - 0.5f * (float)(K - 1));
-                    const float tx = rc.x - fx, ty = rc.y - fy, tz = rc.z - fz;
-                    // first-tap cell inside the brick: 0 .. 15 by construction of the bins; clamped, should a coordinate be off
-                    int cx = __float2int_rz(fx) - b0[0], cy = __float2int_rz(fy) - b0[1], cz = __float2int_rz(fz) - b0[2];
-                    cx = max(0, min(cx, BR - 1)); cy = max(0, min(cy, BR - 1)); cz = max(0, min(cz, BR - 1));
-                    const unsigned addr = boxaddr + (unsigned)((cx * BOX + cy) * PZ + cz) * 8u;
-#ifdef IP_G5_HIGH
-                    // eight z-slots in four pairs; order 6: the eighth carries weight 0 and its slot is cleared after the read (a lattice
-                    // point outside the stencil must not reach the sums: 0 * inf)
-                    float wy[8], wz[8];
-                    wy[7] = 0.f; wz[7] = 0.f;
-                    tiled::weights<K>(0, K, ty, wy);
-                    tiled::weights<K>(0, K, tz, wz);
-                    const f2 wzp[4] = { f2{ wz[0], wz[1] }, f2{ wz[2], wz[3] }, f2{ wz[4], wz[5] }, f2{ wz[6], wz[7] } };
-                    const float xyz[3] = { rc.x, rc.y, rc.z };
-                    const float m = inb_mask(p, xyz);                // nd.py:139-140
-                    const int64_t o = (int64_t)__float_as_int(rc.w);
-                    if (MODE == 0) {
-                        float acc = 0.f;
-#pragma unroll
-                        for (int ii = 0; ii <= K; ++ii) {
-                            f2 t[32];
-                            plane_reads8(addr + (unsigned)(ii * PLANE * 8), t);
-                            float pl = 0.f;
-#pragma unroll
-                            for (int j = 0; j <= K; ++j) {
-                                if (K == 6) t[4 * j + 3].y = 0.f;
-                                const f2 s = (wzp[0] * t[4 * j] + wzp[1] * t[4 * j + 1]) + (wzp[2] * t[4 * j + 2] + wzp[3] * t[4 * j + 3]);
-                                pl = __builtin_fmaf(wy[j], s.x + s.y, pl);
-                            }
-                            acc = __builtin_fmaf(tiled::weight1(0, K, tx, ii, tiled::tap_piece(K, ii)), pl, acc);
-                            asm volatile("" : "+v"(acc));            // (one x-plane at a time)
-                        }
-                        oc[o] = acc * m;
-                    } else {
-                        float gy[8], gzz[8];
-                        gy[7] = 0.f; gzz[7] = 0.f;
-                        tiled::wgrads<K>(0, K, ty, gy);
-                        tiled::wgrads<K>(0, K, tz, gzz);
-                        const f2 gzp[4] = { f2{ gzz[0], gzz[1] }, f2{ gzz[2], gzz[3] }, f2{ gzz[4], gzz[5] }, f2{ gzz[6], gzz[7] } };
-                        float a0 = 0.f, a1 = 0.f, a2 = 0.f;
-#pragma unroll
-                        for (int ii = 0; ii <= K; ++ii) {
-                            f2 t[32];
-                            plane_reads8(addr + (unsigned)(ii * PLANE * 8), t);
-                            float pl = 0.f, ply = 0.f, plz = 0.f;
-#pragma unroll
-                            for (int j = 0; j <= K; ++j) {
-                                if (K == 6) t[4 * j + 3].y = 0.f;
-                                const f2 s = (wzp[0] * t[4 * j] + wzp[1] * t[4 * j + 1]) + (wzp[2] * t[4 * j + 2] + wzp[3] * t[4 * j + 3]);
-                                const f2 sz = (gzp[0] * t[4 * j] + gzp[1] * t[4 * j + 1]) + (gzp[2] * t[4 * j + 2] + gzp[3] * t[4 * j + 3]);
-                                const float rv = s.x + s.y, rz = sz.x + sz.y;
-                                pl = __builtin_fmaf(wy[j], rv, pl);
-                                ply = __builtin_fmaf(gy[j], rv, ply);
-                                plz = __builtin_fmaf(wy[j], rz, plz);
-                            }
-                            const float wxi = tiled::weight1(0, K, tx, ii, tiled::tap_piece(K, ii)), gxi = tiled::wgrad1(0, K, tx, ii, tiled::tap_piece(K, ii));
-                            a0 = __builtin_fmaf(gxi, pl, a0);
-                            a1 = __builtin_fmaf(wxi, ply, a1);
-                            a2 = __builtin_fmaf(wxi, plz, a2);
-                            asm volatile("" : "+v"(a0), "+v"(a1), "+v"(a2));
-                        }
-#else
-                    float wy[6], wz[6];
-                    wy[5] = 0.f; wz[5] = 0.f;                        // (K == 4: the sixth weight is 0)
-                    tiled::weights<K>(0, K, ty, wy);
-                    tiled::weights<K>(0, K, tz, wz);
-                    const f2 wzp[3] = { f2{ wz[0], wz[1] }, f2{ wz[2], wz[3] }, f2{ wz[4], wz[5] } };
-                    const float xyz[3] = { rc.x, rc.y, rc.z };
-                    const float m = inb_mask(p, xyz);                // nd.py:139-140
-                    const int64_t o = (int64_t)__float_as_int(rc.w);
-                    if (MODE == 0) {
-                        float acc = 0.f;
-#pragma unroll
-                        for (int ii = 0; ii <= K; ++ii) {
-                            f2 t[18];
-                            plane_reads(addr + (unsigned)(ii * PLANE * 8), t);
-                            float pl = 0.f;
-#pragma unroll
-                            for (int j = 0; j <= K; ++j) {
-                                const f2 s = wzp[0] * t[3 * j] + (wzp[1] * t[3 * j + 1] + wzp[2] * t[3 * j + 2]);
-                                pl = __builtin_fmaf(wy[j], s.x + s.y, pl);
-                            }
-                            acc = __builtin_fmaf(tiled::weight1(0, K, tx, ii, tiled::tap_piece(K, ii)), pl, acc);
-                            asm volatile("" : "+v"(acc));            // (one x-plane at a time)
-                        }
-                        oc[o] = acc * m;
-                    } else {
-                        float gy[6], gzz[6];
-                        gy[5] = 0.f; gzz[5] = 0.f;
-                        tiled::wgrads<K>(0, K, ty, gy);
-                        tiled::wgrads<K>(0, K, tz, gzz);
-                        const f2 gzp[3] = { f2{ gzz[0], gzz[1] }, f2{ gzz[2], gzz[3] }, f2{ gzz[4], gzz[5] } };
-                        float a0 = 0.f, a1 = 0.f, a2 = 0.f;
-#pragma unroll
-                        for (int ii = 0; ii <= K; ++ii) {
-                            f2 t[18];
-                            plane_reads(addr + (unsigned)(ii * PLANE * 8), t);
-                            float pl = 0.f, ply = 0.f, plz = 0.f;
-#pragma unroll
-                            for (int j = 0; j <= K; ++j) {
-                                const f2 s = wzp[0] * t[3 * j] + (wzp[1] * t[3 * j + 1] + wzp[2] * t[3 * j + 2]);
-                                const f2 sz = gzp[0] * t[3 * j] + (gzp[1] * t[3 * j + 1] + gzp[2] * t[3 * j + 2]);
-                                const float rv = s.x + s.y, rz = sz.x + sz.y;
-                                pl = __builtin_fmaf(wy[j], rv, pl);
-                                ply = __builtin_fmaf(gy[j], rv, ply);
-                                plz = __builtin_fmaf(wy[j], rz, plz);
-                            }
-                            const float wxi = tiled::weight1(0, K, tx, ii, tiled::tap_piece(K, ii)), gxi = tiled::wgrad1(0, K, tx, ii, tiled::tap_piece(K, ii));
-                            a0 = __builtin_fmaf(gxi, pl, a0);
-                            a1 = __builtin_fmaf(wxi, ply, a1);
-                            a2 = __builtin_fmaf(wxi, plz, a2);
-                            asm volatile("" : "+v"(a0), "+v"(a1), "+v"(a2));
-                        }
-#endif
-                        if (MODE == 1) {
-                            // contracted with grad_out; written by the first channel, accumulated by the following ones (the same thread
-                            // meets the sample in every channel)
-                            const float gm = (gout ? gout[b * p.val_sb + (int64_t)c * p.val_sc + o] : 1.f) * m;
-                            float *dst = out + (b * p.N + o) * 3;
-                            if (c == 0) { dst[0] = a0 * gm; dst[1] = a1 * gm; dst[2] = a2 * gm; }
-                            else { dst[0] += a0 * gm; dst[1] += a1 * gm; dst[2] += a2 * gm; }
-                        } else {
-                            float *dst = oc + 3 * o;
-                            dst[0] = a0 * m; dst[1] = a1 * m; dst[2] = a2 * m;
-                        }
-                    }
+#include "gather5_taps.inc"
                 }
+            }
             }
         }
     }
@@ -1131,10 +1018,17 @@ int IP_G5_TRY(const interpol_problem *p, const KParams &k, const void *vol, cons
     {                                                                                                                   \
         hipLaunchKernelGGL((bin5<KK, GM, MD>), tgrid, dim3(NT1), 0, st, k, bg, (const float *)vol, (const float *)grid, (float *)val, \
                            w.ndesc, w.list, w.desc, w.rec, gx, gy, gz, nty, ntz, ntiles, gate, (const float *)gout);   \
-        const int attr = big_lds<gather5<KK, MD>>(sizeof(GatSmem));                                                     \
-        if (attr) return attr;                                                                                          \
-        hipLaunchKernelGGL((gather5<KK, MD>), ggrid, dim3(NT), sizeof(GatSmem), st, k, bg, (const int *)w.ndesc, (const uint2 *)w.desc, \
-                           (const float4 *)w.rec, (const int *)w.list, w.hdr + 40, (const float *)vol, (float *)val, gate, (const float *)gout); \
+        if (MD == 0 && k.C * (KK + 1) * (KK + 1) * (KK + 1) >= 400) {   /* the class-sorted walk pays from there on (see the kernel) */ \
+            const int attr = big_lds<gather5<KK, 0, true>>(sizeof(GatSmem));                                            \
+            if (attr) return attr;                                                                                      \
+            hipLaunchKernelGGL((gather5<KK, 0, true>), ggrid, dim3(NT), sizeof(GatSmem), st, k, bg, (const int *)w.ndesc, (const uint2 *)w.desc, \
+                               (const float4 *)w.rec, (const int *)w.list, w.hdr + 40, (const float *)vol, (float *)val, gate, (const float *)gout); \
+        } else {                                                                                                        \
+            const int attr = big_lds<gather5<KK, MD>>(offsetof(GatSmem, qcnt));                                         \
+            if (attr) return attr;                                                                                      \
+            hipLaunchKernelGGL((gather5<KK, MD>), ggrid, dim3(NT), offsetof(GatSmem, qcnt), st, k, bg, (const int *)w.ndesc, (const uint2 *)w.desc, \
+                               (const float4 *)w.rec, (const int *)w.list, w.hdr + 40, (const float *)vol, (float *)val, gate, (const float *)gout); \
+        }                                                                                                               \
     }
 #define IP_G5_GM(KK, MD) { if (k.sep == 0) IP_G5(KK, 0, MD) else if (k.sep == 1) IP_G5(KK, 1, MD) else if (k.sep == 2) IP_G5(KK, 2, MD) else IP_G5(KK, 3, MD) }
     if (k.order[0] == IP_G5_KHI) { if (mode == 2) IP_G5_GM(IP_G5_KHI, 2) else if (mode == 1) IP_G5_GM(IP_G5_KHI, 1) else IP_G5_GM(IP_G5_KHI, 0) }
