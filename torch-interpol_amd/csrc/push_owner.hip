@@ -2226,3 +2226,8 @@ extern "C" __attribute__((visibility("default"))) int interpol_debug_prof_owner(
 #else // IP_OWNER_MIX_TU
 } // namespace ip
 #endif
+#undef IP_KS
+#undef IP_KD
+#undef IP_WX
+#undef IP_MU
+#undef IP_RECORD_CELL
