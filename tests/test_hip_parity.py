@@ -949,6 +949,56 @@ def test_round5_routers_in_a_captured_graph():
         _same(out_grad, _hip.gather("grad", vol, grid, b, [1] * 3, 1, flags=nf), 2e-5, ("graph trilinear grad", it))
 
 
+def test_round6_routes_in_a_captured_graph():
+    """The organisations added in round 6 -- mixed orders 1..3 (sorted tiles / owner-computes bricks behind the probes), orders 6 - 7 through
+    bricks (gather7.hip), the 1-D scatter tiles (push1d.hip) -- captured ONCE; the replays see fields whose roughness changes: every verdict is
+    taken anew on the device, nothing is synchronised or set from the host."""
+    from interpol import _hip
+    gen = torch.Generator().manual_seed(79)
+    n = 48
+    shape = (n, n, n)
+    vol = torch.randn([2, 2, *shape], generator=gen).to(DEV)
+    src = torch.randn([2, 2, *shape], generator=gen).to(DEV)
+    base = interpol.identity_grid(shape)[None].expand(2, *shape, 3)
+    grid = (base + 0.05 * torch.randn(base.shape, generator=gen)).contiguous().to(DEV)
+    n1 = 6000
+    src1 = torch.randn([2, 3, n1], generator=gen).to(DEV)
+    base1 = torch.arange(n1, dtype=torch.float32)[None, :, None].expand(2, n1, 1)
+    grid1 = (base1 + 0.05 * torch.randn(base1.shape, generator=gen)).contiguous().to(DEV)
+    b, mix, hi = [3, 1, 6], [1, 2, 3], [7] * 3
+
+    def calls():
+        return (_hip.scatter("push", src, grid, list(shape), b, mix, 1, with_count=True), _hip.gather("pull", vol, grid, b, mix, 1),
+                _hip.gather("grad", vol, grid, b, mix, 1), _hip.pull_backward(src, vol, grid, b, mix, 1, True, True),
+                _hip.gather("pull", vol, grid, b, hi, 1), _hip.scatter("push", src, grid, list(shape), b, hi, 1),
+                _hip.scatter("push", src1, grid1, [n1], [3], [3], 1, with_count=True))
+
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):                                    # warm-up on the side stream (workspaces, module loads)
+        calls()
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        out = calls()
+    nf = _hip.FLAG_NO_FASTPATH
+    for it, sigma in enumerate((0.05, 6.0, 0.5, 6.0)):
+        vol.copy_(torch.randn(vol.shape, generator=gen)); src.copy_(torch.randn(src.shape, generator=gen)); src1.copy_(torch.randn(src1.shape, generator=gen))
+        grid.copy_(base + sigma * torch.randn(base.shape, generator=gen))
+        grid1.copy_(base1 + sigma * torch.randn(base1.shape, generator=gen))
+        g.replay()
+        torch.cuda.synchronize()
+        _same(out[0], _hip.scatter("push", src, grid, list(shape), b, mix, 1, flags=nf, with_count=True), 1e-5, ("graph mixed push", it))
+        _same(out[1], _hip.gather("pull", vol, grid, b, mix, 1, flags=nf), 1e-5, ("graph mixed pull", it))
+        _same(out[2], _hip.gather("grad", vol, grid, b, mix, 1, flags=nf), 2e-5, ("graph mixed grad", it))
+        ref = _hip.pull_backward(src, vol, grid, b, mix, 1, True, True, flags=nf)
+        _same(out[3][0], ref[0], 1e-5, ("graph mixed bwd vol", it)); _same(out[3][1], ref[1], 2e-5, ("graph mixed bwd grid", it))
+        _same(out[4], _hip.gather("pull", vol, grid, b, hi, 1, flags=nf), 1.5e-5, ("graph order 7 pull", it))
+        _same(out[5], _hip.scatter("push", src, grid, list(shape), b, hi, 1, flags=nf), 2e-5, ("graph order 7 push", it))
+        _same(out[6], _hip.scatter("push", src1, grid1, [n1], [3], [3], 1, flags=nf, with_count=True), 1e-5, ("graph 1-D push", it))
+
+
 def test_tiled_scatter_nonfinite_sources_keep_ieee_semantics():
     from interpol import _hip
     vol, grid, tshape, sshape = _tiled_problem(3, 1.0, seed=5)
