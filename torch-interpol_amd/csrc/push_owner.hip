@@ -758,7 +758,10 @@ __host__ __device__ __forceinline__ int color_count(int color, int d, const Bric
 // stencil add the same offset in every lane (tools/microbench/lds_gather.hip: 6.3 clk against 12.6 for random lanes;
 // measured here, unsorted: 21 clk).  So the records of a batch are counting-sorted by the CLASS (first slot mod 32) into
 // an index queue in LDS, and lane q of every half wave walks class q: half wave h takes entries h, h + 16, ... of its class.
-template <int K>
+// NEAR (K == 1 only): the nearest-neighbour scatter (all orders 0) -- the float box below.  A template parameter since round 6's last evidence
+// pass: inside the trilinear kernel that code cost it 144 B of scratch per lane (240 against 96) and 13 - 15 % of its time (4 x 2 x 256^3, sigma = 2:
+// 2.43 -> 2.76 ms, profiles/r06_other_configs.json against r05's).
+template <int K, bool NEAR = false>
 __global__ __launch_bounds__(NT, 4) void own_accumulate(KParams p, BrickGrid bg, const int *__restrict__ ndesc, const uint2 *__restrict__ desc,
                                                         const float4 *__restrict__ rec, const float *__restrict__ vals,
                                                         const unsigned short *__restrict__ meta, const int *__restrict__ bmax, int64_t nrec,
@@ -917,7 +920,7 @@ __global__ __launch_bounds__(NT, 4) void own_accumulate(KParams p, BrickGrid bg,
             __syncthreads();
         };
         prof_mark(8);
-        if (IP_KS == 1 && p.mode == MODE_ISO0) {
+        if (NEAR) {
             // Nearest neighbour (all orders 0; own_bin stored the ROUNDED coordinates): a sample touches ONE lattice point with weight 1
             // (iso0.py:65-118: inp * sign * mask, scatter_add_ in no particular order).  Round 6: no fixed point here -- the box holds the
             // channel pair as two FLOATS and every record adds its sources with one ds_add_f32 each (slow LDS atomics, ~190 clk per wave
@@ -2029,7 +2032,15 @@ int try_owner_push(const interpol_problem *p, const KParams &k_in, const void *v
                                (int *)w.hdr + 16 + color);                                                              \
         }
         if (mixed_orders(k)) { const int rm = mix_launch_acc(k, bg, w, vol, nch, color, Bw, gate, agrid.x, st); if (rm) return rm; }
-        else if (k.order[0] == 3) IP_OWN_ACC(3) else if (k.order[0] == 2) IP_OWN_ACC(2) else IP_OWN_ACC(1)
+        else if (k.order[0] == 3) IP_OWN_ACC(3) else if (k.order[0] == 2) IP_OWN_ACC(2)
+        else if (nearest) {
+            const int attr = big_lds<own_accumulate<1, true>>(sizeof(AccSmem));
+            if (attr) return attr;
+            hipLaunchKernelGGL((own_accumulate<1, true>), agrid, dim3(NT), sizeof(AccSmem), st, k, bg, (const int *)w.ndesc,
+                               (const uint2 *)w.desc, (const float4 *)w.rec, (const float *)w.vals, (const unsigned short *)w.meta,
+                               (const int *)w.bmax, w.nrec, (float *)vol, nch, color, Bw, gate, (int *)w.hdr + 16 + color);
+        }
+        else IP_OWN_ACC(1)
 #undef IP_OWN_ACC
     }
     e = hipGetLastError();
