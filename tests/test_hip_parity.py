@@ -1192,6 +1192,14 @@ def test_push1d_tiles_against_the_oracle(order):
                 fin = torch.isfinite(slow)
                 assert bool((torch.isfinite(fast) == fin).all()) and 0 < int((~fin).sum()) < 64, ("non-finite sources",) + what
                 _same(torch.where(fin, fast, 0), torch.where(fin, slow, 0), 1e-5, ("next to non-finite sources",) + what)
+                # a NaN coordinate: what the generic kernel does with it, nothing else
+                gbad = gd.clone()
+                gbad[1, 2500, 0] = float("nan")
+                fast = _hip.scatter("push", sd, gbad, [n_out], b, o, ex)
+                slow = _hip.scatter("push", sd, gbad, [n_out], b, o, ex, flags=_hip.FLAG_NO_FASTPATH)
+                fin = torch.isfinite(slow)
+                assert bool((torch.isfinite(fast) == fin).all()), ("NaN coordinate",) + what
+                _same(torch.where(fin, fast, 0), torch.where(fin, slow, 0), 1e-5, ("next to a NaN coordinate",) + what)
     finally:
         oracle.set_threads(1)
 

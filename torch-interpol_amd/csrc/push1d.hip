@@ -111,7 +111,7 @@ __global__ __launch_bounds__(NT) void push1d(KParams p, const T *__restrict__ va
     int cell[VPT];
 #pragma unroll
     for (int v = 0; v < VPT; ++v) {
-        if (((valid >> v) & 1) && i0[v] >= lo && i0[v] <= lo + S - K - 1) in |= 1u << v;
+        if (((valid >> v) & 1) && i0[v] >= lo && i0[v] <= lo + S - K - 1 && t[v] == t[v]) in |= 1u << v;     // (a NaN coordinate: per thread, like the generic kernel)
         cell[v] = ((in >> v) & 1) ? i0[v] - lo : 0;
     }
     // density: samples per first-tap cell (16-bit counters in the box, cleared again)
