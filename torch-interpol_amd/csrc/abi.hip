@@ -68,6 +68,8 @@ int64_t gather5_workspace_bytes(const interpol_problem *, const KParams &);
 int try_gather5(const interpol_problem *, const KParams &, const void *, const void *, void *, void *, int64_t, int, const void *, hipStream_t, const int **);
 int64_t scatter5_workspace_bytes(const interpol_problem *, const KParams &);
 int try_scatter5(const interpol_problem *, const KParams &, const void *, const void *, void *, void *, int64_t, hipStream_t, const int **);
+int try_backward5(const interpol_problem *, const KParams &, const KParams &, const void *, const void *, const void *, void *, void *, void *, int64_t,
+                  hipStream_t, const int **);
 int64_t scatter2d_workspace_bytes(const interpol_problem *, const KParams &);
 int64_t gather2d_workspace_bytes(const interpol_problem *, const KParams &);
 int try_gather2d(const interpol_problem *, const KParams &, const void *, const void *, void *, void *, int64_t, int, const void *, hipStream_t, const int **);
@@ -856,7 +858,7 @@ int interpol_pull_backward(const interpol_problem *p, const void *grad_out, cons
     const int64_t gsb = img * p->channels, gsc = img;
     rc = 0;
     if (!(p->flags & INTERPOL_FLAG_NO_FASTPATH)) {
-        bool vol_done = false;
+        bool vol_done = false, grid_done = false;
         // (one channel + grid gradient at orders <= 3: the fused kernel is faster; at orders >= 4 the
         //  grid part has its own shifted-pair kernel and the split wins again: config 3 10.9 -> 8.x ms)
         bool high = p->dim == 3 && p->order[0] >= 4;
@@ -873,7 +875,15 @@ int interpol_pull_backward(const interpol_problem *p, const void *grad_out, cons
             int64_t dense = 1;
             for (int d = p->dim - 1; d >= 0; --d) { kp.vol_ss[d] = (int)(dense * (int64_t)acc_esize(p->dtype)); dense *= p->vol_shape[d]; }
             rc = 0;
-            if (high && scratch && p->dtype == INTERPOL_F32 && (p->flags & (INTERPOL_FLAG_BINNED_SCATTER | INTERPOL_FLAG_AUTO_SCATTER))) {
+            if (high && grad_grid && scratch && p->dtype == INTERPOL_F32 && (p->flags & (INTERPOL_FLAG_BINNED_SCATTER | INTERPOL_FLAG_AUTO_SCATTER))) {
+                // orders 4 - 7, both gradients (round 6): ONE binning of the samples for the image gradient (scatter5) and the grid gradient
+                // (gather5<K, 1>) -- gather5.hip: try_backward5; 0: declined, the two halves go their own ways below
+                rc = try_backward5(p, k, kp, grad_out, vol, grid, acc, grad_grid, scratch, scratch_bytes, st, &kp.gate);
+                if (rc < 0 || rc > 2) return rc;
+                grid_done = rc != 0;
+                if (rc == 2) rc = 0;                                 // (the image gradient behind the probe: the tiles below read the same verdict)
+            }
+            if (rc == 0 && !grid_done && high && scratch && p->dtype == INTERPOL_F32 && (p->flags & (INTERPOL_FLAG_BINNED_SCATTER | INTERPOL_FLAG_AUTO_SCATTER))) {
                 // orders 4 - 5 with the bricks' workspace: the image gradient through bricks of the target (gather5.hip: scatter5; the
                 // grid gradient below reuses the workspace behind it on the stream)
                 rc = try_scatter5(p, kp, grad_out, grid, acc, scratch, scratch_bytes, st, &kp.gate);
@@ -891,9 +901,9 @@ int interpol_pull_backward(const interpol_problem *p, const void *grad_out, cons
                 rc = 1;
             }
             vol_done = rc == 1;
-            rc = (vol_done && !grad_grid) ? 1 : 0;
+            rc = (vol_done && (!grad_grid || grid_done)) ? 1 : 0;
         }
-        if (rc == 0 && grad_grid && (vol_done || !grad_vol) && scratch && (p->dtype == INTERPOL_F32 || (p->dim == 2 && !grad_vol && p->dtype != INTERPOL_F64))) {
+        if (rc == 0 && grad_grid && !grid_done && (vol_done || !grad_vol) && scratch && (p->dtype == INTERPOL_F32 || (p->dim == 2 && !grad_vol && p->dtype != INTERPOL_F64))) {
             // (a 16-bit image gradient uses `scratch` as its accumulator: the workspace only when there is none)
             rc = routed_gradc(p, k, grad_out, vol, grid, grad_grid, scratch, scratch_bytes, st);
             if (rc != 0 && rc != 1) return rc;

@@ -32,6 +32,7 @@
 #define IP_G5_WSB gather7_workspace_bytes
 #define IP_S5_TRY try_scatter7
 #define IP_S5_WSB scatter7_workspace_bytes
+#define IP_B5_TRY try_backward7
 #else
 #define IP_G5_CP BR
 #define IP_G5_NS g5
@@ -41,6 +42,7 @@
 #define IP_G5_WSB gather5_workspace_bytes
 #define IP_S5_TRY try_scatter5
 #define IP_S5_WSB scatter5_workspace_bytes
+#define IP_B5_TRY try_backward5
 #endif
 
 namespace ip {
@@ -159,9 +161,12 @@ template <int K, int GM, int MODE>
 __global__ __launch_bounds__(NT1, 4) void bin5(KParams p, Grid5 bg, const float *__restrict__ img, const float *__restrict__ grid, float *__restrict__ out,
                                                int *__restrict__ ndesc, int *__restrict__ list, uint2 *__restrict__ desc, float4 *__restrict__ rec,
                                                int gx, int gy, int gz, int nty, int ntz, int ntiles, const int *__restrict__ gate,
-                                               const float *__restrict__ gout)
+                                               const float *__restrict__ gout, float *__restrict__ acc2)
 {
-    if (gate && *gate != 1) return;                                  // INTERPOL_FLAG_AUTO_SCATTER: the probe chose the tiles
+    // MODE 4 (round 6): ONE binning for both halves of the pull's backward -- the records serve scatter5 (image gradient) and gather5<K, 1>
+    // (grid gradient); img / out / gout as in MODE 1, acc2 = the dense float image gradient, `gate` = the SCATTER's verdict: the binning
+    // itself always runs (the grid gradient needs it), the direct scatter of the unbinned samples only when the bricks have the scatter
+    if (MODE != 4 && gate && *gate != 1) return;                     // INTERPOL_FLAG_AUTO_SCATTER: the probe chose the tiles
     __shared__ BinSmem sm;
     const int tid = threadIdx.x;
     const int64_t b = blockIdx.x / ntiles;
@@ -261,6 +266,20 @@ __global__ __launch_bounds__(NT1, 4) void bin5(KParams p, Grid5 bg, const float 
         const int e = lbin[v] & 255;
         if (sm.cnt[e] < 0) { direct |= 1u << v; continue; }
         rec[tilebase + sm.base[e] + (lbin[v] >> 8)] = make_float4(c[v][0], c[v][1], c[v][2], __int_as_float(idx[v]));
+    }
+    if (MODE == 4) {
+        if (direct) {
+            direct5<K, GM, 1>(p, img, grid, out, b, g, tid, direct, gout);
+            if (!gate || *gate == 1) {
+                KParams q = p;                                       // the scatter's view: sources = grad_out (val_*), target = the dense image gradient
+                int64_t dense = 1;
+#pragma unroll
+                for (int d = 2; d >= 0; --d) { q.vol_ss[d] = (int)(dense * 4); dense *= p.vol_n[d]; }
+                q.vol_sc = dense; q.vol_sb = dense * p.C; q.cc = 0;
+                direct5<K, GM, 3>(q, gout, grid, acc2, b, g, tid, direct, nullptr);
+            }
+        }
+        return;
     }
     if (direct) direct5<K, GM, MODE>(p, img, grid, out, b, g, tid, direct, gout);
 }
@@ -1017,7 +1036,7 @@ int IP_G5_TRY(const interpol_problem *p, const KParams &k, const void *vol, cons
 #define IP_G5(KK, GM, MD)                                                                                               \
     {                                                                                                                   \
         hipLaunchKernelGGL((bin5<KK, GM, MD>), tgrid, dim3(NT1), 0, st, k, bg, (const float *)vol, (const float *)grid, (float *)val, \
-                           w.ndesc, w.list, w.desc, w.rec, gx, gy, gz, nty, ntz, ntiles, gate, (const float *)gout);   \
+                           w.ndesc, w.list, w.desc, w.rec, gx, gy, gz, nty, ntz, ntiles, gate, (const float *)gout, (float *)nullptr);   \
         if (MD == 0 && k.C * (KK + 1) * (KK + 1) * (KK + 1) >= 400) {   /* the class-sorted walk pays from there on (see the kernel) */ \
             const int attr = big_lds<gather5<KK, 0, true>>(sizeof(GatSmem));                                            \
             if (attr) return attr;                                                                                      \
@@ -1105,7 +1124,7 @@ int IP_S5_TRY(const interpol_problem *p, const KParams &k, const void *val, cons
 #define IP_S5(KK, GM)                                                                                                   \
     {                                                                                                                   \
         hipLaunchKernelGGL((bin5<KK, GM, 3>), tgrid, dim3(NT1), 0, st, k, bg, (const float *)val, (const float *)grid, (float *)vol, \
-                           w.ndesc, w.list, w.desc, w.rec, gx, gy, gz, nty, ntz, ntiles, gate, (const float *)nullptr); \
+                           w.ndesc, w.list, w.desc, w.rec, gx, gy, gz, nty, ntz, ntiles, gate, (const float *)nullptr, (float *)nullptr); \
         const int attr = big_lds<scatter5<KK>>(sizeof(ScatSmem));                                                       \
         if (attr) return attr;                                                                                          \
         hipLaunchKernelGGL((scatter5<KK>), ggrid, dim3(NT), sizeof(ScatSmem), st, k, bg, (const int *)w.ndesc, (const uint2 *)w.desc, \
@@ -1115,6 +1134,73 @@ int IP_S5_TRY(const interpol_problem *p, const KParams &k, const void *val, cons
     if (k.order[0] == IP_G5_KHI) IP_S5_GM(IP_G5_KHI) else IP_S5_GM(IP_G5_KLO)
 #undef IP_S5_GM
 #undef IP_S5
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return (int)e;
+    if (gate_out) *gate_out = gate;
+    return gated ? 2 : 1;
+}
+
+// Both gradients of the pull's backward (pushpull.py:237-258) with ONE binning of the samples (round 6; 8 x 1 x 192^3 order 5: 5.09 -> 4.7 ms): the records
+// of bin5<K, GM, 4> serve scatter5 (image gradient: push of grad_out into `acc`, the dense float (B, C, *vol) gradient) and gather5<K, 1> (grid gradient).
+// k: the gather's parameters (vol_* the image, val_* grad_out), kp: the scatter's (vol_* = acc).  1 = both done; 2 = the grid gradient done, the image
+// gradient launched behind the probe's verdict (the caller launches the tiles / generic push as well, with KParams::gate = *gate_out); 0 = declined.
+int try_backward7(const interpol_problem *p, const KParams &k, const KParams &kp, const void *gout, const void *vol, const void *grid, void *acc, void *ggrid,
+                  void *workspace, int64_t workspace_bytes, hipStream_t st, const int **gate_out);
+int IP_B5_TRY(const interpol_problem *p, const KParams &k, const KParams &kp, const void *gout, const void *vol, const void *grid, void *acc, void *ggrid,
+              void *workspace, int64_t workspace_bytes, hipStream_t st, const int **gate_out)
+{
+#ifndef IP_G5_HIGH
+    if (k.order[0] >= 6) return try_backward7(p, k, kp, gout, vol, grid, acc, ggrid, workspace, workspace_bytes, st, gate_out);
+#endif
+    using namespace IP_G5_NS;
+    if (!workspace || ((uintptr_t)workspace & 255u) != 0 || !eligible(p, k) || kp.cc) return 0;
+    const int64_t need = IP_S5_WSB(p, kp);                            // (the scatter's own conditions: density, no shared target)
+    if (need <= 0 || need > workspace_bytes) return 0;
+    const int gx = (int)p->grid_shape[0], gy = (int)p->grid_shape[1], gz = (int)p->grid_shape[2];
+    const int nty = (gy + TS - 1) / TS, ntz = (gz + TS - 1) / TS, ntiles = ((gx + TS - 1) / TS) * nty * ntz;
+    const Grid5 bg = brick_grid(k);
+    Workspace w;
+    if (layout(bg, (int)p->batch, ntiles, workspace, &w) > workspace_bytes) return 0;
+    const int64_t nz = 64 + 2 * w.nbricks + 1;
+    if (nz > 0x7fffffffll) return 0;
+    hipLaunchKernelGGL(zero5, dim3((unsigned)((nz + 1023) / 1024)), dim3(1024), 0, st, w.hdr, (int)nz);
+#ifdef IP_G5_HIGH
+    const bool gated = false;
+#else
+    const bool gated = !(p->flags & INTERPOL_FLAG_BINNED_SCATTER);   // the scatter alone: smooth fields keep the LDS tiles (try_scatter5)
+#endif
+    const int *gate = gated ? w.hdr : nullptr;
+#ifndef IP_G5_HIGH
+    if (gated) {
+        const long long total = (long long)ntiles * p->batch;
+        const dim3 pgrid((unsigned)(total < NPROBE ? total : NPROBE));
+#define IP_P5(KK, GM) hipLaunchKernelGGL((probe5<KK, GM>), pgrid, dim3(NT1), 0, st, k, (const float *)grid, w.hdr, gx, gy, gz, nty, ntz, ntiles, (int)p->batch);
+#define IP_P5_GM(KK) { if (k.sep == 0) IP_P5(KK, 0) else if (k.sep == 1) IP_P5(KK, 1) else if (k.sep == 2) IP_P5(KK, 2) else IP_P5(KK, 3) }
+        if (k.order[0] == 5) IP_P5_GM(5) else IP_P5_GM(4)
+#undef IP_P5_GM
+#undef IP_P5
+    }
+#endif
+    const dim3 tgrid((unsigned)(ntiles * (int)p->batch));
+    const long long want = 2ll * cu_count();
+    const dim3 ggrid_((unsigned)(w.nbricks < want ? w.nbricks : want));
+#define IP_B5(KK, GM)                                                                                                   \
+    {                                                                                                                   \
+        hipLaunchKernelGGL((bin5<KK, GM, 4>), tgrid, dim3(NT1), 0, st, k, bg, (const float *)vol, (const float *)grid, (float *)ggrid, \
+                           w.ndesc, w.list, w.desc, w.rec, gx, gy, gz, nty, ntz, ntiles, gate, (const float *)gout, (float *)acc); \
+        int attr = big_lds<scatter5<KK>>(sizeof(ScatSmem));                                                             \
+        if (attr) return attr;                                                                                          \
+        hipLaunchKernelGGL((scatter5<KK>), ggrid_, dim3(NT), sizeof(ScatSmem), st, kp, bg, (const int *)w.ndesc, (const uint2 *)w.desc, \
+                           (const float4 *)w.rec, (const int *)w.list, w.hdr + 40, (const float *)gout, (float *)acc, gate); \
+        attr = big_lds<gather5<KK, 1>>(offsetof(GatSmem, qcnt));                                                        \
+        if (attr) return attr;                                                                                          \
+        hipLaunchKernelGGL((gather5<KK, 1>), ggrid_, dim3(NT), offsetof(GatSmem, qcnt), st, k, bg, (const int *)w.ndesc, (const uint2 *)w.desc, \
+                           (const float4 *)w.rec, (const int *)w.list, w.hdr + 41, (const float *)vol, (float *)ggrid, (const int *)nullptr, (const float *)gout); \
+    }
+#define IP_B5_GM(KK) { if (k.sep == 0) IP_B5(KK, 0) else if (k.sep == 1) IP_B5(KK, 1) else if (k.sep == 2) IP_B5(KK, 2) else IP_B5(KK, 3) }
+    if (k.order[0] == IP_G5_KHI) IP_B5_GM(IP_G5_KHI) else IP_B5_GM(IP_G5_KLO)
+#undef IP_B5_GM
+#undef IP_B5
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) return (int)e;
     if (gate_out) *gate_out = gate;
