@@ -429,8 +429,9 @@ def test_tiled_scatter_matches_generic(dim, order, sigma):
     src = torch.randn([2, 3, *sshape], generator=torch.Generator().manual_seed(11)).to(DEV)
     # (orders 6 - 7 in 3-D, round 6: bricks of 14^3 cells -- under `replicate` and sigma = 9 a corner voxel of value ~ 50 collects several
     #  hundred float32 atomic adds in either organisation, each rounded at 4e-6 of the running sum: the two sums differ by 1.3e-5 of the
-    #  maximum; north_star's bar is rtol 1e-5 + atol 1e-5 max = 2e-5 at the maximum, and the oracle tests of these orders hold it)
-    tol = 2e-5 if (order >= 6 and dim == 3) else 1e-5
+    #  maximum (the order of the atomics varies from run to run); north_star's bar is rtol 1e-5 + atol 1e-5 max = 2e-5 at the maximum for EACH of
+    #  the two against the reference -- the oracle tests of these orders hold it -- hence up to 4e-5 between them: 3e-5 here)
+    tol = 3e-5 if (order >= 6 and dim == 3) else 1e-5
     for bound in range(7):
         for ex in ((1, 0, 2) if bound in (0, 3, 5) else (1,)):
             b, o = [bound] * dim, [order] * dim
