@@ -2541,6 +2541,12 @@ def test_orders_4_and_5_through_bricks_of_the_image_against_oracle(sigma, hi):
                     _same(got[1], slow[1], 1e-5, ("grid gradient of the pull, bricks", sigma, b, order, ex, need_vol))
                     if need_vol:
                         _same(got[0], slow[0], 1e-5, ("image gradient next to it", sigma, b, order, ex))
+                # the backward of the push, both gradients: one binning for the pull of grad_vol_out and its grid gradient (round 6: try_pushbwd5)
+                gvo = torch.randn([2, C, *ishape], generator=g)
+                slow = _hip.push_backward(gvo.to(DEV), gout.to(DEV), grid.to(DEV), b, [order] * 3, ex, True, True, flags=_hip.FLAG_NO_FASTPATH)
+                got = _hip.push_backward(gvo.to(DEV), gout.to(DEV), grid.to(DEV), b, [order] * 3, ex, True, True)
+                _same(got[0], slow[0], 1.5e-5, ("push backward: values", sigma, b, order, ex))
+                _same(got[1], slow[1], 2e-5, ("push backward: grid", sigma, b, order, ex))
         inp = torch.randn([2, 3, 25, 47, 58], generator=g).to(DEV)
         grid = ((interpol.identity_grid((43, 25, 19)) - 10.0) * 9.0)[None].expand(2, 43, 25, 19, 3).contiguous().to(DEV)
         for order, b in ((hi, [6, 5, 6]), (hi - 1, [3, 1, 2])):

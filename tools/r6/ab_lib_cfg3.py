@@ -29,7 +29,8 @@ if len(sys.argv) > 1 and sys.argv[1] == "--child":
     b, o = [6] * 3, [5] * 3
     print(json.dumps({"pull": timeit(lambda: _hip.gather("pull", x, grid, b, o, 1)), "grad": timeit(lambda: _hip.gather("grad", x, grid, b, o, 1)),
                       "bwd_both": timeit(lambda: _hip.pull_backward(src, x, grid, b, o, 1, True, True)),
-                      "push": timeit(lambda: _hip.scatter("push", src, grid, [192] * 3, b, o, 1))}))
+                      "push": timeit(lambda: _hip.scatter("push", src, grid, [192] * 3, b, o, 1)),
+                      "push_bwd_both": timeit(lambda: _hip.push_backward(x, src, grid, b, o, 1, True, True))}))
     sys.exit(0)
 libs, rep = sys.argv[1:3], int(sys.argv[3]) if len(sys.argv) > 3 else 3
 res = {l: [] for l in libs}

@@ -70,6 +70,7 @@ int64_t scatter5_workspace_bytes(const interpol_problem *, const KParams &);
 int try_scatter5(const interpol_problem *, const KParams &, const void *, const void *, void *, void *, int64_t, hipStream_t, const int **);
 int try_backward5(const interpol_problem *, const KParams &, const KParams &, const void *, const void *, const void *, void *, void *, void *, int64_t,
                   hipStream_t, const int **);
+int try_pushbwd5(const interpol_problem *, const KParams &, const void *, const void *, const void *, void *, void *, void *, int64_t, hipStream_t);
 int64_t scatter2d_workspace_bytes(const interpol_problem *, const KParams &);
 int64_t gather2d_workspace_bytes(const interpol_problem *, const KParams &);
 int try_gather2d(const interpol_problem *, const KParams &, const void *, const void *, void *, void *, int64_t, int, const void *, hipStream_t, const int **);
@@ -976,6 +977,13 @@ int interpol_push_backward_ws(const interpol_problem *p, const void *grad_vol_ou
     if (grad_grid && (p->flags & (INTERPOL_FLAG_SEPARABLE_GRID | INTERPOL_FLAG_AFFINE_GRID))) return INTERPOL_E_STRIDE;
     hipStream_t st = (hipStream_t)stream;
     if (!(p->flags & INTERPOL_FLAG_NO_FASTPATH) && (p->dtype == INTERPOL_F32 || (p->dim == 2 && p->dtype != INTERPOL_F64)) && workspace) {
+        if (grad_grid && grad_val && val && p->dim == 3 && p->dtype == INTERPOL_F32 && k.order[0] >= 4
+            && (p->flags & (INTERPOL_FLAG_BINNED_SCATTER | INTERPOL_FLAG_AUTO_SCATTER))) {
+            // orders 4 - 7, both gradients (round 6): one binning of the samples for the pull of grad_vol_out and for its grid gradient (gather5.hip)
+            rc = try_pushbwd5(p, k, grad_vol_out, val, grid, grad_val, grad_grid, workspace, workspace_bytes, st);
+            if (rc != 0 && rc != 1) return rc;
+            if (rc == 1) return 0;
+        }
         if (grad_grid) {
             rc = routed_gradc(p, k, val, grad_vol_out, grid, grad_grid, workspace, workspace_bytes, st);
             if (rc != 0 && rc != 1) return rc;

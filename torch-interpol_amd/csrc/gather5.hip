@@ -33,6 +33,7 @@
 #define IP_S5_TRY try_scatter7
 #define IP_S5_WSB scatter7_workspace_bytes
 #define IP_B5_TRY try_backward7
+#define IP_PB5_TRY try_pushbwd7
 #else
 #define IP_G5_CP BR
 #define IP_G5_NS g5
@@ -43,6 +44,7 @@
 #define IP_S5_TRY try_scatter5
 #define IP_S5_WSB scatter5_workspace_bytes
 #define IP_B5_TRY try_backward5
+#define IP_PB5_TRY try_pushbwd5
 #endif
 
 namespace ip {
@@ -166,7 +168,7 @@ __global__ __launch_bounds__(NT1, 4) void bin5(KParams p, Grid5 bg, const float 
     // MODE 4 (round 6): ONE binning for both halves of the pull's backward -- the records serve scatter5 (image gradient) and gather5<K, 1>
     // (grid gradient); img / out / gout as in MODE 1, acc2 = the dense float image gradient, `gate` = the SCATTER's verdict: the binning
     // itself always runs (the grid gradient needs it), the direct scatter of the unbinned samples only when the bricks have the scatter
-    if (MODE != 4 && gate && *gate != 1) return;                     // INTERPOL_FLAG_AUTO_SCATTER: the probe chose the tiles
+    if (MODE < 4 && gate && *gate != 1) return;                      // INTERPOL_FLAG_AUTO_SCATTER: the probe chose the tiles
     __shared__ BinSmem sm;
     const int tid = threadIdx.x;
     const int64_t b = blockIdx.x / ntiles;
@@ -266,6 +268,15 @@ __global__ __launch_bounds__(NT1, 4) void bin5(KParams p, Grid5 bg, const float 
         const int e = lbin[v] & 255;
         if (sm.cnt[e] < 0) { direct |= 1u << v; continue; }
         rec[tilebase + sm.base[e] + (lbin[v] >> 8)] = make_float4(c[v][0], c[v][1], c[v][2], __int_as_float(idx[v]));
+    }
+    if (MODE == 5) {
+        // ONE binning for both gradients of the PUSH's backward (pushpull.py:262-282): the records serve gather5<K, 0> (out: the gradient of the
+        // values, a pull of grad_vol_out = img) and gather5<K, 1> (acc2: the grid gradient, contracted with the values = gout)
+        if (direct) {
+            direct5<K, GM, 0>(p, img, grid, out, b, g, tid, direct, nullptr);
+            direct5<K, GM, 1>(p, img, grid, acc2, b, g, tid, direct, gout);
+        }
+        return;
     }
     if (MODE == 4) {
         if (direct) {
@@ -1205,6 +1216,57 @@ int IP_B5_TRY(const interpol_problem *p, const KParams &k, const KParams &kp, co
     if (e != hipSuccess) return (int)e;
     if (gate_out) *gate_out = gate;
     return gated ? 2 : 1;
+}
+
+// Both gradients of the push's backward (pushpull.py:262-282) with ONE binning (round 6): gval = pull of grad_vol_out, ggrid = the grid gradient of that
+// pull contracted with the values.  k: vol_* grad_vol_out, val_* the values / their gradient (same strides).  1 = both done, 0 = declined.
+int try_pushbwd7(const interpol_problem *p, const KParams &k, const void *gvol_out, const void *val, const void *grid, void *gval, void *ggrid,
+                 void *workspace, int64_t workspace_bytes, hipStream_t st);
+int IP_PB5_TRY(const interpol_problem *p, const KParams &k, const void *gvol_out, const void *val, const void *grid, void *gval, void *ggrid,
+               void *workspace, int64_t workspace_bytes, hipStream_t st)
+{
+#ifndef IP_G5_HIGH
+    if (k.order[0] >= 6) return try_pushbwd7(p, k, gvol_out, val, grid, gval, ggrid, workspace, workspace_bytes, st);
+#endif
+    using namespace IP_G5_NS;
+    if (!workspace || ((uintptr_t)workspace & 255u) != 0 || !eligible(p, k) || !val || !gval || !ggrid) return 0;
+    const int gx = (int)p->grid_shape[0], gy = (int)p->grid_shape[1], gz = (int)p->grid_shape[2];
+    const int nty = (gy + TS - 1) / TS, ntz = (gz + TS - 1) / TS, ntiles = ((gx + TS - 1) / TS) * nty * ntz;
+    const Grid5 bg = brick_grid(k);
+    Workspace w;
+    if (layout(bg, (int)p->batch, ntiles, workspace, &w) > workspace_bytes) return 0;
+    const int64_t nz = 64 + 2 * w.nbricks + 1;
+    if (nz > 0x7fffffffll) return 0;
+    hipLaunchKernelGGL(zero5, dim3((unsigned)((nz + 1023) / 1024)), dim3(1024), 0, st, w.hdr, (int)nz);
+    const dim3 tgrid((unsigned)(ntiles * (int)p->batch));
+    const long long want = 2ll * cu_count();
+    const dim3 ggrid_((unsigned)(w.nbricks < want ? w.nbricks : want));
+#define IP_PB5(KK, GM)                                                                                                  \
+    {                                                                                                                   \
+        hipLaunchKernelGGL((bin5<KK, GM, 5>), tgrid, dim3(NT1), 0, st, k, bg, (const float *)gvol_out, (const float *)grid, (float *)gval, \
+                           w.ndesc, w.list, w.desc, w.rec, gx, gy, gz, nty, ntz, ntiles, (const int *)nullptr, (const float *)val, (float *)ggrid); \
+        if (k.C * (KK + 1) * (KK + 1) * (KK + 1) >= 400) {                                                              \
+            const int attr = big_lds<gather5<KK, 0, true>>(sizeof(GatSmem));                                            \
+            if (attr) return attr;                                                                                      \
+            hipLaunchKernelGGL((gather5<KK, 0, true>), ggrid_, dim3(NT), sizeof(GatSmem), st, k, bg, (const int *)w.ndesc, (const uint2 *)w.desc, \
+                               (const float4 *)w.rec, (const int *)w.list, w.hdr + 40, (const float *)gvol_out, (float *)gval, (const int *)nullptr, (const float *)nullptr); \
+        } else {                                                                                                        \
+            const int attr = big_lds<gather5<KK, 0>>(offsetof(GatSmem, qcnt));                                          \
+            if (attr) return attr;                                                                                      \
+            hipLaunchKernelGGL((gather5<KK, 0>), ggrid_, dim3(NT), offsetof(GatSmem, qcnt), st, k, bg, (const int *)w.ndesc, (const uint2 *)w.desc, \
+                               (const float4 *)w.rec, (const int *)w.list, w.hdr + 40, (const float *)gvol_out, (float *)gval, (const int *)nullptr, (const float *)nullptr); \
+        }                                                                                                               \
+        const int attr1 = big_lds<gather5<KK, 1>>(offsetof(GatSmem, qcnt));                                             \
+        if (attr1) return attr1;                                                                                        \
+        hipLaunchKernelGGL((gather5<KK, 1>), ggrid_, dim3(NT), offsetof(GatSmem, qcnt), st, k, bg, (const int *)w.ndesc, (const uint2 *)w.desc, \
+                           (const float4 *)w.rec, (const int *)w.list, w.hdr + 41, (const float *)gvol_out, (float *)ggrid, (const int *)nullptr, (const float *)val); \
+    }
+#define IP_PB5_GM(KK) { if (k.sep == 0) IP_PB5(KK, 0) else if (k.sep == 2) IP_PB5(KK, 2) else return 0; }
+    if (k.order[0] == IP_G5_KHI) IP_PB5_GM(IP_G5_KHI) else IP_PB5_GM(IP_G5_KLO)
+#undef IP_PB5_GM
+#undef IP_PB5
+    const hipError_t e = hipGetLastError();
+    return e != hipSuccess ? (int)e : 1;
 }
 
 } // namespace ip
